@@ -1,0 +1,157 @@
+/*
+ * lvk_c.h — C ABI of liblvk_hip.so: the MI355X (gfx950) implementation of LARVIO's per-frame
+ * hot path (visual front-end + EKF measurement update), the drop-in boundary under the
+ * reference's two C++ classes.
+ *
+ * The reference has no FFI layer; its boundary is larvio::ImageProcessor
+ * (/root/reference/include/larvio/image_processor.h:36-68) and larvio::LarVio
+ * (include/larvio/larvio.h:37-90), called from app/larvioMain.cpp:107,114.  Each entry point
+ * below cites the reference function it replaces.  INTEGRATION.md shows the adapter classes a
+ * maintainer compiles against this header so that larvioMain.cpp / System.cpp link unchanged.
+ *
+ * Conventions
+ *  - plain C types only; every function returns lvk_status; no exceptions cross the ABI;
+ *  - handle-scoped state, no process globals; lvk_last_error(ctx) gives a message;
+ *  - pointers named d_* are DEVICE pointers (hipMalloc / torch data_ptr()); h_* are host;
+ *  - stage-level functions are asynchronous on the context's stream unless stated;
+ *  - there is NO CPU fallback: without a gfx950 device lvk_context_create fails.
+ */
+#ifndef LVK_C_H
+#define LVK_C_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int lvk_status;
+#define LVK_OK              0
+#define LVK_ERR_ARG         1   /* bad argument */
+#define LVK_ERR_DEVICE      2   /* HIP runtime error / no device */
+#define LVK_ERR_CAPACITY    3   /* a fixed capacity was exceeded */
+#define LVK_ERR_UNSUPPORTED 4   /* configuration outside what the kernels are built for */
+
+typedef struct lvk_context  lvk_context;
+typedef struct lvk_pyramid  lvk_pyramid;
+typedef struct lvk_frontend lvk_frontend;
+
+typedef struct { float x, y; } lvk_pt2f;
+/* include/sensors/ImuData.hpp:17-43 */
+typedef struct { double t; double gyro[3]; double acc[3]; } lvk_imu;
+/* include/larvio/feature_msg.h:15-44 (MonoFeatureMeasurement, 72 bytes) */
+typedef struct {
+    uint64_t id;
+    double u, v, u_init, v_init, u_vel, v_vel, u_init_vel, v_init_vel;
+} lvk_feature_obs;
+
+/* ------------------------------------------------------------------ context / memory */
+lvk_status  lvk_context_create(int device, lvk_context** out);
+void        lvk_context_destroy(lvk_context* ctx);
+/* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+lvk_status  lvk_context_set_stream(lvk_context* ctx, void* hip_stream);
+lvk_status  lvk_sync(lvk_context* ctx);
+const char* lvk_last_error(const lvk_context* ctx);
+const char* lvk_version(void);
+/* thin helpers so a host without torch can drive the stage-level API */
+lvk_status  lvk_malloc(lvk_context* ctx, size_t bytes, void** d_out);
+lvk_status  lvk_free(lvk_context* ctx, void* d_ptr);
+lvk_status  lvk_memcpy_h2d(lvk_context* ctx, void* d_dst, const void* h_src, size_t bytes);  /* async */
+lvk_status  lvk_memcpy_d2h(lvk_context* ctx, void* h_dst, const void* d_src, size_t bytes);  /* sync  */
+lvk_status  lvk_memset(lvk_context* ctx, void* d_dst, int value, size_t bytes);
+
+/* ------------------------------------------------------------------ image passes
+ * replaces createImagePyramids (image_processor.cpp:318-334):
+ *   cv::createCLAHE(3.0,(8,8))->apply  +  cv::buildOpticalFlowPyramid(win, levels, derivs)
+ * and ORBdescriptor::initializeLayerAndPyramid level 0 (ORBDescriptor.cpp:418-484). */
+lvk_status lvk_clahe_u8(lvk_context* ctx, const uint8_t* d_src, int w, int h, int sstride,
+                        uint8_t* d_dst, int dstride, double clip, int tiles_x, int tiles_y);
+
+lvk_status lvk_pyramid_create(lvk_context* ctx, int w, int h, int win, int max_level, lvk_pyramid** out);
+void       lvk_pyramid_destroy(lvk_pyramid* p);
+/* level-0 source is d_img (already equalised or raw); builds all levels, padding, Scharr planes */
+lvk_status lvk_pyramid_build(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride);
+/* fused CLAHE + build (what the frame-level path runs) */
+lvk_status lvk_pyramid_build_clahe(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride,
+                                   double clip, int tiles_x, int tiles_y);
+int        lvk_pyramid_levels(const lvk_pyramid* p);
+/* geometry of level l: interior w,h; padded buffers: image row stride (bytes), deriv row stride
+ * (int16 units); device base pointers of the PADDED buffers; pad = win */
+lvk_status lvk_pyramid_level(const lvk_pyramid* p, int level, int* w, int* h, int* pad,
+                             int* istride, int* dstride, const uint8_t** d_img, const int16_t** d_der);
+/* ORB level-0 mosaic (border 32) and its 7x7 sigma-2 blurred copy; both (h+64) x (w+64), stride w+64 */
+lvk_status lvk_orb_prepare(lvk_context* ctx, const lvk_pyramid* p, uint8_t* d_ext, uint8_t* d_blur);
+
+/* replaces cv::goodFeaturesToTrack(img, maxCorners, quality, minDistance, mask, 3)
+ * (image_processor.cpp:343, 1035-1036).  d_mask may be NULL; d_n_out = device int. */
+lvk_status lvk_min_eigen_map(lvk_context* ctx, const lvk_pyramid* p, float* d_eig);
+lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, const uint8_t* d_mask,
+                             int max_corners, double quality, double min_distance,
+                             lvk_pt2f* d_out, int cap, int* d_n_out);
+
+/* ------------------------------------------------------------------ per-point stages
+ * replaces cv::calcOpticalFlowPyrLK(..., OPTFLOW_USE_INITIAL_FLOW) at
+ * image_processor.cpp:368,405,558,618,830,870.  d_next_pts in/out; d_iters optional (n*levels). */
+lvk_status lvk_lk_track(lvk_context* ctx, const lvk_pyramid* prev, const lvk_pyramid* next,
+                        const lvk_pt2f* d_prev_pts, lvk_pt2f* d_next_pts, uint8_t* d_status, int n,
+                        int max_iter, double eps, int* d_iters);
+/* replaces ORBdescriptor::computeDescriptors (ORBDescriptor.cpp:386-416); d_desc n*32 bytes */
+lvk_status lvk_orb_describe(lvk_context* ctx, const uint8_t* d_ext, const uint8_t* d_blur, int w, int h,
+                            const lvk_pt2f* d_pts, int n, uint8_t* d_desc, float* d_angle);
+/* replaces ORBdescriptor::computeDescriptorDistance row-wise (ORBDescriptor.h:43-59) */
+lvk_status lvk_hamming256_rows(lvk_context* ctx, const uint8_t* d_a, const uint8_t* d_b, int n, int* d_dist);
+/* replaces ImageProcessor::undistortPoints (image_processor.cpp:1040-1072); model 0 radtan, 1 equidistant */
+lvk_status lvk_undistort_points(lvk_context* ctx, const lvk_pt2f* d_in, int n, const double intr[4], int model,
+                                const double dist[4], const double new_intr[4], lvk_pt2f* d_out);
+/* replaces cv::findFundamentalMat(p1,p2,FM_RANSAC,thresh,conf,mask) (image_processor.cpp:498,755,968).
+ * d_mask n bytes; d_info[0] = 1 if a mask was written (n>=7) else 0, d_info[1] = hypotheses drawn. */
+lvk_status lvk_find_fundamental_mask(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n,
+                                     double thresh, double conf, uint8_t* d_mask, int* d_info);
+/* the RANSAC branch alone for any n >= 8 (stage parity) */
+lvk_status lvk_ransac_fundamental(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n,
+                                  double thresh, double conf, int max_iters, uint8_t* d_mask, int* d_info);
+/* replaces integrateImuData + predictFeatureTracking's matrix (image_processor.cpp:222-293): host math */
+lvk_status lvk_predict_homography(const lvk_imu* h_imu, int n_imu, double t_prev, double t_curr,
+                                  const double R_cam_imu[9], const double intr[4], float H[9]);
+
+/* ------------------------------------------------------------------ the front-end object
+ * replaces larvio::ImageProcessor (image_processor.h:36-68): lvk_frontend_create = ctor+initialize()
+ * (image_processor.cpp:28-126, parameters as loadParameters reads them), lvk_frontend_process =
+ * processImage (image_processor.cpp:130-219). */
+typedef struct {
+    int width, height;
+    int pyramid_levels;      /* config/euroc.yaml:43 */
+    int patch_size;          /* :44 */
+    int max_iteration;       /* :46 */
+    double track_precision;  /* :47 */
+    int max_features_num;    /* :49 */
+    int min_distance;        /* :50 */
+    int flag_equalize;       /* :51 */
+    int pub_frequency;       /* :52 */
+    int distortion_model;    /* 0 radtan, 1 equidistant (:14) */
+    double intrinsics[4];    /* fx fy cx cy (:17-21) */
+    double distortion[4];    /* (:22-26) */
+    double R_cam_imu[9];     /* row-major, = (T_cam_imu rotation)^T as image_processor.cpp:93 */
+} lvk_fe_config;
+
+lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_frontend** out);
+void       lvk_frontend_destroy(lvk_frontend* fe);
+/* img_is_device: 0 = img is a host pointer (copied in), 1 = device pointer.
+ * h_out receives up to cap features when *has_msg = 1 (the reference's `return haveFeatures`). */
+lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device,
+                                double ts, const lvk_imu* h_imu, int n_imu,
+                                lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg);
+/* introspection (synchronises): live tracks after the last call = the reference's
+ * pts_ids_/prev_pts_/pts_lifetime_/init_pts_/vOrbDescriptors after the rotation at :207-216 */
+lvk_status lvk_frontend_tracks(lvk_frontend* fe, uint64_t* h_ids, lvk_pt2f* h_pts, int* h_lifetime,
+                               lvk_pt2f* h_init, uint8_t* h_desc, int cap, int* n_out);
+lvk_status lvk_frontend_new_pts(lvk_frontend* fe, lvk_pt2f* h_pts, int cap, int* n_out);
+int        lvk_frontend_state(const lvk_frontend* fe);   /* 1 FIRST_IMAGE 2 SECOND_IMAGE 3 OTHER_IMAGES */
+/* cumulative LK work: point-levels processed and iterations executed (SURVEY §8d byte model) */
+lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint64_t* iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

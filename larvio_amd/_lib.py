@@ -1,0 +1,166 @@
+"""ctypes binding of liblvk_hip.so (the C ABI declared in include/lvk_c.h)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblvk_hip.so")
+_LIB = None
+
+PT = np.dtype([("x", np.float32), ("y", np.float32)])
+IMU = np.dtype([("t", np.float64), ("gyro", np.float64, 3), ("acc", np.float64, 3)])
+OBS = np.dtype([("id", np.uint64), ("u", np.float64), ("v", np.float64), ("u_init", np.float64),
+                ("v_init", np.float64), ("u_vel", np.float64), ("v_vel", np.float64),
+                ("u_init_vel", np.float64), ("v_init_vel", np.float64)])
+
+# every symbol include/lvk_c.h declares (checked by tests/test_abi.py against the header text)
+ABI_SYMBOLS = [
+    "lvk_context_create", "lvk_context_destroy", "lvk_context_set_stream", "lvk_sync", "lvk_last_error", "lvk_version",
+    "lvk_malloc", "lvk_free", "lvk_memcpy_h2d", "lvk_memcpy_d2h", "lvk_memset",
+    "lvk_clahe_u8", "lvk_pyramid_create", "lvk_pyramid_destroy", "lvk_pyramid_build", "lvk_pyramid_build_clahe",
+    "lvk_pyramid_levels", "lvk_pyramid_level", "lvk_orb_prepare", "lvk_min_eigen_map", "lvk_good_features",
+    "lvk_lk_track", "lvk_orb_describe", "lvk_hamming256_rows", "lvk_undistort_points", "lvk_find_fundamental_mask",
+    "lvk_ransac_fundamental", "lvk_predict_homography",
+    "lvk_frontend_create", "lvk_frontend_destroy", "lvk_frontend_process", "lvk_frontend_tracks", "lvk_frontend_new_pts",
+    "lvk_frontend_state", "lvk_frontend_lk_stats",
+]
+
+
+class LvkError(RuntimeError):
+    pass
+
+
+class FeConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("pyramid_levels", C.c_int), ("patch_size", C.c_int),
+                ("max_iteration", C.c_int), ("track_precision", C.c_double), ("max_features_num", C.c_int),
+                ("min_distance", C.c_int), ("flag_equalize", C.c_int), ("pub_frequency", C.c_int),
+                ("distortion_model", C.c_int), ("intrinsics", C.c_double * 4), ("distortion", C.c_double * 4),
+                ("R_cam_imu", C.c_double * 9)]
+
+
+def lib():
+    """Load liblvk_hip.so.  Fails loudly when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise LvkError(f"{_SO} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(_SO)
+        vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+        pi = C.POINTER(C.c_int)
+        sig = {
+            "lvk_context_create": ([i, C.POINTER(vp)], i), "lvk_context_destroy": ([vp], None),
+            "lvk_context_set_stream": ([vp, vp], i), "lvk_sync": ([vp], i),
+            "lvk_last_error": ([vp], C.c_char_p), "lvk_version": ([], C.c_char_p),
+            "lvk_malloc": ([vp, sz, C.POINTER(vp)], i), "lvk_free": ([vp, vp], i),
+            "lvk_memcpy_h2d": ([vp, vp, vp, sz], i), "lvk_memcpy_d2h": ([vp, vp, vp, sz], i), "lvk_memset": ([vp, vp, i, sz], i),
+            "lvk_clahe_u8": ([vp, vp, i, i, i, vp, i, d, i, i], i),
+            "lvk_pyramid_create": ([vp, i, i, i, i, C.POINTER(vp)], i), "lvk_pyramid_destroy": ([vp], None),
+            "lvk_pyramid_build": ([vp, vp, vp, i], i), "lvk_pyramid_build_clahe": ([vp, vp, vp, i, d, i, i], i),
+            "lvk_pyramid_levels": ([vp], i),
+            "lvk_pyramid_level": ([vp, i, pi, pi, pi, pi, pi, C.POINTER(vp), C.POINTER(vp)], i),
+            "lvk_orb_prepare": ([vp, vp, vp, vp], i), "lvk_min_eigen_map": ([vp, vp, vp], i),
+            "lvk_good_features": ([vp, vp, vp, i, d, d, vp, i, vp], i),
+            "lvk_lk_track": ([vp, vp, vp, vp, vp, vp, i, i, d, vp], i),
+            "lvk_orb_describe": ([vp, vp, vp, i, i, vp, i, vp, vp], i),
+            "lvk_hamming256_rows": ([vp, vp, vp, i, vp], i),
+            "lvk_undistort_points": ([vp, vp, i, vp, i, vp, vp, vp], i),
+            "lvk_find_fundamental_mask": ([vp, vp, vp, i, d, d, vp, vp], i),
+            "lvk_ransac_fundamental": ([vp, vp, vp, i, d, d, i, vp, vp], i),
+            "lvk_predict_homography": ([vp, i, d, d, vp, vp, vp], i),
+            "lvk_frontend_create": ([vp, C.POINTER(FeConfig), C.POINTER(vp)], i), "lvk_frontend_destroy": ([vp], None),
+            "lvk_frontend_process": ([vp, vp, i, i, d, vp, i, vp, i, pi, pi], i),
+            "lvk_frontend_tracks": ([vp, vp, vp, vp, vp, vp, i, pi], i),
+            "lvk_frontend_new_pts": ([vp, vp, i, pi], i), "lvk_frontend_state": ([vp], i),
+            "lvk_frontend_lk_stats": ([vp, vp, vp], i),
+        }
+        for name, (args, res) in sig.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = res
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceBuffer):
+        return C.c_void_p(a.ptr)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):          # torch tensor on the GPU
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+class Context:
+    """lvk_context: one GPU, one stream."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        h = C.c_void_p()
+        st = L.lvk_context_create(device, C.byref(h))
+        if st != 0:
+            raise LvkError(f"lvk_context_create failed with status {st}: no usable gfx950 device (there is no CPU fallback)")
+        self.h = h
+        self._bufs = []
+        if stream is not None:
+            self.check(L.lvk_context_set_stream(self.h, C.c_void_p(stream)))
+
+    def check(self, st):
+        if st != 0:
+            raise LvkError(f"lvk status {st}: {lib().lvk_last_error(self.h).decode()}")
+
+    def sync(self):
+        self.check(lib().lvk_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = DeviceBuffer(self, arr.nbytes)
+        if arr.nbytes:
+            self.check(lib().lvk_memcpy_h2d(self.h, C.c_void_p(b.ptr), _p(arr), arr.nbytes))
+        return b
+
+    def to_host(self, buf, dtype, shape):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            self.check(lib().lvk_memcpy_d2h(self.h, _p(out), C.c_void_p(buf.ptr if isinstance(buf, DeviceBuffer) else buf), out.nbytes))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().lvk_sync(self.h)
+            lib().lvk_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        p = C.c_void_p()
+        ctx.check(lib().lvk_malloc(ctx.h, max(int(nbytes), 1), C.byref(p)))
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            lib().lvk_free(self.ctx.h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

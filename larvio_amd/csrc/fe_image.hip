@@ -1,0 +1,587 @@
+// fe_image.hip — full-image passes of the front-end for gfx950 (wave64):
+// CLAHE, LK pyramid (+reflect-101 padding, Scharr planes), ORB mosaic + 7x7 blur, GFTT.
+// Replaces the OpenCV calls at /root/reference/src/image_processor.cpp:318-334, 343, 1005-1037 and
+// /root/reference/src/ORBDescriptor.cpp:418-484.  All of these are HBM/L2-bound byte passes; none
+// is GEMM-shaped, so no MFMA here: the rules that matter are coalesced row access, LDS tiles for
+// the stencils and as few dependent launches as possible (each costs ~1.5-2 us on MI355X).
+#include "lvk_internal.h"
+#include <stdarg.h>
+
+lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...)
+{
+    if (ctx) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+// =========================================================================== CLAHE
+// one workgroup per tile: LDS histogram (one sub-histogram per wave), clip + redistribute,
+// inclusive scan -> LUT.  [cv::CLAHE CLAHE_CalcLut_Body]
+__global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int sstride,
+                                                  int tw, int th, int tiles_x, int clip, float lut_scale,
+                                                  uint8_t* __restrict__ lut)
+{
+    __shared__ int sh[4][256];
+    __shared__ int hist[256];
+    __shared__ int red[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    for (int k = 0; k < 4; ++k) sh[k][t] = 0;
+    __syncthreads();
+    const int total = tw * th;
+    for (int i = t; i < total; i += 256) {
+        int y = i / tw, x = i - y * tw;
+        int px = d_reflect101(tx * tw + x, w), py = d_reflect101(ty * th + y, h);   // ext tiles reflect (non-divisible sizes)
+        atomicAdd(&sh[wave][src[(size_t)py * sstride + px]], 1);
+    }
+    __syncthreads();
+    int v = sh[0][t] + sh[1][t] + sh[2][t] + sh[3][t];
+    if (clip > 0) {
+        int over = v > clip ? v - clip : 0;
+        if (v > clip) v = clip;
+        // block sum of `over`
+        int s = over;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        int clipped = red[0] + red[1] + red[2] + red[3];
+        int batch = clipped / 256, residual = clipped - batch * 256;
+        v += batch;
+        if (residual != 0) {
+            int step = 256 / residual; if (step < 1) step = 1;
+            if (t % step == 0 && t / step < residual) v += 1;
+        }
+    }
+    hist[t] = v;
+    __syncthreads();
+    // inclusive scan over 256 ints (Hillis-Steele in LDS)
+    for (int o = 1; o < 256; o <<= 1) {
+        int add = t >= o ? hist[t - o] : 0;
+        __syncthreads();
+        hist[t] += add;
+        __syncthreads();
+    }
+    lut[(size_t)blockIdx.x * 256 + t] = d_sat_u8(d_cv_round((float)hist[t] * lut_scale));
+}
+
+// CLAHE bilinear LUT blend at image coordinate (x,y)  [CLAHE_Interpolation_Body]
+__device__ __forceinline__ uint8_t clahe_pixel(const uint8_t* __restrict__ lut, int tiles_x, int tiles_y,
+                                               float inv_tw, float inv_th, int x, int y, int v)
+{
+    float tyf = y * inv_th - 0.5f;
+    int ty1 = d_cv_floor(tyf), ty2 = ty1 + 1;
+    float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0); ty2 = min(ty2, tiles_y - 1);
+    float txf = x * inv_tw - 0.5f;
+    int tx1 = d_cv_floor(txf), tx2 = tx1 + 1;
+    float xa = txf - tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0); tx2 = min(tx2, tiles_x - 1);
+    const uint8_t* p1 = lut + (size_t)ty1 * tiles_x * 256;
+    const uint8_t* p2 = lut + (size_t)ty2 * tiles_x * 256;
+    int i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+    float res = (p1[i1] * xa1 + p1[i2] * xa) * ya1 + (p2[i1] * xa1 + p2[i2] * xa) * ya;
+    return d_sat_u8(d_cv_round(res));
+}
+
+__global__ void k_clahe_apply(const uint8_t* __restrict__ src, int w, int h, int sstride,
+                              const uint8_t* __restrict__ lut, int tiles_x, int tiles_y, float inv_tw, float inv_th,
+                              uint8_t* __restrict__ dst, int dstride)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    dst[(size_t)y * dstride + x] = clahe_pixel(lut, tiles_x, tiles_y, inv_tw, inv_th, x, y, src[(size_t)y * sstride + x]);
+}
+
+// level 0 of the LK pyramid incl. its reflect-101 frame, optionally through the CLAHE LUT blend:
+// one thread per PADDED pixel; the value of a frame pixel is the value at its reflected coordinate.
+template <bool EQ>
+__global__ void k_level0_pad(const uint8_t* __restrict__ src, int w, int h, int sstride,
+                             const uint8_t* __restrict__ lut, int tiles_x, int tiles_y, float inv_tw, float inv_th,
+                             uint8_t* __restrict__ dst /*padded base*/, int pad, int dstride)
+{
+    int ex = blockIdx.x * blockDim.x + threadIdx.x, ey = blockIdx.y;
+    if (ex >= w + 2 * pad) return;
+    int x = d_reflect101(ex - pad, w), y = d_reflect101(ey - pad, h);
+    int v = src[(size_t)y * sstride + x];
+    uint8_t o = EQ ? clahe_pixel(lut, tiles_x, tiles_y, inv_tw, inv_th, x, y, v) : (uint8_t)v;
+    dst[(size_t)ey * dstride + ex] = o;
+}
+
+// =========================================================================== pyrDown (+ frame)
+// [cv::pyrDown u8]  dst(x,y) = (sum_{5x5} w_i w_j src(2x-2+i, 2y-2+j) + 128) >> 8, w = [1 4 6 4 1].
+// The source's own reflect-101 frame (pad >= 2) supplies the border taps, so no index math.
+__global__ void k_pyr_down_pad(const uint8_t* __restrict__ s0 /*src pixel (0,0)*/, int sstride,
+                               int dw, int dh, uint8_t* __restrict__ dst /*padded base*/, int pad, int dstride)
+{
+    int ex = blockIdx.x * blockDim.x + threadIdx.x, ey = blockIdx.y;
+    if (ex >= dw + 2 * pad) return;
+    int x = d_reflect101(ex - pad, dw), y = d_reflect101(ey - pad, dh);
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint8_t* r = s0 + (ptrdiff_t)(2 * y - 2 + j) * sstride + (2 * x - 2);
+        int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
+        const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+        acc += wj * row;
+    }
+    dst[(size_t)ey * dstride + ex] = (uint8_t)((acc + 128) >> 8);
+}
+
+// =========================================================================== Scharr planes
+// [calcSharrDeriv]  Ix = [3 10 3]^T (x) [-1 0 1],  Iy = [-1 0 1]^T (x) [3 10 3], int16 interleaved.
+// Reads the padded image (reflect-101 frame == calcSharrDeriv's own border rule).
+__global__ void k_scharr(const uint8_t* __restrict__ s0, int w, int h, int sstride,
+                         int16_t* __restrict__ d0 /*deriv of pixel (0,0)*/, int dstride)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* r0 = s0 + (ptrdiff_t)(y - 1) * sstride + x;
+    const uint8_t* r1 = r0 + sstride;
+    const uint8_t* r2 = r1 + sstride;
+    int a_m = (r0[-1] + r2[-1]) * 3 + r1[-1] * 10, a_p = (r0[1] + r2[1]) * 3 + r1[1] * 10;
+    int b_m = r2[-1] - r0[-1], b_c = r2[0] - r0[0], b_p = r2[1] - r0[1];
+    short2 o;
+    o.x = (short)(a_p - a_m);
+    o.y = (short)((b_p + b_m) * 3 + b_c * 10);
+    *reinterpret_cast<short2*>(d0 + (size_t)y * dstride + 2 * x) = o;
+}
+
+// =========================================================================== ORB mosaic + blur
+// ext(e) = level0[ reflect about the frame-grown image ] (non-isolated copyMakeBorder, see oracle)
+__global__ void k_orb_ext(const uint8_t* __restrict__ s0, int w, int h, int sstride, int grow,
+                          uint8_t* __restrict__ ext, int estride)
+{
+    int ex = blockIdx.x * blockDim.x + threadIdx.x, ey = blockIdx.y;
+    if (ex >= w + 2 * LVK_ORB_BORDER) return;
+    int gx = d_reflect101(ex - LVK_ORB_BORDER + grow, w + 2 * grow) - grow;
+    int gy = d_reflect101(ey - LVK_ORB_BORDER + grow, h + 2 * grow) - grow;
+    ext[(size_t)ey * estride + ex] = s0[(ptrdiff_t)gy * sstride + gx];
+}
+
+// 7x7 fixed-point Gaussian {18,34,49,55,49,34,18}, (sum + 2^15) >> 16, interior only; frame copied.
+// LDS-tiled separable: 64x16 output tile per 256-thread workgroup.
+#define BL_TX 64
+#define BL_TY 16
+__global__ void __launch_bounds__(256) k_orb_blur(const uint8_t* __restrict__ ext, int w, int h, int estride,
+                                                 uint8_t* __restrict__ blur)
+{
+    __shared__ uint8_t raw[BL_TY + 6][BL_TX + 8];
+    __shared__ int hs[BL_TY + 6][BL_TX];
+    const int B = LVK_ORB_BORDER;
+    const int ew = w + 2 * B, eh = h + 2 * B;
+    const int x0 = blockIdx.x * BL_TX, y0 = blockIdx.y * BL_TY;      // ext coordinates of the tile
+    const int t = threadIdx.x;
+    for (int i = t; i < (BL_TY + 6) * (BL_TX + 6); i += 256) {
+        int ry = i / (BL_TX + 6), rx = i - ry * (BL_TX + 6);
+        int gx = min(max(x0 + rx - 3, 0), ew - 1), gy = min(max(y0 + ry - 3, 0), eh - 1);
+        raw[ry][rx] = ext[(size_t)gy * estride + gx];
+    }
+    __syncthreads();
+    for (int i = t; i < (BL_TY + 6) * BL_TX; i += 256) {
+        int ry = i / BL_TX, rx = i - ry * BL_TX;
+        const uint8_t* r = &raw[ry][rx];
+        hs[ry][rx] = 18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 49 * (r[2] + r[4]) + 55 * r[3];
+    }
+    __syncthreads();
+    for (int i = t; i < BL_TY * BL_TX; i += 256) {
+        int ry = i / BL_TX, rx = i - ry * BL_TX;
+        int gx = x0 + rx, gy = y0 + ry;
+        if (gx >= ew || gy >= eh) continue;
+        uint8_t o;
+        if (gx >= B && gx < B + w && gy >= B && gy < B + h) {
+            int acc = 18 * (hs[ry][rx] + hs[ry + 6][rx]) + 34 * (hs[ry + 1][rx] + hs[ry + 5][rx]) +
+                      49 * (hs[ry + 2][rx] + hs[ry + 4][rx]) + 55 * hs[ry + 3][rx];
+            o = d_sat_u8((acc + (1 << 15)) >> 16);
+        } else {
+            o = raw[ry + 3][rx + 3];
+        }
+        blur[(size_t)gy * estride + gx] = o;
+    }
+}
+
+// =========================================================================== GFTT
+// min-eigenvalue response [cornerMinEigenVal, Sobel 3, block 3] with the oracle's fixed float order.
+#define EG_TX 64
+#define EG_TY 8
+__device__ __forceinline__ void cov_at(const uint8_t* __restrict__ s0, int sstride, int x, int y, float ke, float kc,
+                                       float& c0, float& c1, float& c2)
+{
+    const uint8_t* r0 = s0 + (ptrdiff_t)(y - 1) * sstride + x;
+    const uint8_t* r1 = r0 + sstride;
+    const uint8_t* r2 = r1 + sstride;
+    float a00 = r0[-1], a01 = r0[0], a02 = r0[1], a10 = r1[-1], a12 = r1[1], a20 = r2[-1], a21 = r2[0], a22 = r2[1];
+    float q0 = a02 - a00, q1 = a12 - a10, q2 = a22 - a20;
+    float dx = kc * q1 + ke * (q0 + q2);
+    float t0 = kc * a01 + ke * (a00 + a02);
+    float t2 = kc * a21 + ke * (a20 + a22);
+    float dy = t2 - t0;
+    c0 = dx * dx; c1 = dx * dy; c2 = dy * dy;
+}
+
+__global__ void __launch_bounds__(256) k_min_eigen(const uint8_t* __restrict__ s0, int w, int h, int sstride,
+                                                  float* __restrict__ eig)
+{
+    __shared__ float cv[3][EG_TY + 2][EG_TX + 2];
+    __shared__ float hs[3][EG_TY + 2][EG_TX];
+    const float ke = (float)(1.0 / 3060.0), kc = 2.0f * ke;
+    const int x0 = blockIdx.x * EG_TX, y0 = blockIdx.y * EG_TY, t = threadIdx.x;
+    for (int i = t; i < (EG_TY + 2) * (EG_TX + 2); i += 256) {
+        int ry = i / (EG_TX + 2), rx = i - ry * (EG_TX + 2);
+        int gx = x0 + rx - 1, gy = y0 + ry - 1;
+        // box filter border = reflect-101 of the covariance map; clamp tile overhang to a valid pixel
+        gx = d_reflect101(min(gx, w), w); gy = d_reflect101(min(gy, h), h);
+        float c0, c1, c2;
+        cov_at(s0, sstride, gx, gy, ke, kc, c0, c1, c2);
+        cv[0][ry][rx] = c0; cv[1][ry][rx] = c1; cv[2][ry][rx] = c2;
+    }
+    __syncthreads();
+    for (int i = t; i < (EG_TY + 2) * EG_TX; i += 256) {
+        int ry = i / EG_TX, rx = i - ry * EG_TX;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hs[c][ry][rx] = (cv[c][ry][rx] + cv[c][ry][rx + 1]) + cv[c][ry][rx + 2];
+    }
+    __syncthreads();
+    for (int i = t; i < EG_TY * EG_TX; i += 256) {
+        int ry = i / EG_TX, rx = i - ry * EG_TX;
+        int gx = x0 + rx, gy = y0 + ry;
+        if (gx >= w || gy >= h) continue;
+        float s[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[c] = (hs[c][ry][rx] + hs[c][ry + 1][rx]) + hs[c][ry + 2][rx];
+        float a = s[0] * 0.5f, b = s[1], c2 = s[2] * 0.5f;
+        eig[(size_t)gy * w + gx] = (a + c2) - sqrtf((a - c2) * (a - c2) + b * b);
+    }
+}
+
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned k) { return k == 0 ? 0.f : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// gftt scratch layout (ints): [0] max key, [1] n candidates, [2] overflow flag
+__global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int n,
+                                                   unsigned* __restrict__ scratch)
+{
+    unsigned best = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        if (!mask || mask[i]) best = max(best, f2ord(eig[i]));
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(&scratch[0], best);
+}
+
+__global__ void k_gftt_candidates(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int w, int h,
+                                  float quality, unsigned* __restrict__ scratch,
+                                  unsigned long long* __restrict__ cands, int cap)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x + 1, y = blockIdx.y + 1;
+    if (x >= w - 1 || y >= h - 1) return;
+    const float max_val = ord2f(scratch[0]);
+    const float thresh = (float)((double)max_val * (double)quality);
+    float v = eig[(size_t)y * w + x];
+    v = v > thresh ? v : 0.f;
+    if (v == 0.f) return;
+    if (mask && !mask[(size_t)y * w + x]) return;
+    float m = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            float u = eig[(size_t)(y + dy) * w + x + dx];
+            u = u > thresh ? u : 0.f;
+            m = fmaxf(m, u);
+        }
+    if (v != m) return;
+    unsigned slot = atomicAdd(&scratch[1], 1u);
+    if (slot < (unsigned)cap) cands[slot] = ((unsigned long long)f2ord(v) << 32) | (unsigned)(y * w + x);
+    else scratch[2] = 1u;
+}
+
+// single-workgroup: sort candidates (value desc, index desc) and run the greedy min-distance selection
+// [goodFeaturesToTrack grid loop].  Sorting is bitonic in LDS (<= 8192 keys) or in global memory.
+#define GF_SORT_LDS 8192
+#define GF_MAX_CELLS 8192
+#define GF_MAX_OUT 4096
+__global__ void __launch_bounds__(1024) k_gftt_select(unsigned long long* __restrict__ cands, int cap, int w, int h,
+                                                     int max_corners, int cell, float md2,
+                                                     unsigned* __restrict__ scratch, lvk_pt2f* __restrict__ out, int out_cap,
+                                                     int* __restrict__ n_out, const int* __restrict__ d_sub)
+{
+    __shared__ unsigned long long keys[GF_SORT_LDS];
+    __shared__ unsigned short cells[GF_MAX_CELLS][4];
+    __shared__ short2 acc[GF_MAX_OUT];
+    const int t = threadIdx.x;
+    if (d_sub) {   // image_processor.cpp:1034-1036: maxCorners = max_features_num - curr_pts_.size(), skipped when 0
+        max_corners -= *d_sub;
+        if (max_corners <= 0) { if (t == 0) *n_out = 0; return; }
+    }
+    int n = (int)min(scratch[1], (unsigned)cap);
+    int np2 = 1; while (np2 < n) np2 <<= 1;          // the candidate buffer is allocated to the next power of two of cap
+    const bool in_lds = np2 <= GF_SORT_LDS;
+    unsigned long long* K = in_lds ? keys : cands;
+    if (in_lds) { for (int i = t; i < np2; i += 1024) keys[i] = i < n ? cands[i] : 0ull; }
+    else { for (int i = n + t; i < np2; i += 1024) cands[i] = 0ull; }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < np2; i += 1024) {
+                int l = i ^ j;
+                if (l > i) {
+                    unsigned long long a = K[i], b = K[l];
+                    bool desc = (i & k) == 0;
+                    if (desc ? a < b : a > b) { K[i] = b; K[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+    for (int i = t; i < gw * gh; i += 1024) { cells[i][0] = cells[i][1] = cells[i][2] = cells[i][3] = 0xFFFF; }
+    __syncthreads();
+    if (t >= 64) return;
+    const int lane = t;
+    int na = 0;
+    bool done = false;
+    for (int base = 0; base < n && !done; base += 64) {
+        int i = base + lane;
+        bool good = i < n;
+        int x = 0, y = 0;
+        if (good) {
+            unsigned idx = (unsigned)(K[i] & 0xFFFFFFFFull);
+            good = (K[i] >> 32) != 0;
+            y = idx / w; x = idx - y * w;
+        }
+        if (good) {
+            int xc = x / cell, yc = y / cell;
+            int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+            for (int yy = y1; yy <= y2 && good; ++yy)
+                for (int xx = x1; xx <= x2 && good; ++xx)
+                    for (int s = 0; s < 4; ++s) {
+                        unsigned short a = cells[yy * gw + xx][s];
+                        if (a == 0xFFFF) break;
+                        float dx = (float)x - (float)acc[a].x, dy = (float)y - (float)acc[a].y;
+                        if (dx * dx + dy * dy < md2) { good = false; break; }
+                    }
+        }
+        unsigned long long m = __ballot(good);
+        while (m) {
+            int j = __ffsll((long long)m) - 1;
+            int xj = __shfl(x, j), yj = __shfl(y, j);
+            if (lane == 0) {
+                if (na < out_cap) { out[na].x = (float)xj; out[na].y = (float)yj; }
+                if (na < GF_MAX_OUT) {
+                    acc[na] = make_short2((short)xj, (short)yj);
+                    unsigned short* c = cells[(yj / cell) * gw + (xj / cell)];
+                    for (int s = 0; s < 4; ++s) if (c[s] == 0xFFFF) { c[s] = (unsigned short)na; break; }
+                }
+            }
+            ++na;
+            if ((max_corners > 0 && na == max_corners) || na >= GF_MAX_OUT) { done = true; break; }
+            if (good && lane > j) {
+                float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
+                if (dx * dx + dy * dy < md2) good = false;
+            }
+            m = __ballot(good && lane > j);
+        }
+    }
+    if (lane == 0) *n_out = na < out_cap ? na : out_cap;
+}
+
+// mask with zeroed (2*md+1)^2 boxes around round(pt)  (image_processor.cpp:1009-1030)
+__global__ void k_mask_boxes(const lvk_pt2f* __restrict__ pts, const int* __restrict__ n_pts, int w, int h, int md,
+                             uint8_t* __restrict__ mask)
+{
+    int i = blockIdx.x;
+    if (i >= *n_pts) return;
+    // round(): half away from zero on the float coordinate
+    int ry = (int)roundf(pts[i].y), rx = (int)roundf(pts[i].x);
+    int r0 = max(ry - md, 0), r1 = min(ry + md, h - 1), c0 = max(rx - md, 0), c1 = min(rx + md, w - 1);
+    int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+    if (bw <= 0 || bh <= 0) return;
+    for (int k = threadIdx.x; k < bw * bh; k += blockDim.x) {
+        int yy = k / bw, xx = k - yy * bw;
+        mask[(size_t)(r0 + yy) * w + c0 + xx] = 0;
+    }
+}
+
+// =========================================================================== host side of the ABI
+extern "C" {
+
+lvk_status lvk_clahe_u8(lvk_context* ctx, const uint8_t* d_src, int w, int h, int sstride,
+                        uint8_t* d_dst, int dstride, double clip_limit, int tiles_x, int tiles_y)
+{
+    if (!ctx || !d_src || !d_dst || w <= 0 || h <= 0 || tiles_x <= 0 || tiles_y <= 0) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_clahe_u8: bad argument");
+    int ew = w, eh = h;
+    if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - (w % tiles_x)); eh = h + (tiles_y - (h % tiles_y)); }
+    const int tw = ew / tiles_x, th = eh / tiles_y, total = tw * th;
+    const float lut_scale = (float)(255) / total;
+    int clip = 0;
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
+    uint8_t* lut = nullptr;
+    LVK_HIP(ctx, hipMallocAsync((void**)&lut, (size_t)tiles_x * tiles_y * 256, ctx->stream));
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, d_src, w, h, sstride, tw, th, tiles_x, clip, lut_scale, lut);
+    hipLaunchKernelGGL(k_clahe_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_src, w, h, sstride, lut, tiles_x, tiles_y,
+                       1.0f / tw, 1.0f / th, d_dst, dstride);
+    LVK_LAUNCH_CHECK(ctx);
+    LVK_HIP(ctx, hipFreeAsync(lut, ctx->stream));
+    return LVK_OK;
+}
+
+lvk_status lvk_pyramid_create(lvk_context* ctx, int w, int h, int win, int max_level, lvk_pyramid** out)
+{
+    if (!ctx || !out || w <= 0 || h <= 0 || win < 3 || max_level < 0) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_pyramid_create: bad argument");
+    if (win > LVK_ORB_BORDER) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "patch_size %d > %d not supported", win, LVK_ORB_BORDER);
+    lvk_pyramid* p = new lvk_pyramid();
+    memset(p, 0, sizeof *p);
+    p->ctx = ctx; p->pad = win; p->max_level = max_level;
+    int lw = w, lh = h;
+    for (int level = 0; level <= max_level && level < LVK_MAX_LEVELS; ++level) {
+        p->w[level] = lw; p->h[level] = lh;
+        p->istride[level] = (lw + 2 * win + 63) & ~63;
+        p->dstride[level] = 2 * p->istride[level];
+        size_t ib = (size_t)p->istride[level] * (lh + 2 * win), db = (size_t)p->dstride[level] * (lh + 2 * win) * sizeof(int16_t);
+        if (hipMalloc((void**)&p->img[level], ib) != hipSuccess || hipMalloc((void**)&p->der[level], db) != hipSuccess) {
+            lvk_pyramid_destroy(p);
+            return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_pyramid_create: hipMalloc failed");
+        }
+        hipMemsetAsync(p->img[level], 0, ib, ctx->stream);
+        hipMemsetAsync(p->der[level], 0, db, ctx->stream);     // BORDER_CONSTANT frame of the derivative planes stays 0
+        p->n_levels = level + 1;
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+        if (lw <= win || lh <= win) break;                     // buildOpticalFlowPyramid stop rule
+    }
+    p->clahe_lut_cap = 64 * 256;
+    if (hipMalloc((void**)&p->clahe_lut, (size_t)p->clahe_lut_cap) != hipSuccess) { lvk_pyramid_destroy(p); return lvk_set_error(ctx, LVK_ERR_DEVICE, "hipMalloc lut"); }
+    *out = p;
+    return LVK_OK;
+}
+
+void lvk_pyramid_destroy(lvk_pyramid* p)
+{
+    if (!p) return;
+    for (int i = 0; i < LVK_MAX_LEVELS; ++i) { if (p->img[i]) hipFree(p->img[i]); if (p->der[i]) hipFree(p->der[i]); }
+    if (p->clahe_lut) hipFree(p->clahe_lut);
+    delete p;
+}
+
+static lvk_status build_levels(lvk_context* ctx, lvk_pyramid* p)
+{
+    // levels 1.. (each depends on the previous) then all Scharr planes
+    for (int l = 1; l < p->n_levels; ++l) {
+        const uint8_t* s0 = p->img[l - 1] + (size_t)p->pad * p->istride[l - 1] + p->pad;
+        hipLaunchKernelGGL(k_pyr_down_pad, dim3((p->w[l] + 2 * p->pad + 255) / 256, p->h[l] + 2 * p->pad), dim3(256), 0, ctx->stream,
+                           s0, p->istride[l - 1], p->w[l], p->h[l], p->img[l], p->pad, p->istride[l]);
+    }
+    for (int l = 0; l < p->n_levels; ++l) {
+        const uint8_t* s0 = p->img[l] + (size_t)p->pad * p->istride[l] + p->pad;
+        int16_t* d0 = p->der[l] + (size_t)p->pad * p->dstride[l] + 2 * p->pad;
+        hipLaunchKernelGGL(k_scharr, dim3((p->w[l] + 255) / 256, p->h[l]), dim3(256), 0, ctx->stream, s0, p->w[l], p->h[l], p->istride[l], d0, p->dstride[l]);
+    }
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+lvk_status lvk_pyramid_build(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride)
+{
+    if (!ctx || !p || !d_img) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_pyramid_build: bad argument");
+    hipLaunchKernelGGL(k_level0_pad<false>, dim3((p->w[0] + 2 * p->pad + 255) / 256, p->h[0] + 2 * p->pad), dim3(256), 0, ctx->stream,
+                       d_img, p->w[0], p->h[0], stride, (const uint8_t*)nullptr, 1, 1, 1.f, 1.f, p->img[0], p->pad, p->istride[0]);
+    return build_levels(ctx, p);
+}
+
+lvk_status lvk_pyramid_build_clahe(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride,
+                                   double clip_limit, int tiles_x, int tiles_y)
+{
+    if (!ctx || !p || !d_img || tiles_x <= 0 || tiles_y <= 0) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_pyramid_build_clahe: bad argument");
+    if (tiles_x * tiles_y * 256 > p->clahe_lut_cap) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "too many CLAHE tiles");
+    const int w = p->w[0], h = p->h[0];
+    int ew = w, eh = h;
+    if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - (w % tiles_x)); eh = h + (tiles_y - (h % tiles_y)); }
+    const int tw = ew / tiles_x, th = eh / tiles_y, total = tw * th;
+    const float lut_scale = (float)(255) / total;
+    int clip = 0;
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, d_img, w, h, stride, tw, th, tiles_x, clip, lut_scale, p->clahe_lut);
+    hipLaunchKernelGGL(k_level0_pad<true>, dim3((w + 2 * p->pad + 255) / 256, h + 2 * p->pad), dim3(256), 0, ctx->stream,
+                       d_img, w, h, stride, (const uint8_t*)p->clahe_lut, tiles_x, tiles_y, 1.0f / tw, 1.0f / th, p->img[0], p->pad, p->istride[0]);
+    return build_levels(ctx, p);
+}
+
+int lvk_pyramid_levels(const lvk_pyramid* p) { return p ? p->n_levels : 0; }
+
+lvk_status lvk_pyramid_level(const lvk_pyramid* p, int level, int* w, int* h, int* pad, int* istride, int* dstride,
+                             const uint8_t** d_img, const int16_t** d_der)
+{
+    if (!p || level < 0 || level >= p->n_levels) return LVK_ERR_ARG;
+    if (w) *w = p->w[level]; if (h) *h = p->h[level]; if (pad) *pad = p->pad;
+    if (istride) *istride = p->istride[level]; if (dstride) *dstride = p->dstride[level];
+    if (d_img) *d_img = p->img[level]; if (d_der) *d_der = p->der[level];
+    return LVK_OK;
+}
+
+lvk_status lvk_orb_prepare(lvk_context* ctx, const lvk_pyramid* p, uint8_t* d_ext, uint8_t* d_blur)
+{
+    if (!ctx || !p || !d_ext || !d_blur) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_orb_prepare: bad argument");
+    const int w = p->w[0], h = p->h[0], B = LVK_ORB_BORDER, es = w + 2 * B, eh = h + 2 * B;
+    const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
+    const int grow = p->pad < B ? p->pad : B;
+    hipLaunchKernelGGL(k_orb_ext, dim3((es + 255) / 256, eh), dim3(256), 0, ctx->stream, s0, w, h, p->istride[0], grow, d_ext, es);
+    hipLaunchKernelGGL(k_orb_blur, dim3((es + BL_TX - 1) / BL_TX, (eh + BL_TY - 1) / BL_TY), dim3(256), 0, ctx->stream, (const uint8_t*)d_ext, w, h, es, d_blur);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+lvk_status lvk_min_eigen_map(lvk_context* ctx, const lvk_pyramid* p, float* d_eig)
+{
+    if (!ctx || !p || !d_eig) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_min_eigen_map: bad argument");
+    const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
+    hipLaunchKernelGGL(k_min_eigen, dim3((p->w[0] + EG_TX - 1) / EG_TX, (p->h[0] + EG_TY - 1) / EG_TY), dim3(256), 0, ctx->stream,
+                       s0, p->w[0], p->h[0], p->istride[0], d_eig);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+}  // extern "C"
+
+// internal: GFTT on a precomputed eig map with caller-provided scratch (used by the frame-level path too)
+lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
+                        double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
+                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub)
+{
+    if (min_distance < 1.0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "goodFeaturesToTrack with minDistance < 1 is not supported");
+    const int cell = (int)rint(min_distance);
+    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+    if (gw * gh > GF_MAX_CELLS) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT grid %dx%d exceeds %d cells", gw, gh, GF_MAX_CELLS);
+    if (max_corners > GF_MAX_OUT || max_corners <= 0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "maxCorners must be in 1..%d", GF_MAX_OUT);
+    LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, 4 * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(k_masked_max, dim3(256), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch);
+    hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, h - 2), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
+    hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), 0, ctx->stream, d_cands, cand_cap, w, h, max_corners, cell,
+                       (float)(min_distance * min_distance), d_scratch, d_out, cap, d_n_out, d_sub);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask)
+{
+    LVK_HIP(ctx, hipMemsetAsync(d_mask, 255, (size_t)w * h, ctx->stream));
+    if (max_pts > 0) hipLaunchKernelGGL(k_mask_boxes, dim3(max_pts), dim3(256), 0, ctx->stream, d_pts, d_n, w, h, md, d_mask);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+extern "C" lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, const uint8_t* d_mask, int max_corners,
+                                        double quality, double min_distance, lvk_pt2f* d_out, int cap, int* d_n_out)
+{
+    if (!ctx || !p || !d_out || !d_n_out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_good_features: bad argument");
+    const int w = p->w[0], h = p->h[0];
+    float* eig = nullptr; unsigned* scratch = nullptr; unsigned long long* cands = nullptr;
+    const int cand_cap = w * h;
+    size_t cand_alloc = 1; while (cand_alloc < (size_t)cand_cap) cand_alloc <<= 1;     // bitonic sort pads to a power of two in place
+    LVK_HIP(ctx, hipMallocAsync((void**)&eig, sizeof(float) * (size_t)w * h, ctx->stream));
+    LVK_HIP(ctx, hipMallocAsync((void**)&scratch, 4 * sizeof(unsigned), ctx->stream));
+    LVK_HIP(ctx, hipMallocAsync((void**)&cands, sizeof(unsigned long long) * cand_alloc, ctx->stream));
+    lvk_status st = lvk_min_eigen_map(ctx, p, eig);
+    if (st == LVK_OK) st = lvk_gftt_run(ctx, eig, d_mask, w, h, max_corners, quality, min_distance, scratch, cands, cand_cap, d_out, cap, d_n_out, nullptr);
+    hipFreeAsync(eig, ctx->stream); hipFreeAsync(scratch, ctx->stream); hipFreeAsync(cands, ctx->stream);
+    return st;
+}

@@ -1,0 +1,640 @@
+// fe_track_dev.h — device functions shared by the stage-level kernels (fe_track.hip) and the
+// frame-level kernels (frontend.hip).  wave64 only.
+#pragma once
+#include "lvk_internal.h"
+#include <float.h>
+
+// ------------------------------------------------------------------------- wave reductions
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// exact sum over the wave of per-lane int32 partials, as int64 (all lanes get the result)
+__device__ __forceinline__ long long wave_sum_i64(int v)
+{
+    int lo = v & 0xFFFF, hi = v >> 16;
+    lo = wave_sum_i32(lo); hi = wave_sum_i32(hi);
+    return ((long long)hi << 16) + (long long)lo;
+}
+
+// ------------------------------------------------------------------------- pyramidal LK
+// [cv::calcOpticalFlowPyrLK / LKTrackerInvoker], OPTFLOW_USE_INITIAL_FLOW, minEigThreshold 1e-4.
+// One wavefront per point.  The WIN x WIN template (I, Ix, Iy after the 14-bit bilinear blend) lives
+// in registers, PL = ceil(WIN^2/64) pixels per lane; A11/A12/A22 and b1/b2 are EXACT integer sums
+// (int32 per lane, int64 across the wave) converted to float once, so the result does not depend on
+// the reduction order (see oracle/fe_track.c).  All lanes hold identical copies of the scalar state.
+#define LK_W_BITS 14
+template <int WIN>
+__device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
+                                        int& status, int max_count, double epsilon, int* __restrict__ iters_out)
+{
+    int total_it = 0;
+    constexpr int NPIX = WIN * WIN;
+    constexpr int PL = (NPIX + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int max_level = n_levels - 1;
+    // per-lane pixel coordinates inside the window
+    int wy[PL], wx[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) { int p = lane + 64 * k; wy[k] = p / WIN; wx[k] = p - wy[k] * WIN; }
+
+    for (int level = max_level; level >= 0; --level) {
+        const int cols = prev.w[level], rows = prev.h[level];
+        const int stepI = prev.istride[level], stepJ = next.istride[level], dstep = prev.dstride[level];
+        const uint8_t* __restrict__ Ibase = prev.img[level];
+        const uint8_t* __restrict__ Jbase = next.img[level];
+        const int16_t* __restrict__ Dbase = prev.der[level];
+        const float lscale = (float)(1. / (1 << level));
+        float prx = prev_pt.x * lscale, pry = prev_pt.y * lscale;
+        float nx, ny;
+        if (level == max_level) { nx = next_pt.x * lscale; ny = next_pt.y * lscale; }
+        else { nx = next_pt.x * 2.f; ny = next_pt.y * 2.f; }
+        next_pt.x = nx; next_pt.y = ny;
+        int n_it = 0;
+
+        prx -= half; pry -= half;
+        const int ipx = d_cv_floor(prx), ipy = d_cv_floor(pry);
+        if (ipx < -WIN || ipx >= cols || ipy < -WIN || ipy >= rows) {
+            if (level == 0) status = 0;
+            if (iters_out && lane == 0) iters_out[level] = 0;
+            continue;
+        }
+        float a = prx - ipx, b = pry - ipy;
+        int iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+        int iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+        int iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+        int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+
+        short Iv[PL], Ixv[PL], Iyv[PL];
+        int pA11 = 0, pA12 = 0, pA22 = 0;
+#pragma unroll
+        for (int k = 0; k < PL; ++k) {
+            Iv[k] = 0; Ixv[k] = 0; Iyv[k] = 0;
+            if (lane + 64 * k < NPIX) {
+                const uint8_t* src = Ibase + (ptrdiff_t)(wy[k] + ipy) * stepI + (wx[k] + ipx);
+                const int16_t* ds = Dbase + (ptrdiff_t)(wy[k] + ipy) * dstep + 2 * (wx[k] + ipx);
+                int ival = (src[0] * iw00 + src[1] * iw01 + src[stepI] * iw10 + src[stepI + 1] * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+                int ixval = (ds[0] * iw00 + ds[2] * iw01 + ds[dstep] * iw10 + ds[dstep + 2] * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int iyval = (ds[1] * iw00 + ds[3] * iw01 + ds[dstep + 1] * iw10 + ds[dstep + 3] * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                Iv[k] = (short)ival; Ixv[k] = (short)ixval; Iyv[k] = (short)iyval;
+                pA11 += ixval * ixval; pA12 += ixval * iyval; pA22 += iyval * iyval;
+            }
+        }
+        const long long sA11 = wave_sum_i64(pA11), sA12 = wave_sum_i64(pA12), sA22 = wave_sum_i64(pA22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if ((double)min_eig < 1e-4 || D < FLT_EPSILON) {
+            if (level == 0) status = 0;
+            if (iters_out && lane == 0) iters_out[level] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; ++j) {
+            const int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
+            if (inx < -WIN || inx >= cols || iny < -WIN || iny >= rows) {
+                if (level == 0) status = 0;
+                break;
+            }
+            ++n_it;
+            a = nx - inx; b = ny - iny;
+            iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+            iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+            iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+            iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            int pb1 = 0, pb2 = 0;
+#pragma unroll
+            for (int k = 0; k < PL; ++k) {
+                if (lane + 64 * k < NPIX) {
+                    const uint8_t* Jp = Jbase + (ptrdiff_t)(wy[k] + iny) * stepJ + (wx[k] + inx);
+                    int diff = ((Jp[0] * iw00 + Jp[1] * iw01 + Jp[stepJ] * iw10 + Jp[stepJ + 1] * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
+                    pb1 += diff * Ixv[k]; pb2 += diff * Iyv[k];
+                }
+            }
+            const long long sb1 = wave_sum_i64(pb1), sb2 = wave_sum_i64(pb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx; ny += dy;
+            next_pt.x = nx + half; next_pt.y = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                next_pt.x -= dx * 0.5f; next_pt.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (iters_out && lane == 0) iters_out[level] = n_it;
+        total_it += n_it;
+    }
+    return total_it;
+}
+
+// ------------------------------------------------------------------------- ORB
+#include "orb_pattern_dev.inc"     // __constant__ int8_t k_orb_pattern[1024]
+// umax of a radius-15 disc (ORBDescriptor.cpp:313-328 evaluated; checked against the formula in tests)
+static __constant__ int8_t k_orb_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ float d_fast_atan2(float y, float x)
+{   // cv::fastAtan2 scalar polynomial, degrees
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// fixed-sequence double cos/sin (identical to oracle det_cos_sin)
+__device__ __forceinline__ void d_det_cos_sin(double x, double& c_out, double& s_out)
+{
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    double fn = rint(x * two_over_pi);
+    double r = (x - fn * pio2_1) - fn * pio2_1t;
+    int q = ((int)fn) & 3;
+    double z = r * r;
+    double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
+              + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
+              + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    double c = 1.0 - (0.5 * z - z * pc);
+    switch (q) {
+        case 0: c_out = c;  s_out = s;  break;
+        case 1: c_out = -s; s_out = c;  break;
+        case 2: c_out = -c; s_out = -s; break;
+        default: c_out = s; s_out = -c; break;
+    }
+}
+
+// one wavefront: IC angle on ext, 256 rotated tests on blur -> 4 x u64 descriptor (all lanes get it).
+__device__ __forceinline__ float orb_point(const uint8_t* __restrict__ ext, const uint8_t* __restrict__ blur, int step, lvk_pt2f pt,
+                                           unsigned long long d[4])
+{
+    const int lane = threadIdx.x & 63, B = LVK_ORB_BORDER;
+    const int cx = d_cv_round(pt.x * 1.0f), cy = d_cv_round(pt.y * 1.0f);
+    const uint8_t* center = ext + (ptrdiff_t)(cy + B) * step + cx + B;
+    int m10 = 0, m01 = 0;
+    for (int p = lane; p < 31 * 31; p += 64) {
+        int v = p / 31 - 15, u = p - (v + 15) * 31 - 15;
+        int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= k_orb_umax[av]) {
+            int val = center[v * step + u];
+            m10 += u * val; m01 += v * val;
+        }
+    }
+    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+    const float angle = d_fast_atan2((float)m01, (float)m10);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ang = angle * factorPI;
+    double cd, sd;
+    d_det_cos_sin((double)ang, cd, sd);
+    const float a = (float)cd, b = (float)sd;
+    const uint8_t* bc = blur + (ptrdiff_t)(cy + B) * step + cx + B;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int T = s * 64 + lane;
+        const int x0 = k_orb_pattern[4 * T], y0 = k_orb_pattern[4 * T + 1], x1 = k_orb_pattern[4 * T + 2], y1 = k_orb_pattern[4 * T + 3];
+        float fx0 = x0 * a - y0 * b, fy0 = x0 * b + y0 * a;
+        float fx1 = x1 * a - y1 * b, fy1 = x1 * b + y1 * a;
+        int t0 = bc[d_cv_round(fy0) * step + d_cv_round(fx0)];
+        int t1 = bc[d_cv_round(fy1) * step + d_cv_round(fx1)];
+        d[s] = __ballot(t0 < t1);
+    }
+    return angle;
+}
+
+__device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* b)
+{
+    int dist = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dist += __popc(a[i] ^ b[i]);
+    return dist;
+}
+__device__ __forceinline__ int hamming256_u64(const unsigned long long a[4], const unsigned long long* b)
+{
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// ------------------------------------------------------------------------- undistortion
+// [cv::undistortPoints 5 iterations | cv::fisheye::undistortPoints Newton] double inside, Point2f out.
+__device__ __forceinline__ lvk_pt2f undistort_point(lvk_pt2f in, const CamParams& cam, const double ni[4])
+{
+    const double fx = cam.intr[0], fy = cam.intr[1], cx = cam.intr[2], cy = cam.intr[3];
+    const double RR00 = ni[0], RR01 = 0.0, RR02 = ni[2], RR10 = 0.0, RR11 = ni[1], RR12 = ni[3], RR20 = 0.0, RR21 = 0.0, RR22 = 1.0;
+    lvk_pt2f o;
+    if (cam.model == 0) {
+        const double ifx = 1. / fx, ify = 1. / fy;
+        const double k0 = cam.dist[0], k1 = cam.dist[1], p1 = cam.dist[2], p2 = cam.dist[3];
+        double x = in.x, y = in.y;
+        const double u = x, v = y;
+        x = (x - cx) * ifx; y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; ++j) {
+            double r2 = x * x + y * y;
+            double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((0. * r2 + k1) * r2 + k0) * r2);
+            if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+            double dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+            double dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + 0. * r2 + 0. * r2 * r2;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+        double xx = RR00 * x + RR01 * y + RR02;
+        double yy = RR10 * x + RR11 * y + RR12;
+        double ww = 1. / (RR20 * x + RR21 * y + RR22);
+        o.x = (float)(xx * ww); o.y = (float)(yy * ww);
+    } else {
+        const double PI_2 = 3.1415926535897932384626433832795 / 2.;
+        double pwx = ((double)in.x - cx) / fx, pwy = ((double)in.y - cy) / fy;
+        double scale = 1.0;
+        double theta_d = sqrt(pwx * pwx + pwy * pwy);
+        theta_d = fmin(fmax(-PI_2, theta_d), PI_2);
+        if (theta_d > 1e-8) {
+            double theta = theta_d;
+            for (int j = 0; j < 10; ++j) {
+                double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+                double k0t2 = cam.dist[0] * t2, k1t4 = cam.dist[1] * t4, k2t6 = cam.dist[2] * t6, k3t8 = cam.dist[3] * t8;
+                double fix = (theta * (1 + k0t2 + k1t4 + k2t6 + k3t8) - theta_d) / (1 + 3 * k0t2 + 5 * k1t4 + 7 * k2t6 + 9 * k3t8);
+                theta = theta - fix;
+                if (fabs(fix) < 1e-8) break;
+            }
+            scale = tan(theta) / theta_d;
+        }
+        double pux = pwx * scale, puy = pwy * scale;
+        double prx = RR00 * pux + RR01 * puy + RR02 * 1.0;
+        double pry = RR10 * pux + RR11 * puy + RR12 * 1.0;
+        double prz = RR20 * pux + RR21 * puy + RR22 * 1.0;
+        o.x = (float)(prx / prz); o.y = (float)(pry / prz);
+    }
+    return o;
+}
+
+// ------------------------------------------------------------------------- fundamental matrix
+#define FM_THREADS 256
+#define FM_MAX_N 4096
+#define FM_ROUND 16            // hypotheses solved and scored per round
+
+__device__ inline void d_nullspace_7x9(const double* A, double* f1, double* f2)
+{   // Householder QR of A^T; last two columns of Q (same operation order as the oracle)
+    double M[9][7], V[7][9], beta[7];
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 7; ++c) M[r][c] = A[c * 9 + r];
+    for (int k = 0; k < 7; ++k) {
+        double nrm2 = 0.;
+        for (int r = k; r < 9; ++r) nrm2 += M[r][k] * M[r][k];
+        double nrm = sqrt(nrm2);
+        for (int r = 0; r < 9; ++r) V[k][r] = 0.;
+        if (nrm == 0.) { beta[k] = 0.; continue; }
+        double alpha = M[k][k] >= 0. ? -nrm : nrm;
+        double v0 = M[k][k] - alpha;
+        V[k][k] = v0;
+        for (int r = k + 1; r < 9; ++r) V[k][r] = M[r][k];
+        double vnorm2 = v0 * v0;
+        for (int r = k + 1; r < 9; ++r) vnorm2 += M[r][k] * M[r][k];
+        beta[k] = vnorm2 == 0. ? 0. : 2. / vnorm2;
+        for (int c = k; c < 7; ++c) {
+            double s = 0.;
+            for (int r = k; r < 9; ++r) s += V[k][r] * M[r][c];
+            s *= beta[k];
+            for (int r = k; r < 9; ++r) M[r][c] -= s * V[k][r];
+        }
+    }
+    for (int j = 7; j < 9; ++j) {
+        double q[9];
+        for (int r = 0; r < 9; ++r) q[r] = (r == j) ? 1. : 0.;
+        for (int k = 6; k >= 0; --k) {
+            double s = 0.;
+            for (int r = k; r < 9; ++r) s += V[k][r] * q[r];
+            s *= beta[k];
+            for (int r = k; r < 9; ++r) q[r] -= s * V[k][r];
+        }
+        double* f = (j == 7) ? f1 : f2;
+        for (int r = 0; r < 9; ++r) f[r] = q[r];
+    }
+}
+
+__device__ inline int d_solve_cubic(const double* coef, double* roots)
+{   // cv::solveCubic, 1x4 form
+    double a0 = coef[0], a1 = coef[1], a2 = coef[2], a3 = coef[3];
+    double x0 = 0., x1 = 0., x2 = 0.;
+    int n = 0;
+    const double PI = 3.1415926535897932384626433832795;
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) n = a3 == 0 ? -1 : 0;
+            else { x0 = -a3 / a2; n = 1; }
+        } else {
+            double d = a2 * a2 - 4 * a1 * a3;
+            if (d >= 0) {
+                d = sqrt(d);
+                double q1 = (-a2 + d) * 0.5;
+                double q2 = (a2 + d) * -0.5;
+                if (fabs(q1) > fabs(q2)) { x0 = q1 / a1; x1 = a3 / q1; }
+                else { x0 = q2 / a1; x1 = a3 / q2; }
+                n = d > 0 ? 2 : 1;
+            }
+        }
+    } else {
+        a0 = 1. / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+        double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+        double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+        double Qcubed = Q * Q * Q;
+        double d = Qcubed - R * R;
+        if (d > 0) {
+            double theta = acos(R / sqrt(Qcubed));
+            double sqrtQ = sqrt(Q);
+            double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+            x0 = t0 * cos(t1) - t2;
+            x1 = t0 * cos(t1 + (2. * PI / 3)) - t2;
+            x2 = t0 * cos(t1 + (4. * PI / 3)) - t2;
+            n = 3;
+        } else if (d == 0) {
+            if (R >= 0) { x0 = -2 * pow(R, 1. / 3) - a1 / 3; x1 = pow(R, 1. / 3) - a1 / 3; }
+            else { x0 = 2 * pow(-R, 1. / 3) - a1 / 3; x1 = -pow(-R, 1. / 3) - a1 / 3; }
+            x2 = 0;
+            n = x0 == x1 ? 1 : 2;
+            x1 = x0 == x1 ? 0 : x1;
+        } else {
+            double e;
+            d = sqrt(-d);
+            e = pow(d + fabs(R), 1. / 3);
+            if (R > 0) e = -e;
+            x0 = (e + Q / e) - a1 * (1. / 3);
+            n = 1;
+        }
+    }
+    roots[0] = x0; roots[1] = x1; roots[2] = x2;
+    return n;
+}
+
+__device__ inline int d_fundamental_7pt(const lvk_pt2f* m1, const lvk_pt2f* m2, double* fmatrix)
+{   // run7Point
+    double a[7 * 9], f1[9], f2[9], c[4], r[3] = {0, 0, 0};
+    for (int i = 0; i < 7; ++i) {
+        double x0 = m1[i].x, y0 = m1[i].y, x1 = m2[i].x, y1 = m2[i].y;
+        a[i * 9 + 0] = x1 * x0; a[i * 9 + 1] = x1 * y0; a[i * 9 + 2] = x1;
+        a[i * 9 + 3] = y1 * x0; a[i * 9 + 4] = y1 * y0; a[i * 9 + 5] = y1;
+        a[i * 9 + 6] = x0; a[i * 9 + 7] = y0; a[i * 9 + 8] = 1;
+    }
+    d_nullspace_7x9(a, f1, f2);
+    for (int i = 0; i < 9; ++i) f1[i] -= f2[i];
+    double t0 = f2[4] * f2[8] - f2[5] * f2[7];
+    double t1 = f2[3] * f2[8] - f2[5] * f2[6];
+    double t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 -
+           f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) -
+           f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) -
+           f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7];
+    t1 = f1[3] * f1[8] - f1[5] * f1[6];
+    t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 -
+           f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) -
+           f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) -
+           f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    int n = d_solve_cubic(c, r);
+    if (n < 1 || n > 3) return 0;
+    for (int k = 0; k < n; ++k, fmatrix += 9) {
+        double lambda = r[k], mu = 1.;
+        double s = f1[8] * r[k] + f2[8];
+        if (fabs(s) > DBL_EPSILON) { mu = 1. / s; lambda *= mu; fmatrix[8] = 1.; }
+        else fmatrix[8] = 0.;
+        for (int i = 0; i < 8; ++i) fmatrix[i] = f1[i] * lambda + f2[i] * mu;
+    }
+    return n;
+}
+
+__device__ __forceinline__ float d_fm_error(lvk_pt2f p1, lvk_pt2f p2, const double* F)
+{   // FMEstimatorCallback::computeError, one point
+    double a, b, c, d1, d2, s1, s2;
+    a = F[0] * p1.x + F[1] * p1.y + F[2];
+    b = F[3] * p1.x + F[4] * p1.y + F[5];
+    c = F[6] * p1.x + F[7] * p1.y + F[8];
+    s2 = 1. / (a * a + b * b);
+    d2 = p2.x * a + p2.y * b + c;
+    a = F[0] * p2.x + F[3] * p2.y + F[6];
+    b = F[1] * p2.x + F[4] * p2.y + F[7];
+    c = F[2] * p2.x + F[5] * p2.y + F[8];
+    s1 = 1. / (a * a + b * b);
+    d1 = p1.x * a + p1.y * b + c;
+    double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)(e1 > e2 ? e1 : e2);
+}
+
+struct d_rng { unsigned long long state; };
+__device__ __forceinline__ unsigned d_rng_next(d_rng& r)
+{
+    r.state = (unsigned long long)(unsigned)r.state * 4164903690ULL + (unsigned)(r.state >> 32);
+    return (unsigned)r.state;
+}
+__device__ __forceinline__ int d_rng_uniform(d_rng& r, int a, int b) { return a == b ? a : (int)(d_rng_next(r) % (unsigned)(b - a) + a); }
+
+__device__ inline bool d_have_collinear(const lvk_pt2f* ptr, int count)
+{
+    int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        double dx1 = ptr[j].x - ptr[i].x, dy1 = ptr[j].y - ptr[i].y;
+        for (int k = 0; k < j; ++k) {
+            double dx2 = ptr[k].x - ptr[i].x, dy2 = ptr[k].y - ptr[i].y;
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+
+__device__ inline bool d_get_subset(const lvk_pt2f* m1, const lvk_pt2f* m2, int count, lvk_pt2f* ms1, lvk_pt2f* ms2, d_rng& rng, int max_attempts)
+{
+    int idx[7], iters = 0;
+    for (; iters < max_attempts; ++iters) {
+        for (int i = 0; i < 7; ++i) {
+            int idx_i;
+            for (;;) {
+                idx_i = d_rng_uniform(rng, 0, count);
+                bool dup = false;
+                for (int q = 0; q < i; ++q) if (idx[q] == idx_i) { dup = true; break; }
+                if (!dup) break;
+            }
+            idx[i] = idx_i;
+            ms1[i] = m1[idx_i]; ms2[i] = m2[idx_i];
+        }
+        if (!d_have_collinear(ms1, 7) && !d_have_collinear(ms2, 7)) break;
+    }
+    return iters < max_attempts;
+}
+
+__device__ inline int d_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num); denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// The whole of cv::findFundamentalMat(..., FM_RANSAC, thresh, conf, mask) for one point set held in
+// LDS, executed by one FM_THREADS workgroup.  Returns (uniformly) 1 if smask[0..n) was written.
+//   n < 7: nothing;  n == 7: ones;  8..14: LMedS (300 hypotheses, all in parallel);
+//   n >= 15 (or force_ransac): RANSAC — rounds of FM_ROUND hypotheses: thread 0 draws the subsets in
+//   OpenCV's RNG order, FM_ROUND threads solve the 7-point systems, all threads score, thread 0 replays
+//   the sequential "better model -> shrink niters" rule over the round in order.
+__device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int n, double thresh, double conf, int max_iters,
+                                    int force_ransac, uint8_t* smask, int* iters_out)
+{
+    __shared__ lvk_pt2f sub1[FM_ROUND][7], sub2[FM_ROUND][7];
+    __shared__ double models[FM_ROUND][27];
+    __shared__ int nmodels[FM_ROUND], found[FM_ROUND], good[FM_ROUND][3];
+    __shared__ double best_model[9];
+    __shared__ int sh_ctl[4];                 // [0] stop, [1] have best, [2] iterations, [3] niters
+    __shared__ unsigned long long sh_rng;
+    __shared__ float lm_med[FM_THREADS]; __shared__ int lm_seq[FM_THREADS];
+    const int t = threadIdx.x;
+    *iters_out = 0;
+    if (n < 7) return 0;
+    if (n == 7) { for (int i = t; i < n; i += FM_THREADS) smask[i] = 1; __syncthreads(); return 1; }
+    if (thresh <= 0) thresh = 3;
+    if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+
+    if (n >= 15 || force_ransac) {
+        const float tthr = (float)(thresh * thresh);
+        if (t == 0) { sh_ctl[0] = 0; sh_ctl[1] = 0; sh_ctl[2] = 0; sh_ctl[3] = max_iters > 1 ? max_iters : 1; sh_rng = ~0ULL; }
+        __syncthreads();
+        int max_good = 0;       // thread 0 only
+        for (int base = 0;; base += FM_ROUND) {
+            if (t == 0) {
+                d_rng rng; rng.state = sh_rng;
+                for (int r = 0; r < FM_ROUND; ++r) found[r] = d_get_subset(s1, s2, n, sub1[r], sub2[r], rng, 10000) ? 1 : 0;
+                sh_rng = rng.state;
+            }
+            if (t < FM_ROUND * 3) good[t / 3][t % 3] = 0;
+            __syncthreads();
+            if (t < FM_ROUND) nmodels[t] = found[t] ? d_fundamental_7pt(sub1[t], sub2[t], models[t]) : 0;
+            __syncthreads();
+            for (int slot = t >> 6; slot < FM_ROUND * 3; slot += FM_THREADS / 64) {
+                int r = slot / 3, m = slot - 3 * r;
+                if (m >= nmodels[r]) continue;
+                int cnt = 0;
+                for (int i = t & 63; i < n; i += 64) cnt += d_fm_error(s1[i], s2[i], &models[r][9 * m]) <= tthr;
+                cnt = wave_sum_i32(cnt);
+                if ((t & 63) == 0) good[r][m] = cnt;
+            }
+            __syncthreads();
+            if (t == 0) {
+                // replay of RANSACPointSetRegistrator::run's loop over this round, in order
+                int niters = sh_ctl[3], iter = base;
+                bool stop = false;
+                for (int r = 0; r < FM_ROUND; ++r, ++iter) {
+                    if (iter >= niters) { stop = true; break; }
+                    if (!found[r]) { stop = true; break; }            // getSubset failed: iter==0 -> no model, else stop
+                    for (int m = 0; m < nmodels[r]; ++m) {
+                        int g = good[r][m];
+                        if (g > (max_good > 6 ? max_good : 6)) {
+                            for (int q = 0; q < 9; ++q) best_model[q] = models[r][9 * m + q];
+                            max_good = g; sh_ctl[1] = 1;
+                            niters = d_ransac_update_num_iters(conf, (double)(n - g) / n, 7, niters);
+                        }
+                    }
+                }
+                if (!stop && iter >= niters) stop = true;
+                sh_ctl[0] = stop ? 1 : 0; sh_ctl[2] = iter; sh_ctl[3] = niters;
+            }
+            __syncthreads();
+            if (sh_ctl[0]) break;
+        }
+        // iterations drawn = value of `iter` when OpenCV's loop exits
+        if (sh_ctl[1]) { for (int i = t; i < n; i += FM_THREADS) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tthr; }
+        else { for (int i = t; i < n; i += FM_THREADS) smask[i] = 0; }
+        *iters_out = sh_ctl[2];
+        __syncthreads();
+        return 1;
+    }
+
+    // ---- LMedS (8 <= n < 15): niters from outlier ratio 0.45, one hypothesis per thread per pass
+    __shared__ lvk_pt2f lsub1[FM_THREADS][7], lsub2[FM_THREADS][7];
+    __shared__ int lfound[FM_THREADS];
+    const int niters = d_ransac_update_num_iters(conf, 0.45, 7, 1000);
+    float my_med = FLT_MAX; int my_seq = 0x7fffffff; double my_model[9];
+    if (t == 0) sh_rng = ~0ULL;
+    __syncthreads();
+    int stop_at = niters;      // iteration at which getSubset failed (uniform via LDS)
+    for (int base = 0; base < niters; base += FM_THREADS) {
+        if (t == 0) {
+            d_rng rng; rng.state = sh_rng;
+            int failed = 0;
+            for (int r = 0; r < FM_THREADS && base + r < niters; ++r) {
+                lfound[r] = failed ? 0 : (d_get_subset(s1, s2, n, lsub1[r], lsub2[r], rng, 1000) ? 1 : 0);
+                if (!lfound[r] && !failed) { failed = 1; sh_ctl[2] = base + r; }
+            }
+            sh_rng = rng.state;
+            sh_ctl[0] = failed;
+        }
+        __syncthreads();
+        if (base + t < niters && lfound[t]) {
+            double mdl[27];
+            int nm = d_fundamental_7pt(lsub1[t], lsub2[t], mdl);
+            for (int m = 0; m < nm; ++m) {
+                float e[16];
+                for (int i = 0; i < n; ++i) e[i] = d_fm_error(s1[i], s2[i], mdl + 9 * m);
+                // median = element count/2 of the ascending order (errors are >= 0: int view == float order)
+                for (int i = 1; i < n; ++i) { float v = e[i]; int j = i - 1; while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; --j; } e[j + 1] = v; }
+                float med = e[n / 2];
+                int seq = (base + t) * 3 + m;
+                if (med < my_med) { my_med = med; my_seq = seq; for (int q = 0; q < 9; ++q) my_model[q] = mdl[9 * m + q]; }
+            }
+        }
+        int failed = sh_ctl[0];
+        if (failed) { stop_at = sh_ctl[2]; __syncthreads(); break; }
+        __syncthreads();
+    }
+    // hypotheses at or after a getSubset failure are not run by OpenCV: none were solved (lfound = 0)
+    (void)stop_at;
+    lm_med[t] = my_med; lm_seq[t] = my_seq;
+    __syncthreads();
+    if (t == 0) {
+        int bi = -1; float bm = FLT_MAX; int bs = 0x7fffffff;
+        for (int i = 0; i < FM_THREADS; ++i)
+            if (lm_seq[i] != 0x7fffffff && (lm_med[i] < bm || (lm_med[i] == bm && lm_seq[i] < bs))) { bm = lm_med[i]; bs = lm_seq[i]; bi = i; }
+        sh_ctl[1] = bi;
+    }
+    __syncthreads();
+    const int bi = sh_ctl[1];
+    if (bi < 0) { for (int i = t; i < n; i += FM_THREADS) smask[i] = 0; __syncthreads(); *iters_out = niters; return 1; }
+    if (t == bi) { for (int q = 0; q < 9; ++q) best_model[q] = my_model[q]; }
+    __syncthreads();
+    {
+        double min_median = (double)lm_med[bi];
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(min_median);
+        sigma = sigma > 0.001 ? sigma : 0.001;
+        const float tt = (float)(sigma * sigma);
+        for (int i = t; i < n; i += FM_THREADS) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tt;
+    }
+    *iters_out = niters;
+    __syncthreads();
+    return 1;
+}

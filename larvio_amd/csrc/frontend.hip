@@ -1,0 +1,673 @@
+// frontend.hip — context management and the frame-level front-end object of liblvk_hip.so.
+// lvk_frontend_process replaces ImageProcessor::processImage (/root/reference/src/image_processor.cpp:130-219).
+//
+// Device-resident design (MI355X): the track table (ids, points, first-seen descriptors, lifetimes),
+// both pyramids and both ORB mosaics stay in HBM across frames; every data-dependent count
+// (tracks alive, new corners, survivors per stage) lives in a device struct, kernels are launched
+// over the full capacity and dead wavefronts exit at once.  The host therefore never waits on the
+// GPU inside a steady-state frame except to fetch the feature message on publish frames.
+// Stages keep points IN PLACE with a stage code instead of compacting six vectors four times
+// (image_processor.h:215-230); the one order-preserving compaction happens inside the RANSAC
+// workgroup, which needs the compacted order anyway (OpenCV's RNG draws indices into it).
+#include "lvk_internal.h"
+#include "fe_track_dev.h"
+#include <math.h>
+#include <float.h>
+#include <new>
+
+lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
+                        double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
+                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub);
+lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask);
+
+// =========================================================================== context
+extern "C" {
+
+const char* lvk_version(void) { return "lvk-hip 0.1 (gfx950)"; }
+
+lvk_status lvk_context_create(int device, lvk_context** out)
+{
+    if (!out) return LVK_ERR_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LVK_ERR_DEVICE;   // no CPU fallback
+    if (hipSetDevice(device) != hipSuccess) return LVK_ERR_DEVICE;
+    lvk_context* c = new (std::nothrow) lvk_context();
+    if (!c) return LVK_ERR_DEVICE;
+    c->device = device; c->err[0] = 0; c->own_stream = true;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LVK_ERR_DEVICE; }
+    *out = c;
+    return LVK_OK;
+}
+
+void lvk_context_destroy(lvk_context* ctx)
+{
+    if (!ctx) return;
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+lvk_status lvk_context_set_stream(lvk_context* ctx, void* hip_stream)
+{
+    if (!ctx) return LVK_ERR_ARG;
+    if (ctx->own_stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+    else { LVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    return LVK_OK;
+}
+
+lvk_status lvk_sync(lvk_context* ctx) { if (!ctx) return LVK_ERR_ARG; LVK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return LVK_OK; }
+const char* lvk_last_error(const lvk_context* ctx) { return ctx ? ctx->err : "null context"; }
+
+lvk_status lvk_malloc(lvk_context* ctx, size_t bytes, void** d_out)
+{
+    if (!ctx || !d_out) return LVK_ERR_ARG;
+    LVK_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
+    return LVK_OK;
+}
+lvk_status lvk_free(lvk_context* ctx, void* d_ptr) { if (!ctx) return LVK_ERR_ARG; LVK_HIP(ctx, hipStreamSynchronize(ctx->stream)); LVK_HIP(ctx, hipFree(d_ptr)); return LVK_OK; }
+lvk_status lvk_memcpy_h2d(lvk_context* ctx, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!ctx) return LVK_ERR_ARG;
+    LVK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));     // pageable source: finish before the caller reuses it
+    return LVK_OK;
+}
+lvk_status lvk_memcpy_d2h(lvk_context* ctx, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx) return LVK_ERR_ARG;
+    LVK_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LVK_OK;
+}
+lvk_status lvk_memset(lvk_context* ctx, void* d_dst, int value, size_t bytes)
+{
+    if (!ctx) return LVK_ERR_ARG;
+    LVK_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return LVK_OK;
+}
+
+// ---- gyro prediction: host math, float32 as the reference (image_processor.cpp:222-293) -----------
+lvk_status lvk_predict_homography(const lvk_imu* imu, int n_imu, double t_prev, double t_curr, const double R_cam_imu[9],
+                                  const double intr[4], float H[9])
+{
+    if ((n_imu > 0 && !imu) || !R_cam_imu || !intr || !H) return LVK_ERR_ARG;
+    int b = 0;
+    while (b < n_imu && imu[b].t - t_prev < -0.0049) ++b;
+    int e = b;
+    while (e < n_imu && imu[e].t - t_curr < 0.0049) ++e;
+    float mw[3] = {0.f, 0.f, 0.f};
+    for (int i = b; i < e; ++i) { mw[0] += (float)imu[i].gyro[0]; mw[1] += (float)imu[i].gyro[1]; mw[2] += (float)imu[i].gyro[2]; }
+    if (e - b > 0) { float s = 1.0f / (e - b); mw[0] *= s; mw[1] *= s; mw[2] *= s; }
+    float cw[3];
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.;
+        for (int k = 0; k < 3; ++k) s += R_cam_imu[k * 3 + i] * (double)mw[k];
+        cw[i] = (float)s;
+    }
+    const double dtime = t_curr - t_prev;
+    const float rv[3] = {(float)(cw[0] * dtime), (float)(cw[1] * dtime), (float)(cw[2] * dtime)};
+    double rx = rv[0], ry = rv[1], rz = rv[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    double R[9];
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1. : 0.;
+    } else {
+        const double c = cos(theta), s = sin(theta), c1 = 1. - c, it = theta ? 1. / theta : 0.;
+        rx *= it; ry *= it; rz *= it;
+        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        for (int i = 0; i < 9; ++i) R[i] = c * ((i % 4 == 0) ? 1. : 0.) + c1 * rrt[i] + s * r_x[i];
+    }
+    float Rt[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = (float)R[j * 3 + i];
+    const float K[9] = {(float)intr[0], 0.f, (float)intr[2], 0.f, (float)intr[1], (float)intr[3], 0.f, 0.f, 1.f};
+    float Ki[9];
+    {
+        const float* a = K;
+        float d = a[0] * (a[4] * a[8] - a[7] * a[5]) - a[1] * (a[3] * a[8] - a[6] * a[5]) + a[2] * (a[3] * a[7] - a[6] * a[4]);
+        if (d == 0) { for (int i = 0; i < 9; ++i) Ki[i] = 0.f; }
+        else {
+            d = 1 / d;
+            Ki[0] = (a[4] * a[8] - a[5] * a[7]) * d; Ki[1] = (a[2] * a[7] - a[1] * a[8]) * d; Ki[2] = (a[1] * a[5] - a[2] * a[4]) * d;
+            Ki[3] = (a[5] * a[6] - a[3] * a[8]) * d; Ki[4] = (a[0] * a[8] - a[2] * a[6]) * d; Ki[5] = (a[2] * a[3] - a[0] * a[5]) * d;
+            Ki[6] = (a[3] * a[7] - a[4] * a[6]) * d; Ki[7] = (a[1] * a[6] - a[0] * a[7]) * d; Ki[8] = (a[0] * a[4] - a[1] * a[3]) * d;
+        }
+    }
+    float T[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += K[i * 3 + k] * Rt[k * 3 + j]; T[i * 3 + j] = s; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = 0; for (int k = 0; k < 3; ++k) s += T[i * 3 + k] * Ki[k * 3 + j]; H[i * 3 + j] = s; }
+    return LVK_OK;
+}
+
+}  // extern "C"
+
+// =========================================================================== frame-level device state
+struct FeDev {
+    unsigned long long next_id;
+    unsigned long long lk_point_levels, lk_iterations;
+    int n_tracks[2];     // live tracks in set 0 / set 1
+    int n_new;           // new_pts_ size
+    int n_msg;           // features in the last message
+    int boot_ok;         // result of the last bootstrap attempt
+    int pad_;
+};
+
+struct TrackSet {       // structure of arrays, capacity cap
+    unsigned long long* id;
+    lvk_pt2f* pts;       // curr_pts_ of the frame that wrote the set == prev_pts_ of the next frame
+    lvk_pt2f* ppts;      // prev_pts_ of the frame that wrote the set (needed by getFeatureMsg)
+    lvk_pt2f* init;
+    int* life;
+    unsigned long long* desc;   // 4 x u64 per track: first-seen descriptor
+};
+
+struct HMat { float h[9]; };
+
+__device__ __forceinline__ lvk_pt2f apply_h(const HMat& H, lvk_pt2f p)
+{   // predictFeatureTracking (:285-290): Matx33f * Vec3f, s = 0; s += H(i,k)*p(k)
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { float s = 0.f; s += H.h[r * 3] * p.x; s += H.h[r * 3 + 1] * p.y; s += H.h[r * 3 + 2] * 1.0f; q[r] = s; }
+    lvk_pt2f o; o.x = q[0] / q[2]; o.y = q[1] / q[2];
+    return o;
+}
+
+// stage codes in the per-point status byte
+#define ST_ALIVE 0
+#define ST_FWD   1
+#define ST_REV   2
+#define ST_ORB   3
+
+// forward LK from the previous pyramid, seeded by the gyro homography; in-image test (:553-578)
+template <int WIN>
+__global__ void __launch_bounds__(64) k_fe_lk_fwd(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                 HMat H, int width, int height, int max_count, double epsilon,
+                                                 lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev)
+{
+    const int p = blockIdx.x;
+    if (p >= *n_ptr) return;
+    const int n_levels = prev.n_levels < next.n_levels ? prev.n_levels : next.n_levels;
+    const lvk_pt2f pp = src_pts[p];
+    lvk_pt2f np = apply_h(H, pp);
+    int st = 1;
+    const int its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
+    if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
+    if ((threadIdx.x & 63) == 0) {
+        w_curr[p] = np; w_status[p] = st ? ST_ALIVE : ST_FWD;
+        atomicAdd(&dev->lk_point_levels, (unsigned long long)n_levels);
+        atomicAdd(&dev->lk_iterations, (unsigned long long)its);
+    }
+}
+
+// reverse LK (curr -> prev) seeded with the original point; in-image and <= 1 px tests (:616-642)
+template <int WIN>
+__global__ void __launch_bounds__(64) k_fe_lk_rev(PyrView curr, PyrView prevp, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                 int width, int height, int max_count, double epsilon,
+                                                 const lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev)
+{
+    const int p = blockIdx.x;
+    if (p >= *n_ptr) return;
+    if (w_status[p] != ST_ALIVE) return;
+    const int n_levels = curr.n_levels < prevp.n_levels ? curr.n_levels : prevp.n_levels;
+    const lvk_pt2f orig = src_pts[p];
+    lvk_pt2f back = orig;
+    int st = 1;
+    const int its = lk_point<WIN>(curr, prevp, n_levels, w_curr[p], back, st, max_count, epsilon, nullptr);
+    if (st) {
+        if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) st = 0;
+        else {
+            float dx = back.x - orig.x, dy = back.y - orig.y;
+            float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
+            if (dis > 1) st = 0;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (!st) w_status[p] = ST_REV;
+        atomicAdd(&dev->lk_point_levels, (unsigned long long)n_levels);
+        atomicAdd(&dev->lk_iterations, (unsigned long long)its);
+    }
+}
+
+// ORB gate.  OLD tracks: descriptor at the current point vs the stored first-seen one (:677-699).
+// NEW points: descriptor in the previous image vs in the current image, the previous one is kept (:909-930).
+__global__ void __launch_bounds__(64) k_fe_orb_gate(const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
+                                                   const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur, int width,
+                                                   const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                   const lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status,
+                                                   const unsigned long long* __restrict__ stored_desc /*old*/,
+                                                   unsigned long long* __restrict__ w_desc /*new: out*/, int is_new)
+{
+    const int p = blockIdx.x;
+    if (p >= *n_ptr) return;
+    if (w_status[p] != ST_ALIVE) return;
+    const int step = width + 2 * LVK_ORB_BORDER;
+    unsigned long long dc[4], dp[4];
+    orb_point(cur_ext, cur_blur, step, w_curr[p], dc);
+    int dist;
+    if (is_new) {
+        orb_point(prv_ext, prv_blur, step, src_pts[p], dp);
+        dist = hamming256_u64(dc, dp);
+        if ((threadIdx.x & 63) == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
+    } else {
+        dist = hamming256_u64(dc, stored_desc + (size_t)p * 4);
+    }
+    if ((threadIdx.x & 63) == 0 && dist > 58) w_status[p] = ST_ORB;
+}
+
+// One workgroup: count survivors per stage, order-preserving compaction of the alive points, undistort
+// both sets to pixel coordinates (K -> K), cv::findFundamentalMat mask, then write the destination
+// track set.  mode 0: old tracks (trackFeatures :701-808), 1: new points appended (trackNewFeatures
+// :932-1001), 2: bootstrap (initializeFirstFeatures :464-536).
+__global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int cap, CamParams cam,
+                                                               const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                               const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
+                                                               const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
+                                                               const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
+                                                               TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
+{
+    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
+    __shared__ uint8_t smask[FM_MAX_N];
+    __shared__ unsigned short sidx[FM_MAX_N];
+    __shared__ int cnt[4];
+    __shared__ int scan[FM_THREADS];
+    const int t = threadIdx.x;
+    const int n = min(*n_ptr, cap);
+    if (t < 4) cnt[t] = 0;
+    __syncthreads();
+    // survivors after each stage + ordered compaction of the alive ones (block scan over chunks)
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += FM_THREADS) {
+        int i = c0 + t;
+        int st = i < n ? w_status[i] : 255;
+        int alive = st == ST_ALIVE;
+        if (i < n) {
+            if (st != ST_FWD) atomicAdd(&cnt[0], 1);                       // after forward LK
+            if (st != ST_FWD && st != ST_REV) atomicAdd(&cnt[1], 1);       // after reverse LK
+            if (alive) atomicAdd(&cnt[2], 1);                              // after the ORB gate
+        }
+        scan[t] = alive;
+        __syncthreads();
+        for (int o = 1; o < FM_THREADS; o <<= 1) { int v = t >= o ? scan[t - o] : 0; __syncthreads(); scan[t] += v; __syncthreads(); }
+        if (alive) sidx[base + scan[t] - 1] = (unsigned short)i;
+        base += scan[FM_THREADS - 1];
+        __syncthreads();
+    }
+    const int m = cnt[2];
+    bool fail = false;
+    if (mode == 2) fail = cnt[0] < 20 || cnt[1] < 20 || m < 20;
+    else if (mode == 1) fail = m < 20;
+    int wrote = 0, iters = 0;
+    if (!fail && m > 0) {
+        for (int k = t; k < m; k += FM_THREADS) {
+            int i = sidx[k];
+            s1[k] = undistort_point(src_pts[i], cam, cam.intr);
+            s2[k] = undistort_point(w_curr[i], cam, cam.intr);
+        }
+        __syncthreads();
+        wrote = fm_mask_block(s1, s2, m, 1.0, 0.99, 1000, 0, smask, &iters);
+        __syncthreads();
+    }
+    // survivors of the mask (size mismatch => everything is kept, image_processor.h:219-223)
+    int kept = 0;
+    if (!fail) {
+        int basek = 0;
+        const int dst_base = (mode == 1) ? *dst_n : 0;
+        for (int c0 = 0; c0 < m; c0 += FM_THREADS) {
+            int k = c0 + t;
+            int keep = k < m ? (wrote ? smask[k] != 0 : 1) : 0;
+            scan[t] = keep;
+            __syncthreads();
+            for (int o = 1; o < FM_THREADS; o <<= 1) { int v = t >= o ? scan[t - o] : 0; __syncthreads(); scan[t] += v; __syncthreads(); }
+            if (keep) {
+                const int i = sidx[k];
+                const int d = dst_base + basek + scan[t] - 1;
+                if (d < cap) {
+                    dst.pts[d] = w_curr[i];
+                    dst.ppts[d] = src_pts[i];
+                    const unsigned long long* ds = src_desc + (size_t)i * 4;
+                    unsigned long long* dd = dst.desc + (size_t)d * 4;
+                    dd[0] = ds[0]; dd[1] = ds[1]; dd[2] = ds[2]; dd[3] = ds[3];
+                    if (mode == 0) { dst.id[d] = src_id[i]; dst.life[d] = src_life[i] + 1; dst.init[d] = src_init[i]; }
+                    else {
+                        dst.id[d] = dev->next_id + (unsigned long long)(basek + scan[t] - 1);
+                        dst.life[d] = 2;
+                        if (mode == 1) dst.init[d] = src_pts[i];
+                        else { dst.init[d].x = -1.f; dst.init[d].y = -1.f; }
+                    }
+                }
+            }
+            basek += scan[FM_THREADS - 1];
+            __syncthreads();
+        }
+        kept = basek;
+    }
+    if (mode == 2 && kept < 20) fail = true;
+    if (mode == 1 && kept <= 0) fail = true;
+    __syncthreads();
+    if (t == 0) {
+        if (mode == 0) *dst_n = kept;
+        else if (mode == 1) { if (!fail) { *dst_n = min(*dst_n + kept, cap); dev->next_id += (unsigned long long)kept; dev->n_new = 0; } }
+        else {
+            dev->boot_ok = fail ? 0 : 1;
+            if (!fail) { *dst_n = kept; dev->next_id += (unsigned long long)kept; dev->n_new = 0; }
+            else *dst_n = 0;
+        }
+    }
+}
+
+// getFeatureMsg (:1076-1128): undistort to normalised coordinates, finite-difference velocities
+__global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams cam, double dt_1, double dt_2, int prev_is_last,
+                         lvk_feature_obs* __restrict__ out, FeDev* __restrict__ dev)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_ptr;
+    if (i == 0) dev->n_msg = n;
+    if (i >= n) return;
+    const double unit[4] = {1, 1, 0, 0};
+    const lvk_pt2f uc = undistort_point(ts.pts[i], cam, unit);
+    const lvk_pt2f ini = ts.init[i];
+    const lvk_pt2f ui = undistort_point(ini, cam, unit);
+    const lvk_pt2f up = undistort_point(ts.ppts[i], cam, unit);
+    lvk_feature_obs f;
+    f.id = ts.id[i];
+    f.u = uc.x; f.v = uc.y;
+    f.u_vel = (uc.x - up.x) / dt_1;
+    f.v_vel = (uc.y - up.y) / dt_1;
+    f.u_init_vel = 0.0; f.v_init_vel = 0.0;
+    if (ini.x == -1 && ini.y == -1) { f.u_init = -1; f.v_init = -1; }
+    else {
+        f.u_init = ui.x; f.v_init = ui.y;
+        ts.init[i].x = -1.f; ts.init[i].y = -1.f;
+        if (prev_is_last) { f.u_init_vel = (uc.x - ui.x) / dt_2; f.v_init_vel = (uc.y - ui.y) / dt_2; }
+        else { f.u_init_vel = (up.x - ui.x) / dt_2; f.v_init_vel = (up.y - ui.y) / dt_2; }
+    }
+    out[i] = f;
+}
+
+
+// =========================================================================== host object
+struct lvk_frontend {
+    lvk_context* ctx;
+    lvk_fe_config cfg;
+    int cap;
+    int image_state;           // 1 FIRST_IMAGE, 2 SECOND_IMAGE, 3 OTHER_IMAGES
+    bool b_first_img;
+    long pub_counter;
+    double last_pub_time, curr_img_time, prev_img_time;
+    int cur;                   // track set holding prev_pts_ (written by the previous frame)
+    lvk_pyramid* pyr[2];       // [0] = prev, [1] = curr (swapped every frame)
+    uint8_t *ext[2], *blur[2];
+    uint8_t* d_img;            // staging for host images
+    TrackSet set[2];
+    lvk_pt2f *w_curr, *wn_curr, *new_pts;
+    uint8_t *w_status, *wn_status;
+    unsigned long long* wn_desc;
+    float* eig; uint8_t* mask; unsigned* gf_scratch; unsigned long long* gf_cands; int gf_cand_cap;
+    lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;     // device + pinned host
+    FeDev* dev; FeDev* h_dev;                            // device + pinned host mirror
+    CamParams cam;
+};
+
+template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess; }
+
+static void set_free(TrackSet& s)
+{
+    if (s.id) hipFree(s.id); if (s.pts) hipFree(s.pts); if (s.ppts) hipFree(s.ppts); if (s.init) hipFree(s.init);
+    if (s.life) hipFree(s.life); if (s.desc) hipFree(s.desc);
+    memset(&s, 0, sizeof s);
+}
+
+template <int WIN>
+static void launch_track_chain(lvk_frontend* fe, const PyrView& pv, const PyrView& cv, const lvk_pt2f* src_pts, const int* n_ptr, int grid,
+                               const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status, const unsigned long long* stored_desc,
+                               unsigned long long* w_desc, int is_new, int max_count, double epsilon)
+{
+    hipStream_t s = fe->ctx->stream;
+    const int W = fe->cfg.width, Hh = fe->cfg.height;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_fwd<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_rev<WIN>), dim3(grid), dim3(64), 0, s, cv, pv, src_pts, n_ptr, W, Hh, max_count, epsilon, (const lvk_pt2f*)w_curr, w_status, fe->dev);
+    hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
+                       (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new);
+}
+
+static lvk_status track_chain(lvk_frontend* fe, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
+                              const unsigned long long* stored_desc, unsigned long long* w_desc, int is_new)
+{
+    int max_count = fe->cfg.max_iteration < 0 ? 0 : fe->cfg.max_iteration > 100 ? 100 : fe->cfg.max_iteration;
+    double epsilon = fe->cfg.track_precision < 0. ? 0. : fe->cfg.track_precision > 10. ? 10. : fe->cfg.track_precision;
+    epsilon *= epsilon;
+    PyrView pv = make_view(fe->pyr[0]), cv = make_view(fe->pyr[1]);
+    switch (fe->cfg.patch_size) {
+        case 21: launch_track_chain<21>(fe, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 15: launch_track_chain<15>(fe, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 31: launch_track_chain<31>(fe, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        default: return lvk_set_error(fe->ctx, LVK_ERR_UNSUPPORTED, "patch_size %d not instantiated (15, 21, 31)", fe->cfg.patch_size);
+    }
+    LVK_LAUNCH_CHECK(fe->ctx);
+    return LVK_OK;
+}
+
+static lvk_status commit(lvk_frontend* fe, int mode, const lvk_pt2f* src_pts, const int* n_ptr, const lvk_pt2f* w_curr, const uint8_t* w_status,
+                         const TrackSet* src, const unsigned long long* desc_src, int dst_set)
+{
+    hipLaunchKernelGGL(k_fe_ransac_commit, dim3(1), dim3(FM_THREADS), 0, fe->ctx->stream, mode, fe->cap, fe->cam, src_pts, n_ptr, w_curr, w_status,
+                       (const unsigned long long*)(src ? src->id : nullptr), (const lvk_pt2f*)(src ? src->init : nullptr),
+                       (const int*)(src ? src->life : nullptr), desc_src, fe->set[dst_set], &fe->dev->n_tracks[dst_set], fe->dev);
+    LVK_LAUNCH_CHECK(fe->ctx);
+    return LVK_OK;
+}
+
+extern "C" {
+
+void lvk_frontend_destroy(lvk_frontend* fe)
+{
+    if (!fe) return;
+    hipStreamSynchronize(fe->ctx->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (fe->pyr[i]) lvk_pyramid_destroy(fe->pyr[i]);
+        if (fe->ext[i]) hipFree(fe->ext[i]); if (fe->blur[i]) hipFree(fe->blur[i]);
+        set_free(fe->set[i]);
+    }
+    void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
+                    fe->gf_scratch, fe->gf_cands, fe->d_msg, fe->dev};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (fe->h_msg) hipHostFree(fe->h_msg);
+    if (fe->h_dev) hipHostFree(fe->h_dev);
+    delete fe;
+}
+
+lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_frontend** out)
+{
+    if (!ctx || !cfg || !out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_frontend_create: bad argument");
+    if (cfg->width < 64 || cfg->height < 64) return lvk_set_error(ctx, LVK_ERR_ARG, "image too small");
+    if (cfg->max_features_num <= 0 || cfg->max_features_num > FM_MAX_N) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "max_features_num must be in 1..%d", FM_MAX_N);
+    if (cfg->distortion_model != 0 && cfg->distortion_model != 1) return lvk_set_error(ctx, LVK_ERR_ARG, "distortion_model must be 0 (radtan) or 1 (equidistant)");
+    if (cfg->min_distance < 1 || cfg->pub_frequency <= 0) return lvk_set_error(ctx, LVK_ERR_ARG, "min_distance >= 1 and pub_frequency > 0 required");
+    lvk_frontend* fe = new (std::nothrow) lvk_frontend();
+    if (!fe) return LVK_ERR_DEVICE;
+    memset(fe, 0, sizeof *fe);
+    fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
+    const int w = cfg->width, h = cfg->height, cap = fe->cap;
+    const size_t esz = (size_t)(w + 64) * (h + 64);
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = ok && lvk_pyramid_create(ctx, w, h, cfg->patch_size, cfg->pyramid_levels, &fe->pyr[i]) == LVK_OK;
+        ok = ok && dalloc(&fe->ext[i], esz) && dalloc(&fe->blur[i], esz);
+        TrackSet& s = fe->set[i];
+        ok = ok && dalloc(&s.id, cap) && dalloc(&s.pts, cap) && dalloc(&s.ppts, cap) && dalloc(&s.init, cap) && dalloc(&s.life, cap) && dalloc(&s.desc, (size_t)cap * 4);
+    }
+    fe->gf_cand_cap = w * h;
+    size_t cand_alloc = 1; while (cand_alloc < (size_t)fe->gf_cand_cap) cand_alloc <<= 1;
+    ok = ok && dalloc(&fe->d_img, (size_t)w * h) && dalloc(&fe->w_curr, cap) && dalloc(&fe->wn_curr, cap) && dalloc(&fe->new_pts, cap) &&
+         dalloc(&fe->w_status, cap) && dalloc(&fe->wn_status, cap) && dalloc(&fe->wn_desc, (size_t)cap * 4) && dalloc(&fe->eig, (size_t)w * h) &&
+         dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->d_msg, cap) && dalloc(&fe->dev, 1);
+    ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap) == hipSuccess &&
+         hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
+    if (!ok) { lvk_frontend_destroy(fe); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_frontend_create: allocation failed"); }
+    hipMemsetAsync(fe->dev, 0, sizeof(FeDev), ctx->stream);
+    memset(&fe->cam, 0, sizeof fe->cam);
+    for (int i = 0; i < 4; ++i) { fe->cam.intr[i] = cfg->intrinsics[i]; fe->cam.dist[i] = cfg->distortion[i]; }
+    fe->cam.model = cfg->distortion_model; fe->cam.width = w; fe->cam.height = h;
+    *out = fe;
+    return LVK_OK;
+}
+
+static lvk_status fe_read_dev(lvk_frontend* fe)
+{
+    LVK_HIP(fe->ctx, hipMemcpyAsync(fe->h_dev, fe->dev, sizeof(FeDev), hipMemcpyDeviceToHost, fe->ctx->stream));
+    LVK_HIP(fe->ctx, hipStreamSynchronize(fe->ctx->stream));
+    return LVK_OK;
+}
+
+// findNewFeaturesToBeTracked (:1005-1037) + getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172)
+static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out)
+{
+    lvk_context* ctx = fe->ctx;
+    const lvk_fe_config& c = fe->cfg;
+    lvk_status st = lvk_mask_boxes(ctx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask);
+    if (st != LVK_OK) return st;
+    st = lvk_gftt_run(ctx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
+                      fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst]);
+    if (st != LVK_OK) return st;
+    const double dt_1 = fe->curr_img_time - fe->prev_img_time;
+    const int prev_is_last = fe->prev_img_time == fe->last_pub_time;
+    const double dt_2 = prev_is_last ? dt_1 : fe->prev_img_time - fe->last_pub_time;
+    hipLaunchKernelGGL(k_fe_msg, dim3((fe->cap + 63) / 64), dim3(64), 0, ctx->stream, fe->set[dst], (const int*)&fe->dev->n_tracks[dst], fe->cam, dt_1, dt_2,
+                       prev_is_last, fe->d_msg, fe->dev);
+    LVK_LAUNCH_CHECK(ctx);
+    LVK_HIP(ctx, hipMemcpyAsync(fe->h_msg, fe->d_msg, sizeof(lvk_feature_obs) * (size_t)fe->cap, hipMemcpyDeviceToHost, ctx->stream));
+    st = fe_read_dev(fe);
+    if (st != LVK_OK) return st;
+    int n = fe->h_dev->n_msg;
+    if (n > cap) n = cap;
+    if (h_out && n > 0) memcpy(h_out, fe->h_msg, sizeof(lvk_feature_obs) * (size_t)n);
+    *n_out = n;
+    fe->last_pub_time = ts; fe->pub_counter++;
+    return LVK_OK;
+}
+
+lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
+                                lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
+{
+    if (!fe || !img || !n_out || !has_msg || (n_imu > 0 && !h_imu)) return lvk_set_error(fe ? fe->ctx : nullptr, LVK_ERR_ARG, "lvk_frontend_process: bad argument");
+    lvk_context* ctx = fe->ctx;
+    const lvk_fe_config& c = fe->cfg;
+    *n_out = 0; *has_msg = 0;
+    if (!fe->b_first_img) {                                          // :134-142
+        if (n_imu > 0 && h_imu[0].t - ts <= 0.0) fe->b_first_img = true;
+        else return LVK_OK;
+    }
+    const uint8_t* d_img = img; int d_stride = stride;
+    if (!img_is_device) {
+        LVK_HIP(ctx, hipMemcpy2DAsync(fe->d_img, c.width, img, stride, c.width, c.height, hipMemcpyHostToDevice, ctx->stream));
+        d_img = fe->d_img; d_stride = c.width;
+    }
+    // createImagePyramids (:318-334) + ORBdescriptor ctor (:150)
+    lvk_status st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride);
+    if (st != LVK_OK) return st;
+    st = lvk_orb_prepare(ctx, fe->pyr[1], fe->ext[1], fe->blur[1]);
+    if (st != LVK_OK) return st;
+    fe->curr_img_time = ts;
+    const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
+    const int src = fe->cur, dst = fe->cur ^ 1;
+    bool curr_valid = false;            // curr_pts_ (set[dst]) holds this frame's tracks
+
+    if (fe->image_state == 1) {
+        // initializeFirstFrame (:337-352): goodFeaturesToTrack(max_features_num, 0.01, min_distance), no mask
+        st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig);
+        if (st == LVK_OK) st = lvk_gftt_run(ctx, fe->eig, nullptr, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
+                                            fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, nullptr);
+        if (st == LVK_OK) st = fe_read_dev(fe);
+        if (st != LVK_OK) return st;
+        fe->last_pub_time = ts;
+        if (fe->h_dev->n_new > 20) fe->image_state = 2;
+    } else {
+        HMat H;
+        st = lvk_predict_homography(h_imu, n_imu, fe->prev_img_time, ts, c.R_cam_imu, c.intrinsics, H.h);
+        if (st != LVK_OK) return lvk_set_error(ctx, st, "predict_homography failed");
+        if (fe->image_state == 2) {
+            // initializeFirstFeatures (:355-537)
+            st = track_chain(fe, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
+            if (st == LVK_OK) st = commit(fe, 2, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
+            if (st == LVK_OK) st = fe_read_dev(fe);
+            if (st != LVK_OK) return st;
+            if (!fe->h_dev->boot_ok) fe->image_state = 1;
+            else {
+                curr_valid = true;
+                if (ts - fe->last_pub_time >= pub_gate) {
+                    st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig);
+                    if (st == LVK_OK) st = fe_publish(fe, dst, ts, h_out, cap, n_out);
+                    if (st != LVK_OK) return st;
+                    *has_msg = 1;
+                }
+                fe->image_state = 3;
+            }
+        } else {
+            // trackFeatures (:540-811) then trackNewFeatures (:813-1002)
+            st = track_chain(fe, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
+            if (st == LVK_OK) st = commit(fe, 0, fe->set[src].pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &fe->set[src], fe->set[src].desc, dst);
+            if (st == LVK_OK) st = track_chain(fe, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
+            if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
+            if (st != LVK_OK) return st;
+            curr_valid = true;
+            if (ts - fe->last_pub_time >= pub_gate) {
+                st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig);
+                if (st == LVK_OK) st = fe_publish(fe, dst, ts, h_out, cap, n_out);
+                if (st != LVK_OK) return st;
+                *has_msg = 1;
+            }
+        }
+    }
+    if (!curr_valid) LVK_HIP(ctx, hipMemsetAsync(&fe->dev->n_tracks[dst], 0, sizeof(int), ctx->stream));
+    // rotation (:207-216)
+    { lvk_pyramid* p = fe->pyr[0]; fe->pyr[0] = fe->pyr[1]; fe->pyr[1] = p; }
+    { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = p; p = fe->blur[0]; fe->blur[0] = fe->blur[1]; fe->blur[1] = p; }
+    fe->cur = dst;
+    fe->prev_img_time = ts;
+    return LVK_OK;
+}
+
+lvk_status lvk_frontend_tracks(lvk_frontend* fe, uint64_t* h_ids, lvk_pt2f* h_pts, int* h_lifetime, lvk_pt2f* h_init, uint8_t* h_desc, int cap, int* n_out)
+{
+    if (!fe || !n_out) return LVK_ERR_ARG;
+    lvk_status st = fe_read_dev(fe);
+    if (st != LVK_OK) return st;
+    const TrackSet& s = fe->set[fe->cur];
+    int n = fe->h_dev->n_tracks[fe->cur];
+    if (n > cap) n = cap;
+    lvk_context* ctx = fe->ctx;
+    if (n > 0) {
+        if (h_ids) LVK_HIP(ctx, hipMemcpy(h_ids, s.id, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+        if (h_pts) LVK_HIP(ctx, hipMemcpy(h_pts, s.pts, sizeof(lvk_pt2f) * (size_t)n, hipMemcpyDeviceToHost));
+        if (h_lifetime) LVK_HIP(ctx, hipMemcpy(h_lifetime, s.life, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+        if (h_init) LVK_HIP(ctx, hipMemcpy(h_init, s.init, sizeof(lvk_pt2f) * (size_t)n, hipMemcpyDeviceToHost));
+        if (h_desc) LVK_HIP(ctx, hipMemcpy(h_desc, s.desc, (size_t)32 * n, hipMemcpyDeviceToHost));
+    }
+    *n_out = n;
+    return LVK_OK;
+}
+
+lvk_status lvk_frontend_new_pts(lvk_frontend* fe, lvk_pt2f* h_pts, int cap, int* n_out)
+{
+    if (!fe || !n_out) return LVK_ERR_ARG;
+    lvk_status st = fe_read_dev(fe);
+    if (st != LVK_OK) return st;
+    int n = fe->h_dev->n_new; if (n > cap) n = cap;
+    if (n > 0 && h_pts) LVK_HIP(fe->ctx, hipMemcpy(h_pts, fe->new_pts, sizeof(lvk_pt2f) * (size_t)n, hipMemcpyDeviceToHost));
+    *n_out = n;
+    return LVK_OK;
+}
+
+int lvk_frontend_state(const lvk_frontend* fe) { return fe ? fe->image_state : 0; }
+
+lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint64_t* iterations)
+{
+    if (!fe) return LVK_ERR_ARG;
+    lvk_status st = fe_read_dev(fe);
+    if (st != LVK_OK) return st;
+    if (point_levels) *point_levels = fe->h_dev->lk_point_levels;
+    if (iterations) *iterations = fe->h_dev->lk_iterations;
+    return LVK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// lvk_internal.h — shared internals of liblvk_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/lvk_c.h"
+
+#define LVK_MAX_LEVELS 8
+#define LVK_ORB_BORDER 32
+
+struct lvk_context {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    char err[512];
+};
+
+struct lvk_pyramid {
+    lvk_context* ctx;
+    int n_levels, pad, max_level;
+    int w[LVK_MAX_LEVELS], h[LVK_MAX_LEVELS];
+    int istride[LVK_MAX_LEVELS];   // bytes per padded image row
+    int dstride[LVK_MAX_LEVELS];   // int16 per padded derivative row
+    uint8_t* img[LVK_MAX_LEVELS];  // padded buffers
+    int16_t* der[LVK_MAX_LEVELS];
+    uint8_t* clahe_lut;            // tiles*256 scratch for the fused CLAHE path
+    int clahe_lut_cap;
+};
+
+// plain-data view of a pyramid passed to kernels by value
+struct PyrView {
+    int n_levels, pad;
+    int w[LVK_MAX_LEVELS], h[LVK_MAX_LEVELS], istride[LVK_MAX_LEVELS], dstride[LVK_MAX_LEVELS];
+    const uint8_t* img[LVK_MAX_LEVELS];   // pointer to pixel (0,0) of the level (inside the padded buffer)
+    const int16_t* der[LVK_MAX_LEVELS];   // pointer to (Ix,Iy) of pixel (0,0)
+};
+
+static inline PyrView make_view(const lvk_pyramid* p)
+{
+    PyrView v;
+    memset(&v, 0, sizeof v);
+    v.n_levels = p->n_levels; v.pad = p->pad;
+    for (int l = 0; l < p->n_levels; ++l) {
+        v.w[l] = p->w[l]; v.h[l] = p->h[l]; v.istride[l] = p->istride[l]; v.dstride[l] = p->dstride[l];
+        v.img[l] = p->img[l] + (size_t)p->pad * p->istride[l] + p->pad;
+        v.der[l] = p->der[l] + (size_t)p->pad * p->dstride[l] + 2 * p->pad;
+    }
+    return v;
+}
+
+lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...);
+
+#define LVK_HIP(ctx, call)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return lvk_set_error((ctx), LVK_ERR_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #call, \
+                                 hipGetErrorString(e_));                                      \
+    } while (0)
+
+#define LVK_LAUNCH_CHECK(ctx) LVK_HIP(ctx, hipGetLastError())
+
+// ---- device helpers shared by the kernels --------------------------------------------------
+__device__ __forceinline__ int d_reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { p = p < 0 ? -p : 2 * len - 2 - p; }
+    return p;
+}
+__device__ __forceinline__ int d_cv_round(float v) { return __float2int_rn(v); }   // half-to-even
+__device__ __forceinline__ int d_cv_floor(float v) { return (int)floorf(v); }
+__device__ __forceinline__ uint8_t d_sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// parameter block for the per-point kernels of the frame-level path (device memory, refreshed per frame)
+struct CamParams {
+    double intr[4];
+    double dist[4];
+    int model;
+    int width, height;
+};

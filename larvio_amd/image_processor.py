@@ -1,0 +1,102 @@
+"""ImageProcessor — host-side mirror of larvio::ImageProcessor over the C ABI.
+
+Same surface as the reference class (include/larvio/image_processor.h:36-68): construct with the
+configuration, ``initialize()``, then ``processImage(img, imu_buffer)`` per frame; the boolean it returns is
+the reference's ``haveFeatures`` and the feature list is the ``MonoCameraMeasurement`` it fills
+(include/larvio/feature_msg.h:15-52).  All arithmetic happens in liblvk_hip.so on the GPU.
+"""
+import ctypes as C
+import numpy as np
+from ._lib import lib, _p, Context, FeConfig, LvkError, IMU, OBS
+
+
+class MonoCameraMeasurement:
+    """feature_msg.h:47-52"""
+
+    def __init__(self, time_stamp, features):
+        self.timeStampToSec = time_stamp
+        self.features = features          # structured array, dtype OBS (id,u,v,u_init,v_init,u_vel,v_vel,u_init_vel,v_init_vel)
+
+
+class ImageProcessor:
+    FIRST_IMAGE, SECOND_IMAGE, OTHER_IMAGES = 1, 2, 3
+
+    def __init__(self, config, ctx=None):
+        """config: dict with the keys ImageProcessor::loadParameters reads (image_processor.cpp:44-113);
+        see larvio_amd.synthetic.frontend_config."""
+        self.config = dict(config)
+        self.ctx = ctx
+        self._h = None
+
+    def initialize(self):
+        if self.ctx is None:
+            self.ctx = Context()
+        c = FeConfig()
+        for k in ("width", "height", "pyramid_levels", "patch_size", "max_iteration", "track_precision",
+                  "max_features_num", "min_distance", "flag_equalize", "pub_frequency", "distortion_model"):
+            setattr(c, k, self.config[k])
+        c.intrinsics = (C.c_double * 4)(*self.config["intrinsics"])
+        c.distortion = (C.c_double * 4)(*self.config["distortion"])
+        c.R_cam_imu = (C.c_double * 9)(*np.asarray(self.config["R_cam_imu"], np.float64).reshape(9))
+        h = C.c_void_p()
+        st = lib().lvk_frontend_create(self.ctx.h, C.byref(c), C.byref(h))
+        if st != 0:
+            print("lvk_frontend_create failed:", lib().lvk_last_error(self.ctx.h).decode())
+            return False
+        self._h = h
+        self._cap = self.config["max_features_num"]
+        self._out = np.zeros(self._cap, OBS)
+        return True
+
+    def processImage(self, img, imu_msg_buffer, ts=None, device_ptr=None, stride=None):
+        """img: (H,W) uint8 array (host) — or pass device_ptr/stride for an image already in HBM.
+        imu_msg_buffer: structured array (t, gyro[3], acc[3]).  Returns (haveFeatures, MonoCameraMeasurement|None)."""
+        if self._h is None:
+            raise LvkError("ImageProcessor.initialize() has not succeeded")
+        imu = np.ascontiguousarray(imu_msg_buffer, IMU)
+        n_out, has = C.c_int(0), C.c_int(0)
+        if device_ptr is not None:
+            ptr, s, is_dev = C.c_void_p(device_ptr), stride, 1
+        else:
+            img = np.ascontiguousarray(img, np.uint8)
+            ptr, s, is_dev = _p(img), img.shape[1], 0
+        st = lib().lvk_frontend_process(self._h, ptr, s, is_dev, float(ts), _p(imu), len(imu), _p(self._out), self._cap,
+                                        C.byref(n_out), C.byref(has))
+        self.ctx.check(st)
+        if not has.value:
+            return False, None
+        return True, MonoCameraMeasurement(float(ts), self._out[:n_out.value].copy())
+
+    # ---- introspection used by the parity tests
+    def tracks(self):
+        cap = self._cap
+        ids = np.empty(cap, np.uint64); p = np.empty((cap, 2), np.float32); life = np.empty(cap, np.int32)
+        ini = np.empty((cap, 2), np.float32); desc = np.empty((cap, 32), np.uint8); n = C.c_int(0)
+        self.ctx.check(lib().lvk_frontend_tracks(self._h, _p(ids), _p(p), _p(life), _p(ini), _p(desc), cap, C.byref(n)))
+        n = n.value
+        return dict(ids=ids[:n].copy(), pts=p[:n].copy(), lifetime=life[:n].copy(), init=ini[:n].copy(), desc=desc[:n].copy())
+
+    def new_pts(self):
+        p = np.empty((self._cap, 2), np.float32); n = C.c_int(0)
+        self.ctx.check(lib().lvk_frontend_new_pts(self._h, _p(p), self._cap, C.byref(n)))
+        return p[:n.value].copy()
+
+    @property
+    def state(self):
+        return lib().lvk_frontend_state(self._h)
+
+    def lk_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(lib().lvk_frontend_lk_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().lvk_frontend_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,242 @@
+"""Seeded synthetic EuRoC-shaped input: images + IMU + ground truth.
+
+The EuRoC dataset is not available offline, so benchmarks and parity tests run on a procedural
+scene: a textured box room rendered through the pinhole+radtan (or equidistant) camera of the
+reference's config (config/euroc.yaml:15-41), seen from a smooth Lissajous trajectory with a
+static lead-in (the reference's static initializer needs ~1 s at rest, euroc.yaml:92), with a
+200 Hz IMU stream (analytic derivatives + white noise, euroc.yaml:69-72).
+Master seed 20260924.  numpy only; this is input generation, not part of the timed path.
+"""
+import numpy as np
+
+MASTER_SEED = 20260924
+
+# config/euroc.yaml:15-41 (values are data, restated)
+EUROC = dict(
+    width=752, height=480,
+    intrinsics=(458.654, 457.296, 367.215, 248.375),
+    distortion_model=0,  # radtan
+    distortion=(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05),
+    T_cam_imu=np.array([[0.014865542981794, 0.999557249008346, -0.025774436697440, 0.065222909535531],
+                        [-0.999880929698575, 0.014967213324719, 0.003756188357967, -0.020706385492719],
+                        [0.004140296794224, 0.025715529947966, 0.999660727177902, -0.008054602460030],
+                        [0, 0, 0, 1.0]]),
+)
+
+
+def frontend_config(cam=EUROC, max_features_num=200, pyramid_levels=2, patch_size=21, max_iteration=30,
+                    track_precision=0.01, min_distance=20, flag_equalize=1, pub_frequency=10):
+    """The ImageProcessor parameters (image_processor.cpp:44-113) as a plain dict."""
+    R_imu_cam = np.asarray(cam["T_cam_imu"], np.float64)[:3, :3]
+    return dict(width=cam["width"], height=cam["height"], pyramid_levels=pyramid_levels, patch_size=patch_size,
+                max_iteration=max_iteration, track_precision=track_precision, max_features_num=max_features_num,
+                min_distance=min_distance, flag_equalize=flag_equalize, pub_frequency=pub_frequency,
+                distortion_model=cam["distortion_model"], intrinsics=tuple(cam["intrinsics"]),
+                distortion=tuple(cam["distortion"]), R_cam_imu=R_imu_cam.T.copy())  # image_processor.cpp:93
+
+
+def _smoothstep(x):
+    x = np.clip(x, 0.0, 1.0)
+    return x * x * x * (x * (6 * x - 15) + 10)
+
+
+def _rot(axis, a):
+    c, s = np.cos(a), np.sin(a)
+    if axis == 0:
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == 1:
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+class Trajectory:
+    """Body (IMU) pose in a z-up world, gravity (0,0,-9.81)."""
+
+    def __init__(self, cam=EUROC, static_s=1.2, ramp_s=2.0, amp=(1.2, 1.0, 0.4), ang=(0.25, 0.12, 0.10), speed=1.0):
+        T = np.asarray(cam["T_cam_imu"], np.float64)
+        self.R_cb, self.t_cb = T[:3, :3], T[:3, 3]
+        R_wc0 = np.array([[0, 0, 1.0], [-1, 0, 0], [0, -1, 0]])
+        self.R_wb0 = R_wc0 @ self.R_cb
+        self.static_s, self.ramp_s, self.amp, self.ang, self.speed = static_s, ramp_s, amp, ang, speed
+        self.g = np.array([0, 0, -9.81])
+
+    def _env(self, t):
+        return _smoothstep((t - self.static_s) / self.ramp_s)
+
+    def p_wb(self, t):
+        e = self._env(t); s = self.speed; tt = t - self.static_s
+        return e * np.array([self.amp[0] * np.sin(0.31 * s * tt), self.amp[1] * np.sin(0.43 * s * tt + 0.7) - self.amp[1] * np.sin(0.7),
+                             self.amp[2] * np.sin(0.59 * s * tt + 1.3) - self.amp[2] * np.sin(1.3)])
+
+    def R_wb(self, t):
+        e = self._env(t); s = self.speed; tt = t - self.static_s
+        yaw = e * self.ang[0] * np.sin(0.37 * s * tt)
+        pitch = e * self.ang[1] * np.sin(0.53 * s * tt + 0.4)
+        roll = e * self.ang[2] * np.sin(0.29 * s * tt + 1.1)
+        return _rot(2, yaw) @ _rot(1, pitch) @ _rot(0, roll) @ self.R_wb0
+
+    def vel(self, t, h=1e-4):
+        return (self.p_wb(t + h) - self.p_wb(t - h)) / (2 * h)
+
+    def acc(self, t, h=1e-4):
+        return (self.p_wb(t + h) - 2 * self.p_wb(t) + self.p_wb(t - h)) / (h * h)
+
+    def omega_b(self, t, h=1e-5):
+        R0, R1, R = self.R_wb(t - h), self.R_wb(t + h), self.R_wb(t)
+        W = R.T @ (R1 - R0) / (2 * h)
+        return np.array([W[2, 1] - W[1, 2], W[0, 2] - W[2, 0], W[1, 0] - W[0, 1]]) * 0.5
+
+    def cam_pose(self, t):
+        R_wb, p = self.R_wb(t), self.p_wb(t)
+        R_wc = R_wb @ self.R_cb.T
+        p_wc = p + R_wb @ (-self.R_cb.T @ self.t_cb)
+        return R_wc, p_wc
+
+    def imu(self, t):
+        R = self.R_wb(t)
+        return self.omega_b(t), R.T @ (self.acc(t) - self.g)
+
+
+def _make_texture(rng, n=1536):
+    """Corner-rich 8-bit texture: band-limited noise + random rectangles/discs, lightly blurred."""
+    from scipy import ndimage
+    tex = np.zeros((n, n), np.float32)
+    for scale, amp in ((96, 38.0), (32, 26.0), (12, 16.0), (5, 9.0)):
+        m = n // scale + 3
+        coarse = rng.standard_normal((m, m)).astype(np.float32)
+        up = ndimage.zoom(coarse, scale, order=3)[:n, :n]
+        tex += amp * up
+    tex += 118.0
+    nshape = 900
+    cx = rng.integers(0, n, nshape); cy = rng.integers(0, n, nshape)
+    sz = rng.integers(6, 42, (nshape, 2)); val = rng.uniform(-85, 85, nshape); kind = rng.integers(0, 2, nshape)
+    yy, xx = np.mgrid[0:n, 0:n]
+    for i in range(nshape):
+        x0, x1 = max(cx[i] - sz[i, 0], 0), min(cx[i] + sz[i, 0], n)
+        y0, y1 = max(cy[i] - sz[i, 1], 0), min(cy[i] + sz[i, 1], n)
+        if kind[i] == 0:
+            tex[y0:y1, x0:x1] += val[i]
+        else:
+            sub = (xx[y0:y1, x0:x1] - cx[i]) ** 2 / max(sz[i, 0], 1) ** 2 + (yy[y0:y1, x0:x1] - cy[i]) ** 2 / max(sz[i, 1], 1) ** 2 <= 1
+            tex[y0:y1, x0:x1] += val[i] * sub
+    tex = ndimage.gaussian_filter(tex, 0.8)
+    return np.clip(tex, 4, 251).astype(np.float32)
+
+
+class Scene:
+    """Box room x,y in [-5,5], z in [-2,2.5]; one texture per face."""
+
+    def __init__(self, seed=MASTER_SEED, tex_px_per_m=150.0, tex_n=1536):
+        ss = np.random.SeedSequence(seed)
+        self.rngs = [np.random.default_rng(s) for s in ss.spawn(8)]
+        self.ppm = tex_px_per_m
+        # (normal, offset d with n.x = d, u axis, v axis)
+        self.planes = [
+            (np.array([1.0, 0, 0]), 5.0, np.array([0, 1.0, 0]), np.array([0, 0, 1.0])),
+            (np.array([-1.0, 0, 0]), 5.0, np.array([0, 1.0, 0]), np.array([0, 0, 1.0])),
+            (np.array([0, 1.0, 0]), 5.0, np.array([1.0, 0, 0]), np.array([0, 0, 1.0])),
+            (np.array([0, -1.0, 0]), 5.0, np.array([1.0, 0, 0]), np.array([0, 0, 1.0])),
+            (np.array([0, 0, 1.0]), 2.5, np.array([1.0, 0, 0]), np.array([0, 1.0, 0])),
+            (np.array([0, 0, -1.0]), 2.0, np.array([1.0, 0, 0]), np.array([0, 1.0, 0])),
+        ]
+        self.tex = [_make_texture(self.rngs[i], tex_n) for i in range(6)]
+        self.tex_n = tex_n
+        self.tex_stack = np.stack(self.tex)
+
+    def shade(self, origin, rays):
+        """rays (...,3) world directions -> intensity float32 (...)."""
+        shp = rays.shape[:-1]
+        r = rays.reshape(-1, 3)
+        N = np.stack([p[0] for p in self.planes])            # (6,3)
+        d = np.array([p[1] for p in self.planes])
+        denom = r @ N.T                                       # (n,6)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (d - N @ origin)[None, :] / denom
+        t = np.where((denom > 1e-9) & (t > 0), t, np.inf)
+        k = np.argmin(t, axis=1)
+        tk = t[np.arange(len(r)), k]
+        hit = origin + tk[:, None] * r
+        UA = np.stack([p[2] for p in self.planes])[k]; VA = np.stack([p[3] for p in self.planes])[k]
+        n = self.tex_n
+        u = np.mod((np.einsum("ij,ij->i", hit, UA) + 5.0) * self.ppm, n - 1)
+        v = np.mod((np.einsum("ij,ij->i", hit, VA) + 5.0) * self.ppm, n - 1)
+        iu = np.floor(u).astype(np.int64); iv = np.floor(v).astype(np.int64)
+        fu = (u - iu).astype(np.float32); fv = (v - iv).astype(np.float32)
+        T = self.tex_stack
+        val = (T[k, iv, iu] * (1 - fu) + T[k, iv, iu + 1] * fu) * (1 - fv) + (T[k, iv + 1, iu] * (1 - fu) + T[k, iv + 1, iu + 1] * fu) * fv
+        return val.reshape(shp)
+
+
+def _undistort_grid(cam):
+    """Normalized undistorted ray (x,y,1) for every pixel centre (vectorised fixed-point inverse)."""
+    w, h = cam["width"], cam["height"]
+    fx, fy, cx, cy = cam["intrinsics"]
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    xd, yd = (xs - cx) / fx, (ys - cy) / fy
+    d = cam["distortion"]
+    if cam["distortion_model"] == 0:
+        k1, k2, p1, p2 = d
+        x, y = xd.copy(), yd.copy()
+        for _ in range(40):
+            r2 = x * x + y * y
+            ic = 1.0 / (1 + (k2 * r2 + k1) * r2)
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x); dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x, y = (xd - dx) * ic, (yd - dy) * ic
+    else:
+        thd = np.sqrt(xd * xd + yd * yd)
+        th = thd.copy()
+        for _ in range(30):
+            t2 = th * th
+            f = th * (1 + t2 * (d[0] + t2 * (d[1] + t2 * (d[2] + t2 * d[3])))) - thd
+            fp = 1 + t2 * (3 * d[0] + t2 * (5 * d[1] + t2 * (7 * d[2] + t2 * 9 * d[3])))
+            th = th - f / fp
+        s = np.where(thd > 1e-9, np.tan(th) / np.maximum(thd, 1e-12), 1.0)
+        x, y = xd * s, yd * s
+    return np.stack([x, y, np.ones_like(x)], -1)
+
+
+class Sequence:
+    """frame(i) -> (ts, u8 image); imu_between(t0, t1) -> structured IMU samples."""
+
+    def __init__(self, cam=EUROC, seed=MASTER_SEED, img_rate=20.0, imu_rate=200.0, t0=0.0,
+                 noise_gyro=0.004, noise_acc=0.08, pixel_noise=1.5, traj=None, scene=None):
+        self.cam, self.img_rate, self.imu_rate, self.t0 = cam, img_rate, imu_rate, t0
+        self.traj = traj or Trajectory(cam)
+        self.scene = scene or Scene(seed)
+        self.rays_c = _undistort_grid(cam)
+        self.seed = seed
+        self.pixel_noise = pixel_noise
+        # discrete-time white noise: sigma_d = sigma_c * sqrt(rate)
+        self.sg, self.sa = noise_gyro * np.sqrt(imu_rate), noise_acc * np.sqrt(imu_rate)
+
+    def frame_time(self, i):
+        return self.t0 + i / self.img_rate
+
+    def frame(self, i):
+        t = self.frame_time(i)
+        R_wc, p_wc = self.traj.cam_pose(t)
+        rays_w = self.rays_c @ R_wc.T
+        img = self.scene.shade(p_wc, rays_w)
+        rng = np.random.default_rng([self.seed, 7, i])
+        img = img + rng.standard_normal(img.shape).astype(np.float32) * self.pixel_noise
+        return t, np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+    def imu_index_range(self, t_lo, t_hi):
+        """IMU sample indices k with t_lo <= t_k < t_hi, t_k = t0 + k/imu_rate - 0.5/imu_rate*0."""
+        k0 = int(np.ceil((t_lo - self.t0) * self.imu_rate - 1e-9)); k1 = int(np.ceil((t_hi - self.t0) * self.imu_rate - 1e-9))
+        return max(k0, 0), max(k1, 0)
+
+    def imu_sample(self, k):
+        t = self.t0 + k / self.imu_rate
+        w, a = self.traj.imu(t)
+        rng = np.random.default_rng([self.seed, 11, k])
+        n = rng.standard_normal(6)
+        return t, w + self.sg * n[:3], a + self.sa * n[3:]
+
+    def imu_array(self, k0, k1):
+        from numpy import zeros
+        out = zeros(max(k1 - k0, 0), dtype=[("t", np.float64), ("gyro", np.float64, 3), ("acc", np.float64, 3)])
+        for j, k in enumerate(range(k0, k1)):
+            t, w, a = self.imu_sample(k)
+            out[j] = (t, w, a)
+        return out

@@ -1,0 +1,178 @@
+/*
+ * lvo.h — CPU ORACLE for the LARVIO per-frame hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This directory is a plain-C restatement of the reference's algorithm for the path
+ * SURVEY.md §8 scopes (front-end: src/image_processor.cpp, src/ORBDescriptor.cpp;
+ * back-end update: src/larvio.cpp, include/larvio/feature.hpp).  It exists so the HIP
+ * path can be checked against something.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product (larvio_amd/, include/) never
+ * includes, links or calls anything here.
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures (SURVEY.md §4,
+ * §8c) and cannot be compiled in this environment (OpenCV, Eigen, SuiteSparse, Boost are
+ * absent).  The arithmetic of the front-end lives in OpenCV (un-vendored, unpinned:
+ * README.md:58 names 3.4.6 / 4.1.2); the functions below restate the published algorithms
+ * of those OpenCV calls ("[upstream]" in comments) and follow the reference's own call
+ * sites for parameters.  Where OpenCV's own result depends on its SIMD dispatch (float
+ * summation order in LK / boxFilter), the oracle fixes ONE order and says so.
+ *
+ * All floating-point code here must be built with -ffp-contract=off (see Makefile): the
+ * HIP kernels are built the same way so that float32 stages agree bit-for-bit.
+ */
+#ifndef LVO_H
+#define LVO_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y; } lvo_pt2f;
+
+/* include/sensors/ImuData.hpp:17-43 */
+typedef struct { double t; double gyro[3]; double acc[3]; } lvo_imu;
+
+/* include/larvio/feature_msg.h:15-44 (72 bytes) */
+typedef struct {
+    uint64_t id;
+    double u, v, u_init, v_init, u_vel, v_vel, u_init_vel, v_init_vel;
+} lvo_feature_obs;
+
+/* ------------------------------------------------------------------ image passes */
+
+/* cv::createCLAHE(clip, Size(tiles_x,tiles_y))->apply  [upstream clahe.cpp];
+ * call site image_processor.cpp:322-325 (clip 3.0, 8x8). */
+void lvo_clahe_u8(const uint8_t* src, int w, int h, int sstride,
+                  uint8_t* dst, int dstride, double clip, int tiles_x, int tiles_y);
+
+/* cv::pyrDown u8: separable [1 4 6 4 1], (s+128)>>8, BORDER_REFLECT_101,
+ * dst = ((w+1)/2,(h+1)/2)  [upstream pyramids.cpp]. */
+void lvo_pyr_down_u8(const uint8_t* src, int w, int h, int sstride,
+                     uint8_t* dst, int dstride);
+
+/* calcSharrDeriv [upstream lkpyramid.cpp]: dst interleaved int16 (Ix,Iy), dstride in int16 units. */
+void lvo_scharr_deriv(const uint8_t* src, int w, int h, int sstride,
+                      int16_t* dst, int dstride);
+
+/* One LK pyramid = what cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), max_level,
+ * withDerivatives=true, BORDER_REFLECT_101, BORDER_CONSTANT, false) returns
+ * (image_processor.cpp:329-333).  Level l image is padded by `pad`(=win) pixels of
+ * reflect-101; derivative planes are padded with zeros. */
+#define LVO_MAX_LEVELS 8
+typedef struct {
+    int n_levels;          /* number of levels actually built (max_level+1 or fewer) */
+    int pad;               /* = win */
+    int w[LVO_MAX_LEVELS], h[LVO_MAX_LEVELS];
+    int istride[LVO_MAX_LEVELS];   /* bytes per padded image row  = w+2*pad */
+    int dstride[LVO_MAX_LEVELS];   /* int16 per padded deriv row = 2*(w+2*pad) */
+    uint8_t* img[LVO_MAX_LEVELS];  /* padded buffers; pixel (x,y) at img[(y+pad)*istride + x+pad] */
+    int16_t* der[LVO_MAX_LEVELS];  /* (Ix,Iy) of (x,y) at der[(y+pad)*dstride + 2*(x+pad)] */
+} lvo_pyramid;
+
+void lvo_pyramid_build(const uint8_t* img, int w, int h, int stride, int win, int max_level,
+                       lvo_pyramid* out);
+void lvo_pyramid_free(lvo_pyramid* p);
+
+/* ORBdescriptor::initializeLayerAndPyramid, level 0 only (ORBDescriptor.cpp:418-484).
+ * `pyr` level 0 is the source (the reference passes curr_pyramid_[0], a ROI inside the
+ * 21-padded LK buffer, so copyMakeBorder without BORDER_ISOLATED sees that padding).
+ * Outputs: ext = (h+64)x(w+64) raw mosaic, blur = same with the interior w x h region
+ * replaced by GaussianBlur 7x7 sigma 2 (border stays raw). */
+#define LVO_ORB_BORDER 32
+void lvo_orb_prepare(const lvo_pyramid* pyr, uint8_t* ext, uint8_t* blur);
+
+/* cv::goodFeaturesToTrack(img, maxCorners, 0.01, min_distance, mask, 3, false) [upstream].
+ * img = level-0 of pyr.  mask may be NULL (all 255); mask stride = w.
+ * Returns number of corners written (<= cap).  max_corners <= 0 = unlimited. */
+int lvo_good_features(const lvo_pyramid* pyr, const uint8_t* mask, int max_corners,
+                      double quality, double min_distance, lvo_pt2f* out, int cap);
+/* the min-eigenvalue response map alone (w*h floats), for stage-level parity tests */
+void lvo_min_eigen_map(const lvo_pyramid* pyr, float* eig);
+
+/* ------------------------------------------------------------------ per-point stages */
+
+/* cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prev, next, status, noArray(), Size(win,win),
+ * maxLevel, TermCriteria(COUNT+EPS, max_iter, eps), OPTFLOW_USE_INITIAL_FLOW, 1e-4)
+ * [upstream lkpyramid.cpp LKTrackerInvoker]; call sites image_processor.cpp:368,405,558,618,830,870.
+ * next_pts is in/out (initial flow in, result out).  iters_out (optional, n*levels ints) =
+ * executed iterations per point and level (for the algorithmic-bytes figure). */
+void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
+                  const lvo_pt2f* prev_pts, lvo_pt2f* next_pts, uint8_t* status, int n,
+                  int max_iter, double eps, int* iters_out);
+
+/* ORBdescriptor::computeDescriptors(pts, levels=0) (ORBDescriptor.cpp:386-416): IC_Angle on
+ * ext, 256 rotated-BRIEF tests on blur.  desc = n*32 bytes; angle_out optional. */
+void lvo_orb_describe(const uint8_t* ext, const uint8_t* blur, int w, int h,
+                      const lvo_pt2f* pts, int n, uint8_t* desc, float* angle_out);
+/* ORBdescriptor::computeDescriptorDistance (ORBDescriptor.h:43-59) */
+int lvo_hamming256(const uint8_t* a, const uint8_t* b);
+/* cv::fastAtan2 [upstream mathfuncs_core] (degrees) */
+float lvo_fast_atan2(float y, float x);
+
+/* ImageProcessor::undistortPoints (image_processor.cpp:1040-1072).
+ * model 0 = radtan (cv::undistortPoints, 5 iterations), 1 = equidistant (cv::fisheye).
+ * K_new given as (fx,fy,cx,cy); rectification = identity (every call site). */
+void lvo_undistort_points(const lvo_pt2f* in, int n, const double intr[4], int model,
+                          const double dist[4], const double new_intr[4], lvo_pt2f* out);
+
+/* cv::findFundamentalMat(p1, p2, FM_RANSAC, thresh, conf, mask) [upstream fundam.cpp, ptsetreg.cpp]
+ * (image_processor.cpp:498,755,968).  Returns 1 when a mask of n bytes was written, 0 when
+ * OpenCV would leave the mask untouched (n < 7).  n==7: all ones; 8..14: LMedS; >=15: RANSAC. */
+int lvo_find_fundamental_mask(const lvo_pt2f* p1, const lvo_pt2f* p2, int n,
+                              double thresh, double conf, uint8_t* mask);
+/* the RANSAC branch alone, any n >= 8 (stage-level parity with the HIP kernel).
+ * iters_out = number of hypotheses drawn. */
+int lvo_ransac_fundamental(const lvo_pt2f* p1, const lvo_pt2f* p2, int n,
+                           double thresh, double conf, int max_iters,
+                           uint8_t* mask, int* iters_out);
+/* FMEstimatorCallback::runKernel 7-point: returns number of models (0..3), F row-major 9 each */
+int lvo_fundamental_7pt(const lvo_pt2f* m1, const lvo_pt2f* m2, double* F);
+
+/* integrateImuData + predictFeatureTracking (image_processor.cpp:222-293):
+ * mean gyro over [t_prev-0.0049, t_curr+0.0049) -> Rodrigues -> R^T ; H = K R K^-1 (float32). */
+void lvo_predict_homography(const lvo_imu* imu, int n_imu, double t_prev, double t_curr,
+                            const double R_cam_imu[9], const double intr[4], float H[9]);
+void lvo_apply_homography(const float H[9], const lvo_pt2f* in, int n, lvo_pt2f* out);
+
+/* ------------------------------------------------------------------ the front-end object */
+
+typedef struct {
+    int width, height;
+    int pyramid_levels;      /* euroc.yaml:43  (maxLevel; levels built = +1) */
+    int patch_size;          /* :44 */
+    int max_iteration;       /* :46 */
+    double track_precision;  /* :47 */
+    int max_features_num;    /* :49 */
+    int min_distance;        /* :50 */
+    int flag_equalize;       /* :51 */
+    int pub_frequency;       /* :52 */
+    int distortion_model;    /* 0 radtan, 1 equidistant */
+    double intrinsics[4];    /* fx fy cx cy */
+    double distortion[4];
+    double R_cam_imu[9];     /* row-major; = R_imu_cam^T as image_processor.cpp:93 */
+} lvo_fe_config;
+
+typedef struct lvo_frontend lvo_frontend;
+
+lvo_frontend* lvo_frontend_create(const lvo_fe_config* cfg);
+void lvo_frontend_destroy(lvo_frontend* fe);
+/* ImageProcessor::processImage (image_processor.cpp:130-219).  Returns 1 when a feature
+ * message was produced (n_out features in out), else 0. */
+int lvo_frontend_process(lvo_frontend* fe, const uint8_t* img, int stride, double ts,
+                         const lvo_imu* imu, int n_imu,
+                         lvo_feature_obs* out, int cap, int* n_out);
+/* introspection for parity tests: live tracks after the call (vectors already rotated,
+ * so these are the reference's prev_pts_/pts_ids_/pts_lifetime_/init_pts_/new_pts_) */
+int lvo_frontend_tracks(const lvo_frontend* fe, uint64_t* ids, lvo_pt2f* pts, int* lifetime,
+                        lvo_pt2f* init_pts, uint8_t* desc, int cap);
+int lvo_frontend_new_pts(const lvo_frontend* fe, lvo_pt2f* pts, int cap);
+int lvo_frontend_state(const lvo_frontend* fe);   /* 1 FIRST_IMAGE 2 SECOND_IMAGE 3 OTHER_IMAGES */
+/* cumulative LK work counters: point-levels run and iterations executed */
+void lvo_frontend_lk_stats(const lvo_frontend* fe, uint64_t* point_levels, uint64_t* iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
