@@ -17,6 +17,18 @@ lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...
     return code;
 }
 
+void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes)
+{
+    if (slot < 0 || slot >= LVK_SCRATCH_SLOTS) return nullptr;
+    if (ctx->scratch_bytes[slot] >= bytes && ctx->scratch[slot]) return ctx->scratch[slot];
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+    if (ctx->scratch[slot]) hipFree(ctx->scratch[slot]);
+    ctx->scratch[slot] = nullptr; ctx->scratch_bytes[slot] = 0;
+    if (hipMalloc(&ctx->scratch[slot], bytes) != hipSuccess) return nullptr;
+    ctx->scratch_bytes[slot] = bytes;
+    return ctx->scratch[slot];
+}
+
 // =========================================================================== CLAHE
 // one workgroup per tile: LDS histogram (one sub-histogram per wave), clip + redistribute,
 // inclusive scan -> LUT.  [cv::CLAHE CLAHE_CalcLut_Body]
@@ -416,13 +428,12 @@ lvk_status lvk_clahe_u8(lvk_context* ctx, const uint8_t* d_src, int w, int h, in
     const float lut_scale = (float)(255) / total;
     int clip = 0;
     if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
-    uint8_t* lut = nullptr;
-    LVK_HIP(ctx, hipMallocAsync((void**)&lut, (size_t)tiles_x * tiles_y * 256, ctx->stream));
+    uint8_t* lut = (uint8_t*)lvk_ctx_scratch(ctx, 0, (size_t)tiles_x * tiles_y * 256);
+    if (!lut) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
     hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, d_src, w, h, sstride, tw, th, tiles_x, clip, lut_scale, lut);
     hipLaunchKernelGGL(k_clahe_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_src, w, h, sstride, lut, tiles_x, tiles_y,
                        1.0f / tw, 1.0f / th, d_dst, dstride);
     LVK_LAUNCH_CHECK(ctx);
-    LVK_HIP(ctx, hipFreeAsync(lut, ctx->stream));
     return LVK_OK;
 }
 
@@ -574,14 +585,13 @@ extern "C" lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, 
 {
     if (!ctx || !p || !d_out || !d_n_out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_good_features: bad argument");
     const int w = p->w[0], h = p->h[0];
-    float* eig = nullptr; unsigned* scratch = nullptr; unsigned long long* cands = nullptr;
     const int cand_cap = w * h;
     size_t cand_alloc = 1; while (cand_alloc < (size_t)cand_cap) cand_alloc <<= 1;     // bitonic sort pads to a power of two in place
-    LVK_HIP(ctx, hipMallocAsync((void**)&eig, sizeof(float) * (size_t)w * h, ctx->stream));
-    LVK_HIP(ctx, hipMallocAsync((void**)&scratch, 4 * sizeof(unsigned), ctx->stream));
-    LVK_HIP(ctx, hipMallocAsync((void**)&cands, sizeof(unsigned long long) * cand_alloc, ctx->stream));
+    float* eig = (float*)lvk_ctx_scratch(ctx, 1, sizeof(float) * (size_t)w * h);
+    unsigned* scratch = (unsigned*)lvk_ctx_scratch(ctx, 2, 4 * sizeof(unsigned));
+    unsigned long long* cands = (unsigned long long*)lvk_ctx_scratch(ctx, 3, sizeof(unsigned long long) * cand_alloc);
+    if (!eig || !scratch || !cands) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
     lvk_status st = lvk_min_eigen_map(ctx, p, eig);
     if (st == LVK_OK) st = lvk_gftt_run(ctx, eig, d_mask, w, h, max_corners, quality, min_distance, scratch, cands, cand_cap, d_out, cap, d_n_out, nullptr);
-    hipFreeAsync(eig, ctx->stream); hipFreeAsync(scratch, ctx->stream); hipFreeAsync(cands, ctx->stream);
     return st;
 }

@@ -33,7 +33,8 @@ lvk_status lvk_context_create(int device, lvk_context** out)
     if (hipSetDevice(device) != hipSuccess) return LVK_ERR_DEVICE;
     lvk_context* c = new (std::nothrow) lvk_context();
     if (!c) return LVK_ERR_DEVICE;
-    c->device = device; c->err[0] = 0; c->own_stream = true;
+    memset(c, 0, sizeof *c);
+    c->device = device; c->own_stream = true;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LVK_ERR_DEVICE; }
     *out = c;
     return LVK_OK;
@@ -42,6 +43,8 @@ lvk_status lvk_context_create(int device, lvk_context** out)
 void lvk_context_destroy(lvk_context* ctx)
 {
     if (!ctx) return;
+    hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < LVK_SCRATCH_SLOTS; ++i) if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

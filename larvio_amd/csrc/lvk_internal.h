@@ -9,12 +9,18 @@
 #define LVK_MAX_LEVELS 8
 #define LVK_ORB_BORDER 32
 
+#define LVK_SCRATCH_SLOTS 4
 struct lvk_context {
     int device;
     hipStream_t stream;
     bool own_stream;
     char err[512];
+    // grow-only scratch buffers for the stage-level entry points (no stream-ordered pool: a fresh
+    // pool block handed out mid-stream was observed to corrupt an in-flight launch sequence)
+    void* scratch[LVK_SCRATCH_SLOTS];
+    size_t scratch_bytes[LVK_SCRATCH_SLOTS];
 };
+void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
 
 struct lvk_pyramid {
     lvk_context* ctx;
