@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: VIO frames/sec + p50 ms/frame on EuRoC-shaped
+synthetic input (752x480 @20 Hz, ~150 tracks, 30-clone window; BASELINE.json / SURVEY.md §8d).
+
+A "step" is one camera frame through the hot path, timed the way the reference times it
+(app/larvioMain.cpp:106-116: processImage, then processFeatures when a message was produced), with the
+frames already resident in HBM.  Each step ends with a stream synchronise (a VIO consumes frame k's
+result before frame k+1 exists), so value = K / sum(frame latencies).
+
+  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+
+N>1 at this configuration runs N independent estimators, one camera stream per GPU ("replicas only",
+DESIGN.md §multi-GPU: at 150 tracks the R-factor all-gather costs more than the whole update);
+value = frames of all ranks / max-over-ranks time, scaling "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
+
+
+def render_frames(first, count, seed_offset=0):
+    from larvio_amd import synthetic as S
+    path = "/tmp/lvk_bench_frames_%d_%d_%d.npz" % (first, count, seed_offset)
+    if os.path.exists(path):
+        z = np.load(path)
+        return z["ts"], z["img"]
+    seq = S.Sequence(seed=S.MASTER_SEED + seed_offset)
+    ts = np.empty(count); img = np.empty((count, S.EUROC["height"], S.EUROC["width"]), np.uint8)
+    for i in range(count):
+        ts[i], img[i] = seq.frame(first + i)
+    try:
+        np.savez(path, ts=ts, img=img)
+    except OSError:
+        pass
+    return ts, img
+
+
+def imu_stream(seed_offset=0):
+    from larvio_amd import synthetic as S
+    seq = S.Sequence.__new__(S.Sequence)
+    seq.traj = S.Trajectory(); seq.t0 = 0.0; seq.imu_rate = 200.0; seq.seed = S.MASTER_SEED + seed_offset
+    seq.sg = 0.004 * np.sqrt(200.0); seq.sa = 0.08 * np.sqrt(200.0)
+    return seq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--max-features", type=int, default=150, help="tracker budget (holds ~150 live tracks)")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=100)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    K, W = args.steps, args.warmup
+    first = 40                                           # t = 2.0 s: the trajectory is moving
+    ts, frames = render_frames(first, K + W, seed_offset=rank)
+    seq = imu_stream(seed_offset=rank)
+    imus = []
+    for t in ts:
+        k0, k1 = seq.imu_index_range(-1.0, t + 0.05)     # driver rule app/larvioMain.cpp:98-102
+        imus.append(seq.imu_array(max(k1 - 40, 0), k1))
+    d_frames = torch.from_numpy(frames).cuda()           # inputs resident in HBM before the timed region
+    stream = torch.cuda.current_stream()
+    ctx = larvio_amd.Context(local_rank, stream=stream.cuda_stream)
+    cfg = S.frontend_config(max_features_num=args.max_features)
+    fe = larvio_amd.ImageProcessor(cfg, ctx)
+    assert fe.initialize()
+    stride = frames.shape[2]
+    fsz = frames.shape[1] * frames.shape[2]
+
+    def step(i):
+        have, msg = fe.processImage(None, imus[i], ts=float(ts[i]), device_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
+        ctx.sync()
+        return have, msg
+
+    for i in range(W):
+        step(i)
+    pl0, it0 = fe.lk_stats()
+    fe.profile_enable((1 << 2) | (1 << 3))               # HIP events around the LK launches only (dominant kernel)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = np.empty(K); n_msgs = 0; n_tracks = []
+    t_begin = time.perf_counter()
+    for k in range(K):
+        t0 = time.perf_counter()
+        have, msg = step(W + k)
+        lat[k] = time.perf_counter() - t0
+        if have:
+            n_msgs += 1; n_tracks.append(len(msg.features))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = fe.profile_read()
+    pl1, it1 = fe.lk_stats()
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
+        win = cfg["patch_size"]
+        lk_bytes = (pl1 - pl0) * (win + 3) ** 2 + (it1 - it0) * (win + 1) ** 2
+        lk_ms = prof["lk_fwd"][0] + prof["lk_rev"][0]
+        lk_launches = prof["lk_fwd"][1] + prof["lk_rev"][1]
+        achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_launches, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        roofline = {"kernel": "k_fe_lk_fwd/k_fe_lk_rev<21>", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
+                    "launches": lk_launches}
+        # ---- CPU baseline: the oracle (a restatement, "port") on this box's host cores, 1 thread, bounded sample
+        from oracle import lvo
+        nb = min(args.cpu_baseline_frames, K + W)
+        ora = lvo.Frontend(cfg)
+        t0 = time.perf_counter()
+        for i in range(nb):
+            ora.process(frames[i], float(ts[i]), imus[i])
+        cpu_s = time.perf_counter() - t0
+        cpu_baseline = {"value": round(nb / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                        "sample": f"first {nb} frames of the same synthetic sequence, oracle front-end only, 1 thread of {os.cpu_count()}"}
+        value = world * K / elapsed
+        out = {"metric": "VIO frames/sec (752x480, ~150 tracks, 30-clone window)", "value": round(value, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
+               "p50_ms_per_frame": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_frame": round(float(np.percentile(lat, 95)) * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
+               "data": "synthetic",
+               "config": {"workload": "configs[1] shape: EuRoC-shaped synthetic 752x480 @20Hz, max_features %d, pyramid 3 levels, win 21, pub 10 Hz" % args.max_features,
+                          "stages": "front-end (processImage) only — back-end update not yet in the timed path",
+                          "mean_tracks_per_msg": round(float(np.mean(n_tracks)) if n_tracks else 0.0, 1), "messages": n_msgs,
+                          "parallelism": "replicas x%d" % world},
+               "roofline": roofline, "cpu_baseline": cpu_baseline}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,15 @@ int        lvk_frontend_state(const lvk_frontend* fe);   /* 1 FIRST_IMAGE 2 SECO
 /* cumulative LK work: point-levels processed and iterations executed (SURVEY §8d byte model) */
 lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint64_t* iterations);
 
+/* Per-stage GPU time measured with HIP events on the context's stream (the reference only times the
+ * whole call, app/larvioMain.cpp:106-109).  stage_mask bit i enables stage i; reading synchronises.
+ * Stages: 0 pyramid(+CLAHE) 1 orb_prepare 2 lk_fwd 3 lk_rev 4 orb_gate 5 ransac_commit 6 min_eigen
+ * 7 gftt_select(mask,max,candidates,select) 8 feature_msg.  LK/ORB/RANSAC stages sum old+new launches. */
+#define LVK_FE_STAGES 9
+lvk_status lvk_frontend_profile_enable(lvk_frontend* fe, unsigned stage_mask);
+lvk_status lvk_frontend_profile_read(lvk_frontend* fe, double ms_sum[LVK_FE_STAGES], uint64_t launches[LVK_FE_STAGES], int reset);
+const char* lvk_frontend_stage_name(int stage);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,8 +22,10 @@ ABI_SYMBOLS = [
     "lvk_lk_track", "lvk_orb_describe", "lvk_hamming256_rows", "lvk_undistort_points", "lvk_find_fundamental_mask",
     "lvk_ransac_fundamental", "lvk_predict_homography",
     "lvk_frontend_create", "lvk_frontend_destroy", "lvk_frontend_process", "lvk_frontend_tracks", "lvk_frontend_new_pts",
-    "lvk_frontend_state", "lvk_frontend_lk_stats",
+    "lvk_frontend_state", "lvk_frontend_lk_stats", "lvk_frontend_profile_enable", "lvk_frontend_profile_read",
+    "lvk_frontend_stage_name",
 ]
+FE_STAGES = 9
 
 
 class LvkError(RuntimeError):
@@ -73,6 +75,8 @@ def lib():
             "lvk_frontend_tracks": ([vp, vp, vp, vp, vp, vp, i, pi], i),
             "lvk_frontend_new_pts": ([vp, vp, i, pi], i), "lvk_frontend_state": ([vp], i),
             "lvk_frontend_lk_stats": ([vp, vp, vp], i),
+            "lvk_frontend_profile_enable": ([vp, C.c_uint], i), "lvk_frontend_profile_read": ([vp, vp, vp, i], i),
+            "lvk_frontend_stage_name": ([i], C.c_char_p),
         }
         for name, (args, res) in sig.items():
             f = getattr(L, name)

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <float.h>
 #include <new>
+#include <vector>
 
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
                         double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
@@ -409,7 +410,36 @@ struct lvk_frontend {
     lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;     // device + pinned host
     FeDev* dev; FeDev* h_dev;                            // device + pinned host mirror
     CamParams cam;
+    // HIP-event profiling of stages
+    unsigned prof_mask;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_free;
+    double prof_ms[LVK_FE_STAGES];
+    uint64_t prof_n[LVK_FE_STAGES];
 };
+
+static hipEvent_t prof_event(lvk_frontend* fe)
+{
+    if (!fe->ev_free.empty()) { hipEvent_t e = fe->ev_free.back(); fe->ev_free.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    lvk_frontend* fe; int stage; hipEvent_t a; bool on;
+    ProfScope(lvk_frontend* f, int s) : fe(f), stage(s), on((f->prof_mask >> s) & 1u) { if (on) { a = prof_event(fe); hipEventRecord(a, fe->ctx->stream); } }
+    ~ProfScope() { if (on) { hipEvent_t b = prof_event(fe); hipEventRecord(b, fe->ctx->stream); fe->pending.push_back({stage, a, b}); } }
+};
+static void prof_collect(lvk_frontend* fe)
+{
+    if (fe->pending.empty()) return;
+    hipStreamSynchronize(fe->ctx->stream);
+    for (auto& p : fe->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { fe->prof_ms[p.stage] += ms; fe->prof_n[p.stage] += 1; }
+        fe->ev_free.push_back(p.a); fe->ev_free.push_back(p.b);
+    }
+    fe->pending.clear();
+}
 
 template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess; }
 
@@ -427,8 +457,11 @@ static void launch_track_chain(lvk_frontend* fe, const PyrView& pv, const PyrVie
 {
     hipStream_t s = fe->ctx->stream;
     const int W = fe->cfg.width, Hh = fe->cfg.height;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_fwd<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_rev<WIN>), dim3(grid), dim3(64), 0, s, cv, pv, src_pts, n_ptr, W, Hh, max_count, epsilon, (const lvk_pt2f*)w_curr, w_status, fe->dev);
+    { ProfScope ps(fe, 2);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_fwd<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
+    { ProfScope ps(fe, 3);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_rev<WIN>), dim3(grid), dim3(64), 0, s, cv, pv, src_pts, n_ptr, W, Hh, max_count, epsilon, (const lvk_pt2f*)w_curr, w_status, fe->dev); }
+    ProfScope ps(fe, 4);
     hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
                        (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new);
 }
@@ -453,6 +486,7 @@ static lvk_status track_chain(lvk_frontend* fe, const lvk_pt2f* src_pts, const i
 static lvk_status commit(lvk_frontend* fe, int mode, const lvk_pt2f* src_pts, const int* n_ptr, const lvk_pt2f* w_curr, const uint8_t* w_status,
                          const TrackSet* src, const unsigned long long* desc_src, int dst_set)
 {
+    ProfScope ps(fe, 5);
     hipLaunchKernelGGL(k_fe_ransac_commit, dim3(1), dim3(FM_THREADS), 0, fe->ctx->stream, mode, fe->cap, fe->cam, src_pts, n_ptr, w_curr, w_status,
                        (const unsigned long long*)(src ? src->id : nullptr), (const lvk_pt2f*)(src ? src->init : nullptr),
                        (const int*)(src ? src->life : nullptr), desc_src, fe->set[dst_set], &fe->dev->n_tracks[dst_set], fe->dev);
@@ -465,7 +499,9 @@ extern "C" {
 void lvk_frontend_destroy(lvk_frontend* fe)
 {
     if (!fe) return;
+    prof_collect(fe);
     hipStreamSynchronize(fe->ctx->stream);
+    for (hipEvent_t e : fe->ev_free) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (fe->pyr[i]) lvk_pyramid_destroy(fe->pyr[i]);
         if (fe->ext[i]) hipFree(fe->ext[i]); if (fe->blur[i]) hipFree(fe->blur[i]);
@@ -486,9 +522,8 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     if (cfg->max_features_num <= 0 || cfg->max_features_num > FM_MAX_N) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "max_features_num must be in 1..%d", FM_MAX_N);
     if (cfg->distortion_model != 0 && cfg->distortion_model != 1) return lvk_set_error(ctx, LVK_ERR_ARG, "distortion_model must be 0 (radtan) or 1 (equidistant)");
     if (cfg->min_distance < 1 || cfg->pub_frequency <= 0) return lvk_set_error(ctx, LVK_ERR_ARG, "min_distance >= 1 and pub_frequency > 0 required");
-    lvk_frontend* fe = new (std::nothrow) lvk_frontend();
+    lvk_frontend* fe = new (std::nothrow) lvk_frontend();     // value-initialised: all PODs zero
     if (!fe) return LVK_ERR_DEVICE;
-    memset(fe, 0, sizeof *fe);
     fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
     const int w = cfg->width, h = cfg->height, cap = fe->cap;
     const size_t esz = (size_t)(w + 64) * (h + 64);
@@ -527,11 +562,14 @@ static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_o
 {
     lvk_context* ctx = fe->ctx;
     const lvk_fe_config& c = fe->cfg;
-    lvk_status st = lvk_mask_boxes(ctx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask);
+    lvk_status st;
+    { ProfScope ps(fe, 7);
+    st = lvk_mask_boxes(ctx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask);
     if (st != LVK_OK) return st;
     st = lvk_gftt_run(ctx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
                       fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst]);
-    if (st != LVK_OK) return st;
+    if (st != LVK_OK) return st; }
+    ProfScope ps8(fe, 8);
     const double dt_1 = fe->curr_img_time - fe->prev_img_time;
     const int prev_is_last = fe->prev_img_time == fe->last_pub_time;
     const double dt_2 = prev_is_last ? dt_1 : fe->prev_img_time - fe->last_pub_time;
@@ -566,9 +604,11 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
         d_img = fe->d_img; d_stride = c.width;
     }
     // createImagePyramids (:318-334) + ORBdescriptor ctor (:150)
-    lvk_status st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride);
+    lvk_status st;
+    { ProfScope ps(fe, 0);
+      st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride); }
     if (st != LVK_OK) return st;
-    st = lvk_orb_prepare(ctx, fe->pyr[1], fe->ext[1], fe->blur[1]);
+    { ProfScope ps(fe, 1); st = lvk_orb_prepare(ctx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
     if (st != LVK_OK) return st;
     fe->curr_img_time = ts;
     const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
@@ -577,7 +617,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
 
     if (fe->image_state == 1) {
         // initializeFirstFrame (:337-352): goodFeaturesToTrack(max_features_num, 0.01, min_distance), no mask
-        st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig);
+        { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
         if (st == LVK_OK) st = lvk_gftt_run(ctx, fe->eig, nullptr, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
                                             fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, nullptr);
         if (st == LVK_OK) st = fe_read_dev(fe);
@@ -598,7 +638,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
             else {
                 curr_valid = true;
                 if (ts - fe->last_pub_time >= pub_gate) {
-                    st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig);
+                    { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
                     if (st == LVK_OK) st = fe_publish(fe, dst, ts, h_out, cap, n_out);
                     if (st != LVK_OK) return st;
                     *has_msg = 1;
@@ -614,7 +654,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
             if (st != LVK_OK) return st;
             curr_valid = true;
             if (ts - fe->last_pub_time >= pub_gate) {
-                st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig);
+                { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
                 if (st == LVK_OK) st = fe_publish(fe, dst, ts, h_out, cap, n_out);
                 if (st != LVK_OK) return st;
                 *has_msg = 1;
@@ -627,6 +667,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
     { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = p; p = fe->blur[0]; fe->blur[0] = fe->blur[1]; fe->blur[1] = p; }
     fe->cur = dst;
     fe->prev_img_time = ts;
+    if (fe->pending.size() > 4096) prof_collect(fe);
     return LVK_OK;
 }
 
@@ -662,6 +703,30 @@ lvk_status lvk_frontend_new_pts(lvk_frontend* fe, lvk_pt2f* h_pts, int cap, int*
 }
 
 int lvk_frontend_state(const lvk_frontend* fe) { return fe ? fe->image_state : 0; }
+
+lvk_status lvk_frontend_profile_enable(lvk_frontend* fe, unsigned stage_mask)
+{
+    if (!fe) return LVK_ERR_ARG;
+    prof_collect(fe);
+    fe->prof_mask = stage_mask;
+    return LVK_OK;
+}
+lvk_status lvk_frontend_profile_read(lvk_frontend* fe, double ms_sum[LVK_FE_STAGES], uint64_t launches[LVK_FE_STAGES], int reset)
+{
+    if (!fe) return LVK_ERR_ARG;
+    prof_collect(fe);
+    for (int i = 0; i < LVK_FE_STAGES; ++i) {
+        if (ms_sum) ms_sum[i] = fe->prof_ms[i];
+        if (launches) launches[i] = fe->prof_n[i];
+        if (reset) { fe->prof_ms[i] = 0.; fe->prof_n[i] = 0; }
+    }
+    return LVK_OK;
+}
+const char* lvk_frontend_stage_name(int stage)
+{
+    static const char* names[LVK_FE_STAGES] = {"pyramid_clahe", "orb_prepare", "lk_fwd", "lk_rev", "orb_gate", "ransac_commit", "min_eigen", "gftt_select", "feature_msg"};
+    return stage >= 0 && stage < LVK_FE_STAGES ? names[stage] : "?";
+}
 
 lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint64_t* iterations)
 {

@@ -90,6 +90,16 @@ class ImageProcessor:
         self.ctx.check(lib().lvk_frontend_lk_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def profile_enable(self, stage_mask=0x1FF):
+        self.ctx.check(lib().lvk_frontend_profile_enable(self._h, stage_mask))
+
+    def profile_read(self, reset=True):
+        """-> {stage_name: (gpu_ms_sum, launches)} from HIP events on the context stream"""
+        from ._lib import FE_STAGES
+        ms = np.zeros(FE_STAGES, np.float64); n = np.zeros(FE_STAGES, np.uint64)
+        self.ctx.check(lib().lvk_frontend_profile_read(self._h, _p(ms), _p(n), 1 if reset else 0))
+        return {lib().lvk_frontend_stage_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(FE_STAGES)}
+
     def close(self):
         if self._h:
             lib().lvk_frontend_destroy(self._h)
