@@ -46,9 +46,7 @@ def render_frames(first, count, seed_offset=0):
 
 def imu_stream(seed_offset=0):
     from larvio_amd import synthetic as S
-    seq = S.Sequence.__new__(S.Sequence)
-    seq.traj = S.Trajectory(); seq.t0 = 0.0; seq.imu_rate = 200.0; seq.seed = S.MASTER_SEED + seed_offset
-    seq.sg = 0.004 * np.sqrt(200.0); seq.sa = 0.08 * np.sqrt(200.0)
+    seq = S.imu_only_sequence(S.MASTER_SEED + seed_offset)
     return seq
 
 

@@ -10,6 +10,11 @@ Master seed 20260924.  numpy only; this is input generation, not part of the tim
 import numpy as np
 
 MASTER_SEED = 20260924
+# Simulated IMU noise densities: the EuRoC sensor's (ADIS16448 datasheet class), NOT the filter's parameters —
+# config/euroc.yaml:69-72 (0.004 / 0.08) are deliberately inflated tuning values; feeding noise that large makes the
+# reference's 5%-lower-tail chi-square gate (larvio.cpp:353-357) reject most features.
+IMU_NOISE_GYRO = 1.7e-4     # rad/s/sqrt(Hz)
+IMU_NOISE_ACC = 2.0e-3      # m/s^2/sqrt(Hz)
 
 # config/euroc.yaml:15-41 (values are data, restated)
 EUROC = dict(
@@ -199,7 +204,7 @@ class Sequence:
     """frame(i) -> (ts, u8 image); imu_between(t0, t1) -> structured IMU samples."""
 
     def __init__(self, cam=EUROC, seed=MASTER_SEED, img_rate=20.0, imu_rate=200.0, t0=0.0,
-                 noise_gyro=0.004, noise_acc=0.08, pixel_noise=1.5, traj=None, scene=None):
+                 noise_gyro=IMU_NOISE_GYRO, noise_acc=IMU_NOISE_ACC, pixel_noise=1.5, traj=None, scene=None):
         self.cam, self.img_rate, self.imu_rate, self.t0 = cam, img_rate, imu_rate, t0
         self.traj = traj or Trajectory(cam)
         self.scene = scene or Scene(seed)
@@ -240,3 +245,27 @@ class Sequence:
             t, w, a = self.imu_sample(k)
             out[j] = (t, w, a)
         return out
+
+
+def backend_config(cam=EUROC, sw_size=30, max_track_len=6, max_features_in_one_grid=1, **over):
+    """The LarVio parameters (larvio.cpp:58-311) with config/euroc.yaml's values; sw_size 30 per BASELINE.json."""
+    c = dict(if_fej=1, estimate_extrin=1, estimate_td=1, if_zupt_valid=1, sw_size=sw_size, max_track_len=max_track_len,
+             least_observation_number=3, max_features_in_one_grid=max_features_in_one_grid, aug_grid_rows=5, aug_grid_cols=6,
+             pub_frequency=10, imu_rate=200, width=cam["width"], height=cam["height"], intrinsics=tuple(cam["intrinsics"]),
+             T_cam_imu=np.asarray(cam["T_cam_imu"], np.float64), td=0.0,
+             noise_gyro=0.004, noise_acc=0.08, noise_gyro_bias=2e-6, noise_acc_bias=4e-5, noise_feature=0.008,
+             initial_covariance_orientation=4e-4, initial_covariance_velocity=0.25, initial_covariance_position=1.0,
+             initial_covariance_gyro_bias=4e-4, initial_covariance_acc_bias=0.01, initial_covariance_extrin_rot=3.0462e-8,
+             initial_covariance_extrin_trans=9e-8, rotation_threshold=0.2618, translation_threshold=0.4, tracking_rate_threshold=0.5,
+             feature_translation_threshold=-1.0, zupt_max_feature_dis=2e-3, zupt_noise_v=1e-2, zupt_noise_p=1e-2, zupt_noise_q=3.4e-2,
+             static_duration=1.0)
+    c.update(over)
+    return c
+
+
+def imu_only_sequence(seed=MASTER_SEED, cam=EUROC, imu_rate=200.0, noise_scale=1.0):
+    """A Sequence without scene/ray tables: only frame times and the IMU stream (cheap to construct)."""
+    seq = Sequence.__new__(Sequence)
+    seq.cam = cam; seq.traj = Trajectory(cam); seq.t0 = 0.0; seq.img_rate = 20.0; seq.imu_rate = imu_rate; seq.seed = seed
+    seq.sg = IMU_NOISE_GYRO * np.sqrt(imu_rate) * noise_scale; seq.sa = IMU_NOISE_ACC * np.sqrt(imu_rate) * noise_scale
+    return seq

@@ -172,6 +172,82 @@ int lvo_frontend_state(const lvo_frontend* fe);   /* 1 FIRST_IMAGE 2 SECOND_IMAG
 /* cumulative LK work counters: point-levels run and iterations executed */
 void lvo_frontend_lk_stats(const lvo_frontend* fe, uint64_t* point_levels, uint64_t* iterations);
 
+/* ==================================================================== back-end (EKF update)
+ * Restates /root/reference/src/larvio.cpp (processFeatures :363-461 and everything it calls) and
+ * include/larvio/feature.hpp:252-890 for feature_idp_dim = 1, use_schmidt = 0, calib_imu = 0
+ * (the settings of config/euroc.yaml:8-10,105,108).  Dense algebra that the reference delegates to
+ * Eigen / SuiteSparse SPQR is restated with Householder QR and Cholesky: the quantities that reach
+ * the state (gate value, K r, (I-KH)P) are invariant to the choice of orthonormal basis / factorisation. */
+
+typedef struct { double R[9]; double t[3]; } lvo_pose;      /* camera-to-world rotation (row-major) + position */
+
+/* one sliding-window clone (IMUState_Aug, imu_state.h:72-117) */
+typedef struct {
+    int64_t id;
+    double time, dt;
+    double q[4], p[3], p_fej[3];          /* orientation [x y z w], position, position_FEJ */
+    double R_b2c[9], t_c_b[3];            /* extrinsics copied at augmentation time */
+    double q_cam[4], p_cam[3];            /* orientation_cam, position_cam */
+} lvo_clone;
+
+/* Feature::initializePosition family (feature.hpp:383-890): LM on (alpha,beta,rho) in the LAST pose's frame.
+ * poses/obs are the already-selected views in observation order.  use_position: start from position_in
+ * (is_initialized branch, :45-48) instead of the two-view guess.  Returns is_valid_solution. */
+int lvo_triangulate(const lvo_pose* poses, const double* obs, int n, int use_position, const double* position_in,
+                    double* position_out, double* solution_out, double* inv_depth_out, double* obs_anchor_out);
+/* Feature::checkMotion (feature.hpp:334-381) on the first and last selected poses */
+int lvo_check_motion(const lvo_pose* first, const lvo_pose* last, const double* first_obs, double translation_threshold);
+
+/* featureJacobian_msckf (larvio.cpp:924-981): H ((2M-3) x N, row-major, ld = N) and r from M observations.
+ * clone_rank[i] = rank of the observing clone in the window.  Returns the number of rows 2M-3. */
+int lvo_msckf_feature_jacobian(const lvo_clone* clones, const int* clone_rank, const double* obs, const double* obs_vel, int M,
+                               const double p_w[3], int N, int leg_dim, int if_fej, int estimate_td, double* H, double* r);
+/* gatingTest (larvio.cpp:1865-1880): gamma = r^T (H P H^T + sigma2 I)^-1 r */
+double lvo_gating_gamma(const double* H, const double* r, int k, int N, const double* P, int ldp, double sigma2);
+/* the chi-square table of larvio.cpp:353-357: boost::math::quantile(chi_squared(dof), 0.05), dof 1..99 (0 otherwise) */
+double lvo_chi2_table(int dof);
+/* QR compression (larvio.cpp:1430-1445): top `cols` rows of Q^T [H r]; H is rows x cols (ld = cols), in place. */
+void lvo_qr_compress(double* H, double* r, int rows, int cols);
+/* measurement update core (larvio.cpp:1453-1460,1578-1594): dx = K r, P <- (I-KH)P symmetrised. */
+void lvo_ekf_update(double* P, int N, int ldp, const double* H, int m, const double* r, double sigma2, double* dx);
+
+typedef struct {
+    /* config/euroc.yaml, names as larvio.cpp:58-311 reads them */
+    int if_fej, estimate_extrin, estimate_td, if_zupt_valid;
+    int sw_size, max_track_len, least_observation_number;
+    int max_features_in_one_grid, aug_grid_rows, aug_grid_cols;
+    int pub_frequency, imu_rate;
+    int width, height;
+    double intrinsics[4];
+    double T_cam_imu[16];
+    double td;
+    double noise_gyro, noise_acc, noise_gyro_bias, noise_acc_bias, noise_feature;      /* standard deviations */
+    double initial_covariance_orientation, initial_covariance_velocity, initial_covariance_position,
+           initial_covariance_gyro_bias, initial_covariance_acc_bias, initial_covariance_extrin_rot, initial_covariance_extrin_trans;
+    double rotation_threshold, translation_threshold, tracking_rate_threshold, feature_translation_threshold;
+    double zupt_max_feature_dis, zupt_noise_v, zupt_noise_p, zupt_noise_q;
+    double static_duration;
+} lvo_ekf_config;
+
+typedef struct lvo_ekf lvo_ekf;
+lvo_ekf* lvo_ekf_create(const lvo_ekf_config* cfg);
+void lvo_ekf_destroy(lvo_ekf* e);
+/* LarVio::processFeatures (larvio.cpp:363-461).  imu: the caller's buffer; *n_consumed = samples the reference would erase. */
+int lvo_ekf_process(lvo_ekf* e, double ts, const lvo_feature_obs* feats, int n_feats, const lvo_imu* imu, int n_imu, int* n_consumed);
+/* bypass the initializer (tests): IMU state at time t; gyro/acc = last IMU sample (m_gyro_old/m_acc_old) */
+void lvo_ekf_set_state(lvo_ekf* e, double t, const double q[4], const double p[3], const double v[3], const double bg[3], const double ba[3],
+                       const double gyro_old[3], const double acc_old[3]);
+int lvo_ekf_dim(const lvo_ekf* e);                                  /* N */
+int lvo_ekf_is_initialized(const lvo_ekf* e);
+/* IMU state block: t, q[4], v[3], p[3], bg[3], ba[3], R_b2c[9], t_c_b[3], td  (27 doubles after t) */
+void lvo_ekf_get_state(const lvo_ekf* e, double* out28);
+void lvo_ekf_get_cov(const lvo_ekf* e, double* P /* N*N row-major */);
+int lvo_ekf_get_clones(const lvo_ekf* e, lvo_clone* out, int cap);
+/* in-state features: ids, inverse depths, world positions */
+int lvo_ekf_get_features(const lvo_ekf* e, int64_t* ids, double* inv_depth, double* pos_w, int cap);
+/* counters: [0] hybrid updates, [1] msckf updates, [2] rows of last H_o, [3] zupt updates, [4] features gated in, [5] gated out, [6] map size */
+void lvo_ekf_counters(const lvo_ekf* e, long* out7);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: liblvk_hip.so loads, exports every symbol include/lvk_c.h declares,
+and refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "lvk_c.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lvk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from larvio_amd._lib import lib, ABI_SYMBOLS
+    L = lib()
+    declared = _header_symbols()
+    assert len(declared) >= 35
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(ABI_SYMBOLS) == declared, set(declared) ^ set(ABI_SYMBOLS)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import larvio_amd
+    with pytest.raises(larvio_amd.LvkError):
+        larvio_amd.Context()
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under larvio_amd/ or include/ may reference it"""
+    bad = []
+    for base in ("larvio_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
+                    src = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle|oracle/lvo|liblvo|lvo_[a-z]+\(", src):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_feature_obs_layout_matches_reference_message():
+    from larvio_amd._lib import OBS, IMU
+    assert OBS.itemsize == 72          # feature_msg.h:15-44: u64 id + 8 doubles
+    assert IMU.itemsize == 56          # ImuData.hpp: t + gyro[3] + acc[3]

@@ -43,9 +43,7 @@ def test_sequence_parity_euroc_shape(gpu_ctx):
     from tests.conftest import synth_frames
     from larvio_amd import synthetic as S
     frames = synth_frames(40, 36)                 # t = 2.0 .. 3.75 s: bootstrap, steady tracking, re-detection
-    seq = S.Sequence.__new__(S.Sequence)
-    seq.traj = S.Trajectory(); seq.t0 = 0.0; seq.imu_rate = 200.0; seq.seed = S.MASTER_SEED
-    seq.sg = 0.004 * np.sqrt(200.0); seq.sa = 0.08 * np.sqrt(200.0)
+    seq = S.imu_only_sequence(S.MASTER_SEED)
     cfg = S.frontend_config(max_features_num=200)
     n_msgs, ora = _run_pair(gpu_ctx, frames, seq, cfg)
     assert n_msgs >= 15
@@ -57,8 +55,6 @@ def test_sequence_parity_few_features_and_no_clahe(gpu_ctx):
     from tests.conftest import synth_frames
     from larvio_amd import synthetic as S
     frames = synth_frames(40, 26)
-    seq = S.Sequence.__new__(S.Sequence)
-    seq.traj = S.Trajectory(); seq.t0 = 0.0; seq.imu_rate = 200.0; seq.seed = S.MASTER_SEED
-    seq.sg = 0.004 * np.sqrt(200.0); seq.sa = 0.08 * np.sqrt(200.0)
+    seq = S.imu_only_sequence(S.MASTER_SEED)
     cfg = S.frontend_config(max_features_num=30, flag_equalize=0, min_distance=40)
     _run_pair(gpu_ctx, frames, seq, cfg)

@@ -202,9 +202,7 @@ def test_predict_homography_host_math():
     """host-side float32 math of the C ABI equals the oracle's (no GPU involved, but lives in the HIP library)."""
     from oracle import lvo
     from larvio_amd import ops, synthetic as S
-    seq = S.Sequence.__new__(S.Sequence)        # only the IMU model is needed
-    seq.traj = S.Trajectory(); seq.t0 = 0.0; seq.imu_rate = 200.0; seq.seed = S.MASTER_SEED
-    seq.sg = 0.004 * np.sqrt(200.0); seq.sa = 0.08 * np.sqrt(200.0)
+    seq = S.imu_only_sequence(S.MASTER_SEED)
     imu = seq.imu_array(580, 640)
     cfg = S.frontend_config()
     a = ops.predict_homography(imu, 3.0, 3.05, cfg["R_cam_imu"], cfg["intrinsics"])

@@ -1,0 +1,182 @@
+"""Pins the back-end oracle (oracle/be_*.c) against an INDEPENDENT numpy/scipy float64 implementation of the same
+algebra (SVD null space, dense QR, literal K = P H^T S^-1, (I-KH)P) and against closed-form properties.  The reference's
+own implementation (Eigen + SPQR) cannot be built here and ships no vectors: parity unpinned."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+from scipy.stats import chi2
+from oracle import lvo_be
+
+
+def _rot(rv):
+    th = np.linalg.norm(rv)
+    if th < 1e-12:
+        return np.eye(3)
+    k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _R2q(R):
+    t = np.trace(R)
+    s = np.sqrt(t + 1) * 2
+    return np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+
+
+def _scene(seed, M=6, n_clones=10):
+    rng = np.random.default_rng(seed)
+    R_b2c = _rot(rng.normal(0, 0.02, 3)) @ np.array([[0, 1.0, 0], [-1, 0, 0], [0, 0, 1]])
+    t_c_b = rng.normal(0, 0.05, 3)
+    clones = np.zeros(n_clones, lvo_be.CLONE)
+    for i in range(n_clones):
+        R = _rot(rng.normal(0, 0.08, 3)); p = np.array([0.1 * i, 0.02 * i * i * 0.1, 0.0]) + rng.normal(0, 0.02, 3)
+        clones[i]["id"] = 100 + i; clones[i]["q"] = _R2q(R); clones[i]["p"] = p; clones[i]["p_fej"] = p + rng.normal(0, 1e-3, 3)
+        clones[i]["R_b2c"] = R_b2c.ravel(); clones[i]["t_c_b"] = t_c_b
+        R_c2w = R @ R_b2c.T
+        clones[i]["q_cam"] = _R2q(R_c2w); clones[i]["p_cam"] = p + R @ t_c_b
+    # a landmark in front of the cameras (camera z = body x for this R_b2c... pick it from the first camera)
+    R0 = _rot(np.zeros(3))
+    Rc0 = np.array(clones[0]["q_cam"])
+    from_q = lambda q: np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[3] * q[2]), 2 * (q[0] * q[2] + q[3] * q[1])],
+                                 [2 * (q[0] * q[1] + q[3] * q[2]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[3] * q[0])],
+                                 [2 * (q[0] * q[2] - q[3] * q[1]), 2 * (q[1] * q[2] + q[3] * q[0]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+    p_w = clones[0]["p_cam"] + from_q(Rc0) @ np.array([0.3, -0.2, 4.0])
+    ranks = np.sort(rng.choice(n_clones, M, replace=False)).astype(np.int32)
+    obs = np.zeros((M, 2)); vel = rng.normal(0, 0.05, (M, 2))
+    for j, r in enumerate(ranks):
+        pc = from_q(clones[r]["q_cam"]).T @ (p_w - clones[r]["p_cam"])
+        obs[j] = pc[:2] / pc[2] + rng.normal(0, 0.002, 2)
+    return clones, ranks, obs, vel, p_w, from_q
+
+
+def test_chi2_table_is_the_lower_5_percent_quantile():
+    for dof in (1, 2, 9, 57, 99):
+        assert lvo_be.chi2_table(dof) == pytest.approx(chi2.ppf(0.05, dof), rel=1e-14)
+    assert lvo_be.chi2_table(0) == 0.0 and lvo_be.chi2_table(100) == 0.0       # larvio.cpp:353-357 fills dof 1..99 only
+
+
+def test_triangulation_recovers_the_landmark():
+    clones, ranks, obs, vel, p_w, from_q = _scene(1, M=7)
+    poses = np.zeros(len(ranks), lvo_be.POSE)
+    for j, r in enumerate(ranks):
+        poses[j]["R"] = from_q(clones[r]["q_cam"]).ravel(); poses[j]["t"] = clones[r]["p_cam"]
+    ok, pos, sol, idp, oa = lvo_be.triangulate(poses, obs)
+    assert ok
+    assert np.linalg.norm(pos - p_w) < 0.15                      # 2e-3 observation noise at ~4 m depth
+    # consistency of the outputs: position = R_last (alpha, beta, 1)/rho + t_last ; obs_anchor = (alpha, beta, 1)
+    Rl = poses[-1]["R"].reshape(3, 3)
+    assert np.allclose(pos, Rl @ (np.array([sol[0], sol[1], 1.0]) / sol[2]) + poses[-1]["t"], atol=1e-12)
+    assert np.allclose(oa, [sol[0], sol[1], 1.0], atol=1e-12) and idp == pytest.approx(sol[2], rel=1e-12)
+    # warm start from the solution converges to (numerically) the same point
+    ok2, pos2, *_ = lvo_be.triangulate(poses, obs, use_position=True, position_in=pos)
+    assert ok2 and np.linalg.norm(pos2 - pos) < 1e-5
+    # a landmark behind the cameras is rejected
+    ok3, *_ = lvo_be.triangulate(poses, -obs)
+    assert not ok3
+
+
+def _numeric_msckf(clones, ranks, obs, vel, p_w, from_q, N, leg=22, td=True):
+    """independent: numeric differentiation of the measurement function w.r.t. the error state (no FEJ)"""
+    M = len(ranks)
+    Hx = np.zeros((2 * M, N)); Hf = np.zeros((2 * M, 3)); r = np.zeros(2 * M)
+
+    def h(R_b2w, p_b, R_b2c, t_c_b, pw):
+        pc = R_b2c @ R_b2w.T @ (pw - (p_b + R_b2w @ t_c_b))
+        return pc[:2] / pc[2]
+    eps = 1e-6
+    for j, rk in enumerate(ranks):
+        c = clones[rk]
+        R = from_q(c["q"]); p = np.array(c["p"]); Rbc = c["R_b2c"].reshape(3, 3); tcb = np.array(c["t_c_b"])
+        z0 = h(R, p, Rbc, tcb, p_w)
+        r[2 * j:2 * j + 2] = obs[j] - z0
+        for k in range(3):
+            d = np.zeros(3); d[k] = eps
+            Hx[2 * j:2 * j + 2, leg + 6 * rk + k] = (h(_rot(d) @ R, p, Rbc, tcb, p_w) - h(_rot(-d) @ R, p, Rbc, tcb, p_w)) / (2 * eps)
+            Hx[2 * j:2 * j + 2, leg + 6 * rk + 3 + k] = (h(R, p + d, Rbc, tcb, p_w) - h(R, p - d, Rbc, tcb, p_w)) / (2 * eps)
+            # extrinsic rotation error: R_b2c <- R_b2c * R(dq)^T (larvio.cpp:1488-1490)
+            Hx[2 * j:2 * j + 2, 15 + k] = (h(R, p, Rbc @ _rot(d).T, tcb, p_w) - h(R, p, Rbc @ _rot(-d).T, tcb, p_w)) / (2 * eps)
+            Hx[2 * j:2 * j + 2, 18 + k] = (h(R, p, Rbc, tcb + d, p_w) - h(R, p, Rbc, tcb - d, p_w)) / (2 * eps)
+            Hf[2 * j:2 * j + 2, k] = (h(R, p, Rbc, tcb, p_w + d) - h(R, p, Rbc, tcb, p_w - d)) / (2 * eps)
+        if td:
+            Hx[2 * j:2 * j + 2, 21] = vel[j]
+    return Hx, Hf, r
+
+
+def test_msckf_jacobian_and_nullspace_projection_vs_numeric():
+    clones, ranks, obs, vel, p_w, from_q = _scene(2, M=6, n_clones=10)
+    N = 22 + 6 * 10 + 3
+    H, r = lvo_be.msckf_feature_jacobian(clones, ranks, obs, vel, p_w, N, if_fej=0)
+    assert H.shape == (9, N)
+    Hx, Hf, rr = _numeric_msckf(clones, ranks, obs, vel, p_w, from_q, N)
+    A = sla.null_space(Hf.T)                                   # 12 x 9, the reference's JacobiSVD full-U tail (larvio.cpp:973-976)
+    Hn, rn = A.T @ Hx, A.T @ rr
+    # both are orthonormal projections onto the same 9-dim subspace: compare basis-invariant quantities
+    assert np.allclose(H.T @ H, Hn.T @ Hn, atol=2e-6 * np.abs(Hn.T @ Hn).max())
+    assert np.allclose(H.T @ r, Hn.T @ rn, atol=2e-6 * np.abs(Hn.T @ rn).max() + 1e-9)
+    rng = np.random.default_rng(3)
+    B = rng.normal(0, 1, (N, N)); P = B @ B.T * 1e-4 + np.eye(N) * 1e-6
+    g = lvo_be.gating_gamma(H, r, P, 0.008 ** 2)
+    gn = rn @ np.linalg.solve(Hn @ P @ Hn.T + 0.008 ** 2 * np.eye(9), rn)
+    assert g == pytest.approx(gn, rel=1e-5)
+
+
+def test_qr_compress_preserves_the_information():
+    rng = np.random.default_rng(4)
+    H = rng.normal(0, 1, (300, 82)); H[:, :15] = 0.0            # the IMU columns of MSCKF rows are zero (rank deficient)
+    r = rng.normal(0, 1, 300)
+    R, rc = lvo_be.qr_compress(H, r)
+    assert R.shape == (82, 82) and rc.shape == (82,)
+    assert np.allclose(np.tril(R, -1), 0, atol=1e-12)
+    assert np.allclose(R.T @ R, H.T @ H, atol=1e-10 * 300)
+    assert np.allclose(R.T @ rc, H.T @ r, atol=1e-10 * 300)
+
+
+def test_update_matches_literal_numpy_kalman_update():
+    rng = np.random.default_rng(5)
+    N, m = 118, 140
+    B = rng.normal(0, 1, (N, N)); P = B @ B.T * 1e-3 + np.diag(rng.uniform(1e-8, 1e-2, N))
+    H = rng.normal(0, 1, (m, N)) * (rng.uniform(0, 1, (m, N)) < 0.2); H[:, :15] = 0
+    r = rng.normal(0, 0.01, m); s2 = 0.008 ** 2
+    dx, Pn = lvo_be.ekf_update(P, H, r, s2)
+    S = H @ P @ H.T + s2 * np.eye(m)
+    K = np.linalg.solve(S, H @ P).T                             # larvio.cpp:1456-1457
+    dx_np = K @ r
+    P_np = (np.eye(N) - K @ H) @ P; P_np = (P_np + P_np.T) / 2  # :1578-1594
+    assert np.allclose(dx, dx_np, rtol=1e-9, atol=1e-14)
+    assert np.abs(Pn - P_np).max() <= 1e-9 * np.abs(P_np).max()
+    assert np.array_equal(Pn, Pn.T)
+    assert np.linalg.eigvalsh(Pn).min() > -1e-12
+
+
+def test_end_to_end_vio_tracks_ground_truth():
+    """sequence level: oracle front-end + oracle back-end on the synthetic sequence, initialised from ground truth,
+    must stay within a few centimetres over 2.5 s (sanity of the whole restatement, incl. propagation and pruning)"""
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    frames = synth_frames(40, 50)
+    seq = S.imu_only_sequence()
+    fe = lvo.Frontend(S.frontend_config(max_features_num=150))
+    be = lvo_be.Ekf(S.backend_config(sw_size=20))
+    k_first = int(frames[0][0] * 200) - 2
+    imu_all = seq.imu_array(k_first, k_first + 200 * 4)
+    ptr, inited, errs = 0, False, []
+    for ts, img in frames:
+        buf = imu_all[ptr:int(np.searchsorted(imu_all["t"], ts + 0.05))]
+        have, msg = fe.process(img, ts, buf)
+        if not have:
+            continue
+        if not inited:
+            k = int(np.searchsorted(imu_all["t"], ts, side="right")) - 1
+            t0 = imu_all["t"][k]; tr = seq.traj
+            be.set_state(t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            inited = True
+        ok, used = be.process(ts, msg, buf); ptr += used
+        s = be.state()
+        errs.append(np.linalg.norm(s["p"] - seq.traj.p_wb(s["t"])))
+        P = be.cov()
+        assert np.array_equal(P, P.T) and np.linalg.eigvalsh(P).min() > -1e-9
+    c = be.counters()
+    assert c["hybrid"] >= 10 and c["msckf"] >= 1 and c["gated_in"] > 5 * c["gated_out"]
+    assert be.dim > 22 + 6 * 18
+    assert max(errs) < 0.08, max(errs)
