@@ -160,6 +160,72 @@ lvk_status lvk_frontend_profile_enable(lvk_frontend* fe, unsigned stage_mask);
 lvk_status lvk_frontend_profile_read(lvk_frontend* fe, double ms_sum[LVK_FE_STAGES], uint64_t launches[LVK_FE_STAGES], int reset);
 const char* lvk_frontend_stage_name(int stage);
 
+/* ==================================================================== back-end: EKF measurement update
+ * replaces larvio::LarVio (include/larvio/larvio.h:37-90).  feature_idp_dim = 1, use_schmidt = 0,
+ * calib_imu_instrinsic = 0 (config/euroc.yaml:8-10,105,108) are implemented; other values are refused.
+ * Matrices crossing the ABI are ROW-MAJOR doubles with an explicit leading dimension (P is symmetric, so the
+ * reference's column-major Eigen::MatrixXd state_cov maps onto it unchanged). */
+typedef struct lvk_ekf lvk_ekf;
+
+/* stage level (device pointers): the dense algebra of measurementUpdate_msckf / _hybrid (larvio.cpp:1430-1460,1578-1594) */
+/* [H | r] (rows x cols) -> top `cols` rows of Q^T [H | r], in place (SPQR replacement, larvio.cpp:1430-1445). */
+lvk_status lvk_ekf_compress_qr(lvk_context* ctx, double* d_H, int ld, int rows, int cols, double* d_r, int* rows_out);
+/* S = H P H^T + sigma2 I ; dx = P H^T S^-1 r ; P <- (I - K H) P symmetrised.  H is m x n (ldh), P n x n (ldp). */
+lvk_status lvk_ekf_update(lvk_context* ctx, double* d_P, int ldp, int n, const double* d_H, int ldh, int m,
+                          const double* d_r, double sigma2, double* d_dx);
+/* C = alpha op(A) op(B) + beta C on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) — the P H^T-class contraction */
+lvk_status lvk_dgemm(lvk_context* ctx, int transa, int transb, int M, int N, int K, double alpha, const double* d_A, int lda,
+                     const double* d_B, int ldb, double beta, double* d_C, int ldc);
+
+typedef struct {
+    /* names and meaning as LarVio::loadParameters reads them (larvio.cpp:58-311, config/euroc.yaml) */
+    int if_fej, estimate_extrin, estimate_td, if_zupt_valid;
+    int sw_size, max_track_len, least_observation_number;
+    int max_features_in_one_grid, aug_grid_rows, aug_grid_cols;
+    int pub_frequency, imu_rate;
+    int width, height;
+    double intrinsics[4];
+    double T_cam_imu[16];
+    double td;
+    double noise_gyro, noise_acc, noise_gyro_bias, noise_acc_bias, noise_feature;      /* standard deviations */
+    double initial_covariance_orientation, initial_covariance_velocity, initial_covariance_position,
+           initial_covariance_gyro_bias, initial_covariance_acc_bias, initial_covariance_extrin_rot, initial_covariance_extrin_trans;
+    double rotation_threshold, translation_threshold, tracking_rate_threshold, feature_translation_threshold;
+    double zupt_max_feature_dis, zupt_noise_v, zupt_noise_p, zupt_noise_q;
+    double static_duration;
+    int feature_idp_dim, use_schmidt, calib_imu_instrinsic;   /* must be 1, 0, 0 */
+    int max_features;                                          /* capacity hint: features per message (0 = 1024) */
+} lvk_ekf_config;
+
+/* one sliding-window clone (IMUState_Aug, include/larvio/imu_state.h:72-117) */
+typedef struct {
+    int64_t id;
+    double time, dt;
+    double q[4], p[3], p_fej[3];
+    double R_b2c[9], t_c_b[3];
+    double q_cam[4], p_cam[3];
+} lvk_clone;
+
+/* ctor + initialize() (larvio.cpp:40-360) */
+lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf** out);
+void       lvk_ekf_destroy(lvk_ekf* e);
+/* LarVio::processFeatures (larvio.cpp:363-461).  h_imu is the caller's buffer; *n_consumed = how many leading samples the
+ * reference would erase from it (larvio.cpp:511-512, StaticInitializer.cpp:146-147); *updated = the bool it returns. */
+lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* h_feats, int n_feats,
+                           const lvk_imu* h_imu, int n_imu, int* n_consumed, int* updated);
+/* bypass the initializer (tests, benchmarks): IMU state at time t, last IMU sample (m_gyro_old / m_acc_old) */
+lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const double p[3], const double v[3],
+                             const double bg[3], const double ba[3], const double gyro_old[3], const double acc_old[3]);
+int        lvk_ekf_dim(const lvk_ekf* e);                      /* state_cov.rows() */
+int        lvk_ekf_is_initialized(const lvk_ekf* e);
+/* 30 doubles: t, q[4] (x y z w), v[3], p[3], bg[3], ba[3], R_imu_cam0[9], t_cam0_imu[3], td  (getTbw/getVel, larvio.cpp:2644-2700) */
+lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* h_out30);
+lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P);           /* N*N row-major, synchronises (getPpose/getPvel read blocks of it) */
+int        lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* h_out, int cap);       /* getSwPoses */
+int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_depth, double* h_pos_w, int cap);  /* getActiveeMapPointPositions */
+/* [0] hybrid updates [1] msckf updates [2] rows of the last update [3] zupt updates [4] gated in [5] gated out [6] map size [7] triangulations */
+void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,3 +8,4 @@ context without a GPU, raises.
 """
 from ._lib import LvkError, lib, Context  # noqa: F401
 from .image_processor import ImageProcessor  # noqa: F401
+from .larvio import LarVio  # noqa: F401

@@ -24,6 +24,9 @@ ABI_SYMBOLS = [
     "lvk_frontend_create", "lvk_frontend_destroy", "lvk_frontend_process", "lvk_frontend_tracks", "lvk_frontend_new_pts",
     "lvk_frontend_state", "lvk_frontend_lk_stats", "lvk_frontend_profile_enable", "lvk_frontend_profile_read",
     "lvk_frontend_stage_name",
+    "lvk_ekf_compress_qr", "lvk_ekf_update", "lvk_dgemm", "lvk_ekf_create", "lvk_ekf_destroy", "lvk_ekf_process", "lvk_ekf_set_state",
+    "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_get_state", "lvk_ekf_get_cov", "lvk_ekf_get_clones", "lvk_ekf_get_features",
+    "lvk_ekf_counters",
 ]
 FE_STAGES = 9
 

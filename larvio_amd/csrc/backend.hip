@@ -1,0 +1,1180 @@
+// backend.hip — the frame-level back-end object of liblvk_hip.so: lvk_ekf_process replaces
+// LarVio::processFeatures (/root/reference/src/larvio.cpp:363-461).
+//
+// Split of labour.  The HOST keeps what is pointer-chasing bookkeeping in the reference — the feature map with
+// its per-clone observations (feature.hpp:34-250), the clone list, triage of lost / long / in-state features
+// (larvio.cpp:1897-2005), key-frame selection (:2259-2307) — and the 22-dimensional IMU state integration.
+// The DEVICE keeps the covariance P resident in HBM (fixed leading dimension, logical N) and does every
+// O(N^2)/O(N^3) operation and every per-feature numerical block: covariance propagation with the frame's
+// composed transition matrix, clone augmentation / deletion as index gathers, LM triangulation (one wavefront
+// per feature), Jacobians + null-space projection + chi-square gate (one workgroup per feature, compact columns),
+// row stacking, Householder compression, and the FP64-MFMA update.  feature_idp_dim = 1, use_schmidt = 0,
+// calib_imu = 0 (LEG_DIM 22) — the settings of config/euroc.yaml:8-10,105,108; anything else is refused.
+#include "lvk_internal.h"
+#include "be_dev.h"
+#include "be_host_math.h"
+#include <vector>
+#include <map>
+#include <algorithm>
+#include <new>
+#include <float.h>
+
+#define LEG 22
+#define GRAV 9.81
+
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; };
+lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
+lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
+lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq);
+lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const double* d_J, int fc);
+lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, int nn, const double* H1, int ldh, const double* H2, const double* r1,
+                                   const double* dx, double sigma2, double* tmp, double* dx_new);
+lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out);
+lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
+                                   const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out);
+lvk_status lvk_launch_stack_rows(lvk_context* ctx, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
+lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
+double lvk_chi2_005(int dof);
+
+// ------------------------------------------------------------------------- host records
+struct Obs { long long sid; double z[2], zv[2]; };
+struct Feature {
+    long long id = 0;
+    std::vector<Obs> obs;                  // ascending state id (std::map in the reference)
+    double position[3] = {0, 0, 0}, position_fej[3] = {0, 0, 0};
+    bool is_initialized = false;
+    long long id_anchor = -1;
+    double inv_depth = 0, obs_anchor[3] = {0, 0, 0};
+    bool in_state = false, ekf_feature = false;
+    int total_obs = 0;
+    int find(long long sid) const { for (size_t i = 0; i < obs.size(); ++i) if (obs[i].sid == sid) return (int)i; return -1; }
+    void set(long long sid, double u, double v, double uv, double vv)
+    {
+        int i = find(sid);
+        if (i < 0) {
+            Obs o; o.sid = sid;
+            auto it = obs.begin(); while (it != obs.end() && it->sid < sid) ++it;
+            it = obs.insert(it, o); i = (int)(it - obs.begin());
+        }
+        obs[i].z[0] = u; obs[i].z[1] = v; obs[i].zv[0] = uv; obs[i].zv[1] = vv;
+    }
+    void erase(long long sid) { int i = find(sid); if (i >= 0) obs.erase(obs.begin() + i); }
+};
+struct Clone {
+    long long id; double time, dt; double q[4], p[3], p_fej[3], R_b2c[9], t_c_b[3], q_cam[4], p_cam[3];
+};
+struct ImuS { double t; double q[4], p[3], v[3], bg[3], ba[3]; };
+
+struct lvk_ekf {
+    lvk_context* ctx;
+    lvk_ekf_config cfg;
+    // state_server
+    long long imu_id = 0; double imu_dt = 0;
+    ImuS s, s_old, s_fej_now, s_fej_old;
+    double R_b2c[9], t_c_b[3], td = 0;
+    std::vector<Clone> clones;
+    std::vector<long long> feature_states;
+    std::map<long long, Feature> map;                  // map_server (ascending id)
+    int N = LEG;
+    long long next_state_id = 0;
+    bool is_gravity_set = false, b_first_features = false, if_fej = false, if_zupt = false;
+    double m_gyro_old[3], m_acc_old[3];
+    double take_off_stamp = 0, last_update_time = 0, last_zupt_time = 0, tracking_rate = 0;
+    double sigma2, zupt_v2, zupt_p2, zupt_q2, imu_img_time_th, Qc[12];
+    double x_min, y_min, grid_w, grid_h;
+    std::vector<int> grid_count;
+    std::vector<double> coarse_dis;
+    int static_counter = 0, static_num = 0; double lower_time_bound = 0;
+    std::map<long long, std::pair<double, double>> init_features;
+    long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // per-frame composed transition (processModel): Phi_tot, Q_tot
+    double Phi_tot[LEG * LEG], Q_tot[LEG * LEG]; bool have_prop = false;
+    // device
+    int ld = 0, nmax = 0, rows_cap = 0, feat_cap = 0, obs_cap = 0;
+    double* dP[2] = {nullptr, nullptr}; int cur = 0;
+    int* d_idx = nullptr; double *d_phiq = nullptr, *d_J = nullptr, *d_dx = nullptr, *d_tmp = nullptr;
+    TriJob* d_tri = nullptr; TriResult* d_triout = nullptr; FeatJob* d_fj = nullptr; FeatResult* d_fout = nullptr;
+    int* d_rank = nullptr; double *d_z = nullptr, *d_zv = nullptr; CamPose* d_cams = nullptr; CloneDev* d_clones = nullptr;
+    double* d_staging = nullptr; size_t staging_cap = 0; int* d_ccols = nullptr; size_t ccols_cap = 0; StackRow* d_map = nullptr;
+    double *d_H = nullptr, *d_r = nullptr, *d_H1 = nullptr, *d_H2 = nullptr, *d_r1 = nullptr;
+    UpdateWs ws;
+    // pinned host arenas
+    char* h_up = nullptr; size_t up_cap = 0, up_off = 0;
+    char* h_down = nullptr; size_t down_cap = 0;
+    // timing of GPU stages via events is done by the caller (bench) around lvk_ekf_process
+};
+
+// ------------------------------------------------------------------------- small helpers
+static int clone_rank(const lvk_ekf* e, long long id) { for (size_t i = 0; i < e->clones.size(); ++i) if (e->clones[i].id == id) return (int)i; return -1; }
+static int fs_rank(const lvk_ekf* e, long long id) { for (size_t i = 0; i < e->feature_states.size(); ++i) if (e->feature_states[i] == id) return (int)i; return -1; }
+static void clone_refresh_cam(const lvk_ekf* e, Clone* c)
+{   // larvio.cpp:1529-1541
+    double R_c2b[9], R_b2w[9], R_c2w[9], t[3];
+    m3_t(e->R_b2c, R_c2b); quat_to_rot(c->q, R_b2w); m3_mul(R_b2w, R_c2b, R_c2w);
+    rot_to_quat(R_c2w, c->q_cam);
+    m3_v(R_b2w, e->t_c_b, t);
+    for (int i = 0; i < 3; ++i) c->p_cam[i] = c->p[i] + t[i];
+}
+template <typename T> static T* up_alloc(lvk_ekf* e, size_t n)
+{   // bump allocation in the pinned upload arena (reset once per frame; copies are stream-ordered)
+    size_t bytes = (sizeof(T) * n + 63) & ~(size_t)63;
+    if (e->up_off + bytes > e->up_cap) return nullptr;
+    T* p = (T*)(e->h_up + e->up_off); e->up_off += bytes; return p;
+}
+#define EKF_HIP(call) LVK_HIP(e->ctx, call)
+template <typename T> static lvk_status h2d(lvk_ekf* e, T* dst, const T* src, size_t n)
+{
+    if (n == 0) return LVK_OK;
+    EKF_HIP(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyHostToDevice, e->ctx->stream));
+    return LVK_OK;
+}
+static lvk_status d2h_sync(lvk_ekf* e, void* dst, const void* src, size_t bytes)
+{
+    if (bytes) EKF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->ctx->stream));
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    return LVK_OK;
+}
+// P <- P[idx, idx] (ping-pong)
+static lvk_status cov_gather(lvk_ekf* e, const std::vector<int>& idx)
+{
+    int* h = up_alloc<int>(e, idx.size());
+    if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    memcpy(h, idx.data(), sizeof(int) * idx.size());
+    lvk_status st = h2d(e, e->d_idx, h, idx.size());
+    if (st != LVK_OK) return st;
+    st = lvk_cov_gather(e->ctx, e->dP[e->cur], e->ld, e->dP[e->cur ^ 1], e->ld, e->d_idx, (int)idx.size());
+    if (st != LVK_OK) return st;
+    e->cur ^= 1; e->N = (int)idx.size();
+    return LVK_OK;
+}
+static lvk_status cov_delete(lvk_ekf* e, int start, int len)
+{
+    std::vector<int> idx; idx.reserve(e->N);
+    for (int i = 0; i < e->N; ++i) if (i < start || i >= start + len) idx.push_back(i);
+    return cov_gather(e, idx);
+}
+
+// ------------------------------------------------------------------------- propagation (host state, composed Phi for the device)
+static void predict_new_state(lvk_ekf* e, double dt, const double* gyro, const double* acc)
+{   // larvio.cpp:581-649
+    const double gn = v3_norm(gyro);
+    double Om[16] = {0}, S[9]; skew3(gyro, S);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Om[i * 4 + j] = -S[i * 3 + j]; Om[i * 4 + 3] = gyro[i]; Om[12 + i] = -gyro[i]; }
+    e->s_old = e->s;
+    double* q = e->s.q; double* v = e->s.v; double* p = e->s.p;
+    double dq[4], dq2[4];
+    for (int half = 0; half < 2; ++half) {
+        double* o = half ? dq2 : dq;
+        const double ang = half ? gn * dt * 0.25 : gn * dt * 0.5;
+        double M[16];
+        if (gn > 1e-5) { const double c = cos(ang), s = 1 / gn * sin(ang); for (int i = 0; i < 16; ++i) M[i] = c * ((i % 5 == 0) ? 1.0 : 0.0) + s * Om[i]; }
+        else { const double f = half ? 0.25 * dt : 0.5 * dt, c = cos(ang); for (int i = 0; i < 16; ++i) M[i] = (((i % 5 == 0) ? 1.0 : 0.0) + f * Om[i]) * c; }
+        for (int i = 0; i < 4; ++i) { double a = 0; for (int k = 0; k < 4; ++k) a += M[i * 4 + k] * q[k]; o[i] = a; }
+    }
+    double Rdt[9], Rdt2[9], R0[9];
+    quat_to_rot(dq, Rdt); quat_to_rot(dq2, Rdt2); quat_to_rot(q, R0);
+    const double g[3] = {0, 0, -GRAV};
+    double k1v[3], k2v[3], k3v[3], k4v[3], k1p[3], k2p[3], k3p[3], k4p[3], t1[3], t2[3], k1_v[3], k2_v[3], k3_v[3];
+    m3_v(R0, acc, t1); for (int i = 0; i < 3; ++i) { k1v[i] = t1[i] + g[i]; k1p[i] = v[i]; k1_v[i] = v[i] + k1v[i] * dt / 2; }
+    m3_v(Rdt2, acc, t2); for (int i = 0; i < 3; ++i) { k2v[i] = t2[i] + g[i]; k2p[i] = k1_v[i]; k2_v[i] = v[i] + k2v[i] * dt / 2; }
+    for (int i = 0; i < 3; ++i) { k3v[i] = t2[i] + g[i]; k3p[i] = k2_v[i]; k3_v[i] = v[i] + k3v[i] * dt; }
+    m3_v(Rdt, acc, t1); for (int i = 0; i < 3; ++i) { k4v[i] = t1[i] + g[i]; k4p[i] = k3_v[i]; }
+    const double n = sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+    for (int i = 0; i < 4; ++i) q[i] = dq[i] / n;
+    for (int i = 0; i < 3; ++i) {
+        double nv = v[i] + dt / 6 * (k1v[i] + 2 * k2v[i] + 2 * k3v[i] + k4v[i]);
+        double np = p[i] + dt / 6 * (k1p[i] + 2 * k2p[i] + 2 * k3p[i] + k4p[i]);
+        v[i] = nv; p[i] = np;
+    }
+    e->s_fej_old = e->s_fej_now; e->s_fej_now = e->s;
+}
+
+static void cal_phi(const lvk_ekf* e, double* Phi, double dt, const double* gyro, const double* gyro_old)
+{   // larvio.cpp:3475-3530 with Ma = Tg = I, As = 0 (calib_imu = 0)
+    double cr[3] = {gyro_old[1] * gyro[2] - gyro_old[2] * gyro[1], gyro_old[2] * gyro[0] - gyro_old[0] * gyro[2], gyro_old[0] * gyro[1] - gyro_old[1] * gyro[0]};
+    double aa[3]; for (int i = 0; i < 3; ++i) aa[i] = dt * (gyro_old[i] + gyro[i]) / 2 + dt * dt * cr[i] / 12;
+    double Ah[9]; skew3(aa, Ah);
+    double C[9]; quat_to_rot(e->s_old.q, C);
+    for (int i = 0; i < LEG * LEG; ++i) Phi[i] = (i % (LEG + 1) == 0) ? 1.0 : 0.0;
+    const ImuS* so = e->if_fej ? &e->s_fej_old : &e->s_old;
+    const ImuS* sn = e->if_fej ? &e->s_fej_now : &e->s;
+    const double *vk = so->v, *pk = so->p, *vk1 = sn->v, *pk1 = sn->p;
+    const double g[3] = {0, 0, -GRAV};
+    double I2A[9]; for (int i = 0; i < 9; ++i) I2A[i] = 2 * ((i % 4 == 0) ? 1.0 : 0.0) + Ah[i];
+    double CI2A[9]; m3_mul(C, I2A, CI2A);
+#define BLK(r, c, M, sc) for (int i_ = 0; i_ < 3; ++i_) for (int j_ = 0; j_ < 3; ++j_) Phi[((r) + i_) * LEG + (c) + j_] = (sc) * (M)[i_ * 3 + j_]
+    { double M[9]; for (int i = 0; i < 9; ++i) M[i] = -0.5 * CI2A[i] * dt; BLK(0, 9, M, 1.0); }
+    { double Z[9] = {0}; BLK(0, 12, Z, 1.0); }
+    { double a[3], S[9]; for (int i = 0; i < 3; ++i) a[i] = vk1[i] - vk[i] - g[i] * dt; skew3(a, S); BLK(3, 0, S, -1.0); }
+    { double a[3], b[3], S1[9], S2[9], T1[9], T2[9], T3[9], M[9];
+      for (int i = 0; i < 3; ++i) { a[i] = -pk1[i] + pk[i] + vk1[i] * dt - 0.5 * g[i] * dt * dt; b[i] = -0.5 * pk1[i] + 0.5 * pk[i] + 0.5 * vk1[i] * dt - g[i] * dt * dt / 6; }
+      skew3(a, S1); skew3(b, S2); m3_mul(S1, C, T1); m3_mul(S2, C, T2); m3_mul(T2, Ah, T3);
+      for (int i = 0; i < 9; ++i) M[i] = T1[i] + T3[i];
+      BLK(3, 9, M, 1.0); }
+    { double M[9]; for (int i = 0; i < 9; ++i) M[i] = -0.5 * CI2A[i] * dt - 0.0; BLK(3, 12, M, 1.0); }
+    { double a[3], S[9]; for (int i = 0; i < 3; ++i) a[i] = pk1[i] - pk[i] - vk[i] * dt - 0.5 * g[i] * dt * dt; skew3(a, S); BLK(6, 0, S, -1.0); }
+    { double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; BLK(6, 3, I, dt); }
+    { double Sg[9], T1[9], a[3], S2[9], T2[9], T3[9], M[9];
+      skew3(g, Sg); m3_mul(Sg, C, T1);
+      for (int i = 0; i < 3; ++i) a[i] = pk1[i] - pk[i] - g[i] * dt * dt / 6;
+      skew3(a, S2); m3_mul(S2, C, T2); m3_mul(T2, Ah, T3);
+      for (int i = 0; i < 9; ++i) M[i] = -dt * dt * dt * T1[i] / 6 + dt * T3[i] / 4;
+      BLK(6, 9, M, 1.0); }
+    { double I3A[9], T[9], M[9]; for (int i = 0; i < 9; ++i) I3A[i] = 3 * ((i % 4 == 0) ? 1.0 : 0.0) + Ah[i];
+      m3_mul(C, I3A, T); for (int i = 0; i < 9; ++i) M[i] = -T[i] * dt * dt / 6; BLK(6, 12, M, 1.0); }
+#undef BLK
+}
+
+static void process_model(lvk_ekf* e, double time, const double* m_gyro, const double* m_acc)
+{   // larvio.cpp:520-578.  The covariance part is COMPOSED over the frame's IMU samples:
+    //   Phi_tot <- Phi Phi_tot ;  Q_tot <- Phi Q_tot Phi^T + Q     (then applied once on the device)
+    double f[3], w[3], w_old[3];
+    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; w[i] = m_gyro[i] - e->s.bg[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; }
+    const double dtime = time - e->s.t;
+    predict_new_state(e, dtime, w, f);
+    double Phi[LEG * LEG]; cal_phi(e, Phi, dtime, w, w_old);
+    double C[9]; quat_to_rot(e->s_old.q, C);
+    double G[LEG * 12]; memset(G, 0, sizeof G);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { G[i * 12 + j] = -C[i * 3 + j]; G[(3 + i) * 12 + 3 + j] = -C[i * 3 + j]; }
+    for (int i = 0; i < 3; ++i) { G[(9 + i) * 12 + 6 + i] = 1.0; G[(12 + i) * 12 + 9 + i] = 1.0; }
+    double PG[LEG * 12], Q[LEG * LEG];
+    for (int i = 0; i < LEG; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
+    for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < 12; ++k) s += PG[i * 12 + k] * e->Qc[k] * PG[j * 12 + k]; Q[i * LEG + j] = s * dtime; }
+    if (!e->have_prop) { memcpy(e->Phi_tot, Phi, sizeof Phi); memcpy(e->Q_tot, Q, sizeof Q); e->have_prop = true; }
+    else {
+        double T[LEG * LEG], U[LEG * LEG];
+        for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * e->Phi_tot[k * LEG + j]; T[i * LEG + j] = s; }
+        memcpy(e->Phi_tot, T, sizeof T);
+        for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * e->Q_tot[k * LEG + j]; T[i * LEG + j] = s; }
+        for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += T[i * LEG + k] * Phi[j * LEG + k]; U[i * LEG + j] = s + Q[i * LEG + j]; }
+        memcpy(e->Q_tot, U, sizeof U);
+    }
+    e->s.t = time; e->s_fej_now.t = time;
+}
+
+static lvk_status apply_propagation(lvk_ekf* e)
+{
+    if (!e->have_prop) return LVK_OK;
+    double* h = up_alloc<double>(e, 2 * LEG * LEG);
+    if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    memcpy(h, e->Phi_tot, sizeof e->Phi_tot); memcpy(h + LEG * LEG, e->Q_tot, sizeof e->Q_tot);
+    lvk_status st = h2d(e, e->d_phiq, h, (size_t)2 * LEG * LEG);
+    if (st != LVK_OK) return st;
+    e->have_prop = false;
+    return lvk_cov_propagate(e->ctx, e->dP[e->cur], e->ld, e->N, LEG, e->d_phiq);
+}
+
+static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
+{   // larvio.cpp:464-517
+    int used = 0; double dt = 0.0;
+    for (int i = 0; i < n_imu; ++i) {
+        const double imu_time = imu[i].t;
+        if (imu_time <= e->s.t) { ++used; continue; }
+        if (imu_time - time_bound > e->imu_img_time_th) break;
+        dt = imu_time - time_bound;
+        process_model(e, imu_time, imu[i].gyro, imu[i].acc);
+        ++used;
+        memcpy(e->m_gyro_old, imu[i].gyro, 24); memcpy(e->m_acc_old, imu[i].acc, 24);
+    }
+    e->imu_id = e->next_state_id++;
+    e->imu_dt = dt;
+    return used;
+}
+
+static lvk_status state_augmentation(lvk_ekf* e)
+{   // larvio.cpp:720-801; the covariance part is an index gather (rows/cols {0,1,2,6,7,8} duplicated before the feature block)
+    Clone c; memset(&c, 0, sizeof c);
+    c.id = e->imu_id; c.time = e->s.t; c.dt = e->imu_dt;
+    memcpy(c.q, e->s.q, 32); memcpy(c.p, e->s.p, 24); memcpy(c.p_fej, e->s_fej_now.p, 24);
+    memcpy(c.R_b2c, e->R_b2c, 72); memcpy(c.t_c_b, e->t_c_b, 24);
+    {
+        double R_b2w[9], R_w2b[9], R_w2c[9], R_c2w[9], t[3];
+        quat_to_rot(c.q, R_b2w); m3_t(R_b2w, R_w2b); m3_mul(e->R_b2c, R_w2b, R_w2c); m3_t(R_w2c, R_c2w);
+        rot_to_quat(R_c2w, c.q_cam);
+        m3_v(R_b2w, e->t_c_b, t);
+        for (int i = 0; i < 3; ++i) c.p_cam[i] = e->s.p[i] + t[i];
+    }
+    const int pose_rows = LEG + 6 * (int)e->clones.size();
+    e->clones.push_back(c);
+    if (e->N + 6 > e->nmax) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "state dimension %d exceeds capacity %d", e->N + 6, e->nmax);
+    static const int sel[6] = {0, 1, 2, 6, 7, 8};
+    std::vector<int> idx; idx.reserve(e->N + 6);
+    for (int i = 0; i < pose_rows; ++i) idx.push_back(i);
+    for (int i = 0; i < 6; ++i) idx.push_back(sel[i]);
+    for (int i = pose_rows; i < e->N; ++i) idx.push_back(i);
+    return cov_gather(e, idx);
+}
+
+static void add_observations(lvk_ekf* e, const lvk_feature_obs* f, int n)
+{   // larvio.cpp:804-856
+    const long long sid = e->imu_id;
+    const int curr_num = (int)e->map.size();
+    int tracked = 0;
+    const double dt = e->imu_dt;
+    const int prev_rank = clone_rank(e, sid - 1);
+    for (int i = 0; i < n; ++i) {
+        const long long id = (long long)f[i].id;
+        auto it = e->map.find(id);
+        if (it == e->map.end()) {
+            Feature& ft = e->map[id]; ft.id = id;
+            ft.set(sid, f[i].u + f[i].u_vel * dt, f[i].v + f[i].v_vel * dt, f[i].u_vel, f[i].v_vel);
+            ft.total_obs++;
+            if (!(f[i].u_init == -1 && f[i].v_init == -1) && prev_rank >= 0) {
+                const double dt_ = e->clones[prev_rank].dt;
+                ft.set(sid - 1, f[i].u_init + f[i].u_init_vel * dt_, f[i].v_init + f[i].v_init_vel * dt_, f[i].u_init_vel, f[i].v_init_vel);
+                ft.total_obs++;
+            }
+        } else {
+            Feature& ft = it->second;
+            ft.set(sid, f[i].u + f[i].u_vel * dt, f[i].v + f[i].v_vel * dt, f[i].u_vel, f[i].v_vel);
+            ft.total_obs++;
+            ++tracked;
+            int pi;
+            if (e->cfg.if_zupt_valid && (pi = ft.find(sid - 1)) >= 0) {
+                double dx = f[i].u - ft.obs[pi].z[0], dy = f[i].v - ft.obs[pi].z[1];
+                e->coarse_dis.push_back(sqrt(dx * dx + dy * dy));
+            }
+        }
+    }
+    e->tracking_rate = (double)tracked / (double)curr_num;
+}
+
+// ------------------------------------------------------------------------- state injection (larvio.cpp:1476-1575 etc.)
+static void inject(lvk_ekf* e, const double* dx)
+{
+    double dq[4], q[4];
+    small_angle_quat(dx, dq); quat_mul(dq, e->s.q, q); memcpy(e->s.q, q, 32);
+    for (int i = 0; i < 3; ++i) { e->s.v[i] += dx[3 + i]; e->s.p[i] += dx[6 + i]; e->s.bg[i] += dx[9 + i]; e->s.ba[i] += dx[12 + i]; }
+    double dqe[4], Re[9], Ret[9], Rn[9];
+    small_angle_quat(dx + 15, dqe); quat_to_rot(dqe, Re); m3_t(Re, Ret); m3_mul(e->R_b2c, Ret, Rn); memcpy(e->R_b2c, Rn, 72);
+    for (int i = 0; i < 3; ++i) e->t_c_b[i] += dx[18 + i];
+    e->td += dx[21];
+    for (size_t c = 0; c < e->clones.size(); ++c) {
+        Clone* cl = &e->clones[c];
+        const double* d = dx + LEG + 6 * c;
+        double dqc[4], qc[4];
+        small_angle_quat(d, dqc); quat_mul(dqc, cl->q, qc); memcpy(cl->q, qc, 32);
+        for (int i = 0; i < 3; ++i) cl->p[i] += d[3 + i];
+        clone_refresh_cam(e, cl);
+    }
+    const int base = LEG + 6 * (int)e->clones.size();
+    for (size_t i = 0; i < e->feature_states.size(); ++i) {
+        Feature& f = e->map[e->feature_states[i]];
+        const int ar = clone_rank(e, f.id_anchor);
+        if (ar < 0) continue;
+        const Clone* a = &e->clones[ar];
+        double R_c2w[9]; quat_to_rot(a->q_cam, R_c2w);
+        f.inv_depth += dx[base + i];
+        double pc[3] = {f.obs_anchor[0] / f.inv_depth, f.obs_anchor[1] / f.inv_depth, 1 / f.inv_depth}, pw[3];
+        m3_v(R_c2w, pc, pw);
+        for (int k = 0; k < 3; ++k) f.position[k] = pw[k] + a->p_cam[k];
+    }
+}
+
+// ------------------------------------------------------------------------- device job batches
+struct TriReq { Feature* f; int mode; std::vector<int> ranks; std::vector<double> z; std::vector<long long> ids; bool use_pos; };
+struct TriAns { bool ok; double position[3], inv_depth, obs_anchor[3]; long long id_anchor; };
+
+static lvk_status upload_clones(lvk_ekf* e)
+{
+    const size_t n = e->clones.size();
+    CamPose* hc = up_alloc<CamPose>(e, n); CloneDev* hd = up_alloc<CloneDev>(e, n);
+    if (!hc || !hd) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    for (size_t i = 0; i < n; ++i) {
+        const Clone& c = e->clones[i];
+        quat_to_rot(c.q_cam, hc[i].R); memcpy(hc[i].t, c.p_cam, 24);
+        memcpy(hd[i].q, c.q, 32); memcpy(hd[i].p, c.p, 24); memcpy(hd[i].p_fej, c.p_fej, 24); memcpy(hd[i].R_b2c, c.R_b2c, 72); memcpy(hd[i].t_c_b, c.t_c_b, 24);
+    }
+    lvk_status st = h2d(e, e->d_cams, hc, n);
+    if (st == LVK_OK) st = h2d(e, e->d_clones, hd, n);
+    return st;
+}
+
+// mode 0 initializePosition(curr_id), 1 initializePosition_AssignAnchor, 2 initializeInvParamPosition(curr_id) (feature.hpp:383-890)
+static void make_tri_req(lvk_ekf* e, Feature* f, int mode, TriReq* rq)
+{
+    rq->f = f; rq->mode = mode; rq->ranks.clear(); rq->z.clear(); rq->ids.clear();
+    for (const Obs& o : f->obs) {
+        int r = clone_rank(e, o.sid);
+        if (r < 0) continue;
+        if (mode != 1 && o.sid == e->imu_id) continue;
+        rq->ranks.push_back(r); rq->z.push_back(o.z[0]); rq->z.push_back(o.z[1]); rq->ids.push_back(o.sid);
+    }
+    rq->use_pos = (mode != 2) && f->is_initialized;
+}
+static void apply_tri(Feature* f, int mode, const TriAns& a)
+{   // feature.hpp:537-546 incl. the FEJ quirk (position_FEJ takes the OLD position of a first-time feature)
+    if (!a.ok) return;
+    if (!f->is_initialized) memcpy(f->position_fej, f->position, 24);
+    f->is_initialized = true;
+    memcpy(f->position, a.position, 24);
+    f->id_anchor = a.id_anchor;
+    f->inv_depth = a.inv_depth; memcpy(f->obs_anchor, a.obs_anchor, 24);
+    if (mode == 2) f->ekf_feature = true;
+}
+static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::vector<TriAns>& ans)
+{
+    ans.assign(reqs.size(), TriAns());
+    if (reqs.empty()) return LVK_OK;
+    size_t tot = 0; for (auto& r : reqs) tot += r.ranks.size();
+    if ((int)reqs.size() > e->feat_cap || (int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "triangulation batch exceeds capacity");
+    TriJob* hj = up_alloc<TriJob>(e, reqs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot);
+    if (!hj || !hr || !hz) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    size_t off = 0;
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        TriReq& r = reqs[i];
+        hj[i].n = (int)r.ranks.size(); hj[i].use_position = r.use_pos ? 1 : 0; hj[i].obs_off = (int)off; hj[i].pad = 0;
+        memcpy(hj[i].position_in, r.f->position, 24);
+        for (size_t k = 0; k < r.ranks.size(); ++k) { hr[off + k] = r.ranks[k]; hz[2 * (off + k)] = r.z[2 * k]; hz[2 * (off + k) + 1] = r.z[2 * k + 1]; }
+        off += r.ranks.size();
+    }
+    lvk_status st = h2d(e, e->d_tri, hj, reqs.size());
+    if (st == LVK_OK) st = h2d(e, e->d_rank, hr, tot);
+    if (st == LVK_OK) st = h2d(e, e->d_z, hz, 2 * tot);
+    if (st == LVK_OK) st = lvk_launch_triangulate(e->ctx, e->d_tri, (int)reqs.size(), e->d_cams, e->d_rank, e->d_z, e->d_triout);
+    if (st != LVK_OK) return st;
+    TriResult* ho = (TriResult*)e->h_down;
+    st = d2h_sync(e, ho, e->d_triout, sizeof(TriResult) * reqs.size());
+    if (st != LVK_OK) return st;
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        ans[i].ok = ho[i].ok != 0; memcpy(ans[i].position, ho[i].position, 24); ans[i].inv_depth = ho[i].inv_depth; memcpy(ans[i].obs_anchor, ho[i].obs_anchor, 24);
+        ans[i].id_anchor = reqs[i].ids.empty() ? -1 : reqs[i].ids.back();
+    }
+    e->counters[7] += (long)reqs.size();
+    return LVK_OK;
+}
+static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracked)
+{   // Feature::checkMotion (feature.hpp:334-381)
+    const int first = 0, last = if_tracked ? (int)f.obs.size() - 2 : (int)f.obs.size() - 1;
+    const Clone& a = e->clones[clone_rank(e, f.obs[first].sid)]; const Clone& b = e->clones[clone_rank(e, f.obs[last].sid)];
+    double Ra[9]; quat_to_rot(a.q_cam, Ra);
+    double d[3] = {f.obs[first].z[0], f.obs[first].z[1], 1.0};
+    const double n = v3_norm(d); d[0] /= n; d[1] /= n; d[2] /= n;
+    double dw[3]; m3_v(Ra, d, dw);
+    double tr[3] = {b.p_cam[0] - a.p_cam[0], b.p_cam[1] - a.p_cam[1], b.p_cam[2] - a.p_cam[2]};
+    const double par = tr[0] * dw[0] + tr[1] * dw[1] + tr[2] * dw[2];
+    double o[3] = {tr[0] - par * dw[0], tr[1] - par * dw[1], tr[2] - par * dw[2]};
+    return v3_norm(o) > e->cfg.feature_translation_threshold;
+}
+
+// One feature-rows job (rows on the device) ------------------------------------------------------------
+struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; };
+
+static lvk_status run_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
+{
+    if (jobs.empty()) return LVK_OK;
+    if ((int)jobs.size() > 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
+    size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2;
+    for (auto& j : jobs) tot += j.sids.size();
+    if ((int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "observation batch exceeds capacity");
+    FeatJob* hj = up_alloc<FeatJob>(e, jobs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot); double* hv = up_alloc<double>(e, 2 * tot);
+    if (!hj || !hr || !hz || !hv) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    size_t off = 0;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        RowJob& j = jobs[i]; Feature* f = j.f;
+        const int M = (int)j.sids.size();
+        const int c = (j.type == JOB_MSCKF) ? 7 + 6 * M : 7 + 6 + 6 * M + 1;
+        FeatJob& d = j.dev; memset(&d, 0, sizeof d);
+        d.type = j.type; d.n_obs = M; d.obs_off = (int)off; d.want_gate = j.want_gate ? 1 : 0;
+        d.anchor_rank = (j.type == JOB_MSCKF) ? 0 : clone_rank(e, f->id_anchor);
+        d.fcol = (j.type == JOB_MSCKF) ? 0 : LEG + 6 * (int)e->clones.size() + fs_rank(e, f->id);
+        d.stage_off = (long long)stage; d.ccol_off = (int)ccols;
+        memcpy(d.p_w, f->position, 24); memcpy(d.p_fej, f->position_fej, 24); d.inv_depth = f->inv_depth; memcpy(d.obs_anchor, f->obs_anchor, 24);
+        for (int k = 0; k < M; ++k) {
+            const int oi = f->find(j.sids[k]);
+            hr[off + k] = clone_rank(e, j.sids[k]);
+            hz[2 * (off + k)] = f->obs[oi].z[0]; hz[2 * (off + k) + 1] = f->obs[oi].z[1];
+            hv[2 * (off + k)] = f->obs[oi].zv[0]; hv[2 * (off + k) + 1] = f->obs[oi].zv[1];
+        }
+        off += M;
+        stage += (size_t)2 * M * c * 2 + 2 * M; ccols += c;
+        max_rows = std::max(max_rows, 2 * M);
+        hj[i] = d;
+    }
+    if (stage > e->staging_cap || ccols > e->ccols_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "staging buffer too small (%zu doubles needed)", stage);
+    lvk_status st = h2d(e, e->d_fj, hj, jobs.size());
+    if (st == LVK_OK) st = h2d(e, e->d_rank, hr, tot);
+    if (st == LVK_OK) st = h2d(e, e->d_z, hz, 2 * tot);
+    if (st == LVK_OK) st = h2d(e, e->d_zv, hv, 2 * tot);
+    FilterFlags fl; fl.leg_dim = LEG; fl.if_fej = e->if_fej ? 1 : 0; fl.estimate_td = e->cfg.estimate_td; fl.pad = 0; fl.sigma2 = e->sigma2;
+    if (st == LVK_OK) st = lvk_launch_feature_rows(e->ctx, e->d_fj, (int)jobs.size(), max_rows, e->d_clones, e->d_rank, e->d_z, e->d_zv, e->dP[e->cur], e->ld, fl,
+                                                   e->d_staging, e->d_ccols, e->d_fout);
+    if (st != LVK_OK) return st;
+    FeatResult* ho = (FeatResult*)e->h_down;
+    st = d2h_sync(e, ho, e->d_fout, sizeof(FeatResult) * jobs.size());
+    if (st != LVK_OK) return st;
+    for (size_t i = 0; i < jobs.size(); ++i) jobs[i].res = ho[i];
+    return LVK_OK;
+}
+static bool gate_ok(lvk_ekf* e, const RowJob& j)
+{
+    const bool ok = j.res.gamma < lvk_chi2_005(j.dof);
+    e->counters[ok ? 4 : 5]++;
+    return ok;
+}
+// rows [first, first+count) of a job's compact block -> consecutive dense rows starting at dst
+static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst)
+{
+    const int M = j.dev.n_obs, c = j.res.c;
+    for (int k = 0; k < count; ++k) {
+        StackRow s; s.g_off = j.dev.stage_off; s.r_off = j.dev.stage_off + (long long)2 * M * c * 2; s.src_row = first + k; s.c = c; s.ccol_off = j.dev.ccol_off; s.dst_row = dst + k;
+        map.push_back(s);
+    }
+}
+static lvk_status stack_rows(lvk_ekf* e, const std::vector<StackRow>& map, double* dH, int ncols, double* dr)
+{
+    if (map.empty()) return LVK_OK;
+    StackRow* h = up_alloc<StackRow>(e, map.size());
+    if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    memcpy(h, map.data(), sizeof(StackRow) * map.size());
+    lvk_status st = h2d(e, e->d_map, h, map.size());
+    if (st == LVK_OK) st = lvk_launch_stack_rows(e->ctx, e->d_map, (int)map.size(), e->d_staging, e->d_ccols, dH, e->ld, ncols, dr);
+    return st;
+}
+// dense update with m stacked rows already in d_H/d_r: compress when too tall, update P, fetch dx
+static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int extra)
+{
+    lvk_status st = LVK_OK;
+    if (m > e->rows_cap - 32) {
+        int m2 = m;
+        st = lvk_qr_compress_dev(e->ctx, e->d_H, e->ld, m, e->N, e->d_r, &m2);
+        if (st != LVK_OK) return st;
+        m = m2;
+    }
+    st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, e->d_H, e->ld, m, e->d_r, e->sigma2, e->d_dx, e->ws);
+    if (st != LVK_OK) return st;
+    dx.assign((size_t)e->N + extra, 0.0);
+    e->counters[2] = m;
+    return LVK_OK;
+}
+
+// ------------------------------------------------------------------------- removeLostFeatures (larvio.cpp:1883-2256)
+static int grid_code(const lvk_ekf* e, const double* xy)
+{
+    int row = (int)((xy[1] - e->y_min) / e->grid_h), col = (int)((xy[0] - e->x_min) / e->grid_w);
+    return row * e->cfg.aug_grid_cols + col;
+}
+static lvk_status remove_lost_features(lvk_ekf* e)
+{
+    const lvk_ekf_config& c = e->cfg;
+    const int cells = c.aug_grid_rows * c.aug_grid_cols;
+    std::vector<long long> ekf_ids, ekf_lost;
+    for (auto& kv : e->map) {
+        Feature& f = kv.second;
+        const bool tracked = f.find(e->imu_id) >= 0;
+        if (f.in_state) { if (tracked) ekf_ids.push_back(f.id); else ekf_lost.push_back(f.id); }
+    }
+    lvk_status st;
+    for (long long id : ekf_lost) {                              // rmLostFeaturesCov (:3296-3348)
+        const int seq = fs_rank(e, id);
+        st = cov_delete(e, LEG + 6 * (int)e->clones.size() + seq, 1);
+        if (st != LVK_OK) return st;
+        e->feature_states.erase(e->feature_states.begin() + seq);
+        e->map.erase(id);
+    }
+    if (cells) {                                                 // updateGridMap (:3351-3370)
+        std::fill(e->grid_count.begin(), e->grid_count.end(), 0);
+        for (long long id : e->feature_states) {
+            Feature& f = e->map[id];
+            const int oi = f.find(e->imu_id);
+            double xy[2] = {0, 0}; if (oi >= 0) { xy[0] = f.obs[oi].z[0]; xy[1] = f.obs[oi].z[1]; }
+            const int code = grid_code(e, xy);
+            if (code >= 0 && code < cells) e->grid_count[code]++;
+        }
+    }
+    st = upload_clones(e);
+    if (st != LVK_OK) return st;
+    // ---- pass 1: every triangulation the triage may ask for, batched on the device, then replayed in map order.
+    //      (a) lost, not initialised: initializePosition.  (b) tracked long, not in state: the EKF branch wants
+    //      initializeInvParamPosition (always from the two-view guess), the MSCKF branch initializePosition.
+    std::vector<TriReq> reqs; std::vector<TriAns> ans;
+    struct Cand { Feature* f; int idx_pos = -1, idx_inv = -1; bool motion; };
+    std::vector<Cand> cands;
+    for (auto& kv : e->map) {
+        Feature& f = kv.second;
+        if (f.in_state) continue;
+        const bool tracked = f.find(e->imu_id) >= 0;
+        Cand cd; cd.f = &f; cd.motion = false;
+        if (!tracked) {
+            if ((int)f.obs.size() < c.least_observation_number) continue;
+            if (!f.is_initialized) { cd.motion = feat_check_motion(e, f, tracked); if (cd.motion) { reqs.emplace_back(); make_tri_req(e, &f, 0, &reqs.back()); cd.idx_pos = (int)reqs.size() - 1; } }
+        } else {
+            if (!((int)f.obs.size() >= c.max_track_len)) continue;
+            cd.motion = feat_check_motion(e, f, tracked);
+            if (cd.motion) {
+                if (!f.ekf_feature) { reqs.emplace_back(); make_tri_req(e, &f, 2, &reqs.back()); reqs.back().use_pos = false; cd.idx_inv = (int)reqs.size() - 1; }
+                if (!f.is_initialized || !f.ekf_feature) {
+                    // the MSCKF branch runs initializePosition only when !is_initialized; the EKF branch resets is_initialized first.
+                    reqs.emplace_back(); make_tri_req(e, &f, 0, &reqs.back()); cd.idx_pos = (int)reqs.size() - 1;
+                }
+            }
+        }
+        cands.push_back(cd);
+    }
+    st = run_triangulation(e, reqs, ans);
+    if (st != LVK_OK) return st;
+    // ---- pass 2: sequential triage (map order) with the precomputed results
+    std::vector<long long> invalid, msckf, ekf_new;
+    size_t ci = 0;
+    for (auto& kv : e->map) {
+        Feature& f = kv.second;
+        if (f.in_state) continue;
+        const bool tracked = f.find(e->imu_id) >= 0;
+        if (!tracked) {
+            if ((int)f.obs.size() < c.least_observation_number) { invalid.push_back(f.id); continue; }
+            Cand& cd = cands[ci++];
+            if (!f.is_initialized) {
+                if (!cd.motion) { invalid.push_back(f.id); continue; }
+                apply_tri(&f, 0, ans[cd.idx_pos]);
+                if (!ans[cd.idx_pos].ok) { invalid.push_back(f.id); continue; }
+            }
+            msckf.push_back(f.id);
+        } else {
+            if (!((int)f.obs.size() >= c.max_track_len)) continue;
+            Cand& cd = cands[ci++];
+            const int oi = f.find(e->imu_id);
+            const int code = grid_code(e, f.obs[oi].z);
+            const int gcount = (code >= 0 && code < cells) ? e->grid_count[code] : 0;
+            if (gcount < c.max_features_in_one_grid && e->s.t - e->last_zupt_time > 5 &&
+                (int)(e->feature_states.size() + ekf_new.size()) < c.max_features_in_one_grid * cells) {
+                if (!f.ekf_feature) {
+                    f.is_initialized = false;
+                    if (cd.motion) apply_tri(&f, 2, ans[cd.idx_inv]);
+                }
+                if (!f.is_initialized) continue;
+                ekf_new.push_back(f.id);
+                if (code >= 0 && code < cells) e->grid_count[code]++;
+            } else {
+                if (!f.is_initialized) { if (cd.motion && cd.idx_pos >= 0) apply_tri(&f, 0, ans[cd.idx_pos]); }
+                if (!f.is_initialized) continue;
+                msckf.push_back(f.id);
+            }
+        }
+    }
+    for (long long id : invalid) e->map.erase(id);
+    if (msckf.empty() && ekf_new.empty() && ekf_ids.empty()) return LVK_OK;
+    if (!e->if_zupt) {
+        const int N = e->N;
+        const size_t n_fs_old = e->feature_states.size();
+        for (long long id : ekf_new) { e->map[id].in_state = true; e->feature_states.push_back(id); }
+        // ---- device batch: [new: msckf-form gate | new: ekf rows] [tracked ekf] [msckf]
+        std::vector<RowJob> jobs;
+        auto all_sids = [](Feature& f) { std::vector<long long> v; for (auto& o : f.obs) v.push_back(o.sid); return v; };
+        for (long long id : ekf_new) {
+            Feature& f = e->map[id];
+            RowJob g; g.f = &f; g.type = JOB_MSCKF; g.sids = all_sids(f); g.want_gate = true; g.dof = 2 * (int)f.obs.size() - 3; jobs.push_back(g);
+            RowJob r; r.f = &f; r.type = JOB_EKF_NEW; r.want_gate = false; r.dof = 0;
+            for (auto& o : f.obs) if (o.sid != f.id_anchor) r.sids.push_back(o.sid);
+            jobs.push_back(r);
+        }
+        const size_t j_ekf = jobs.size();
+        for (long long id : ekf_ids) { Feature& f = e->map[id]; RowJob r; r.f = &f; r.type = JOB_EKF_TRACKED; r.sids = {e->imu_id}; r.want_gate = true; r.dof = 2; jobs.push_back(r); }
+        const size_t j_msckf = jobs.size();
+        for (long long id : msckf) { Feature& f = e->map[id]; RowJob r; r.f = &f; r.type = JOB_MSCKF; r.sids = all_sids(f); r.want_gate = true; r.dof = 2 * (int)f.obs.size() - 3; jobs.push_back(r); }
+        // NOTE: the feature column index of a new feature must be its FINAL one (after rejected candidates are dropped);
+        // it is not used by JOB_EKF_NEW rows (the feature column never reaches H_o), so any value works here.
+        st = run_feature_rows(e, jobs);
+        if (st != LVK_OK) return st;
+        // ---- accepted sets and row layout: H_o = [H_msckf ; H_ekf ; top rows of the new block] (:1612-1626)
+        std::vector<StackRow> map_o, map_1;
+        int rows_m = 0, rows_e = 0, top = 0;
+        for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m); rows_m += jobs[k].res.rows; }
+        for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e); rows_e += 2; }
+        std::vector<long long> acc_ids; std::vector<double> h2;
+        std::vector<size_t> acc_jobs;
+        for (size_t k = 0; k < j_ekf; k += 2) {
+            Feature* f = jobs[k].f;
+            if (gate_ok(e, jobs[k])) { acc_ids.push_back(f->id); acc_jobs.push_back(k + 1); h2.push_back(jobs[k + 1].res.h2); }
+            else f->in_state = false;
+        }
+        for (size_t a = 0; a < acc_jobs.size(); ++a) {
+            const RowJob& j = jobs[acc_jobs[a]];
+            push_rows(map_o, j, 1, j.res.rows, rows_m + rows_e + top); top += j.res.rows;
+            push_rows(map_1, j, 0, 1, (int)a);
+        }
+        e->feature_states.resize(n_fs_old);
+        for (long long id : acc_ids) e->feature_states.push_back(id);
+        const int m = rows_m + rows_e + top, n_acc = (int)acc_ids.size();
+        if (m + n_acc > 0) {
+            if (m > 8 * e->rows_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
+            st = stack_rows(e, map_o, e->d_H, N, e->d_r);
+            if (st == LVK_OK && n_acc) st = stack_rows(e, map_1, e->d_H1, N, e->d_r1);
+            if (st != LVK_OK) return st;
+            std::vector<double> dx;
+            st = dense_update(e, m, dx, n_acc);
+            if (st != LVK_OK) return st;
+            if (n_acc) {
+                double* hh = up_alloc<double>(e, n_acc);
+                if (!hh) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+                memcpy(hh, h2.data(), sizeof(double) * n_acc);
+                st = h2d(e, e->d_H2, hh, (size_t)n_acc);
+                if (N + n_acc > e->nmax) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "state dimension exceeds capacity");
+                if (st == LVK_OK) st = lvk_cov_append_features(e->ctx, e->dP[e->cur], e->ld, N, n_acc, e->d_H1, e->ld, e->d_H2, e->d_r1, e->d_dx, e->sigma2, e->d_tmp, e->d_dx + N);
+                if (st != LVK_OK) return st;
+            }
+            st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)(N + n_acc));
+            if (st != LVK_OK) return st;
+            inject(e, dx.data());
+            e->N = N + n_acc;
+            e->last_update_time = e->s.t;
+            e->counters[0]++;
+        }
+    } else {
+        for (long long id : msckf) { auto it = e->map.find(id); if (it != e->map.end()) it->second.is_initialized = false; }
+    }
+    for (long long id : msckf) e->map.erase(id);
+    return LVK_OK;
+}
+
+// ------------------------------------------------------------------------- pruning (larvio.cpp:2259-2641)
+static void find_redundant(lvk_ekf* e, long long* rm)
+{
+    int key = (int)e->clones.size() - 4, si = key + 1, fi = 0, n = 0;
+    double Rk[9]; quat_to_rot(e->clones[key].q_cam, Rk);
+    for (int i = 0; i < 2; ++i) {
+        const Clone* c = &e->clones[si];
+        double R[9], Rt[9], M[9], q[4];
+        quat_to_rot(c->q_cam, R); m3_t(R, Rt); m3_mul(Rt, Rk, M);
+        double d[3] = {c->p_cam[0] - e->clones[key].p_cam[0], c->p_cam[1] - e->clones[key].p_cam[1], c->p_cam[2] - e->clones[key].p_cam[2]};
+        const double distance = v3_norm(d);
+        rot_to_quat(M, q);
+        const double angle = 2 * atan2(sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), fabs(q[3]));
+        if (angle < e->cfg.rotation_threshold && distance < e->cfg.translation_threshold && e->tracking_rate > e->cfg.tracking_rate_threshold) { rm[n++] = c->id; ++si; }
+        else { rm[n++] = e->clones[fi].id; ++fi; si -= 2; }
+    }
+    if (rm[0] > rm[1]) std::swap(rm[0], rm[1]);
+}
+static long long get_new_anchor_id(lvk_ekf* e, Feature& f, const long long* rm, int nrm)
+{   // :3412-3472
+    const int size = (int)e->clones.size();
+    if (size <= 2) return e->clones[size - 1].id;
+    bool valid = false; double min_dis = 99999; long long id_min = 0;
+    for (int i = 0; i < size - 2; ++i) {
+        const Clone* c = &e->clones[i];
+        const int oi = f.find(c->id);
+        if (oi < 0) continue;
+        bool removed = false; for (int k = 0; k < nrm; ++k) if (rm[k] == c->id) removed = true;
+        if (removed) continue;
+        double R[9], d[3] = {f.position[0] - c->p_cam[0], f.position[1] - c->p_cam[1], f.position[2] - c->p_cam[2]}, pn[3];
+        quat_to_rot(c->q_cam, R); m3t_v(R, d, pn);
+        const double a = pn[0] / pn[2] - f.obs[oi].z[0], b = pn[1] / pn[2] - f.obs[oi].z[1];
+        const double dis = sqrt(a * a + b * b);
+        if (min_dis > dis) { min_dis = dis; id_min = c->id; valid = true; }
+    }
+    return valid ? id_min : e->clones[size - 1].id;
+}
+static lvk_status update_feature_cov_1d(lvk_ekf* e, const Feature& f, long long old_id, long long new_id)
+{   // :3125-3293 — the row J is built on the host (a few 3x3 products), J P and J P J^T on the device
+    const int N = e->N;
+    const Clone* co = &e->clones[clone_rank(e, old_id)];
+    const Clone* cn = &e->clones[clone_rank(e, new_id)];
+    const double* R_b2c = e->R_b2c; const double* t_c_b = e->t_c_b; const double* p_w = f.position;
+    double R_b2w_old[9], R_c2w_old[9], R_w2c_old[9];
+    quat_to_rot(co->q, R_b2w_old); quat_to_rot(co->q_cam, R_c2w_old); m3_t(R_c2w_old, R_w2c_old);
+    double d[3] = {p_w[0] - co->p_cam[0], p_w[1] - co->p_cam[1], p_w[2] - co->p_cam[2]}, p_old_[3], p_old[3];
+    m3_v(R_w2c_old, d, p_old_);
+    if (e->if_fej) {
+        double dd[3] = {f.position_fej[0] - co->p_fej[0], f.position_fej[1] - co->p_fej[1], f.position_fej[2] - co->p_fej[2]}, q[3];
+        m3t_v(R_b2w_old, dd, q); q[0] -= t_c_b[0]; q[1] -= t_c_b[1]; q[2] -= t_c_b[2];
+        m3_v(R_b2c, q, p_old);
+    } else memcpy(p_old, p_old_, 24);
+    const double inv_old = 1 / p_old_[2];
+    const double f_old[3] = {p_old_[0] / p_old_[2], p_old_[1] / p_old_[2], 1};
+    double R_b2w_new[9], R_w2b_new[9], R_c2w_new[9], R_w2c_new[9];
+    quat_to_rot(cn->q, R_b2w_new); m3_t(R_b2w_new, R_w2b_new); quat_to_rot(cn->q_cam, R_c2w_new); m3_t(R_c2w_new, R_w2c_new);
+    const double inv_new = f.inv_depth;
+    double pbo[3], pbn[3];
+    for (int i = 0; i < 3; ++i) { pbo[i] = e->if_fej ? f.position_fej[i] - co->p_fej[i] : p_w[i] - co->p[i]; pbn[i] = e->if_fej ? f.position_fej[i] - cn->p_fej[i] : p_w[i] - cn->p[i]; }
+    const double J_rho_d_new = -inv_new * inv_new;
+    double M[9], Jd_[3]; m3_mul(R_w2c_new, R_c2w_old, M); m3_v(M, f_old, Jd_);
+    double So[9], Sn[9], Jto[9], Jtn[9];
+    skew3(pbo, So); skew3(pbn, Sn); m3_mul(R_w2c_new, So, Jto); m3_mul(R_w2c_new, Sn, Jtn);
+    double v1[3], SkewMx[9], RR[9], R_c2b[9], v2[3], S2[9], Mx[9], D[9], JeT[9], E[9], JeP[9];
+    m3_v(R_w2b_new, pbn, v1); v1[0] -= t_c_b[0]; v1[1] -= t_c_b[1]; v1[2] -= t_c_b[2]; skew3(v1, SkewMx);
+    m3_mul(R_w2b_new, R_b2w_old, RR);
+    m3_t(R_b2c, R_c2b); m3_v(R_c2b, p_old, v2); skew3(v2, S2); m3_mul(RR, S2, Mx);
+    for (int i = 0; i < 9; ++i) D[i] = SkewMx[i] - Mx[i];
+    m3_mul(R_b2c, D, JeT);
+    for (int i = 0; i < 9; ++i) E[i] = RR[i] - ((i % 4 == 0) ? 1.0 : 0.0);
+    m3_mul(R_b2c, E, JeP);
+    const double J_d_rho_old = -1 / (inv_old * inv_old);
+    double* J = up_alloc<double>(e, N);
+    if (!J) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    memset(J, 0, sizeof(double) * N);
+    const int fc = LEG + 6 * (int)e->clones.size() + fs_rank(e, f.id);
+    const int oc = LEG + 6 * clone_rank(e, old_id), ncn = LEG + 6 * clone_rank(e, new_id);
+    J[fc] = J_rho_d_new * Jd_[2] * J_d_rho_old;
+    for (int j = 0; j < 3; ++j) { J[oc + j] = J_rho_d_new * (-Jto[6 + j]); J[oc + 3 + j] = J_rho_d_new * R_w2c_new[6 + j]; }
+    for (int j = 0; j < 3; ++j) { J[ncn + j] = J_rho_d_new * Jtn[6 + j]; J[ncn + 3 + j] = J_rho_d_new * (-R_w2c_new[6 + j]); }
+    for (int j = 0; j < 3; ++j) { J[15 + j] = J_rho_d_new * JeT[6 + j]; J[18 + j] = J_rho_d_new * JeP[6 + j]; }
+    lvk_status st = h2d(e, e->d_J, J, (size_t)N);
+    if (st == LVK_OK) st = lvk_cov_reanchor(e->ctx, e->dP[e->cur], e->ld, N, e->d_J, fc);
+    return st;
+}
+
+static lvk_status prune_imu_state_buffer(lvk_ekf* e)
+{
+    long long rm[2]; int nrm = 0;
+    if (!e->if_zupt) {
+        if ((int)e->clones.size() < e->cfg.sw_size) return LVK_OK;
+        find_redundant(e, rm); nrm = 2;
+    } else { rm[0] = e->imu_id - 1; nrm = 1; }
+    lvk_status st;
+    // pass A: re-anchoring (host + rank-1 covariance op) and collection of the features that need a triangulation
+    struct Use { Feature* f; std::vector<long long> inv; int tri = -1; bool motion = true; };
+    std::vector<Use> uses; std::vector<TriReq> reqs; std::vector<TriAns> ans;
+    bool clones_uploaded = false;
+    for (auto& kv : e->map) {
+        Feature& f = kv.second;
+        std::vector<long long> inv;
+        for (int k = 0; k < nrm; ++k) if (f.find(rm[k]) >= 0) inv.push_back(rm[k]);
+        if (inv.empty()) continue;
+        const bool anchor_involved = std::find(inv.begin(), inv.end(), f.id_anchor) != inv.end();
+        if (f.in_state) {
+            if (anchor_involved) {
+                const long long new_id = get_new_anchor_id(e, f, inv.data(), (int)inv.size());
+                const Clone* cn = &e->clones[clone_rank(e, new_id)];
+                double R[9], d[3] = {f.position[0] - cn->p_cam[0], f.position[1] - cn->p_cam[1], f.position[2] - cn->p_cam[2]}, pn[3];
+                quat_to_rot(cn->q_cam, R); m3t_v(R, d, pn);
+                f.inv_depth = 1 / pn[2];
+                f.obs_anchor[0] = pn[0] / pn[2]; f.obs_anchor[1] = pn[1] / pn[2];
+                st = update_feature_cov_1d(e, f, f.id_anchor, new_id);
+                if (st != LVK_OK) return st;
+                f.id_anchor = new_id;
+            }
+        } else {
+            if (f.is_initialized && anchor_involved) {
+                const long long new_id = get_new_anchor_id(e, f, inv.data(), (int)inv.size());
+                const Clone* cn = &e->clones[clone_rank(e, new_id)];
+                double R[9], d[3] = {f.position[0] - cn->p_cam[0], f.position[1] - cn->p_cam[1], f.position[2] - cn->p_cam[2]}, pn[3];
+                quat_to_rot(cn->q_cam, R); m3t_v(R, d, pn);
+                f.inv_depth = 1 / pn[2];
+                const int oi = f.find(new_id);
+                if (oi >= 0) { f.obs_anchor[0] = f.obs[oi].z[0]; f.obs_anchor[1] = f.obs[oi].z[1]; } else { f.obs_anchor[0] = 0; f.obs_anchor[1] = 0; }
+                f.id_anchor = new_id;
+            }
+            if (!e->if_zupt && !f.ekf_feature && inv.size() > 1) {
+                Use u; u.f = &f; u.inv = inv;
+                if (!f.is_initialized) {
+                    const bool tracked = f.find(e->imu_id) >= 0;
+                    u.motion = feat_check_motion(e, f, tracked);
+                    if (u.motion) { reqs.emplace_back(); make_tri_req(e, &f, 1, &reqs.back()); u.tri = (int)reqs.size() - 1; }
+                }
+                uses.push_back(u);
+            }
+        }
+    }
+    std::vector<Use*> used;
+    if (!e->if_zupt && !uses.empty()) {
+        if (!reqs.empty()) {
+            st = upload_clones(e); clones_uploaded = true;
+            if (st == LVK_OK) st = run_triangulation(e, reqs, ans);
+            if (st != LVK_OK) return st;
+        }
+        for (auto& u : uses) {
+            if (!u.f->is_initialized) {
+                if (!u.motion) continue;
+                apply_tri(u.f, 1, ans[u.tri]);
+                if (!ans[u.tri].ok) continue;
+            }
+            used.push_back(&u);
+        }
+    }
+    if (!e->if_zupt && !used.empty()) {
+        if (!clones_uploaded) { st = upload_clones(e); if (st != LVK_OK) return st; }
+        std::vector<RowJob> jobs;
+        for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
+        st = run_feature_rows(e, jobs);
+        if (st != LVK_OK) return st;
+        std::vector<StackRow> map_o; int rows = 0;
+        for (auto& j : jobs) if (gate_ok(e, j)) { push_rows(map_o, j, j.res.first_row, j.res.rows, rows); rows += j.res.rows; }
+        for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
+        if (rows > 0) {                                         // measurementUpdate_msckf (:1420-1602)
+            st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
+            std::vector<double> dx;
+            if (st == LVK_OK) st = dense_update(e, rows, dx, 0);
+            if (st == LVK_OK) st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)e->N);
+            if (st != LVK_OK) return st;
+            inject(e, dx.data());
+            e->last_update_time = e->s.t;
+            e->counters[1]++;
+        }
+    } else {
+        for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
+    }
+    for (int k = 0; k < nrm; ++k) {
+        const int seq = clone_rank(e, rm[k]);
+        if (seq < 0) continue;
+        st = cov_delete(e, LEG + 6 * seq, 6);
+        if (st != LVK_OK) return st;
+        e->clones.erase(e->clones.begin() + seq);
+    }
+    return LVK_OK;
+}
+
+// ------------------------------------------------------------------------- ZUPT (larvio.cpp:2751-2962)
+static lvk_status update_zupt(lvk_ekf* e)
+{
+    const int N = e->N, n = (int)e->clones.size();
+    double* H = up_alloc<double>(e, (size_t)9 * e->ld); double* r = up_alloc<double>(e, 16);
+    if (!H || !r) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    memset(H, 0, sizeof(double) * 9 * e->ld);
+    for (int i = 0; i < 3; ++i) {
+        H[(size_t)i * e->ld + 3 + i] = 1.0;
+        H[(size_t)(3 + i) * e->ld + LEG + 6 * n - 3 + i] = 1.0; H[(size_t)(3 + i) * e->ld + LEG + 6 * n - 9 + i] = -1.0;
+        H[(size_t)(6 + i) * e->ld + LEG + 6 * n - 6 + i] = -0.5; H[(size_t)(6 + i) * e->ld + LEG + 6 * n - 12 + i] = 0.5;
+    }
+    const Clone* cc = &e->clones[clone_rank(e, e->imu_id)]; const Clone* cp = &e->clones[clone_rank(e, e->imu_id - 1)];
+    for (int i = 0; i < 3; ++i) { r[i] = -e->s.v[i]; r[3 + i] = -(cc->p[i] - cp->p[i]); }
+    double qpc[4] = {-cp->q[0], -cp->q[1], -cp->q[2], cp->q[3]}, dq[4];
+    quat_mul(cc->q, qpc, dq);
+    r[6] = dq[0]; r[7] = dq[1]; r[8] = dq[2];
+    // rows are whitened by sigma/sqrt(R_ii) so the shared isotropic update applies (K r and K H are unchanged)
+    const double Rd[9] = {e->zupt_v2, e->zupt_v2, e->zupt_v2, e->zupt_p2, e->zupt_p2, e->zupt_p2, e->zupt_q2, e->zupt_q2, e->zupt_q2};
+    for (int i = 0; i < 9; ++i) { const double s = sqrt(e->sigma2 / Rd[i]); for (int j = 0; j < N; ++j) H[(size_t)i * e->ld + j] *= s; r[i] *= s; }
+    lvk_status st = h2d(e, e->d_H, H, (size_t)9 * e->ld);
+    if (st == LVK_OK) st = h2d(e, e->d_r, r, (size_t)9);
+    std::vector<double> dx;
+    if (st == LVK_OK) st = dense_update(e, 9, dx, 0);
+    if (st == LVK_OK) st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)N);
+    if (st != LVK_OK) return st;
+    inject(e, dx.data());
+    e->last_update_time = e->s.t; e->last_zupt_time = e->s.t;
+    e->counters[3]++;
+    return LVK_OK;
+}
+static lvk_status check_zupt(lvk_ekf* e, bool* out)
+{
+    *out = false;
+    if (e->coarse_dis.size() < 20) { e->coarse_dis.clear(); return LVK_OK; }
+    std::sort(e->coarse_dis.begin(), e->coarse_dis.end());
+    const double max_dis = e->coarse_dis[e->coarse_dis.size() - 9];
+    e->coarse_dis.clear();
+    if (max_dis < e->cfg.zupt_max_feature_dis) {
+        if (!e->feature_states.empty()) {
+            lvk_status st = cov_delete(e, e->N - (int)e->feature_states.size(), (int)e->feature_states.size());
+            if (st != LVK_OK) return st;
+            for (long long id : e->feature_states) { Feature& f = e->map[id]; f.is_initialized = false; f.ekf_feature = false; f.in_state = false; }
+            e->feature_states.clear();
+        }
+        lvk_status st = update_zupt(e);
+        if (st != LVK_OK) return st;
+        *out = true;
+    }
+    return LVK_OK;
+}
+
+// ------------------------------------------------------------------------- static initializer (StaticInitializer.cpp:12-163)
+static bool static_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, int n, const lvk_imu* imu, int n_imu, int* n_erased)
+{
+    *n_erased = 0;
+    auto snapshot = [&]() { e->init_features.clear(); for (int i = 0; i < n; ++i) e->init_features[(long long)f[i].id] = std::make_pair(f[i].u, f[i].v); };
+    if (e->static_counter == 0) { e->static_counter++; snapshot(); e->lower_time_bound = ts + e->td; return false; }
+    std::vector<double> dis;
+    for (int i = 0; i < n; ++i) { auto it = e->init_features.find((long long)f[i].id); if (it != e->init_features.end()) { double dx = f[i].u - it->second.first, dy = f[i].v - it->second.second; dis.push_back(sqrt(dx * dx + dy * dy)); } }
+    if (dis.size() < 20) { e->static_counter = 0; return false; }
+    std::sort(dis.begin(), dis.end());
+    const double max_dis = dis[dis.size() - 19];
+    if (max_dis < e->cfg.zupt_max_feature_dis) { e->static_counter++; snapshot(); if (e->static_counter < e->static_num) return false; }
+    else { e->static_counter = 0; return false; }
+    const double time_bound = ts + e->td;
+    double sw[3] = {0, 0, 0}, sa[3] = {0, 0, 0}; int cnt = 0; double last_t = 0;
+    for (int i = 0; i < n_imu; ++i) {
+        if (imu[i].t < e->lower_time_bound) continue;
+        if (imu[i].t > time_bound) break;
+        for (int k = 0; k < 3; ++k) { sw[k] += imu[i].gyro[k]; sa[k] += imu[i].acc[k]; }
+        cnt++; last_t = imu[i].t;
+    }
+    double gi[3];
+    for (int k = 0; k < 3; ++k) { e->s.bg[k] = sw[k] / cnt; gi[k] = sa[k] / cnt; }
+    const double gn = v3_norm(gi);
+    {   // Quaterniond::FromTwoVectors(gravity_imu, (0,0,|g|))
+        double v0[3] = {gi[0] / gn, gi[1] / gn, gi[2] / gn}, v1[3] = {0, 0, 1.0};
+        const double cdot = v1[0] * v0[0] + v1[1] * v0[1] + v1[2] * v0[2];
+        double ax[3] = {v0[1] * v1[2] - v0[2] * v1[1], v0[2] * v1[0] - v0[0] * v1[2], v0[0] * v1[1] - v0[1] * v1[0]};
+        const double s = sqrt((1 + cdot) * 2), invs = 1 / s;
+        e->s.q[0] = ax[0] * invs; e->s.q[1] = ax[1] * invs; e->s.q[2] = ax[2] * invs; e->s.q[3] = s * 0.5;
+    }
+    e->s.t = last_t;
+    memset(e->s.p, 0, 24); memset(e->s.v, 0, 24); memset(e->s.ba, 0, 24);
+    int useful = 0;
+    for (int i = 0; i < n_imu; ++i) { if (imu[i].t > last_t) break; useful++; }
+    if (useful >= n_imu) useful--;
+    memcpy(e->m_gyro_old, imu[useful].gyro, 24); memcpy(e->m_acc_old, imu[useful].acc, 24);
+    *n_erased = useful;
+    return true;
+}
+
+// ------------------------------------------------------------------------- C ABI
+template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess; }
+
+extern "C" {
+
+void lvk_ekf_destroy(lvk_ekf* e)
+{
+    if (!e) return;
+    hipStreamSynchronize(e->ctx->stream);
+    void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_triout, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
+                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (e->h_up) hipHostFree(e->h_up);
+    if (e->h_down) hipHostFree(e->h_down);
+    delete e;
+}
+
+lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf** out)
+{
+    if (!ctx || !cfg || !out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_create: bad argument");
+    if (cfg->feature_idp_dim != 1 || cfg->use_schmidt != 0 || cfg->calib_imu_instrinsic != 0)
+        return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "only feature_idp_dim 1, use_schmidt 0, calib_imu_instrinsic 0 are implemented");
+    if (cfg->sw_size < 5 || cfg->sw_size > 62) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "sw_size must be in 5..62");
+    lvk_ekf* e = new (std::nothrow) lvk_ekf();
+    if (!e) return LVK_ERR_DEVICE;
+    e->ctx = ctx; e->cfg = *cfg;
+    const lvk_ekf_config& c = e->cfg;
+    e->td = c.td;
+    e->sigma2 = c.noise_feature * c.noise_feature;
+    e->zupt_v2 = c.zupt_noise_v * c.zupt_noise_v; e->zupt_p2 = c.zupt_noise_p * c.zupt_noise_p; e->zupt_q2 = c.zupt_noise_q * c.zupt_noise_q;
+    e->imu_img_time_th = 1.0 / (2 * c.imu_rate);
+    for (int i = 0; i < 3; ++i) { e->Qc[i] = c.noise_gyro * c.noise_gyro; e->Qc[3 + i] = c.noise_acc * c.noise_acc; e->Qc[6 + i] = c.noise_gyro_bias * c.noise_gyro_bias; e->Qc[9 + i] = c.noise_acc_bias * c.noise_acc_bias; }
+    memset(&e->s, 0, sizeof e->s); e->s.q[3] = 1.0; e->s_old = e->s; e->s_fej_now = e->s; e->s_fej_old = e->s;
+    double R[9], t[3];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = c.T_cam_imu[i * 4 + j]; t[i] = c.T_cam_imu[i * 4 + 3]; }
+    memcpy(e->R_b2c, R, sizeof R);
+    double a[3]; m3t_v(R, t, a);
+    for (int i = 0; i < 3; ++i) e->t_c_b[i] = -a[i];
+    const double fx = c.intrinsics[0], fy = c.intrinsics[1], cx = c.intrinsics[2], cy = c.intrinsics[3];
+    e->x_min = -cx / fx; e->y_min = -cy / fy;
+    const double x_max = (c.width - cx) / fx, y_max = (c.height - cy) / fy;
+    const int cells = c.aug_grid_rows * c.aug_grid_cols;
+    if (cells != 0) { e->grid_w = (x_max - e->x_min) / c.aug_grid_cols; e->grid_h = (y_max - e->y_min) / c.aug_grid_rows; }
+    else { e->grid_w = x_max - e->x_min; e->grid_h = y_max - e->y_min; }
+    e->grid_count.assign((size_t)cells + 1, 0);
+    e->static_num = (int)((float)c.static_duration * (double)c.pub_frequency);
+    // capacities
+    const int max_feat_state = std::max(0, c.max_features_in_one_grid) * cells;
+    e->nmax = LEG + 6 * (c.sw_size + 2) + max_feat_state + 8;
+    e->ld = (e->nmax + 15) & ~15;
+    e->rows_cap = 544;
+    e->feat_cap = c.max_features > 0 ? c.max_features : 1024;
+    e->obs_cap = 2 * e->feat_cap * (c.sw_size + 2);
+    const int max_c = 7 + 6 + 6 * (c.sw_size + 2) + 1;
+    e->staging_cap = (size_t)2 * e->feat_cap * ((size_t)2 * (c.sw_size + 2) * max_c * 2 + 2 * (c.sw_size + 2));
+    e->ccols_cap = (size_t)2 * e->feat_cap * max_c;
+    const size_t hrows = (size_t)8 * e->rows_cap;
+    bool ok = dalloc(&e->dP[0], (size_t)e->ld * e->ld) && dalloc(&e->dP[1], (size_t)e->ld * e->ld) && dalloc(&e->d_idx, e->ld) && dalloc(&e->d_phiq, 2 * LEG * LEG) &&
+              dalloc(&e->d_J, e->ld) && dalloc(&e->d_dx, e->ld + 64) && dalloc(&e->d_tmp, (size_t)64 * e->ld) &&
+              dalloc(&e->d_tri, (size_t)2 * e->feat_cap) && dalloc(&e->d_triout, (size_t)2 * e->feat_cap) && dalloc(&e->d_fj, (size_t)2 * e->feat_cap) && dalloc(&e->d_fout, (size_t)2 * e->feat_cap) &&
+              dalloc(&e->d_rank, e->obs_cap) && dalloc(&e->d_z, (size_t)2 * e->obs_cap) && dalloc(&e->d_zv, (size_t)2 * e->obs_cap) &&
+              dalloc(&e->d_cams, c.sw_size + 4) && dalloc(&e->d_clones, c.sw_size + 4) && dalloc(&e->d_staging, e->staging_cap) && dalloc(&e->d_ccols, e->ccols_cap) &&
+              dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
+    e->ws.ldb = (e->ld + 8 + 7) & ~7; e->ws.lds = e->rows_cap;
+    ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds) && dalloc(&e->ws.info, 16);
+    e->up_cap = (size_t)64 << 20; e->down_cap = (size_t)4 << 20;
+    ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
+    if (!ok) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_ekf_create: allocation failed"); }
+    // initial covariance (larvio.cpp:163-186)
+    std::vector<double> P0((size_t)e->ld * e->ld, 0.0);
+    for (int i = 0; i < 3; ++i) {
+        P0[(size_t)i * e->ld + i] = c.initial_covariance_orientation; P0[(size_t)(3 + i) * e->ld + 3 + i] = c.initial_covariance_velocity;
+        P0[(size_t)(6 + i) * e->ld + 6 + i] = c.initial_covariance_position; P0[(size_t)(9 + i) * e->ld + 9 + i] = c.initial_covariance_gyro_bias;
+        P0[(size_t)(12 + i) * e->ld + 12 + i] = c.initial_covariance_acc_bias;
+        if (c.estimate_extrin) { P0[(size_t)(15 + i) * e->ld + 15 + i] = c.initial_covariance_extrin_rot; P0[(size_t)(18 + i) * e->ld + 18 + i] = c.initial_covariance_extrin_trans; }
+    }
+    if (c.estimate_td) P0[(size_t)21 * e->ld + 21] = 4e-6;
+    if (hipMemcpy(e->dP[0], P0.data(), sizeof(double) * P0.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(e->dP[1], 0, sizeof(double) * P0.size()) != hipSuccess) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "covariance upload failed"); }
+    e->N = LEG; e->cur = 0;
+    *out = e;
+    return LVK_OK;
+}
+
+lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const double p[3], const double v[3], const double bg[3], const double ba[3],
+                             const double gyro_old[3], const double acc_old[3])
+{
+    if (!e) return LVK_ERR_ARG;
+    e->s.t = t; memcpy(e->s.q, q, 32); memcpy(e->s.p, p, 24); memcpy(e->s.v, v, 24); memcpy(e->s.bg, bg, 24); memcpy(e->s.ba, ba, 24);
+    memcpy(e->m_gyro_old, gyro_old, 24); memcpy(e->m_acc_old, acc_old, 24);
+    e->is_gravity_set = true; e->b_first_features = true;
+    e->take_off_stamp = t; e->last_zupt_time = t - 10.0; e->last_update_time = t;     // initializer bypass: EKF-SLAM features allowed at once
+    e->s_fej_now = e->s;
+    return LVK_OK;
+}
+
+lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated)
+{
+    if (!e || !n_consumed || !updated || (n_feats > 0 && !feats) || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
+    *n_consumed = 0; *updated = 0;
+    e->up_off = 0;
+    if (!e->b_first_features) {
+        if (n_imu > 0 && imu[0].t - ts - e->td <= 0.0) e->b_first_features = true;
+        else return LVK_OK;
+    }
+    int off = 0;
+    if (!e->is_gravity_set) {
+        int erased = 0;
+        if (static_try_init(e, ts, feats, n_feats, imu, n_imu, &erased)) {
+            e->is_gravity_set = true;
+            e->take_off_stamp = e->s.t; e->last_zupt_time = e->s.t; e->last_update_time = e->s.t;
+            e->s_fej_now = e->s;
+            off = erased;
+        } else return LVK_OK;
+    }
+    const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
+    *n_consumed = off + used;
+    lvk_status st = apply_propagation(e);
+    if (st != LVK_OK) return st;
+    add_observations(e, feats, n_feats);
+    st = state_augmentation(e);
+    if (st != LVK_OK) return st;
+    if (e->cfg.if_zupt_valid) { bool z = false; st = check_zupt(e, &z); if (st != LVK_OK) return st; e->if_zupt = z; }
+    st = remove_lost_features(e);
+    if (st != LVK_OK) return st;
+    st = prune_imu_state_buffer(e);
+    if (st != LVK_OK) return st;
+    if (e->cfg.if_fej && !e->if_fej && e->s.t - e->take_off_stamp >= 0) e->if_fej = true;
+    e->counters[6] = (long)e->map.size();
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    *updated = 1;
+    return LVK_OK;
+}
+
+int lvk_ekf_dim(const lvk_ekf* e) { return e ? e->N : 0; }
+int lvk_ekf_is_initialized(const lvk_ekf* e) { return e && e->is_gravity_set ? 1 : 0; }
+lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* o)
+{
+    if (!e || !o) return LVK_ERR_ARG;
+    o[0] = e->s.t; memcpy(o + 1, e->s.q, 32); memcpy(o + 5, e->s.v, 24); memcpy(o + 8, e->s.p, 24); memcpy(o + 11, e->s.bg, 24); memcpy(o + 14, e->s.ba, 24);
+    memcpy(o + 17, e->R_b2c, 72); memcpy(o + 26, e->t_c_b, 24); o[29] = e->td;
+    return LVK_OK;
+}
+lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P)
+{
+    if (!e || !h_P) return LVK_ERR_ARG;
+    EKF_HIP(hipMemcpy2D(h_P, sizeof(double) * e->N, e->dP[e->cur], sizeof(double) * e->ld, sizeof(double) * e->N, e->N, hipMemcpyDeviceToHost));
+    return LVK_OK;
+}
+int lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* out, int cap)
+{
+    if (!e || !out) return 0;
+    int n = std::min((int)e->clones.size(), cap);
+    for (int i = 0; i < n; ++i) {
+        const Clone& c = e->clones[i]; lvk_clone& o = out[i];
+        o.id = c.id; o.time = c.time; o.dt = c.dt; memcpy(o.q, c.q, 32); memcpy(o.p, c.p, 24); memcpy(o.p_fej, c.p_fej, 24);
+        memcpy(o.R_b2c, c.R_b2c, 72); memcpy(o.t_c_b, c.t_c_b, 24); memcpy(o.q_cam, c.q_cam, 32); memcpy(o.p_cam, c.p_cam, 24);
+    }
+    return n;
+}
+int lvk_ekf_get_features(const lvk_ekf* e, int64_t* ids, double* inv_depth, double* pos_w, int cap)
+{
+    if (!e) return 0;
+    int n = std::min((int)e->feature_states.size(), cap);
+    for (int i = 0; i < n; ++i) {
+        const Feature& f = e->map.at(e->feature_states[i]);
+        ids[i] = f.id; inv_depth[i] = f.inv_depth; memcpy(pos_w + 3 * i, f.position, 24);
+    }
+    return n;
+}
+void lvk_ekf_counters(const lvk_ekf* e, long* out8) { if (e && out8) memcpy(out8, e->counters, sizeof e->counters); }
+
+}  // extern "C"

@@ -1,0 +1,346 @@
+// be_feature.hip — per-feature kernels of the EKF measurement update for gfx950 (wave64, FP64):
+//   k_triangulate  : Levenberg-Marquardt inverse-depth triangulation, one wavefront per feature
+//                    (/root/reference/include/larvio/feature.hpp:252-552; sums over views are taken in view
+//                    order so that the CPU oracle is reproduced bit-for-bit)
+//   k_feature_rows : one workgroup per feature: per-observation reprojection Jacobians
+//                    (larvio.cpp:859-921 MSCKF, :1117-1244 1-D inverse depth), Householder left-null-space
+//                    projection of the stacked block (:924-981; any orthonormal basis of null(H_f^T) gives the
+//                    same chi-square value and the same update), chi-square gate value
+//                    gamma = r^T (H P H^T + sigma^2 I)^-1 r (:1865-1880) on the touched columns of P only
+//   k_stack_rows   : scatter the accepted compact rows into the dense measurement matrix H_o
+// H blocks are kept COMPACT (only the columns a feature touches: extrinsics+td 15..21, the observing clones'
+// 6-column blocks, the anchor's block and the feature's own column) — the reference forms dense (2M-3) x N
+// blocks that are ~85 % zeros and multiplies them against the full P for every gate.
+#include "lvk_internal.h"
+#include "be_dev.h"
+
+// ========================================================================= triangulation
+__global__ void __launch_bounds__(64) k_triangulate(const TriJob* __restrict__ jobs, int n_jobs, const CamPose* __restrict__ cams,
+                                                   const int* __restrict__ obs_rank, const double* __restrict__ obs_z, TriResult* __restrict__ out)
+{
+    __shared__ double red[64][13];
+    const int jb = blockIdx.x;
+    if (jb >= n_jobs) return;
+    const TriJob job = jobs[jb];
+    const int lane = threadIdx.x & 63, n = job.n;
+    // rel_i = pose_i^-1 * pose_last  (feature.hpp:404-422)
+    double Rr[9], tr[3], z[2] = {0, 0};
+    const CamPose L = cams[obs_rank[job.obs_off + n - 1]];
+    if (lane < n) {
+        const CamPose Pi = cams[obs_rank[job.obs_off + lane]];
+        double Rt[9]; d_m3_t(Pi.R, Rt);
+        d_m3_mul(Rt, L.R, Rr);
+        double a[3], b[3]; d_m3_v(Rt, L.t, a); d_m3_v(Rt, Pi.t, b);
+        tr[0] = a[0] + (-b[0]); tr[1] = a[1] + (-b[1]); tr[2] = a[2] + (-b[2]);
+        z[0] = obs_z[2 * (job.obs_off + lane)]; z[1] = obs_z[2 * (job.obs_off + lane) + 1];
+    }
+    // share view 0's relative pose and the first/last observations (initial guess needs them)
+    double R0[9], t0[3], z_first[2], z_last[2];
+    for (int k = 0; k < 9; ++k) R0[k] = __shfl(Rr[k], 0);
+    for (int k = 0; k < 3; ++k) t0[k] = __shfl(tr[k], 0);
+    z_first[0] = __shfl(z[0], 0); z_first[1] = __shfl(z[1], 0);
+    z_last[0] = __shfl(z[0], n - 1); z_last[1] = __shfl(z[1], n - 1);
+    double ip[3];
+    if (!job.use_position) {
+        double v[3] = {z_last[0], z_last[1], 1.0}, m[3];
+        d_m3_v(R0, v, m);
+        double A0 = m[0] - z_first[0] * m[2], A1 = m[1] - z_first[1] * m[2];
+        double b0 = z_first[0] * t0[2] - t0[0], b1 = z_first[1] * t0[2] - t0[1];
+        double depth = (1.0 / (A0 * A0 + A1 * A1)) * A0 * b0 + (1.0 / (A0 * A0 + A1 * A1)) * A1 * b1;
+        ip[0] = z_last[0] * depth; ip[1] = z_last[1] * depth; ip[2] = depth;
+    } else {
+        double Lt[9]; d_m3_t(L.R, Lt);
+        double a[3], b[3]; d_m3_v(Lt, job.position_in, a); d_m3_v(Lt, L.t, b);
+        ip[0] = a[0] + (-b[0]); ip[1] = a[1] + (-b[1]); ip[2] = a[2] + (-b[2]);
+    }
+    double sol[3] = {ip[0] / ip[2], ip[1] / ip[2], 1.0 / ip[2]};
+    double lambda = 1e-3;
+    int inner = 0, outer = 0, reduced = 0;
+    double delta_norm = 0., total_cost = 0.;
+    // ordered sum of the per-view costs
+    auto cost_sum = [&](const double* x) -> double {
+        double c = 0.;
+        if (lane < n) c = d_tri_cost(Rr, tr, x, z);
+        red[lane][0] = c;
+        __syncthreads();
+        double s = 0.;
+        for (int i = 0; i < n; ++i) s += red[i][0];
+        __syncthreads();
+        return s;
+    };
+    total_cost = cost_sum(sol);
+    do {
+        double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        {
+            double J[6], r[2], w = 1.0;
+            if (lane < n) {
+                d_tri_jacobian(Rr, tr, sol, z, J, r, w);
+                const double w2 = (w == 1) ? 1.0 : w * w;
+                for (int p = 0; p < 3; ++p) {
+                    for (int q = 0; q < 3; ++q) { double jtj = J[p] * J[q] + J[3 + p] * J[3 + q]; red[lane][p * 3 + q] = (w == 1) ? jtj : w2 * jtj; }
+                    double jtr = J[p] * r[0] + J[3 + p] * r[1];
+                    red[lane][9 + p] = (w == 1) ? jtr : w2 * jtr;
+                }
+            }
+            __syncthreads();
+            for (int i = 0; i < n; ++i) { for (int k = 0; k < 9; ++k) A[k] += red[i][k]; for (int k = 0; k < 3; ++k) b[k] += red[i][9 + k]; }
+            __syncthreads();
+        }
+        do {
+            double Ad[9]; for (int k = 0; k < 9; ++k) Ad[k] = A[k];
+            Ad[0] += lambda; Ad[4] += lambda; Ad[8] += lambda;
+            double delta[3]; d_solve3_spd(Ad, b, delta);
+            double ns[3] = {sol[0] - delta[0], sol[1] - delta[1], sol[2] - delta[2]};
+            delta_norm = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+            double new_cost = cost_sum(ns);
+            if (new_cost < total_cost) {
+                reduced = 1; sol[0] = ns[0]; sol[1] = ns[1]; sol[2] = ns[2]; total_cost = new_cost;
+                lambda = lambda / 10 > 1e-10 ? lambda / 10 : 1e-10;
+            } else {
+                reduced = 0;
+                lambda = lambda * 10 < 1e12 ? lambda * 10 : 1e12;
+            }
+        } while (inner++ < 10 && !reduced);
+        inner = 0;
+    } while (outer++ < 10 && delta_norm > 5e-7);
+    const double fp[3] = {sol[0] / sol[2], sol[1] / sol[2], 1.0 / sol[2]};
+    int bad = 0;
+    if (lane < n) { double pz = Rr[6] * fp[0] + Rr[7] * fp[1] + Rr[8] * fp[2] + tr[2]; bad = pz <= 0; }
+    int valid = __ballot(bad) == 0ull;
+    const double normalized_cost = total_cost / (2 * n * n);
+    if (normalized_cost > 4.7673e-04) valid = 0;
+    if (lane == 0) {
+        TriResult o;
+        o.ok = valid;
+        double pw[3]; d_m3_v(L.R, fp, pw);
+        o.position[0] = pw[0] + L.t[0]; o.position[1] = pw[1] + L.t[1]; o.position[2] = pw[2] + L.t[2];
+        o.solution[0] = sol[0]; o.solution[1] = sol[1]; o.solution[2] = sol[2];
+        const double idp = 1 / fp[2];
+        o.inv_depth = idp;
+        o.obs_anchor[0] = fp[0] * idp; o.obs_anchor[1] = fp[1] * idp; o.obs_anchor[2] = 1;
+        out[jb] = o;
+    }
+}
+
+// ========================================================================= per-feature rows + gate
+// Staging slot of a job (doubles): G [rows_raw x c] | T [rows_raw x c] | r [rows_raw]; ccol ints kept separately.
+#define FR_THREADS 128
+__global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __restrict__ jobs, int n_jobs, const CloneDev* __restrict__ clones,
+                                                            const int* __restrict__ obs_rank, const double* __restrict__ obs_z, const double* __restrict__ obs_zv,
+                                                            const double* __restrict__ P, int ldp, FilterFlags fl,
+                                                            double* __restrict__ staging, int* __restrict__ ccols, FeatResult* __restrict__ out)
+{
+    extern __shared__ double sh[];
+    const int jb = blockIdx.x;
+    if (jb >= n_jobs) return;
+    const FeatJob job = jobs[jb];
+    const int t = threadIdx.x, M = job.n_obs;
+    const int rows = 2 * M;
+    const int nf = (job.type == JOB_MSCKF) ? 3 : 1;                  // columns of H_f
+    const int c = (job.type == JOB_MSCKF) ? 7 + 6 * M : 7 + 6 + 6 * M + 1;
+    double* G = staging + job.stage_off;
+    double* T = G + (size_t)rows * c;
+    double* rr = T + (size_t)rows * c;
+    int* cc = ccols + job.ccol_off;
+    // LDS: Hf [rows x 3] | v [rows] | S [k x k] | y [k] | scal[4]
+    double* Hf = sh;
+    double* v = Hf + rows * 3;
+    double* S = v + rows;
+    // ---- zero the block, write the compact column map
+    for (int e = t; e < rows * c; e += FR_THREADS) G[e] = 0.;
+    for (int e = t; e < c; e += FR_THREADS) {
+        int col;
+        if (e < 7) col = 15 + e;
+        else if (job.type == JOB_MSCKF) col = fl.leg_dim + 6 * obs_rank[job.obs_off + (e - 7) / 6] + (e - 7) % 6;
+        else if (e < 13) col = fl.leg_dim + 6 * job.anchor_rank + (e - 7);
+        else if (e < 13 + 6 * M) col = fl.leg_dim + 6 * obs_rank[job.obs_off + (e - 13) / 6] + (e - 13) % 6;
+        else col = job.fcol;
+        cc[e] = col;
+    }
+    __syncthreads();
+    // ---- per-observation Jacobians (one thread per observation)
+    if (t < M) {
+        const int oi = job.obs_off + t;
+        const CloneDev ck = clones[obs_rank[oi]];
+        const double z[2] = {obs_z[2 * oi], obs_z[2 * oi + 1]};
+        double Hx[12], He[12], r2[2];
+        if (job.type == JOB_MSCKF) {
+            double hf[6];
+            d_msckf_obs_jacobian(ck, job.p_w, z, fl.if_fej, Hx, He, hf, r2);
+            for (int a = 0; a < 2; ++a) {
+                double* row = G + (size_t)(2 * t + a) * c;
+                for (int j = 0; j < 6; ++j) row[j] = He[a * 6 + j];
+                if (fl.estimate_td) row[6] = obs_zv[2 * oi + a];
+                for (int j = 0; j < 6; ++j) row[7 + 6 * t + j] = Hx[a * 6 + j];
+                for (int j = 0; j < 3; ++j) Hf[(2 * t + a) * 3 + j] = hf[a * 3 + j];
+                rr[2 * t + a] = r2[a];
+            }
+        } else {
+            const CloneDev ca = clones[job.anchor_rank];
+            double hf[2], Ha[12];
+            d_ekf_obs_jacobian(ck, ca, job, z, fl.if_fej, hf, Ha, Hx, He, r2);
+            for (int a = 0; a < 2; ++a) {
+                double* row = G + (size_t)(2 * t + a) * c;
+                for (int j = 0; j < 6; ++j) row[j] = He[a * 6 + j];
+                if (fl.estimate_td) row[6] = obs_zv[2 * oi + a];
+                for (int j = 0; j < 6; ++j) row[7 + j] = Ha[a * 6 + j];
+                for (int j = 0; j < 6; ++j) row[13 + 6 * t + j] = Hx[a * 6 + j];
+                row[c - 1] = hf[a];
+                Hf[(2 * t + a) * 3] = hf[a];
+                rr[2 * t + a] = r2[a];
+            }
+        }
+    }
+    __syncthreads();
+    int first_row = 0, k_rows = rows;
+    double h2 = 0.;
+    if (job.type != JOB_EKF_TRACKED) {
+        // ---- Householder on H_f, applied to [G | r]  (oracle householder_apply / the rotation W of larvio.cpp:2095-2119)
+        const int gcols = (job.type == JOB_MSCKF) ? c : c - 1;       // the feature column of an EKF block is H_f itself
+        for (int k = 0; k < nf && k < rows; ++k) {
+            double nrm2 = 0.;
+            for (int i = k; i < rows; ++i) nrm2 += Hf[i * 3 + k] * Hf[i * 3 + k];     // every thread: same ordered sum
+            const double nrm = sqrt(nrm2);
+            if (nrm == 0.) continue;
+            const double alpha = Hf[k * 3 + k] >= 0. ? -nrm : nrm;
+            __syncthreads();
+            for (int i = k + t; i < rows; i += FR_THREADS) v[i] = Hf[i * 3 + k] - (i == k ? alpha : 0.);
+            __syncthreads();
+            double vn2 = 0.;
+            for (int i = k; i < rows; ++i) vn2 += v[i] * v[i];
+            if (vn2 == 0.) continue;
+            const double beta = 2. / vn2;
+            if (k == 0) h2 = alpha;
+            // H_f columns k.. (few): thread q handles column k+q
+            if (t < nf - k) {
+                const int col = k + t;
+                double s = 0.; for (int i = k; i < rows; ++i) s += v[i] * Hf[i * 3 + col];
+                s *= beta;
+                for (int i = k; i < rows; ++i) Hf[i * 3 + col] -= s * v[i];
+            }
+            for (int col = t; col < gcols; col += FR_THREADS) {
+                double s = 0.; for (int i = k; i < rows; ++i) s += v[i] * G[(size_t)i * c + col];
+                if (s == 0.) continue;
+                s *= beta;
+                for (int i = k; i < rows; ++i) G[(size_t)i * c + col] -= s * v[i];
+            }
+            if (t == FR_THREADS - 1) {
+                double s = 0.; for (int i = k; i < rows; ++i) s += v[i] * rr[i];
+                s *= beta;
+                for (int i = k; i < rows; ++i) rr[i] -= s * v[i];
+            }
+            __syncthreads();
+        }
+        first_row = nf; k_rows = rows - nf;
+        if (job.type == JOB_EKF_NEW) {
+            // the null rows' feature column is zero after the rotation; the range row keeps H_2 = alpha in it
+            for (int i = 1 + t; i < rows; i += FR_THREADS) G[(size_t)i * c + c - 1] = 0.;
+            if (t == 0) G[c - 1] = h2;
+            __syncthreads();
+        }
+    }
+    // ---- gate: S = G' P_cc G'^T + sigma2 I on rows first_row.. ; gamma = r'^T S^-1 r'
+    double gamma = 0.;
+    if (job.want_gate && k_rows > 0) {
+        const int k = k_rows;
+        const double* Gp = G + (size_t)first_row * c;
+        for (int e = t; e < k * c; e += FR_THREADS) {
+            int a = e / c, j = e - a * c;
+            double s = 0.;
+            const int colj = cc[j];
+            for (int i = 0; i < c; ++i) { const double g = Gp[(size_t)a * c + i]; if (g != 0.) s += g * P[(size_t)cc[i] * ldp + colj]; }
+            T[(size_t)a * c + j] = s;
+        }
+        __syncthreads();
+        for (int e = t; e < k * k; e += FR_THREADS) {
+            int a = e / k, b = e - a * k;
+            if (b > a) continue;
+            double s = 0.;
+            for (int i = 0; i < c; ++i) s += T[(size_t)a * c + i] * Gp[(size_t)b * c + i];
+            S[a * k + b] = s + (a == b ? fl.sigma2 : 0.);
+        }
+        __syncthreads();
+        // Cholesky in LDS (column by column), then forward substitution on r'
+        int fail = 0;
+        for (int j = 0; j < k; ++j) {
+            double d = S[j * k + j];
+            for (int q = 0; q < j; ++q) d -= S[j * k + q] * S[j * k + q];
+            if (!(d > 0.)) { fail = 1; break; }
+            d = sqrt(d);
+            __syncthreads();
+            if (t == 0) S[j * k + j] = d;
+            for (int i = j + 1 + t; i < k; i += FR_THREADS) {
+                double s = S[i * k + j];
+                for (int q = 0; q < j; ++q) s -= S[i * k + q] * S[j * k + q];
+                S[i * k + j] = s / d;
+            }
+            __syncthreads();
+        }
+        if (fail) gamma = 1e300;
+        else {
+            double* y = S + k * k;
+            if (t == 0) {
+                for (int i = 0; i < k; ++i) {
+                    double s = rr[first_row + i];
+                    for (int q = 0; q < i; ++q) s -= S[i * k + q] * y[q];
+                    y[i] = s / S[i * k + i];
+                }
+                double g = 0.; for (int i = 0; i < k; ++i) g += y[i] * y[i];
+                y[k] = g;
+            }
+            __syncthreads();
+            gamma = y[k];
+        }
+    }
+    if (t == 0) { FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2; out[jb] = o; }
+}
+
+// dense H row d <- compact row src (job staging) ; r[d] likewise.  One workgroup per destination row.
+__global__ void __launch_bounds__(128) k_stack_rows(const StackRow* __restrict__ map, int n_rows, const double* __restrict__ staging,
+                                                   const int* __restrict__ ccols, double* __restrict__ H, int ldh, int ncols, double* __restrict__ r)
+{
+    const int d = blockIdx.x;
+    if (d >= n_rows) return;
+    const StackRow m = map[d];
+    double* row = H + (size_t)m.dst_row * ldh;
+    for (int j = threadIdx.x; j < ncols; j += 128) row[j] = 0.;
+    __syncthreads();
+    const double* src = staging + m.g_off + (size_t)m.src_row * m.c;
+    const int* cc = ccols + m.ccol_off;
+    for (int j = threadIdx.x; j < m.c; j += 128) { const int col = cc[j]; if (col >= 0 && col < ncols) row[col] = src[j]; }
+    if (threadIdx.x == 0) r[m.dst_row] = staging[m.r_off + m.src_row];
+}
+
+// ========================================================================= host launchers (internal)
+lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z,
+                                  TriResult* d_out)
+{
+    if (n_jobs <= 0) return LVK_OK;
+    hipLaunchKernelGGL(k_triangulate, dim3(n_jobs), dim3(64), 0, ctx->stream, d_jobs, n_jobs, d_cams, d_rank, d_z, d_out);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
+                                   const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging,
+                                   int* d_ccols, FeatResult* d_out)
+{
+    if (n_jobs <= 0) return LVK_OK;
+    const size_t shmem = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
+    if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_feature_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_feature_rows, dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv, d_P, ldp, fl,
+                       d_staging, d_ccols, d_out);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+lvk_status lvk_launch_stack_rows(lvk_context* ctx, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh,
+                                 int ncols, double* d_r)
+{
+    if (n_rows <= 0) return LVK_OK;
+    hipLaunchKernelGGL(k_stack_rows, dim3(n_rows), dim3(128), 0, ctx->stream, d_map, n_rows, d_staging, d_ccols, d_H, ldh, ncols, d_r);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}

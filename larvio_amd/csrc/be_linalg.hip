@@ -1,0 +1,353 @@
+// be_linalg.hip — FP64 dense algebra of the EKF measurement update for gfx950 (wave64).
+// Replaces the Eigen expressions of /root/reference/src/larvio.cpp:1453-1460,1578-1594 (and the identical
+// blocks at :1651-1659,1803-1819 and :2826-2834,2938-2957):
+//     S = H P H^T + sigma^2 I ;  K^T = S.ldlt().solve(H P) ;  dx = K r ;  P <- (I - K H) P ;  P <- (P + P^T)/2
+// as   HP = H P (MFMA f64) ; S = HP H^T + sigma^2 I (MFMA f64) ; S = L L^T ; W = L^-1 [HP | r] ;
+//      dx = W^T w_r ; P <- P - W^T W (MFMA f64, symmetric by construction: K H P = (HP)^T S^-1 (HP)).
+// Covariance entries span ~1e-8..1 and parity is 1e-5 relative on P, so everything is FP64; the dense
+// contractions use v_mfma_f64_16x16x4_f64 (one 16x16 tile per wavefront, operands straight from L2: the
+// matrices are <= ~2 MB and the update is latency-, not bandwidth-bound at N ~ 232).
+// All matrices are ROW-MAJOR with a leading dimension in doubles.
+#include "lvk_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------- MFMA f64 GEMM
+// C (M x N) = alpha * op(A) (M x K) * op(B) (K x N) + beta * C ; optional diag_add on the diagonal.
+// v_mfma_f64_16x16x4_f64: lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// D: col = l&15, row = (l>>4) + 4*reg  (f64 has its own C/D map, cdna_hip_programming.md §3).
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                              double* __restrict__ C, int ldc, double alpha, double beta, double diag_add)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.y * 2 + (wave >> 1)) * 16, col0 = (blockIdx.x * 2 + (wave & 1)) * 16;
+    if (row0 >= M || col0 >= N) return;
+    const int i = lane & 15, kk = lane >> 4;
+    const int ar = row0 + i, bc = col0 + i;
+    const bool a_ok = ar < M, b_ok = bc < N;
+    d4 acc = {0., 0., 0., 0.};
+    int k0 = 0;
+    for (; k0 + 16 <= K; k0 += 16) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + kk;
+            a[u] = a_ok ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
+            b[u] = b_ok ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 4) {
+        const int k = k0 + kk;
+        const bool k_ok = k < K;
+        double a = (a_ok && k_ok) ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
+        double b = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + kk + 4 * r, col = col0 + i;
+        if (row < M && col < N) {
+            double v = alpha * acc[r];
+            if (beta != 0.) v += beta * C[(size_t)row * ldc + col];
+            if (row == col) v += diag_add;
+            C[(size_t)row * ldc + col] = v;
+        }
+    }
+}
+
+template <bool TA, bool TB>
+static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
+                         double alpha, double beta, double diag_add)
+{
+    if (M <= 0 || N <= 0) return;
+    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add);
+}
+
+// ------------------------------------------------------------------------- Cholesky (one workgroup)
+// Right-looking, panel width 32, lower triangle in place.  m <= CH_MAX_M.  info[0] = first non-positive pivot + 1 (0 = ok).
+#define CH_NB 32
+#define CH_MAX_M 544
+__global__ void __launch_bounds__(1024) k_chol_single(double* __restrict__ S, int m, int ld, int* __restrict__ info)
+{
+    extern __shared__ double sh[];
+    double* Ld = sh;                          // CH_NB x (CH_NB+1)
+    double* X = sh + CH_NB * (CH_NB + 1);     // (m) x CH_NB panel below the diagonal block
+    const int t = threadIdx.x;
+    if (t == 0) info[0] = 0;
+    for (int j0 = 0; j0 < m; j0 += CH_NB) {
+        const int nb = min(CH_NB, m - j0);
+        for (int e = t; e < nb * nb; e += 1024) { int a = e / nb, b = e - a * nb; Ld[a * (CH_NB + 1) + b] = S[(size_t)(j0 + a) * ld + j0 + b]; }
+        __syncthreads();
+        // unblocked factorisation of the nb x nb block
+        for (int j = 0; j < nb; ++j) {
+            if (t == 0) {
+                double d = Ld[j * (CH_NB + 1) + j];
+                if (!(d > 0.)) { if (info[0] == 0) info[0] = j0 + j + 1; d = 1.0; }
+                Ld[j * (CH_NB + 1) + j] = sqrt(d);
+            }
+            __syncthreads();
+            const double djj = Ld[j * (CH_NB + 1) + j];
+            if (t > j && t < nb) Ld[t * (CH_NB + 1) + j] /= djj;
+            __syncthreads();
+            // rank-1 update of the trailing part of the block (lower triangle)
+            for (int e = t; e < (nb - j - 1) * (nb - j - 1); e += 1024) {
+                int a = j + 1 + e / (nb - j - 1), b = j + 1 + e % (nb - j - 1);
+                if (b <= a) Ld[a * (CH_NB + 1) + b] -= Ld[a * (CH_NB + 1) + j] * Ld[b * (CH_NB + 1) + j];
+            }
+            __syncthreads();
+        }
+        for (int e = t; e < nb * nb; e += 1024) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * ld + j0 + b] = Ld[a * (CH_NB + 1) + b]; }
+        const int rest = m - j0 - nb;
+        if (rest <= 0) break;
+        // panel: X = A21 * L11^-T, one thread per row
+        for (int rix = t; rix < rest; rix += 1024) {
+            double x[CH_NB];
+            const double* arow = S + (size_t)(j0 + nb + rix) * ld + j0;
+            for (int c = 0; c < nb; ++c) {
+                double s = arow[c];
+                for (int k = 0; k < c; ++k) s -= x[k] * Ld[c * (CH_NB + 1) + k];
+                x[c] = s / Ld[c * (CH_NB + 1) + c];
+            }
+            for (int c = 0; c < nb; ++c) { X[(size_t)rix * CH_NB + c] = x[c]; S[(size_t)(j0 + nb + rix) * ld + j0 + c] = x[c]; }
+        }
+        __syncthreads();
+        // trailing update A22 -= X X^T (lower triangle)
+        const int tot = rest * rest;
+        for (int e = t; e < tot; e += 1024) {
+            int a = e / rest, b = e - a * rest;
+            if (b > a) continue;
+            double s = 0.;
+            for (int c = 0; c < nb; ++c) s += X[(size_t)a * CH_NB + c] * X[(size_t)b * CH_NB + c];
+            S[(size_t)(j0 + nb + a) * ld + j0 + nb + b] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------- W = L^-1 B (forward substitution, many right-hand sides)
+// one workgroup per chunk of TR_NC columns of B (m x nc); row panels of 32.
+#define TR_NC 32
+__global__ void __launch_bounds__(256) k_trsm_lower(const double* __restrict__ L, int m, int ldl, double* __restrict__ B, int nc, int ldb)
+{
+    __shared__ double Lp[32][33];
+    __shared__ double Wp[32][TR_NC + 1];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * TR_NC, ncb = min(TR_NC, nc - c0);
+    for (int p0 = 0; p0 < m; p0 += 32) {
+        const int nb = min(32, m - p0);
+        for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; Lp[a][b] = L[(size_t)(p0 + a) * ldl + p0 + b]; }
+        for (int e = t; e < nb * ncb; e += 256) { int a = e / ncb, c = e - a * ncb; Wp[a][c] = B[(size_t)(p0 + a) * ldb + c0 + c]; }
+        __syncthreads();
+        if (t < ncb) {
+            for (int a = 0; a < nb; ++a) {
+                double s = Wp[a][t];
+                for (int k = 0; k < a; ++k) s -= Lp[a][k] * Wp[k][t];
+                Wp[a][t] = s / Lp[a][a];
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < nb * ncb; e += 256) { int a = e / ncb, c = e - a * ncb; B[(size_t)(p0 + a) * ldb + c0 + c] = Wp[a][c]; }
+        // rows below: B[i][c] -= sum_k L[i][p0+k] W[k][c]
+        const int rest = m - p0 - nb;
+        for (int e = t; e < rest * ncb; e += 256) {
+            int a = e / ncb, c = e - a * ncb;
+            const double* lrow = L + (size_t)(p0 + nb + a) * ldl + p0;
+            double s = 0.;
+            for (int k = 0; k < nb; ++k) s += lrow[k] * Wp[k][c];
+            B[(size_t)(p0 + nb + a) * ldb + c0 + c] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// dx[j] = sum_i W[i][j] * W[i][wcol]  (K r = (HP)^T S^-1 r)
+__global__ void k_dx_from_w(const double* __restrict__ W, int m, int ldw, int n, int wcol, double* __restrict__ dx)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.;
+    for (int i = 0; i < m; ++i) s += W[(size_t)i * ldw + j] * W[(size_t)i * ldw + wcol];
+    dx[j] = s;
+}
+__global__ void k_set_column(double* __restrict__ B, int ldb, int col, const double* __restrict__ v, int m)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) B[(size_t)i * ldb + col] = v[i];
+}
+
+// ------------------------------------------------------------------------- structural covariance operations
+// Pout[a][b] = Pin[idx[a]][idx[b]]   (clone augmentation larvio.cpp:752-798, row/col deletion :2563-2638, :3311-3327)
+__global__ void k_cov_gather(const double* __restrict__ Pin, int ldin, double* __restrict__ Pout, int ldout, const int* __restrict__ idx, int n)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+    if (b >= n || a >= n) return;
+    Pout[(size_t)a * ldout + b] = Pin[(size_t)idx[a] * ldin + idx[b]];
+}
+
+// IMU propagation of the covariance (processModel, larvio.cpp:553-571) with the per-frame composed Phi (L x L) and Q:
+//   P_II <- sym(Phi P_II Phi^T + Q) ; P_IC <- Phi P_IC ; P_CI <- P_IC^T.    phiq = [Phi | Q] (2*L*L doubles).
+__global__ void __launch_bounds__(256) k_cov_propagate(double* __restrict__ P, int ld, int n, int L, const double* __restrict__ phiq)
+{
+    extern __shared__ double sh[];
+    double* Phi = sh;                 // L x L
+    double* Q = sh + L * L;           // L x L
+    double* T = Q + L * L;            // L x L  : Phi * P_II
+    double* R = T + L * L;            // L x n  : old rows 0..L-1 of P
+    const int t = threadIdx.x;
+    for (int e = t; e < 2 * L * L; e += 256) sh[e] = phiq[e];
+    for (int e = t; e < L * n; e += 256) { int i = e / n, j = e - i * n; R[e] = P[(size_t)i * ld + j]; }
+    __syncthreads();
+    for (int e = t; e < L * L; e += 256) {
+        int i = e / L, j = e - i * L; double s = 0.;
+        for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * n + j];
+        T[e] = s;
+    }
+    // P_IC = Phi * R[:, L:]
+    for (int e = t; e < L * (n - L); e += 256) {
+        int i = e / (n - L), j = L + e % (n - L); double s = 0.;
+        for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * n + j];
+        P[(size_t)i * ld + j] = s; P[(size_t)j * ld + i] = s;
+    }
+    __syncthreads();
+    for (int e = t; e < L * L; e += 256) {
+        int i = e / L, j = e - i * L;
+        if (j > i) continue;
+        double s1 = 0., s2 = 0.;
+        for (int k = 0; k < L; ++k) { s1 += T[i * L + k] * Phi[j * L + k]; s2 += T[j * L + k] * Phi[i * L + k]; }
+        double v = ((s1 + Q[i * L + j]) + (s2 + Q[j * L + i])) / 2.0;
+        P[(size_t)i * ld + j] = v; P[(size_t)j * ld + i] = v;
+    }
+}
+
+// re-anchoring of a 1-D inverse-depth feature (updateFeatureCov_1didp, larvio.cpp:3125-3293): row/col fc <- J P, J P J^T
+__global__ void __launch_bounds__(256) k_cov_reanchor(double* __restrict__ P, int ld, int n, const double* __restrict__ J, int fc)
+{
+    extern __shared__ double pf[];     // n
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    for (int b = t; b < n; b += 256) { double s = 0.; for (int k = 0; k < n; ++k) s += J[k] * P[(size_t)k * ld + b]; pf[b] = s; }
+    __syncthreads();
+    double part = 0.;
+    for (int k = t; k < n; k += 256) part += pf[k] * J[k];
+    red[t] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    for (int b = t; b < n; b += 256) if (b != fc) { P[(size_t)fc * ld + b] = pf[b]; P[(size_t)b * ld + fc] = pf[b]; }
+    if (t == 0) P[(size_t)fc * ld + fc] = red[0];
+}
+
+// delayed initialisation of new in-state features (larvio.cpp:1821-1854), 1-D: HH = diag(H2)^-1 H1 (nn x n);
+// rows/cols n..n+nn-1 of P:  P_new,old = -HH P ; P_new,new = HH P HH^T + sigma2 / H2^2 (diag).  tmp: nn x n scratch.
+__global__ void __launch_bounds__(256) k_cov_append_features(double* __restrict__ P, int ld, int n, int nn, const double* __restrict__ H1, int ldh,
+                                                            const double* __restrict__ H2, double sigma2, double* __restrict__ tmp)
+{
+    const int t = threadIdx.x;
+    for (int e = t; e < nn * n; e += 256) {
+        int j = e / n, b = e - j * n; double s = 0.;
+        for (int k = 0; k < n; ++k) s += (H1[(size_t)j * ldh + k] / H2[j]) * P[(size_t)k * ld + b];
+        tmp[e] = -s;
+    }
+    __syncthreads();
+    for (int e = t; e < nn * n; e += 256) { int j = e / n, b = e - j * n; P[(size_t)(n + j) * ld + b] = tmp[e]; P[(size_t)b * ld + n + j] = tmp[e]; }
+    for (int e = t; e < nn * nn; e += 256) {
+        int j = e / nn, l = e - j * nn;
+        if (l > j) continue;
+        double s1 = 0., s2 = 0.;
+        for (int k = 0; k < n; ++k) { s1 += tmp[(size_t)j * n + k] * (H1[(size_t)l * ldh + k] / H2[l]); s2 += tmp[(size_t)l * n + k] * (H1[(size_t)j * ldh + k] / H2[j]); }
+        double a = -s1 + (j == l ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0), b = -s2 + (j == l ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0);
+        double v = (a + b) / 2.0;
+        P[(size_t)(n + j) * ld + n + l] = v; P[(size_t)(n + l) * ld + n + j] = v;
+    }
+}
+__global__ void k_dx_new(const double* __restrict__ H1, int ldh, const double* __restrict__ H2, const double* __restrict__ r1, const double* __restrict__ dx,
+                         int n, int nn, double* __restrict__ dx_new)
+{   // dx_new = -HH dx_leg + H2^-1 r1
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nn) return;
+    double s = 0.;
+    for (int k = 0; k < n; ++k) s += (H1[(size_t)j * ldh + k] / H2[j]) * dx[k];
+    dx_new[j] = -s + r1[j] / H2[j];
+}
+
+// ------------------------------------------------------------------------- host drivers (internal + C ABI)
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; };
+
+// dx (device, n) and P updated in place.  B: m x (n+1) workspace, S: m x m workspace.
+lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2,
+                           double* dx, UpdateWs ws)
+{
+    if (m <= 0) { LVK_HIP(ctx, hipMemsetAsync(dx, 0, sizeof(double) * (size_t)n, ctx->stream)); return LVK_OK; }
+    if (m > CH_MAX_M) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "update with %d rows exceeds %d (compress first)", m, CH_MAX_M);
+    hipStream_t s = ctx->stream;
+    launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0);                   // HP = H P
+    hipLaunchKernelGGL(k_set_column, dim3((m + 255) / 256), dim3(256), 0, s, ws.B, ws.ldb, n, r, m);       // [HP | r]
+    launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
+    const size_t shmem = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)m * CH_NB);
+    hipLaunchKernelGGL(k_chol_single, dim3(1), dim3(1024), shmem, s, ws.S, m, ws.lds, ws.info);
+    hipLaunchKernelGGL(k_trsm_lower, dim3((n + 1 + TR_NC - 1) / TR_NC), dim3(256), 0, s, (const double*)ws.S, m, ws.lds, ws.B, n + 1, ws.ldb);
+    hipLaunchKernelGGL(k_dx_from_w, dim3((n + 127) / 128), dim3(128), 0, s, (const double*)ws.B, m, ws.ldb, n, n, dx);
+    launch_dgemm<true, false>(s, n, n, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0);              // P -= W^T W
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n)
+{
+    hipLaunchKernelGGL(k_cov_gather, dim3((n + 127) / 128, n), dim3(128), 0, ctx->stream, Pin, ldin, Pout, ldout, d_idx, n);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq)
+{
+    const size_t shmem = sizeof(double) * ((size_t)3 * L * L + (size_t)L * n);
+    if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n);
+    hipLaunchKernelGGL(k_cov_propagate, dim3(1), dim3(256), shmem, ctx->stream, P, ld, n, L, d_phiq);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const double* d_J, int fc)
+{
+    hipLaunchKernelGGL(k_cov_reanchor, dim3(1), dim3(256), sizeof(double) * (size_t)n, ctx->stream, P, ld, n, d_J, fc);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, int nn, const double* H1, int ldh, const double* H2, const double* r1,
+                                   const double* dx, double sigma2, double* tmp, double* dx_new)
+{
+    if (nn <= 0) return LVK_OK;
+    hipLaunchKernelGGL(k_dx_new, dim3((nn + 63) / 64), dim3(64), 0, ctx->stream, H1, ldh, H2, r1, dx, n, nn, dx_new);
+    hipLaunchKernelGGL(k_cov_append_features, dim3(1), dim3(256), 0, ctx->stream, P, ld, n, nn, H1, ldh, H2, sigma2, tmp);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+extern "C" lvk_status lvk_ekf_update(lvk_context* ctx, double* d_P, int ldp, int n, const double* d_H, int ldh, int m, const double* d_r,
+                                     double sigma2, double* d_dx)
+{
+    if (!ctx || !d_P || !d_dx || n <= 0 || m < 0 || (m > 0 && (!d_H || !d_r)) || ldp < n || ldh < n)
+        return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_update: bad argument");
+    UpdateWs ws;
+    ws.ldb = (n + 1 + 7) & ~7; ws.lds = (m + 7) & ~7;
+    ws.B = (double*)lvk_ctx_scratch(ctx, 4, sizeof(double) * (size_t)(m > 0 ? m : 1) * ws.ldb);
+    ws.S = (double*)lvk_ctx_scratch(ctx, 5, sizeof(double) * (size_t)(m > 0 ? m : 1) * (ws.lds > 0 ? ws.lds : 8));
+    ws.info = (int*)lvk_ctx_scratch(ctx, 6, 64);
+    if (!ws.B || !ws.S || !ws.info) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
+    return lvk_update_core(ctx, d_P, ldp, n, d_H, ldh, m, d_r, sigma2, d_dx, ws);
+}
+
+extern "C" lvk_status lvk_dgemm(lvk_context* ctx, int transa, int transb, int M, int N, int K, double alpha, const double* d_A, int lda,
+                                const double* d_B, int ldb, double beta, double* d_C, int ldc)
+{
+    if (!ctx || !d_A || !d_B || !d_C) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_dgemm: bad argument");
+    hipStream_t s = ctx->stream;
+    if (!transa && !transb) launch_dgemm<false, false>(s, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, alpha, beta, 0.0);
+    else if (!transa && transb) launch_dgemm<false, true>(s, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, alpha, beta, 0.0);
+    else if (transa && !transb) launch_dgemm<true, false>(s, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, alpha, beta, 0.0);
+    else launch_dgemm<true, true>(s, M, N, K, d_A, lda, d_B, ldb, d_C, ldc, alpha, beta, 0.0);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}

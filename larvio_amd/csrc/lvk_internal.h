@@ -9,7 +9,7 @@
 #define LVK_MAX_LEVELS 8
 #define LVK_ORB_BORDER 32
 
-#define LVK_SCRATCH_SLOTS 4
+#define LVK_SCRATCH_SLOTS 12
 struct lvk_context {
     int device;
     hipStream_t stream;

@@ -1,0 +1,175 @@
+"""LarVio — host-side mirror of larvio::LarVio over the C ABI (include/lvk_c.h, back-end section).
+
+Same surface as the reference class (include/larvio/larvio.h:37-90): construct with the configuration,
+``initialize()``, then ``processFeatures(msg, imu_buffer)`` per feature message; getters for pose / velocity /
+covariance / sliding window / map points.  The arithmetic runs in liblvk_hip.so on the GPU; like the reference,
+``processFeatures`` erases the IMU samples it consumed from the caller's buffer (larvio.cpp:511-512).
+"""
+import ctypes as C
+import numpy as np
+from ._lib import lib, _p, Context, LvkError, IMU, OBS
+
+CLONE = np.dtype([("id", np.int64), ("time", np.float64), ("dt", np.float64), ("q", np.float64, 4), ("p", np.float64, 3),
+                  ("p_fej", np.float64, 3), ("R_b2c", np.float64, 9), ("t_c_b", np.float64, 3), ("q_cam", np.float64, 4),
+                  ("p_cam", np.float64, 3)])
+
+_CFG_INT = ["if_fej", "estimate_extrin", "estimate_td", "if_zupt_valid", "sw_size", "max_track_len", "least_observation_number",
+            "max_features_in_one_grid", "aug_grid_rows", "aug_grid_cols", "pub_frequency", "imu_rate", "width", "height"]
+_CFG_DBL = ["td", "noise_gyro", "noise_acc", "noise_gyro_bias", "noise_acc_bias", "noise_feature",
+            "initial_covariance_orientation", "initial_covariance_velocity", "initial_covariance_position",
+            "initial_covariance_gyro_bias", "initial_covariance_acc_bias", "initial_covariance_extrin_rot",
+            "initial_covariance_extrin_trans", "rotation_threshold", "translation_threshold", "tracking_rate_threshold",
+            "feature_translation_threshold", "zupt_max_feature_dis", "zupt_noise_v", "zupt_noise_p", "zupt_noise_q", "static_duration"]
+
+
+class EkfConfig(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in _CFG_INT] + [("intrinsics", C.c_double * 4), ("T_cam_imu", C.c_double * 16)] +
+                [(k, C.c_double) for k in _CFG_DBL] +
+                [("feature_idp_dim", C.c_int), ("use_schmidt", C.c_int), ("calib_imu_instrinsic", C.c_int), ("max_features", C.c_int)])
+
+
+_sig_done = False
+
+
+def _L():
+    global _sig_done
+    L = lib()
+    if not _sig_done:
+        vp, i, d = C.c_void_p, C.c_int, C.c_double
+        pi = C.POINTER(C.c_int)
+        L.lvk_ekf_compress_qr.argtypes = [vp, vp, i, i, i, vp, pi]; L.lvk_ekf_compress_qr.restype = i
+        L.lvk_ekf_update.argtypes = [vp, vp, i, i, vp, i, i, vp, d, vp]; L.lvk_ekf_update.restype = i
+        L.lvk_dgemm.argtypes = [vp, i, i, i, i, i, d, vp, i, vp, i, d, vp, i]; L.lvk_dgemm.restype = i
+        L.lvk_ekf_create.argtypes = [vp, C.POINTER(EkfConfig), C.POINTER(vp)]; L.lvk_ekf_create.restype = i
+        L.lvk_ekf_destroy.argtypes = [vp]; L.lvk_ekf_destroy.restype = None
+        L.lvk_ekf_process.argtypes = [vp, d, vp, i, vp, i, pi, pi]; L.lvk_ekf_process.restype = i
+        L.lvk_ekf_set_state.argtypes = [vp, d, vp, vp, vp, vp, vp, vp, vp]; L.lvk_ekf_set_state.restype = i
+        L.lvk_ekf_dim.argtypes = [vp]; L.lvk_ekf_dim.restype = i
+        L.lvk_ekf_is_initialized.argtypes = [vp]; L.lvk_ekf_is_initialized.restype = i
+        L.lvk_ekf_get_state.argtypes = [vp, vp]; L.lvk_ekf_get_state.restype = i
+        L.lvk_ekf_get_cov.argtypes = [vp, vp]; L.lvk_ekf_get_cov.restype = i
+        L.lvk_ekf_get_clones.argtypes = [vp, vp, i]; L.lvk_ekf_get_clones.restype = i
+        L.lvk_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvk_ekf_get_features.restype = i
+        L.lvk_ekf_counters.argtypes = [vp, vp]; L.lvk_ekf_counters.restype = None
+        _sig_done = True
+    return L
+
+
+# ---------------------------------------------------------------- stage-level wrappers (numpy in / numpy out)
+def dgemm(ctx, A, B, transa=False, transb=False, alpha=1.0, beta=0.0, Cin=None):
+    A = np.ascontiguousarray(A, np.float64); B = np.ascontiguousarray(B, np.float64)
+    M = A.shape[1] if transa else A.shape[0]; K = A.shape[0] if transa else A.shape[1]; N = B.shape[0] if transb else B.shape[1]
+    Cm = np.zeros((M, N)) if Cin is None else np.array(Cin, np.float64, order="C")
+    dA, dB, dC = ctx.to_device(A), ctx.to_device(B), ctx.to_device(Cm)
+    ctx.check(_L().lvk_dgemm(ctx.h, int(transa), int(transb), M, N, K, alpha, _p(dA), A.shape[1], _p(dB), B.shape[1], beta, _p(dC), N))
+    return ctx.to_host(dC, np.float64, (M, N))
+
+
+def ekf_update(ctx, P, H, r, sigma2):
+    P = np.array(P, np.float64, order="C"); H = np.ascontiguousarray(H, np.float64); r = np.ascontiguousarray(r, np.float64)
+    n, m = P.shape[0], H.shape[0]
+    dP, dH, dr, ddx = ctx.to_device(P), ctx.to_device(H), ctx.to_device(r), ctx.alloc(8 * n)
+    ctx.check(_L().lvk_ekf_update(ctx.h, _p(dP), n, n, _p(dH), H.shape[1], m, _p(dr), sigma2, _p(ddx)))
+    return ctx.to_host(ddx, np.float64, (n,)), ctx.to_host(dP, np.float64, (n, n))
+
+
+def compress_qr(ctx, H, r):
+    H = np.array(H, np.float64, order="C"); r = np.array(r, np.float64)
+    rows, cols = H.shape
+    dH, dr = ctx.to_device(H), ctx.to_device(r)
+    out = C.c_int(0)
+    ctx.check(_L().lvk_ekf_compress_qr(ctx.h, _p(dH), cols, rows, cols, _p(dr), C.byref(out)))
+    k = out.value
+    return ctx.to_host(dH, np.float64, (rows, cols))[:k].copy(), ctx.to_host(dr, np.float64, (rows,))[:k].copy()
+
+
+class LarVio:
+    def __init__(self, config, ctx=None):
+        """config: dict with the keys LarVio::loadParameters reads (larvio.cpp:58-311); see synthetic.backend_config."""
+        self.config = dict(config)
+        self.ctx = ctx
+        self._h = None
+
+    def initialize(self):
+        if self.ctx is None:
+            self.ctx = Context()
+        c = EkfConfig()
+        for k in _CFG_INT + _CFG_DBL:
+            setattr(c, k, self.config[k])
+        c.intrinsics = (C.c_double * 4)(*self.config["intrinsics"])
+        c.T_cam_imu = (C.c_double * 16)(*np.asarray(self.config["T_cam_imu"], np.float64).reshape(16))
+        c.feature_idp_dim = self.config.get("feature_idp_dim", 1); c.use_schmidt = self.config.get("use_schmidt", 0)
+        c.calib_imu_instrinsic = self.config.get("calib_imu_instrinsic", 0); c.max_features = self.config.get("max_features", 0)
+        h = C.c_void_p()
+        st = _L().lvk_ekf_create(self.ctx.h, C.byref(c), C.byref(h))
+        if st != 0:
+            print("lvk_ekf_create failed:", lib().lvk_last_error(self.ctx.h).decode())
+            return False
+        self._h = h
+        return True
+
+    def processFeatures(self, msg, imu_msg_buffer):
+        """msg: MonoCameraMeasurement (or (ts, features)); imu_msg_buffer: structured IMU array.
+        Returns (bool, remaining_imu_buffer) — the reference mutates the caller's vector in place."""
+        ts, feats = (msg.timeStampToSec, msg.features) if hasattr(msg, "features") else msg
+        feats = np.ascontiguousarray(feats, OBS); imu = np.ascontiguousarray(imu_msg_buffer, IMU)
+        used, upd = C.c_int(0), C.c_int(0)
+        self.ctx.check(_L().lvk_ekf_process(self._h, float(ts), _p(feats), len(feats), _p(imu), len(imu), C.byref(used), C.byref(upd)))
+        return bool(upd.value), imu[used.value:]
+
+    def set_state(self, t, q, p, v, bg, ba, gyro_old, acc_old):
+        a = [np.ascontiguousarray(x, np.float64) for x in (q, p, v, bg, ba, gyro_old, acc_old)]
+        self.ctx.check(_L().lvk_ekf_set_state(self._h, float(t), *[_p(x) for x in a]))
+
+    @property
+    def dim(self):
+        return _L().lvk_ekf_dim(self._h)
+
+    @property
+    def initialized(self):
+        return bool(_L().lvk_ekf_is_initialized(self._h))
+
+    def state(self):
+        o = np.zeros(30); self.ctx.check(_L().lvk_ekf_get_state(self._h, _p(o)))
+        return dict(t=o[0], q=o[1:5].copy(), v=o[5:8].copy(), p=o[8:11].copy(), bg=o[11:14].copy(), ba=o[14:17].copy(),
+                    R_b2c=o[17:26].reshape(3, 3).copy(), t_c_b=o[26:29].copy(), td=o[29])
+
+    def cov(self):
+        N = self.dim; P = np.zeros((N, N)); self.ctx.check(_L().lvk_ekf_get_cov(self._h, _p(P))); return P
+
+    def clones(self):
+        o = np.zeros(256, CLONE); n = _L().lvk_ekf_get_clones(self._h, _p(o), 256); return o[:n].copy()
+
+    def features(self):
+        ids = np.zeros(4096, np.int64); idp = np.zeros(4096); pos = np.zeros((4096, 3))
+        n = _L().lvk_ekf_get_features(self._h, _p(ids), _p(idp), _p(pos), 4096)
+        return ids[:n].copy(), idp[:n].copy(), pos[:n].copy()
+
+    def counters(self):
+        o = np.zeros(8, np.int64); _L().lvk_ekf_counters(self._h, _p(o))
+        return dict(hybrid=int(o[0]), msckf=int(o[1]), last_rows=int(o[2]), zupt=int(o[3]), gated_in=int(o[4]), gated_out=int(o[5]),
+                    map=int(o[6]), triangulations=int(o[7]))
+
+    # reference getters (larvio.cpp:2644-2735)
+    def getTbw(self):
+        s = self.state(); q = s["q"]
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = s["p"]
+        return T
+
+    def getVel(self):
+        return self.state()["v"]
+
+    def close(self):
+        if self._h:
+            _L().lvk_ekf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

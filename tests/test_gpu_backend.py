@@ -1,0 +1,157 @@
+"""GPU parity of the back-end: FP64-MFMA algebra against numpy, the stage-level update / compression against the oracle,
+and the device-resident LarVio against the oracle's, update by update (state and covariance within 1e-5 relative —
+the tolerance BASELINE.json's north_star states)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("shape", [(232, 262, 232), (17, 5, 33), (64, 64, 64), (300, 1, 7)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
+def test_dgemm_mfma_f64(gpu_ctx, shape, ta, tb):
+    from larvio_amd import larvio as lv
+    M, N, K = shape
+    rng = np.random.default_rng(M * 1000 + N)
+    A = rng.normal(0, 1, (K, M) if ta else (M, K)); B = rng.normal(0, 1, (N, K) if tb else (K, N)); C0 = rng.normal(0, 1, (M, N))
+    ref = 0.7 * (A.T if ta else A) @ (B.T if tb else B) - 0.3 * C0
+    out = lv.dgemm(gpu_ctx, A, B, ta, tb, alpha=0.7, beta=-0.3, Cin=C0)
+    assert np.abs(out - ref).max() < 1e-12 * K
+    # an asymmetric B with A = I catches a row/column swap in the f64 accumulator map
+    if not ta and not tb and M == K:
+        out = lv.dgemm(gpu_ctx, np.eye(M), B)
+        assert np.array_equal(out, B)
+
+
+def _update_problem(seed, N, m):
+    rng = np.random.default_rng(seed)
+    Bm = rng.normal(0, 1, (N, N)); P = Bm @ Bm.T * 1e-3 + np.diag(rng.uniform(1e-8, 1e-2, N))
+    H = rng.normal(0, 1, (m, N)) * (rng.uniform(0, 1, (m, N)) < 0.2); H[:, :15] = 0
+    r = rng.normal(0, 0.01, m)
+    return P, H, r
+
+
+@pytest.mark.parametrize("N,m", [(232, 262), (118, 40), (46, 9), (232, 530), (250, 1)])
+def test_ekf_update_matches_oracle(gpu_ctx, N, m):
+    from oracle import lvo_be
+    from larvio_amd import larvio as lv
+    P, H, r = _update_problem(N + m, N, m)
+    dx_o, P_o = lvo_be.ekf_update(P, H, r, 0.008 ** 2)
+    dx_g, P_g = lv.ekf_update(gpu_ctx, P, H, r, 0.008 ** 2)
+    assert _rel(dx_g, dx_o) < 1e-9
+    assert _rel(P_g, P_o) < 1e-10
+    assert np.array_equal(P_g, P_g.T)                              # P - W^T W is symmetric by construction
+    assert np.linalg.eigvalsh(P_g).min() > -1e-12
+
+
+@pytest.mark.parametrize("rows,cols", [(300, 202), (700, 202), (2500, 82), (18000, 120), (150, 202)])
+def test_qr_compression_preserves_information(gpu_ctx, rows, cols):
+    from larvio_amd import larvio as lv
+    rng = np.random.default_rng(rows)
+    H = rng.normal(0, 1, (rows, cols)); H[:, :15] = 0.0
+    r = rng.normal(0, 1, rows)
+    R, rc = lv.compress_qr(gpu_ctx, H, r)
+    assert R.shape[0] == min(rows, cols)
+    G = H.T @ H
+    assert np.abs(R.T @ R - G).max() < 1e-11 * np.abs(G).max() * np.sqrt(rows)
+    assert np.abs(R.T @ rc - H.T @ r).max() < 1e-11 * np.abs(H.T @ r).max() * np.sqrt(rows)
+    if rows > cols:
+        assert np.abs(np.tril(R, -1)).max() < 1e-12 * np.abs(R).max()
+
+
+def _R2q(R):
+    t = np.trace(R); s = np.sqrt(t + 1) * 2
+    return np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+
+
+def _messages(first, count, max_features=150):
+    """feature messages of the ORACLE front-end on the synthetic sequence (the back-end parity input)"""
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    frames = synth_frames(first, count)
+    seq = S.imu_only_sequence()
+    fe = lvo.Frontend(S.frontend_config(max_features_num=max_features))
+    k_first = int(frames[0][0] * 200) - 2
+    imu_all = seq.imu_array(k_first, k_first + 200 * (count // 20 + 2))
+    msgs = []
+    for ts, img in frames:
+        buf = imu_all[:int(np.searchsorted(imu_all["t"], ts + 0.05))]
+        have, msg = fe.process(img, ts, buf[-60:])
+        if have:
+            msgs.append((ts, msg))
+    return msgs, imu_all, seq
+
+
+def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True):
+    from oracle import lvo_be
+    import larvio_amd
+    ora = lvo_be.Ekf(cfg)
+    gpu = larvio_amd.LarVio(cfg, gpu_ctx)
+    assert gpu.initialize()
+    buf_o = imu_all.copy(); buf_g = imu_all.copy()
+    inited = not init_from_gt
+    n_upd, worst_x, worst_P = 0, 0.0, 0.0
+    for ts, msg in msgs:
+        bo = buf_o[:int(np.searchsorted(buf_o["t"], ts + 0.05))]
+        bg = buf_g[:int(np.searchsorted(buf_g["t"], ts + 0.05))]
+        if not inited:
+            k = int(np.searchsorted(imu_all["t"], ts, side="right")) - 1
+            t0 = imu_all["t"][k]; tr = seq.traj
+            args = (t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            ora.set_state(*args); gpu.set_state(*args)
+            inited = True
+        ok_o, used_o = ora.process(ts, msg, bo)
+        ok_g, rest = gpu.processFeatures((ts, msg), bg)
+        used_g = len(bg) - len(rest)
+        assert ok_g == ok_o and used_g == used_o
+        buf_o = buf_o[used_o:]; buf_g = buf_g[used_g:]
+        if not ok_o:
+            continue
+        n_upd += 1
+        assert gpu.dim == ora.dim
+        so, sg = ora.state(), gpu.state()
+        for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
+            worst_x = max(worst_x, _rel(np.asarray(sg[k]), np.asarray(so[k])))
+        assert abs(sg["td"] - so["td"]) <= REL * max(abs(so["td"]), 1e-3)
+        Po, Pg = ora.cov(), gpu.cov()
+        worst_P = max(worst_P, _rel(Pg, Po))
+        co, cg = ora.clones(), gpu.clones()
+        assert np.array_equal(cg["id"], co["id"])
+        assert _rel(cg["p"], co["p"]) < REL and _rel(cg["q"], co["q"]) < REL
+        io, do_, po = ora.features(); ig, dg, pg = gpu.features()
+        assert np.array_equal(ig, io)
+        if len(io):
+            assert _rel(dg, do_) < REL and _rel(pg, po) < REL
+        assert worst_x < REL and worst_P < REL, (n_upd, worst_x, worst_P)
+    cg, co = gpu.counters(), ora.counters()
+    for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map"):
+        assert cg[k] == co[k], (k, cg, co)
+    gpu.close()
+    return n_upd, worst_x, worst_P, co, ora
+
+
+def test_backend_sequence_parity_hybrid(gpu_ctx):
+    """EuRoC-shaped hybrid MSCKF / 1-D EKF-SLAM, sw_size 20: window fills, prunes, re-anchors; state and P within 1e-5"""
+    from larvio_amd import synthetic as S
+    msgs, imu_all, seq = _messages(40, 90)
+    cfg = S.backend_config(sw_size=20, if_zupt_valid=0)
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, msgs, imu_all, seq, cfg)
+    assert n_upd >= 40 and c["hybrid"] >= 30 and c["msckf"] >= 5
+    assert len(ora.features()[0]) >= 5                               # in-state (EKF-SLAM) features exist
+    print("hybrid parity: updates", n_upd, "max rel state", wx, "max rel P", wP, c)
+
+
+def test_backend_sequence_parity_pure_msckf_and_static_init(gpu_ctx):
+    """configs[0] flavour: max_features_in_one_grid 0 (pure MSCKF), start at rest: static initializer + ZUPT updates"""
+    from larvio_amd import synthetic as S
+    msgs, imu_all, seq = _messages(0, 70)
+    cfg = S.backend_config(sw_size=12, max_features_in_one_grid=0)
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=False)
+    assert n_upd >= 15 and c["zupt"] >= 1 and c["hybrid"] + c["msckf"] >= 5
+    assert ora.dim == 22 + 6 * len(ora.clones())
