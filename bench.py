@@ -53,10 +53,11 @@ def imu_stream(seed_offset=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=80, help="untimed frames; >= 70 so the 30-clone window is full when timing starts")
+    ap.add_argument("--sw-size", type=int, default=30)
     ap.add_argument("--max-features", type=int, default=150, help="tracker budget (holds ~150 live tracks)")
-    ap.add_argument("--cpu-baseline-frames", type=int, default=100)
+    ap.add_argument("--cpu-baseline-frames", type=int, default=150)
     args = ap.parse_args()
 
     import torch
@@ -87,18 +88,45 @@ def main():
     cfg = S.frontend_config(max_features_num=args.max_features)
     fe = larvio_amd.ImageProcessor(cfg, ctx)
     assert fe.initialize()
+    bcfg = S.backend_config(sw_size=args.sw_size, max_features=args.max_features)
+    be = larvio_amd.LarVio(bcfg, ctx)
+    assert be.initialize()
     stride = frames.shape[2]
     fsz = frames.shape[1] * frames.shape[2]
+    # the driver's IMU buffer (app/larvioMain.cpp:98-102): samples with t < t_img + 0.05 are appended, processFeatures erases
+    k_lo = max(int(ts[0] * 200) - 4, 0)
+    imu_all = seq.imu_array(k_lo, int(ts[-1] * 200) + 40)
+    state = {"buf_lo": 0, "inited": False, "t_fe": 0.0, "t_be": 0.0, "n_be": 0}
+
+    def R2q(R):
+        t = np.trace(R); s_ = np.sqrt(t + 1) * 2
+        return np.array([(R[2, 1] - R[1, 2]) / s_, (R[0, 2] - R[2, 0]) / s_, (R[1, 0] - R[0, 1]) / s_, 0.25 * s_])
 
     def step(i):
+        t0 = time.perf_counter()
         have, msg = fe.processImage(None, imus[i], ts=float(ts[i]), device_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
         ctx.sync()
+        t1 = time.perf_counter()
+        state["t_fe"] += t1 - t0
+        if have:
+            hi = int(np.searchsorted(imu_all["t"], ts[i] + 0.05))
+            buf = imu_all[state["buf_lo"]:hi]
+            if not state["inited"]:
+                # the initializers are a cold path outside the scope: start from ground truth
+                k = int(np.searchsorted(imu_all["t"], ts[i], side="right")) - 1
+                t_i = imu_all["t"][k]; tr = seq.traj
+                be.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+                state["inited"] = True
+            ok, rest = be.processFeatures(msg, buf)
+            state["buf_lo"] += len(buf) - len(rest)
+            state["t_be"] += time.perf_counter() - t1; state["n_be"] += 1
         return have, msg
 
     for i in range(W):
         step(i)
     pl0, it0 = fe.lk_stats()
     fe.profile_enable((1 << 2) | (1 << 3))               # HIP events around the LK launches only (dominant kernel)
+    state["t_fe"] = state["t_be"] = 0.0; state["n_be"] = 0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -133,23 +161,39 @@ def main():
                     "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
                     "launches": lk_launches}
         # ---- CPU baseline: the oracle (a restatement, "port") on this box's host cores, 1 thread, bounded sample
-        from oracle import lvo
+        from oracle import lvo, lvo_be
         nb = min(args.cpu_baseline_frames, K + W)
-        ora = lvo.Frontend(cfg)
+        ora = lvo.Frontend(cfg); orb = lvo_be.Ekf(bcfg)
+        lo, inited, c_fe, c_be = 0, False, 0.0, 0.0
         t0 = time.perf_counter()
         for i in range(nb):
-            ora.process(frames[i], float(ts[i]), imus[i])
+            ta = time.perf_counter()
+            have, m = ora.process(frames[i], float(ts[i]), imus[i])
+            tb = time.perf_counter(); c_fe += tb - ta
+            if have:
+                buf = imu_all[lo:int(np.searchsorted(imu_all["t"], ts[i] + 0.05))]
+                if not inited:
+                    k = int(np.searchsorted(imu_all["t"], ts[i], side="right")) - 1
+                    t_i = imu_all["t"][k]; tr = seq.traj
+                    orb.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+                    inited = True
+                ok, used = orb.process(float(ts[i]), m, buf); lo += used
+                c_be += time.perf_counter() - tb
         cpu_s = time.perf_counter() - t0
         cpu_baseline = {"value": round(nb / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                        "sample": f"first {nb} frames of the same synthetic sequence, oracle front-end only, 1 thread of {os.cpu_count()}"}
+                        "front_end_ms_per_frame": round(c_fe / nb * 1e3, 3), "back_end_ms_per_frame": round(c_be / nb * 1e3, 3),
+                        "sample": f"first {nb} frames of the same synthetic sequence (window still filling), CPU oracle front-end + back-end, "
+                                  f"1 thread of {os.cpu_count()} (LARVIO is single-threaded); a restatement, not the Eigen/OpenCV build"}
         value = world * K / elapsed
         out = {"metric": "VIO frames/sec (752x480, ~150 tracks, 30-clone window)", "value": round(value, 2), "unit": "frames/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
                "p50_ms_per_frame": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_frame": round(float(np.percentile(lat, 95)) * 1e3, 4),
+               "front_end_ms_per_frame": round(state["t_fe"] / K * 1e3, 4), "back_end_ms_per_update": round(state["t_be"] / max(state["n_be"], 1) * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
                "config": {"workload": "configs[1] shape: EuRoC-shaped synthetic 752x480 @20Hz, max_features %d, pyramid 3 levels, win 21, pub 10 Hz" % args.max_features,
-                          "stages": "front-end (processImage) only — back-end update not yet in the timed path",
+                          "stages": "processImage every frame + processFeatures on every feature message (10 Hz), as app/larvioMain.cpp:106-116",
+                          "sw_size": args.sw_size, "state_dim": be.dim, "backend": be.counters(),
                           "mean_tracks_per_msg": round(float(np.mean(n_tracks)) if n_tracks else 0.0, 1), "messages": n_msgs,
                           "parallelism": "replicas x%d" % world},
                "roofline": roofline, "cpu_baseline": cpu_baseline}

@@ -1056,10 +1056,10 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     e->nmax = LEG + 6 * (c.sw_size + 2) + max_feat_state + 8;
     e->ld = (e->nmax + 15) & ~15;
     e->rows_cap = 544;
-    e->feat_cap = c.max_features > 0 ? c.max_features : 1024;
+    e->feat_cap = std::max(1024, 4 * c.max_features);        // jobs per batch: the map holds lost and young features besides the tracked ones
     e->obs_cap = 2 * e->feat_cap * (c.sw_size + 2);
     const int max_c = 7 + 6 + 6 * (c.sw_size + 2) + 1;
-    e->staging_cap = (size_t)2 * e->feat_cap * ((size_t)2 * (c.sw_size + 2) * max_c * 2 + 2 * (c.sw_size + 2));
+    e->staging_cap = std::min((size_t)2 * e->feat_cap * ((size_t)2 * (c.sw_size + 2) * max_c * 2 + 2 * (c.sw_size + 2)), (size_t)48 << 20);   // doubles; checked per batch
     e->ccols_cap = (size_t)2 * e->feat_cap * max_c;
     const size_t hrows = (size_t)8 * e->rows_cap;
     bool ok = dalloc(&e->dP[0], (size_t)e->ld * e->ld) && dalloc(&e->dP[1], (size_t)e->ld * e->ld) && dalloc(&e->d_idx, e->ld) && dalloc(&e->d_phiq, 2 * LEG * LEG) &&

@@ -77,7 +77,7 @@ def _messages(first, count, max_features=150):
     frames = synth_frames(first, count)
     seq = S.imu_only_sequence()
     fe = lvo.Frontend(S.frontend_config(max_features_num=max_features))
-    k_first = int(frames[0][0] * 200) - 2
+    k_first = max(int(frames[0][0] * 200) - 2, 0)
     imu_all = seq.imu_array(k_first, k_first + 200 * (count // 20 + 2))
     msgs = []
     for ts, img in frames:
