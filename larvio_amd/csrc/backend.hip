@@ -99,7 +99,9 @@ struct lvk_ekf {
     double *d_H = nullptr, *d_r = nullptr, *d_H1 = nullptr, *d_H2 = nullptr, *d_r1 = nullptr;
     UpdateWs ws;
     // pinned host arenas
-    char* h_up = nullptr; size_t up_cap = 0, up_off = 0;
+    char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
+    char* d_up = nullptr;                               // device mirror of the upload arena: ONE H2D copy per sync point
+    CamPose* dv_cams = nullptr; CloneDev* dv_clones = nullptr;
     char* h_down = nullptr; size_t down_cap = 0;
     // timing of GPU stages via events is done by the caller (bench) around lvk_ekf_process
 };
@@ -122,10 +124,13 @@ template <typename T> static T* up_alloc(lvk_ekf* e, size_t n)
     T* p = (T*)(e->h_up + e->up_off); e->up_off += bytes; return p;
 }
 #define EKF_HIP(call) LVK_HIP(e->ctx, call)
-template <typename T> static lvk_status h2d(lvk_ekf* e, T* dst, const T* src, size_t n)
-{
-    if (n == 0) return LVK_OK;
-    EKF_HIP(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyHostToDevice, e->ctx->stream));
+template <typename T> static T* dev(lvk_ekf* e, T* host) { return (T*)(e->d_up + ((char*)host - e->h_up)); }
+static lvk_status flush_uploads(lvk_ekf* e)
+{   // everything staged in the pinned arena since the last flush goes up in one stream-ordered copy
+    if (e->up_off > e->up_flushed) {
+        EKF_HIP(hipMemcpyAsync(e->d_up + e->up_flushed, e->h_up + e->up_flushed, e->up_off - e->up_flushed, hipMemcpyHostToDevice, e->ctx->stream));
+        e->up_flushed = e->up_off;
+    }
     return LVK_OK;
 }
 static lvk_status d2h_sync(lvk_ekf* e, void* dst, const void* src, size_t bytes)
@@ -140,9 +145,9 @@ static lvk_status cov_gather(lvk_ekf* e, const std::vector<int>& idx)
     int* h = up_alloc<int>(e, idx.size());
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, idx.data(), sizeof(int) * idx.size());
-    lvk_status st = h2d(e, e->d_idx, h, idx.size());
+    lvk_status st = flush_uploads(e);
     if (st != LVK_OK) return st;
-    st = lvk_cov_gather(e->ctx, e->dP[e->cur], e->ld, e->dP[e->cur ^ 1], e->ld, e->d_idx, (int)idx.size());
+    st = lvk_cov_gather(e->ctx, e->dP[e->cur], e->ld, e->dP[e->cur ^ 1], e->ld, dev(e, h), (int)idx.size());
     if (st != LVK_OK) return st;
     e->cur ^= 1; e->N = (int)idx.size();
     return LVK_OK;
@@ -258,10 +263,10 @@ static lvk_status apply_propagation(lvk_ekf* e)
     double* h = up_alloc<double>(e, 2 * LEG * LEG);
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, e->Phi_tot, sizeof e->Phi_tot); memcpy(h + LEG * LEG, e->Q_tot, sizeof e->Q_tot);
-    lvk_status st = h2d(e, e->d_phiq, h, (size_t)2 * LEG * LEG);
+    lvk_status st = flush_uploads(e);
     if (st != LVK_OK) return st;
     e->have_prop = false;
-    return lvk_cov_propagate(e->ctx, e->dP[e->cur], e->ld, e->N, LEG, e->d_phiq);
+    return lvk_cov_propagate(e->ctx, e->dP[e->cur], e->ld, e->N, LEG, dev(e, h));
 }
 
 static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
@@ -385,9 +390,8 @@ static lvk_status upload_clones(lvk_ekf* e)
         quat_to_rot(c.q_cam, hc[i].R); memcpy(hc[i].t, c.p_cam, 24);
         memcpy(hd[i].q, c.q, 32); memcpy(hd[i].p, c.p, 24); memcpy(hd[i].p_fej, c.p_fej, 24); memcpy(hd[i].R_b2c, c.R_b2c, 72); memcpy(hd[i].t_c_b, c.t_c_b, 24);
     }
-    lvk_status st = h2d(e, e->d_cams, hc, n);
-    if (st == LVK_OK) st = h2d(e, e->d_clones, hd, n);
-    return st;
+    e->dv_cams = dev(e, hc); e->dv_clones = dev(e, hd);
+    return LVK_OK;
 }
 
 // mode 0 initializePosition(curr_id), 1 initializePosition_AssignAnchor, 2 initializeInvParamPosition(curr_id) (feature.hpp:383-890)
@@ -428,10 +432,8 @@ static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::
         for (size_t k = 0; k < r.ranks.size(); ++k) { hr[off + k] = r.ranks[k]; hz[2 * (off + k)] = r.z[2 * k]; hz[2 * (off + k) + 1] = r.z[2 * k + 1]; }
         off += r.ranks.size();
     }
-    lvk_status st = h2d(e, e->d_tri, hj, reqs.size());
-    if (st == LVK_OK) st = h2d(e, e->d_rank, hr, tot);
-    if (st == LVK_OK) st = h2d(e, e->d_z, hz, 2 * tot);
-    if (st == LVK_OK) st = lvk_launch_triangulate(e->ctx, e->d_tri, (int)reqs.size(), e->d_cams, e->d_rank, e->d_z, e->d_triout);
+    lvk_status st = flush_uploads(e);
+    if (st == LVK_OK) st = lvk_launch_triangulate(e->ctx, dev(e, hj), (int)reqs.size(), e->dv_cams, dev(e, hr), dev(e, hz), e->d_triout);
     if (st != LVK_OK) return st;
     TriResult* ho = (TriResult*)e->h_down;
     st = d2h_sync(e, ho, e->d_triout, sizeof(TriResult) * reqs.size());
@@ -492,12 +494,9 @@ static lvk_status run_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
         hj[i] = d;
     }
     if (stage > e->staging_cap || ccols > e->ccols_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "staging buffer too small (%zu doubles needed)", stage);
-    lvk_status st = h2d(e, e->d_fj, hj, jobs.size());
-    if (st == LVK_OK) st = h2d(e, e->d_rank, hr, tot);
-    if (st == LVK_OK) st = h2d(e, e->d_z, hz, 2 * tot);
-    if (st == LVK_OK) st = h2d(e, e->d_zv, hv, 2 * tot);
+    lvk_status st = flush_uploads(e);
     FilterFlags fl; fl.leg_dim = LEG; fl.if_fej = e->if_fej ? 1 : 0; fl.estimate_td = e->cfg.estimate_td; fl.pad = 0; fl.sigma2 = e->sigma2;
-    if (st == LVK_OK) st = lvk_launch_feature_rows(e->ctx, e->d_fj, (int)jobs.size(), max_rows, e->d_clones, e->d_rank, e->d_z, e->d_zv, e->dP[e->cur], e->ld, fl,
+    if (st == LVK_OK) st = lvk_launch_feature_rows(e->ctx, dev(e, hj), (int)jobs.size(), max_rows, e->dv_clones, dev(e, hr), dev(e, hz), dev(e, hv), e->dP[e->cur], e->ld, fl,
                                                    e->d_staging, e->d_ccols, e->d_fout);
     if (st != LVK_OK) return st;
     FeatResult* ho = (FeatResult*)e->h_down;
@@ -527,8 +526,8 @@ static lvk_status stack_rows(lvk_ekf* e, const std::vector<StackRow>& map, doubl
     StackRow* h = up_alloc<StackRow>(e, map.size());
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, map.data(), sizeof(StackRow) * map.size());
-    lvk_status st = h2d(e, e->d_map, h, map.size());
-    if (st == LVK_OK) st = lvk_launch_stack_rows(e->ctx, e->d_map, (int)map.size(), e->d_staging, e->d_ccols, dH, e->ld, ncols, dr);
+    lvk_status st = flush_uploads(e);
+    if (st == LVK_OK) st = lvk_launch_stack_rows(e->ctx, dev(e, h), (int)map.size(), e->d_staging, e->d_ccols, dH, e->ld, ncols, dr);
     return st;
 }
 // dense update with m stacked rows already in d_H/d_r: compress when too tall, update P, fetch dx
@@ -707,9 +706,9 @@ static lvk_status remove_lost_features(lvk_ekf* e)
                 double* hh = up_alloc<double>(e, n_acc);
                 if (!hh) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
                 memcpy(hh, h2.data(), sizeof(double) * n_acc);
-                st = h2d(e, e->d_H2, hh, (size_t)n_acc);
+                st = flush_uploads(e);
                 if (N + n_acc > e->nmax) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "state dimension exceeds capacity");
-                if (st == LVK_OK) st = lvk_cov_append_features(e->ctx, e->dP[e->cur], e->ld, N, n_acc, e->d_H1, e->ld, e->d_H2, e->d_r1, e->d_dx, e->sigma2, e->d_tmp, e->d_dx + N);
+                if (st == LVK_OK) st = lvk_cov_append_features(e->ctx, e->dP[e->cur], e->ld, N, n_acc, e->d_H1, e->ld, dev(e, hh), e->d_r1, e->d_dx, e->sigma2, e->d_tmp, e->d_dx + N);
                 if (st != LVK_OK) return st;
             }
             st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)(N + n_acc));
@@ -807,8 +806,8 @@ static lvk_status update_feature_cov_1d(lvk_ekf* e, const Feature& f, long long 
     for (int j = 0; j < 3; ++j) { J[oc + j] = J_rho_d_new * (-Jto[6 + j]); J[oc + 3 + j] = J_rho_d_new * R_w2c_new[6 + j]; }
     for (int j = 0; j < 3; ++j) { J[ncn + j] = J_rho_d_new * Jtn[6 + j]; J[ncn + 3 + j] = J_rho_d_new * (-R_w2c_new[6 + j]); }
     for (int j = 0; j < 3; ++j) { J[15 + j] = J_rho_d_new * JeT[6 + j]; J[18 + j] = J_rho_d_new * JeP[6 + j]; }
-    lvk_status st = h2d(e, e->d_J, J, (size_t)N);
-    if (st == LVK_OK) st = lvk_cov_reanchor(e->ctx, e->dP[e->cur], e->ld, N, e->d_J, fc);
+    lvk_status st = flush_uploads(e);
+    if (st == LVK_OK) st = lvk_cov_reanchor(e->ctx, e->dP[e->cur], e->ld, N, dev(e, J), fc);
     return st;
 }
 
@@ -932,8 +931,9 @@ static lvk_status update_zupt(lvk_ekf* e)
     // rows are whitened by sigma/sqrt(R_ii) so the shared isotropic update applies (K r and K H are unchanged)
     const double Rd[9] = {e->zupt_v2, e->zupt_v2, e->zupt_v2, e->zupt_p2, e->zupt_p2, e->zupt_p2, e->zupt_q2, e->zupt_q2, e->zupt_q2};
     for (int i = 0; i < 9; ++i) { const double s = sqrt(e->sigma2 / Rd[i]); for (int j = 0; j < N; ++j) H[(size_t)i * e->ld + j] *= s; r[i] *= s; }
-    lvk_status st = h2d(e, e->d_H, H, (size_t)9 * e->ld);
-    if (st == LVK_OK) st = h2d(e, e->d_r, r, (size_t)9);
+    lvk_status st = flush_uploads(e);
+    if (st == LVK_OK) { EKF_HIP(hipMemcpyAsync(e->d_H, dev(e, H), sizeof(double) * 9 * e->ld, hipMemcpyDeviceToDevice, e->ctx->stream));
+                        EKF_HIP(hipMemcpyAsync(e->d_r, dev(e, r), sizeof(double) * 9, hipMemcpyDeviceToDevice, e->ctx->stream)); }
     std::vector<double> dx;
     if (st == LVK_OK) st = dense_update(e, 9, dx, 0);
     if (st == LVK_OK) st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)N);
@@ -1015,7 +1015,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
     if (!e) return;
     hipStreamSynchronize(e->ctx->stream);
     void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_triout, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
-                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info};
+                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info, e->d_up};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_up) hipHostFree(e->h_up);
     if (e->h_down) hipHostFree(e->h_down);
@@ -1055,7 +1055,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     const int max_feat_state = std::max(0, c.max_features_in_one_grid) * cells;
     e->nmax = LEG + 6 * (c.sw_size + 2) + max_feat_state + 8;
     e->ld = (e->nmax + 15) & ~15;
-    e->rows_cap = 544;
+    e->rows_cap = 1024;                                      // dense update up to this many stacked rows; taller blocks are QR-compressed first
     e->feat_cap = std::max(1024, 4 * c.max_features);        // jobs per batch: the map holds lost and young features besides the tracked ones
     e->obs_cap = 2 * e->feat_cap * (c.sw_size + 2);
     const int max_c = 7 + 6 + 6 * (c.sw_size + 2) + 1;
@@ -1070,7 +1070,8 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
               dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
     e->ws.ldb = (e->ld + 8 + 7) & ~7; e->ws.lds = e->rows_cap;
     ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds) && dalloc(&e->ws.info, 16);
-    e->up_cap = (size_t)64 << 20; e->down_cap = (size_t)4 << 20;
+    e->up_cap = (size_t)32 << 20; e->down_cap = (size_t)4 << 20;
+    ok = ok && hipMalloc((void**)&e->d_up, e->up_cap) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
     if (!ok) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_ekf_create: allocation failed"); }
     // initial covariance (larvio.cpp:163-186)
@@ -1105,7 +1106,7 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
 {
     if (!e || !n_consumed || !updated || (n_feats > 0 && !feats) || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
     *n_consumed = 0; *updated = 0;
-    e->up_off = 0;
+    e->up_off = 0; e->up_flushed = 0;
     if (!e->b_first_features) {
         if (n_imu > 0 && imu[0].t - ts - e->td <= 0.0) e->b_first_features = true;
         else return LVK_OK;

@@ -328,8 +328,8 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
     if (n_jobs <= 0) return LVK_OK;
     const size_t shmem = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
     if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_feature_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static size_t attr_set = 0;
+    if (attr_set < shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_feature_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
     hipLaunchKernelGGL(k_feature_rows, dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv, d_P, ldp, fl,
                        d_staging, d_ccols, d_out);
     LVK_LAUNCH_CHECK(ctx);

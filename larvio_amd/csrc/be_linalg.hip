@@ -227,39 +227,51 @@ __global__ void __launch_bounds__(256) k_cov_propagate(double* __restrict__ P, i
 __global__ void __launch_bounds__(256) k_cov_reanchor(double* __restrict__ P, int ld, int n, const double* __restrict__ J, int fc)
 {
     extern __shared__ double pf[];     // n
-    __shared__ double red[256];
+    __shared__ int nz_idx[64]; __shared__ double nz_val[64]; __shared__ int nnz_s;
     const int t = threadIdx.x;
-    for (int b = t; b < n; b += 256) { double s = 0.; for (int k = 0; k < n; ++k) s += J[k] * P[(size_t)k * ld + b]; pf[b] = s; }
+    if (t == 0) {                      // J has ~19 non-zeros (feature, two clone blocks, extrinsics): compact them once
+        int c = 0;
+        for (int k = 0; k < n && c < 64; ++k) { const double v = J[k]; if (v != 0.) { nz_idx[c] = k; nz_val[c] = v; ++c; } }
+        nnz_s = c;
+    }
     __syncthreads();
-    double part = 0.;
-    for (int k = t; k < n; k += 256) part += pf[k] * J[k];
-    red[t] = part;
+    const int nnz = nnz_s;
+    for (int b = t; b < n; b += 256) { double s = 0.; for (int q = 0; q < nnz; ++q) s += nz_val[q] * P[(size_t)nz_idx[q] * ld + b]; pf[b] = s; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
     for (int b = t; b < n; b += 256) if (b != fc) { P[(size_t)fc * ld + b] = pf[b]; P[(size_t)b * ld + fc] = pf[b]; }
-    if (t == 0) P[(size_t)fc * ld + fc] = red[0];
+    if (t == 0) { double s = 0.; for (int q = 0; q < nnz; ++q) s += pf[nz_idx[q]] * nz_val[q]; P[(size_t)fc * ld + fc] = s; }
 }
 
 // delayed initialisation of new in-state features (larvio.cpp:1821-1854), 1-D: HH = diag(H2)^-1 H1 (nn x n);
 // rows/cols n..n+nn-1 of P:  P_new,old = -HH P ; P_new,new = HH P HH^T + sigma2 / H2^2 (diag).  tmp: nn x n scratch.
-__global__ void __launch_bounds__(256) k_cov_append_features(double* __restrict__ P, int ld, int n, int nn, const double* __restrict__ H1, int ldh,
-                                                            const double* __restrict__ H2, double sigma2, double* __restrict__ tmp)
+// step 1: tmp[j][b] = -(HH P)[j][b], written to the new rows and columns of P.  grid (ceil(n/256), nn)
+__global__ void __launch_bounds__(256) k_cov_append_rows(double* __restrict__ P, int ld, int n, int nn, const double* __restrict__ H1, int ldh,
+                                                        const double* __restrict__ H2, double* __restrict__ tmp)
+{
+    extern __shared__ double hh[];     // row j of HH
+    const int j = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    const double inv = 1.0 / H2[j];
+    for (int k = threadIdx.x; k < n; k += 256) hh[k] = H1[(size_t)j * ldh + k] * inv;
+    __syncthreads();
+    if (b >= n) return;
+    double s = 0.;
+    for (int k = 0; k < n; ++k) s += hh[k] * P[(size_t)k * ld + b];
+    tmp[(size_t)j * n + b] = -s;
+    P[(size_t)(n + j) * ld + b] = -s; P[(size_t)b * ld + n + j] = -s;
+}
+// step 2: P_new,new = HH P HH^T + sigma2 / H2^2 (symmetrised).  one workgroup, nn <= 64
+__global__ void __launch_bounds__(256) k_cov_append_corner(double* __restrict__ P, int ld, int n, int nn, const double* __restrict__ H1, int ldh,
+                                                          const double* __restrict__ H2, double sigma2, const double* __restrict__ tmp)
 {
     const int t = threadIdx.x;
-    for (int e = t; e < nn * n; e += 256) {
-        int j = e / n, b = e - j * n; double s = 0.;
-        for (int k = 0; k < n; ++k) s += (H1[(size_t)j * ldh + k] / H2[j]) * P[(size_t)k * ld + b];
-        tmp[e] = -s;
-    }
-    __syncthreads();
-    for (int e = t; e < nn * n; e += 256) { int j = e / n, b = e - j * n; P[(size_t)(n + j) * ld + b] = tmp[e]; P[(size_t)b * ld + n + j] = tmp[e]; }
     for (int e = t; e < nn * nn; e += 256) {
         int j = e / nn, l = e - j * nn;
         if (l > j) continue;
         double s1 = 0., s2 = 0.;
-        for (int k = 0; k < n; ++k) { s1 += tmp[(size_t)j * n + k] * (H1[(size_t)l * ldh + k] / H2[l]); s2 += tmp[(size_t)l * n + k] * (H1[(size_t)j * ldh + k] / H2[j]); }
-        double a = -s1 + (j == l ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0), b = -s2 + (j == l ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0);
-        double v = (a + b) / 2.0;
+        const double il = 1.0 / H2[l], ij = 1.0 / H2[j];
+        for (int k = 0; k < n; ++k) { s1 += tmp[(size_t)j * n + k] * (H1[(size_t)l * ldh + k] * il); s2 += tmp[(size_t)l * n + k] * (H1[(size_t)j * ldh + k] * ij); }
+        const double dg = (j == l) ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0;
+        const double v = ((-s1 + dg) + (-s2 + dg)) / 2.0;
         P[(size_t)(n + j) * ld + n + l] = v; P[(size_t)(n + l) * ld + n + j] = v;
     }
 }
@@ -269,8 +281,130 @@ __global__ void k_dx_new(const double* __restrict__ H1, int ldh, const double* _
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nn) return;
     double s = 0.;
-    for (int k = 0; k < n; ++k) s += (H1[(size_t)j * ldh + k] / H2[j]) * dx[k];
+    for (int k = 0; k < n; ++k) s += (H1[(size_t)j * ldh + k] * (1.0 / H2[j])) * dx[k];
     dx_new[j] = -s + r1[j] / H2[j];
+}
+
+
+// ------------------------------------------------------------------------- blocked Cholesky + forward substitution, multi-workgroup
+// Right-looking, panel width 32, two launches per panel:
+//   k_chol_panel : every workgroup factors the 32x32 diagonal block in LDS (redundantly, it is tiny), then
+//                  S-workgroups solve X = A21 L11^-T for 256 rows each, B-workgroups solve W_p = L11^-1 B_p for 256 columns each
+//   k_chol_update: trailing S22 -= X X^T (lower tiles) and B2 -= X W_p on the FP64 matrix cores (K = 32 => 8 MFMAs per tile)
+// so the O(m^3) work runs on all CUs and the dependent chain is 2*ceil(m/32) short launches instead of one workgroup.
+#define CP_NB 32
+__global__ void __launch_bounds__(256) k_chol_panel(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
+                                                   int j0, int n_sblocks, int* __restrict__ info)
+{
+    __shared__ double Ld[CP_NB][CP_NB + 1];
+    const int t = threadIdx.x;
+    const int nb = min(CP_NB, m - j0);
+    for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; Ld[a][b] = S[(size_t)(j0 + a) * lds_ + j0 + b]; }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        double d = Ld[j][j];
+        if (!(d > 0.)) { if (t == 0 && blockIdx.x == 0 && info[0] == 0) info[0] = j0 + j + 1; d = 1.0; }
+        const double djj = sqrt(d);
+        __syncthreads();
+        if (t == 0) Ld[j][j] = djj;
+        if (t > j && t < nb) Ld[t][j] /= djj;
+        __syncthreads();
+        for (int e = t; e < (nb - j - 1) * (nb - j - 1); e += 256) {
+            int a = j + 1 + e / (nb - j - 1), b = j + 1 + e % (nb - j - 1);
+            if (b <= a) Ld[a][b] -= Ld[a][j] * Ld[b][j];
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * lds_ + j0 + b] = Ld[a][b]; }
+    if ((int)blockIdx.x < n_sblocks) {
+        const int rix = j0 + nb + blockIdx.x * 256 + t;
+        if (rix < m) {
+            double x[CP_NB];
+            double* arow = S + (size_t)rix * lds_ + j0;
+#pragma unroll
+            for (int c = 0; c < CP_NB; ++c) {                 // compile-time bounds: x[] stays in registers
+                double s = c < nb ? arow[c] : 0.;
+#pragma unroll
+                for (int k = 0; k < c; ++k) s -= x[k] * Ld[c][k];
+                x[c] = c < nb ? s / Ld[c][c] : 0.;
+            }
+#pragma unroll
+            for (int c = 0; c < CP_NB; ++c) if (c < nb) arow[c] = x[c];
+        }
+    } else {
+        const int col = (blockIdx.x - n_sblocks) * 256 + t;
+        if (col < nbcols) {
+            double w[CP_NB];
+#pragma unroll
+            for (int a = 0; a < CP_NB; ++a) {
+                double s = a < nb ? B[(size_t)(j0 + a) * ldb + col] : 0.;
+#pragma unroll
+                for (int k = 0; k < a; ++k) s -= Ld[a][k] * w[k];
+                w[a] = a < nb ? s / Ld[a][a] : 0.;
+            }
+#pragma unroll
+            for (int a = 0; a < CP_NB; ++a) if (a < nb) B[(size_t)(j0 + a) * ldb + col] = w[a];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols, int j0)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rest = m - j0 - CP_NB;
+    const int tr = (rest + 15) / 16, tcs = tr, tcb = (nbcols + 15) / 16;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tr * (tcs + tcb)) return;
+    const int ti = tile / (tcs + tcb), tj = tile - ti * (tcs + tcb);
+    const bool is_s = tj < tcs;
+    if (is_s && tj > ti) return;                               // lower triangle of S only
+    const int i = lane & 15, kk = lane >> 4;
+    const int row0 = j0 + CP_NB + ti * 16;
+    const int ar = row0 + i;
+    d4 acc = {0., 0., 0., 0.};
+    if (is_s) {
+        const int cr = j0 + CP_NB + tj * 16 + i;               // row of X that supplies column (tj*16+i) of X^T
+#pragma unroll
+        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
+            const double a = ar < m ? S[(size_t)ar * lds_ + j0 + k0 + kk] : 0.;
+            const double b = cr < m ? S[(size_t)cr * lds_ + j0 + k0 + kk] : 0.;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + kk + 4 * r, col = j0 + CP_NB + tj * 16 + i;
+            if (row < m && col <= row) S[(size_t)row * lds_ + col] -= acc[r];
+        }
+    } else {
+        const int bc = (tj - tcs) * 16 + i;
+#pragma unroll
+        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
+            const double a = ar < m ? S[(size_t)ar * lds_ + j0 + k0 + kk] : 0.;
+            const double b = bc < nbcols ? B[(size_t)(j0 + k0 + kk) * ldb + bc] : 0.;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + kk + 4 * r, col = (tj - tcs) * 16 + i;
+            if (row < m && col < nbcols) B[(size_t)row * ldb + col] -= acc[r];
+        }
+    }
+}
+
+// S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary
+static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
+{
+    hipMemsetAsync(info, 0, sizeof(int), s);
+    for (int j0 = 0; j0 < m; j0 += CP_NB) {
+        const int nb = (m - j0) < CP_NB ? (m - j0) : CP_NB;
+        const int rest = m - j0 - nb;
+        const int n_sblocks = (rest + 255) / 256, n_bblocks = (nbcols + 255) / 256;
+        hipLaunchKernelGGL(k_chol_panel, dim3(n_sblocks + n_bblocks), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0, n_sblocks, info);
+        if (rest > 0) {
+            const int tr = (rest + 15) / 16, tiles = tr * (tr + (nbcols + 15) / 16);
+            hipLaunchKernelGGL(k_chol_update, dim3((tiles + 3) / 4), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------- host drivers (internal + C ABI)
@@ -281,15 +415,12 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
                            double* dx, UpdateWs ws)
 {
     if (m <= 0) { LVK_HIP(ctx, hipMemsetAsync(dx, 0, sizeof(double) * (size_t)n, ctx->stream)); return LVK_OK; }
-    if (m > CH_MAX_M) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "update with %d rows exceeds %d (compress first)", m, CH_MAX_M);
     hipStream_t s = ctx->stream;
     launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0);                   // HP = H P
     hipLaunchKernelGGL(k_set_column, dim3((m + 255) / 256), dim3(256), 0, s, ws.B, ws.ldb, n, r, m);       // [HP | r]
     launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
-    const size_t shmem = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)m * CH_NB);
-    hipLaunchKernelGGL(k_chol_single, dim3(1), dim3(1024), shmem, s, ws.S, m, ws.lds, ws.info);
-    hipLaunchKernelGGL(k_trsm_lower, dim3((n + 1 + TR_NC - 1) / TR_NC), dim3(256), 0, s, (const double*)ws.S, m, ws.lds, ws.B, n + 1, ws.ldb);
-    hipLaunchKernelGGL(k_dx_from_w, dim3((n + 127) / 128), dim3(128), 0, s, (const double*)ws.B, m, ws.ldb, n, n, dx);
+    launch_chol_solve(s, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info);                                    // S = L L^T ; W = L^-1 [HP | r]
+    launch_dgemm<true, false>(s, n, 1, m, ws.B, ws.ldb, ws.B + n, ws.ldb, dx, 1, 1.0, 0.0, 0.0);             // dx = W^T w_r
     launch_dgemm<true, false>(s, n, n, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0);              // P -= W^T W
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -320,7 +451,8 @@ lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, i
 {
     if (nn <= 0) return LVK_OK;
     hipLaunchKernelGGL(k_dx_new, dim3((nn + 63) / 64), dim3(64), 0, ctx->stream, H1, ldh, H2, r1, dx, n, nn, dx_new);
-    hipLaunchKernelGGL(k_cov_append_features, dim3(1), dim3(256), 0, ctx->stream, P, ld, n, nn, H1, ldh, H2, sigma2, tmp);
+    hipLaunchKernelGGL(k_cov_append_rows, dim3((n + 255) / 256, nn), dim3(256), sizeof(double) * (size_t)n, ctx->stream, P, ld, n, nn, H1, ldh, H2, tmp);
+    hipLaunchKernelGGL(k_cov_append_corner, dim3(1), dim3(256), 0, ctx->stream, P, ld, n, nn, H1, ldh, H2, sigma2, (const double*)tmp);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

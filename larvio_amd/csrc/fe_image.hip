@@ -271,7 +271,10 @@ __global__ void __launch_bounds__(256) k_min_eigen(const uint8_t* __restrict__ s
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned k) { return k == 0 ? 0.f : __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-// gftt scratch layout (ints): [0] max key, [1] n candidates, [2] overflow flag
+// gftt scratch layout (uints): [0] max key, [1] n candidates, [2] overflow flag, [3] spare, [GF_HIST_OFF ...) strength histogram
+#define GF_HIST_BITS 13
+#define GF_HIST_OFF 4
+#define GF_SCRATCH_UINTS (GF_HIST_OFF + (1 << GF_HIST_BITS))
 __global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int n,
                                                    unsigned* __restrict__ scratch)
 {
@@ -304,98 +307,160 @@ __global__ void k_gftt_candidates(const float* __restrict__ eig, const uint8_t* 
             m = fmaxf(m, u);
         }
     if (v != m) return;
-    unsigned slot = atomicAdd(&scratch[1], 1u);
+    // wave-aggregated append: one atomic per wavefront instead of one per candidate
+    const unsigned long long act = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)act) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&scratch[1], (unsigned)__popcll(act));
+    base = __shfl(base, leader);
+    const unsigned slot = base + (unsigned)__popcll(act & ((1ull << lane) - 1ull));
     if (slot < (unsigned)cap) cands[slot] = ((unsigned long long)f2ord(v) << 32) | (unsigned)(y * w + x);
     else scratch[2] = 1u;
+    atomicAdd(&scratch[GF_HIST_OFF + (f2ord(v) >> (32 - GF_HIST_BITS))], 1u);      // strength histogram: bucket boundaries for the select kernel
 }
 
-// single-workgroup: sort candidates (value desc, index desc) and run the greedy min-distance selection
-// [goodFeaturesToTrack grid loop].  Sorting is bitonic in LDS (<= 8192 keys) or in global memory.
-#define GF_SORT_LDS 8192
+// single workgroup: the greedy min-distance pass of goodFeaturesToTrack ("visit candidates by descending strength, accept
+// one iff no accepted corner is closer than minDistance") WITHOUT sorting all candidates.  3x3 NMS leaves ~1/9 of the
+// unmasked pixels as candidates (15-40 K at 752x480) but almost all of them are rejected by the first few hundred accepted
+// corners.  So candidates are visited in strength BUCKETS (boundaries from the histogram the candidate kernel filled; sizes
+// 1 K, 2 K, 4 K, then <= 8 K): every thread tests the bucket's candidates against the accepted grid (cell = minDistance, so
+// conflicts live in the 3x3 cells around a candidate, <= 4 corners per cell), only the SURVIVORS are sorted (bitonic, LDS)
+// and wave 0 resolves them in order exactly like the sequential rule.  Rejections by the grid are final because the grid
+// only grows; buckets are visited in descending strength, survivors in descending (strength, index): identical result.
 #define GF_MAX_CELLS 8192
 #define GF_MAX_OUT 4096
-__global__ void __launch_bounds__(1024) k_gftt_select(unsigned long long* __restrict__ cands, int cap, int w, int h,
+#define GF_SURV 8192
+__device__ __forceinline__ bool gf_grid_conflict(const unsigned short (*cells)[4], const short2* acc, int gw, int gh, int cell, float md2, int x, int y)
+{
+    const int xc = x / cell, yc = y / cell;
+    const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+    for (int yy = y1; yy <= y2; ++yy)
+        for (int xx = x1; xx <= x2; ++xx)
+            for (int sl = 0; sl < 4; ++sl) {
+                const unsigned short a = cells[yy * gw + xx][sl];
+                if (a == 0xFFFF) break;
+                const float dx = (float)x - (float)acc[a].x, dy = (float)y - (float)acc[a].y;
+                if (dx * dx + dy * dy < md2) return true;
+            }
+    return false;
+}
+
+__global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* __restrict__ cands, int cap, int w, int h,
                                                      int max_corners, int cell, float md2,
-                                                     unsigned* __restrict__ scratch, lvk_pt2f* __restrict__ out, int out_cap,
+                                                     const unsigned* __restrict__ scratch, lvk_pt2f* __restrict__ out, int out_cap,
                                                      int* __restrict__ n_out, const int* __restrict__ d_sub)
 {
-    __shared__ unsigned long long keys[GF_SORT_LDS];
-    __shared__ unsigned short cells[GF_MAX_CELLS][4];
-    __shared__ short2 acc[GF_MAX_OUT];
-    const int t = threadIdx.x;
+    extern __shared__ unsigned long long gf_sh[];           // surv [GF_SURV] u64 | cells [gw*gh][4] u16 | acc [GF_MAX_OUT] short2
+    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+    unsigned long long* surv = gf_sh;
+    unsigned short (*cells)[4] = reinterpret_cast<unsigned short (*)[4]>(gf_sh + GF_SURV);
+    short2* acc = reinterpret_cast<short2*>(gf_sh + GF_SURV + gw * gh);
+    __shared__ unsigned coarse[1024];                        // histogram folded to 1024 groups (8 bins each at 13 bits)
+    __shared__ unsigned hist[1 << GF_HIST_BITS];
+    __shared__ int sh_ns, sh_na, sh_done, sh_lo, sh_hi;
+    const int t = threadIdx.x, lane = t & 63;
     if (d_sub) {   // image_processor.cpp:1034-1036: maxCorners = max_features_num - curr_pts_.size(), skipped when 0
         max_corners -= *d_sub;
         if (max_corners <= 0) { if (t == 0) *n_out = 0; return; }
     }
-    int n = (int)min(scratch[1], (unsigned)cap);
-    int np2 = 1; while (np2 < n) np2 <<= 1;          // the candidate buffer is allocated to the next power of two of cap
-    const bool in_lds = np2 <= GF_SORT_LDS;
-    unsigned long long* K = in_lds ? keys : cands;
-    if (in_lds) { for (int i = t; i < np2; i += 1024) keys[i] = i < n ? cands[i] : 0ull; }
-    else { for (int i = n + t; i < np2; i += 1024) cands[i] = 0ull; }
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < np2; i += 1024) {
-                int l = i ^ j;
-                if (l > i) {
-                    unsigned long long a = K[i], b = K[l];
-                    bool desc = (i & k) == 0;
-                    if (desc ? a < b : a > b) { K[i] = b; K[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
-    for (int i = t; i < gw * gh; i += 1024) { cells[i][0] = cells[i][1] = cells[i][2] = cells[i][3] = 0xFFFF; }
-    __syncthreads();
-    if (t >= 64) return;
-    const int lane = t;
-    int na = 0;
-    bool done = false;
-    for (int base = 0; base < n && !done; base += 64) {
-        int i = base + lane;
-        bool good = i < n;
-        int x = 0, y = 0;
-        if (good) {
-            unsigned idx = (unsigned)(K[i] & 0xFFFFFFFFull);
-            good = (K[i] >> 32) != 0;
-            y = idx / w; x = idx - y * w;
-        }
-        if (good) {
-            int xc = x / cell, yc = y / cell;
-            int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
-            for (int yy = y1; yy <= y2 && good; ++yy)
-                for (int xx = x1; xx <= x2 && good; ++xx)
-                    for (int s = 0; s < 4; ++s) {
-                        unsigned short a = cells[yy * gw + xx][s];
-                        if (a == 0xFFFF) break;
-                        float dx = (float)x - (float)acc[a].x, dy = (float)y - (float)acc[a].y;
-                        if (dx * dx + dy * dy < md2) { good = false; break; }
-                    }
-        }
-        unsigned long long m = __ballot(good);
-        while (m) {
-            int j = __ffsll((long long)m) - 1;
-            int xj = __shfl(x, j), yj = __shfl(y, j);
-            if (lane == 0) {
-                if (na < out_cap) { out[na].x = (float)xj; out[na].y = (float)yj; }
-                if (na < GF_MAX_OUT) {
-                    acc[na] = make_short2((short)xj, (short)yj);
-                    unsigned short* c = cells[(yj / cell) * gw + (xj / cell)];
-                    for (int s = 0; s < 4; ++s) if (c[s] == 0xFFFF) { c[s] = (unsigned short)na; break; }
-                }
-            }
-            ++na;
-            if ((max_corners > 0 && na == max_corners) || na >= GF_MAX_OUT) { done = true; break; }
-            if (good && lane > j) {
-                float dx = (float)x - (float)xj, dy = (float)y - (float)yj;
-                if (dx * dx + dy * dy < md2) good = false;
-            }
-            m = __ballot(good && lane > j);
-        }
+    const int n = (int)min(scratch[1], (unsigned)cap);
+    constexpr int GROUP = (1 << GF_HIST_BITS) / 1024;
+    {
+        unsigned s = 0;
+        for (int q = 0; q < GROUP; ++q) { const unsigned c = scratch[GF_HIST_OFF + t * GROUP + q]; hist[t * GROUP + q] = c; s += c; }
+        coarse[t] = s;
     }
-    if (lane == 0) *n_out = na < out_cap ? na : out_cap;
+    for (int i = t; i < gw * gh; i += 1024) { cells[i][0] = cells[i][1] = cells[i][2] = cells[i][3] = 0xFFFF; }
+    if (t == 0) { sh_na = 0; sh_done = 0; sh_hi = 1 << GF_HIST_BITS; }
+    __syncthreads();
+    int target = 1024;
+    for (int bucket = 0; bucket < 4096; ++bucket) {
+        // next bucket: groups [lo, hi) walking down from the strongest; at least one group, at most ~target candidates (<= GF_SURV)
+        if (t == 0) {
+            int hi = sh_hi, lo = hi; unsigned cnt = 0;
+            while (lo > 0) {
+                if ((lo & (GROUP - 1)) == 0 && coarse[lo / GROUP - 1] == 0) { lo -= GROUP; continue; }     // empty group: skip
+                const unsigned c = hist[lo - 1];
+                if (cnt > 0 && cnt + c > (unsigned)target) break;
+                cnt += c; --lo;
+                if (cnt >= (unsigned)target) break;
+            }
+            sh_lo = lo; sh_ns = 0;
+            if (cnt > GF_SURV) sh_done = 2;                 // one histogram group alone exceeds the survivor buffer (pathological)
+        }
+        __syncthreads();
+        const int lo = sh_lo, hi = sh_hi;
+        if (sh_done == 2) break;
+        if (hi == 0 || lo == hi) break;
+        const unsigned klo = (unsigned)lo << (32 - GF_HIST_BITS), khi_excl = hi >= (1 << GF_HIST_BITS) ? 0xFFFFFFFFu : ((unsigned)hi << (32 - GF_HIST_BITS));
+        for (int i = t; i < n; i += 1024) {
+            const unsigned long long k = cands[i];
+            const unsigned sv = (unsigned)(k >> 32);
+            if (sv < klo || (hi < (1 << GF_HIST_BITS) && sv >= khi_excl)) continue;
+            const unsigned idx = (unsigned)(k & 0xFFFFFFFFull);
+            const int y = idx / w, x = idx - y * w;
+            if (gf_grid_conflict(cells, acc, gw, gh, cell, md2, x, y)) continue;
+            const int slot = atomicAdd(&sh_ns, 1);
+            if (slot < GF_SURV) surv[slot] = k;
+        }
+        __syncthreads();
+        const int ns = min(sh_ns, GF_SURV);
+        int np2 = 1; while (np2 < ns) np2 <<= 1;
+        for (int i = ns + t; i < np2; i += 1024) surv[i] = 0ull;
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < np2; i += 1024) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = surv[i], b = surv[l];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? a < b : a > b) { surv[i] = b; surv[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        if (t < 64) {
+            int na = sh_na;
+            bool done = false;
+            for (int sb = 0; sb < ns && !done; sb += 64) {
+                const int si = sb + lane;
+                bool g = si < ns;
+                int sx = 0, sy = 0;
+                if (g) {
+                    const unsigned idx = (unsigned)(surv[si] & 0xFFFFFFFFull);
+                    sy = idx / w; sx = idx - sy * w;
+                    if (sb > 0 && gf_grid_conflict(cells, acc, gw, gh, cell, md2, sx, sy)) g = false;   // corners accepted earlier in this bucket
+                }
+                unsigned long long mm = __ballot(g);
+                while (mm) {
+                    const int j = __ffsll((long long)mm) - 1;
+                    const int xj = __shfl(sx, j), yj = __shfl(sy, j);
+                    if (lane == 0) {
+                        if (na < out_cap) { out[na].x = (float)xj; out[na].y = (float)yj; }
+                        if (na < GF_MAX_OUT) {
+                            acc[na] = make_short2((short)xj, (short)yj);
+                            unsigned short* c = cells[(yj / cell) * gw + (xj / cell)];
+                            for (int sl = 0; sl < 4; ++sl) if (c[sl] == 0xFFFF) { c[sl] = (unsigned short)na; break; }
+                        }
+                    }
+                    ++na;
+                    if ((max_corners > 0 && na == max_corners) || na >= GF_MAX_OUT) { done = true; break; }
+                    if (g && lane > j) {
+                        const float dx = (float)sx - (float)xj, dy = (float)sy - (float)yj;
+                        if (dx * dx + dy * dy < md2) g = false;
+                    }
+                    mm = __ballot(g && lane > j);
+                }
+            }
+            if (lane == 0) { sh_na = na; if (done) sh_done = 1; sh_hi = lo; }
+        }
+        __syncthreads();
+        if (sh_done) break;
+        if (target < GF_SURV) target <<= 1;
+    }
+    if (t == 0) *n_out = sh_na < out_cap ? sh_na : out_cap;
 }
 
 // mask with zeroed (2*md+1)^2 boxes around round(pt)  (image_processor.cpp:1009-1030)
@@ -563,11 +628,14 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     if (gw * gh > GF_MAX_CELLS) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT grid %dx%d exceeds %d cells", gw, gh, GF_MAX_CELLS);
     if (max_corners > GF_MAX_OUT || max_corners <= 0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "maxCorners must be in 1..%d", GF_MAX_OUT);
-    LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, 4 * sizeof(unsigned), ctx->stream));
+    LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL(k_masked_max, dim3(256), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch);
     hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, h - 2), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
-    hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), 0, ctx->stream, d_cands, cand_cap, w, h, max_corners, cell,
-                       (float)(min_distance * min_distance), d_scratch, d_out, cap, d_n_out, d_sub);
+    const size_t shm = (size_t)GF_SURV * 8 + (size_t)gw * gh * 8 + (size_t)GF_MAX_OUT * 4;
+    static size_t attr_set = 0;       // the opt-in must leave room for the kernel's static LDS: ask for exactly what is launched
+    if (attr_set < shm) { attr_set = shm; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); }
+    hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), shm, ctx->stream, (const unsigned long long*)d_cands, cand_cap, w, h, max_corners, cell,
+                       (float)(min_distance * min_distance), (const unsigned*)d_scratch, d_out, cap, d_n_out, d_sub);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
@@ -588,7 +656,7 @@ extern "C" lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, 
     const int cand_cap = w * h;
     size_t cand_alloc = 1; while (cand_alloc < (size_t)cand_cap) cand_alloc <<= 1;     // bitonic sort pads to a power of two in place
     float* eig = (float*)lvk_ctx_scratch(ctx, 1, sizeof(float) * (size_t)w * h);
-    unsigned* scratch = (unsigned*)lvk_ctx_scratch(ctx, 2, 4 * sizeof(unsigned));
+    unsigned* scratch = (unsigned*)lvk_ctx_scratch(ctx, 2, GF_SCRATCH_UINTS * sizeof(unsigned));
     unsigned long long* cands = (unsigned long long*)lvk_ctx_scratch(ctx, 3, sizeof(unsigned long long) * cand_alloc);
     if (!eig || !scratch || !cands) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
     lvk_status st = lvk_min_eigen_map(ctx, p, eig);

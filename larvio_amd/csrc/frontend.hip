@@ -538,7 +538,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     size_t cand_alloc = 1; while (cand_alloc < (size_t)fe->gf_cand_cap) cand_alloc <<= 1;
     ok = ok && dalloc(&fe->d_img, (size_t)w * h) && dalloc(&fe->w_curr, cap) && dalloc(&fe->wn_curr, cap) && dalloc(&fe->new_pts, cap) &&
          dalloc(&fe->w_status, cap) && dalloc(&fe->wn_status, cap) && dalloc(&fe->wn_desc, (size_t)cap * 4) && dalloc(&fe->eig, (size_t)w * h) &&
-         dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->d_msg, cap) && dalloc(&fe->dev, 1);
+         dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4 + 8192) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->d_msg, cap) && dalloc(&fe->dev, 1);
     ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap) == hipSuccess &&
          hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
     if (!ok) { lvk_frontend_destroy(fe); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_frontend_create: allocation failed"); }
