@@ -226,6 +226,14 @@ int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_
 /* [0] hybrid updates [1] msckf updates [2] rows of the last update [3] zupt updates [4] gated in [5] gated out [6] map size [7] triangulations */
 void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
 
+/* ==================================================================== the driver step
+ * One camera frame through both halves, exactly the two calls the reference's drivers make per image
+ * (app/larvioMain.cpp:104-116: processImage, then processFeatures when it returned true), with the driver's IMU buffer
+ * semantics (samples with t < t_img + 0.05 are visible, processFeatures erases what it consumed, :98-102 and larvio.cpp:511-512).
+ * h_imu[0..n_imu) is the CURRENT buffer; *n_consumed tells the caller how many leading samples to drop. */
+lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, int stride, int img_is_device, double ts,
+                           const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated);
+
 #ifdef __cplusplus
 }
 #endif

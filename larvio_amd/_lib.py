@@ -1,10 +1,11 @@
 """ctypes binding of liblvk_hip.so (the C ABI declared in include/lvk_c.h)."""
 import ctypes as C
+import weakref
 import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblvk_hip.so")
+_SO = os.environ.get("LVK_LIB", os.path.join(_HERE, "liblvk_hip.so"))
 _LIB = None
 
 PT = np.dtype([("x", np.float32), ("y", np.float32)])
@@ -26,7 +27,7 @@ ABI_SYMBOLS = [
     "lvk_frontend_stage_name",
     "lvk_ekf_compress_qr", "lvk_ekf_update", "lvk_dgemm", "lvk_ekf_create", "lvk_ekf_destroy", "lvk_ekf_process", "lvk_ekf_set_state",
     "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_get_state", "lvk_ekf_get_cov", "lvk_ekf_get_clones", "lvk_ekf_get_features",
-    "lvk_ekf_counters",
+    "lvk_ekf_counters", "lvk_vio_process",
 ]
 FE_STAGES = 9
 
@@ -114,6 +115,7 @@ class Context:
             raise LvkError(f"lvk_context_create failed with status {st}: no usable gfx950 device (there is no CPU fallback)")
         self.h = h
         self._bufs = []
+        self._children = weakref.WeakSet()      # front-ends / filters created on this context: closed before it
         if stream is not None:
             self.check(L.lvk_context_set_stream(self.h, C.c_void_p(stream)))
 
@@ -140,8 +142,16 @@ class Context:
             self.check(lib().lvk_memcpy_d2h(self.h, _p(out), C.c_void_p(buf.ptr if isinstance(buf, DeviceBuffer) else buf), out.nbytes))
         return out
 
+    def adopt(self, obj):
+        self._children.add(obj)
+
     def close(self):
         if self.h:
+            for o in list(self._children):
+                try:
+                    o.close()
+                except Exception:
+                    pass
             lib().lvk_sync(self.h)
             lib().lvk_context_destroy(self.h)
             self.h = None

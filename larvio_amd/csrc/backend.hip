@@ -1178,4 +1178,17 @@ int lvk_ekf_get_features(const lvk_ekf* e, int64_t* ids, double* inv_depth, doub
 }
 void lvk_ekf_counters(const lvk_ekf* e, long* out8) { if (e && out8) memcpy(out8, e->counters, sizeof e->counters); }
 
+lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, int stride, int img_is_device, double ts,
+                           const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated)
+{
+    if (!fe || !ekf || !n_consumed || !has_msg || !updated) return LVK_ERR_ARG;
+    *n_consumed = 0; *updated = 0; *has_msg = 0;
+    static thread_local std::vector<lvk_feature_obs> msg;
+    if (msg.size() < 8192) msg.resize(8192);
+    int n_out = 0;
+    lvk_status st = lvk_frontend_process(fe, img, stride, img_is_device, ts, h_imu, n_imu, msg.data(), (int)msg.size(), &n_out, has_msg);
+    if (st != LVK_OK || !*has_msg) return st;
+    return lvk_ekf_process(ekf, ts, msg.data(), n_out, h_imu, n_imu, n_consumed, updated);
+}
+
 }  // extern "C"

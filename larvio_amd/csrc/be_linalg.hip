@@ -229,12 +229,22 @@ __global__ void __launch_bounds__(256) k_cov_reanchor(double* __restrict__ P, in
     extern __shared__ double pf[];     // n
     __shared__ int nz_idx[64]; __shared__ double nz_val[64]; __shared__ int nnz_s;
     const int t = threadIdx.x;
-    if (t == 0) {                      // J has ~19 non-zeros (feature, two clone blocks, extrinsics): compact them once
-        int c = 0;
-        for (int k = 0; k < n && c < 64; ++k) { const double v = J[k]; if (v != 0.) { nz_idx[c] = k; nz_val[c] = v; ++c; } }
-        nnz_s = c;
+    // J has ~19 non-zeros (feature, two clone blocks, extrinsics): ordered compaction (ballot prefix per wave)
+    __shared__ int wave_cnt[8];
+    if (t == 0) nnz_s = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int k = base + t;
+        const double v = k < n ? J[k] : 0.;
+        const unsigned long long m = __ballot(v != 0.);
+        if ((t & 63) == 0) wave_cnt[t >> 6] = (int)__popcll(m);
+        __syncthreads();
+        int off = nnz_s;
+        for (int q = 0; q < (t >> 6); ++q) off += wave_cnt[q];
+        if (v != 0.) { const int slot = off + (int)__popcll(m & ((1ull << (t & 63)) - 1ull)); if (slot < 64) { nz_idx[slot] = k; nz_val[slot] = v; } }
+        __syncthreads();
+        if (t == 0) nnz_s = min(nnz_s + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3], 64);
+        __syncthreads();
     }
-    __syncthreads();
     const int nnz = nnz_s;
     for (int b = t; b < n; b += 256) { double s = 0.; for (int q = 0; q < nnz; ++q) s += nz_val[q] * P[(size_t)nz_idx[q] * ld + b]; pf[b] = s; }
     __syncthreads();
@@ -293,6 +303,38 @@ __global__ void k_dx_new(const double* __restrict__ H1, int ldh, const double* _
 //   k_chol_update: trailing S22 -= X X^T (lower tiles) and B2 -= X W_p on the FP64 matrix cores (K = 32 => 8 MFMAs per tile)
 // so the O(m^3) work runs on all CUs and the dependent chain is 2*ceil(m/32) short launches instead of one workgroup.
 #define CP_NB 32
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{   // lane is a compile-time constant after unrolling: two v_readlane_b32
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rsqrt_refined(double x)
+{   // v_rsq_f64 seed + two Newton steps (full double precision for SPD pivots); replaces sqrt + divide on the pivot chain
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+// One wavefront factors the nb x nb (nb <= 32) diagonal block held in LDS: lane i keeps row i in registers, column j of L is
+// broadcast with v_readlane (all indices compile-time after unrolling), no barriers and no LDS traffic on the pivot chain.
+__device__ __forceinline__ void chol32_wave(double (*Ld)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
+{
+    double a[CP_NB];
+#pragma unroll
+    for (int c = 0; c < CP_NB; ++c) a[c] = (lane < nb && c < nb) ? Ld[lane][c] : ((lane == c) ? 1.0 : 0.0);
+#pragma unroll
+    for (int j = 0; j < CP_NB; ++j) {
+        double piv = readlane_f64(a[j], j);
+        if (!(piv > 0.)) { if (report && lane == 0 && j < nb && info[0] == 0) info[0] = j0 + j + 1; piv = 1.0; }
+        const double rinv = rsqrt_refined(piv);
+        const double l = (lane == j) ? piv * rinv : a[j] * rinv;      // L[i][j]; the diagonal is sqrt(piv)
+        a[j] = l;
+#pragma unroll
+        for (int k = j + 1; k < CP_NB; ++k) { const double lk = readlane_f64(l, k); a[k] -= l * lk; }
+    }
+#pragma unroll
+    for (int c = 0; c < CP_NB; ++c) if (lane < nb && c < nb && c <= lane) Ld[lane][c] = a[c];
+}
 __global__ void __launch_bounds__(256) k_chol_panel(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
                                                    int j0, int n_sblocks, int* __restrict__ info)
 {
@@ -301,20 +343,8 @@ __global__ void __launch_bounds__(256) k_chol_panel(double* __restrict__ S, int 
     const int nb = min(CP_NB, m - j0);
     for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; Ld[a][b] = S[(size_t)(j0 + a) * lds_ + j0 + b]; }
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        double d = Ld[j][j];
-        if (!(d > 0.)) { if (t == 0 && blockIdx.x == 0 && info[0] == 0) info[0] = j0 + j + 1; d = 1.0; }
-        const double djj = sqrt(d);
-        __syncthreads();
-        if (t == 0) Ld[j][j] = djj;
-        if (t > j && t < nb) Ld[t][j] /= djj;
-        __syncthreads();
-        for (int e = t; e < (nb - j - 1) * (nb - j - 1); e += 256) {
-            int a = j + 1 + e / (nb - j - 1), b = j + 1 + e % (nb - j - 1);
-            if (b <= a) Ld[a][b] -= Ld[a][j] * Ld[b][j];
-        }
-        __syncthreads();
-    }
+    if (t < 64) chol32_wave(Ld, nb, t, info, j0, blockIdx.x == 0);
+    __syncthreads();
     if (blockIdx.x == 0) for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * lds_ + j0 + b] = Ld[a][b]; }
     if ((int)blockIdx.x < n_sblocks) {
         const int rix = j0 + nb + blockIdx.x * 256 + t;

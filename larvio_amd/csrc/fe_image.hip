@@ -274,7 +274,7 @@ __device__ __forceinline__ float ord2f(unsigned k) { return k == 0 ? 0.f : __uin
 // gftt scratch layout (uints): [0] max key, [1] n candidates, [2] overflow flag, [3] spare, [GF_HIST_OFF ...) strength histogram
 #define GF_HIST_BITS 13
 #define GF_HIST_OFF 4
-#define GF_SCRATCH_UINTS (GF_HIST_OFF + (1 << GF_HIST_BITS))
+#define GF_SCRATCH_UINTS 4
 __global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int n,
                                                    unsigned* __restrict__ scratch)
 {
@@ -282,42 +282,52 @@ __global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ ei
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
         if (!mask || mask[i]) best = max(best, f2ord(eig[i]));
     for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(&scratch[0], best);
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) { best = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); if (best) atomicMax(&scratch[0], best); }
 }
 
-__global__ void k_gftt_candidates(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int w, int h,
-                                  float quality, unsigned* __restrict__ scratch,
-                                  unsigned long long* __restrict__ cands, int cap)
+// 3x3 non-maximum suppression above quality*max, inside the mask.  One workgroup scans 256 columns x GC_ROWS rows, collects its
+// candidates in LDS and reserves space in the global list with ONE atomic (a per-wavefront atomic on a single counter serialises
+// ~2,000 L2 atomics per frame: 35 us).
+#define GC_ROWS 8
+__global__ void __launch_bounds__(256) k_gftt_candidates(const float* __restrict__ eig, const uint8_t* __restrict__ mask, int w, int h,
+                                                        float quality, unsigned* __restrict__ scratch,
+                                                        unsigned long long* __restrict__ cands, int cap)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x + 1, y = blockIdx.y + 1;
-    if (x >= w - 1 || y >= h - 1) return;
+    __shared__ unsigned long long loc[256 * GC_ROWS / 2];
+    __shared__ unsigned cnt, base;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x + 1;
     const float max_val = ord2f(scratch[0]);
     const float thresh = (float)((double)max_val * (double)quality);
-    float v = eig[(size_t)y * w + x];
-    v = v > thresh ? v : 0.f;
-    if (v == 0.f) return;
-    if (mask && !mask[(size_t)y * w + x]) return;
-    float m = v;
+    for (int ry = 0; ry < GC_ROWS; ++ry) {
+        const int y = blockIdx.y * GC_ROWS + ry + 1;
+        if (x >= w - 1 || y >= h - 1) continue;
+        float v = eig[(size_t)y * w + x];
+        v = v > thresh ? v : 0.f;
+        if (v == 0.f) continue;
+        if (mask && !mask[(size_t)y * w + x]) continue;
+        float m = v;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            float u = eig[(size_t)(y + dy) * w + x + dx];
-            u = u > thresh ? u : 0.f;
-            m = fmaxf(m, u);
-        }
-    if (v != m) return;
-    // wave-aggregated append: one atomic per wavefront instead of one per candidate
-    const unsigned long long act = __ballot(1);
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)act) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&scratch[1], (unsigned)__popcll(act));
-    base = __shfl(base, leader);
-    const unsigned slot = base + (unsigned)__popcll(act & ((1ull << lane) - 1ull));
-    if (slot < (unsigned)cap) cands[slot] = ((unsigned long long)f2ord(v) << 32) | (unsigned)(y * w + x);
-    else scratch[2] = 1u;
-    atomicAdd(&scratch[GF_HIST_OFF + (f2ord(v) >> (32 - GF_HIST_BITS))], 1u);      // strength histogram: bucket boundaries for the select kernel
+            for (int dx = -1; dx <= 1; ++dx) {
+                float u = eig[(size_t)(y + dy) * w + x + dx];
+                u = u > thresh ? u : 0.f;
+                m = fmaxf(m, u);
+            }
+        if (v != m) continue;
+        const unsigned slot = atomicAdd(&cnt, 1u);
+        if (slot < 256 * GC_ROWS / 2) loc[slot] = ((unsigned long long)f2ord(v) << 32) | (unsigned)(y * w + x);
+    }
+    __syncthreads();
+    const unsigned n_loc = min(cnt, (unsigned)(256 * GC_ROWS / 2));
+    if (threadIdx.x == 0) { base = n_loc ? atomicAdd(&scratch[1], n_loc) : 0u; if (cnt > n_loc) scratch[2] = 1u; }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < n_loc; i += 256) { const unsigned slot = base + i; if (slot < (unsigned)cap) cands[slot] = loc[i]; else scratch[2] = 1u; }
 }
 
 // single workgroup: the greedy min-distance pass of goodFeaturesToTrack ("visit candidates by descending strength, accept
@@ -366,13 +376,18 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
     }
     const int n = (int)min(scratch[1], (unsigned)cap);
     constexpr int GROUP = (1 << GF_HIST_BITS) / 1024;
-    {
-        unsigned s = 0;
-        for (int q = 0; q < GROUP; ++q) { const unsigned c = scratch[GF_HIST_OFF + t * GROUP + q]; hist[t * GROUP + q] = c; s += c; }
-        coarse[t] = s;
-    }
+    // strength histogram of the candidates (LDS atomics; one pass over the candidate keys)
+    for (int q = 0; q < GROUP; ++q) hist[t * GROUP + q] = 0u;
     for (int i = t; i < gw * gh; i += 1024) { cells[i][0] = cells[i][1] = cells[i][2] = cells[i][3] = 0xFFFF; }
     if (t == 0) { sh_na = 0; sh_done = 0; sh_hi = 1 << GF_HIST_BITS; }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) atomicAdd(&hist[(unsigned)(cands[i] >> (64 - GF_HIST_BITS))], 1u);
+    __syncthreads();
+    {
+        unsigned s = 0;
+        for (int q = 0; q < GROUP; ++q) s += hist[t * GROUP + q];
+        coarse[t] = s;
+    }
     __syncthreads();
     int target = 1024;
     for (int bucket = 0; bucket < 4096; ++bucket) {
@@ -629,8 +644,8 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
     if (gw * gh > GF_MAX_CELLS) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT grid %dx%d exceeds %d cells", gw, gh, GF_MAX_CELLS);
     if (max_corners > GF_MAX_OUT || max_corners <= 0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "maxCorners must be in 1..%d", GF_MAX_OUT);
     LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(k_masked_max, dim3(256), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch);
-    hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, h - 2), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
+    hipLaunchKernelGGL(k_masked_max, dim3(128), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch);
+    hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, (h - 2 + GC_ROWS - 1) / GC_ROWS), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
     const size_t shm = (size_t)GF_SURV * 8 + (size_t)gw * gh * 8 + (size_t)GF_MAX_OUT * 4;
     static size_t attr_set = 0;       // the opt-in must leave room for the kernel's static LDS: ask for exactly what is launched
     if (attr_set < shm) { attr_set = shm; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); }

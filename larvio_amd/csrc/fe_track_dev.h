@@ -5,11 +5,15 @@
 #include <float.h>
 
 // ------------------------------------------------------------------------- wave reductions
+// integer all-reduce over the wavefront: four DPP row rotations (every lane gets its 16-lane row sum), then the four row
+// sums are combined through v_readlane (scalar).  Integer adds are exact, so any order gives the same bits.
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 // exact sum over the wave of per-lane int32 partials, as int64 (all lanes get the result)
 __device__ __forceinline__ long long wave_sum_i64(int v)
@@ -21,7 +25,8 @@ __device__ __forceinline__ long long wave_sum_i64(int v)
 
 // ------------------------------------------------------------------------- pyramidal LK
 // [cv::calcOpticalFlowPyrLK / LKTrackerInvoker], OPTFLOW_USE_INITIAL_FLOW, minEigThreshold 1e-4.
-// One wavefront per point.  The WIN x WIN template (I, Ix, Iy after the 14-bit bilinear blend) lives
+// One wavefront per point.  (An LDS-staged variant of the template/search windows was measured and was NOT faster: the kernel is
+// bound by the dependent VALU chain of the slowest track, ~0.5 us per iteration, not by the L2 gathers.)  The WIN x WIN template (I, Ix, Iy after the 14-bit bilinear blend) lives
 // in registers, PL = ceil(WIN^2/64) pixels per lane; A11/A12/A22 and b1/b2 are EXACT integer sums
 // (int32 per lane, int64 across the wave) converted to float once, so the result does not depend on
 // the reduction order (see oracle/fe_track.c).  All lanes hold identical copies of the scalar state.

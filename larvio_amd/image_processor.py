@@ -44,6 +44,7 @@ class ImageProcessor:
             print("lvk_frontend_create failed:", lib().lvk_last_error(self.ctx.h).decode())
             return False
         self._h = h
+        self.ctx.adopt(self)
         self._cap = self.config["max_features_num"]
         self._out = np.zeros(self._cap, OBS)
         return True

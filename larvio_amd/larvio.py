@@ -106,6 +106,7 @@ class LarVio:
             print("lvk_ekf_create failed:", lib().lvk_last_error(self.ctx.h).decode())
             return False
         self._h = h
+        self.ctx.adopt(self)
         return True
 
     def processFeatures(self, msg, imu_msg_buffer):
