@@ -293,9 +293,17 @@ __device__ __forceinline__ lvk_pt2f undistort_point(lvk_pt2f in, const CamParams
 }
 
 // ------------------------------------------------------------------------- fundamental matrix
+#ifdef LVK_FM_TIMING
+static __device__ unsigned long long g_fm_tick[32];
+static __device__ int g_fm_on = 1;
+#define FM_TICK(k) do { if (threadIdx.x == 0 && g_fm_on) g_fm_tick[k] = wall_clock64(); } while (0)
+#else
+#define FM_TICK(k) do { } while (0)
+#endif
 #define FM_THREADS 256
 #define FM_MAX_N 4096
 #define FM_ROUND 16            // hypotheses solved and scored per round
+#define FM_FIRST 4             // ... in the first round
 
 __device__ inline void d_nullspace_7x9(const double* A, double* f1, double* f2)
 {   // Householder QR of A^T; last two columns of Q (same operation order as the oracle)
@@ -389,9 +397,10 @@ __device__ inline int d_solve_cubic(const double* coef, double* roots)
     return n;
 }
 
+__device__ inline int d_7pt_finish(double* f1, double* f2, double* fmatrix);
 __device__ inline int d_fundamental_7pt(const lvk_pt2f* m1, const lvk_pt2f* m2, double* fmatrix)
 {   // run7Point
-    double a[7 * 9], f1[9], f2[9], c[4], r[3] = {0, 0, 0};
+    double a[7 * 9], f1[9], f2[9];
     for (int i = 0; i < 7; ++i) {
         double x0 = m1[i].x, y0 = m1[i].y, x1 = m2[i].x, y1 = m2[i].y;
         a[i * 9 + 0] = x1 * x0; a[i * 9 + 1] = x1 * y0; a[i * 9 + 2] = x1;
@@ -399,6 +408,13 @@ __device__ inline int d_fundamental_7pt(const lvk_pt2f* m1, const lvk_pt2f* m2, 
         a[i * 9 + 6] = x0; a[i * 9 + 7] = y0; a[i * 9 + 8] = 1;
     }
     d_nullspace_7x9(a, f1, f2);
+    return d_7pt_finish(f1, f2, fmatrix);
+}
+
+// second half of run7Point: det(lambda*f1 + (1-lambda)*f2) = 0, up to three models
+__device__ inline int d_7pt_finish(double* f1, double* f2, double* fmatrix)
+{
+    double c[4], r[3] = {0, 0, 0};
     for (int i = 0; i < 9; ++i) f1[i] -= f2[i];
     double t0 = f2[4] * f2[8] - f2[5] * f2[7];
     double t1 = f2[3] * f2[8] - f2[5] * f2[6];
@@ -459,6 +475,20 @@ __device__ __forceinline__ unsigned d_rng_next(d_rng& r)
 }
 __device__ __forceinline__ int d_rng_uniform(d_rng& r, int a, int b) { return a == b ? a : (int)(d_rng_next(r) % (unsigned)(b - a) + a); }
 
+// cv::findFundamentalMat seeds a fresh cv::RNG(-1) on every call, so the raw 32-bit draws of one call are always the same
+// sequence: FM_RNG.s[k] is the generator state after k+1 draws (draw k = its low word).  Built at compile time.
+#define FM_RNG_DRAWS 4096
+struct FmRngTable {
+    unsigned long long s[FM_RNG_DRAWS];
+    constexpr FmRngTable() : s{} {
+        unsigned long long st = ~0ULL;
+        for (int k = 0; k < FM_RNG_DRAWS; ++k) { st = (unsigned long long)(unsigned)st * 4164903690ULL + (unsigned)(st >> 32); s[k] = st; }
+    }
+};
+static __device__ const FmRngTable FM_RNG = FmRngTable();
+#define FM_WIN FM_THREADS      // draws looked at per round (16 subsets use ~115 of them)
+#define FM_NOFIT 0xffffu
+
 __device__ inline bool d_have_collinear(const lvk_pt2f* ptr, int count)
 {
     int i = count - 1;
@@ -503,6 +533,90 @@ __device__ inline int d_ransac_update_num_iters(double p, double ep, int model_p
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
+// d_fundamental_7pt for the hypotheses of one RANSAC round, eight lanes per hypothesis: lane c owns column c of A^T (the nine
+// monomials of correspondence c) in registers; reflector k is built by lane k, published through LDS and applied by lanes
+// c >= k to their own column; lanes 0/1 back-accumulate the two null vectors; lane 0 finishes.  Every sum runs in the order
+// of d_nullspace_7x9, so the models are the same bits.  Called by the whole workgroup (barriers inside).
+struct FmSolveLds { double V[FM_ROUND][7][9]; double beta[FM_ROUND][7]; double f12[FM_ROUND][2][9]; };
+__device__ inline void fm_solve_round(int nr, const lvk_pt2f (*sub1)[7], const lvk_pt2f (*sub2)[7], const int* found,
+                                      double (*models)[27], int* nmodels, FmSolveLds& L)
+{
+    const int t = threadIdx.x, g = t >> 3, c = t & 7;
+    const bool act = g < nr && c < 7 && found[g];
+    double M[9];
+    if (act) {
+        const double x0 = sub1[g][c].x, y0 = sub1[g][c].y, x1 = sub2[g][c].x, y1 = sub2[g][c].y;
+        M[0] = x1 * x0; M[1] = x1 * y0; M[2] = x1; M[3] = y1 * x0; M[4] = y1 * y0; M[5] = y1; M[6] = x0; M[7] = y0; M[8] = 1;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) M[r] = 0.;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        if (act && c == k) {
+            double nrm2 = 0.;
+#pragma unroll
+            for (int r = k; r < 9; ++r) nrm2 += M[r] * M[r];
+            const double nrm = sqrt(nrm2);
+            double b = 0.;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) L.V[g][k][r] = 0.;
+            if (nrm != 0.) {
+                const double alpha = M[k] >= 0. ? -nrm : nrm;
+                const double v0 = M[k] - alpha;
+                L.V[g][k][k] = v0;
+                double vnorm2 = v0 * v0;
+#pragma unroll
+                for (int r = k + 1; r < 9; ++r) { L.V[g][k][r] = M[r]; vnorm2 += M[r] * M[r]; }
+                b = vnorm2 == 0. ? 0. : 2. / vnorm2;
+                // a negative beta marks "norm was zero: skip" for the appliers (2/vnorm2 is never negative)
+            } else b = -1.;
+            L.beta[g][k] = b;
+        }
+        __syncthreads();
+        if (act && c >= k) {
+            const double b = L.beta[g][k];
+            if (b >= 0.) {
+                double sacc = 0.;
+#pragma unroll
+                for (int r = k; r < 9; ++r) sacc += L.V[g][k][r] * M[r];
+                sacc *= b;
+#pragma unroll
+                for (int r = k; r < 9; ++r) M[r] -= sacc * L.V[g][k][r];
+            }
+        }
+    }
+    FM_TICK(11);
+    if (g < nr && c < 2 && found[g]) {
+        double q[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) q[r] = (r == 7 + c) ? 1. : 0.;
+#pragma unroll
+        for (int k = 6; k >= 0; --k) {
+            double b = L.beta[g][k];
+            b = b < 0. ? 0. : b;
+            double sacc = 0.;
+#pragma unroll
+            for (int r = k; r < 9; ++r) sacc += L.V[g][k][r] * q[r];
+            sacc *= b;
+#pragma unroll
+            for (int r = k; r < 9; ++r) q[r] -= sacc * L.V[g][k][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) L.f12[g][c][r] = q[r];
+    }
+    __syncthreads();
+    FM_TICK(12);
+    if (g < nr && c == 0) {
+        if (found[g]) {
+            double f1[9], f2[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) { f1[r] = L.f12[g][0][r]; f2[r] = L.f12[g][1][r]; }
+            nmodels[g] = d_7pt_finish(f1, f2, models[g]);
+        } else nmodels[g] = 0;
+    }
+}
+
 // The whole of cv::findFundamentalMat(..., FM_RANSAC, thresh, conf, mask) for one point set held in
 // LDS, executed by one FM_THREADS workgroup.  Returns (uniformly) 1 if smask[0..n) was written.
 //   n < 7: nothing;  n == 7: ones;  8..14: LMedS (300 hypotheses, all in parallel);
@@ -518,6 +632,10 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
     __shared__ double best_model[9];
     __shared__ int sh_ctl[4];                 // [0] stop, [1] have best, [2] iterations, [3] niters
     __shared__ unsigned long long sh_rng;
+    __shared__ unsigned short idxw[FM_WIN], fw[FM_WIN], selw[FM_WIN][7];
+    __shared__ int off[FM_ROUND + 1];
+    __shared__ FmSolveLds solve_lds;
+    __shared__ int sh_pos, sh_serial, sh_anybad;
     __shared__ float lm_med[FM_THREADS]; __shared__ int lm_seq[FM_THREADS];
     const int t = threadIdx.x;
     *iters_out = 0;
@@ -528,33 +646,113 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
 
     if (n >= 15 || force_ransac) {
         const float tthr = (float)(thresh * thresh);
-        if (t == 0) { sh_ctl[0] = 0; sh_ctl[1] = 0; sh_ctl[2] = 0; sh_ctl[3] = max_iters > 1 ? max_iters : 1; sh_rng = ~0ULL; }
+        if (t == 0) { sh_ctl[0] = 0; sh_ctl[1] = 0; sh_ctl[2] = 0; sh_ctl[3] = max_iters > 1 ? max_iters : 1; sh_rng = ~0ULL; sh_pos = 0; sh_serial = 0; sh_anybad = 0; }
         __syncthreads();
         int max_good = 0;       // thread 0 only
-        for (int base = 0;; base += FM_ROUND) {
-            if (t == 0) {
+        int base = 0;
+        for (int round = 0;; ++round) {
+            // LARVIO's point sets are mostly inliers after the LK and descriptor gates: the first hypotheses usually end the loop
+            // (niters collapses to a handful), so the first round is short
+            const int nr = round == 0 ? FM_FIRST : FM_ROUND;
+            FM_TICK(4);
+            // ---- the round's FM_ROUND subsets, in OpenCV's RNG order.  Fast path: every thread maps one table draw to a point
+            // index, then works out the subset that WOULD start at its draw (7 distinct indices, duplicates redrawn one at a
+            // time as getSubset does); thread 0 only chases the 16 start offsets.  A collinear subset (redraw of all 7) or a
+            // window overrun drops to the sequential path for the rest of the call.
+            const int pos = sh_pos;
+            bool serial = sh_serial != 0;
+            if (!serial && pos + FM_WIN > FM_RNG_DRAWS) {
+                serial = true;
+                if (t == 0) { sh_rng = pos ? FM_RNG.s[pos - 1] : ~0ULL; sh_serial = 1; }
+            }
+            if (!serial) {
+                idxw[t] = (unsigned short)((unsigned)FM_RNG.s[pos + t] % (unsigned)n);
+                if (t == 0) sh_anybad = 0;
+                __syncthreads();
+                {
+                    int sel[7] = {-1, -1, -1, -1, -1, -1, -1};
+                    int c = 0, q = t;
+                    while (c < 7 && q < FM_WIN) {
+                        const int v = idxw[q++];
+                        bool dup = false;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) dup |= sel[k] == v;
+                        if (!dup) {
+#pragma unroll
+                            for (int k = 0; k < 7; ++k) if (k == c) sel[k] = v;
+                            ++c;
+                        }
+                    }
+                    fw[t] = c == 7 ? (unsigned short)(q - t) : (unsigned short)FM_NOFIT;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) selw[t][k] = (unsigned short)sel[k];
+                }
+                __syncthreads();
+                if (t == 0) {
+                    int o = 0;
+                    for (int r = 0; r < nr; ++r) {
+                        if (o >= FM_WIN || fw[o] == FM_NOFIT) { sh_anybad = 1; break; }
+                        off[r] = o; o += fw[o];
+                    }
+                    off[nr] = o;
+                }
+                __syncthreads();
+                if (!sh_anybad) {
+                    if (t < nr * 7) {
+                        const int r = t / 7, i = t - 7 * r, k = selw[off[r]][i];
+                        sub1[r][i] = s1[k]; sub2[r][i] = s2[k];
+                    }
+                    if (t < nr) found[t] = 1;
+                    __syncthreads();
+                    if (t < nr * 15) {            // haveCollinearPoints: the last point against every pair of the others
+                        const int r = t / 15, pr = t - 15 * r;
+                        int j = 1, k = pr;
+                        while (k >= j) { k -= j; ++j; }  // pr -> (j, k), 0 <= k < j <= 5
+                        bool bad = false;
+                        for (int im = 0; im < 2; ++im) {
+                            const lvk_pt2f* ptr = im ? sub2[r] : sub1[r];
+                            double dx1 = ptr[j].x - ptr[6].x, dy1 = ptr[j].y - ptr[6].y;
+                            double dx2 = ptr[k].x - ptr[6].x, dy2 = ptr[k].y - ptr[6].y;
+                            bad |= fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+                        }
+                        if (bad) sh_anybad = 1;
+                    }
+                    __syncthreads();
+                }
+                serial = sh_anybad != 0;
+                if (serial) { if (t == 0) { sh_rng = pos ? FM_RNG.s[pos - 1] : ~0ULL; sh_serial = 1; } }
+                else if (t == 0) sh_pos = pos + off[nr];
+                __syncthreads();
+            }
+            if (serial && t == 0) {
                 d_rng rng; rng.state = sh_rng;
-                for (int r = 0; r < FM_ROUND; ++r) found[r] = d_get_subset(s1, s2, n, sub1[r], sub2[r], rng, 10000) ? 1 : 0;
+                for (int r = 0; r < nr; ++r) found[r] = d_get_subset(s1, s2, n, sub1[r], sub2[r], rng, 10000) ? 1 : 0;
                 sh_rng = rng.state;
             }
-            if (t < FM_ROUND * 3) good[t / 3][t % 3] = 0;
+            if (t < nr * 3) good[t / 3][t % 3] = 0;
             __syncthreads();
-            if (t < FM_ROUND) nmodels[t] = found[t] ? d_fundamental_7pt(sub1[t], sub2[t], models[t]) : 0;
+            FM_TICK(5);
+            fm_solve_round(nr, sub1, sub2, found, models, nmodels, solve_lds);
             __syncthreads();
-            for (int slot = t >> 6; slot < FM_ROUND * 3; slot += FM_THREADS / 64) {
-                int r = slot / 3, m = slot - 3 * r;
-                if (m >= nmodels[r]) continue;
-                int cnt = 0;
-                for (int i = t & 63; i < n; i += 64) cnt += d_fm_error(s1[i], s2[i], &models[r][9 * m]) <= tthr;
-                cnt = wave_sum_i32(cnt);
-                if ((t & 63) == 0) good[r][m] = cnt;
+            FM_TICK(6);
+            {   // inlier counts: (model slot, point) pairs dealt round-robin to the threads; integer counts, order-free
+                int slot = 0, i = t;
+                const int nslots = nr * 3;
+                while (i >= n) { i -= n; ++slot; }
+                while (slot < nslots) {
+                    const int r = slot / 3, m = slot - 3 * r;
+                    if (m < nmodels[r] && d_fm_error(s1[i], s2[i], &models[r][9 * m]) <= tthr) atomicAdd(&good[r][m], 1);
+                    i += FM_THREADS;
+                    while (i >= n) { i -= n; ++slot; }
+                }
             }
             __syncthreads();
+            FM_TICK(7);
             if (t == 0) {
                 // replay of RANSACPointSetRegistrator::run's loop over this round, in order
                 int niters = sh_ctl[3], iter = base;
                 bool stop = false;
-                for (int r = 0; r < FM_ROUND; ++r, ++iter) {
+                for (int r = 0; r < nr; ++r, ++iter) {
                     if (iter >= niters) { stop = true; break; }
                     if (!found[r]) { stop = true; break; }            // getSubset failed: iter==0 -> no model, else stop
                     for (int m = 0; m < nmodels[r]; ++m) {
@@ -570,7 +768,9 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
                 sh_ctl[0] = stop ? 1 : 0; sh_ctl[2] = iter; sh_ctl[3] = niters;
             }
             __syncthreads();
+            FM_TICK(8);
             if (sh_ctl[0]) break;
+            base += nr;
         }
         // iterations drawn = value of `iter` when OpenCV's loop exits
         if (sh_ctl[1]) { for (int i = t; i < n; i += FM_THREADS) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tthr; }

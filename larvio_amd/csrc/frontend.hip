@@ -275,6 +275,10 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int c
     __shared__ int cnt[4];
     __shared__ int scan[FM_THREADS];
     const int t = threadIdx.x;
+#ifdef LVK_FM_TIMING
+    if (t == 0) g_fm_on = mode == 0;
+#endif
+    FM_TICK(0);
     const int n = min(*n_ptr, cap);
     if (t < 4) cnt[t] = 0;
     __syncthreads();
@@ -296,6 +300,7 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int c
         base += scan[FM_THREADS - 1];
         __syncthreads();
     }
+    FM_TICK(1);
     const int m = cnt[2];
     bool fail = false;
     if (mode == 2) fail = cnt[0] < 20 || cnt[1] < 20 || m < 20;
@@ -308,8 +313,10 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int c
             s2[k] = undistort_point(w_curr[i], cam, cam.intr);
         }
         __syncthreads();
+        FM_TICK(2);
         wrote = fm_mask_block(s1, s2, m, 1.0, 0.99, 1000, 0, smask, &iters);
         __syncthreads();
+        FM_TICK(9);
     }
     // survivors of the mask (size mismatch => everything is kept, image_processor.h:219-223)
     int kept = 0;
@@ -348,6 +355,10 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int c
     if (mode == 2 && kept < 20) fail = true;
     if (mode == 1 && kept <= 0) fail = true;
     __syncthreads();
+    FM_TICK(10);
+#ifdef LVK_FM_TIMING
+    if (t == 0 && g_fm_on) { g_fm_tick[16 + 0] = m; g_fm_tick[16 + 1] = iters; g_fm_tick[16 + 2] = mode; }
+#endif
     if (t == 0) {
         if (mode == 0) *dst_n = kept;
         else if (mode == 1) { if (!fail) { *dst_n = min(*dst_n + kept, cap); dev->next_id += (unsigned long long)kept; dev->n_new = 0; } }
@@ -493,6 +504,10 @@ static lvk_status commit(lvk_frontend* fe, int mode, const lvk_pt2f* src_pts, co
     LVK_LAUNCH_CHECK(fe->ctx);
     return LVK_OK;
 }
+
+#ifdef LVK_FM_TIMING
+extern "C" void lvk_debug_fm_ticks(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_tick), sizeof(unsigned long long) * 32); }
+#endif
 
 extern "C" {
 
