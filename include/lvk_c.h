@@ -234,6 +234,18 @@ void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
 lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, int stride, int img_is_device, double ts,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated);
 
+/* The same loop, pipelined across two HIP streams: the filter update of frame k (worker thread, ekf's context) overlaps the
+ * front-end of frame k+1 (caller's thread, fe's context).  fe and ekf must have been created on DIFFERENT lvk_contexts.
+ * The pipe owns the driver's IMU vector: push samples as larvioMain.cpp:98-102 does (t < t_img + 0.05) before each submit;
+ * erasure happens inside, in the order the sequential loop would do it, so every result is identical to lvk_vio_process.
+ * push/submit/drain are called from one thread.  Read the filter (lvk_ekf_get_*) only after lvk_vio_pipe_drain. */
+typedef struct lvk_vio_pipe lvk_vio_pipe;
+lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** out);
+void       lvk_vio_pipe_destroy(lvk_vio_pipe* p);
+lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n);
+lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, int img_is_device, double ts, int* has_msg);
+lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs);
+
 #ifdef __cplusplus
 }
 #endif

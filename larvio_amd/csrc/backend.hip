@@ -18,6 +18,10 @@
 #include <algorithm>
 #include <new>
 #include <float.h>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
 
 #define LEG 22
 #define GRAV 9.81
@@ -103,8 +107,26 @@ struct lvk_ekf {
     char* d_up = nullptr;                               // device mirror of the upload arena: ONE H2D copy per sync point
     CamPose* dv_cams = nullptr; CloneDev* dv_clones = nullptr;
     char* h_down = nullptr; size_t down_cap = 0;
-    // timing of GPU stages via events is done by the caller (bench) around lvk_ekf_process
+    // fired as soon as the number of IMU samples this call erases is final (before any GPU work): lets a pipelined driver
+    // hand the next frame's front-end the right buffer view while this update is still running
+    void (*on_consumed)(void*, int) = nullptr; void* on_consumed_user = nullptr;
 };
+
+// ------------------------------------------------------------------------- host-side phase tracer (LVK_EKF_TRACE=1)
+#include <chrono>
+enum { TR_IMU, TR_PROP, TR_ADDOBS, TR_AUG, TR_ZUPT, TR_RLF_PRE, TR_RLF_TRI, TR_RLF_TRIAGE, TR_RLF_ROWS, TR_RLF_UPD, TR_RLF_DX, TR_RLF_INJ,
+       TR_PR_PRE, TR_PR_TRI, TR_PR_ROWS, TR_PR_UPD, TR_PR_DX, TR_PR_END, TR_FINAL, TR_N };
+static const char* const TR_NAMES[TR_N] = {"batch_imu", "propagate(launch)", "add_obs", "augment(launch)", "zupt_check", "lost:prepare", "lost:triangulate+sync",
+    "lost:triage+jobs", "lost:rows+sync", "lost:stack+update(launch)", "lost:dx sync", "lost:inject", "prune:prepare(+reanchor)", "prune:triangulate+sync",
+    "prune:rows+sync", "prune:update(launch)", "prune:dx sync", "prune:inject+delete", "final sync"};
+struct EkfTrace {
+    bool on = false; double acc[TR_N] = {0}; long n = 0;
+    std::chrono::steady_clock::time_point last;
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(int slot) { if (!on) return; auto t = std::chrono::steady_clock::now(); acc[slot] += std::chrono::duration<double, std::micro>(t - last).count(); last = t; }
+};
+static EkfTrace g_tr;
+#define TR(slot) g_tr.mark(slot)
 
 // ------------------------------------------------------------------------- small helpers
 static int clone_rank(const lvk_ekf* e, long long id) { for (size_t i = 0; i < e->clones.size(); ++i) if (e->clones[i].id == id) return (int)i; return -1; }
@@ -242,17 +264,42 @@ static void process_model(lvk_ekf* e, double time, const double* m_gyro, const d
     double G[LEG * 12]; memset(G, 0, sizeof G);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { G[i * 12 + j] = -C[i * 3 + j]; G[(3 + i) * 12 + 3 + j] = -C[i * 3 + j]; }
     for (int i = 0; i < 3; ++i) { G[(9 + i) * 12 + 6 + i] = 1.0; G[(12 + i) * 12 + 9 + i] = 1.0; }
-    double PG[LEG * 12], Q[LEG * LEG];
-    for (int i = 0; i < LEG; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
-    for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < 12; ++k) s += PG[i * 12 + k] * e->Qc[k] * PG[j * 12 + k]; Q[i * LEG + j] = s * dtime; }
-    if (!e->have_prop) { memcpy(e->Phi_tot, Phi, sizeof Phi); memcpy(e->Q_tot, Q, sizeof Q); e->have_prop = true; }
-    else {
-        double T[LEG * LEG], U[LEG * LEG];
-        for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * e->Phi_tot[k * LEG + j]; T[i * LEG + j] = s; }
+    // Structure of the discrete model (cal_phi): rows 9.. of Phi are identity rows and rows 0..8 are zero beyond column 14
+    // (q, v, p depend on q, v, p, bg, ba only); G is zero below row 14.  Skipping the exact-zero products leaves every sum
+    // bit-identical to the dense triple loops and cuts the per-sample host work ~4x.
+    const int A = 9, B = 15;
+    double PG[B * 12], Q[B * B];
+    for (int i = 0; i < A; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += Phi[i * LEG + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
+    for (int i = A; i < B; ++i) for (int j = 0; j < 12; ++j) PG[i * 12 + j] = G[i * 12 + j];
+    for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) { double s = 0; for (int k = 0; k < 12; ++k) s += PG[i * 12 + k] * e->Qc[k] * PG[j * 12 + k]; Q[i * B + j] = s * dtime; }
+    if (!e->have_prop) {
+        memcpy(e->Phi_tot, Phi, sizeof Phi);
+        memset(e->Q_tot, 0, sizeof e->Q_tot);
+        for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * LEG + j] = Q[i * B + j];
+        e->have_prop = true;
+    } else {
+        double T[A * LEG];
+        // Phi_tot <- Phi Phi_tot : only rows 0..8 change
+        for (int i = 0; i < A; ++i) {
+            double* t = T + i * LEG;
+            for (int j = 0; j < LEG; ++j) t[j] = 0;
+            for (int k = 0; k < B; ++k) { const double a = Phi[i * LEG + k]; const double* x = e->Phi_tot + k * LEG; for (int j = 0; j < LEG; ++j) t[j] += a * x[j]; }
+        }
         memcpy(e->Phi_tot, T, sizeof T);
-        for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * e->Q_tot[k * LEG + j]; T[i * LEG + j] = s; }
-        for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += T[i * LEG + k] * Phi[j * LEG + k]; U[i * LEG + j] = s + Q[i * LEG + j]; }
-        memcpy(e->Q_tot, U, sizeof U);
+        // Q_tot <- Phi Q_tot Phi^T + Q : rows 0..8 of (Phi Q_tot), then columns 0..8 of (. Phi^T)
+        for (int i = 0; i < A; ++i) {
+            double* t = T + i * LEG;
+            for (int j = 0; j < LEG; ++j) t[j] = 0;
+            for (int k = 0; k < B; ++k) { const double a = Phi[i * LEG + k]; const double* x = e->Q_tot + k * LEG; for (int j = 0; j < LEG; ++j) t[j] += a * x[j]; }
+        }
+        memcpy(e->Q_tot, T, sizeof T);
+        for (int i = 0; i < LEG; ++i) {
+            double u[A];
+            const double* t = e->Q_tot + i * LEG;
+            for (int j = 0; j < A; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += t[k] * Phi[j * LEG + k]; u[j] = s; }
+            for (int j = 0; j < A; ++j) e->Q_tot[i * LEG + j] = u[j];
+        }
+        for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * LEG + j] += Q[i * B + j];
     }
     e->s.t = time; e->s_fej_now.t = time;
 }
@@ -283,6 +330,17 @@ static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_im
     }
     e->imu_id = e->next_state_id++;
     e->imu_dt = dt;
+    return used;
+}
+
+static int batch_imu_count(const lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
+{   // how many samples batch_imu will erase, without touching the state (timestamps only)
+    int used = 0; double t = e->s.t;
+    for (int i = 0; i < n_imu; ++i) {
+        if (imu[i].t <= t) { ++used; continue; }
+        if (imu[i].t - time_bound > e->imu_img_time_th) break;
+        t = imu[i].t; ++used;
+    }
     return used;
 }
 
@@ -610,8 +668,10 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         }
         cands.push_back(cd);
     }
+    TR(TR_RLF_PRE);
     st = run_triangulation(e, reqs, ans);
     if (st != LVK_OK) return st;
+    TR(TR_RLF_TRI);
     // ---- pass 2: sequential triage (map order) with the precomputed results
     std::vector<long long> invalid, msckf, ekf_new;
     size_t ci = 0;
@@ -672,8 +732,10 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         for (long long id : msckf) { Feature& f = e->map[id]; RowJob r; r.f = &f; r.type = JOB_MSCKF; r.sids = all_sids(f); r.want_gate = true; r.dof = 2 * (int)f.obs.size() - 3; jobs.push_back(r); }
         // NOTE: the feature column index of a new feature must be its FINAL one (after rejected candidates are dropped);
         // it is not used by JOB_EKF_NEW rows (the feature column never reaches H_o), so any value works here.
+        TR(TR_RLF_TRIAGE);
         st = run_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
+        TR(TR_RLF_ROWS);
         // ---- accepted sets and row layout: H_o = [H_msckf ; H_ekf ; top rows of the new block] (:1612-1626)
         std::vector<StackRow> map_o, map_1;
         int rows_m = 0, rows_e = 0, top = 0;
@@ -711,8 +773,10 @@ static lvk_status remove_lost_features(lvk_ekf* e)
                 if (st == LVK_OK) st = lvk_cov_append_features(e->ctx, e->dP[e->cur], e->ld, N, n_acc, e->d_H1, e->ld, dev(e, hh), e->d_r1, e->d_dx, e->sigma2, e->d_tmp, e->d_dx + N);
                 if (st != LVK_OK) return st;
             }
+            TR(TR_RLF_UPD);
             st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)(N + n_acc));
             if (st != LVK_OK) return st;
+            TR(TR_RLF_DX);
             inject(e, dx.data());
             e->N = N + n_acc;
             e->last_update_time = e->s.t;
@@ -722,6 +786,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         for (long long id : msckf) { auto it = e->map.find(id); if (it != e->map.end()) it->second.is_initialized = false; }
     }
     for (long long id : msckf) e->map.erase(id);
+    TR(TR_RLF_INJ);
     return LVK_OK;
 }
 
@@ -864,6 +929,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         }
     }
     std::vector<Use*> used;
+    TR(TR_PR_PRE);
     if (!e->if_zupt && !uses.empty()) {
         if (!reqs.empty()) {
             st = upload_clones(e); clones_uploaded = true;
@@ -879,12 +945,14 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
             used.push_back(&u);
         }
     }
+    TR(TR_PR_TRI);
     if (!e->if_zupt && !used.empty()) {
         if (!clones_uploaded) { st = upload_clones(e); if (st != LVK_OK) return st; }
         std::vector<RowJob> jobs;
         for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
         st = run_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
+        TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; int rows = 0;
         for (auto& j : jobs) if (gate_ok(e, j)) { push_rows(map_o, j, j.res.first_row, j.res.rows, rows); rows += j.res.rows; }
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
@@ -892,8 +960,10 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
             st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, rows, dx, 0);
+            TR(TR_PR_UPD);
             if (st == LVK_OK) st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)e->N);
             if (st != LVK_OK) return st;
+            TR(TR_PR_DX);
             inject(e, dx.data());
             e->last_update_time = e->s.t;
             e->counters[1]++;
@@ -1014,6 +1084,12 @@ void lvk_ekf_destroy(lvk_ekf* e)
 {
     if (!e) return;
     hipStreamSynchronize(e->ctx->stream);
+    if (g_tr.on && g_tr.n > 0) {
+        double tot = 0; for (int i = 0; i < TR_N; ++i) tot += g_tr.acc[i];
+        fprintf(stderr, "[lvk_ekf trace] %ld updates, %.1f us/update host wall\n", g_tr.n, tot / g_tr.n);
+        for (int i = 0; i < TR_N; ++i) fprintf(stderr, "  %-28s %8.1f us\n", TR_NAMES[i], g_tr.acc[i] / g_tr.n);
+        g_tr = EkfTrace();
+    }
     void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_triout, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
                     e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info, e->d_up};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1028,6 +1104,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     if (cfg->feature_idp_dim != 1 || cfg->use_schmidt != 0 || cfg->calib_imu_instrinsic != 0)
         return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "only feature_idp_dim 1, use_schmidt 0, calib_imu_instrinsic 0 are implemented");
     if (cfg->sw_size < 5 || cfg->sw_size > 62) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "sw_size must be in 5..62");
+    g_tr.on = getenv("LVK_EKF_TRACE") != nullptr;
     lvk_ekf* e = new (std::nothrow) lvk_ekf();
     if (!e) return LVK_ERR_DEVICE;
     e->ctx = ctx; e->cfg = *cfg;
@@ -1106,6 +1183,11 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
 {
     if (!e || !n_consumed || !updated || (n_feats > 0 && !feats) || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
     *n_consumed = 0; *updated = 0;
+    struct Notify {                                     // every return path reports the consumption exactly once
+        lvk_ekf* e; int* n; bool fired = false;
+        void fire() { if (!fired) { fired = true; if (e->on_consumed) e->on_consumed(e->on_consumed_user, *n); } }
+        ~Notify() { fire(); }
+    } notify{e, n_consumed};
     e->up_off = 0; e->up_flushed = 0;
     if (!e->b_first_features) {
         if (n_imu > 0 && imu[0].t - ts - e->td <= 0.0) e->b_first_features = true;
@@ -1121,21 +1203,32 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
             off = erased;
         } else return LVK_OK;
     }
+    g_tr.start();
+    *n_consumed = off + batch_imu_count(e, ts + e->td, imu + off, n_imu - off);
+    notify.fire();                                      // a pipelined driver may start the next frame's front-end now
     const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
-    *n_consumed = off + used;
+    if (off + used != *n_consumed) return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "internal: IMU consumption count mismatch");
+    TR(TR_IMU);
     lvk_status st = apply_propagation(e);
     if (st != LVK_OK) return st;
+    TR(TR_PROP);
     add_observations(e, feats, n_feats);
+    TR(TR_ADDOBS);
     st = state_augmentation(e);
     if (st != LVK_OK) return st;
+    TR(TR_AUG);
     if (e->cfg.if_zupt_valid) { bool z = false; st = check_zupt(e, &z); if (st != LVK_OK) return st; e->if_zupt = z; }
+    TR(TR_ZUPT);
     st = remove_lost_features(e);
     if (st != LVK_OK) return st;
     st = prune_imu_state_buffer(e);
     if (st != LVK_OK) return st;
+    TR(TR_PR_END);
     if (e->cfg.if_fej && !e->if_fej && e->s.t - e->take_off_stamp >= 0) e->if_fej = true;
     e->counters[6] = (long)e->map.size();
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    TR(TR_FINAL);
+    g_tr.n++;
     *updated = 1;
     return LVK_OK;
 }
@@ -1189,6 +1282,128 @@ lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, i
     lvk_status st = lvk_frontend_process(fe, img, stride, img_is_device, ts, h_imu, n_imu, msg.data(), (int)msg.size(), &n_out, has_msg);
     if (st != LVK_OK || !*has_msg) return st;
     return lvk_ekf_process(ekf, ts, msg.data(), n_out, h_imu, n_imu, n_consumed, updated);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------- pipelined driver
+// The reference's driver thread alternates processImage and processFeatures (app/larvioMain.cpp:87-117).  The two halves only
+// meet at the feature message and at the shared IMU vector, so here the back-end of frame k runs on its own context (stream)
+// in a worker thread while the front-end of frame k+1 runs on the caller's thread.  The one coupling that needs care is the
+// IMU vector: processFeatures erases what it consumed and the NEXT processImage integrates gyro samples from whatever is
+// left — submit() therefore waits until the erase count of every queued update is known (it is final before any GPU work).
+struct lvk_vio_pipe {
+    lvk_frontend* fe; lvk_ekf* ekf;
+    std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..)
+    struct Job { double ts; std::vector<lvk_feature_obs> feats; std::vector<lvk_imu> view; };
+    std::deque<Job> q;
+    std::thread worker; std::mutex mu; std::condition_variable cv_job, cv_state;
+    int unknown_consume = 0;                            // queued or running updates whose erase count is not final yet
+    int in_flight = 0;                                  // queued + running
+    long n_updates = 0, n_msgs = 0;
+    lvk_status st = LVK_OK;
+    bool stop = false;
+    std::vector<lvk_feature_obs> msg;
+};
+
+static void pipe_on_consumed(void* user, int n)
+{
+    lvk_vio_pipe* p = (lvk_vio_pipe*)user;
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->head += (size_t)n; p->unknown_consume -= 1;
+    p->cv_state.notify_all();
+}
+
+static void pipe_worker(lvk_vio_pipe* p)
+{
+    hipSetDevice(p->ekf->ctx->device);
+    for (;;) {
+        lvk_vio_pipe::Job job;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_job.wait(lk, [&] { return p->stop || !p->q.empty(); });
+            if (p->q.empty()) return;
+            job = std::move(p->q.front()); p->q.pop_front();
+        }
+        int used = 0, upd = 0;
+        lvk_status st = lvk_ekf_process(p->ekf, job.ts, job.feats.data(), (int)job.feats.size(), job.view.data(), (int)job.view.size(), &used, &upd);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (st != LVK_OK && p->st == LVK_OK) p->st = st;
+            p->n_updates += upd; p->in_flight -= 1;
+            p->cv_state.notify_all();
+        }
+    }
+}
+
+extern "C" {
+
+lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** out)
+{
+    if (!fe || !ekf || !out) return LVK_ERR_ARG;
+    if (lvk_frontend_context(fe) == ekf->ctx)
+        return lvk_set_error(ekf->ctx, LVK_ERR_ARG, "lvk_vio_pipe_create: the front-end and the filter must live on different contexts (streams)");
+    lvk_vio_pipe* p = new lvk_vio_pipe();
+    p->fe = fe; p->ekf = ekf; p->msg.resize(8192);
+    ekf->on_consumed = pipe_on_consumed; ekf->on_consumed_user = p;
+    p->worker = std::thread(pipe_worker, p);
+    *out = p;
+    return LVK_OK;
+}
+
+void lvk_vio_pipe_destroy(lvk_vio_pipe* p)
+{
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+    p->cv_job.notify_all();
+    if (p->worker.joinable()) p->worker.join();
+    p->ekf->on_consumed = nullptr; p->ekf->on_consumed_user = nullptr;
+    delete p;
+}
+
+lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n)
+{
+    if (!p || (n > 0 && !h_imu)) return LVK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->head > 4096 && p->unknown_consume == 0) { p->imu.erase(p->imu.begin(), p->imu.begin() + (long)p->head); p->head = 0; }
+    p->imu.insert(p->imu.end(), h_imu, h_imu + n);
+    return LVK_OK;
+}
+
+lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, int img_is_device, double ts, int* has_msg)
+{
+    if (!p || !has_msg) return LVK_ERR_ARG;
+    *has_msg = 0;
+    size_t head, end;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_state.wait(lk, [&] { return p->unknown_consume == 0; });
+        if (p->st != LVK_OK) return p->st;
+        head = p->head; end = p->imu.size();
+    }
+    // only this thread appends to imu, and no update can move `head` until a new job is queued below
+    int n_out = 0;
+    lvk_status st = lvk_frontend_process(p->fe, img, stride, img_is_device, ts, p->imu.data() + head, (int)(end - head), p->msg.data(), (int)p->msg.size(), &n_out, has_msg);
+    if (st != LVK_OK || !*has_msg) return st;
+    lvk_vio_pipe::Job job;
+    job.ts = ts; job.feats.assign(p->msg.begin(), p->msg.begin() + n_out);
+    job.view.assign(p->imu.begin() + (long)head, p->imu.begin() + (long)end);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->q.push_back(std::move(job)); p->unknown_consume += 1; p->in_flight += 1; p->n_msgs += 1;
+    }
+    p->cv_job.notify_one();
+    return LVK_OK;
+}
+
+lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs)
+{
+    if (!p) return LVK_ERR_ARG;
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_state.wait(lk, [&] { return p->in_flight == 0; });
+    if (n_updates) *n_updates = p->n_updates;
+    if (n_msgs) *n_msgs = p->n_msgs;
+    return p->st;
 }
 
 }  // extern "C"

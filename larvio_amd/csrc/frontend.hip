@@ -505,6 +505,8 @@ static lvk_status commit(lvk_frontend* fe, int mode, const lvk_pt2f* src_pts, co
     return LVK_OK;
 }
 
+lvk_context* lvk_frontend_context(lvk_frontend* fe) { return fe ? fe->ctx : nullptr; }
+
 #ifdef LVK_FM_TIMING
 extern "C" void lvk_debug_fm_ticks(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_tick), sizeof(unsigned long long) * 32); }
 #endif

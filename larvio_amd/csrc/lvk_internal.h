@@ -21,6 +21,8 @@ struct lvk_context {
     size_t scratch_bytes[LVK_SCRATCH_SLOTS];
 };
 void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
+struct lvk_frontend;
+lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
 
 struct lvk_pyramid {
     lvk_context* ctx;

@@ -15,6 +15,12 @@ def _L():
         pi = C.POINTER(C.c_int)
         L.lvk_vio_process.argtypes = [vp, vp, vp, i, i, d, vp, i, pi, pi, pi]
         L.lvk_vio_process.restype = i
+        pl = C.POINTER(C.c_long)
+        L.lvk_vio_pipe_create.argtypes = [vp, vp, C.POINTER(vp)]; L.lvk_vio_pipe_create.restype = i
+        L.lvk_vio_pipe_destroy.argtypes = [vp]; L.lvk_vio_pipe_destroy.restype = None
+        L.lvk_vio_pipe_push_imu.argtypes = [vp, vp, i]; L.lvk_vio_pipe_push_imu.restype = i
+        L.lvk_vio_pipe_submit.argtypes = [vp, vp, i, i, d, pi]; L.lvk_vio_pipe_submit.restype = i
+        L.lvk_vio_pipe_drain.argtypes = [vp, pl, pl]; L.lvk_vio_pipe_drain.restype = i
         _done = True
     return L
 
@@ -48,3 +54,61 @@ class VioDriver:
         self.fe.ctx.check(st)
         self.lo += used.value
         return bool(has.value), bool(upd.value)
+
+
+class VioPipeline:
+    """The same loop with the filter update of frame k overlapping the front-end of frame k+1 (lvk_vio_pipe_*): the front-end
+    and the filter live on different contexts (streams); results are identical to VioDriver's."""
+    _close_order = 0            # closed before the front-end and the filter it points at
+
+    def __init__(self, image_processor, larvio, imu_all):
+        if image_processor.ctx is larvio.ctx:
+            raise ValueError("VioPipeline needs the front-end and the filter on different Contexts")
+        self.fe, self.be = image_processor, larvio
+        self.imu = np.ascontiguousarray(imu_all, IMU)
+        self.t = self.imu["t"].copy()
+        self.pushed = 0
+        self._has = C.c_int(0)
+        self._base = self.imu.ctypes.data
+        self._isz = self.imu.dtype.itemsize
+        h = C.c_void_p()
+        self.be.ctx.check(_L().lvk_vio_pipe_create(self.fe._h, self.be._h, C.byref(h)))
+        self._h = h
+        self.be.ctx.adopt(self); self.fe.ctx.adopt(self)
+
+    def visible_end(self, ts):
+        return int(np.searchsorted(self.t, ts + 0.05, side="left"))
+
+    def step(self, ts, hi, img=None, device_ptr=None, stride=None):
+        """hi = visible_end(ts).  Returns has_msg; the update it triggers completes asynchronously (drain())."""
+        L = _L()
+        if hi > self.pushed:
+            L.lvk_vio_pipe_push_imu(self._h, C.c_void_p(self._base + self.pushed * self._isz), hi - self.pushed)
+            self.pushed = hi
+        if device_ptr is not None:
+            ptr, s, is_dev = C.c_void_p(device_ptr), stride, 1
+        else:
+            img = np.ascontiguousarray(img, np.uint8)
+            ptr, s, is_dev = _p(img), img.shape[1], 0
+        st = L.lvk_vio_pipe_submit(self._h, ptr, s, is_dev, float(ts), C.byref(self._has))
+        if st != 0:
+            self.fe.ctx.check(st); self.be.ctx.check(st)
+        return bool(self._has.value)
+
+    def drain(self):
+        nu, nm = C.c_long(0), C.c_long(0)
+        st = _L().lvk_vio_pipe_drain(self._h, C.byref(nu), C.byref(nm))
+        if st != 0:
+            self.be.ctx.check(st); self.fe.ctx.check(st)
+        return nu.value, nm.value
+
+    def close(self):
+        if self._h:
+            _L().lvk_vio_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

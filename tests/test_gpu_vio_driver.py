@@ -75,3 +75,51 @@ def test_driver_loop_matches_oracle(gpu_ctx, device_frames):
     for k in ("hybrid", "msckf", "gated_in", "gated_out", "map"):
         assert cg[k] == co[k]
     print("driver loop parity: updates", n_upd, "worst rel", worst)
+
+
+def test_pipelined_driver_is_identical_to_sequential(gpu_ctx):
+    """lvk_vio_pipe_*: front-end of frame k+1 overlapping the update of frame k on a second stream gives the same bits as the
+    sequential driver step (same library, same kernels — only the schedule differs), hence the same parity with the oracle."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver, VioPipeline
+    from tests.conftest import synth_frames
+    frames = synth_frames(40, 70)
+    seq = S.imu_only_sequence()
+    ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    fcfg = S.frontend_config(max_features_num=150)
+    bcfg = S.backend_config(sw_size=15, if_zupt_valid=0)
+    ctx2 = larvio_amd.Context(0)                                    # second context = second stream, for the filter
+    out = []
+    for mode in ("seq", "pipe"):
+        fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
+        be = larvio_amd.LarVio(bcfg, ctx2 if mode == "pipe" else gpu_ctx); assert be.initialize()
+        drv = (VioPipeline if mode == "pipe" else VioDriver)(fe, be, imu_all)
+        n_msg = 0
+        for i, (t, img) in enumerate(frames):
+            if i == 1:
+                if mode == "pipe":
+                    drv.drain()
+                k = int(np.searchsorted(imu_all["t"], t, side="right")) - 1
+                t0 = imu_all["t"][k]; tr = seq.traj
+                be.set_state(t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            r = drv.step(t, drv.visible_end(t), img=img)
+            n_msg += int(r if mode == "pipe" else r[0])
+        if mode == "pipe":
+            n_upd, n_m = drv.drain()
+            assert n_m == n_msg
+            drv.close()
+        st = be.state()
+        out.append((n_msg, be.dim, {k: np.array(v, copy=True) for k, v in st.items()}, be.cov(), be.clones()["id"].copy(), be.features()[0].copy(),
+                    be.counters(), fe.tracks()))
+        be.close(); fe.close()
+    ctx2.close()
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1] and a[0] >= 30
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k]), k
+    assert np.array_equal(a[3], b[3])
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and a[6] == b[6]
+    for k in ("ids", "pts", "lifetime"):
+        assert np.array_equal(a[7][k], b[7][k])
