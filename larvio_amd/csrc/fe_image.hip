@@ -556,6 +556,7 @@ void lvk_pyramid_destroy(lvk_pyramid* p)
 
 static lvk_status build_levels(lvk_context* ctx, lvk_pyramid* p)
 {
+    if (p->ev_level0) hipEventRecord(p->ev_level0, ctx->stream);
     // levels 1.. (each depends on the previous) then all Scharr planes
     for (int l = 1; l < p->n_levels; ++l) {
         const uint8_t* s0 = p->img[l - 1] + (size_t)p->pad * p->istride[l - 1] + p->pad;

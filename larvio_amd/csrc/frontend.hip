@@ -421,6 +421,12 @@ struct lvk_frontend {
     lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;     // device + pinned host
     FeDev* dev; FeDev* h_dev;                            // device + pinned host mirror
     CamParams cam;
+    // Side stream side[0] ("new points"): goodFeaturesToTrack after a publish, then the next frame's ORB planes and the LK /
+    // descriptor gate of those points.  The main stream keeps the image pyramid, the old tracks and both commits.  One side
+    // stream only: HIP maps streams onto 4 hardware queues by default, and two streams sharing a queue serialise (measured: a
+    // third front-end stream slowed the filter's stream by 30%).
+    lvk_context* side[1];
+    hipEvent_t ev_l0, ev_pyr, ev_orb, ev_new, ev_commit, ev_end, ev_tail;
     // HIP-event profiling of stages
     unsigned prof_mask;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -437,13 +443,16 @@ static hipEvent_t prof_event(lvk_frontend* fe)
 }
 struct ProfScope {
     lvk_frontend* fe; int stage; hipEvent_t a; bool on;
-    ProfScope(lvk_frontend* f, int s) : fe(f), stage(s), on((f->prof_mask >> s) & 1u) { if (on) { a = prof_event(fe); hipEventRecord(a, fe->ctx->stream); } }
-    ~ProfScope() { if (on) { hipEvent_t b = prof_event(fe); hipEventRecord(b, fe->ctx->stream); fe->pending.push_back({stage, a, b}); } }
+    hipStream_t st;
+    ProfScope(lvk_frontend* f, int s, hipStream_t stream = nullptr) : fe(f), stage(s), on((f->prof_mask >> s) & 1u), st(stream ? stream : f->ctx->stream)
+    { if (on) { a = prof_event(fe); hipEventRecord(a, st); } }
+    ~ProfScope() { if (on) { hipEvent_t b = prof_event(fe); hipEventRecord(b, st); fe->pending.push_back({stage, a, b}); } }
 };
 static void prof_collect(lvk_frontend* fe)
 {
     if (fe->pending.empty()) return;
     hipStreamSynchronize(fe->ctx->stream);
+    for (int i = 0; i < 1; ++i) if (fe->side[i]) hipStreamSynchronize(fe->side[i]->stream);
     for (auto& p : fe->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { fe->prof_ms[p.stage] += ms; fe->prof_n[p.stage] += 1; }
@@ -462,22 +471,22 @@ static void set_free(TrackSet& s)
 }
 
 template <int WIN>
-static void launch_track_chain(lvk_frontend* fe, const PyrView& pv, const PyrView& cv, const lvk_pt2f* src_pts, const int* n_ptr, int grid,
+static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& pv, const PyrView& cv, const lvk_pt2f* src_pts, const int* n_ptr, int grid,
                                const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status, const unsigned long long* stored_desc,
                                unsigned long long* w_desc, int is_new, int max_count, double epsilon)
 {
-    hipStream_t s = fe->ctx->stream;
     const int W = fe->cfg.width, Hh = fe->cfg.height;
-    { ProfScope ps(fe, 2);
+    { ProfScope ps(fe, 2, s);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_fwd<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
-    { ProfScope ps(fe, 3);
+    { ProfScope ps(fe, 3, s);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_rev<WIN>), dim3(grid), dim3(64), 0, s, cv, pv, src_pts, n_ptr, W, Hh, max_count, epsilon, (const lvk_pt2f*)w_curr, w_status, fe->dev); }
-    ProfScope ps(fe, 4);
+    hipStreamWaitEvent(s, fe->ev_orb, 0);                         // the ORB planes of this frame may come from the side stream
+    ProfScope ps(fe, 4, s);
     hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
                        (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new);
 }
 
-static lvk_status track_chain(lvk_frontend* fe, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
+static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
                               const unsigned long long* stored_desc, unsigned long long* w_desc, int is_new)
 {
     int max_count = fe->cfg.max_iteration < 0 ? 0 : fe->cfg.max_iteration > 100 ? 100 : fe->cfg.max_iteration;
@@ -485,9 +494,9 @@ static lvk_status track_chain(lvk_frontend* fe, const lvk_pt2f* src_pts, const i
     epsilon *= epsilon;
     PyrView pv = make_view(fe->pyr[0]), cv = make_view(fe->pyr[1]);
     switch (fe->cfg.patch_size) {
-        case 21: launch_track_chain<21>(fe, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
-        case 15: launch_track_chain<15>(fe, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
-        case 31: launch_track_chain<31>(fe, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 21: launch_track_chain<21>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 15: launch_track_chain<15>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 31: launch_track_chain<31>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
         default: return lvk_set_error(fe->ctx, LVK_ERR_UNSUPPORTED, "patch_size %d not instantiated (15, 21, 31)", fe->cfg.patch_size);
     }
     LVK_LAUNCH_CHECK(fe->ctx);
@@ -518,6 +527,9 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     if (!fe) return;
     prof_collect(fe);
     hipStreamSynchronize(fe->ctx->stream);
+    for (int i = 0; i < 1; ++i) if (fe->side[i]) { hipStreamSynchronize(fe->side[i]->stream); lvk_context_destroy(fe->side[i]); }
+    hipEvent_t evs[] = {fe->ev_l0, fe->ev_pyr, fe->ev_orb, fe->ev_new, fe->ev_commit, fe->ev_end, fe->ev_tail};
+    for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (hipEvent_t e : fe->ev_free) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (fe->pyr[i]) lvk_pyramid_destroy(fe->pyr[i]);
@@ -558,8 +570,13 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
          dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4 + 8192) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->d_msg, cap) && dalloc(&fe->dev, 1);
     ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap) == hipSuccess &&
          hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
+    for (int i = 0; i < 1 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
+    hipEvent_t* evs[] = {&fe->ev_l0, &fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_end, &fe->ev_tail};
+    for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { lvk_frontend_destroy(fe); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_frontend_create: allocation failed"); }
+    for (int i = 0; i < 2; ++i) fe->pyr[i]->ev_level0 = fe->ev_l0;
     hipMemsetAsync(fe->dev, 0, sizeof(FeDev), ctx->stream);
+    hipEventRecord(fe->ev_end, ctx->stream);
     memset(&fe->cam, 0, sizeof fe->cam);
     for (int i = 0; i < 4; ++i) { fe->cam.intr[i] = cfg->intrinsics[i]; fe->cam.dist[i] = cfg->distortion[i]; }
     fe->cam.model = cfg->distortion_model; fe->cam.width = w; fe->cam.height = h;
@@ -567,6 +584,11 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     return LVK_OK;
 }
 
+static lvk_status fe_quiesce(lvk_frontend* fe)
+{   // the getters look at buffers the side streams may still be filling
+    for (int i = 0; i < 1; ++i) LVK_HIP(fe->ctx, hipStreamSynchronize(fe->side[i]->stream));
+    return LVK_OK;
+}
 static lvk_status fe_read_dev(lvk_frontend* fe)
 {
     LVK_HIP(fe->ctx, hipMemcpyAsync(fe->h_dev, fe->dev, sizeof(FeDev), hipMemcpyDeviceToHost, fe->ctx->stream));
@@ -574,28 +596,41 @@ static lvk_status fe_read_dev(lvk_frontend* fe)
     return LVK_OK;
 }
 
-// findNewFeaturesToBeTracked (:1005-1037) + getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172)
+// findNewFeaturesToBeTracked (:1005-1037).  Nothing in this frame's message depends on it, so it runs on side[0] behind the
+// commit and overlaps the message read-back, the filter update and the next frame's pyramid; the next frame's LK of the new
+// points is queued on the same stream, right behind it.
+static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
+{
+    lvk_context* cx = fe->side[0];
+    const lvk_fe_config& c = fe->cfg;
+    lvk_status st;
+    { ProfScope ps(fe, 6, cx->stream); st = lvk_min_eigen_map(cx, fe->pyr[1], fe->eig); }
+    if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
+    hipStreamWaitEvent(cx->stream, fe->ev_commit, 0);
+    ProfScope ps(fe, 7, cx->stream);
+    st = lvk_mask_boxes(cx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask);
+    if (st == LVK_OK) st = lvk_gftt_run(cx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
+                                        fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst]);
+    if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
+    return LVK_OK;
+}
+// getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172)
 static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out)
 {
     lvk_context* ctx = fe->ctx;
-    const lvk_fe_config& c = fe->cfg;
     lvk_status st;
-    { ProfScope ps(fe, 7);
-    st = lvk_mask_boxes(ctx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask);
-    if (st != LVK_OK) return st;
-    st = lvk_gftt_run(ctx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
-                      fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst]);
-    if (st != LVK_OK) return st; }
-    ProfScope ps8(fe, 8);
+    { ProfScope ps8(fe, 8);
     const double dt_1 = fe->curr_img_time - fe->prev_img_time;
     const int prev_is_last = fe->prev_img_time == fe->last_pub_time;
     const double dt_2 = prev_is_last ? dt_1 : fe->prev_img_time - fe->last_pub_time;
     hipLaunchKernelGGL(k_fe_msg, dim3((fe->cap + 63) / 64), dim3(64), 0, ctx->stream, fe->set[dst], (const int*)&fe->dev->n_tracks[dst], fe->cam, dt_1, dt_2,
                        prev_is_last, fe->d_msg, fe->dev);
     LVK_LAUNCH_CHECK(ctx);
-    LVK_HIP(ctx, hipMemcpyAsync(fe->h_msg, fe->d_msg, sizeof(lvk_feature_obs) * (size_t)fe->cap, hipMemcpyDeviceToHost, ctx->stream));
-    st = fe_read_dev(fe);
+    LVK_HIP(ctx, hipMemcpyAsync(fe->h_msg, fe->d_msg, sizeof(lvk_feature_obs) * (size_t)fe->cap, hipMemcpyDeviceToHost, ctx->stream)); }
+    LVK_HIP(ctx, hipMemcpyAsync(fe->h_dev, fe->dev, sizeof(FeDev), hipMemcpyDeviceToHost, ctx->stream));
+    st = fe_detect_new(fe, dst);                         // queued on side[0] before the host blocks on the message
     if (st != LVK_OK) return st;
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int n = fe->h_dev->n_msg;
     if (n > cap) n = cap;
     if (h_out && n > 0) memcpy(h_out, fe->h_msg, sizeof(lvk_feature_obs) * (size_t)n);
@@ -620,18 +655,30 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
         LVK_HIP(ctx, hipMemcpy2DAsync(fe->d_img, c.width, img, stride, c.width, c.height, hipMemcpyHostToDevice, ctx->stream));
         d_img = fe->d_img; d_stride = c.width;
     }
-    // createImagePyramids (:318-334) + ORBdescriptor ctor (:150)
+    // createImagePyramids (:318-334) on the main stream; ORBdescriptor ctor (:150) on the side stream as soon as level 0 exists
+    // (steady state) or in line (bootstrap frames)
     lvk_status st;
+    hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
+    lvk_context* orb_cx = fe->image_state == 3 ? fe->side[0] : ctx;
+    hipStream_t S3 = orb_cx->stream;
     { ProfScope ps(fe, 0);
       st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride); }
     if (st != LVK_OK) return st;
-    { ProfScope ps(fe, 1); st = lvk_orb_prepare(ctx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
-    if (st != LVK_OK) return st;
+    hipEventRecord(fe->ev_pyr, S1);
+    if (S3 != S1) { hipStreamWaitEvent(S3, fe->ev_end, 0); hipStreamWaitEvent(S3, fe->ev_l0, 0); }
+    { ProfScope ps(fe, 1, S3); st = lvk_orb_prepare(orb_cx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
+    if (st != LVK_OK) return orb_cx == ctx ? st : lvk_set_error(ctx, st, "%s", orb_cx->err);
+    hipEventRecord(fe->ev_orb, S3);
     fe->curr_img_time = ts;
     const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
     const int src = fe->cur, dst = fe->cur ^ 1;
     bool curr_valid = false;            // curr_pts_ (set[dst]) holds this frame's tracks
 
+    if (fe->image_state != 3) {
+        // bootstrap frames run on the main stream alone, behind whatever side[0] still has in flight
+        hipEventRecord(fe->ev_tail, S2);
+        hipStreamWaitEvent(S1, fe->ev_tail, 0);
+    }
     if (fe->image_state == 1) {
         // initializeFirstFrame (:337-352): goodFeaturesToTrack(max_features_num, 0.01, min_distance), no mask
         { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
@@ -647,32 +694,38 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
         if (st != LVK_OK) return lvk_set_error(ctx, st, "predict_homography failed");
         if (fe->image_state == 2) {
             // initializeFirstFeatures (:355-537)
-            st = track_chain(fe, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
+            st = track_chain(fe, S1, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
             if (st == LVK_OK) st = commit(fe, 2, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st == LVK_OK) st = fe_read_dev(fe);
             if (st != LVK_OK) return st;
             if (!fe->h_dev->boot_ok) fe->image_state = 1;
             else {
                 curr_valid = true;
+                hipEventRecord(fe->ev_commit, S1);
                 if (ts - fe->last_pub_time >= pub_gate) {
-                    { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
-                    if (st == LVK_OK) st = fe_publish(fe, dst, ts, h_out, cap, n_out);
+                    hipStreamWaitEvent(S2, fe->ev_l0, 0);
+                    st = fe_publish(fe, dst, ts, h_out, cap, n_out);
                     if (st != LVK_OK) return st;
                     *has_msg = 1;
                 }
                 fe->image_state = 3;
             }
         } else {
-            // trackFeatures (:540-811) then trackNewFeatures (:813-1002)
-            st = track_chain(fe, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
+            // trackFeatures (:540-811) on the main stream; trackNewFeatures' LK and descriptor gate (:813-931) on side[0], queued
+            // behind the detection that produced the points; its RANSAC + append (:932-1001) joins the main stream.
+            hipStreamWaitEvent(S2, fe->ev_end, 0);             // everything the previous frame left on the main stream
+            hipStreamWaitEvent(S2, fe->ev_pyr, 0);
+            st = track_chain(fe, S2, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
+            hipEventRecord(fe->ev_new, S2);
+            if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
             if (st == LVK_OK) st = commit(fe, 0, fe->set[src].pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &fe->set[src], fe->set[src].desc, dst);
-            if (st == LVK_OK) st = track_chain(fe, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
+            hipStreamWaitEvent(S1, fe->ev_new, 0);
             if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st != LVK_OK) return st;
             curr_valid = true;
+            hipEventRecord(fe->ev_commit, S1);
             if (ts - fe->last_pub_time >= pub_gate) {
-                { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
-                if (st == LVK_OK) st = fe_publish(fe, dst, ts, h_out, cap, n_out);
+                st = fe_publish(fe, dst, ts, h_out, cap, n_out);
                 if (st != LVK_OK) return st;
                 *has_msg = 1;
             }
@@ -684,6 +737,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
     { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = p; p = fe->blur[0]; fe->blur[0] = fe->blur[1]; fe->blur[1] = p; }
     fe->cur = dst;
     fe->prev_img_time = ts;
+    hipEventRecord(fe->ev_end, ctx->stream);
     if (fe->pending.size() > 4096) prof_collect(fe);
     return LVK_OK;
 }
@@ -691,6 +745,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
 lvk_status lvk_frontend_tracks(lvk_frontend* fe, uint64_t* h_ids, lvk_pt2f* h_pts, int* h_lifetime, lvk_pt2f* h_init, uint8_t* h_desc, int cap, int* n_out)
 {
     if (!fe || !n_out) return LVK_ERR_ARG;
+    { lvk_status qs = fe_quiesce(fe); if (qs != LVK_OK) return qs; }
     lvk_status st = fe_read_dev(fe);
     if (st != LVK_OK) return st;
     const TrackSet& s = fe->set[fe->cur];
@@ -711,6 +766,7 @@ lvk_status lvk_frontend_tracks(lvk_frontend* fe, uint64_t* h_ids, lvk_pt2f* h_pt
 lvk_status lvk_frontend_new_pts(lvk_frontend* fe, lvk_pt2f* h_pts, int cap, int* n_out)
 {
     if (!fe || !n_out) return LVK_ERR_ARG;
+    { lvk_status qs = fe_quiesce(fe); if (qs != LVK_OK) return qs; }
     lvk_status st = fe_read_dev(fe);
     if (st != LVK_OK) return st;
     int n = fe->h_dev->n_new; if (n > cap) n = cap;
@@ -748,6 +804,7 @@ const char* lvk_frontend_stage_name(int stage)
 lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint64_t* iterations)
 {
     if (!fe) return LVK_ERR_ARG;
+    { lvk_status qs = fe_quiesce(fe); if (qs != LVK_OK) return qs; }
     lvk_status st = fe_read_dev(fe);
     if (st != LVK_OK) return st;
     if (point_levels) *point_levels = fe->h_dev->lk_point_levels;

@@ -34,6 +34,7 @@ struct lvk_pyramid {
     int16_t* der[LVK_MAX_LEVELS];
     uint8_t* clahe_lut;            // tiles*256 scratch for the fused CLAHE path
     int clahe_lut_cap;
+    hipEvent_t ev_level0;          // optional: recorded on the build stream once level 0 is complete (side streams fork here)
 };
 
 // plain-data view of a pyramid passed to kernels by value
