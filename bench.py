@@ -165,8 +165,19 @@ def main():
         lk_ms = prof["lk_fwd"][0] + prof["lk_rev"][0]
         lk_launches = prof["lk_fwd"][1] + prof["lk_rev"][1]
         achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_launches, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        # HBM traffic per launch: not measurable inside this process (PMC needs rocprofv3) - taken from the committed counter pass
+        # of this same command (profiles/*_pmc_fetch_size.csv, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        traffic, traffic_src = None, None
+        import glob
+        pm = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_fetch_size.csv")))
+        if pm:
+            with open(pm[-1]) as f:
+                rows = [l.strip().split(",") for l in f.readlines()[1:]]
+            lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_lk_")]
+            if lk:
+                traffic = round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1); traffic_src = os.path.basename(pm[-1])
         roofline = {"kernel": "k_fe_lk_fwd/k_fe_lk_rev<21>", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
                     "launches": lk_launches}
         # ---- CPU baseline: the oracle (a restatement, "port") on this box's host cores, 1 thread, bounded sample
