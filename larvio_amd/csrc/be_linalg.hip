@@ -67,112 +67,6 @@ static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, in
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add);
 }
 
-// ------------------------------------------------------------------------- Cholesky (one workgroup)
-// Right-looking, panel width 32, lower triangle in place.  m <= CH_MAX_M.  info[0] = first non-positive pivot + 1 (0 = ok).
-#define CH_NB 32
-#define CH_MAX_M 544
-__global__ void __launch_bounds__(1024) k_chol_single(double* __restrict__ S, int m, int ld, int* __restrict__ info)
-{
-    extern __shared__ double sh[];
-    double* Ld = sh;                          // CH_NB x (CH_NB+1)
-    double* X = sh + CH_NB * (CH_NB + 1);     // (m) x CH_NB panel below the diagonal block
-    const int t = threadIdx.x;
-    if (t == 0) info[0] = 0;
-    for (int j0 = 0; j0 < m; j0 += CH_NB) {
-        const int nb = min(CH_NB, m - j0);
-        for (int e = t; e < nb * nb; e += 1024) { int a = e / nb, b = e - a * nb; Ld[a * (CH_NB + 1) + b] = S[(size_t)(j0 + a) * ld + j0 + b]; }
-        __syncthreads();
-        // unblocked factorisation of the nb x nb block
-        for (int j = 0; j < nb; ++j) {
-            if (t == 0) {
-                double d = Ld[j * (CH_NB + 1) + j];
-                if (!(d > 0.)) { if (info[0] == 0) info[0] = j0 + j + 1; d = 1.0; }
-                Ld[j * (CH_NB + 1) + j] = sqrt(d);
-            }
-            __syncthreads();
-            const double djj = Ld[j * (CH_NB + 1) + j];
-            if (t > j && t < nb) Ld[t * (CH_NB + 1) + j] /= djj;
-            __syncthreads();
-            // rank-1 update of the trailing part of the block (lower triangle)
-            for (int e = t; e < (nb - j - 1) * (nb - j - 1); e += 1024) {
-                int a = j + 1 + e / (nb - j - 1), b = j + 1 + e % (nb - j - 1);
-                if (b <= a) Ld[a * (CH_NB + 1) + b] -= Ld[a * (CH_NB + 1) + j] * Ld[b * (CH_NB + 1) + j];
-            }
-            __syncthreads();
-        }
-        for (int e = t; e < nb * nb; e += 1024) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * ld + j0 + b] = Ld[a * (CH_NB + 1) + b]; }
-        const int rest = m - j0 - nb;
-        if (rest <= 0) break;
-        // panel: X = A21 * L11^-T, one thread per row
-        for (int rix = t; rix < rest; rix += 1024) {
-            double x[CH_NB];
-            const double* arow = S + (size_t)(j0 + nb + rix) * ld + j0;
-            for (int c = 0; c < nb; ++c) {
-                double s = arow[c];
-                for (int k = 0; k < c; ++k) s -= x[k] * Ld[c * (CH_NB + 1) + k];
-                x[c] = s / Ld[c * (CH_NB + 1) + c];
-            }
-            for (int c = 0; c < nb; ++c) { X[(size_t)rix * CH_NB + c] = x[c]; S[(size_t)(j0 + nb + rix) * ld + j0 + c] = x[c]; }
-        }
-        __syncthreads();
-        // trailing update A22 -= X X^T (lower triangle)
-        const int tot = rest * rest;
-        for (int e = t; e < tot; e += 1024) {
-            int a = e / rest, b = e - a * rest;
-            if (b > a) continue;
-            double s = 0.;
-            for (int c = 0; c < nb; ++c) s += X[(size_t)a * CH_NB + c] * X[(size_t)b * CH_NB + c];
-            S[(size_t)(j0 + nb + a) * ld + j0 + nb + b] -= s;
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------- W = L^-1 B (forward substitution, many right-hand sides)
-// one workgroup per chunk of TR_NC columns of B (m x nc); row panels of 32.
-#define TR_NC 32
-__global__ void __launch_bounds__(256) k_trsm_lower(const double* __restrict__ L, int m, int ldl, double* __restrict__ B, int nc, int ldb)
-{
-    __shared__ double Lp[32][33];
-    __shared__ double Wp[32][TR_NC + 1];
-    const int t = threadIdx.x;
-    const int c0 = blockIdx.x * TR_NC, ncb = min(TR_NC, nc - c0);
-    for (int p0 = 0; p0 < m; p0 += 32) {
-        const int nb = min(32, m - p0);
-        for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; Lp[a][b] = L[(size_t)(p0 + a) * ldl + p0 + b]; }
-        for (int e = t; e < nb * ncb; e += 256) { int a = e / ncb, c = e - a * ncb; Wp[a][c] = B[(size_t)(p0 + a) * ldb + c0 + c]; }
-        __syncthreads();
-        if (t < ncb) {
-            for (int a = 0; a < nb; ++a) {
-                double s = Wp[a][t];
-                for (int k = 0; k < a; ++k) s -= Lp[a][k] * Wp[k][t];
-                Wp[a][t] = s / Lp[a][a];
-            }
-        }
-        __syncthreads();
-        for (int e = t; e < nb * ncb; e += 256) { int a = e / ncb, c = e - a * ncb; B[(size_t)(p0 + a) * ldb + c0 + c] = Wp[a][c]; }
-        // rows below: B[i][c] -= sum_k L[i][p0+k] W[k][c]
-        const int rest = m - p0 - nb;
-        for (int e = t; e < rest * ncb; e += 256) {
-            int a = e / ncb, c = e - a * ncb;
-            const double* lrow = L + (size_t)(p0 + nb + a) * ldl + p0;
-            double s = 0.;
-            for (int k = 0; k < nb; ++k) s += lrow[k] * Wp[k][c];
-            B[(size_t)(p0 + nb + a) * ldb + c0 + c] -= s;
-        }
-        __syncthreads();
-    }
-}
-
-// dx[j] = sum_i W[i][j] * W[i][wcol]  (K r = (HP)^T S^-1 r)
-__global__ void k_dx_from_w(const double* __restrict__ W, int m, int ldw, int n, int wcol, double* __restrict__ dx)
-{
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    double s = 0.;
-    for (int i = 0; i < m; ++i) s += W[(size_t)i * ldw + j] * W[(size_t)i * ldw + wcol];
-    dx[j] = s;
-}
 __global__ void k_set_column(double* __restrict__ B, int ldb, int col, const double* __restrict__ v, int m)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
