@@ -36,7 +36,7 @@ lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, i
 lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out);
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out);
-lvk_status lvk_launch_stack_rows(lvk_context* ctx, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
+lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
 double lvk_chi2_005(int dof);
 
@@ -520,8 +520,8 @@ static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracke
 // One feature-rows job (rows on the device) ------------------------------------------------------------
 struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; };
 
-static lvk_status run_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
-{
+static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
+{   // stages the jobs and queues k_feature_rows; nothing is read back (fetch_feature_results does that)
     if (jobs.empty()) return LVK_OK;
     if ((int)jobs.size() > 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
     size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2;
@@ -539,6 +539,7 @@ static lvk_status run_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
         d.anchor_rank = (j.type == JOB_MSCKF) ? 0 : clone_rank(e, f->id_anchor);
         d.fcol = (j.type == JOB_MSCKF) ? 0 : LEG + 6 * (int)e->clones.size() + fs_rank(e, f->id);
         d.stage_off = (long long)stage; d.ccol_off = (int)ccols;
+        d.gate_thr = j.want_gate ? lvk_chi2_005(j.dof) : 0.0;
         memcpy(d.p_w, f->position, 24); memcpy(d.p_fej, f->position_fej, 24); d.inv_depth = f->inv_depth; memcpy(d.obs_anchor, f->obs_anchor, 24);
         for (int k = 0; k < M; ++k) {
             const int oi = f->find(j.sids[k]);
@@ -556,13 +557,33 @@ static lvk_status run_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
     FilterFlags fl; fl.leg_dim = LEG; fl.if_fej = e->if_fej ? 1 : 0; fl.estimate_td = e->cfg.estimate_td; fl.pad = 0; fl.sigma2 = e->sigma2;
     if (st == LVK_OK) st = lvk_launch_feature_rows(e->ctx, dev(e, hj), (int)jobs.size(), max_rows, e->dv_clones, dev(e, hr), dev(e, hz), dev(e, hv), e->dP[e->cur], e->ld, fl,
                                                    e->d_staging, e->d_ccols, e->d_fout);
-    if (st != LVK_OK) return st;
+    return st;
+}
+// results of the queued jobs (+ optionally n_dx doubles of d_dx in the same sync)
+static lvk_status fetch_feature_results(lvk_ekf* e, std::vector<RowJob>& jobs, double* dx = nullptr, size_t n_dx = 0)
+{
     FeatResult* ho = (FeatResult*)e->h_down;
-    st = d2h_sync(e, ho, e->d_fout, sizeof(FeatResult) * jobs.size());
-    if (st != LVK_OK) return st;
+    const size_t rb = (sizeof(FeatResult) * jobs.size() + 63) & ~(size_t)63;
+    if (rb + sizeof(double) * n_dx > e->down_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "download buffer too small");
+    if (!jobs.empty()) EKF_HIP(hipMemcpyAsync(ho, e->d_fout, sizeof(FeatResult) * jobs.size(), hipMemcpyDeviceToHost, e->ctx->stream));
+    if (n_dx) EKF_HIP(hipMemcpyAsync(e->h_down + rb, e->d_dx, sizeof(double) * n_dx, hipMemcpyDeviceToHost, e->ctx->stream));
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
     for (size_t i = 0; i < jobs.size(); ++i) jobs[i].res = ho[i];
+    if (n_dx) memcpy(dx, e->h_down + rb, sizeof(double) * n_dx);
     return LVK_OK;
 }
+static lvk_status run_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
+{
+    if (jobs.empty()) return LVK_OK;
+    lvk_status st = launch_feature_rows(e, jobs);
+    if (st == LVK_OK) st = fetch_feature_results(e, jobs);
+    return st;
+}
+// row layout of a job, known before it runs: MSCKF blocks lose the 3 rows of the null-space projection, a new in-state
+// feature's block keeps its range row first, a tracked in-state feature contributes its 2 rows as they are
+static int job_first_row(const RowJob& j) { return j.type == JOB_MSCKF ? 3 : j.type == JOB_EKF_NEW ? 1 : 0; }
+static int job_rows(const RowJob& j) { return 2 * (int)j.sids.size() - job_first_row(j); }
+static int job_cols(const RowJob& j) { const int M = (int)j.sids.size(); return j.type == JOB_MSCKF ? 7 + 6 * M : 7 + 6 + 6 * M + 1; }
 static bool gate_ok(lvk_ekf* e, const RowJob& j)
 {
     const bool ok = j.res.gamma < lvk_chi2_005(j.dof);
@@ -570,11 +591,12 @@ static bool gate_ok(lvk_ekf* e, const RowJob& j)
     return ok;
 }
 // rows [first, first+count) of a job's compact block -> consecutive dense rows starting at dst
-static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst)
+static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst, int gate_job = -1)
 {
-    const int M = j.dev.n_obs, c = j.res.c;
+    const int M = j.dev.n_obs, c = job_cols(j);
     for (int k = 0; k < count; ++k) {
         StackRow s; s.g_off = j.dev.stage_off; s.r_off = j.dev.stage_off + (long long)2 * M * c * 2; s.src_row = first + k; s.c = c; s.ccol_off = j.dev.ccol_off; s.dst_row = dst + k;
+        s.job = gate_job; s.pad = 0;
         map.push_back(s);
     }
 }
@@ -585,7 +607,7 @@ static lvk_status stack_rows(lvk_ekf* e, const std::vector<StackRow>& map, doubl
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, map.data(), sizeof(StackRow) * map.size());
     lvk_status st = flush_uploads(e);
-    if (st == LVK_OK) st = lvk_launch_stack_rows(e->ctx, dev(e, h), (int)map.size(), e->d_staging, e->d_ccols, dH, e->ld, ncols, dr);
+    if (st == LVK_OK) st = lvk_launch_stack_rows(e->ctx, e->d_fout, dev(e, h), (int)map.size(), e->d_staging, e->d_ccols, dH, e->ld, ncols, dr);
     return st;
 }
 // dense update with m stacked rows already in d_H/d_r: compress when too tall, update P, fetch dx
@@ -733,6 +755,38 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         // NOTE: the feature column index of a new feature must be its FINAL one (after rejected candidates are dropped);
         // it is not used by JOB_EKF_NEW rows (the feature column never reaches H_o), so any value works here.
         TR(TR_RLF_TRIAGE);
+        if (ekf_new.empty()) {
+            // No feature enters the state in this update, so nothing on the host depends on the gate before the update is
+            // launched: every candidate row gets its slot, the device zeroes the rows of rejected features, and gate results and
+            // dx come back in ONE sync.
+            st = launch_feature_rows(e, jobs);
+            if (st != LVK_OK) return st;
+            std::vector<StackRow> map_o;
+            int rows_m = 0, rows_e = 0;
+            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k); rows_m += r; }
+            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k); rows_e += 2; }
+            const int m = rows_m + rows_e;
+            if (m > 8 * e->rows_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
+            st = stack_rows(e, map_o, e->d_H, N, e->d_r);
+            std::vector<double> dx;
+            if (st == LVK_OK) st = dense_update(e, m, dx, 0);
+            TR(TR_RLF_UPD);
+            if (st == LVK_OK) st = fetch_feature_results(e, jobs, dx.data(), (size_t)N);
+            if (st != LVK_OK) return st;
+            TR(TR_RLF_DX);
+            int accepted = 0;
+            for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) accepted += job_rows(jobs[k]);
+            for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) accepted += 2;
+            if (accepted > 0) {
+                inject(e, dx.data());
+                e->last_update_time = e->s.t;
+                e->counters[0]++;
+                e->counters[2] = accepted;
+            }
+            for (long long id : msckf) e->map.erase(id);
+            TR(TR_RLF_INJ);
+            return LVK_OK;
+        }
         st = run_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
         TR(TR_RLF_ROWS);
@@ -950,23 +1004,29 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         if (!clones_uploaded) { st = upload_clones(e); if (st != LVK_OK) return st; }
         std::vector<RowJob> jobs;
         for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
-        st = run_feature_rows(e, jobs);
+        // measurementUpdate_msckf (:1420-1602), gate decided on the device (see remove_lost_features): one sync for gate + dx
+        st = launch_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; int rows = 0;
-        for (auto& j : jobs) if (gate_ok(e, j)) { push_rows(map_o, j, j.res.first_row, j.res.rows, rows); rows += j.res.rows; }
+        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k); rows += r; }
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
-        if (rows > 0) {                                         // measurementUpdate_msckf (:1420-1602)
+        {
             st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, rows, dx, 0);
             TR(TR_PR_UPD);
-            if (st == LVK_OK) st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)e->N);
+            if (st == LVK_OK) st = fetch_feature_results(e, jobs, dx.data(), (size_t)e->N);
             if (st != LVK_OK) return st;
             TR(TR_PR_DX);
-            inject(e, dx.data());
-            e->last_update_time = e->s.t;
-            e->counters[1]++;
+            int accepted = 0;
+            for (auto& j : jobs) if (gate_ok(e, j)) accepted += job_rows(j);
+            if (accepted > 0) {
+                inject(e, dx.data());
+                e->last_update_time = e->s.t;
+                e->counters[1]++;
+                e->counters[2] = accepted;
+            }
         }
     } else {
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
@@ -1131,7 +1191,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     // capacities
     const int max_feat_state = std::max(0, c.max_features_in_one_grid) * cells;
     e->nmax = LEG + 6 * (c.sw_size + 2) + max_feat_state + 8;
-    e->ld = (e->nmax + 15) & ~15;
+    e->ld = ((e->nmax + 15) & ~15) + 8;                  // not a power of two: see ws.lds
     e->rows_cap = 1024;                                      // dense update up to this many stacked rows; taller blocks are QR-compressed first
     e->feat_cap = std::max(1024, 4 * c.max_features);        // jobs per batch: the map holds lost and young features besides the tracked ones
     e->obs_cap = 2 * e->feat_cap * (c.sw_size + 2);
@@ -1145,7 +1205,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
               dalloc(&e->d_rank, e->obs_cap) && dalloc(&e->d_z, (size_t)2 * e->obs_cap) && dalloc(&e->d_zv, (size_t)2 * e->obs_cap) &&
               dalloc(&e->d_cams, c.sw_size + 4) && dalloc(&e->d_clones, c.sw_size + 4) && dalloc(&e->d_staging, e->staging_cap) && dalloc(&e->d_ccols, e->ccols_cap) &&
               dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
-    e->ws.ldb = (e->ld + 8 + 7) & ~7; e->ws.lds = e->rows_cap;
+    e->ws.ldb = ((e->ld + 8 + 7) & ~7) | 8; e->ws.lds = e->rows_cap + 8;      // odd multiples of 64 B: power-of-two row strides pile onto one L2 channel
     ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds) && dalloc(&e->ws.info, 16);
     e->up_cap = (size_t)32 << 20; e->down_cap = (size_t)4 << 20;
     ok = ok && hipMalloc((void**)&e->d_up, e->up_cap) == hipSuccess;

@@ -14,9 +14,12 @@ struct FeatJob {
     int ccol_off, pad;
     long long stage_off;
     double p_w[3], p_fej[3], inv_depth, obs_anchor[3];
+    double gate_thr;                 // chi-square 5 % lower-tail threshold for this job's dof (gatingTest, larvio.cpp:1865-1880)
 };
-struct FeatResult { double gamma, h2; int rows, first_row, c, pad; };
-struct StackRow { long long g_off, r_off; int src_row, c, ccol_off, dst_row; };
+struct FeatResult { double gamma, h2; int rows, first_row, c, accept; };   // accept = !want_gate || gamma < gate_thr
+// job >= 0: the row is stacked only if that job's gate accepted it, otherwise the destination row is zeroed (a zero row with a
+// zero residual leaves the update unchanged) - the host then never has to read the gate back before launching the update
+struct StackRow { long long g_off, r_off; int src_row, c, ccol_off, dst_row, job, pad; };
 struct FilterFlags { int leg_dim, if_fej, estimate_td, pad; double sigma2; };
 
 #ifdef __HIPCC__

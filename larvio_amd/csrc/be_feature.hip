@@ -292,18 +292,24 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             gamma = y[k];
         }
     }
-    if (t == 0) { FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2; out[jb] = o; }
+    if (t == 0) {
+        FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2;
+        o.accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;
+        out[jb] = o;
+    }
 }
 
 // dense H row d <- compact row src (job staging) ; r[d] likewise.  One workgroup per destination row.
 __global__ void __launch_bounds__(128) k_stack_rows(const StackRow* __restrict__ map, int n_rows, const double* __restrict__ staging,
-                                                   const int* __restrict__ ccols, double* __restrict__ H, int ldh, int ncols, double* __restrict__ r)
+                                                   const int* __restrict__ ccols, double* __restrict__ H, int ldh, int ncols, double* __restrict__ r,
+                                                   const FeatResult* __restrict__ fout)
 {
     const int d = blockIdx.x;
     if (d >= n_rows) return;
     const StackRow m = map[d];
     double* row = H + (size_t)m.dst_row * ldh;
     for (int j = threadIdx.x; j < ncols; j += 128) row[j] = 0.;
+    if (m.job >= 0 && !fout[m.job].accept) { if (threadIdx.x == 0) r[m.dst_row] = 0.; return; }
     __syncthreads();
     const double* src = staging + m.g_off + (size_t)m.src_row * m.c;
     const int* cc = ccols + m.ccol_off;
@@ -336,11 +342,11 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
     return LVK_OK;
 }
 
-lvk_status lvk_launch_stack_rows(lvk_context* ctx, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh,
+lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh,
                                  int ncols, double* d_r)
 {
     if (n_rows <= 0) return LVK_OK;
-    hipLaunchKernelGGL(k_stack_rows, dim3(n_rows), dim3(128), 0, ctx->stream, d_map, n_rows, d_staging, d_ccols, d_H, ldh, ncols, d_r);
+    hipLaunchKernelGGL(k_stack_rows, dim3(n_rows), dim3(128), 0, ctx->stream, d_map, n_rows, d_staging, d_ccols, d_H, ldh, ncols, d_r, d_fout);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

@@ -315,6 +315,260 @@ __global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int
     }
 }
 
+// ------------------------------------------------------------------------- left-looking variant: ONE launch per 32-column panel
+// Every workgroup first brings its own piece up to date with all previous panels on the FP64 matrix cores
+// (S rows: A[R, p] -= L[R, 0:j0] L[p, 0:j0]^T ; B columns: B[p, C] -= L[p, 0:j0] W[0:j0, C]) and, redundantly, the 32x32 diagonal
+// block; one wavefront factors the block in registers AND inverts the factor (column c of L11^-1 in lane c, L broadcast with
+// v_readlane); the triangular solves then become two small MFMA products with L11^-1 (X = A L11^-T, W_p = L11^-1 B_p).
+// Compared with the right-looking pair (panel + trailing update) this halves the launches on the dependent chain and removes
+// the per-thread forward substitutions (496 dependent FMAs each).
+#ifdef LVK_CHOL_TIMING
+static __device__ unsigned long long g_ch_tick[16];
+#define CH_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ch_tick[k] = wall_clock64(); } while (0)
+extern "C" void lvk_debug_chol_ticks(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_tick), sizeof(unsigned long long) * 16); }
+#else
+#define CH_TICK(k) do { } while (0)
+#endif
+// One wavefront: Cholesky factor L of the 32x32 block in Ld (in place, lower, upper part zeroed) and Yi = L^-1.
+// Done as two 16x16 halves so that the fully unrolled register code (lane i = row i, columns broadcast with v_readlane) stays a
+// few KB - the 32-wide version was ~30 KB of straight-line code and ran at instruction-fetch speed - and is executed twice from a
+// loop; the off-diagonal blocks go through the FP64 matrix cores:
+//   L21 = A21 Y11^T ;  A22 -= L21 L21^T ;  Y21 = -Y22 (L21 Y11)
+#define CH_H 16
+__device__ __forceinline__ void chol32_inv_wave(double (*Ld)[CP_NB + 1], double (*Yi)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
+{
+    const int i16 = lane & 15, kk = lane >> 4;
+#pragma nounroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int base = CH_H * hb;
+        // ---- 16x16 factor + inverse in registers (the four 16-lane groups work redundantly; group 0 stores)
+        double a[CH_H], rd[CH_H], y[CH_H];
+#pragma unroll
+        for (int c = 0; c < CH_H; ++c) a[c] = Ld[base + i16][base + c];
+#pragma unroll
+        for (int j = 0; j < CH_H; ++j) {
+            double piv = readlane_f64(a[j], j);
+            if (!(piv > 0.)) { if (report && lane == 0 && base + j < nb && info[0] == 0) info[0] = j0 + base + j + 1; piv = 1.0; }
+            const double rinv = rsqrt_refined(piv);
+            rd[j] = rinv;
+            const double l = (i16 == j) ? piv * rinv : a[j] * rinv;     // L[i][j]; the diagonal is sqrt(piv)
+            a[j] = l;
+#pragma unroll
+            for (int k = j + 1; k < CH_H; ++k) { const double lk = readlane_f64(l, k); a[k] = __builtin_fma(-l, lk, a[k]); }
+        }
+        // column-oriented substitution for Y = L^-1 (lane = column): the updates of a step are independent
+#pragma unroll
+        for (int i = 0; i < CH_H; ++i) y[i] = (i16 == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < CH_H; ++k) {
+            y[k] *= rd[k];
+#pragma unroll
+            for (int i = k + 1; i < CH_H; ++i) y[i] = __builtin_fma(-readlane_f64(a[k], i), y[k], y[i]);
+        }
+        if (lane < CH_H) {
+#pragma unroll
+            for (int c = 0; c < CH_H; ++c) Ld[base + lane][base + c] = (c <= lane) ? a[c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < CH_H; ++i) Yi[base + i][base + lane] = (i >= lane) ? y[i] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (hb == 0) {
+            // L21 = A21 Y11^T  (A[i][k] = A21[i][k], B[k][j] = Y11[j][k])
+            d4 acc = {0., 0., 0., 0.};
+#pragma unroll
+            for (int k0 = 0; k0 < CH_H; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ld[CH_H + i16][k0 + kk], Yi[i16][k0 + kk], acc, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ld[CH_H + kk + 4 * r][i16] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+            // A22 -= L21 L21^T
+            d4 sy = {0., 0., 0., 0.};
+#pragma unroll
+            for (int k0 = 0; k0 < CH_H; k0 += 4) { const double v = Ld[CH_H + i16][k0 + kk]; sy = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, sy, 0, 0, 0); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ld[CH_H + kk + 4 * r][CH_H + i16] -= sy[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // Y21 = -Y22 (L21 Y11); the upper-right blocks are zero
+    d4 tt = {0., 0., 0., 0.};
+#pragma unroll
+    for (int k0 = 0; k0 < CH_H; k0 += 4) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(Ld[CH_H + i16][k0 + kk], Yi[k0 + kk][i16], tt, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Yi[CH_H + kk + 4 * r][i16] = tt[r];
+    __builtin_amdgcn_wave_barrier();
+    d4 yy = {0., 0., 0., 0.};
+#pragma unroll
+    for (int k0 = 0; k0 < CH_H; k0 += 4) yy = __builtin_amdgcn_mfma_f64_16x16x4f64(Yi[CH_H + i16][CH_H + k0 + kk], Yi[CH_H + k0 + kk][i16], yy, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Yi[CH_H + kk + 4 * r][i16] = -yy[r];
+        Yi[kk + 4 * r][CH_H + i16] = 0.; Ld[kk + 4 * r][CH_H + i16] = 0.;
+    }
+}
+
+#define CL_KC 128
+__global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
+                                                  int j0, int n_sblocks, int* __restrict__ info)
+{
+    __shared__ double Ld[CP_NB][CP_NB + 1], Yi[CP_NB][CP_NB + 1];
+    __shared__ double Cs[4][CP_NB][CP_NB + 1];
+    __shared__ __attribute__((aligned(32))) double Lp[CP_NB][CL_KC + 4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
+    const int nb = min(CP_NB, m - j0);
+    const bool s_role = (int)blockIdx.x < n_sblocks;
+    CH_TICK(0);
+    // ---- own piece, brought up to date with panels 0..p-1 (kept in the accumulators)
+    d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
+    const int rbase = j0 + nb + blockIdx.x * 64 + wave * 16;                     // S role: 16 rows per wavefront
+    const int bc = (blockIdx.x - n_sblocks) * 64 + wave * 16 + i16;             // B role: 16 columns per wavefront
+    // K (= all previous panels) is walked in chunks of CL_KC columns.  Per chunk the 32 rows L[p, chunk] - the operand every
+    // wavefront shares - are staged in LDS by all threads with four 32-byte loads each, and each wavefront's private operand is
+    // fetched with all its loads in flight at once: S and B were just written by other XCDs, so a dependent load costs a trip
+    // to the memory side (~1.5 us); what matters is the number of round trips, not the bytes.
+    // Lane (i, kk) takes the four CONSECUTIVE k = k0 + 4 kk + q and feeds element q to the q-th MFMA - a permutation of the
+    // summation index that both operands share.
+    const d4 zero4 = {0., 0., 0., 0.};
+    d4 dacc = {0., 0., 0., 0.};
+    const int ti = wave >> 1, tj = wave & 1;
+    // the current values of the own piece and of the diagonal tile are fetched up front, in the shadow of the first chunk
+    double own0[4], own1[4], dcur[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (s_role) {
+            const int row = rbase + kk + 4 * r;
+            own0[r] = (row < m && i16 < nb) ? S[(size_t)row * lds_ + j0 + i16] : 0.;
+            own1[r] = (row < m && 16 + i16 < nb) ? S[(size_t)row * lds_ + j0 + 16 + i16] : 0.;
+        } else {
+            const int r0 = kk + 4 * r, r1 = 16 + kk + 4 * r;
+            own0[r] = (r0 < nb && bc < nbcols) ? B[(size_t)(j0 + r0) * ldb + bc] : 0.;
+            own1[r] = (r1 < nb && bc < nbcols) ? B[(size_t)(j0 + r1) * ldb + bc] : 0.;
+        }
+        const int row = 16 * ti + kk + 4 * r, col = 16 * tj + i16;
+        dcur[r] = (row < nb && col < nb) ? S[(size_t)(j0 + row) * lds_ + j0 + col] : (row == col ? 1.0 : 0.0);
+    }
+    for (int kc = 0; kc < j0; kc += CL_KC) {
+        const int kw = min(CL_KC, j0 - kc);
+        {
+            const int row = t >> 3, seg = (t & 7) * 16;
+            const bool ok = j0 + row < m;
+            const double* src = S + (size_t)(ok ? j0 + row : 0) * lds_ + kc + seg;
+            d4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (ok && seg + 4 * q < kw) ? *(const d4*)(src + 4 * q) : zero4;
+            if (kc) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(d4*)&Lp[row][seg + 4 * q] = v[q];
+        }
+        if (s_role) {
+            const int ar = rbase + i16;
+            const double* pa = S + (size_t)(ar < m ? ar : 0) * lds_ + kc + 4 * kk;
+            d4 av[CL_KC / 16];
+#pragma unroll
+            for (int u = 0; u < CL_KC / 16; ++u) av[u] = (ar < m && 16 * u < kw) ? *(const d4*)(pa + 16 * u) : zero4;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < CL_KC / 16; ++u) {
+                if (16 * u >= kw) break;                                             // FP64 MFMA is 64 cycles: no padded K
+                const d4 v0 = *(const d4*)&Lp[i16][16 * u + 4 * kk], v1 = *(const d4*)&Lp[16 + i16][16 * u + 4 * kk];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][q], v0[q], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][q], v1[q], c1, 0, 0, 0);
+                }
+            }
+        } else {
+            const double* pb = B + (size_t)(kc + 4 * kk) * ldb + (bc < nbcols ? bc : 0);
+            double bv[CL_KC / 16][4];
+#pragma unroll
+            for (int u = 0; u < CL_KC / 16; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[u][q] = (bc < nbcols && 16 * u < kw) ? pb[(size_t)(16 * u + q) * ldb] : 0.;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < CL_KC / 16; ++u) {
+                if (16 * u >= kw) break;
+                const d4 v0 = *(const d4*)&Lp[i16][16 * u + 4 * kk], v1 = *(const d4*)&Lp[16 + i16][16 * u + 4 * kk];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0[q], bv[u][q], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[q], bv[u][q], c1, 0, 0, 0);
+                }
+            }
+        }
+        // the diagonal block's tile of this wavefront: both operands are in LDS
+#pragma unroll
+        for (int u = 0; u < CL_KC / 16; ++u) {
+            if (16 * u >= kw) break;
+            const d4 va = *(const d4*)&Lp[16 * ti + i16][16 * u + 4 * kk], vb = *(const d4*)&Lp[16 * tj + i16][16 * u + 4 * kk];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[q], vb[q], dacc, 0, 0, 0);
+        }
+    }
+    CH_TICK(1);
+    if (s_role) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Cs[wave][kk + 4 * r][i16] = own0[r] - c0[r];                           // Cs[row 0..15][col 0..31]
+            Cs[wave][kk + 4 * r][16 + i16] = own1[r] - c1[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int r0 = kk + 4 * r, r1 = 16 + kk + 4 * r;
+            Cs[wave][r0][i16] = own0[r] - c0[r];                                   // Cs[row k 0..31][col 0..15]
+            Cs[wave][r1][i16] = own1[r] - c1[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + kk + 4 * r, col = 16 * tj + i16;
+        Ld[row][col] = (row < nb && col < nb) ? dcur[r] - dacc[r] : dcur[r];
+    }
+    __syncthreads();
+    CH_TICK(2);
+    if (wave == 0) chol32_inv_wave(Ld, Yi, nb, lane, info, j0, blockIdx.x == 0);
+    CH_TICK(5);
+    __syncthreads();
+    CH_TICK(6);
+    if (blockIdx.x == 0) for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * lds_ + j0 + b] = Ld[a][b]; }
+    // ---- triangular solves as products with L11^-1
+    d4 o0 = {0., 0., 0., 0.}, o1 = {0., 0., 0., 0.};
+    if (s_role) {                                                                  // X = C Y^T : X[r][c] = sum_k C[r][k] Y[c][k]
+#pragma unroll
+        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
+            const double a = Cs[wave][i16][k0 + kk];
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yi[i16][k0 + kk], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yi[16 + i16][k0 + kk], o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rbase + kk + 4 * r;
+            if (row < m && i16 < nb) S[(size_t)row * lds_ + j0 + i16] = o0[r];
+            if (row < m && 16 + i16 < nb) S[(size_t)row * lds_ + j0 + 16 + i16] = o1[r];
+        }
+    } else {                                                                       // W = Y C : W[a][j] = sum_k Y[a][k] C[k][j]
+#pragma unroll
+        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
+            const double b = Cs[wave][k0 + kk][i16];
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yi[i16][k0 + kk], b, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yi[16 + i16][k0 + kk], b, o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int r0 = kk + 4 * r, r1 = 16 + kk + 4 * r;
+            if (r0 < nb && bc < nbcols) B[(size_t)(j0 + r0) * ldb + bc] = o0[r];
+            if (r1 < nb && bc < nbcols) B[(size_t)(j0 + r1) * ldb + bc] = o1[r];
+        }
+    }
+    CH_TICK(7);
+#ifdef LVK_CHOL_TIMING
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_ch_tick[8] = j0; g_ch_tick[9] = m; }
+#endif
+}
+
 // S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary
 static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
 {
@@ -322,12 +576,8 @@ static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double*
     for (int j0 = 0; j0 < m; j0 += CP_NB) {
         const int nb = (m - j0) < CP_NB ? (m - j0) : CP_NB;
         const int rest = m - j0 - nb;
-        const int n_sblocks = (rest + 255) / 256, n_bblocks = (nbcols + 255) / 256;
-        hipLaunchKernelGGL(k_chol_panel, dim3(n_sblocks + n_bblocks), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0, n_sblocks, info);
-        if (rest > 0) {
-            const int tr = (rest + 15) / 16, tiles = tr * (tr + (nbcols + 15) / 16);
-            hipLaunchKernelGGL(k_chol_update, dim3((tiles + 3) / 4), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0);
-        }
+        const int n_sblocks = (rest + 63) / 64, n_bblocks = (nbcols + 63) / 64;
+        hipLaunchKernelGGL(k_chol_left, dim3(n_sblocks + n_bblocks), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0, n_sblocks, info);
     }
 }
 
