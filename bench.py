@@ -53,7 +53,7 @@ def imu_stream(seed_offset=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=80, help="untimed frames; >= 70 so the 30-clone window is full when timing starts")
     ap.add_argument("--sw-size", type=int, default=30)
     ap.add_argument("--max-features", type=int, default=150, help="tracker budget (holds ~150 live tracks)")
@@ -130,7 +130,7 @@ def main():
     for i in range(W):
         step(i)
     if not args.sequential:
-        drv.drain()
+        drv.drain(); drv.stats(reset=True)
     pl0, it0 = fe.lk_stats()
     fe.profile_enable((1 << 2) | (1 << 3))               # HIP events around the LK launches only (dominant kernel)
     state["n_be"] = 0
@@ -157,6 +157,7 @@ def main():
         elapsed = float(t.item())
     prof = fe.profile_read()
     pl1, it1 = fe.lk_stats()
+    pst = None if args.sequential else drv.stats()
 
     if rank == 0:
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
@@ -211,6 +212,8 @@ def main():
                "p50_ms_per_frame": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_frame": round(float(np.percentile(lat, 95)) * 1e3, 4),
                "p50_ms_frame_without_update": round(float(np.median(lat[~upd_mask])) * 1e3, 4) if (~upd_mask).any() else None,
                "p50_ms_frame_with_update": round(float(np.median(lat[upd_mask])) * 1e3, 4) if upd_mask.any() else None,
+               "front_end_ms_per_frame": None if pst is None else round(pst["front_end_us"] / K * 1e-3, 4),
+               "back_end_ms_per_update": None if pst is None else round(pst["filter_us"] / max(state["n_be"], 1) * 1e-3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
                "config": {"workload": "configs[1] shape: EuRoC-shaped synthetic 752x480 @20Hz, max_features %d, pyramid 3 levels, win 21, pub 10 Hz" % args.max_features,

@@ -226,6 +226,22 @@ int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_
 /* [0] hybrid updates [1] msckf updates [2] rows of the last update [3] zupt updates [4] gated in [5] gated out [6] map size [7] triangulations */
 void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
 
+/* ---- per-feature stages of the update, one call each (parity tests; callers that want a single stage).  Host buffers.
+ * lvk_triangulate: Feature::initializePosition (use_position 0) / the LM refinement from a given position (1), feature.hpp:383-890,
+ *   n views = camera-to-world poses + normalised observations; *ok_out = the reference's return value.
+ * lvk_ekf_gate_and_stack: for a batch of MSCKF features, featureJacobian_msckf (larvio.cpp:924-981: H_x blocks, null-space projection),
+ *   gatingTest (:1865-1880) against P, and the stacking of the accepted features' rows (:2185-2201) into H (rows x N, row-major,
+ *   ld = N) and r.  h_clone_rank / h_obs / h_obs_vel are indexed by obs_off + k.  gamma / accept are per feature. */
+typedef struct { double R[9]; double t[3]; } lvk_cam_pose;
+typedef struct { double p_w[3]; int n_obs, obs_off; } lvk_msckf_feature;
+lvk_status lvk_triangulate(lvk_context* ctx, const lvk_cam_pose* h_poses, const double* h_obs, int n, int use_position,
+                           const double* h_position_in, int* ok_out, double* h_position, double* h_solution, double* h_inv_depth,
+                           double* h_obs_anchor);
+lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* h_clones, int n_clones, const lvk_msckf_feature* h_feats, int n_feats,
+                                  const int* h_clone_rank, const double* h_obs, const double* h_obs_vel, const double* h_P, int N,
+                                  int if_fej, int estimate_td, double sigma2, double* h_H, double* h_r, int rows_cap, int* rows_out,
+                                  double* h_gamma, int* h_accept);
+
 /* ==================================================================== the driver step
  * One camera frame through both halves, exactly the two calls the reference's drivers make per image
  * (app/larvioMain.cpp:104-116: processImage, then processFeatures when it returned true), with the driver's IMU buffer
@@ -245,6 +261,9 @@ void       lvk_vio_pipe_destroy(lvk_vio_pipe* p);
 lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n);
 lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, int img_is_device, double ts, int* has_msg);
 lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs);
+/* host wall time in microseconds since the last reset: [0] caller thread inside the front-end, [1] caller waiting for an erase
+ * count, [2] worker inside filter updates, [3] worker waiting for a message */
+lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* h_out4, int reset);
 
 #ifdef __cplusplus
 }

@@ -1486,6 +1486,15 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
     return LVK_OK;
 }
 
+lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* out4, int reset)
+{
+    if (!p || !out4) return LVK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    out4[0] = p->t_fe; out4[1] = p->t_submit_wait; out4[2] = p->t_busy; out4[3] = p->t_idle;
+    if (reset) p->t_busy = p->t_idle = p->t_fe = p->t_submit_wait = 0;
+    return LVK_OK;
+}
+
 lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs)
 {
     if (!p) return LVK_ERR_ARG;
@@ -1493,11 +1502,6 @@ lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs)
     pipe_wait(lk, p->cv_state, [&] { return p->in_flight == 0; });
     if (n_updates) *n_updates = p->n_updates;
     if (n_msgs) *n_msgs = p->n_msgs;
-    if (g_tr.on && p->n_msgs > 0) {
-        fprintf(stderr, "[lvk_vio_pipe] per message: worker busy %.1f us, worker idle %.1f us | caller: front-end %.1f us, waiting for erase count %.1f us\n",
-                p->t_busy / p->n_msgs, p->t_idle / p->n_msgs, p->t_fe / p->n_msgs, p->t_submit_wait / p->n_msgs);
-        p->t_busy = p->t_idle = p->t_fe = p->t_submit_wait = 0;
-    }
     return p->st;
 }
 

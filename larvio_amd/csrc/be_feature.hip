@@ -13,6 +13,8 @@
 // blocks that are ~85 % zeros and multiplies them against the full P for every gate.
 #include "lvk_internal.h"
 #include "be_dev.h"
+#include <vector>
+#include <algorithm>
 
 // ========================================================================= triangulation
 __global__ void __launch_bounds__(64) k_triangulate(const TriJob* __restrict__ jobs, int n_jobs, const CamPose* __restrict__ cams,
@@ -348,5 +350,122 @@ lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, con
     if (n_rows <= 0) return LVK_OK;
     hipLaunchKernelGGL(k_stack_rows, dim3(n_rows), dim3(128), 0, ctx->stream, d_map, n_rows, d_staging, d_ccols, d_H, ldh, ncols, d_r, d_fout);
     LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+// ========================================================================= stage-level C ABI (parity tests, single-stage callers)
+double lvk_chi2_005(int dof);
+
+extern "C" lvk_status lvk_triangulate(lvk_context* ctx, const lvk_cam_pose* h_poses, const double* h_obs, int n, int use_position,
+                                      const double* h_position_in, int* ok_out, double* h_position, double* h_solution, double* h_inv_depth,
+                                      double* h_obs_anchor)
+{
+    if (!ctx || !h_poses || !h_obs || n < 2 || n > 64 || !ok_out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_triangulate: 2..64 views required");
+    static_assert(sizeof(lvk_cam_pose) == sizeof(CamPose), "lvk_cam_pose is CamPose");
+    const size_t o_cams = 0, o_rank = o_cams + sizeof(CamPose) * n, o_z = (o_rank + sizeof(int) * n + 63) & ~(size_t)63, o_job = o_z + sizeof(double) * 2 * n,
+                 o_out = (o_job + sizeof(TriJob) + 63) & ~(size_t)63, total = o_out + sizeof(TriResult);
+    char* d = (char*)lvk_ctx_scratch(ctx, 9, total);
+    if (!d) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
+    std::vector<char> h(total, 0);
+    memcpy(h.data() + o_cams, h_poses, sizeof(CamPose) * n);
+    for (int i = 0; i < n; ++i) ((int*)(h.data() + o_rank))[i] = i;
+    memcpy(h.data() + o_z, h_obs, sizeof(double) * 2 * n);
+    TriJob* j = (TriJob*)(h.data() + o_job);
+    j->n = n; j->use_position = use_position ? 1 : 0; j->obs_off = 0; j->pad = 0;
+    if (h_position_in) memcpy(j->position_in, h_position_in, 24);
+    LVK_HIP(ctx, hipMemcpyAsync(d, h.data(), o_out, hipMemcpyHostToDevice, ctx->stream));
+    lvk_status st = lvk_launch_triangulate(ctx, (const TriJob*)(d + o_job), 1, (const CamPose*)(d + o_cams), (const int*)(d + o_rank), (const double*)(d + o_z), (TriResult*)(d + o_out));
+    if (st != LVK_OK) return st;
+    TriResult r;
+    LVK_HIP(ctx, hipMemcpyAsync(&r, d + o_out, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *ok_out = r.ok;
+    if (h_position) memcpy(h_position, r.position, 24);
+    if (h_solution) memcpy(h_solution, r.solution, 24);
+    if (h_inv_depth) *h_inv_depth = r.inv_depth;
+    if (h_obs_anchor) memcpy(h_obs_anchor, r.obs_anchor, 24);
+    return LVK_OK;
+}
+
+extern "C" lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* h_clones, int n_clones, const lvk_msckf_feature* h_feats, int n_feats,
+                                             const int* h_clone_rank, const double* h_obs, const double* h_obs_vel, const double* h_P, int N,
+                                             int if_fej, int estimate_td, double sigma2, double* h_H, double* h_r, int rows_cap, int* rows_out,
+                                             double* h_gamma, int* h_accept)
+{
+    if (!ctx || !h_clones || n_clones <= 0 || !h_feats || n_feats <= 0 || !h_clone_rank || !h_obs || !h_obs_vel || !h_P || !h_H || !h_r || !rows_out ||
+        N < 22 + 6 * n_clones) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_gate_and_stack: bad argument");
+    size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2, cand_rows = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        const int M = h_feats[f].n_obs;
+        if (M < 2 || M > 64 || h_feats[f].obs_off < 0) return lvk_set_error(ctx, LVK_ERR_ARG, "feature %d: 2..64 observations required", f);
+        for (int k = 0; k < M; ++k) { const int cr = h_clone_rank[h_feats[f].obs_off + k]; if (cr < 0 || cr >= n_clones) return lvk_set_error(ctx, LVK_ERR_ARG, "clone rank out of range"); }
+        tot = std::max(tot, (size_t)h_feats[f].obs_off + M);
+        const int c = 7 + 6 * M;
+        stage += (size_t)2 * M * c * 2 + 2 * M; ccols += c; max_rows = std::max(max_rows, 2 * M); cand_rows += 2 * M - 3;
+    }
+    const int ld = (N + 7) & ~7;
+    // one input blob, one staging blob, one output blob
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 63) & ~(size_t)63; return at; };
+    const size_t o_cl = take(sizeof(CloneDev) * n_clones), o_job = take(sizeof(FeatJob) * n_feats), o_rk = take(sizeof(int) * tot), o_z = take(16 * tot),
+                 o_zv = take(16 * tot), o_P = take(sizeof(double) * (size_t)N * ld), o_map = take(sizeof(StackRow) * (size_t)std::max(cand_rows, 1)), in_bytes = o;
+    char* d_in = (char*)lvk_ctx_scratch(ctx, 9, in_bytes);
+    char* d_st = (char*)lvk_ctx_scratch(ctx, 10, sizeof(double) * stage + sizeof(int) * ccols + 64);
+    const size_t oH = 0, o_r = (sizeof(double) * (size_t)std::max(cand_rows, 1) * ld + 63) & ~(size_t)63, o_fo = (o_r + sizeof(double) * std::max(cand_rows, 1) + 63) & ~(size_t)63,
+                 out_bytes = o_fo + sizeof(FeatResult) * n_feats;
+    char* d_out = (char*)lvk_ctx_scratch(ctx, 11, out_bytes);
+    if (!d_in || !d_st || !d_out) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
+    std::vector<char> h(in_bytes, 0);
+    CloneDev* hc = (CloneDev*)(h.data() + o_cl);
+    for (int i = 0; i < n_clones; ++i) {
+        memcpy(hc[i].q, h_clones[i].q, 32); memcpy(hc[i].p, h_clones[i].p, 24); memcpy(hc[i].p_fej, h_clones[i].p_fej, 24);
+        memcpy(hc[i].R_b2c, h_clones[i].R_b2c, 72); memcpy(hc[i].t_c_b, h_clones[i].t_c_b, 24);
+    }
+    FeatJob* hj = (FeatJob*)(h.data() + o_job);
+    size_t s_off = 0, c_off = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        const int M = h_feats[f].n_obs, c = 7 + 6 * M;
+        FeatJob& j = hj[f];
+        j.type = JOB_MSCKF; j.n_obs = M; j.obs_off = h_feats[f].obs_off; j.want_gate = 1; j.stage_off = (long long)s_off; j.ccol_off = (int)c_off;
+        memcpy(j.p_w, h_feats[f].p_w, 24); memcpy(j.p_fej, h_feats[f].p_w, 24);
+        j.gate_thr = lvk_chi2_005(2 * M - 3);
+        s_off += (size_t)2 * M * c * 2 + 2 * M; c_off += c;
+    }
+    memcpy(h.data() + o_rk, h_clone_rank, sizeof(int) * tot);
+    memcpy(h.data() + o_z, h_obs, 16 * tot); memcpy(h.data() + o_zv, h_obs_vel, 16 * tot);
+    for (int i = 0; i < N; ++i) memcpy(h.data() + o_P + sizeof(double) * (size_t)i * ld, h_P + (size_t)i * N, sizeof(double) * N);
+    LVK_HIP(ctx, hipMemcpyAsync(d_in, h.data(), o_map, hipMemcpyHostToDevice, ctx->stream));
+    FilterFlags fl; fl.leg_dim = 22; fl.if_fej = if_fej ? 1 : 0; fl.estimate_td = estimate_td ? 1 : 0; fl.pad = 0; fl.sigma2 = sigma2;
+    double* d_staging = (double*)d_st; int* d_ccols = (int*)(d_st + ((sizeof(double) * stage + 63) & ~(size_t)63));
+    FeatResult* d_fout = (FeatResult*)(d_out + o_fo);
+    lvk_status st = lvk_launch_feature_rows(ctx, (const FeatJob*)(d_in + o_job), n_feats, max_rows, (const CloneDev*)(d_in + o_cl), (const int*)(d_in + o_rk),
+                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout);
+    if (st != LVK_OK) return st;
+    std::vector<FeatResult> res(n_feats);
+    LVK_HIP(ctx, hipMemcpyAsync(res.data(), d_fout, sizeof(FeatResult) * n_feats, hipMemcpyDeviceToHost, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // accepted features' rows, in feature order (larvio.cpp:2185-2201 appends only the rows that pass the gate)
+    std::vector<StackRow> map; int rows = 0;
+    for (int f = 0; f < n_feats; ++f) {
+        if (h_gamma) h_gamma[f] = res[f].gamma;
+        if (h_accept) h_accept[f] = res[f].accept;
+        if (!res[f].accept) continue;
+        const int M = h_feats[f].n_obs, c = res[f].c;
+        for (int k = 0; k < res[f].rows; ++k) {
+            StackRow s; s.g_off = hj[f].stage_off; s.r_off = hj[f].stage_off + (long long)2 * M * c * 2; s.src_row = res[f].first_row + k; s.c = c; s.ccol_off = hj[f].ccol_off;
+            s.dst_row = rows + k; s.job = -1; s.pad = 0;
+            map.push_back(s);
+        }
+        rows += res[f].rows;
+    }
+    *rows_out = rows;
+    if (rows > rows_cap) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "%d stacked rows exceed rows_cap %d", rows, rows_cap);
+    if (rows == 0) return LVK_OK;
+    LVK_HIP(ctx, hipMemcpyAsync(d_in + o_map, map.data(), sizeof(StackRow) * map.size(), hipMemcpyHostToDevice, ctx->stream));
+    st = lvk_launch_stack_rows(ctx, d_fout, (const StackRow*)(d_in + o_map), rows, d_staging, d_ccols, (double*)(d_out + oH), ld, N, (double*)(d_out + o_r));
+    if (st != LVK_OK) return st;
+    LVK_HIP(ctx, hipMemcpy2DAsync(h_H, sizeof(double) * N, d_out + oH, sizeof(double) * ld, sizeof(double) * N, rows, hipMemcpyDeviceToHost, ctx->stream));
+    LVK_HIP(ctx, hipMemcpyAsync(h_r, d_out + o_r, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LVK_OK;
 }

@@ -26,25 +26,26 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
     const int i = lane & 15, kk = lane >> 4;
     const int ar = row0 + i, bc = col0 + i;
     const bool a_ok = ar < M, b_ok = bc < N;
+    // The operands come from other XCDs' L2s / the memory side (they were written by the previous kernel), so a dependent load
+    // costs microseconds and the tile's time is (number of load round trips) x latency, not bytes or flops: K is walked in
+    // chunks of 64 with all 32 loads of a chunk in flight before its 16 MFMAs.  Lane (i, kk) takes k = k0 + 16 u + 4 kk + q
+    // (4 consecutive k per lane: contiguous for the row-major operand) - a permutation of the summation index shared by A and B.
     d4 acc = {0., 0., 0., 0.};
-    int k0 = 0;
-    for (; k0 + 16 <= K; k0 += 16) {
-        double a[4], b[4];
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        double a[16], b[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + 4 * u + kk;
-            a[u] = a_ok ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
-            b[u] = b_ok ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 16 * (u >> 2) + 4 * kk + (u & 3);
+            const bool k_ok = k < K;
+            a[u] = (a_ok && k_ok) ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
+            b[u] = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
-    }
-    for (; k0 < K; k0 += 4) {
-        const int k = k0 + kk;
-        const bool k_ok = k < K;
-        double a = (a_ok && k_ok) ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
-        double b = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int u = 0; u < 16; ++u) {
+            if (k0 + 16 * (u >> 2) >= K) break;                       // FP64 MFMA is 64 cycles: no padded K groups
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -51,11 +51,42 @@ def _L():
         L.lvk_ekf_get_clones.argtypes = [vp, vp, i]; L.lvk_ekf_get_clones.restype = i
         L.lvk_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvk_ekf_get_features.restype = i
         L.lvk_ekf_counters.argtypes = [vp, vp]; L.lvk_ekf_counters.restype = None
+        L.lvk_triangulate.argtypes = [vp, vp, vp, i, i, vp, pi, vp, vp, vp, vp]; L.lvk_triangulate.restype = i
+        L.lvk_ekf_gate_and_stack.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, i, i, i, d, vp, vp, i, pi, vp, vp]; L.lvk_ekf_gate_and_stack.restype = i
         _sig_done = True
     return L
 
 
 # ---------------------------------------------------------------- stage-level wrappers (numpy in / numpy out)
+POSE = np.dtype([("R", np.float64, 9), ("t", np.float64, 3)])
+MSCKF_FEATURE = np.dtype([("p_w", np.float64, 3), ("n_obs", np.int32), ("obs_off", np.int32)])
+
+
+def triangulate(ctx, poses, obs, use_position=False, position_in=None):
+    """Feature::initializePosition for one feature (feature.hpp:383-552).  Returns (ok, position, solution, inv_depth, obs_anchor)."""
+    poses = np.ascontiguousarray(poses, POSE); obs = np.ascontiguousarray(obs, np.float64)
+    pin = np.ascontiguousarray(position_in if position_in is not None else np.zeros(3), np.float64)
+    ok = C.c_int(0); pos = np.zeros(3); sol = np.zeros(3); idp = np.zeros(1); oa = np.zeros(3)
+    ctx.check(_L().lvk_triangulate(ctx.h, _p(poses), _p(obs), len(poses), int(use_position), _p(pin), C.byref(ok), _p(pos), _p(sol), _p(idp), _p(oa)))
+    return bool(ok.value), pos, sol, float(idp[0]), oa
+
+
+def gate_and_stack(ctx, clones, feats, clone_rank, obs, obs_vel, P, sigma2, if_fej=1, estimate_td=1):
+    """featureJacobian_msckf + gatingTest + stacking for a batch of MSCKF features.  feats: list of (p_w, n_obs, obs_off).
+    Returns (H (rows x N), r, gamma[n_feats], accept[n_feats])."""
+    clones = np.ascontiguousarray(clones, CLONE)
+    fa = np.zeros(len(feats), MSCKF_FEATURE)
+    for k, (pw, n, off) in enumerate(feats):
+        fa[k]["p_w"] = pw; fa[k]["n_obs"] = n; fa[k]["obs_off"] = off
+    cr = np.ascontiguousarray(clone_rank, np.int32); obs = np.ascontiguousarray(obs, np.float64); ov = np.ascontiguousarray(obs_vel, np.float64)
+    P = np.ascontiguousarray(P, np.float64); N = P.shape[0]
+    cap = int(sum(2 * n - 3 for _, n, _ in feats)) + 1
+    H = np.zeros((cap, N)); r = np.zeros(cap); rows = C.c_int(0); gamma = np.zeros(len(feats)); acc = np.zeros(len(feats), np.int32)
+    ctx.check(_L().lvk_ekf_gate_and_stack(ctx.h, _p(clones), len(clones), _p(fa), len(fa), _p(cr), _p(obs), _p(ov), _p(P), N, int(if_fej), int(estimate_td),
+                                          float(sigma2), _p(H), _p(r), cap, C.byref(rows), _p(gamma), _p(acc)))
+    return H[:rows.value].copy(), r[:rows.value].copy(), gamma, acc.astype(bool)
+
+
 def dgemm(ctx, A, B, transa=False, transb=False, alpha=1.0, beta=0.0, Cin=None):
     A = np.ascontiguousarray(A, np.float64); B = np.ascontiguousarray(B, np.float64)
     M = A.shape[1] if transa else A.shape[0]; K = A.shape[0] if transa else A.shape[1]; N = B.shape[0] if transb else B.shape[1]

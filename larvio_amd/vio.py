@@ -21,6 +21,7 @@ def _L():
         L.lvk_vio_pipe_push_imu.argtypes = [vp, vp, i]; L.lvk_vio_pipe_push_imu.restype = i
         L.lvk_vio_pipe_submit.argtypes = [vp, vp, i, i, d, pi]; L.lvk_vio_pipe_submit.restype = i
         L.lvk_vio_pipe_drain.argtypes = [vp, pl, pl]; L.lvk_vio_pipe_drain.restype = i
+        L.lvk_vio_pipe_stats.argtypes = [vp, C.POINTER(C.c_double), i]; L.lvk_vio_pipe_stats.restype = i
         _done = True
     return L
 
@@ -101,6 +102,12 @@ class VioPipeline:
         if st != 0:
             self.be.ctx.check(st); self.fe.ctx.check(st)
         return nu.value, nm.value
+
+    def stats(self, reset=False):
+        """host wall microseconds since the last reset: front-end (caller thread), caller waiting, filter (worker), worker idle"""
+        o = (C.c_double * 4)()
+        _L().lvk_vio_pipe_stats(self._h, o, 1 if reset else 0)
+        return dict(front_end_us=o[0], caller_wait_us=o[1], filter_us=o[2], worker_idle_us=o[3])
 
     def close(self):
         if self._h:

@@ -155,3 +155,59 @@ def test_backend_sequence_parity_pure_msckf_and_static_init(gpu_ctx):
     n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=False)
     assert n_upd >= 15 and c["zupt"] >= 1 and c["hybrid"] + c["msckf"] >= 5
     assert ora.dim == 22 + 6 * len(ora.clones())
+
+
+def test_triangulation_stage_bit_exact(gpu_ctx):
+    """lvk_triangulate vs the oracle: sums are taken in view order on both sides, so the results are the same bits"""
+    from oracle import lvo_be
+    from larvio_amd import larvio as lv
+    from tests.test_oracle_backend import _scene
+    for seed, M in ((1, 7), (5, 3), (9, 12), (11, 2)):
+        clones, ranks, obs, vel, p_w, from_q = _scene(seed, M=M, n_clones=14)
+        poses = np.zeros(len(ranks), lvo_be.POSE)
+        for j, r in enumerate(ranks):
+            poses[j]["R"] = from_q(clones[r]["q_cam"]).ravel(); poses[j]["t"] = clones[r]["p_cam"]
+        for o in (obs, -obs):                                            # -obs: behind the cameras, must be rejected on both sides
+            ok_o, pos_o, sol_o, idp_o, oa_o = lvo_be.triangulate(poses, o)
+            ok_g, pos_g, sol_g, idp_g, oa_g = lv.triangulate(gpu_ctx, poses, o)
+            assert ok_g == ok_o
+            if ok_o:                                                      # a rejected feature's outputs are never read (larvio.cpp:1915-1920)
+                assert np.array_equal(pos_g, pos_o) and np.array_equal(sol_g, sol_o) and idp_g == idp_o and np.array_equal(oa_g, oa_o)
+        ok_o, pos_o, *_ = lvo_be.triangulate(poses, obs, use_position=True, position_in=p_w)
+        ok_g, pos_g, *_ = lv.triangulate(gpu_ctx, poses, obs, use_position=True, position_in=p_w)
+        assert ok_g == ok_o and np.array_equal(pos_g, pos_o)
+
+
+def test_gate_and_stack_stage_matches_oracle(gpu_ctx):
+    """lvk_ekf_gate_and_stack: per-feature Jacobian rows, null-space projection and chi-square gate vs the oracle's
+    featureJacobian_msckf / gatingTest.  Both use the same Householder sequence: rows agree to 1e-10; gate decisions identical."""
+    from oracle import lvo_be
+    from larvio_amd import larvio as lv
+    from tests.test_oracle_backend import _scene
+    n_clones = 12; N = 22 + 6 * n_clones + 4
+    rng = np.random.default_rng(77)
+    Bm = rng.normal(0, 1, (N, N)); P = Bm @ Bm.T * 2e-6 + np.eye(N) * 1e-7
+    sigma2 = 0.008 ** 2
+    clones = None; feats = []; ranks_all = []; obs_all = []; vel_all = []; ref = []
+    for k, (seed, M) in enumerate(((2, 6), (3, 3), (4, 12), (6, 2), (8, 9))):
+        c, ranks, obs, vel, p_w, _ = _scene(seed, M=M, n_clones=n_clones)
+        if clones is None:
+            clones = c
+        else:                                                            # same window for every feature: re-project into the first scene's clones
+            from_q = _
+            for j, r in enumerate(ranks):
+                pc = from_q(clones[r]["q_cam"]).T @ (p_w - clones[r]["p_cam"])
+                obs[j] = pc[:2] / pc[2] + rng.normal(0, 0.004 * (1 + 3 * (k == 2)), 2)
+        feats.append((p_w, M, len(ranks_all)))
+        ranks_all += list(ranks); obs_all += list(obs); vel_all += list(vel)
+        H, r = lvo_be.msckf_feature_jacobian(clones, ranks, obs, vel, p_w, N)
+        g = lvo_be.gating_gamma(H, r, P, sigma2)
+        ref.append((H, r, g, g < lvo_be.chi2_table(2 * M - 3)))
+    Hg, rg, gamma, acc = lv.gate_and_stack(gpu_ctx, clones, feats, ranks_all, np.array(obs_all), np.array(vel_all), P, sigma2)
+    assert list(acc) == [bool(x[3]) for x in ref]
+    assert any(acc) and not all(acc)                                     # the batch exercises both outcomes
+    for k, x in enumerate(ref):
+        assert gamma[k] == pytest.approx(x[2], rel=1e-8)
+    Ho = np.vstack([x[0] for x in ref if x[3]]); ro = np.concatenate([x[1] for x in ref if x[3]])
+    assert Hg.shape == Ho.shape
+    assert np.abs(Hg - Ho).max() < 1e-10 * max(np.abs(Ho).max(), 1) and np.abs(rg - ro).max() < 1e-10
