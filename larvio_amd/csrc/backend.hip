@@ -94,7 +94,7 @@ struct lvk_ekf {
     // per-frame composed transition (processModel): Phi_tot, Q_tot
     double Phi_tot[LEG * LEG], Q_tot[LEG * LEG]; bool have_prop = false;
     // device
-    int ld = 0, nmax = 0, rows_cap = 0, feat_cap = 0, obs_cap = 0;
+    int ld = 0, nmax = 0, rows_cap = 0, hrows = 0, feat_cap = 0, obs_cap = 0;
     double* dP[2] = {nullptr, nullptr}; int cur = 0;
     int* d_idx = nullptr; double *d_phiq = nullptr, *d_J = nullptr, *d_dx = nullptr, *d_tmp = nullptr;
     TriJob* d_tri = nullptr; TriResult* d_triout = nullptr; FeatJob* d_fj = nullptr; FeatResult* d_fout = nullptr;
@@ -766,7 +766,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k); rows_m += r; }
             for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k); rows_e += 2; }
             const int m = rows_m + rows_e;
-            if (m > 8 * e->rows_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
+            if (m > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
             st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, m, dx, 0);
@@ -811,7 +811,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         for (long long id : acc_ids) e->feature_states.push_back(id);
         const int m = rows_m + rows_e + top, n_acc = (int)acc_ids.size();
         if (m + n_acc > 0) {
-            if (m > 8 * e->rows_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
+            if (m > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
             st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             if (st == LVK_OK && n_acc) st = stack_rows(e, map_1, e->d_H1, N, e->d_r1);
             if (st != LVK_OK) return st;
@@ -1198,7 +1198,9 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     const int max_c = 7 + 6 + 6 * (c.sw_size + 2) + 1;
     e->staging_cap = std::min((size_t)2 * e->feat_cap * ((size_t)2 * (c.sw_size + 2) * max_c * 2 + 2 * (c.sw_size + 2)), (size_t)48 << 20);   // doubles; checked per batch
     e->ccols_cap = (size_t)2 * e->feat_cap * max_c;
-    const size_t hrows = (size_t)8 * e->rows_cap;
+    // stacked rows before compression: every feature of a message can contribute 2M-3 rows (18,000 at 2000 tracks, M = 6)
+    e->hrows = std::max(8 * e->rows_cap, 12 * c.max_features);
+    const size_t hrows = (size_t)e->hrows;
     bool ok = dalloc(&e->dP[0], (size_t)e->ld * e->ld) && dalloc(&e->dP[1], (size_t)e->ld * e->ld) && dalloc(&e->d_idx, e->ld) && dalloc(&e->d_phiq, 2 * LEG * LEG) &&
               dalloc(&e->d_J, e->ld) && dalloc(&e->d_dx, e->ld + 64) && dalloc(&e->d_tmp, (size_t)64 * e->ld) &&
               dalloc(&e->d_tri, (size_t)2 * e->feat_cap) && dalloc(&e->d_triout, (size_t)2 * e->feat_cap) && dalloc(&e->d_fj, (size_t)2 * e->feat_cap) && dalloc(&e->d_fout, (size_t)2 * e->feat_cap) &&

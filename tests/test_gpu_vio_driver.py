@@ -123,3 +123,82 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx):
     assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and a[6] == b[6]
     for k in ("ids", "pts", "lifetime"):
         assert np.array_equal(a[7][k], b[7][k])
+
+
+TUMVI_LIKE = dict(
+    width=512, height=512, intrinsics=(190.978, 190.973, 254.932, 256.897), distortion_model=1,      # equidistant (config 4 shape)
+    distortion=(0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367),
+    T_cam_imu=None)
+
+
+def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates):
+    """oracle loop vs VioDriver on frames [first, first+count) of the synthetic sequence seen through `cam`"""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver
+    from oracle import lvo, lvo_be
+    from tests.conftest import synth_frames
+    cam = dict(cam)
+    if cam.get("T_cam_imu") is None:
+        cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
+    frames = synth_frames(first, count, cam=cam)
+    seq = S.imu_only_sequence(cam=cam)
+    ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    fcfg = S.frontend_config(cam=cam, **fcfg_over)
+    bcfg = S.backend_config(cam=cam, **bcfg_over)
+    fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
+    be = larvio_amd.LarVio(bcfg, gpu_ctx); assert be.initialize()
+    ofe = lvo.Frontend(fcfg); obe = lvo_be.Ekf(bcfg)
+    drv = VioDriver(fe, be, imu_all)
+    lo = 0; n_upd = 0; worst = 0.0
+    for i, (t, img) in enumerate(frames):
+        hi = drv.visible_end(t)
+        if init_from_gt and i == 1:
+            k = int(np.searchsorted(imu_all["t"], t, side="right")) - 1
+            t0 = imu_all["t"][k]; tr = seq.traj
+            a = (t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            obe.set_state(*a); be.set_state(*a)
+        buf = imu_all[lo:hi]
+        have_o, m = ofe.process(img, t, buf)
+        upd_o = False
+        if have_o:
+            upd_o, used = obe.process(t, m, buf); lo += used
+        has_g, upd_g = drv.step(t, hi, img=img)
+        assert has_g == have_o and upd_g == bool(upd_o) and drv.lo == lo, (i, has_g, have_o, upd_g, upd_o)
+        if not upd_o:
+            continue
+        n_upd += 1
+        assert be.dim == obe.dim
+        so, sg = obe.state(), be.state()
+        for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
+            worst = max(worst, _rel(sg[k], so[k]))
+        worst = max(worst, _rel(be.cov(), obe.cov()))
+        assert np.array_equal(be.clones()["id"], obe.clones()["id"]) and np.array_equal(be.features()[0], obe.features()[0])
+        assert worst < REL, (i, worst)
+    assert n_upd >= min_updates
+    tg, to = fe.tracks(), ofe.tracks()
+    assert np.array_equal(tg["ids"], to["ids"]) and np.array_equal(tg["pts"], to["pts"])
+    co, cg = obe.counters(), be.counters()
+    for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map"):
+        assert cg[k] == co[k], (k, cg, co)
+    be.close(); fe.close()
+    return n_upd, worst, co, len(to["ids"])
+
+
+def test_driver_loop_config4_shape_equidistant_static_start_zupt(gpu_ctx):
+    """512x512 equidistant camera, 300-feature budget, start at rest: static initialiser, ZUPT updates, then motion"""
+    n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, TUMVI_LIKE, 0, 64, dict(max_features_num=300, min_distance=15),
+                                             dict(sw_size=12, if_zupt_valid=1), init_from_gt=False, min_updates=15)
+    assert c["zupt"] >= 1 and n_tracks > 60
+    print("config-4 shape: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
+
+
+def test_driver_loop_config5_shape_1080p_many_tracks(gpu_ctx):
+    """1920x1080, 2000-feature budget, long window: capacities and the tall-H (QR compression) path at the largest configuration"""
+    cam = dict(width=1920, height=1080, intrinsics=(1100.0, 1100.0, 960.0, 540.0), distortion_model=0,
+               distortion=(-0.12, 0.03, 0.0002, -0.0001), T_cam_imu=None)
+    n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, cam, 40, 14, dict(max_features_num=2000, min_distance=20),
+                                             dict(sw_size=40, max_features_in_one_grid=2, if_zupt_valid=0, max_features=2000), init_from_gt=True, min_updates=5)
+    assert n_tracks > 600
+    print("config-5 shape: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
