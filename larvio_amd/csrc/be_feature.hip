@@ -127,6 +127,14 @@ __global__ void __launch_bounds__(64) k_triangulate(const TriJob* __restrict__ j
 // ========================================================================= per-feature rows + gate
 // Staging slot of a job (doubles): G [rows_raw x c] | T [rows_raw x c] | r [rows_raw]; ccol ints kept separately.
 #define FR_THREADS 128
+// SMALL = every job of the batch has <= FRS_ROWS raw rows and <= FRS_COLS compact columns (true in steady state: max_track_len 6
+// caps a track at 7 observations): the block [G | r], the projected T and the touched sub-block P_cc live in LDS, P_cc is fetched
+// with all loads of a thread in flight (one trip to the memory side instead of one per inner-product term), and [G | r] is written
+// to the staging buffer once at the end.  The arithmetic and its order are those of the general path.
+#define FRS_ROWS 16
+#define FRS_COLS 64
+#define FRS_PLD (FRS_COLS + 1)
+template <bool SMALL>
 __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __restrict__ jobs, int n_jobs, const CloneDev* __restrict__ clones,
                                                             const int* __restrict__ obs_rank, const double* __restrict__ obs_z, const double* __restrict__ obs_zv,
                                                             const double* __restrict__ P, int ldp, FilterFlags fl,
@@ -140,14 +148,18 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     const int rows = 2 * M;
     const int nf = (job.type == JOB_MSCKF) ? 3 : 1;                  // columns of H_f
     const int c = (job.type == JOB_MSCKF) ? 7 + 6 * M : 7 + 6 + 6 * M + 1;
-    double* G = staging + job.stage_off;
-    double* T = G + (size_t)rows * c;
-    double* rr = T + (size_t)rows * c;
+    double* Gg = staging + job.stage_off;                             // staging slot: G [rows x c] | T [rows x c] | r [rows]
+    double* rrg = Gg + (size_t)2 * rows * c;
     int* cc = ccols + job.ccol_off;
-    // LDS: Hf [rows x 3] | v [rows] | S [k x k] | y [k] | scal[4]
+    // LDS: Hf [rows x 3] | v [rows] | S [k x k] | y [k] | scal[4]  (+ SMALL: G | T | r | P_cc)
     double* Hf = sh;
     double* v = Hf + rows * 3;
     double* S = v + rows;
+    double* Gl = S + (size_t)rows * rows + rows + 8;                  // SMALL only
+    double* G = SMALL ? Gl : Gg;
+    double* T = SMALL ? Gl + FRS_ROWS * FRS_COLS : Gg + (size_t)rows * c;
+    double* rr = SMALL ? Gl + 2 * FRS_ROWS * FRS_COLS : rrg;
+    double* Pcc = Gl + 2 * FRS_ROWS * FRS_COLS + FRS_ROWS;           // SMALL only: [c][FRS_PLD]
     // ---- zero the block, write the compact column map
     for (int e = t; e < rows * c; e += FR_THREADS) G[e] = 0.;
     for (int e = t; e < c; e += FR_THREADS) {
@@ -160,6 +172,21 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         cc[e] = col;
     }
     __syncthreads();
+    if (SMALL && job.want_gate) {
+        // P_cc = P[cc, cc]: up to 32 entries per thread, every load issued before the first store
+        constexpr int PER = (FRS_COLS * FRS_COLS + FR_THREADS - 1) / FR_THREADS;
+        double pv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + FR_THREADS * u;
+            if (e < c * c) { const int i = e / c, j = e - i * c; pv[u] = P[(size_t)cc[i] * ldp + cc[j]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + FR_THREADS * u;
+            if (e < c * c) { const int i = e / c, j = e - i * c; Pcc[i * FRS_PLD + j] = pv[u]; }
+        }
+    }
     // ---- per-observation Jacobians (one thread per observation)
     if (t < M) {
         const int oi = job.obs_off + t;
@@ -250,7 +277,10 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             int a = e / c, j = e - a * c;
             double s = 0.;
             const int colj = cc[j];
-            for (int i = 0; i < c; ++i) { const double g = Gp[(size_t)a * c + i]; if (g != 0.) s += g * P[(size_t)cc[i] * ldp + colj]; }
+            for (int i = 0; i < c; ++i) {
+                const double g = Gp[(size_t)a * c + i];
+                if (g != 0.) s += g * (SMALL ? Pcc[i * FRS_PLD + j] : P[(size_t)cc[i] * ldp + colj]);
+            }
             T[(size_t)a * c + j] = s;
         }
         __syncthreads();
@@ -294,6 +324,11 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             gamma = y[k];
         }
     }
+    if (SMALL) {
+        __syncthreads();
+        for (int e = t; e < rows * c; e += FR_THREADS) Gg[e] = G[e];
+        for (int e = t; e < rows; e += FR_THREADS) rrg[e] = rr[e];
+    }
     if (t == 0) {
         FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2;
         o.accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;
@@ -334,12 +369,20 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
                                    int* d_ccols, FeatResult* d_out)
 {
     if (n_jobs <= 0) return LVK_OK;
-    const size_t shmem = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
+    const size_t base = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
+    // max_rows = 2 M_max; compact columns <= 7 + 6 + 6 M_max + 1
+    const bool small = max_rows <= FRS_ROWS && 14 + 3 * max_rows <= FRS_COLS;
+    const size_t shmem = base + (small ? sizeof(double) * ((size_t)2 * FRS_ROWS * FRS_COLS + FRS_ROWS + (size_t)FRS_COLS * FRS_PLD) : 0);
     if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
-    static size_t attr_set = 0;
-    if (attr_set < shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_feature_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
-    hipLaunchKernelGGL(k_feature_rows, dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv, d_P, ldp, fl,
-                       d_staging, d_ccols, d_out);
+    if (small) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<true>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
+                           d_P, ldp, fl, d_staging, d_ccols, d_out);
+    } else {
+        static size_t attr_set = 0;
+        if (attr_set < shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_feature_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<false>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
+                           d_P, ldp, fl, d_staging, d_ccols, d_out);
+    }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

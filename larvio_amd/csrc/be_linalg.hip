@@ -85,7 +85,8 @@ __global__ void k_cov_gather(const double* __restrict__ Pin, int ldin, double* _
 
 // IMU propagation of the covariance (processModel, larvio.cpp:553-571) with the per-frame composed Phi (L x L) and Q:
 //   P_II <- sym(Phi P_II Phi^T + Q) ; P_IC <- Phi P_IC ; P_CI <- P_IC^T.    phiq = [Phi | Q] (2*L*L doubles).
-__global__ void __launch_bounds__(256) k_cov_propagate(double* __restrict__ P, int ld, int n, int L, const double* __restrict__ phiq)
+#define CPR_THREADS 1024
+__global__ void __launch_bounds__(CPR_THREADS) k_cov_propagate(double* __restrict__ P, int ld, int n, int L, const double* __restrict__ phiq)
 {
     extern __shared__ double sh[];
     double* Phi = sh;                 // L x L
@@ -93,22 +94,29 @@ __global__ void __launch_bounds__(256) k_cov_propagate(double* __restrict__ P, i
     double* T = Q + L * L;            // L x L  : Phi * P_II
     double* R = T + L * L;            // L x n  : old rows 0..L-1 of P
     const int t = threadIdx.x;
-    for (int e = t; e < 2 * L * L; e += 256) sh[e] = phiq[e];
-    for (int e = t; e < L * n; e += 256) { int i = e / n, j = e - i * n; R[e] = P[(size_t)i * ld + j]; }
+    // one workgroup on the dependent chain: all global loads of a thread are issued before the first one is used
+    for (int e = t; e < 2 * L * L; e += CPR_THREADS) sh[e] = phiq[e];
+    for (int e0 = t; e0 < L * n; e0 += CPR_THREADS * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + CPR_THREADS * u; if (e < L * n) { int i = e / n, j = e - i * n; v[u] = P[(size_t)i * ld + j]; } }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + CPR_THREADS * u; if (e < L * n) R[e] = v[u]; }
+    }
     __syncthreads();
-    for (int e = t; e < L * L; e += 256) {
+    for (int e = t; e < L * L; e += CPR_THREADS) {
         int i = e / L, j = e - i * L; double s = 0.;
         for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * n + j];
         T[e] = s;
     }
     // P_IC = Phi * R[:, L:]
-    for (int e = t; e < L * (n - L); e += 256) {
+    for (int e = t; e < L * (n - L); e += CPR_THREADS) {
         int i = e / (n - L), j = L + e % (n - L); double s = 0.;
         for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * n + j];
         P[(size_t)i * ld + j] = s; P[(size_t)j * ld + i] = s;
     }
     __syncthreads();
-    for (int e = t; e < L * L; e += 256) {
+    for (int e = t; e < L * L; e += CPR_THREADS) {
         int i = e / L, j = e - i * L;
         if (j > i) continue;
         double s1 = 0., s2 = 0.;
@@ -611,7 +619,9 @@ lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, 
 {
     const size_t shmem = sizeof(double) * ((size_t)3 * L * L + (size_t)L * n);
     if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n);
-    hipLaunchKernelGGL(k_cov_propagate, dim3(1), dim3(256), shmem, ctx->stream, P, ld, n, L, d_phiq);
+    static size_t attr_set = 0;                                      // beyond 64 KB the launch needs the attribute (exactly the launched size)
+    if (shmem > 64 * 1024 && attr_set != shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_cov_propagate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
+    hipLaunchKernelGGL(k_cov_propagate, dim3(1), dim3(CPR_THREADS), shmem, ctx->stream, P, ld, n, L, d_phiq);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

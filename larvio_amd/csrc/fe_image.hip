@@ -6,6 +6,7 @@
 // the stencils and as few dependent launches as possible (each costs ~1.5-2 us on MI355X).
 #include "lvk_internal.h"
 #include <stdarg.h>
+#include <algorithm>
 
 lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...)
 {
@@ -44,10 +45,21 @@ __global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t* __restrict__ s
     for (int k = 0; k < 4; ++k) sh[k][t] = 0;
     __syncthreads();
     const int total = tw * th;
-    for (int i = t; i < total; i += 256) {
-        int y = i / tw, x = i - y * tw;
-        int px = d_reflect101(tx * tw + x, w), py = d_reflect101(ty * th + y, h);   // ext tiles reflect (non-divisible sizes)
-        atomicAdd(&sh[wave][src[(size_t)py * sstride + px]], 1);
+    // the frame was just written by another agent (camera DMA / another XCD): a dependent load is a trip to the memory side, so
+    // the pixels of this thread are fetched in batches of 16 loads in flight before any of them is counted
+    for (int i0 = t; i0 < total; i0 += 256 * 16) {
+        int v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < total) {
+                int y = i / tw, x = i - y * tw;
+                int px = d_reflect101(tx * tw + x, w), py = d_reflect101(ty * th + y, h);   // ext tiles reflect (non-divisible sizes)
+                v[u] = src[(size_t)py * sstride + px];
+            } else v[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (v[u] >= 0) atomicAdd(&sh[wave][v[u]], 1);
     }
     __syncthreads();
     int v = sh[0][t] + sh[1][t] + sh[2][t] + sh[3][t];
@@ -122,43 +134,44 @@ __global__ void k_level0_pad(const uint8_t* __restrict__ src, int w, int h, int 
     dst[(size_t)ey * dstride + ex] = o;
 }
 
-// =========================================================================== pyrDown (+ frame)
+// =========================================================================== pyrDown (+ frame) and Scharr planes
 // [cv::pyrDown u8]  dst(x,y) = (sum_{5x5} w_i w_j src(2x-2+i, 2y-2+j) + 128) >> 8, w = [1 4 6 4 1].
 // The source's own reflect-101 frame (pad >= 2) supplies the border taps, so no index math.
-__global__ void k_pyr_down_pad(const uint8_t* __restrict__ s0 /*src pixel (0,0)*/, int sstride,
-                               int dw, int dh, uint8_t* __restrict__ dst /*padded base*/, int pad, int dstride)
-{
-    int ex = blockIdx.x * blockDim.x + threadIdx.x, ey = blockIdx.y;
-    if (ex >= dw + 2 * pad) return;
-    int x = d_reflect101(ex - pad, dw), y = d_reflect101(ey - pad, dh);
-    int acc = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const uint8_t* r = s0 + (ptrdiff_t)(2 * y - 2 + j) * sstride + (2 * x - 2);
-        int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
-        const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
-        acc += wj * row;
-    }
-    dst[(size_t)ey * dstride + ex] = (uint8_t)((acc + 128) >> 8);
-}
-
-// =========================================================================== Scharr planes
 // [calcSharrDeriv]  Ix = [3 10 3]^T (x) [-1 0 1],  Iy = [-1 0 1]^T (x) [3 10 3], int16 interleaved.
 // Reads the padded image (reflect-101 frame == calcSharrDeriv's own border rule).
-__global__ void k_scharr(const uint8_t* __restrict__ s0, int w, int h, int sstride,
-                         int16_t* __restrict__ d0 /*deriv of pixel (0,0)*/, int dstride)
+// Scharr plane of level l and the (padded) image of level l+1 in ONE launch: both read only level l, and a launch on the
+// frame's dependent chain costs ~7 us (kernel + inter-kernel barrier) whatever it computes.  Rows [0, h) of the grid are Scharr
+// rows, rows [h, h + dh + 2 pad) are rows of the next level (none when dh == 0).
+__global__ void k_scharr_and_down(const uint8_t* __restrict__ s0, int w, int h, int sstride, int16_t* __restrict__ d0, int dstride,
+                                  int dw, int dh, uint8_t* __restrict__ dst, int pad, int nstride)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const uint8_t* r0 = s0 + (ptrdiff_t)(y - 1) * sstride + x;
-    const uint8_t* r1 = r0 + sstride;
-    const uint8_t* r2 = r1 + sstride;
-    int a_m = (r0[-1] + r2[-1]) * 3 + r1[-1] * 10, a_p = (r0[1] + r2[1]) * 3 + r1[1] * 10;
-    int b_m = r2[-1] - r0[-1], b_c = r2[0] - r0[0], b_p = r2[1] - r0[1];
-    short2 o;
-    o.x = (short)(a_p - a_m);
-    o.y = (short)((b_p + b_m) * 3 + b_c * 10);
-    *reinterpret_cast<short2*>(d0 + (size_t)y * dstride + 2 * x) = o;
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)blockIdx.y < h) {
+        const int x = gx, y = blockIdx.y;
+        if (x >= w) return;
+        const uint8_t* r0 = s0 + (ptrdiff_t)(y - 1) * sstride + x;
+        const uint8_t* r1 = r0 + sstride;
+        const uint8_t* r2 = r1 + sstride;
+        int a_m = (r0[-1] + r2[-1]) * 3 + r1[-1] * 10, a_p = (r0[1] + r2[1]) * 3 + r1[1] * 10;
+        int b_m = r2[-1] - r0[-1], b_c = r2[0] - r0[0], b_p = r2[1] - r0[1];
+        short2 o;
+        o.x = (short)(a_p - a_m);
+        o.y = (short)((b_p + b_m) * 3 + b_c * 10);
+        *reinterpret_cast<short2*>(d0 + (size_t)y * dstride + 2 * x) = o;
+    } else {
+        const int ex = gx, ey = blockIdx.y - h;
+        if (ex >= dw + 2 * pad) return;
+        int x = d_reflect101(ex - pad, dw), y = d_reflect101(ey - pad, dh);
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint8_t* r = s0 + (ptrdiff_t)(2 * y - 2 + j) * sstride + (2 * x - 2);
+            int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
+            const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+            acc += wj * row;
+        }
+        dst[(size_t)ey * nstride + ex] = (uint8_t)((acc + 128) >> 8);
+    }
 }
 
 // =========================================================================== ORB mosaic + blur
@@ -557,16 +570,15 @@ void lvk_pyramid_destroy(lvk_pyramid* p)
 static lvk_status build_levels(lvk_context* ctx, lvk_pyramid* p)
 {
     if (p->ev_level0) hipEventRecord(p->ev_level0, ctx->stream);
-    // levels 1.. (each depends on the previous) then all Scharr planes
-    for (int l = 1; l < p->n_levels; ++l) {
-        const uint8_t* s0 = p->img[l - 1] + (size_t)p->pad * p->istride[l - 1] + p->pad;
-        hipLaunchKernelGGL(k_pyr_down_pad, dim3((p->w[l] + 2 * p->pad + 255) / 256, p->h[l] + 2 * p->pad), dim3(256), 0, ctx->stream,
-                           s0, p->istride[l - 1], p->w[l], p->h[l], p->img[l], p->pad, p->istride[l]);
-    }
+    // per level: its Scharr plane and the next level's image in one launch (both depend on level l only)
     for (int l = 0; l < p->n_levels; ++l) {
         const uint8_t* s0 = p->img[l] + (size_t)p->pad * p->istride[l] + p->pad;
         int16_t* d0 = p->der[l] + (size_t)p->pad * p->dstride[l] + 2 * p->pad;
-        hipLaunchKernelGGL(k_scharr, dim3((p->w[l] + 255) / 256, p->h[l]), dim3(256), 0, ctx->stream, s0, p->w[l], p->h[l], p->istride[l], d0, p->dstride[l]);
+        const bool next = l + 1 < p->n_levels;
+        const int dw = next ? p->w[l + 1] : 0, dh = next ? p->h[l + 1] : 0;
+        const int gx = std::max((p->w[l] + 255) / 256, next ? (dw + 2 * p->pad + 255) / 256 : 0);
+        hipLaunchKernelGGL(k_scharr_and_down, dim3(gx, p->h[l] + (next ? dh + 2 * p->pad : 0)), dim3(256), 0, ctx->stream,
+                           s0, p->w[l], p->h[l], p->istride[l], d0, p->dstride[l], dw, dh, next ? p->img[l + 1] : nullptr, p->pad, next ? p->istride[l + 1] : 0);
     }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
