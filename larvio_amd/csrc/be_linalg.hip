@@ -16,13 +16,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // C (M x N) = alpha * op(A) (M x K) * op(B) (K x N) + beta * C ; optional diag_add on the diagonal.
 // v_mfma_f64_16x16x4_f64: lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
 // D: col = l&15, row = (l>>4) + 4*reg  (f64 has its own C/D map, cdna_hip_programming.md §3).
+// Two optional riders save launches on the update's dependent chain: (xin, xin_col) copies a vector into column xin_col of C
+// ([HP | r] in one launch); (xout, xout_col) diverts output column xout_col to a vector, unscaled (W^T [W | w] -> P update and dx).
+struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; };
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                              double* __restrict__ C, int ldc, double alpha, double beta, double diag_add)
+                                              double* __restrict__ C, int ldc, double alpha, double beta, double diag_add, GemmRider rd)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.y * 2 + (wave >> 1)) * 16, col0 = (blockIdx.x * 2 + (wave & 1)) * 16;
     if (row0 >= M || col0 >= N) return;
+    if (rd.xin && col0 == 0 && lane < 16 && row0 + lane < M) C[(size_t)(row0 + lane) * ldc + rd.xin_col] = rd.xin[row0 + lane];
     const int i = lane & 15, kk = lane >> 4;
     const int ar = row0 + i, bc = col0 + i;
     const bool a_ok = ar < M, b_ok = bc < N;
@@ -31,7 +35,6 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
     // chunks of 64 with all 32 loads of a chunk in flight before its 16 MFMAs.  Lane (i, kk) takes k = k0 + 16 u + 4 kk + q
     // (4 consecutive k per lane: contiguous for the row-major operand) - a permutation of the summation index shared by A and B.
     d4 acc = {0., 0., 0., 0.};
-#pragma unroll 2
     for (int k0 = 0; k0 < K; k0 += 64) {
         double a[16], b[16];
 #pragma unroll
@@ -42,15 +45,14 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
             b[u] = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (k0 + 16 * (u >> 2) >= K) break;                       // FP64 MFMA is 64 cycles: no padded K groups
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
-        }
+        for (int u = 0; u < 16; ++u)
+            if (k0 + 16 * (u >> 2) < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);   // FP64 MFMA is 64 cycles: no padded K groups
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + kk + 4 * r, col = col0 + i;
         if (row < M && col < N) {
+            if (rd.xout && col == rd.xout_col) { rd.xout[row] = acc[r]; continue; }
             double v = alpha * acc[r];
             if (beta != 0.) v += beta * C[(size_t)row * ldc + col];
             if (row == col) v += diag_add;
@@ -61,18 +63,13 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
 
 template <bool TA, bool TB>
 static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
-                         double alpha, double beta, double diag_add)
+                         double alpha, double beta, double diag_add, GemmRider rd = GemmRider{nullptr, 0, nullptr, 0})
 {
     if (M <= 0 || N <= 0) return;
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
 }
 
-__global__ void k_set_column(double* __restrict__ B, int ldb, int col, const double* __restrict__ v, int m)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) B[(size_t)i * ldb + col] = v[i];
-}
 
 // ------------------------------------------------------------------------- structural covariance operations
 // Pout[a][b] = Pin[idx[a]][idx[b]]   (clone augmentation larvio.cpp:752-798, row/col deletion :2563-2638, :3311-3327)
@@ -428,6 +425,7 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
     const int nb = min(CP_NB, m - j0);
     const bool s_role = (int)blockIdx.x < n_sblocks;
+    if (j0 == 0 && blockIdx.x == 0 && t == 0) info[0] = 0;          // the reporter below is this same thread
     CH_TICK(0);
     // ---- own piece, brought up to date with panels 0..p-1 (kept in the accumulators)
     d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
@@ -581,7 +579,6 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
 // S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary
 static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
 {
-    hipMemsetAsync(info, 0, sizeof(int), s);
     for (int j0 = 0; j0 < m; j0 += CP_NB) {
         const int nb = (m - j0) < CP_NB ? (m - j0) : CP_NB;
         const int rest = m - j0 - nb;
@@ -599,12 +596,11 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
 {
     if (m <= 0) { LVK_HIP(ctx, hipMemsetAsync(dx, 0, sizeof(double) * (size_t)n, ctx->stream)); return LVK_OK; }
     hipStream_t s = ctx->stream;
-    launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0);                   // HP = H P
-    hipLaunchKernelGGL(k_set_column, dim3((m + 255) / 256), dim3(256), 0, s, ws.B, ws.ldb, n, r, m);       // [HP | r]
+    launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0, GemmRider{r, n, nullptr, 0});   // [HP | r]
     launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
     launch_chol_solve(s, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info);                                    // S = L L^T ; W = L^-1 [HP | r]
-    launch_dgemm<true, false>(s, n, 1, m, ws.B, ws.ldb, ws.B + n, ws.ldb, dx, 1, 1.0, 0.0, 0.0);             // dx = W^T w_r
-    launch_dgemm<true, false>(s, n, n, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0);              // P -= W^T W
+    // W^T [W | w]: columns 0..n-1 update P (P -= W^T W), column n is dx = W^T w
+    launch_dgemm<true, false>(s, n, n + 1, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0, GemmRider{nullptr, 0, dx, n});
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

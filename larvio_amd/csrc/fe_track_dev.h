@@ -25,11 +25,14 @@ __device__ __forceinline__ long long wave_sum_i64(int v)
 
 // ------------------------------------------------------------------------- pyramidal LK
 // [cv::calcOpticalFlowPyrLK / LKTrackerInvoker], OPTFLOW_USE_INITIAL_FLOW, minEigThreshold 1e-4.
-// One wavefront per point.  (An LDS-staged variant of the template/search windows was measured and was NOT faster: the kernel is
-// bound by the dependent VALU chain of the slowest track, ~0.5 us per iteration, not by the L2 gathers.)  The WIN x WIN template (I, Ix, Iy after the 14-bit bilinear blend) lives
-// in registers, PL = ceil(WIN^2/64) pixels per lane; A11/A12/A22 and b1/b2 are EXACT integer sums
-// (int32 per lane, int64 across the wave) converted to float once, so the result does not depend on
-// the reduction order (see oracle/fe_track.c).  All lanes hold identical copies of the scalar state.
+// One wavefront per point, all levels and iterations in one launch.  The WIN x WIN template (I, Ix, Iy after the 14-bit bilinear
+// blend) lives in registers, PL = ceil(WIN^2/64) pixels per lane; A11/A12/A22 and b1/b2 are EXACT integer sums (int32 per lane,
+// int64 across the wave) converted to float once, so the result does not depend on the reduction order (see oracle/fe_track.c).
+// All lanes hold identical copies of the scalar state.
+// Measured cost model (MI355X, 21x21): ~4 us launch + ~2.9 us per level + ~0.7 us per iteration of the slowest track - the
+// dependent instruction stream of ONE wavefront (~5 cycles per instruction), not bytes.  Three restructurings were measured and
+// were not faster: LDS-staged search window; row-segment lanes with two unaligned 8-byte loads per iteration instead of 28 byte
+// loads; requesting all levels' template/gradient runs up front.
 #define LK_W_BITS 14
 template <int WIN>
 __device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
