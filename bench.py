@@ -214,6 +214,8 @@ def main():
                "p50_ms_frame_with_update": round(float(np.median(lat[upd_mask])) * 1e3, 4) if upd_mask.any() else None,
                "front_end_ms_per_frame": None if pst is None else round(pst["front_end_us"] / K * 1e-3, 4),
                "back_end_ms_per_update": None if pst is None else round(pst["filter_us"] / max(state["n_be"], 1) * 1e-3, 4),
+               "caller_wait_ms_per_frame": None if pst is None else round(pst["caller_wait_us"] / K * 1e-3, 4),
+               "worker_idle_ms_per_update": None if pst is None else round(pst["worker_idle_us"] / max(state["n_be"], 1) * 1e-3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
                "config": {"workload": "configs[1] shape: EuRoC-shaped synthetic 752x480 @20Hz, max_features %d, pyramid 3 levels, win 21, pub 10 Hz" % args.max_features,

@@ -644,12 +644,14 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         if (f.in_state) { if (tracked) ekf_ids.push_back(f.id); else ekf_lost.push_back(f.id); }
     }
     lvk_status st;
-    for (long long id : ekf_lost) {                              // rmLostFeaturesCov (:3296-3348)
-        const int seq = fs_rank(e, id);
-        st = cov_delete(e, LEG + 6 * (int)e->clones.size() + seq, 1);
+    if (!ekf_lost.empty()) {                                     // rmLostFeaturesCov (:3296-3348): all lost columns in one gather
+        std::vector<char> drop(e->N, 0);
+        for (long long id : ekf_lost) drop[LEG + 6 * (int)e->clones.size() + fs_rank(e, id)] = 1;
+        std::vector<int> idx; idx.reserve(e->N);
+        for (int i = 0; i < e->N; ++i) if (!drop[i]) idx.push_back(i);
+        st = cov_gather(e, idx);
         if (st != LVK_OK) return st;
-        e->feature_states.erase(e->feature_states.begin() + seq);
-        e->map.erase(id);
+        for (long long id : ekf_lost) { e->feature_states.erase(e->feature_states.begin() + fs_rank(e, id)); e->map.erase(id); }
     }
     if (cells) {                                                 // updateGridMap (:3351-3370)
         std::fill(e->grid_count.begin(), e->grid_count.end(), 0);
@@ -1031,12 +1033,22 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
     } else {
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
     }
-    for (int k = 0; k < nrm; ++k) {
-        const int seq = clone_rank(e, rm[k]);
-        if (seq < 0) continue;
-        st = cov_delete(e, LEG + 6 * seq, 6);
-        if (st != LVK_OK) return st;
-        e->clones.erase(e->clones.begin() + seq);
+    {   // both clones' rows/columns leave P in ONE gather (the reference deletes them one after the other, :2563-2638)
+        std::vector<char> drop(e->N, 0);
+        bool any = false;
+        for (int k = 0; k < nrm; ++k) {
+            const int seq = clone_rank(e, rm[k]);
+            if (seq < 0) continue;
+            for (int j = 0; j < 6; ++j) drop[LEG + 6 * seq + j] = 1;
+            any = true;
+        }
+        if (any) {
+            std::vector<int> idx; idx.reserve(e->N);
+            for (int i = 0; i < e->N; ++i) if (!drop[i]) idx.push_back(i);
+            st = cov_gather(e, idx);
+            if (st != LVK_OK) return st;
+            for (int k = 0; k < nrm; ++k) { const int seq = clone_rank(e, rm[k]); if (seq >= 0) e->clones.erase(e->clones.begin() + seq); }
+        }
     }
     return LVK_OK;
 }
@@ -1354,6 +1366,7 @@ lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, i
 // in a worker thread while the front-end of frame k+1 runs on the caller's thread.  The one coupling that needs care is the
 // IMU vector: processFeatures erases what it consumed and the NEXT processImage integrates gyro samples from whatever is
 // left — submit() therefore waits until the erase count of every queued update is known (it is final before any GPU work).
+static double now_us_fwd();
 struct lvk_vio_pipe {
     lvk_frontend* fe; lvk_ekf* ekf;
     std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..)
@@ -1367,8 +1380,12 @@ struct lvk_vio_pipe {
     lvk_status st = LVK_OK;
     bool stop = false;
     std::vector<lvk_feature_obs> msg;
-    double t_busy = 0, t_idle = 0, t_submit_wait = 0, t_fe = 0;   // LVK_EKF_TRACE: where the two threads spend their time (us)
+    double t_busy = 0, t_idle = 0, t_submit_wait = 0, t_fe = 0;
+    struct Ev { double t; int what; };                    // LVK_PIPE_LOG=<file>: event log (0 submit begin, 1 wait done, 2 front-end done,
+    std::vector<Ev> log; bool logging = false;            //  3 job queued [4 precounted], 5 job start, 6 job end)
+    void ev(int what) { if (logging) log.push_back({now_us_fwd(), what}); }   // LVK_EKF_TRACE: where the two threads spend their time (us)
 };
+static double now_us_fwd() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void pipe_on_consumed(void* user, int n)
@@ -1405,11 +1422,12 @@ static void pipe_worker(lvk_vio_pipe* p)
             p->cur_precounted = job.precounted;
         }
         const double t1 = now_us();
+        { std::lock_guard<std::mutex> lk(p->mu); p->ev(5); }
         int used = 0, upd = 0;
         lvk_status st = lvk_ekf_process(p->ekf, job.ts, job.feats.data(), (int)job.feats.size(), job.view.data(), (int)job.view.size(), &used, &upd);
         {
             std::lock_guard<std::mutex> lk(p->mu);
-            p->t_idle += t1 - t0; p->t_busy += now_us() - t1;
+            p->t_idle += t1 - t0; p->t_busy += now_us() - t1; p->ev(6);
             if (st != LVK_OK && p->st == LVK_OK) p->st = st;
             p->n_updates += upd; p->in_flight -= 1;
             p->cv_state.notify_all();
@@ -1426,6 +1444,7 @@ lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** ou
         return lvk_set_error(ekf->ctx, LVK_ERR_ARG, "lvk_vio_pipe_create: the front-end and the filter must live on different contexts (streams)");
     lvk_vio_pipe* p = new lvk_vio_pipe();
     p->fe = fe; p->ekf = ekf; p->msg.resize(8192);
+    p->logging = getenv("LVK_PIPE_LOG") != nullptr; if (p->logging) p->log.reserve(1 << 16);
     ekf->on_consumed = pipe_on_consumed; ekf->on_consumed_user = p;
     p->worker = std::thread(pipe_worker, p);
     *out = p;
@@ -1438,6 +1457,7 @@ void lvk_vio_pipe_destroy(lvk_vio_pipe* p)
     { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
     p->cv_job.notify_all();
     if (p->worker.joinable()) p->worker.join();
+    if (p->logging) { if (FILE* f = fopen(getenv("LVK_PIPE_LOG"), "w")) { for (auto& e : p->log) fprintf(f, "%.1f,%d\n", e.t, e.what); fclose(f); } }
     p->ekf->on_consumed = nullptr; p->ekf->on_consumed_user = nullptr;
     delete p;
 }
@@ -1456,12 +1476,19 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
     if (!p || !has_msg) return LVK_ERR_ARG;
     *has_msg = 0;
     size_t head, end;
+    // the image stage (upload, pyramid, ORB planes) does not look at the IMU buffer: queue it before waiting for the erase count
+    const double tb = now_us();
+    lvk_status st0 = lvk_frontend_begin(p->fe, img, stride, img_is_device, ts);
+    if (st0 != LVK_OK) return st0;
     const double t0 = now_us();
+    p->t_fe += t0 - tb;
     {
         std::unique_lock<std::mutex> lk(p->mu);
+        p->ev(0);
         pipe_wait(lk, p->cv_state, [&] { return p->unknown_consume == 0; });
         if (p->st != LVK_OK) return p->st;
         head = p->head; end = p->imu.size();
+        p->ev(1);
     }
     const double t1 = now_us();
     p->t_submit_wait += t1 - t0;
@@ -1469,6 +1496,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
     int n_out = 0;
     lvk_status st = lvk_frontend_process(p->fe, img, stride, img_is_device, ts, p->imu.data() + head, (int)(end - head), p->msg.data(), (int)p->msg.size(), &n_out, has_msg);
     p->t_fe += now_us() - t1;
+    if (p->logging) { std::lock_guard<std::mutex> lk(p->mu); p->ev(2); }
     if (st != LVK_OK || !*has_msg) return st;
     lvk_vio_pipe::Job job;
     job.ts = ts; job.feats.assign(p->msg.begin(), p->msg.begin() + n_out);
@@ -1480,8 +1508,8 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
         lvk_ekf* e = p->ekf;
         if (p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
             p->head += (size_t)batch_imu_count(e, ts + e->td, job.view.data(), (int)job.view.size());
-            job.precounted = true;
-        } else p->unknown_consume += 1;
+            job.precounted = true; p->ev(4);
+        } else { p->unknown_consume += 1; p->ev(3); }
         p->q.push_back(std::move(job)); p->in_flight += 1; p->n_msgs += 1;
     }
     p->cv_job.notify_one();

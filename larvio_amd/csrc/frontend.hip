@@ -426,6 +426,7 @@ struct lvk_frontend {
     // stream only: HIP maps streams onto 4 hardware queues by default, and two streams sharing a queue serialise (measured: a
     // third front-end stream slowed the filter's stream by 30%).
     lvk_context* side[1];
+    bool image_done; double image_done_ts;       // lvk_frontend_begin already queued this frame's image stage
     hipEvent_t ev_l0, ev_pyr, ev_orb, ev_new, ev_commit, ev_end, ev_tail;
     // HIP-event profiling of stages
     unsigned prof_mask;
@@ -639,6 +640,43 @@ static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_o
     return LVK_OK;
 }
 
+// The IMU-independent part of a frame: image upload, createImagePyramids (:318-334) on the main stream, ORBdescriptor ctor (:150)
+// on the side stream as soon as level 0 exists (steady state) or in line (bootstrap frames).  Split out so that a pipelined
+// driver can queue it before it knows which IMU samples the previous update erased (lvk_frontend_begin).
+static lvk_status fe_image_stage(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device)
+{
+    lvk_context* ctx = fe->ctx;
+    const lvk_fe_config& c = fe->cfg;
+    const uint8_t* d_img = img; int d_stride = stride;
+    if (!img_is_device) {
+        LVK_HIP(ctx, hipMemcpy2DAsync(fe->d_img, c.width, img, stride, c.width, c.height, hipMemcpyHostToDevice, ctx->stream));
+        d_img = fe->d_img; d_stride = c.width;
+    }
+    lvk_status st;
+    hipStream_t S1 = ctx->stream;
+    lvk_context* orb_cx = fe->image_state == 3 ? fe->side[0] : ctx;
+    hipStream_t S3 = orb_cx->stream;
+    { ProfScope ps(fe, 0);
+      st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride); }
+    if (st != LVK_OK) return st;
+    hipEventRecord(fe->ev_pyr, S1);
+    if (S3 != S1) { hipStreamWaitEvent(S3, fe->ev_end, 0); hipStreamWaitEvent(S3, fe->ev_l0, 0); }
+    { ProfScope ps(fe, 1, S3); st = lvk_orb_prepare(orb_cx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
+    if (st != LVK_OK) return orb_cx == ctx ? st : lvk_set_error(ctx, st, "%s", orb_cx->err);
+    hipEventRecord(fe->ev_orb, S3);
+    return LVK_OK;
+}
+
+lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts)
+{
+    if (!fe || !img) return LVK_ERR_ARG;
+    if (!fe->b_first_img) return LVK_OK;                 // the first-image gate needs the IMU buffer (:134-142): nothing to do early
+    lvk_status st = fe_image_stage(fe, img, stride, img_is_device);
+    if (st != LVK_OK) return st;
+    fe->image_done = true; fe->image_done_ts = ts;
+    return LVK_OK;
+}
+
 lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
                                 lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
 {
@@ -650,25 +688,11 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
         if (n_imu > 0 && h_imu[0].t - ts <= 0.0) fe->b_first_img = true;
         else return LVK_OK;
     }
-    const uint8_t* d_img = img; int d_stride = stride;
-    if (!img_is_device) {
-        LVK_HIP(ctx, hipMemcpy2DAsync(fe->d_img, c.width, img, stride, c.width, c.height, hipMemcpyHostToDevice, ctx->stream));
-        d_img = fe->d_img; d_stride = c.width;
-    }
-    // createImagePyramids (:318-334) on the main stream; ORBdescriptor ctor (:150) on the side stream as soon as level 0 exists
-    // (steady state) or in line (bootstrap frames)
-    lvk_status st;
-    hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
-    lvk_context* orb_cx = fe->image_state == 3 ? fe->side[0] : ctx;
-    hipStream_t S3 = orb_cx->stream;
-    { ProfScope ps(fe, 0);
-      st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride); }
+    lvk_status st = LVK_OK;
+    if (!(fe->image_done && fe->image_done_ts == ts)) st = fe_image_stage(fe, img, stride, img_is_device);
+    fe->image_done = false;
     if (st != LVK_OK) return st;
-    hipEventRecord(fe->ev_pyr, S1);
-    if (S3 != S1) { hipStreamWaitEvent(S3, fe->ev_end, 0); hipStreamWaitEvent(S3, fe->ev_l0, 0); }
-    { ProfScope ps(fe, 1, S3); st = lvk_orb_prepare(orb_cx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
-    if (st != LVK_OK) return orb_cx == ctx ? st : lvk_set_error(ctx, st, "%s", orb_cx->err);
-    hipEventRecord(fe->ev_orb, S3);
+    hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
     fe->curr_img_time = ts;
     const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
     const int src = fe->cur, dst = fe->cur ^ 1;

@@ -23,6 +23,7 @@ struct lvk_context {
 void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
 struct lvk_frontend;
 lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
+extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts);   // image stage only (internal)
 
 struct lvk_pyramid {
     lvk_context* ctx;
