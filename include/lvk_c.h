@@ -162,7 +162,7 @@ const char* lvk_frontend_stage_name(int stage);
 
 /* ==================================================================== back-end: EKF measurement update
  * replaces larvio::LarVio (include/larvio/larvio.h:37-90).  feature_idp_dim = 1, use_schmidt = 0,
- * calib_imu_instrinsic = 0 (config/euroc.yaml:8-10,105,108) are implemented; other values are refused.
+ * calib_imu_instrinsic = 0 or 1 (config/euroc.yaml:8-10,105,108) are implemented; other values are refused.
  * Matrices crossing the ABI are ROW-MAJOR doubles with an explicit leading dimension (P is symmetric, so the
  * reference's column-major Eigen::MatrixXd state_cov maps onto it unchanged). */
 typedef struct lvk_ekf lvk_ekf;
@@ -193,7 +193,7 @@ typedef struct {
     double rotation_threshold, translation_threshold, tracking_rate_threshold, feature_translation_threshold;
     double zupt_max_feature_dis, zupt_noise_v, zupt_noise_p, zupt_noise_q;
     double static_duration;
-    int feature_idp_dim, use_schmidt, calib_imu_instrinsic;   /* must be 1, 0, 0 */
+    int feature_idp_dim, use_schmidt, calib_imu_instrinsic;   /* must be 1, 0, 0|1 (1: LEG_DIM 46, IMU intrinsics in the state) */
     int max_features;                                          /* capacity hint: features per message (0 = 1024) */
 } lvk_ekf_config;
 
@@ -220,6 +220,9 @@ int        lvk_ekf_dim(const lvk_ekf* e);                      /* state_cov.rows
 int        lvk_ekf_is_initialized(const lvk_ekf* e);
 /* 30 doubles: t, q[4] (x y z w), v[3], p[3], bg[3], ba[3], R_imu_cam0[9], t_cam0_imu[3], td  (getTbw/getVel, larvio.cpp:2644-2700) */
 lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* h_out30);
+/* the 24 IMU-intrinsic parameters T1 T2 T3 A1 A2 A3 M1 M2 (larvio.cpp:129-154; state columns 22..45 when calibrated) */
+lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* h_out24);
+lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* h_in24);
 lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P);           /* N*N row-major, synchronises (getPpose/getPvel read blocks of it) */
 int        lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* h_out, int cap);       /* getSwPoses */
 int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_depth, double* h_pos_w, int cap);  /* getActiveeMapPointPositions */

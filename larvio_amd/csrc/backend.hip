@@ -9,7 +9,7 @@
 // composed transition matrix, clone augmentation / deletion as index gathers, LM triangulation (one wavefront
 // per feature), Jacobians + null-space projection + chi-square gate (one workgroup per feature, compact columns),
 // row stacking, Householder compression, and the FP64-MFMA update.  feature_idp_dim = 1, use_schmidt = 0,
-// calib_imu = 0 (LEG_DIM 22) — the settings of config/euroc.yaml:8-10,105,108; anything else is refused.
+// calib_imu = 0 or 1 (LEG_DIM 22 / 46) — config/euroc.yaml:8-10,105,108 and its calibration variant; anything else is refused.
 #include "lvk_internal.h"
 #include "be_dev.h"
 #include "be_host_math.h"
@@ -23,7 +23,8 @@
 #include <condition_variable>
 #include <deque>
 
-#define LEG 22
+#define LEG (e->leg)           // LEG_DIM: 22, or 46 with online IMU-intrinsics calibration (larvio.cpp:158-161)
+#define LEG_MAX 46
 #define GRAV 9.81
 
 struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; };
@@ -79,7 +80,10 @@ struct lvk_ekf {
     std::vector<Clone> clones;
     std::vector<long long> feature_states;
     std::map<long long, Feature> map;                  // map_server (ascending id)
-    int N = LEG;
+    int leg = 22;
+    int N = 22;
+    double imx[24];                                     // T1 T2 T3 A1 A2 A3 M1 M2 (larvio.cpp:129-154)
+    double Tg[9], As[9], Ma[9];                         // updateImuMx (:3803-3846)
     long long next_state_id = 0;
     bool is_gravity_set = false, b_first_features = false, if_fej = false, if_zupt = false;
     double m_gyro_old[3], m_acc_old[3];
@@ -92,7 +96,7 @@ struct lvk_ekf {
     std::map<long long, std::pair<double, double>> init_features;
     long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // per-frame composed transition (processModel): Phi_tot, Q_tot
-    double Phi_tot[LEG * LEG], Q_tot[LEG * LEG]; bool have_prop = false;
+    double Phi_tot[LEG_MAX * LEG_MAX], Q_tot[LEG_MAX * LEG_MAX]; bool have_prop = false;
     // device
     int ld = 0, nmax = 0, rows_cap = 0, hrows = 0, feat_cap = 0, obs_cap = 0;
     double* dP[2] = {nullptr, nullptr}; int cur = 0;
@@ -252,54 +256,167 @@ static void cal_phi(const lvk_ekf* e, double* Phi, double dt, const double* gyro
 #undef BLK
 }
 
+static void update_imu_mx(lvk_ekf* e)
+{   // larvio.cpp:3803-3846
+    const double *T1 = e->imx, *T2 = e->imx + 3, *T3 = e->imx + 6, *A1 = e->imx + 9, *A2 = e->imx + 12, *A3 = e->imx + 15, *M1 = e->imx + 18, *M2 = e->imx + 21;
+    double* Tg = e->Tg; double* As = e->As; double* Ma = e->Ma;
+    Tg[0] = T2[0]; Tg[1] = T3[0]; Tg[2] = T3[1]; Tg[3] = T1[0]; Tg[4] = T2[1]; Tg[5] = T3[2]; Tg[6] = T1[1]; Tg[7] = T1[2]; Tg[8] = T2[2];
+    As[0] = A2[0]; As[1] = A3[0]; As[2] = A3[1]; As[3] = A1[0]; As[4] = A2[1]; As[5] = A3[2]; As[6] = A1[1]; As[7] = A1[2]; As[8] = A2[2];
+    Ma[0] = M2[0]; Ma[1] = 0; Ma[2] = 0; Ma[3] = M1[0]; Ma[4] = M2[1]; Ma[5] = 0; Ma[6] = M1[1]; Ma[7] = M1[2]; Ma[8] = M2[2];
+}
+
+// calPhi for calib_imu = 1 (larvio.cpp:3475-3800): Tg / Tg As / Ma enter the bias columns, and 24 columns are added for the
+// intrinsic parameters.  Every extra 3x3 block follows one recipe per parameter group (T1-T3: gyro matrix, A1-A3: g-sensitivity,
+// M1-M2: accelerometer matrix): Simpson-weighted sensitivity of the rotation (RX), then of the velocity (fRX), then of the
+// position, built from strictly-lower / diagonal / strictly-upper patterns of w, acc or f at t_k, the midpoint and t_k+1.
+static void imx_pattern(int kind, const double* v, double* M)
+{
+    for (int i = 0; i < 9; ++i) M[i] = 0;
+    if (kind == 0) { M[3] = v[0]; M[7] = v[0]; M[8] = v[1]; }          // d(X v)/d(lower entries (1,0) (2,0) (2,1))
+    else if (kind == 1) { M[0] = v[0]; M[4] = v[1]; M[8] = v[2]; }     // d/d(diagonal)
+    else { M[0] = v[1]; M[1] = v[2]; M[5] = v[2]; }                    // d/d(upper entries (0,1) (0,2) (1,2))
+}
+static void cal_phi_calib(const lvk_ekf* e, double* Phi, double dt, const double* f, const double* w, const double* acc, const double* gyro,
+                          const double* f_old, const double* w_old, const double* acc_old, const double* gyro_old)
+{
+    const int L = e->leg;
+    double f_mid[3], acc_mid[3], w_mid[3];
+    const double cw[3] = {w_old[1] * w[2] - w_old[2] * w[1], w_old[2] * w[0] - w_old[0] * w[2], w_old[0] * w[1] - w_old[1] * w[0]};
+    for (int i = 0; i < 3; ++i) { f_mid[i] = (f[i] + f_old[i]) / 2; acc_mid[i] = (acc[i] + acc_old[i]) / 2; w_mid[i] = (w_old[i] + w[i]) / 2 + dt * cw[i] / 12; }
+    const double cr[3] = {gyro_old[1] * gyro[2] - gyro_old[2] * gyro[1], gyro_old[2] * gyro[0] - gyro_old[0] * gyro[2], gyro_old[0] * gyro[1] - gyro_old[1] * gyro[0]};
+    double aa[3]; for (int i = 0; i < 3; ++i) aa[i] = dt * (gyro_old[i] + gyro[i]) / 2 + dt * dt * cr[i] / 12;
+    double Ah[9]; skew3(aa, Ah);
+    double C[9]; quat_to_rot(e->s_old.q, C);
+    for (int i = 0; i < L * L; ++i) Phi[i] = (i % (L + 1) == 0) ? 1.0 : 0.0;
+    double TA[9], TAMa[9]; m3_mul(e->Tg, e->As, TA); m3_mul(TA, e->Ma, TAMa);
+    const ImuS* so = e->if_fej ? &e->s_fej_old : &e->s_old;
+    const ImuS* sn = e->if_fej ? &e->s_fej_now : &e->s;
+    const double *vk = so->v, *pk = so->p, *vk1 = sn->v, *pk1 = sn->p;
+    const double g[3] = {0, 0, -GRAV};
+    double I2A[9]; for (int i = 0; i < 9; ++i) I2A[i] = 2 * ((i % 4 == 0) ? 1.0 : 0.0) + Ah[i];
+    double CI2A[9]; m3_mul(C, I2A, CI2A);
+#define BLK(r, c, M, sc) for (int i_ = 0; i_ < 3; ++i_) for (int j_ = 0; j_ < 3; ++j_) Phi[((r) + i_) * L + (c) + j_] = (sc) * (M)[i_ * 3 + j_]
+    { double M[9], T[9]; for (int i = 0; i < 9; ++i) M[i] = -0.5 * CI2A[i] * dt; m3_mul(M, e->Tg, T); BLK(0, 9, T, 1.0); }
+    { double M[9], T[9]; for (int i = 0; i < 9; ++i) M[i] = 0.5 * CI2A[i] * dt; m3_mul(M, TAMa, T); BLK(0, 12, T, 1.0); }
+    { double a[3], S[9]; for (int i = 0; i < 3; ++i) a[i] = vk1[i] - vk[i] - g[i] * dt; skew3(a, S); BLK(3, 0, S, -1.0); }
+    double Pvbg[9], Ppbg[9];
+    { double a[3], b[3], S1[9], S2[9], T1[9], T2[9], T3[9];
+      for (int i = 0; i < 3; ++i) { a[i] = -pk1[i] + pk[i] + vk1[i] * dt - 0.5 * g[i] * dt * dt; b[i] = -0.5 * pk1[i] + 0.5 * pk[i] + 0.5 * vk1[i] * dt - g[i] * dt * dt / 6; }
+      skew3(a, S1); skew3(b, S2); m3_mul(S1, C, T1); m3_mul(S2, C, T2); m3_mul(T2, Ah, T3);
+      for (int i = 0; i < 9; ++i) Pvbg[i] = T1[i] + T3[i];
+      BLK(3, 9, Pvbg, 1.0); }
+    { double M[9], T1[9], T2[9]; for (int i = 0; i < 9; ++i) M[i] = -0.5 * CI2A[i] * dt; m3_mul(M, e->Ma, T1); m3_mul(Pvbg, TAMa, T2);
+      for (int i = 0; i < 9; ++i) M[i] = T1[i] - T2[i]; BLK(3, 12, M, 1.0); }
+    { double a[3], S[9]; for (int i = 0; i < 3; ++i) a[i] = pk1[i] - pk[i] - vk[i] * dt - 0.5 * g[i] * dt * dt; skew3(a, S); BLK(6, 0, S, -1.0); }
+    { double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; BLK(6, 3, I, dt); }
+    { double Sg[9], T1[9], a[3], S2[9], T2[9], T3[9];
+      skew3(g, Sg); m3_mul(Sg, C, T1);
+      for (int i = 0; i < 3; ++i) a[i] = pk1[i] - pk[i] - g[i] * dt * dt / 6;
+      skew3(a, S2); m3_mul(S2, C, T2); m3_mul(T2, Ah, T3);
+      for (int i = 0; i < 9; ++i) Ppbg[i] = -dt * dt * dt * T1[i] / 6 + dt * T3[i] / 4;
+      BLK(6, 9, Ppbg, 1.0); }
+    { double I3A[9], T[9], M[9], T1[9], T2[9]; for (int i = 0; i < 9; ++i) I3A[i] = 3 * ((i % 4 == 0) ? 1.0 : 0.0) + Ah[i];
+      m3_mul(C, I3A, T); for (int i = 0; i < 9; ++i) M[i] = -T[i] * dt * dt / 6; m3_mul(M, e->Ma, T1); m3_mul(Ppbg, TAMa, T2);
+      for (int i = 0; i < 9; ++i) M[i] = T1[i] - T2[i]; BLK(6, 12, M, 1.0); }
+    double R_mid[9], R_kp1[9];
+    for (int i = 0; i < 9; ++i) { const double id = (i % 4 == 0) ? 1.0 : 0.0; R_mid[i] = id + 0.5 * Ah[i]; R_kp1[i] = id + Ah[i]; }
+    double ram[3], rka[3], Sm[9], Sk[9];
+    m3_v(R_mid, acc_mid, ram); m3_v(R_kp1, acc, rka); skew3(ram, Sm); skew3(rka, Sk);
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    struct Grp { int col, kind; const double *a, *m, *b; const double* Pm; bool has_f; double sq, sv; };
+    const Grp grp[8] = {
+        {22, 0, w_old, w_mid, w, I3, false, 1.0, -1.0}, {25, 1, w_old, w_mid, w, I3, false, 1.0, -1.0}, {28, 2, w_old, w_mid, w, I3, false, 1.0, -1.0},
+        {31, 0, acc_old, acc_mid, acc, e->Tg, false, -1.0, 1.0}, {34, 1, acc_old, acc_mid, acc, e->Tg, false, -1.0, 1.0}, {37, 2, acc_old, acc_mid, acc, e->Tg, false, -1.0, 1.0},
+        {40, 0, f_old, f_mid, f, TA, true, -1.0, 1.0}, {43, 1, f_old, f_mid, f, TA, true, -1.0, 1.0}};
+    for (const Grp& gq : grp) {
+        double Xk[9], Xm[9], Xp[9], kq1[9], kq2[9], kq4[9], T[9], RX[9];
+        imx_pattern(gq.kind, gq.a, Xk); imx_pattern(gq.kind, gq.m, Xm); imx_pattern(gq.kind, gq.b, Xp);
+        m3_mul(gq.Pm, Xk, kq1);
+        m3_mul(gq.Pm, Xm, T); m3_mul(R_mid, T, kq2);
+        m3_mul(gq.Pm, Xp, T); m3_mul(R_kp1, T, kq4);
+        for (int i = 0; i < 9; ++i) RX[i] = dt * (kq1[i] + 4 * kq2[i] + kq4[i]) / 6;
+        m3_mul(C, RX, T); BLK(0, gq.col, T, gq.sq);
+        double kv1[9], kv2[9], kv3[9], kv4[9], A[9], fRX[9];
+        for (int i = 0; i < 9; ++i) kv1[i] = gq.has_f ? Xk[i] : 0.0;
+        m3_mul(Sm, kq1, A); for (int i = 0; i < 9; ++i) kv2[i] = A[i] * dt / 2;
+        m3_mul(Sm, kq2, A); for (int i = 0; i < 9; ++i) kv3[i] = A[i] * dt / 2;
+        m3_mul(Sk, RX, kv4);
+        if (gq.has_f) {
+            double RF[9];
+            m3_mul(R_mid, Xm, RF); for (int i = 0; i < 9; ++i) { kv2[i] += RF[i]; kv3[i] += RF[i]; }
+            m3_mul(R_kp1, Xp, RF); for (int i = 0; i < 9; ++i) kv4[i] += RF[i];
+        }
+        for (int i = 0; i < 9; ++i) fRX[i] = dt * (kv1[i] + 2 * kv2[i] + 2 * kv3[i] + kv4[i]) / 6;
+        m3_mul(C, fRX, T); BLK(3, gq.col, T, gq.sv);
+        double kp[9];
+        for (int i = 0; i < 9; ++i) kp[i] = dt * (2 * (dt * kv1[i] / 2) + 2 * (dt * kv2[i] / 2) + fRX[i]) / 6;
+        m3_mul(C, kp, T); BLK(6, gq.col, T, gq.sv);
+    }
+#undef BLK
+}
+
 static void process_model(lvk_ekf* e, double time, const double* m_gyro, const double* m_acc)
 {   // larvio.cpp:520-578.  The covariance part is COMPOSED over the frame's IMU samples:
     //   Phi_tot <- Phi Phi_tot ;  Q_tot <- Phi Q_tot Phi^T + Q     (then applied once on the device)
-    double f[3], w[3], w_old[3];
-    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; w[i] = m_gyro[i] - e->s.bg[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; }
+    const int L = e->leg;
+    const bool calib = e->cfg.calib_imu_instrinsic != 0;
+    double f[3], w[3], w_old[3], f_old[3], acc[3], gyro[3], acc_old[3], gyro_old[3];
+    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; f_old[i] = e->m_acc_old[i] - e->s.ba[i]; }
+    if (calib) {
+        double t[3];
+        m3_v(e->Ma, f, acc); m3_v(e->As, acc, t); for (int i = 0; i < 3; ++i) w[i] = m_gyro[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w, gyro);
+        m3_v(e->Ma, f_old, acc_old); m3_v(e->As, acc_old, t); for (int i = 0; i < 3; ++i) w_old[i] = e->m_gyro_old[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w_old, gyro_old);
+    } else {
+        for (int i = 0; i < 3; ++i) { w[i] = m_gyro[i] - e->s.bg[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; acc[i] = f[i]; gyro[i] = w[i]; acc_old[i] = f_old[i]; gyro_old[i] = w_old[i]; }
+    }
     const double dtime = time - e->s.t;
-    predict_new_state(e, dtime, w, f);
-    double Phi[LEG * LEG]; cal_phi(e, Phi, dtime, w, w_old);
+    predict_new_state(e, dtime, gyro, acc);
+    double Phi[LEG_MAX * LEG_MAX];
+    if (calib) cal_phi_calib(e, Phi, dtime, f, w, acc, gyro, f_old, w_old, acc_old, gyro_old);
+    else cal_phi(e, Phi, dtime, w, w_old);
     double C[9]; quat_to_rot(e->s_old.q, C);
-    double G[LEG * 12]; memset(G, 0, sizeof G);
+    double G[15 * 12]; memset(G, 0, sizeof G);                      // rows 15.. of G are zero
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { G[i * 12 + j] = -C[i * 3 + j]; G[(3 + i) * 12 + 3 + j] = -C[i * 3 + j]; }
     for (int i = 0; i < 3; ++i) { G[(9 + i) * 12 + 6 + i] = 1.0; G[(12 + i) * 12 + 9 + i] = 1.0; }
-    // Structure of the discrete model (cal_phi): rows 9.. of Phi are identity rows and rows 0..8 are zero beyond column 14
-    // (q, v, p depend on q, v, p, bg, ba only); G is zero below row 14.  Skipping the exact-zero products leaves every sum
-    // bit-identical to the dense triple loops and cuts the per-sample host work ~4x.
+    // Structure of the discrete model: rows 9.. of Phi are identity rows; rows 0..8 (q, v, p) are zero outside the columns of
+    // q, v, p, bg, ba (0..14) and, when calibrating, the 24 intrinsic columns (22..45).  G is zero below row 14.  Skipping the
+    // exact-zero products leaves every sum identical to the dense triple loops and cuts the per-sample host work several times.
     const int A = 9, B = 15;
+    int nzc[39]; int nnz = 0;                                       // columns where rows 0..8 of Phi may be non-zero
+    for (int k = 0; k < 15; ++k) nzc[nnz++] = k;
+    if (calib) for (int k = 22; k < 46; ++k) nzc[nnz++] = k;
     double PG[B * 12], Q[B * B];
-    for (int i = 0; i < A; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += Phi[i * LEG + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
+    for (int i = 0; i < A; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += Phi[i * L + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
     for (int i = A; i < B; ++i) for (int j = 0; j < 12; ++j) PG[i * 12 + j] = G[i * 12 + j];
     for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) { double s = 0; for (int k = 0; k < 12; ++k) s += PG[i * 12 + k] * e->Qc[k] * PG[j * 12 + k]; Q[i * B + j] = s * dtime; }
     if (!e->have_prop) {
-        memcpy(e->Phi_tot, Phi, sizeof Phi);
-        memset(e->Q_tot, 0, sizeof e->Q_tot);
-        for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * LEG + j] = Q[i * B + j];
+        memcpy(e->Phi_tot, Phi, sizeof(double) * L * L);
+        memset(e->Q_tot, 0, sizeof(double) * L * L);
+        for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * L + j] = Q[i * B + j];
         e->have_prop = true;
     } else {
-        double T[A * LEG];
+        double T[A * LEG_MAX];
         // Phi_tot <- Phi Phi_tot : only rows 0..8 change
         for (int i = 0; i < A; ++i) {
-            double* t = T + i * LEG;
-            for (int j = 0; j < LEG; ++j) t[j] = 0;
-            for (int k = 0; k < B; ++k) { const double a = Phi[i * LEG + k]; const double* x = e->Phi_tot + k * LEG; for (int j = 0; j < LEG; ++j) t[j] += a * x[j]; }
+            double* t = T + i * L;
+            for (int j = 0; j < L; ++j) t[j] = 0;
+            for (int q = 0; q < nnz; ++q) { const int k = nzc[q]; const double a = Phi[i * L + k]; const double* x = e->Phi_tot + k * L; for (int j = 0; j < L; ++j) t[j] += a * x[j]; }
         }
-        memcpy(e->Phi_tot, T, sizeof T);
+        memcpy(e->Phi_tot, T, sizeof(double) * A * L);
         // Q_tot <- Phi Q_tot Phi^T + Q : rows 0..8 of (Phi Q_tot), then columns 0..8 of (. Phi^T)
         for (int i = 0; i < A; ++i) {
-            double* t = T + i * LEG;
-            for (int j = 0; j < LEG; ++j) t[j] = 0;
-            for (int k = 0; k < B; ++k) { const double a = Phi[i * LEG + k]; const double* x = e->Q_tot + k * LEG; for (int j = 0; j < LEG; ++j) t[j] += a * x[j]; }
+            double* t = T + i * L;
+            for (int j = 0; j < L; ++j) t[j] = 0;
+            for (int q = 0; q < nnz; ++q) { const int k = nzc[q]; const double a = Phi[i * L + k]; const double* x = e->Q_tot + k * L; for (int j = 0; j < L; ++j) t[j] += a * x[j]; }
         }
-        memcpy(e->Q_tot, T, sizeof T);
-        for (int i = 0; i < LEG; ++i) {
+        memcpy(e->Q_tot, T, sizeof(double) * A * L);
+        for (int i = 0; i < L; ++i) {
             double u[A];
-            const double* t = e->Q_tot + i * LEG;
-            for (int j = 0; j < A; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += t[k] * Phi[j * LEG + k]; u[j] = s; }
-            for (int j = 0; j < A; ++j) e->Q_tot[i * LEG + j] = u[j];
+            const double* t = e->Q_tot + i * L;
+            for (int j = 0; j < A; ++j) { double s = 0; for (int q = 0; q < nnz; ++q) { const int k = nzc[q]; s += t[k] * Phi[j * L + k]; } u[j] = s; }
+            for (int j = 0; j < A; ++j) e->Q_tot[i * L + j] = u[j];
         }
-        for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * LEG + j] += Q[i * B + j];
+        for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * L + j] += Q[i * B + j];
     }
     e->s.t = time; e->s_fej_now.t = time;
 }
@@ -309,7 +426,7 @@ static lvk_status apply_propagation(lvk_ekf* e)
     if (!e->have_prop) return LVK_OK;
     double* h = up_alloc<double>(e, 2 * LEG * LEG);
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
-    memcpy(h, e->Phi_tot, sizeof e->Phi_tot); memcpy(h + LEG * LEG, e->Q_tot, sizeof e->Q_tot);
+    memcpy(h, e->Phi_tot, sizeof(double) * LEG * LEG); memcpy(h + LEG * LEG, e->Q_tot, sizeof(double) * LEG * LEG);
     lvk_status st = flush_uploads(e);
     if (st != LVK_OK) return st;
     e->have_prop = false;
@@ -412,6 +529,7 @@ static void inject(lvk_ekf* e, const double* dx)
     small_angle_quat(dx + 15, dqe); quat_to_rot(dqe, Re); m3_t(Re, Ret); m3_mul(e->R_b2c, Ret, Rn); memcpy(e->R_b2c, Rn, 72);
     for (int i = 0; i < 3; ++i) e->t_c_b[i] += dx[18 + i];
     e->td += dx[21];
+    if (e->cfg.calib_imu_instrinsic) { for (int i = 0; i < 24; ++i) e->imx[i] += dx[22 + i]; update_imu_mx(e); }      // :1497-1507
     for (size_t c = 0; c < e->clones.size(); ++c) {
         Clone* cl = &e->clones[c];
         const double* d = dx + LEG + 6 * c;
@@ -1173,14 +1291,18 @@ void lvk_ekf_destroy(lvk_ekf* e)
 lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf** out)
 {
     if (!ctx || !cfg || !out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_create: bad argument");
-    if (cfg->feature_idp_dim != 1 || cfg->use_schmidt != 0 || cfg->calib_imu_instrinsic != 0)
-        return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "only feature_idp_dim 1, use_schmidt 0, calib_imu_instrinsic 0 are implemented");
+    if (cfg->feature_idp_dim != 1 || cfg->use_schmidt != 0 || (cfg->calib_imu_instrinsic != 0 && cfg->calib_imu_instrinsic != 1))
+        return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "only feature_idp_dim 1, use_schmidt 0, calib_imu_instrinsic 0/1 are implemented");
     if (cfg->sw_size < 5 || cfg->sw_size > 62) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "sw_size must be in 5..62");
     g_tr.on = getenv("LVK_EKF_TRACE") != nullptr;
     lvk_ekf* e = new (std::nothrow) lvk_ekf();
     if (!e) return LVK_ERR_DEVICE;
     e->ctx = ctx; e->cfg = *cfg;
     const lvk_ekf_config& c = e->cfg;
+    e->leg = c.calib_imu_instrinsic ? 46 : 22;
+    memset(e->imx, 0, sizeof e->imx);
+    for (int i = 0; i < 3; ++i) { e->imx[3 + i] = 1.0; e->imx[21 + i] = 1.0; }      // Tg = Ma = I, As = 0 (larvio.cpp:129-131)
+    update_imu_mx(e);
     e->td = c.td;
     e->sigma2 = c.noise_feature * c.noise_feature;
     e->zupt_v2 = c.zupt_noise_v * c.zupt_noise_v; e->zupt_p2 = c.zupt_noise_p * c.zupt_noise_p; e->zupt_q2 = c.zupt_noise_q * c.zupt_noise_q;
@@ -1213,7 +1335,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     // stacked rows before compression: every feature of a message can contribute 2M-3 rows (18,000 at 2000 tracks, M = 6)
     e->hrows = std::max(8 * e->rows_cap, 12 * c.max_features);
     const size_t hrows = (size_t)e->hrows;
-    bool ok = dalloc(&e->dP[0], (size_t)e->ld * e->ld) && dalloc(&e->dP[1], (size_t)e->ld * e->ld) && dalloc(&e->d_idx, e->ld) && dalloc(&e->d_phiq, 2 * LEG * LEG) &&
+    bool ok = dalloc(&e->dP[0], (size_t)e->ld * e->ld) && dalloc(&e->dP[1], (size_t)e->ld * e->ld) && dalloc(&e->d_idx, e->ld) && dalloc(&e->d_phiq, 2 * LEG_MAX * LEG_MAX) &&
               dalloc(&e->d_J, e->ld) && dalloc(&e->d_dx, e->ld + 64) && dalloc(&e->d_tmp, (size_t)64 * e->ld) &&
               dalloc(&e->d_tri, (size_t)2 * e->feat_cap) && dalloc(&e->d_triout, (size_t)2 * e->feat_cap) && dalloc(&e->d_fj, (size_t)2 * e->feat_cap) && dalloc(&e->d_fout, (size_t)2 * e->feat_cap) &&
               dalloc(&e->d_rank, e->obs_cap) && dalloc(&e->d_z, (size_t)2 * e->obs_cap) && dalloc(&e->d_zv, (size_t)2 * e->obs_cap) &&
@@ -1234,6 +1356,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
         if (c.estimate_extrin) { P0[(size_t)(15 + i) * e->ld + 15 + i] = c.initial_covariance_extrin_rot; P0[(size_t)(18 + i) * e->ld + 18 + i] = c.initial_covariance_extrin_trans; }
     }
     if (c.estimate_td) P0[(size_t)21 * e->ld + 21] = 4e-6;
+    if (c.calib_imu_instrinsic) for (int i = 22; i < 46; ++i) P0[(size_t)i * e->ld + i] = 1e-4;      // :183-186
     if (hipMemcpy(e->dP[0], P0.data(), sizeof(double) * P0.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(e->dP[1], 0, sizeof(double) * P0.size()) != hipSuccess) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "covariance upload failed"); }
     e->N = LEG; e->cur = 0;
@@ -1308,6 +1431,8 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
 }
 
 int lvk_ekf_dim(const lvk_ekf* e) { return e ? e->N : 0; }
+lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* o24) { if (!e || !o24) return LVK_ERR_ARG; memcpy(o24, e->imx, sizeof e->imx); return LVK_OK; }
+lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* i24) { if (!e || !i24) return LVK_ERR_ARG; memcpy(e->imx, i24, sizeof e->imx); update_imu_mx(e); return LVK_OK; }
 int lvk_ekf_is_initialized(const lvk_ekf* e) { return e && e->is_gravity_set ? 1 : 0; }
 lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* o)
 {

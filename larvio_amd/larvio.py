@@ -48,6 +48,8 @@ def _L():
         L.lvk_ekf_is_initialized.argtypes = [vp]; L.lvk_ekf_is_initialized.restype = i
         L.lvk_ekf_get_state.argtypes = [vp, vp]; L.lvk_ekf_get_state.restype = i
         L.lvk_ekf_get_cov.argtypes = [vp, vp]; L.lvk_ekf_get_cov.restype = i
+        L.lvk_ekf_get_imu_intrinsics.argtypes = [vp, vp]; L.lvk_ekf_get_imu_intrinsics.restype = i
+        L.lvk_ekf_set_imu_intrinsics.argtypes = [vp, vp]; L.lvk_ekf_set_imu_intrinsics.restype = i
         L.lvk_ekf_get_clones.argtypes = [vp, vp, i]; L.lvk_ekf_get_clones.restype = i
         L.lvk_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvk_ekf_get_features.restype = i
         L.lvk_ekf_counters.argtypes = [vp, vp]; L.lvk_ekf_counters.restype = None
@@ -165,6 +167,14 @@ class LarVio:
         o = np.zeros(30); self.ctx.check(_L().lvk_ekf_get_state(self._h, _p(o)))
         return dict(t=o[0], q=o[1:5].copy(), v=o[5:8].copy(), p=o[8:11].copy(), bg=o[11:14].copy(), ba=o[14:17].copy(),
                     R_b2c=o[17:26].reshape(3, 3).copy(), t_c_b=o[26:29].copy(), td=o[29])
+
+    def imu_intrinsics(self):
+        """T1 T2 T3 A1 A2 A3 M1 M2 (24 numbers; state columns 22..45 when calib_imu_instrinsic = 1)"""
+        o = np.zeros(24); self.ctx.check(_L().lvk_ekf_get_imu_intrinsics(self._h, _p(o))); return o
+
+    def set_imu_intrinsics(self, v):
+        v = np.ascontiguousarray(v, np.float64); assert v.shape == (24,)
+        self.ctx.check(_L().lvk_ekf_set_imu_intrinsics(self._h, _p(v)))
 
     def cov(self):
         N = self.dim; P = np.zeros((N, N)); self.ctx.check(_L().lvk_ekf_get_cov(self._h, _p(P))); return P

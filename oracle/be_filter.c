@@ -15,7 +15,8 @@
 #include <stdio.h>
 #include <float.h>
 
-#define LEG 22
+#define LEG (e->leg)          /* LEG_DIM: 22, or 46 with IMU-intrinsics calibration (larvio.cpp:158-161) */
+#define LEG_MAX 46
 #define MAX_OBS 192
 #define GRAV 9.81
 
@@ -39,6 +40,9 @@ struct lvo_ekf {
     int64_t imu_id; double imu_dt;
     imu_state_t s, s_old, s_fej_now, s_fej_old;
     double R_b2c[9], t_c_b[3], td;
+    int leg;                                /* LEG_DIM */
+    double imx[24];                         /* T1 T2 T3 A1 A2 A3 M1 M2 (larvio.cpp:129-154) */
+    double Tg[9], As[9], Ma[9];             /* gyro misalignment/scale, g-sensitivity, accel misalignment/scale (updateImuMx :3803-3846) */
     lvo_clone* clones; int n_clones, cap_clones;
     int64_t* feature_states; int n_fs, cap_fs;
     double* P; int N;
@@ -140,6 +144,17 @@ static void clone_refresh_cam(const lvo_ekf* e, lvo_clone* c)
 }
 
 /* ------------------------------------------------------------------------ create / config */
+static void update_imu_mx(lvo_ekf* e)
+{   /* larvio.cpp:3803-3846 */
+    const double *T1 = e->imx, *T2 = e->imx + 3, *T3 = e->imx + 6, *A1 = e->imx + 9, *A2 = e->imx + 12, *A3 = e->imx + 15, *M1 = e->imx + 18, *M2 = e->imx + 21;
+    double* Tg = e->Tg; double* As = e->As; double* Ma = e->Ma;
+    Tg[0] = T2[0]; Tg[1] = T3[0]; Tg[2] = T3[1]; Tg[3] = T1[0]; Tg[4] = T2[1]; Tg[5] = T3[2]; Tg[6] = T1[1]; Tg[7] = T1[2]; Tg[8] = T2[2];
+    As[0] = A2[0]; As[1] = A3[0]; As[2] = A3[1]; As[3] = A1[0]; As[4] = A2[1]; As[5] = A3[2]; As[6] = A1[1]; As[7] = A1[2]; As[8] = A2[2];
+    Ma[0] = M2[0]; Ma[1] = 0; Ma[2] = 0; Ma[3] = M1[0]; Ma[4] = M2[1]; Ma[5] = 0; Ma[6] = M1[1]; Ma[7] = M1[2]; Ma[8] = M2[2];
+}
+void lvo_ekf_get_imu_intrinsics(const lvo_ekf* e, double* out24) { memcpy(out24, e->imx, sizeof e->imx); }
+void lvo_ekf_set_imu_intrinsics(lvo_ekf* e, const double* in24) { memcpy(e->imx, in24, sizeof e->imx); update_imu_mx(e); }
+
 lvo_ekf* lvo_ekf_create(const lvo_ekf_config* cfg)
 {
     lvo_ekf* e = (lvo_ekf*)calloc(1, sizeof *e);
@@ -153,6 +168,10 @@ lvo_ekf* lvo_ekf_create(const lvo_ekf_config* cfg)
         e->Qc[i] = c->noise_gyro * c->noise_gyro; e->Qc[3 + i] = c->noise_acc * c->noise_acc;
         e->Qc[6 + i] = c->noise_gyro_bias * c->noise_gyro_bias; e->Qc[9 + i] = c->noise_acc_bias * c->noise_acc_bias;
     }
+    e->leg = c->calib_imu_instrinsic ? 46 : 22;
+    memset(e->imx, 0, sizeof e->imx);
+    for (int i = 0; i < 3; ++i) { e->imx[3 + i] = 1.0; e->imx[21 + i] = 1.0; }     /* T2 = diag(Tg) = 1, M2 = diag(Ma) = 1 */
+    update_imu_mx(e);
     e->N = LEG;
     e->P = (double*)calloc((size_t)LEG * LEG, sizeof(double));
     for (int i = 0; i < 3; ++i) {
@@ -167,6 +186,7 @@ lvo_ekf* lvo_ekf_create(const lvo_ekf_config* cfg)
         }
     }
     if (c->estimate_td) e->P[(size_t)21 * LEG + 21] = 4e-6;
+    if (c->calib_imu_instrinsic) for (int i = 22; i < 46; ++i) e->P[(size_t)i * LEG + i] = 1e-4;      /* :183-186 */
     /* extrinsics (larvio.cpp:189-203): R_imu_cam0 = R of T_cam_imu, t_cam0_imu = -R^T t */
     double R[9], t[3];
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = c->T_cam_imu[i * 4 + j]; t[i] = c->T_cam_imu[i * 4 + 3]; }
@@ -299,25 +319,129 @@ static void cal_phi(const lvo_ekf* e, double* Phi /*22x22*/, double dt, const do
     #undef BLK
 }
 
+/* calPhi with the IMU-intrinsic matrices in the legacy blocks and the 24 extra columns (larvio.cpp:3475-3800, calib_imu = 1).
+ * The extra blocks share one pattern per parameter group X in {T1,T2,T3 | A1,A2,A3 | M1,M2}:
+ *   kq1 = Pm X_k, kq2 = R_mid Pm X_kh, kq4 = R_kp1 Pm X_kp1, RX = dt (kq1 + 4 kq2 + kq4)/6               Phi_q = sq C RX
+ *   kv1 = F_k, kv2 = R_mid F_kh + [R_mid acc_mid]x dt kq1/2, kv3 = R_mid F_kh + [R_mid acc_mid]x dt kq2/2,
+ *   kv4 = R_kp1 F_kp1 + [R_kp1 acc]x RX, fRX = dt (kv1 + 2 kv2 + 2 kv3 + kv4)/6                            Phi_v = sv C fRX
+ *   Phi_p = sv C dt (2 (dt kv1/2) + 2 (dt kv2/2) + fRX)/6
+ * with Pm = I / Tg / Tg As, X built from w / acc / f as a strictly-lower (L), diagonal (D) or strictly-upper (U) pattern, the
+ * F terms present for the M groups only, sq = +,-,- and sv = -,+,+ for the T, A, M groups. */
+static void pat3(int kind, const double* v, double* M)
+{   /* L: (1,0)=v0 (2,1)=v0 (2,2)=v1 ; D: diag(v) ; U: (0,0)=v1 (0,1)=v2 (1,2)=v2   (larvio.cpp:3534-3630, as written there) */
+    for (int i = 0; i < 9; ++i) M[i] = 0;
+    if (kind == 0) { M[3] = v[0]; M[7] = v[0]; M[8] = v[1]; }
+    else if (kind == 1) { M[0] = v[0]; M[4] = v[1]; M[8] = v[2]; }
+    else { M[0] = v[1]; M[1] = v[2]; M[5] = v[2]; }
+}
+static void cal_phi_calib(const lvo_ekf* e, double* Phi, double dt, const double* f, const double* w, const double* acc, const double* gyro,
+                          const double* f_old, const double* w_old, const double* acc_old, const double* gyro_old)
+{
+    const int L = e->leg;
+    double f_mid[3], acc_mid[3], w_mid[3], cw[3] = {w_old[1] * w[2] - w_old[2] * w[1], w_old[2] * w[0] - w_old[0] * w[2], w_old[0] * w[1] - w_old[1] * w[0]};
+    for (int i = 0; i < 3; ++i) { f_mid[i] = (f[i] + f_old[i]) / 2; acc_mid[i] = (acc[i] + acc_old[i]) / 2; w_mid[i] = (w_old[i] + w[i]) / 2 + dt * cw[i] / 12; }
+    double cr[3] = {gyro_old[1] * gyro[2] - gyro_old[2] * gyro[1], gyro_old[2] * gyro[0] - gyro_old[0] * gyro[2], gyro_old[0] * gyro[1] - gyro_old[1] * gyro[0]};
+    double aa[3];
+    for (int i = 0; i < 3; ++i) aa[i] = dt * (gyro_old[i] + gyro[i]) / 2 + dt * dt * cr[i] / 12;
+    double Ah[9]; skew3(aa, Ah);
+    double C[9]; quat_to_rot(e->s_old.q, C);
+    for (int i = 0; i < L * L; ++i) Phi[i] = (i % (L + 1) == 0) ? 1.0 : 0.0;
+    double TA[9]; m3_mul(e->Tg, e->As, TA);
+    const imu_state_t* so = e->if_fej ? &e->s_fej_old : &e->s_old;
+    const imu_state_t* sn = e->if_fej ? &e->s_fej_now : &e->s;
+    const double* vk = so->v; const double* pk = so->p; const double* vk1 = sn->v; const double* pk1 = sn->p;
+    const double g[3] = {0, 0, -GRAV};
+    double I2A[9]; for (int i = 0; i < 9; ++i) I2A[i] = 2 * ((i % 4 == 0) ? 1.0 : 0.0) + Ah[i];
+    double CI2A[9]; m3_mul(C, I2A, CI2A);
+    #define BLK(r, c, M, sc) for (int i_ = 0; i_ < 3; ++i_) for (int j_ = 0; j_ < 3; ++j_) Phi[((r) + i_) * L + (c) + j_] = (sc) * (M)[i_ * 3 + j_]
+    double TAMa[9]; m3_mul(TA, e->Ma, TAMa);
+    { double M[9], T[9]; for (int i = 0; i < 9; ++i) M[i] = -0.5 * CI2A[i] * dt; m3_mul(M, e->Tg, T); BLK(0, 9, T, 1.0); }          /* Phi_q_bg */
+    { double M[9], T[9]; for (int i = 0; i < 9; ++i) M[i] = 0.5 * CI2A[i] * dt; m3_mul(M, TAMa, T); BLK(0, 12, T, 1.0); }           /* Phi_q_ba */
+    { double a[3], S[9]; for (int i = 0; i < 3; ++i) a[i] = vk1[i] - vk[i] - g[i] * dt; skew3(a, S); BLK(3, 0, S, -1.0); }          /* Phi_v_q */
+    double Pvbg[9], Ppbg[9];
+    { double a[3], b[3], S1[9], S2[9], T1[9], T2[9], T3[9];
+      for (int i = 0; i < 3; ++i) { a[i] = -pk1[i] + pk[i] + vk1[i] * dt - 0.5 * g[i] * dt * dt; b[i] = -0.5 * pk1[i] + 0.5 * pk[i] + 0.5 * vk1[i] * dt - g[i] * dt * dt / 6; }
+      skew3(a, S1); skew3(b, S2); m3_mul(S1, C, T1); m3_mul(S2, C, T2); m3_mul(T2, Ah, T3);
+      for (int i = 0; i < 9; ++i) Pvbg[i] = T1[i] + T3[i];
+      BLK(3, 9, Pvbg, 1.0); }                                                                                                       /* Phi_v_bg */
+    { double M[9], T1[9], T2[9]; for (int i = 0; i < 9; ++i) M[i] = -0.5 * CI2A[i] * dt; m3_mul(M, e->Ma, T1); m3_mul(Pvbg, TAMa, T2);
+      for (int i = 0; i < 9; ++i) M[i] = T1[i] - T2[i]; BLK(3, 12, M, 1.0); }                                                       /* Phi_v_ba */
+    { double a[3], S[9]; for (int i = 0; i < 3; ++i) a[i] = pk1[i] - pk[i] - vk[i] * dt - 0.5 * g[i] * dt * dt; skew3(a, S); BLK(6, 0, S, -1.0); }   /* Phi_p_q */
+    { double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; BLK(6, 3, I, dt); }                                                                /* Phi_p_v */
+    { double Sg[9], T1[9], a[3], S2[9], T2[9], T3[9];
+      skew3(g, Sg); m3_mul(Sg, C, T1);
+      for (int i = 0; i < 3; ++i) a[i] = pk1[i] - pk[i] - g[i] * dt * dt / 6;
+      skew3(a, S2); m3_mul(S2, C, T2); m3_mul(T2, Ah, T3);
+      for (int i = 0; i < 9; ++i) Ppbg[i] = -dt * dt * dt * T1[i] / 6 + dt * T3[i] / 4;
+      BLK(6, 9, Ppbg, 1.0); }                                                                                                       /* Phi_p_bg */
+    { double I3A[9], T[9], M[9], T1[9], T2[9]; for (int i = 0; i < 9; ++i) I3A[i] = 3 * ((i % 4 == 0) ? 1.0 : 0.0) + Ah[i];
+      m3_mul(C, I3A, T); for (int i = 0; i < 9; ++i) M[i] = -T[i] * dt * dt / 6; m3_mul(M, e->Ma, T1); m3_mul(Ppbg, TAMa, T2);
+      for (int i = 0; i < 9; ++i) M[i] = T1[i] - T2[i]; BLK(6, 12, M, 1.0); }                                                       /* Phi_p_ba */
+    /* ---- the 24 intrinsic columns */
+    double R_mid[9], R_kp1[9];
+    for (int i = 0; i < 9; ++i) { const double id = (i % 4 == 0) ? 1.0 : 0.0; R_mid[i] = id + 0.5 * Ah[i]; R_kp1[i] = id + Ah[i]; }
+    double ram[3], rka[3], Sm[9], Sk[9];
+    m3_v(R_mid, acc_mid, ram); m3_v(R_kp1, acc, rka); skew3(ram, Sm); skew3(rka, Sk);
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    /* group table: column, pattern kind, source vectors (k, mid, k+1), pre-multiplier, has F terms, signs */
+    struct { int col, kind; const double *vk_, *vm_, *vp_; const double* Pm; int has_f; double sq, sv; } grp[8] = {
+        {22, 0, w_old, w_mid, w, I3, 0, 1.0, -1.0}, {25, 1, w_old, w_mid, w, I3, 0, 1.0, -1.0}, {28, 2, w_old, w_mid, w, I3, 0, 1.0, -1.0},
+        {31, 0, acc_old, acc_mid, acc, e->Tg, 0, -1.0, 1.0}, {34, 1, acc_old, acc_mid, acc, e->Tg, 0, -1.0, 1.0}, {37, 2, acc_old, acc_mid, acc, e->Tg, 0, -1.0, 1.0},
+        {40, 0, f_old, f_mid, f, TA, 1, -1.0, 1.0}, {43, 1, f_old, f_mid, f, TA, 1, -1.0, 1.0}};
+    for (int gi = 0; gi < 8; ++gi) {
+        double Xk[9], Xm[9], Xp[9], kq1[9], kq2[9], kq4[9], T[9], RX[9];
+        pat3(grp[gi].kind, grp[gi].vk_, Xk); pat3(grp[gi].kind, grp[gi].vm_, Xm); pat3(grp[gi].kind, grp[gi].vp_, Xp);
+        m3_mul(grp[gi].Pm, Xk, kq1);
+        m3_mul(grp[gi].Pm, Xm, T); m3_mul(R_mid, T, kq2);
+        m3_mul(grp[gi].Pm, Xp, T); m3_mul(R_kp1, T, kq4);
+        for (int i = 0; i < 9; ++i) RX[i] = dt * (kq1[i] + 4 * kq2[i] + kq4[i]) / 6;
+        m3_mul(C, RX, T); BLK(0, grp[gi].col, T, grp[gi].sq);
+        double kv1[9], kv2[9], kv3[9], kv4[9], A[9], fRX[9];
+        for (int i = 0; i < 9; ++i) kv1[i] = grp[gi].has_f ? Xk[i] : 0.0;
+        m3_mul(Sm, kq1, A); for (int i = 0; i < 9; ++i) kv2[i] = A[i] * dt / 2;
+        m3_mul(Sm, kq2, A); for (int i = 0; i < 9; ++i) kv3[i] = A[i] * dt / 2;
+        m3_mul(Sk, RX, kv4);
+        if (grp[gi].has_f) {
+            double RF[9];
+            m3_mul(R_mid, Xm, RF); for (int i = 0; i < 9; ++i) { kv2[i] += RF[i]; kv3[i] += RF[i]; }
+            m3_mul(R_kp1, Xp, RF); for (int i = 0; i < 9; ++i) kv4[i] += RF[i];
+        }
+        for (int i = 0; i < 9; ++i) fRX[i] = dt * (kv1[i] + 2 * kv2[i] + 2 * kv3[i] + kv4[i]) / 6;
+        m3_mul(C, fRX, T); BLK(3, grp[gi].col, T, grp[gi].sv);
+        double kp[9];
+        for (int i = 0; i < 9; ++i) kp[i] = dt * (2 * (dt * kv1[i] / 2) + 2 * (dt * kv2[i] / 2) + fRX[i]) / 6;
+        m3_mul(C, kp, T); BLK(6, grp[gi].col, T, grp[gi].sv);
+    }
+    #undef BLK
+}
+
 static void process_model(lvo_ekf* e, double time, const double* m_gyro, const double* m_acc)
 {   /* larvio.cpp:520-578 */
-    double f[3], w[3], f_old[3], w_old[3];
-    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; w[i] = m_gyro[i] - e->s.bg[i]; f_old[i] = e->m_acc_old[i] - e->s.ba[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; }
+    double f[3], w[3], f_old[3], w_old[3], acc[3], gyro[3], acc_old[3], gyro_old[3];
+    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; f_old[i] = e->m_acc_old[i] - e->s.ba[i]; }
+    if (e->cfg.calib_imu_instrinsic) {
+        double t[3];
+        m3_v(e->Ma, f, acc); m3_v(e->As, acc, t); for (int i = 0; i < 3; ++i) w[i] = m_gyro[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w, gyro);
+        m3_v(e->Ma, f_old, acc_old); m3_v(e->As, acc_old, t); for (int i = 0; i < 3; ++i) w_old[i] = e->m_gyro_old[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w_old, gyro_old);
+    } else {
+        for (int i = 0; i < 3; ++i) { w[i] = m_gyro[i] - e->s.bg[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; acc[i] = f[i]; gyro[i] = w[i]; acc_old[i] = f_old[i]; gyro_old[i] = w_old[i]; }
+    }
     double dtime = time - e->s.t;
-    predict_new_state(e, dtime, w, f);
-    double Phi[LEG * LEG];
-    cal_phi(e, Phi, dtime, f, w, f, w, f_old, w_old, f_old, w_old);
+    predict_new_state(e, dtime, gyro, acc);
+    double Phi[LEG_MAX * LEG_MAX];
+    if (e->cfg.calib_imu_instrinsic) cal_phi_calib(e, Phi, dtime, f, w, acc, gyro, f_old, w_old, acc_old, gyro_old);
+    else cal_phi(e, Phi, dtime, f, w, acc, gyro, f_old, w_old, acc_old, gyro_old);
     double C[9]; quat_to_rot(e->s_old.q, C);
-    double G[LEG * 12]; memset(G, 0, sizeof G);
+    double G[LEG_MAX * 12]; memset(G, 0, sizeof G);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { G[i * 12 + j] = -C[i * 3 + j]; G[(3 + i) * 12 + 3 + j] = -C[i * 3 + j]; }
     for (int i = 0; i < 3; ++i) { G[(9 + i) * 12 + 6 + i] = 1.0; G[(12 + i) * 12 + 9 + i] = 1.0; }
-    double PG[LEG * 12], Q[LEG * LEG];
+    double PG[LEG_MAX * 12], Q[LEG_MAX * LEG_MAX];
     for (int i = 0; i < LEG; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
     for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < 12; ++k) s += PG[i * 12 + k] * e->Qc[k] * PG[j * 12 + k]; Q[i * LEG + j] = s * dtime; }
     const int N = e->N;
     double* P = e->P;
     /* P_II <- Phi P_II Phi^T + Q */
-    double T[LEG * LEG], PII[LEG * LEG];
+    double T[LEG_MAX * LEG_MAX], PII[LEG_MAX * LEG_MAX];
     for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += Phi[i * LEG + k] * P[(size_t)k * N + j]; T[i * LEG + j] = s; }
     for (int i = 0; i < LEG; ++i) for (int j = 0; j < LEG; ++j) { double s = 0; for (int k = 0; k < LEG; ++k) s += T[i * LEG + k] * Phi[j * LEG + k]; PII[i * LEG + j] = s + Q[i * LEG + j]; }
     if (N > LEG) {
@@ -426,6 +550,7 @@ static void inject(lvo_ekf* e, const double* dx, int n_old_features /* features 
     small_angle_quat(dx + 15, dqe); quat_to_rot(dqe, Re); m3_t(Re, Ret); m3_mul(e->R_b2c, Ret, Rn); memcpy(e->R_b2c, Rn, 72);
     for (int i = 0; i < 3; ++i) e->t_c_b[i] += dx[18 + i];
     e->td += dx[21];
+    if (e->cfg.calib_imu_instrinsic) { for (int i = 0; i < 24; ++i) e->imx[i] += dx[22 + i]; update_imu_mx(e); }      /* :1497-1507 */
     for (int c = 0; c < e->n_clones; ++c) {
         lvo_clone* cl = &e->clones[c];
         const double* d = dx + LEG + 6 * c;

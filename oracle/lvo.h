@@ -174,7 +174,7 @@ void lvo_frontend_lk_stats(const lvo_frontend* fe, uint64_t* point_levels, uint6
 
 /* ==================================================================== back-end (EKF update)
  * Restates /root/reference/src/larvio.cpp (processFeatures :363-461 and everything it calls) and
- * include/larvio/feature.hpp:252-890 for feature_idp_dim = 1, use_schmidt = 0, calib_imu = 0
+ * include/larvio/feature.hpp:252-890 for feature_idp_dim = 1, use_schmidt = 0, calib_imu = 0 or 1
  * (the settings of config/euroc.yaml:8-10,105,108).  Dense algebra that the reference delegates to
  * Eigen / SuiteSparse SPQR is restated with Householder QR and Cholesky: the quantities that reach
  * the state (gate value, K r, (I-KH)P) are invariant to the choice of orthonormal basis / factorisation. */
@@ -227,11 +227,15 @@ typedef struct {
     double rotation_threshold, translation_threshold, tracking_rate_threshold, feature_translation_threshold;
     double zupt_max_feature_dis, zupt_noise_v, zupt_noise_p, zupt_noise_q;
     double static_duration;
+    int calib_imu_instrinsic;           /* 1: online IMU intrinsics (larvio.cpp:127-186), LEG_DIM 46 instead of 22 */
 } lvo_ekf_config;
 
 typedef struct lvo_ekf lvo_ekf;
 lvo_ekf* lvo_ekf_create(const lvo_ekf_config* cfg);
 void lvo_ekf_destroy(lvo_ekf* e);
+/* the 24 IMU-intrinsic parameters T1 T2 T3 A1 A2 A3 M1 M2 (larvio.cpp:129-154; state columns 22..45 when calibrated) */
+void lvo_ekf_get_imu_intrinsics(const lvo_ekf* e, double* out24);
+void lvo_ekf_set_imu_intrinsics(lvo_ekf* e, const double* in24);
 /* LarVio::processFeatures (larvio.cpp:363-461).  imu: the caller's buffer; *n_consumed = samples the reference would erase. */
 int lvo_ekf_process(lvo_ekf* e, double ts, const lvo_feature_obs* feats, int n_feats, const lvo_imu* imu, int n_imu, int* n_consumed);
 /* bypass the initializer (tests): IMU state at time t; gyro/acc = last IMU sample (m_gyro_old/m_acc_old) */

@@ -19,13 +19,15 @@ _CFG_DBL = ["td", "noise_gyro", "noise_acc", "noise_gyro_bias", "noise_acc_bias"
 
 class EkfConfig(C.Structure):
     _fields_ = ([(k, C.c_int) for k in _CFG_INT[:14]] + [("intrinsics", C.c_double * 4), ("T_cam_imu", C.c_double * 16)] +
-                [(k, C.c_double) for k in _CFG_DBL])
+                [(k, C.c_double) for k in _CFG_DBL] + [("calib_imu_instrinsic", C.c_int)])
 
 
 def make_ekf_config(cfg, cls=EkfConfig):
     c = cls()
     for k in _CFG_INT + _CFG_DBL:
         setattr(c, k, cfg[k])
+    if hasattr(c, "calib_imu_instrinsic"):
+        c.calib_imu_instrinsic = int(cfg.get("calib_imu_instrinsic", 0))
     c.intrinsics = (C.c_double * 4)(*cfg["intrinsics"])
     c.T_cam_imu = (C.c_double * 16)(*np.asarray(cfg["T_cam_imu"], np.float64).reshape(16))
     return c
@@ -39,6 +41,8 @@ def _lib():
     L = lvo.lib()
     if not _done:
         vp, i, d = C.c_void_p, C.c_int, C.c_double
+        L.lvo_ekf_get_imu_intrinsics.argtypes = [vp, vp]; L.lvo_ekf_get_imu_intrinsics.restype = None
+        L.lvo_ekf_set_imu_intrinsics.argtypes = [vp, vp]; L.lvo_ekf_set_imu_intrinsics.restype = None
         L.lvo_triangulate.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp]; L.lvo_triangulate.restype = i
         L.lvo_check_motion.argtypes = [vp, vp, vp, d]; L.lvo_check_motion.restype = i
         L.lvo_msckf_feature_jacobian.argtypes = [vp, vp, vp, vp, i, vp, i, i, i, i, vp, vp]; L.lvo_msckf_feature_jacobian.restype = i
@@ -138,6 +142,14 @@ class Ekf:
         o = np.zeros(30); _lib().lvo_ekf_get_state(self.h, _p(o))
         return dict(t=o[0], q=o[1:5].copy(), v=o[5:8].copy(), p=o[8:11].copy(), bg=o[11:14].copy(), ba=o[14:17].copy(),
                     R_b2c=o[17:26].reshape(3, 3).copy(), t_c_b=o[26:29].copy(), td=o[29])
+
+    def imu_intrinsics(self):
+        """T1 T2 T3 A1 A2 A3 M1 M2 (24 numbers; state columns 22..45 when calib_imu_instrinsic = 1)"""
+        o = np.zeros(24); _lib().lvo_ekf_get_imu_intrinsics(self.h, _p(o)); return o
+
+    def set_imu_intrinsics(self, v):
+        v = np.ascontiguousarray(v, np.float64); assert v.shape == (24,)
+        _lib().lvo_ekf_set_imu_intrinsics(self.h, _p(v))
 
     def cov(self):
         N = self.dim; P = np.zeros((N, N)); _lib().lvo_ekf_get_cov(self.h, _p(P)); return P

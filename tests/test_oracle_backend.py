@@ -180,3 +180,86 @@ def test_end_to_end_vio_tracks_ground_truth():
     assert c["hybrid"] >= 10 and c["msckf"] >= 1 and c["gated_in"] > 5 * c["gated_out"]
     assert be.dim > 22 + 6 * 18
     assert max(errs) < 0.08, max(errs)
+
+
+def _one_imu_step(cfg, imx, bg, ba, n=1):
+    """oracle filter after exactly n IMU samples from a ground-truth state (no features: pure propagation + one clone)"""
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    seq = S.imu_only_sequence()
+    imu = seq.imu_array(600, 600 + n + 2)
+    tr = seq.traj; t0 = imu["t"][0]
+    e = lvo_be.Ekf(cfg)
+    e.set_state(t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), bg, ba, imu["gyro"][0], imu["acc"][0])
+    e.set_imu_intrinsics(imx)
+    e.process(float(imu["t"][n]), np.zeros(0, lvo.OBS), imu[1:n + 1])
+    return e
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def test_imu_intrinsics_transition_blocks_vs_finite_differences():
+    """calib_imu_instrinsic = 1 (config 3, LEG_DIM 46): the 24 intrinsic columns and the bias columns of Phi (larvio.cpp:3475-3800)
+    against finite differences of the state predictor.  Phi[0:9, c] is read from the cross-covariance after ONE IMU step from the
+    diagonal initial covariance (rows c of Phi are identity rows, so P'[0:9, c] = Phi[0:9, c] P0[c, c]).  LARVIO's blocks are
+    Simpson/RK-weighted approximations, so the agreement is to a few percent, block by block, with the right signs."""
+    from larvio_amd import synthetic as S
+    cfg = S.backend_config(sw_size=10, calib_imu_instrinsic=1, if_fej=0)
+    base = np.zeros(24); base[3:6] = 1; base[21:24] = 1
+    base += np.random.default_rng(0).normal(0, 0.02, 24)              # non-trivial Tg, As, Ma
+    bg0, ba0 = np.array([0.01, -0.02, 0.005]), np.array([0.05, 0.02, -0.03])
+    e0 = _one_imu_step(cfg, base, bg0, ba0)
+    assert e0.dim == 46 + 6
+    s0, P = e0.state(), e0.cov()
+    P0 = np.zeros(46); P0[9:12] = cfg["initial_covariance_gyro_bias"]; P0[12:15] = cfg["initial_covariance_acc_bias"]; P0[22:46] = 1e-4
+
+    def err_state(s1):
+        qi = s0["q"] * np.array([-1, -1, -1, 1]); dq = _qmul(s1["q"], qi)
+        return np.concatenate([2 * dq[:3] * np.sign(dq[3]), s1["v"] - s0["v"], s1["p"] - s0["p"]])
+
+    eps = 1e-6
+    for c in list(range(9, 15)) + list(range(22, 46)):
+        phi_c = P[0:9, c] / P0[c]
+        imx, bg, ba = base.copy(), bg0.copy(), ba0.copy()
+        if c < 12: bg[c - 9] += eps
+        elif c < 15: ba[c - 12] += eps
+        else: imx[c - 22] += eps
+        num = err_state(_one_imu_step(cfg, imx, bg, ba).state()) / eps
+        g0 = 3 * ((c - 22) // 3) + 22 if c >= 22 else (9 if c < 12 else 12)          # first column of this parameter group
+        for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+            scale = np.abs(P[blk, g0:g0 + 3] / P0[c]).max()                            # size of the whole 3x3 block
+            assert np.abs(phi_c[blk] - num[blk]).max() <= 0.08 * scale + 1e-13, (c, blk, phi_c[blk], num[blk])
+
+
+def test_calibrating_filter_tracks_ground_truth_and_keeps_intrinsics_near_identity():
+    """whole oracle VIO with calib_imu_instrinsic = 1 on the synthetic sequence (perfect IMU intrinsics): position error stays at the
+    centimetre level and the 24 calibration states stay within a few 1e-3 of identity"""
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    frames = synth_frames(40, 70)
+    seq = S.imu_only_sequence()
+    ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    ofe = lvo.Frontend(S.frontend_config(max_features_num=150))
+    obe = lvo_be.Ekf(S.backend_config(sw_size=15, if_zupt_valid=0, calib_imu_instrinsic=1))
+    lo = 0; n_upd = 0
+    for i, (t, img) in enumerate(frames):
+        hi = int(np.searchsorted(imu_all["t"], t + 0.05, side="left"))
+        if i == 1:
+            k = int(np.searchsorted(imu_all["t"], t, side="right")) - 1
+            t0 = imu_all["t"][k]; tr = seq.traj
+            obe.set_state(t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+        buf = imu_all[lo:hi]
+        have, m = ofe.process(img, t, buf)
+        if have:
+            ok, used = obe.process(t, m, buf); lo += used; n_upd += int(ok)
+    assert n_upd >= 25 and obe.dim >= 46 + 6 * 10
+    s = obe.state()
+    assert np.linalg.norm(s["p"] - seq.traj.p_wb(s["t"])) < 0.08
+    ident = np.zeros(24); ident[3:6] = 1; ident[21:24] = 1
+    assert np.abs(obe.imu_intrinsics() - ident).max() < 0.02
