@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
 
 
@@ -133,6 +134,7 @@ def main():
         drv.drain(); drv.stats(reset=True)
     pl0, it0 = fe.lk_stats()
     fe.profile_enable((1 << 2) | (1 << 3))               # HIP events around the LK launches only (dominant kernel)
+    be.profile(True)                                     # ... and around the H P GEMM of every update (MFMA utilisation)
     state["n_be"] = 0
     if dist is not None:
         dist.barrier()
@@ -158,6 +160,7 @@ def main():
     prof = fe.profile_read()
     pl1, it1 = fe.lk_stats()
     pst = None if args.sequential else drv.stats()
+    hp = be.profile(False)
 
     if rank == 0:
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
@@ -227,7 +230,13 @@ def main():
                           "sw_size": args.sw_size, "state_dim": be.dim, "backend": be.counters(),
                           "live_tracks": int(len(fe.tracks()["ids"])), "messages": n_msgs,
                           "parallelism": "replicas x%d" % world},
-               "roofline": roofline, "cpu_baseline": cpu_baseline}
+               "roofline": roofline,
+               # the one GEMM-shaped contraction of the path (P H^T as H P, FP64 MFMA 16x16x4): utilisation against the dense FP64 matrix peak
+               "roofline_mfma": {"kernel": "k_dgemm<false,false> (H P)", "bound": "mfma", "achieved": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9, 4),
+                                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 6),
+                                 "flops_per_launch": round(hp["flops"] / max(hp["launches"], 1), 1),
+                                 "avg_launch_us": round(hp["ms"] / max(hp["launches"], 1) * 1e3, 3), "launches": hp["launches"]},
+               "cpu_baseline": cpu_baseline}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

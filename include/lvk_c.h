@@ -228,6 +228,9 @@ int        lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* h_out, int cap);     
 int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_depth, double* h_pos_w, int cap);  /* getActiveeMapPointPositions */
 /* [0] hybrid updates [1] msckf updates [2] rows of the last update [3] zupt updates [4] gated in [5] gated out [6] map size [7] triangulations */
 void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
+/* HIP-event bracket around the H P GEMM (the P H^T contraction, FP64 MFMA) of every update: enable/disable; h_out3 (optional) receives
+ * [milliseconds, flops = sum 2 m N^2, launches] accumulated since the previous call */
+lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* h_out3);
 
 /* ---- per-feature stages of the update, one call each (parity tests; callers that want a single stage).  Host buffers.
  * lvk_triangulate: Feature::initializePosition (use_position 0) / the LM refinement from a given position (1), feature.hpp:383-890,

@@ -27,7 +27,7 @@
 #define LEG_MAX 46
 #define GRAV 9.81
 
-struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; };
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; };   // ev_*: optional bracket around the H P GEMM
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
 lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq);
@@ -114,6 +114,10 @@ struct lvk_ekf {
     // fired as soon as the number of IMU samples this call erases is final (before any GPU work): lets a pipelined driver
     // hand the next frame's front-end the right buffer view while this update is still running
     void (*on_consumed)(void*, int) = nullptr; void* on_consumed_user = nullptr;
+    // optional HIP-event bracket around the H P GEMM of every update (bench: MFMA utilisation of the P H^T contraction)
+    bool prof_on = false; double prof_ms = 0, prof_flops = 0; long prof_n = 0;
+    struct ProfEv { hipEvent_t a, b; double flops; };
+    std::vector<ProfEv> prof_pending; std::vector<hipEvent_t> prof_free;
 };
 
 // ------------------------------------------------------------------------- host-side phase tracer (LVK_EKF_TRACE=1)
@@ -738,7 +742,13 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
         if (st != LVK_OK) return st;
         m = m2;
     }
-    st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, e->d_H, e->ld, m, e->d_r, e->sigma2, e->d_dx, e->ws);
+    UpdateWs ws = e->ws;
+    if (e->prof_on && m > 0) {
+        auto take = [&]() { hipEvent_t ev; if (!e->prof_free.empty()) { ev = e->prof_free.back(); e->prof_free.pop_back(); } else hipEventCreate(&ev); return ev; };
+        ws.ev_a = take(); ws.ev_b = take();
+        e->prof_pending.push_back({ws.ev_a, ws.ev_b, 2.0 * m * (double)e->N * (double)e->N});
+    }
+    st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, e->d_H, e->ld, m, e->d_r, e->sigma2, e->d_dx, ws);
     if (st != LVK_OK) return st;
     dx.assign((size_t)e->N + extra, 0.0);
     e->counters[2] = m;
@@ -1274,6 +1284,8 @@ void lvk_ekf_destroy(lvk_ekf* e)
 {
     if (!e) return;
     hipStreamSynchronize(e->ctx->stream);
+    for (auto& pe : e->prof_pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
+    for (hipEvent_t ev : e->prof_free) hipEventDestroy(ev);
     if (g_tr.on && g_tr.n > 0) {
         double tot = 0; for (int i = 0; i < TR_N; ++i) tot += g_tr.acc[i];
         fprintf(stderr, "[lvk_ekf trace] %ld updates, %.1f us/update host wall\n", g_tr.n, tot / g_tr.n);
@@ -1424,12 +1436,25 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
     if (e->cfg.if_fej && !e->if_fej && e->s.t - e->take_off_stamp >= 0) e->if_fej = true;
     e->counters[6] = (long)e->map.size();
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    for (auto& pe : e->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) { e->prof_ms += ms; e->prof_flops += pe.flops; e->prof_n += 1; }
+        e->prof_free.push_back(pe.a); e->prof_free.push_back(pe.b);
+    }
+    e->prof_pending.clear();
     TR(TR_FINAL);
     g_tr.n++;
     *updated = 1;
     return LVK_OK;
 }
 
+lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* out3)
+{   // out3 (optional): [ms inside the H P GEMM, its flops 2 m N^2, launches] since the last call, then reset
+    if (!e) return LVK_ERR_ARG;
+    if (out3) { out3[0] = e->prof_ms; out3[1] = e->prof_flops; out3[2] = (double)e->prof_n; }
+    e->prof_ms = e->prof_flops = 0; e->prof_n = 0; e->prof_on = enable != 0;
+    return LVK_OK;
+}
 int lvk_ekf_dim(const lvk_ekf* e) { return e ? e->N : 0; }
 lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* o24) { if (!e || !o24) return LVK_ERR_ARG; memcpy(o24, e->imx, sizeof e->imx); return LVK_OK; }
 lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* i24) { if (!e || !i24) return LVK_ERR_ARG; memcpy(e->imx, i24, sizeof e->imx); update_imu_mx(e); return LVK_OK; }

@@ -588,7 +588,7 @@ static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double*
 }
 
 // ------------------------------------------------------------------------- host drivers (internal + C ABI)
-struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; };
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; };   // ev_*: optional bracket around the H P GEMM
 
 // dx (device, n) and P updated in place.  B: m x (n+1) workspace, S: m x m workspace.
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2,
@@ -596,7 +596,9 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
 {
     if (m <= 0) { LVK_HIP(ctx, hipMemsetAsync(dx, 0, sizeof(double) * (size_t)n, ctx->stream)); return LVK_OK; }
     hipStream_t s = ctx->stream;
+    if (ws.ev_a) hipEventRecord(ws.ev_a, s);
     launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0, GemmRider{r, n, nullptr, 0});   // [HP | r]
+    if (ws.ev_b) hipEventRecord(ws.ev_b, s);
     launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
     launch_chol_solve(s, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info);                                    // S = L L^T ; W = L^-1 [HP | r]
     // W^T [W | w]: columns 0..n-1 update P (P -= W^T W), column n is dx = W^T w

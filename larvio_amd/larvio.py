@@ -53,6 +53,7 @@ def _L():
         L.lvk_ekf_get_clones.argtypes = [vp, vp, i]; L.lvk_ekf_get_clones.restype = i
         L.lvk_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvk_ekf_get_features.restype = i
         L.lvk_ekf_counters.argtypes = [vp, vp]; L.lvk_ekf_counters.restype = None
+        L.lvk_ekf_profile.argtypes = [vp, i, vp]; L.lvk_ekf_profile.restype = i
         L.lvk_triangulate.argtypes = [vp, vp, vp, i, i, vp, pi, vp, vp, vp, vp]; L.lvk_triangulate.restype = i
         L.lvk_ekf_gate_and_stack.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, i, i, i, d, vp, vp, i, pi, vp, vp]; L.lvk_ekf_gate_and_stack.restype = i
         _sig_done = True
@@ -167,6 +168,11 @@ class LarVio:
         o = np.zeros(30); self.ctx.check(_L().lvk_ekf_get_state(self._h, _p(o)))
         return dict(t=o[0], q=o[1:5].copy(), v=o[5:8].copy(), p=o[8:11].copy(), bg=o[11:14].copy(), ba=o[14:17].copy(),
                     R_b2c=o[17:26].reshape(3, 3).copy(), t_c_b=o[26:29].copy(), td=o[29])
+
+    def profile(self, enable=True):
+        """HIP-event time of the H P GEMM since the last call: dict(ms, flops, launches); enables/disables the bracket"""
+        o = np.zeros(3); self.ctx.check(_L().lvk_ekf_profile(self._h, int(enable), _p(o)))
+        return dict(ms=o[0], flops=o[1], launches=int(o[2]))
 
     def imu_intrinsics(self):
         """T1 T2 T3 A1 A2 A3 M1 M2 (24 numbers; state columns 22..45 when calib_imu_instrinsic = 1)"""
