@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <new>
 #include <float.h>
+#include <sched.h>
+#include <pthread.h>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -1561,6 +1563,15 @@ template <typename Pred> static void pipe_wait(std::unique_lock<std::mutex>& lk,
 static void pipe_worker(lvk_vio_pipe* p)
 {
     hipSetDevice(p->ekf->ctx->device);
+    if (const char* pin = getenv("LVK_PIN_WORKER")) {       // optional: keep the filter thread on one core (less jitter on big hosts)
+        cpu_set_t allowed, one; CPU_ZERO(&allowed); CPU_ZERO(&one);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+            int want = atoi(pin), pick = -1, seen = 0;
+            for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) { if (seen == want) pick = c; ++seen; }
+            if (pick < 0) for (int c = CPU_SETSIZE - 1; c >= 0; --c) if (CPU_ISSET(c, &allowed)) { pick = c; break; }
+            if (pick >= 0) { CPU_SET(pick, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); }
+        }
+    }
     for (;;) {
         lvk_vio_pipe::Job job;
         const double t0 = now_us();

@@ -182,11 +182,13 @@ __device__ __forceinline__ lvk_pt2f apply_h(const HMat& H, lvk_pt2f p)
 #define ST_REV   2
 #define ST_ORB   3
 
-// forward LK from the previous pyramid, seeded by the gyro homography; in-image test (:553-578)
+// forward LK (prev -> curr, seeded with the gyro-predicted point, :558-590 / :830-860) then reverse LK (curr -> prev, seeded with
+// the original point; in-image and <= 1 px tests, :616-642) of a point in ONE launch: the reverse pass needs nothing but this
+// point's forward result, and a launch less is one inter-kernel barrier less on the frame's dependent chain.
 template <int WIN>
-__global__ void __launch_bounds__(64) k_fe_lk_fwd(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                 HMat H, int width, int height, int max_count, double epsilon,
-                                                 lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev)
+__global__ void __launch_bounds__(64) k_fe_lk_both(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                  HMat H, int width, int height, int max_count, double epsilon,
+                                                  lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev)
 {
     const int p = blockIdx.x;
     if (p >= *n_ptr) return;
@@ -194,40 +196,27 @@ __global__ void __launch_bounds__(64) k_fe_lk_fwd(PyrView prev, PyrView next, co
     const lvk_pt2f pp = src_pts[p];
     lvk_pt2f np = apply_h(H, pp);
     int st = 1;
-    const int its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
+    int its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
     if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
-    if ((threadIdx.x & 63) == 0) {
-        w_curr[p] = np; w_status[p] = st ? ST_ALIVE : ST_FWD;
-        atomicAdd(&dev->lk_point_levels, (unsigned long long)n_levels);
-        atomicAdd(&dev->lk_iterations, (unsigned long long)its);
-    }
-}
-
-// reverse LK (curr -> prev) seeded with the original point; in-image and <= 1 px tests (:616-642)
-template <int WIN>
-__global__ void __launch_bounds__(64) k_fe_lk_rev(PyrView curr, PyrView prevp, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                 int width, int height, int max_count, double epsilon,
-                                                 const lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev)
-{
-    const int p = blockIdx.x;
-    if (p >= *n_ptr) return;
-    if (w_status[p] != ST_ALIVE) return;
-    const int n_levels = curr.n_levels < prevp.n_levels ? curr.n_levels : prevp.n_levels;
-    const lvk_pt2f orig = src_pts[p];
-    lvk_pt2f back = orig;
-    int st = 1;
-    const int its = lk_point<WIN>(curr, prevp, n_levels, w_curr[p], back, st, max_count, epsilon, nullptr);
+    int code = st ? ST_ALIVE : ST_FWD, passes = 1;
     if (st) {
-        if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) st = 0;
-        else {
-            float dx = back.x - orig.x, dy = back.y - orig.y;
-            float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
-            if (dis > 1) st = 0;
+        lvk_pt2f back = pp;
+        int sr = 1;
+        its += lk_point<WIN>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr);
+        passes = 2;
+        if (sr) {
+            if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
+            else {
+                float dx = back.x - pp.x, dy = back.y - pp.y;
+                float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
+                if (dis > 1) sr = 0;
+            }
         }
+        if (!sr) code = ST_REV;
     }
     if ((threadIdx.x & 63) == 0) {
-        if (!st) w_status[p] = ST_REV;
-        atomicAdd(&dev->lk_point_levels, (unsigned long long)n_levels);
+        w_curr[p] = np; w_status[p] = (uint8_t)code;
+        atomicAdd(&dev->lk_point_levels, (unsigned long long)(passes * n_levels));
         atomicAdd(&dev->lk_iterations, (unsigned long long)its);
     }
 }
@@ -478,9 +467,7 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
 {
     const int W = fe->cfg.width, Hh = fe->cfg.height;
     { ProfScope ps(fe, 2, s);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_fwd<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
-    { ProfScope ps(fe, 3, s);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_rev<WIN>), dim3(grid), dim3(64), 0, s, cv, pv, src_pts, n_ptr, W, Hh, max_count, epsilon, (const lvk_pt2f*)w_curr, w_status, fe->dev); }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
     hipStreamWaitEvent(s, fe->ev_orb, 0);                         // the ORB planes of this frame may come from the side stream
     ProfScope ps(fe, 4, s);
     hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
@@ -821,7 +808,7 @@ lvk_status lvk_frontend_profile_read(lvk_frontend* fe, double ms_sum[LVK_FE_STAG
 }
 const char* lvk_frontend_stage_name(int stage)
 {
-    static const char* names[LVK_FE_STAGES] = {"pyramid_clahe", "orb_prepare", "lk_fwd", "lk_rev", "orb_gate", "ransac_commit", "min_eigen", "gftt_select", "feature_msg"};
+    static const char* names[LVK_FE_STAGES] = {"pyramid_clahe", "orb_prepare", "lk_fwd_rev", "(unused)", "orb_gate", "ransac_commit", "min_eigen", "gftt_select", "feature_msg"};
     return stage >= 0 && stage < LVK_FE_STAGES ? names[stage] : "?";
 }
 
