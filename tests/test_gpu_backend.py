@@ -241,3 +241,58 @@ def test_backend_sequence_parity_imu_intrinsics_calibration(gpu_ctx):
     assert np.abs(xg - xo).max() < 1e-5 * max(np.abs(xo).max(), 1.0)
     gpu.close()
     print("calibration parity: updates", n_upd, "max rel state", wx, "max rel P", wP)
+
+
+def test_sharded_update_equals_unsharded_on_device(gpu_ctx):
+    """SURVEY 8e on ONE GPU: the per-rank work of the sharded MSCKF update (each "rank" builds and gates the rows of a contiguous
+    feature range with lvk_ekf_gate_and_stack, reduces them to its packed n x n triangle with lvk_ekf_compress_qr) followed by
+    the rank-ordered stack -> QR -> lvk_ekf_update gives the update of the unsharded rows.  The all-gather of the packed
+    triangles between the two halves is exercised by tests/test_sharding_gloo.py; here the exchange is a concatenation."""
+    from larvio_amd import larvio as lv
+    from larvio_amd import sharding as sh
+    from tests.test_oracle_backend import _scene
+    n_clones = 14; n = 22 + 6 * n_clones; N = n + 6                       # six in-state feature columns the MSCKF rows do not touch
+    rng = np.random.default_rng(5)
+    Bm = rng.normal(0, 1, (N, N)); P = Bm @ Bm.T * 2e-6 + np.eye(N) * 1e-7
+    sigma2 = 0.008 ** 2
+    clones = None; feats = []; ranks_all = []; obs_all = []; vel_all = []
+    for k in range(60):                                                   # 60 features x ~15 rows: taller than wide (900 > 112)
+        c, ranks, obs, vel, p_w, from_q = _scene(100 + k, M=int(rng.integers(6, 12)), n_clones=n_clones)
+        if clones is None:
+            clones = c
+        p_w = clones[0]["p_cam"] + from_q(clones[0]["q_cam"]) @ np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1, 1), rng.uniform(3, 7)])
+        for j, r in enumerate(ranks):
+            pc = from_q(clones[r]["q_cam"]).T @ (p_w - clones[r]["p_cam"])
+            obs[j] = pc[:2] / pc[2] + rng.normal(0, 0.0008, 2)
+        feats.append((p_w, len(ranks), len(ranks_all)))
+        ranks_all += list(ranks); obs_all += list(obs); vel_all += list(vel)
+    obs_all = np.array(obs_all); vel_all = np.array(vel_all)
+    # unsharded: all accepted rows -> (compress) -> update
+    H, r, gamma, acc = lv.gate_and_stack(gpu_ctx, clones, feats, ranks_all, obs_all, vel_all, P, sigma2)
+    assert acc.sum() >= 40 and H.shape[0] > N
+    Hc, rc = lv.compress_qr(gpu_ctx, H, r)
+    dx_ref, P_ref = lv.ekf_update(gpu_ctx, P, Hc, rc, sigma2)
+    # sharded over 2 and over 4 "ranks"
+    for world in (2, 4):
+        blocks = []
+        for lo, hi in sh.shard_ranges([2 * f[1] - 3 for f in feats], world):
+            Hs, rs, _, _ = lv.gate_and_stack(gpu_ctx, clones, feats[lo:hi], ranks_all, obs_all, vel_all, P, sigma2)
+            Rs, qs = lv.compress_qr(gpu_ctx, Hs, rs)                       # rank-local TSQR: <= N rows
+            Rg, qg = sh.unpack_upper(sh.pack_upper(Rs, qs), N)             # the wire format (packed upper triangle + rhs)
+            blocks.append((Rg, qg))
+        Hst = np.vstack([b[0] for b in blocks]); rst = np.concatenate([b[1] for b in blocks])
+        Hf, rf = lv.compress_qr(gpu_ctx, Hst, rst)
+        dx, Pn = lv.ekf_update(gpu_ctx, P, Hf, rf, sigma2)
+        assert _rel(dx, dx_ref) < 1e-8 and _rel(Pn, P_ref) < 1e-9, (world, _rel(dx, dx_ref), _rel(Pn, P_ref))
+
+
+def test_backend_accepts_empty_feature_messages(gpu_ctx):
+    """messages with zero features between normal ones (the ABI allows them): pure propagation + augmentation + pruning"""
+    from larvio_amd import synthetic as S
+    msgs, imu_all, seq = _messages(40, 60)
+    import numpy as _np
+    from oracle import lvo
+    thin = [(ts, m if (i % 3) else _np.zeros(0, lvo.OBS)) for i, (ts, m) in enumerate(msgs)]
+    cfg = S.backend_config(sw_size=12, if_zupt_valid=0)
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, thin, imu_all, seq, cfg)
+    assert n_upd >= 25
