@@ -20,6 +20,7 @@
 #include <float.h>
 #include <sched.h>
 #include <pthread.h>
+#include <functional>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -111,6 +112,7 @@ struct lvk_ekf {
     // pinned host arenas
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
     char* d_up = nullptr;                               // device mirror of the upload arena: ONE H2D copy per sync point
+    int defer = 0; std::vector<std::function<lvk_status()>> deferred;   // launches waiting for a shared flush (begin_defer/end_defer)
     CamPose* dv_cams = nullptr; CloneDev* dv_clones = nullptr;
     char* h_down = nullptr; size_t down_cap = 0;
     // fired as soon as the number of IMU samples this call erases is final (before any GPU work): lets a pipelined driver
@@ -165,6 +167,23 @@ static lvk_status flush_uploads(lvk_ekf* e)
     }
     return LVK_OK;
 }
+// A launch that reads staged data.  Normally: flush what is staged, launch.  Between begin_defer and end_defer the launches are held
+// back so that several of them share ONE host-to-device copy (each copy is ~4 us on the filter's dependent chain plus its barrier).
+static lvk_status run_or_defer(lvk_ekf* e, std::function<lvk_status()> fn)
+{
+    if (e->defer > 0) { e->deferred.push_back(std::move(fn)); return LVK_OK; }
+    lvk_status st = flush_uploads(e);
+    return st == LVK_OK ? fn() : st;
+}
+static void begin_defer(lvk_ekf* e) { e->defer += 1; }
+static lvk_status end_defer(lvk_ekf* e)
+{
+    if (--e->defer > 0) return LVK_OK;
+    lvk_status st = flush_uploads(e);
+    for (auto& fn : e->deferred) if (st == LVK_OK) st = fn();
+    e->deferred.clear();
+    return st;
+}
 static lvk_status d2h_sync(lvk_ekf* e, void* dst, const void* src, size_t bytes)
 {
     if (bytes) EKF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->ctx->stream));
@@ -177,11 +196,11 @@ static lvk_status cov_gather(lvk_ekf* e, const std::vector<int>& idx)
     int* h = up_alloc<int>(e, idx.size());
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, idx.data(), sizeof(int) * idx.size());
-    lvk_status st = flush_uploads(e);
+    double* src = e->dP[e->cur]; double* dst = e->dP[e->cur ^ 1];
+    const int* d_idx = dev(e, h); const int n = (int)idx.size();
+    lvk_status st = run_or_defer(e, [=]() { return lvk_cov_gather(e->ctx, src, e->ld, dst, e->ld, d_idx, n); });
     if (st != LVK_OK) return st;
-    st = lvk_cov_gather(e->ctx, e->dP[e->cur], e->ld, e->dP[e->cur ^ 1], e->ld, dev(e, h), (int)idx.size());
-    if (st != LVK_OK) return st;
-    e->cur ^= 1; e->N = (int)idx.size();
+    e->cur ^= 1; e->N = n;
     return LVK_OK;
 }
 static lvk_status cov_delete(lvk_ekf* e, int start, int len)
@@ -433,10 +452,9 @@ static lvk_status apply_propagation(lvk_ekf* e)
     double* h = up_alloc<double>(e, 2 * LEG * LEG);
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, e->Phi_tot, sizeof(double) * LEG * LEG); memcpy(h + LEG * LEG, e->Q_tot, sizeof(double) * LEG * LEG);
-    lvk_status st = flush_uploads(e);
-    if (st != LVK_OK) return st;
     e->have_prop = false;
-    return lvk_cov_propagate(e->ctx, e->dP[e->cur], e->ld, e->N, LEG, dev(e, h));
+    double* P = e->dP[e->cur]; const int N = e->N, L = LEG; const double* d_h = dev(e, h);
+    return run_or_defer(e, [=]() { return lvk_cov_propagate(e->ctx, P, e->ld, N, L, d_h); });
 }
 
 static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
@@ -677,11 +695,10 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
         hj[i] = d;
     }
     if (stage > e->staging_cap || ccols > e->ccols_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "staging buffer too small (%zu doubles needed)", stage);
-    lvk_status st = flush_uploads(e);
     FilterFlags fl; fl.leg_dim = LEG; fl.if_fej = e->if_fej ? 1 : 0; fl.estimate_td = e->cfg.estimate_td; fl.pad = 0; fl.sigma2 = e->sigma2;
-    if (st == LVK_OK) st = lvk_launch_feature_rows(e->ctx, dev(e, hj), (int)jobs.size(), max_rows, e->dv_clones, dev(e, hr), dev(e, hz), dev(e, hv), e->dP[e->cur], e->ld, fl,
-                                                   e->d_staging, e->d_ccols, e->d_fout);
-    return st;
+    const FeatJob* d_j = dev(e, hj); const int* d_r = dev(e, hr); const double* d_z = dev(e, hz); const double* d_v = dev(e, hv);
+    const int nj = (int)jobs.size(); const CloneDev* d_cl = e->dv_clones; double* P = e->dP[e->cur];
+    return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout); });
 }
 // results of the queued jobs (+ optionally n_dx doubles of d_dx in the same sync)
 static lvk_status fetch_feature_results(lvk_ekf* e, std::vector<RowJob>& jobs, double* dx = nullptr, size_t n_dx = 0)
@@ -730,9 +747,8 @@ static lvk_status stack_rows(lvk_ekf* e, const std::vector<StackRow>& map, doubl
     StackRow* h = up_alloc<StackRow>(e, map.size());
     if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h, map.data(), sizeof(StackRow) * map.size());
-    lvk_status st = flush_uploads(e);
-    if (st == LVK_OK) st = lvk_launch_stack_rows(e->ctx, e->d_fout, dev(e, h), (int)map.size(), e->d_staging, e->d_ccols, dH, e->ld, ncols, dr);
-    return st;
+    const StackRow* d_map = dev(e, h); const int n = (int)map.size();
+    return run_or_defer(e, [=]() { return lvk_launch_stack_rows(e->ctx, e->d_fout, d_map, n, e->d_staging, e->d_ccols, dH, e->ld, ncols, dr); });
 }
 // dense update with m stacked rows already in d_H/d_r: compress when too tall, update P, fetch dx
 static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int extra)
@@ -891,15 +907,17 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             // No feature enters the state in this update, so nothing on the host depends on the gate before the update is
             // launched: every candidate row gets its slot, the device zeroes the rows of rejected features, and gate results and
             // dx come back in ONE sync.
+            begin_defer(e);                             // the jobs and the stacking map go up in one copy
             st = launch_feature_rows(e, jobs);
-            if (st != LVK_OK) return st;
+            if (st != LVK_OK) { end_defer(e); return st; }
             std::vector<StackRow> map_o;
             int rows_m = 0, rows_e = 0;
             for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k); rows_m += r; }
             for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k); rows_e += 2; }
             const int m = rows_m + rows_e;
-            if (m > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
+            if (m > e->hrows) { end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
             st = stack_rows(e, map_o, e->d_H, N, e->d_r);
+            { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, m, dx, 0);
             TR(TR_RLF_UPD);
@@ -1137,14 +1155,16 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         std::vector<RowJob> jobs;
         for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
         // measurementUpdate_msckf (:1420-1602), gate decided on the device (see remove_lost_features): one sync for gate + dx
+        begin_defer(e);
         st = launch_feature_rows(e, jobs);
-        if (st != LVK_OK) return st;
+        if (st != LVK_OK) { end_defer(e); return st; }
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; int rows = 0;
         for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k); rows += r; }
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
         {
             st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
+            { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, rows, dx, 0);
             TR(TR_PR_UPD);
@@ -1420,13 +1440,14 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
     const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
     if (off + used != *n_consumed) return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "internal: IMU consumption count mismatch");
     TR(TR_IMU);
+    begin_defer(e);                                     // propagation and augmentation share one upload
     lvk_status st = apply_propagation(e);
+    if (st == LVK_OK) st = state_augmentation(e);
+    { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
     if (st != LVK_OK) return st;
     TR(TR_PROP);
     add_observations(e, feats, n_feats);
     TR(TR_ADDOBS);
-    st = state_augmentation(e);
-    if (st != LVK_OK) return st;
     TR(TR_AUG);
     if (e->cfg.if_zupt_valid) { bool z = false; st = check_zupt(e, &z); if (st != LVK_OK) return st; e->if_zupt = z; }
     TR(TR_ZUPT);
