@@ -18,6 +18,18 @@ class MonoCameraMeasurement:
         self.features = features          # structured array, dtype OBS (id,u,v,u_init,v_init,u_vel,v_vel,u_init_vel,v_init_vel)
 
 
+def make_fe_config(config):
+    """lvk_fe_config from the dict of ImageProcessor parameters (larvio_amd.synthetic.frontend_config)"""
+    c = FeConfig()
+    for k in ("width", "height", "pyramid_levels", "patch_size", "max_iteration", "track_precision",
+              "max_features_num", "min_distance", "flag_equalize", "pub_frequency", "distortion_model"):
+        setattr(c, k, config[k])
+    c.intrinsics = (C.c_double * 4)(*config["intrinsics"])
+    c.distortion = (C.c_double * 4)(*config["distortion"])
+    c.R_cam_imu = (C.c_double * 9)(*np.asarray(config["R_cam_imu"], np.float64).reshape(9))
+    return c
+
+
 class ImageProcessor:
     FIRST_IMAGE, SECOND_IMAGE, OTHER_IMAGES = 1, 2, 3
 
@@ -31,13 +43,7 @@ class ImageProcessor:
     def initialize(self):
         if self.ctx is None:
             self.ctx = Context()
-        c = FeConfig()
-        for k in ("width", "height", "pyramid_levels", "patch_size", "max_iteration", "track_precision",
-                  "max_features_num", "min_distance", "flag_equalize", "pub_frequency", "distortion_model"):
-            setattr(c, k, self.config[k])
-        c.intrinsics = (C.c_double * 4)(*self.config["intrinsics"])
-        c.distortion = (C.c_double * 4)(*self.config["distortion"])
-        c.R_cam_imu = (C.c_double * 9)(*np.asarray(self.config["R_cam_imu"], np.float64).reshape(9))
+        c = make_fe_config(self.config)
         h = C.c_void_p()
         st = lib().lvk_frontend_create(self.ctx.h, C.byref(c), C.byref(h))
         if st != 0:

@@ -2,6 +2,7 @@
 and refuses to run without a GPU (no CPU fallback)."""
 import os
 import re
+import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,3 +50,24 @@ def test_feature_obs_layout_matches_reference_message():
     from larvio_amd._lib import OBS, IMU
     assert OBS.itemsize == 72          # feature_msg.h:15-44: u64 id + 8 doubles
     assert IMU.itemsize == 56          # ImuData.hpp: t + gyro[3] + acc[3]
+
+
+def test_cpp_host_classes_compile_against_the_abi_and_fail_loudly_without_a_gpu(tmp_path):
+    """include/lvk_larvio.hpp (ImageProcessor / LarVio with the reference's method names) + examples/larvio_main.cpp build with plain
+    g++ against the C ABI; without a device the driver exits like the reference's (initialize() false => exit), it does not fall
+    back to anything"""
+    import subprocess
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    sys.path.insert(0, os.path.join(root, "examples"))
+    from make_sequence import write_sequence
+    frames = [(0.05 * i, np.full((480, 752), 100, np.uint8)) for i in range(3)]
+    seq = str(tmp_path / "s.bin")
+    write_sequence(seq, frames=frames)
+    r = subprocess.run([os.path.join(root, "examples", "larvio_main"), seq], capture_output=True, text=True)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 3 and "no usable gfx950 device" in r.stderr
+    else:
+        assert r.returncode == 0 and "state" in r.stdout

@@ -202,3 +202,42 @@ def test_driver_loop_config5_shape_1080p_many_tracks(gpu_ctx):
                                              dict(sw_size=40, max_features_in_one_grid=2, if_zupt_valid=0, max_features=2000), init_from_gt=True, min_updates=5)
     assert n_tracks > 600
     print("config-5 shape: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
+
+
+def test_cpp_driver_matches_python_driver_bit_for_bit(gpu_ctx, tmp_path):
+    """examples/larvio_main (C++ host classes of include/lvk_larvio.hpp, the loop of app/larvioMain.cpp:84-117) against the Python
+    mirror driving the same library on the same sequence file contents: identical doubles."""
+    import os, subprocess, sys
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver
+    from tests.conftest import synth_frames
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    sys.path.insert(0, os.path.join(root, "examples"))
+    from make_sequence import write_sequence
+    frames = synth_frames(40, 50)
+    path = str(tmp_path / "seq.bin")
+    meta = write_sequence(path, frames=frames, max_features=150, sw_size=15)
+    r = subprocess.run([os.path.join(root, "examples", "larvio_main"), path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = {l.split()[0]: l.split()[1:] for l in r.stdout.strip().splitlines()}
+    cpp_state = np.array([float(x) for x in lines["state"]])
+    # the same loop through the Python mirror (host images, one context)
+    fe = larvio_amd.ImageProcessor(S.frontend_config(max_features_num=150), gpu_ctx); assert fe.initialize()
+    be = larvio_amd.LarVio(S.backend_config(sw_size=15, if_zupt_valid=0), gpu_ctx); assert be.initialize()
+    imu_all = meta["imu"]
+    drv = VioDriver(fe, be, imu_all)
+    n_msgs = n_upd = 0
+    for i, (t, img) in enumerate(frames):
+        if i == meta["init_frame"]:
+            x = meta["init"]
+            be.set_state(x[0], x[1:5], x[5:8], x[8:11], x[11:14], x[14:17], x[17:20], x[20:23])
+        has, upd = drv.step(t, drv.visible_end(t), img=img)
+        n_msgs += int(has); n_upd += int(upd)
+    assert [int(lines["frames"][0]), int(lines["frames"][2]), int(lines["frames"][4]), int(lines["frames"][6])] == [len(frames), n_msgs, n_upd, be.dim]
+    s = be.state()
+    py_state = np.concatenate([[s["t"]], s["q"], s["v"], s["p"], s["bg"], s["ba"], s["R_b2c"].ravel(), s["t_c_b"], [s["td"]]])
+    assert np.array_equal(cpp_state, py_state)
+    assert n_upd >= 15
+    be.close(); fe.close()
