@@ -369,6 +369,13 @@ __device__ __forceinline__ bool gf_grid_conflict(const unsigned short (*cells)[4
     return false;
 }
 
+#ifdef LVK_GF_TIMING
+static __device__ unsigned long long g_gf_tick[32];
+#define GF_TICK(k) do { if (threadIdx.x == 0) g_gf_tick[k] = wall_clock64(); } while (0)
+extern "C" void lvk_debug_gf_ticks(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gf_tick), sizeof(unsigned long long) * 32); }
+#else
+#define GF_TICK(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* __restrict__ cands, int cap, int w, int h,
                                                      int max_corners, int cell, float md2,
                                                      const unsigned* __restrict__ scratch, lvk_pt2f* __restrict__ out, int out_cap,
@@ -382,11 +389,13 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
     __shared__ unsigned coarse[1024];                        // histogram folded to 1024 groups (8 bins each at 13 bits)
     __shared__ unsigned hist[1 << GF_HIST_BITS];
     __shared__ int sh_ns, sh_na, sh_done, sh_lo, sh_hi;
+    unsigned* scan = reinterpret_cast<unsigned*>(surv);      // the survivor buffer is idle while the next bucket is being chosen
     const int t = threadIdx.x, lane = t & 63;
     if (d_sub) {   // image_processor.cpp:1034-1036: maxCorners = max_features_num - curr_pts_.size(), skipped when 0
         max_corners -= *d_sub;
         if (max_corners <= 0) { if (t == 0) *n_out = 0; return; }
     }
+    GF_TICK(0);
     const int n = (int)min(scratch[1], (unsigned)cap);
     constexpr int GROUP = (1 << GF_HIST_BITS) / 1024;
     // strength histogram of the candidates (LDS atomics; one pass over the candidate keys)
@@ -394,19 +403,55 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
     for (int i = t; i < gw * gh; i += 1024) { cells[i][0] = cells[i][1] = cells[i][2] = cells[i][3] = 0xFFFF; }
     if (t == 0) { sh_na = 0; sh_done = 0; sh_hi = 1 << GF_HIST_BITS; }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) atomicAdd(&hist[(unsigned)(cands[i] >> (64 - GF_HIST_BITS))], 1u);
+    // the candidate keys were written by the previous kernel on other XCDs: 8 loads in flight per thread, not one trip per key
+    for (int i0 = t; i0 < n; i0 += 1024 * 8) {
+        unsigned long long kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 1024 * u; kv[u] = i < n ? cands[i] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + 1024 * u < n) atomicAdd(&hist[(unsigned)(kv[u] >> (64 - GF_HIST_BITS))], 1u);
+    }
     __syncthreads();
+    GF_TICK(1);
     {
         unsigned s = 0;
         for (int q = 0; q < GROUP; ++q) s += hist[t * GROUP + q];
         coarse[t] = s;
     }
     __syncthreads();
+    GF_TICK(2);
+    // first bucket: a few times the corners still wanted (the publish-frame case asks for 10-50), later buckets double
     int target = 1024;
+    if (max_corners > 0) { target = 256; while (target < 4 * max_corners && target < 1024) target <<= 1; }
     for (int bucket = 0; bucket < 4096; ++bucket) {
-        // next bucket: groups [lo, hi) walking down from the strongest; at least one group, at most ~target candidates (<= GF_SURV)
-        if (t == 0) {
+        // next bucket = whole histogram groups [lo, hi) below the current top holding >= target candidates (or all that is left):
+        // suffix sums of the 1024 group counts by a block scan, then ONE thread-parallel boundary test - a serial walk over
+        // thousands of mostly empty bins by one thread was 26 us.  (Any bucket boundaries give the same corners.)
+        bool serial_walk = (sh_hi % GROUP) != 0;           // only after a bin-granular bucket (see below)
+        if (!serial_walk) {
+            const int hg = sh_hi / GROUP;                   // groups >= hg are done
+            scan[t] = t < hg ? coarse[t] : 0u;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {            // suffix sum: scan[g] = candidates in groups [g, hg)
+                const unsigned add = t + o < 1024 ? scan[t + o] : 0u;
+                __syncthreads();
+                scan[t] += add;
+                __syncthreads();
+            }
+            if (t == 0) { sh_lo = -1; sh_ns = 0; }
+            __syncthreads();
+            const unsigned mine = scan[t], above = t + 1 < 1024 ? scan[t + 1] : 0u;
+            if (t < hg && mine >= (unsigned)target && above < (unsigned)target) sh_lo = t * GROUP;       // exactly one such group, if any
+            __syncthreads();
+            if (t == 0 && sh_lo < 0) sh_lo = scan[0] > 0 ? 0 : sh_hi;                                     // fewer than target left: all of it
+            __syncthreads();
+            serial_walk = sh_lo < sh_hi && scan[sh_lo / GROUP] > GF_SURV;
+            __syncthreads();
+        }
+        if (serial_walk && t == 0) {
+            // the group-aligned bucket would overflow the survivor buffer (pathological strength distribution): bin-by-bin walk
             int hi = sh_hi, lo = hi; unsigned cnt = 0;
+            sh_ns = 0;
             while (lo > 0) {
                 if ((lo & (GROUP - 1)) == 0 && coarse[lo / GROUP - 1] == 0) { lo -= GROUP; continue; }     // empty group: skip
                 const unsigned c = hist[lo - 1];
@@ -414,47 +459,91 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                 cnt += c; --lo;
                 if (cnt >= (unsigned)target) break;
             }
-            sh_lo = lo; sh_ns = 0;
-            if (cnt > GF_SURV) sh_done = 2;                 // one histogram group alone exceeds the survivor buffer (pathological)
+            sh_lo = lo;
+            if (cnt > GF_SURV) sh_done = 2;                 // one histogram bin alone exceeds the survivor buffer
         }
         __syncthreads();
+        if (bucket == 0) GF_TICK(3);
         const int lo = sh_lo, hi = sh_hi;
         if (sh_done == 2) break;
         if (hi == 0 || lo == hi) break;
         const unsigned klo = (unsigned)lo << (32 - GF_HIST_BITS), khi_excl = hi >= (1 << GF_HIST_BITS) ? 0xFFFFFFFFu : ((unsigned)hi << (32 - GF_HIST_BITS));
-        for (int i = t; i < n; i += 1024) {
-            const unsigned long long k = cands[i];
-            const unsigned sv = (unsigned)(k >> 32);
-            if (sv < klo || (hi < (1 << GF_HIST_BITS) && sv >= khi_excl)) continue;
-            const unsigned idx = (unsigned)(k & 0xFFFFFFFFull);
-            const int y = idx / w, x = idx - y * w;
-            if (gf_grid_conflict(cells, acc, gw, gh, cell, md2, x, y)) continue;
-            const int slot = atomicAdd(&sh_ns, 1);
-            if (slot < GF_SURV) surv[slot] = k;
+        for (int i0 = t; i0 < n; i0 += 1024 * 8) {
+            unsigned long long kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 1024 * u; kv[u] = i < n ? cands[i] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long k = kv[u];
+                const unsigned sv = (unsigned)(k >> 32);
+                const bool keep = i0 + 1024 * u < n && !(sv < klo || (hi < (1 << GF_HIST_BITS) && sv >= khi_excl));
+                // one LDS atomic per wavefront (a single-address atomic per survivor serialised: ~1000 x 16 ns)
+                const unsigned long long mk = __ballot(keep);
+                if (mk) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&sh_ns, __popcll(mk));
+                    base = __shfl(base, 0);
+                    if (keep) { const int slot = base + __popcll(mk & ((1ull << lane) - 1ull)); if (slot < GF_SURV) surv[slot] = k; }
+                }
+            }
         }
         __syncthreads();
+        if (bucket == 0) GF_TICK(4);
         const int ns = min(sh_ns, GF_SURV);
-        int np2 = 1; while (np2 < ns) np2 <<= 1;
-        for (int i = ns + t; i < np2; i += 1024) surv[i] = 0ull;
-        __syncthreads();
-        for (int k = 2; k <= np2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = t; i < np2; i += 1024) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const unsigned long long a = surv[i], b = surv[l];
-                        const bool desc = (i & k) == 0;
-                        if (desc ? a < b : a > b) { surv[i] = b; surv[l] = a; }
-                    }
-                }
-                __syncthreads();
+        // candidates of this bucket that an already accepted corner rules out are dropped BEFORE the sort (key 0 sorts last and ends
+        // the greedy pass); one candidate per thread, so the grid walk is paid once, not once per diverged lane group.  The grid
+        // is empty in the first bucket.
+        if (sh_na > 0) {
+            for (int i = t; i < ns; i += 1024) {
+                const unsigned idx = (unsigned)(surv[i] & 0xFFFFFFFFull);
+                const int y = idx / w, x = idx - y * w;
+                if (gf_grid_conflict(cells, acc, gw, gh, cell, md2, x, y)) surv[i] = 0ull;
             }
+            __syncthreads();
+        }
+        if (ns <= 512) {
+            // rank sort, two threads per key: rank = number of larger keys (keys are unique: the pixel index is in the low word)
+            unsigned* rank = reinterpret_cast<unsigned*>(surv + 1024);
+            unsigned long long* sorted = surv + 2048;
+            if (t < 512) rank[t] = 0u;
+            __syncthreads();
+            const int e = t & 511, half = t >> 9;
+            if (e < ns) {
+                const unsigned long long mine = surv[e];
+                const int j0 = half * 256, j1 = min(ns, j0 + 256);
+                unsigned c = 0;
+                for (int j = j0; j < j1; ++j) c += surv[j] > mine;
+                if (c) atomicAdd(&rank[e], c);
+            }
+            __syncthreads();
+            if (t < ns) sorted[rank[t]] = surv[t];
+            __syncthreads();
+            if (t < ns) surv[t] = sorted[t];
+            __syncthreads();
+        } else {
+            int np2 = 1; while (np2 < ns) np2 <<= 1;
+            for (int i = ns + t; i < np2; i += 1024) surv[i] = 0ull;
+            __syncthreads();
+            for (int k = 2; k <= np2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = t; i < np2; i += 1024) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const unsigned long long a = surv[i], b = surv[l];
+                            const bool desc = (i & k) == 0;
+                            if (desc ? a < b : a > b) { surv[i] = b; surv[l] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        if (bucket == 0) GF_TICK(5);
         if (t < 64) {
             int na = sh_na;
             bool done = false;
             for (int sb = 0; sb < ns && !done; sb += 64) {
                 const int si = sb + lane;
-                bool g = si < ns;
+                bool g = si < ns && surv[si] != 0ull;      // 0 = ruled out before the sort
                 int sx = 0, sy = 0;
                 if (g) {
                     const unsigned idx = (unsigned)(surv[si] & 0xFFFFFFFFull);
@@ -485,9 +574,11 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
             if (lane == 0) { sh_na = na; if (done) sh_done = 1; sh_hi = lo; }
         }
         __syncthreads();
+        if (bucket == 0) GF_TICK(6);
         if (sh_done) break;
         if (target < GF_SURV) target <<= 1;
     }
+    GF_TICK(7);
     if (t == 0) *n_out = sh_na < out_cap ? sh_na : out_cap;
 }
 
