@@ -138,7 +138,8 @@ template <bool SMALL>
 __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __restrict__ jobs, int n_jobs, const CloneDev* __restrict__ clones,
                                                             const int* __restrict__ obs_rank, const double* __restrict__ obs_z, const double* __restrict__ obs_zv,
                                                             const double* __restrict__ P, int ldp, FilterFlags fl,
-                                                            double* __restrict__ staging, int* __restrict__ ccols, FeatResult* __restrict__ out)
+                                                            double* __restrict__ staging, int* __restrict__ ccols, FeatResult* __restrict__ out,
+                                                            FeatResult* __restrict__ out_host /* optional mirror in device-mapped host memory */)
 {
     extern __shared__ double sh[];
     const int jb = blockIdx.x;
@@ -333,6 +334,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2;
         o.accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;
         out[jb] = o;
+        if (out_host) out_host[jb] = o;
     }
 }
 
@@ -366,7 +368,7 @@ lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_
 
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging,
-                                   int* d_ccols, FeatResult* d_out)
+                                   int* d_ccols, FeatResult* d_out, FeatResult* d_out_host)
 {
     if (n_jobs <= 0) return LVK_OK;
     const size_t base = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
@@ -376,12 +378,12 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
     if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
     if (small) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<true>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host);
     } else {
         static size_t attr_set = 0;
         if (attr_set < shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_feature_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<false>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host);
     }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -482,7 +484,7 @@ extern "C" lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* 
     double* d_staging = (double*)d_st; int* d_ccols = (int*)(d_st + ((sizeof(double) * stage + 63) & ~(size_t)63));
     FeatResult* d_fout = (FeatResult*)(d_out + o_fo);
     lvk_status st = lvk_launch_feature_rows(ctx, (const FeatJob*)(d_in + o_job), n_feats, max_rows, (const CloneDev*)(d_in + o_cl), (const int*)(d_in + o_rk),
-                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout);
+                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr);
     if (st != LVK_OK) return st;
     std::vector<FeatResult> res(n_feats);
     LVK_HIP(ctx, hipMemcpyAsync(res.data(), d_fout, sizeof(FeatResult) * n_feats, hipMemcpyDeviceToHost, ctx->stream));

@@ -18,7 +18,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // D: col = l&15, row = (l>>4) + 4*reg  (f64 has its own C/D map, cdna_hip_programming.md §3).
 // Two optional riders save launches on the update's dependent chain: (xin, xin_col) copies a vector into column xin_col of C
 // ([HP | r] in one launch); (xout, xout_col) diverts output column xout_col to a vector, unscaled (W^T [W | w] -> P update and dx).
-struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; };
+struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; double* xout_host = nullptr; };   // xout_host: mirror of xout in device-mapped host memory
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
                                               double* __restrict__ C, int ldc, double alpha, double beta, double diag_add, GemmRider rd)
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + kk + 4 * r, col = col0 + i;
         if (row < M && col < N) {
-            if (rd.xout && col == rd.xout_col) { rd.xout[row] = acc[r]; continue; }
+            if (rd.xout && col == rd.xout_col) { rd.xout[row] = acc[r]; if (rd.xout_host) rd.xout_host[row] = acc[r]; continue; }
             double v = alpha * acc[r];
             if (beta != 0.) v += beta * C[(size_t)row * ldc + col];
             if (row == col) v += diag_add;
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
 
 template <bool TA, bool TB>
 static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
-                         double alpha, double beta, double diag_add, GemmRider rd = GemmRider{nullptr, 0, nullptr, 0})
+                         double alpha, double beta, double diag_add, GemmRider rd = GemmRider{nullptr, 0, nullptr, 0, nullptr})
 {
     if (M <= 0 || N <= 0) return;
     dim3 grid((N + 31) / 32, (M + 31) / 32);
@@ -588,7 +588,7 @@ static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double*
 }
 
 // ------------------------------------------------------------------------- host drivers (internal + C ABI)
-struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; };   // ev_*: optional bracket around the H P GEMM
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; double* dx_host = nullptr; };   // ev_*: optional bracket around the H P GEMM; dx_host: host-mapped mirror of dx
 
 // dx (device, n) and P updated in place.  B: m x (n+1) workspace, S: m x m workspace.
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2,
@@ -597,12 +597,12 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
     if (m <= 0) { LVK_HIP(ctx, hipMemsetAsync(dx, 0, sizeof(double) * (size_t)n, ctx->stream)); return LVK_OK; }
     hipStream_t s = ctx->stream;
     if (ws.ev_a) hipEventRecord(ws.ev_a, s);
-    launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0, GemmRider{r, n, nullptr, 0});   // [HP | r]
+    launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0, GemmRider{r, n, nullptr, 0, nullptr});   // [HP | r]
     if (ws.ev_b) hipEventRecord(ws.ev_b, s);
     launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
     launch_chol_solve(s, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info);                                    // S = L L^T ; W = L^-1 [HP | r]
     // W^T [W | w]: columns 0..n-1 update P (P -= W^T W), column n is dx = W^T w
-    launch_dgemm<true, false>(s, n, n + 1, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0, GemmRider{nullptr, 0, dx, n});
+    launch_dgemm<true, false>(s, n, n + 1, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0, GemmRider{nullptr, 0, dx, n, ws.dx_host});
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

@@ -361,11 +361,11 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int c
 
 // getFeatureMsg (:1076-1128): undistort to normalised coordinates, finite-difference velocities
 __global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams cam, double dt_1, double dt_2, int prev_is_last,
-                         lvk_feature_obs* __restrict__ out, FeDev* __restrict__ dev)
-{
+                         lvk_feature_obs* __restrict__ out, FeDev* __restrict__ dev, int* __restrict__ n_host)
+{   // `out` and `n_host` are device-mapped pinned host memory: the message needs no copy command, only the stream sync
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *n_ptr;
-    if (i == 0) dev->n_msg = n;
+    if (i == 0) { dev->n_msg = n; *n_host = n; }
     if (i >= n) return;
     const double unit[4] = {1, 1, 0, 0};
     const lvk_pt2f uc = undistort_point(ts.pts[i], cam, unit);
@@ -407,7 +407,8 @@ struct lvk_frontend {
     uint8_t *w_status, *wn_status;
     unsigned long long* wn_desc;
     float* eig; uint8_t* mask; unsigned* gf_scratch; unsigned long long* gf_cands; int gf_cand_cap;
-    lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;     // device + pinned host
+    lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;     // the message buffer: pinned host memory (h_msg) and its device-mapped view (d_msg)
+    int* h_nmsg; int* d_nmsg;                            // its length, same arrangement
     FeDev* dev; FeDev* h_dev;                            // device + pinned host mirror
     CamParams cam;
     // Side stream side[0] ("new points"): goodFeaturesToTrack after a publish, then the next frame's ORB planes and the LK /
@@ -525,9 +526,10 @@ void lvk_frontend_destroy(lvk_frontend* fe)
         set_free(fe->set[i]);
     }
     void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
-                    fe->gf_scratch, fe->gf_cands, fe->d_msg, fe->dev};
+                    fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (fe->h_msg) hipHostFree(fe->h_msg);
+    if (fe->h_nmsg) hipHostFree(fe->h_nmsg);
     if (fe->h_dev) hipHostFree(fe->h_dev);
     delete fe;
 }
@@ -555,9 +557,14 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     size_t cand_alloc = 1; while (cand_alloc < (size_t)fe->gf_cand_cap) cand_alloc <<= 1;
     ok = ok && dalloc(&fe->d_img, (size_t)w * h) && dalloc(&fe->w_curr, cap) && dalloc(&fe->wn_curr, cap) && dalloc(&fe->new_pts, cap) &&
          dalloc(&fe->w_status, cap) && dalloc(&fe->wn_status, cap) && dalloc(&fe->wn_desc, (size_t)cap * 4) && dalloc(&fe->eig, (size_t)w * h) &&
-         dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4 + 8192) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->d_msg, cap) && dalloc(&fe->dev, 1);
+         dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4 + 8192) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->dev, 1);
     ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap) == hipSuccess &&
-         hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
+         hipHostMalloc((void**)&fe->h_nmsg, 64) == hipSuccess && hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
+    if (ok) {
+        void *dm = nullptr, *dn = nullptr;
+        ok = hipHostGetDevicePointer(&dm, fe->h_msg, 0) == hipSuccess && hipHostGetDevicePointer(&dn, fe->h_nmsg, 0) == hipSuccess && dm && dn;
+        fe->d_msg = (lvk_feature_obs*)dm; fe->d_nmsg = (int*)dn;
+    }
     for (int i = 0; i < 1 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
     hipEvent_t* evs[] = {&fe->ev_l0, &fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_end, &fe->ev_tail};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
@@ -612,14 +619,12 @@ static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_o
     const int prev_is_last = fe->prev_img_time == fe->last_pub_time;
     const double dt_2 = prev_is_last ? dt_1 : fe->prev_img_time - fe->last_pub_time;
     hipLaunchKernelGGL(k_fe_msg, dim3((fe->cap + 63) / 64), dim3(64), 0, ctx->stream, fe->set[dst], (const int*)&fe->dev->n_tracks[dst], fe->cam, dt_1, dt_2,
-                       prev_is_last, fe->d_msg, fe->dev);
-    LVK_LAUNCH_CHECK(ctx);
-    LVK_HIP(ctx, hipMemcpyAsync(fe->h_msg, fe->d_msg, sizeof(lvk_feature_obs) * (size_t)fe->cap, hipMemcpyDeviceToHost, ctx->stream)); }
-    LVK_HIP(ctx, hipMemcpyAsync(fe->h_dev, fe->dev, sizeof(FeDev), hipMemcpyDeviceToHost, ctx->stream));
+                       prev_is_last, fe->d_msg, fe->dev, fe->d_nmsg);
+    LVK_LAUNCH_CHECK(ctx); }
     st = fe_detect_new(fe, dst);                         // queued on side[0] before the host blocks on the message
     if (st != LVK_OK) return st;
     LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int n = fe->h_dev->n_msg;
+    int n = *fe->h_nmsg;
     if (n > cap) n = cap;
     if (h_out && n > 0) memcpy(h_out, fe->h_msg, sizeof(lvk_feature_obs) * (size_t)n);
     *n_out = n;
