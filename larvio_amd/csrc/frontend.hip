@@ -417,7 +417,10 @@ struct lvk_frontend {
     // third front-end stream slowed the filter's stream by 30%).
     lvk_context* side[1];
     bool image_done; double image_done_ts;       // lvk_frontend_begin already queued this frame's image stage
-    hipEvent_t ev_l0, ev_pyr, ev_orb, ev_new, ev_commit, ev_end, ev_tail;
+    // fork/join events.  Each record or wait is a barrier packet on its stream (~5 us on the frame's chain), so there are as few as
+    // the data flow allows: ev_pyr (pyramid of this frame ready; being recorded on the main stream it also orders everything the
+    // previous frame left there), ev_orb, ev_new (side stream -> main), ev_commit (main -> side), ev_tail (bootstrap only)
+    hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
     // HIP-event profiling of stages
     unsigned prof_mask;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -517,7 +520,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     prof_collect(fe);
     hipStreamSynchronize(fe->ctx->stream);
     for (int i = 0; i < 1; ++i) if (fe->side[i]) { hipStreamSynchronize(fe->side[i]->stream); lvk_context_destroy(fe->side[i]); }
-    hipEvent_t evs[] = {fe->ev_l0, fe->ev_pyr, fe->ev_orb, fe->ev_new, fe->ev_commit, fe->ev_end, fe->ev_tail};
+    hipEvent_t evs[] = {fe->ev_pyr, fe->ev_orb, fe->ev_new, fe->ev_commit, fe->ev_tail};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (hipEvent_t e : fe->ev_free) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
@@ -566,12 +569,10 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
         fe->d_msg = (lvk_feature_obs*)dm; fe->d_nmsg = (int*)dn;
     }
     for (int i = 0; i < 1 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
-    hipEvent_t* evs[] = {&fe->ev_l0, &fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_end, &fe->ev_tail};
+    hipEvent_t* evs[] = {&fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_tail};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { lvk_frontend_destroy(fe); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_frontend_create: allocation failed"); }
-    for (int i = 0; i < 2; ++i) fe->pyr[i]->ev_level0 = fe->ev_l0;
     hipMemsetAsync(fe->dev, 0, sizeof(FeDev), ctx->stream);
-    hipEventRecord(fe->ev_end, ctx->stream);
     memset(&fe->cam, 0, sizeof fe->cam);
     for (int i = 0; i < 4; ++i) { fe->cam.intr[i] = cfg->intrinsics[i]; fe->cam.dist[i] = cfg->distortion[i]; }
     fe->cam.model = cfg->distortion_model; fe->cam.width = w; fe->cam.height = h;
@@ -652,7 +653,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const uint8_t* img, int strid
       st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride); }
     if (st != LVK_OK) return st;
     hipEventRecord(fe->ev_pyr, S1);
-    if (S3 != S1) { hipStreamWaitEvent(S3, fe->ev_end, 0); hipStreamWaitEvent(S3, fe->ev_l0, 0); }
+    if (S3 != S1) hipStreamWaitEvent(S3, fe->ev_pyr, 0);
     { ProfScope ps(fe, 1, S3); st = lvk_orb_prepare(orb_cx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
     if (st != LVK_OK) return orb_cx == ctx ? st : lvk_set_error(ctx, st, "%s", orb_cx->err);
     hipEventRecord(fe->ev_orb, S3);
@@ -719,7 +720,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
                 curr_valid = true;
                 hipEventRecord(fe->ev_commit, S1);
                 if (ts - fe->last_pub_time >= pub_gate) {
-                    hipStreamWaitEvent(S2, fe->ev_l0, 0);
+                    hipStreamWaitEvent(S2, fe->ev_pyr, 0);
                     st = fe_publish(fe, dst, ts, h_out, cap, n_out);
                     if (st != LVK_OK) return st;
                     *has_msg = 1;
@@ -729,8 +730,8 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
         } else {
             // trackFeatures (:540-811) on the main stream; trackNewFeatures' LK and descriptor gate (:813-931) on side[0], queued
             // behind the detection that produced the points; its RANSAC + append (:932-1001) joins the main stream.
-            hipStreamWaitEvent(S2, fe->ev_end, 0);             // everything the previous frame left on the main stream
-            hipStreamWaitEvent(S2, fe->ev_pyr, 0);
+            // (the side stream already waited for ev_pyr before the ORB planes: this frame's pyramid and everything the previous
+            //  frame left on the main stream are done)
             st = track_chain(fe, S2, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
             hipEventRecord(fe->ev_new, S2);
             if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
@@ -753,7 +754,6 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride
     { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = p; p = fe->blur[0]; fe->blur[0] = fe->blur[1]; fe->blur[1] = p; }
     fe->cur = dst;
     fe->prev_img_time = ts;
-    hipEventRecord(fe->ev_end, ctx->stream);
     if (fe->pending.size() > 4096) prof_collect(fe);
     return LVK_OK;
 }
