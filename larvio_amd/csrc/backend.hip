@@ -20,6 +20,7 @@
 #include <float.h>
 #include <sched.h>
 #include <pthread.h>
+#include <atomic>
 #include <functional>
 #include <thread>
 #include <mutex>
@@ -384,25 +385,11 @@ static void cal_phi_calib(const lvk_ekf* e, double* Phi, double dt, const double
 #undef BLK
 }
 
-static void process_model(lvk_ekf* e, double time, const double* m_gyro, const double* m_acc)
-{   // larvio.cpp:520-578.  The covariance part is COMPOSED over the frame's IMU samples:
-    //   Phi_tot <- Phi Phi_tot ;  Q_tot <- Phi Q_tot Phi^T + Q     (then applied once on the device)
-    const int L = e->leg;
-    const bool calib = e->cfg.calib_imu_instrinsic != 0;
-    double f[3], w[3], w_old[3], f_old[3], acc[3], gyro[3], acc_old[3], gyro_old[3];
-    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; f_old[i] = e->m_acc_old[i] - e->s.ba[i]; }
-    if (calib) {
-        double t[3];
-        m3_v(e->Ma, f, acc); m3_v(e->As, acc, t); for (int i = 0; i < 3; ++i) w[i] = m_gyro[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w, gyro);
-        m3_v(e->Ma, f_old, acc_old); m3_v(e->As, acc_old, t); for (int i = 0; i < 3; ++i) w_old[i] = e->m_gyro_old[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w_old, gyro_old);
-    } else {
-        for (int i = 0; i < 3; ++i) { w[i] = m_gyro[i] - e->s.bg[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; acc[i] = f[i]; gyro[i] = w[i]; acc_old[i] = f_old[i]; gyro_old[i] = w_old[i]; }
-    }
-    const double dtime = time - e->s.t;
-    predict_new_state(e, dtime, gyro, acc);
-    double Phi[LEG_MAX * LEG_MAX];
-    if (calib) cal_phi_calib(e, Phi, dtime, f, w, acc, gyro, f_old, w_old, acc_old, gyro_old);
-    else cal_phi(e, Phi, dtime, w, w_old);
+// Phi_tot <- Phi Phi_tot ; Q_tot <- Phi Q_tot Phi^T + Q for one IMU sample, with the legacy dimension as a compile-time constant
+// (22, or 46 when the IMU intrinsics are calibrated) so that the short fixed-length loops unroll and vectorise.
+template <int L, bool CALIB>
+static void compose_transition(lvk_ekf* e, const double* Phi, double dtime)
+{
     double C[9]; quat_to_rot(e->s_old.q, C);
     double G[15 * 12]; memset(G, 0, sizeof G);                      // rows 15.. of G are zero
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { G[i * 12 + j] = -C[i * 3 + j]; G[(3 + i) * 12 + 3 + j] = -C[i * 3 + j]; }
@@ -410,10 +397,11 @@ static void process_model(lvk_ekf* e, double time, const double* m_gyro, const d
     // Structure of the discrete model: rows 9.. of Phi are identity rows; rows 0..8 (q, v, p) are zero outside the columns of
     // q, v, p, bg, ba (0..14) and, when calibrating, the 24 intrinsic columns (22..45).  G is zero below row 14.  Skipping the
     // exact-zero products leaves every sum identical to the dense triple loops and cuts the per-sample host work several times.
-    const int A = 9, B = 15;
-    int nzc[39]; int nnz = 0;                                       // columns where rows 0..8 of Phi may be non-zero
-    for (int k = 0; k < 15; ++k) nzc[nnz++] = k;
-    if (calib) for (int k = 22; k < 46; ++k) nzc[nnz++] = k;
+    constexpr int A = 9, B = 15, NNZ = CALIB ? 39 : 15;
+    int nzc[NNZ];                                                   // columns where rows 0..8 of Phi may be non-zero
+    for (int k = 0; k < 15; ++k) nzc[k] = k;
+    if (CALIB) for (int k = 22; k < 46; ++k) nzc[15 + k - 22] = k;
+    constexpr int nnz = NNZ;
     double PG[B * 12], Q[B * B];
     for (int i = 0; i < A; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += Phi[i * L + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
     for (int i = A; i < B; ++i) for (int j = 0; j < 12; ++j) PG[i * 12 + j] = G[i * 12 + j];
@@ -447,6 +435,27 @@ static void process_model(lvk_ekf* e, double time, const double* m_gyro, const d
         }
         for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * L + j] += Q[i * B + j];
     }
+}
+
+static void process_model(lvk_ekf* e, double time, const double* m_gyro, const double* m_acc)
+{   // larvio.cpp:520-578.  The covariance part is COMPOSED over the frame's IMU samples:
+    //   Phi_tot <- Phi Phi_tot ;  Q_tot <- Phi Q_tot Phi^T + Q     (then applied once on the device)
+    const bool calib = e->cfg.calib_imu_instrinsic != 0;
+    double f[3], w[3], w_old[3], f_old[3], acc[3], gyro[3], acc_old[3], gyro_old[3];
+    for (int i = 0; i < 3; ++i) { f[i] = m_acc[i] - e->s.ba[i]; f_old[i] = e->m_acc_old[i] - e->s.ba[i]; }
+    if (calib) {
+        double t[3];
+        m3_v(e->Ma, f, acc); m3_v(e->As, acc, t); for (int i = 0; i < 3; ++i) w[i] = m_gyro[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w, gyro);
+        m3_v(e->Ma, f_old, acc_old); m3_v(e->As, acc_old, t); for (int i = 0; i < 3; ++i) w_old[i] = e->m_gyro_old[i] - t[i] - e->s.bg[i]; m3_v(e->Tg, w_old, gyro_old);
+    } else {
+        for (int i = 0; i < 3; ++i) { w[i] = m_gyro[i] - e->s.bg[i]; w_old[i] = e->m_gyro_old[i] - e->s.bg[i]; acc[i] = f[i]; gyro[i] = w[i]; acc_old[i] = f_old[i]; gyro_old[i] = w_old[i]; }
+    }
+    const double dtime = time - e->s.t;
+    predict_new_state(e, dtime, gyro, acc);
+    double Phi[LEG_MAX * LEG_MAX];
+    if (calib) cal_phi_calib(e, Phi, dtime, f, w, acc, gyro, f_old, w_old, acc_old, gyro_old);
+    else cal_phi(e, Phi, dtime, w, w_old);
+    if (calib) compose_transition<46, true>(e, Phi, dtime); else compose_transition<22, false>(e, Phi, dtime);
     e->s.t = time; e->s_fej_now.t = time;
 }
 
@@ -1560,6 +1569,7 @@ struct lvk_vio_pipe {
     bool cur_precounted = false;                        // the running job's erase count was already applied by submit()
     std::deque<Job> q;
     std::thread worker; std::mutex mu; std::condition_variable cv_job, cv_state;
+    std::atomic<unsigned> gen{0};                       // bumped on every state change: waiters poll it WITHOUT the mutex
     int unknown_consume = 0;                            // queued or running updates whose erase count is not final yet
     int in_flight = 0;                                  // queued + running
     long n_updates = 0, n_msgs = 0;
@@ -1577,18 +1587,24 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 static void pipe_on_consumed(void* user, int n)
 {
     lvk_vio_pipe* p = (lvk_vio_pipe*)user;
-    std::lock_guard<std::mutex> lk(p->mu);
-    if (p->cur_precounted) return;
-    p->head += (size_t)n; p->unknown_consume -= 1;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (p->cur_precounted) return;
+        p->head += (size_t)n; p->unknown_consume -= 1;
+        p->gen.fetch_add(1, std::memory_order_release);
+    }
     p->cv_state.notify_all();
 }
 // Both threads hand over within tens of microseconds: poll briefly before sleeping on the condition variable.
-template <typename Pred> static void pipe_wait(std::unique_lock<std::mutex>& lk, std::condition_variable& cv, Pred pred)
+// The poll reads only the generation counter, never the mutex: a waiter that re-locks in a tight loop makes the other thread's
+// (short) critical sections queue behind it - that alone added ~30 us to every filter update.
+template <typename Pred> static void pipe_wait(lvk_vio_pipe* p, std::unique_lock<std::mutex>& lk, std::condition_variable& cv, Pred pred)
 {
-    for (int spin = 0; spin < 4000; ++spin) {
+    for (int round = 0; round < 64; ++round) {
         if (pred()) return;
+        const unsigned seen = p->gen.load(std::memory_order_acquire);
         lk.unlock();
-        for (int k = 0; k < 16; ++k) __builtin_ia32_pause();
+        for (int spin = 0; spin < 4000 && p->gen.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
         lk.lock();
     }
     cv.wait(lk, pred);
@@ -1611,7 +1627,7 @@ static void pipe_worker(lvk_vio_pipe* p)
         const double t0 = now_us();
         {
             std::unique_lock<std::mutex> lk(p->mu);
-            pipe_wait(lk, p->cv_job, [&] { return p->stop || !p->q.empty(); });
+            pipe_wait(p, lk, p->cv_job, [&] { return p->stop || !p->q.empty(); });
             if (p->q.empty()) return;
             job = std::move(p->q.front()); p->q.pop_front();
             p->cur_precounted = job.precounted;
@@ -1625,8 +1641,9 @@ static void pipe_worker(lvk_vio_pipe* p)
             p->t_idle += t1 - t0; p->t_busy += now_us() - t1; p->ev(6);
             if (st != LVK_OK && p->st == LVK_OK) p->st = st;
             p->n_updates += upd; p->in_flight -= 1;
-            p->cv_state.notify_all();
+            p->gen.fetch_add(1, std::memory_order_release);
         }
+        p->cv_state.notify_all();
     }
 }
 
@@ -1649,7 +1666,7 @@ lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** ou
 void lvk_vio_pipe_destroy(lvk_vio_pipe* p)
 {
     if (!p) return;
-    { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+    { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; p->gen.fetch_add(1, std::memory_order_release); }
     p->cv_job.notify_all();
     if (p->worker.joinable()) p->worker.join();
     if (p->logging) { if (FILE* f = fopen(getenv("LVK_PIPE_LOG"), "w")) { for (auto& e : p->log) fprintf(f, "%.1f,%d\n", e.t, e.what); fclose(f); } }
@@ -1680,7 +1697,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->ev(0);
-        pipe_wait(lk, p->cv_state, [&] { return p->unknown_consume == 0; });
+        pipe_wait(p, lk, p->cv_state, [&] { return p->unknown_consume == 0; });
         if (p->st != LVK_OK) return p->st;
         head = p->head; end = p->imu.size();
         p->ev(1);
@@ -1706,6 +1723,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
             job.precounted = true; p->ev(4);
         } else { p->unknown_consume += 1; p->ev(3); }
         p->q.push_back(std::move(job)); p->in_flight += 1; p->n_msgs += 1;
+        p->gen.fetch_add(1, std::memory_order_release);
     }
     p->cv_job.notify_one();
     return LVK_OK;
@@ -1724,7 +1742,7 @@ lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs)
 {
     if (!p) return LVK_ERR_ARG;
     std::unique_lock<std::mutex> lk(p->mu);
-    pipe_wait(lk, p->cv_state, [&] { return p->in_flight == 0; });
+    pipe_wait(p, lk, p->cv_state, [&] { return p->in_flight == 0; });
     if (n_updates) *n_updates = p->n_updates;
     if (n_msgs) *n_msgs = p->n_msgs;
     return p->st;
