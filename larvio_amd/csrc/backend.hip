@@ -82,6 +82,7 @@ struct lvk_ekf {
     ImuS s, s_old, s_fej_now, s_fej_old;
     double R_b2c[9], t_c_b[3], td = 0;
     std::vector<Clone> clones;
+    mutable std::vector<short> rank_tab; mutable long long rank_base = 0; mutable bool ranks_dirty = true;   // see clone_rank()
     std::vector<long long> feature_states;
     std::map<long long, Feature> map;                  // map_server (ascending id)
     int leg = 22;
@@ -145,7 +146,22 @@ static EkfTrace g_tr;
 #define TR(slot) g_tr.mark(slot)
 
 // ------------------------------------------------------------------------- small helpers
-static int clone_rank(const lvk_ekf* e, long long id) { for (size_t i = 0; i < e->clones.size(); ++i) if (e->clones[i].id == id) return (int)i; return -1; }
+// rank of a clone in the window by state id: direct-address table over [first id, last id] (ids only grow; the window spans a few
+// dozen of them), rebuilt lazily after the clone list changes - the linear search ran thousands of times per update
+static int clone_rank(const lvk_ekf* e, long long id)
+{
+    if (e->ranks_dirty) {
+        e->rank_tab.clear();
+        e->rank_base = e->clones.empty() ? 0 : e->clones.front().id;
+        if (!e->clones.empty()) {
+            e->rank_tab.assign((size_t)(e->clones.back().id - e->rank_base + 1), (short)-1);
+            for (size_t i = 0; i < e->clones.size(); ++i) e->rank_tab[(size_t)(e->clones[i].id - e->rank_base)] = (short)i;
+        }
+        e->ranks_dirty = false;
+    }
+    const long long k = id - e->rank_base;
+    return (k < 0 || k >= (long long)e->rank_tab.size()) ? -1 : e->rank_tab[(size_t)k];
+}
 static int fs_rank(const lvk_ekf* e, long long id) { for (size_t i = 0; i < e->feature_states.size(); ++i) if (e->feature_states[i] == id) return (int)i; return -1; }
 static void clone_refresh_cam(const lvk_ekf* e, Clone* c)
 {   // larvio.cpp:1529-1541
@@ -512,7 +528,7 @@ static lvk_status state_augmentation(lvk_ekf* e)
         for (int i = 0; i < 3; ++i) c.p_cam[i] = e->s.p[i] + t[i];
     }
     const int pose_rows = LEG + 6 * (int)e->clones.size();
-    e->clones.push_back(c);
+    e->clones.push_back(c); e->ranks_dirty = true;
     if (e->N + 6 > e->nmax) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "state dimension %d exceeds capacity %d", e->N + 6, e->nmax);
     static const int sel[6] = {0, 1, 2, 6, 7, 8};
     std::vector<int> idx; idx.reserve(e->N + 6);
@@ -1208,7 +1224,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
             for (int i = 0; i < e->N; ++i) if (!drop[i]) idx.push_back(i);
             st = cov_gather(e, idx);
             if (st != LVK_OK) return st;
-            for (int k = 0; k < nrm; ++k) { const int seq = clone_rank(e, rm[k]); if (seq >= 0) e->clones.erase(e->clones.begin() + seq); }
+            for (int k = 0; k < nrm; ++k) { const int seq = clone_rank(e, rm[k]); if (seq >= 0) { e->clones.erase(e->clones.begin() + seq); e->ranks_dirty = true; } }
         }
     }
     return LVK_OK;
