@@ -218,6 +218,8 @@ lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const doub
                              const double bg[3], const double ba[3], const double gyro_old[3], const double acc_old[3]);
 int        lvk_ekf_dim(const lvk_ekf* e);                      /* state_cov.rows() */
 int        lvk_ekf_is_initialized(const lvk_ekf* e);
+/* take_off_stamp (larvio.cpp:380): the state time at which the initializer succeeded; the state log's time origin (:446) */
+double     lvk_ekf_take_off_stamp(const lvk_ekf* e);
 /* 30 doubles: t, q[4] (x y z w), v[3], p[3], bg[3], ba[3], R_imu_cam0[9], t_cam0_imu[3], td  (getTbw/getVel, larvio.cpp:2644-2700) */
 lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* h_out30);
 /* the 24 IMU-intrinsic parameters T1 T2 T3 A1 A2 A3 M1 M2 (larvio.cpp:129-154; state columns 22..45 when calibrated) */

@@ -13,8 +13,10 @@
 #ifndef LVK_LARVIO_HPP
 #define LVK_LARVIO_HPP
 #include "lvk_c.h"
+#include "lvk_config.hpp"
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace lvk {
@@ -43,9 +45,16 @@ public:
     // the reference's constructor takes the YAML path and loadParameters() reads it (image_processor.cpp:44-113); here the caller
     // hands over the same parameters as a plain struct (field names = YAML keys)
     ImageProcessor(const lvk_fe_config& cfg, lvk_context* ctx) : cfg_(cfg), ctx_(ctx), fe_(nullptr) {}
+    // the reference's own constructor (image_processor.cpp:28-33): the configuration file is read by initialize()
+    ImageProcessor(const std::string& config_file, lvk_context* ctx) : cfg_(), config_file_(config_file), ctx_(ctx), fe_(nullptr) {}
     ~ImageProcessor() { if (fe_) lvk_frontend_destroy(fe_); }
     bool initialize()                                                                   // image_processor.cpp:116-126
     {
+        if (!config_file_.empty()) {                                                    // loadParameters (:44-113)
+            ConfigFile f; std::string err;
+            if (!f.open(config_file_)) { std::fprintf(stderr, "config_file error: %s\n", f.error().c_str()); return false; }
+            if (!load_fe_config(f, &cfg_, &err)) { std::fprintf(stderr, "config_file error: %s\n", err.c_str()); return false; }
+        }
         if (!ctx_) { std::fprintf(stderr, "ImageProcessor: no device context\n"); return false; }
         if (lvk_frontend_create(ctx_, &cfg_, &fe_) != LVK_OK) { std::fprintf(stderr, "ImageProcessor: %s\n", lvk_last_error(ctx_)); return false; }
         out_.resize((size_t)cfg_.max_features_num);
@@ -70,16 +79,25 @@ public:
     lvk_frontend* handle() const { return fe_; }
 private:
     ImageProcessor(const ImageProcessor&); ImageProcessor& operator=(const ImageProcessor&);
-    lvk_fe_config cfg_; lvk_context* ctx_; lvk_frontend* fe_;
+    lvk_fe_config cfg_; std::string config_file_; lvk_context* ctx_; lvk_frontend* fe_;
     std::vector<MonoFeatureMeasurement> out_;
 };
 
 class LarVio {
 public:
-    LarVio(const lvk_ekf_config& cfg, lvk_context* ctx) : cfg_(cfg), ctx_(ctx), ekf_(nullptr) {}
-    ~LarVio() { if (ekf_) lvk_ekf_destroy(ekf_); }
+    LarVio(const lvk_ekf_config& cfg, lvk_context* ctx) : cfg_(cfg), ctx_(ctx), ekf_(nullptr), f_state_(nullptr), f_takeoff_(nullptr), takeoff_written_(false) {}
+    // the reference's own constructor (larvio.cpp:40-44): initialize() reads the file and opens the two debug logs in output_dir
+    LarVio(const std::string& config_file, lvk_context* ctx) : cfg_(), config_file_(config_file), ctx_(ctx), ekf_(nullptr), f_state_(nullptr), f_takeoff_(nullptr), takeoff_written_(false) {}
+    ~LarVio() { if (ekf_) lvk_ekf_destroy(ekf_); if (f_state_) std::fclose(f_state_); if (f_takeoff_) std::fclose(f_takeoff_); }   // larvio.cpp:47-55
     bool initialize()                                                                   // larvio.cpp:314-360
     {
+        if (!config_file_.empty()) {                                                    // loadParameters (:58-311)
+            ConfigFile f; std::string err;
+            if (!f.open(config_file_)) { std::fprintf(stderr, "config_file error: %s\n", f.error().c_str()); return false; }
+            if (!load_ekf_config(f, &cfg_, &err)) { std::fprintf(stderr, "config_file error: %s\n", err.c_str()); return false; }
+            const std::string dir = f.str("output_dir");                               // :220, :318-319; a directory that does not exist => no logs, as with ofstream
+            if (!dir.empty()) { f_state_ = std::fopen((dir + "msckf_2_state.txt").c_str(), "w"); f_takeoff_ = std::fopen((dir + "msckf_2_takeoff.txt").c_str(), "w"); }
+        }
         if (!ctx_) { std::fprintf(stderr, "LarVio: no device context\n"); return false; }
         if (lvk_ekf_create(ctx_, &cfg_, &ekf_) != LVK_OK) { std::fprintf(stderr, "LarVio: %s\n", lvk_last_error(ctx_)); return false; }
         return true;
@@ -96,6 +114,7 @@ public:
             return false;
         }
         imu_msg_buffer.erase(imu_msg_buffer.begin(), imu_msg_buffer.begin() + used);
+        if (updated) write_logs();
         return updated != 0;
     }
     // getTbw (larvio.cpp:2644-2655): body-to-world pose as a row-major 4x4
@@ -132,7 +151,36 @@ public:
     lvk_ekf* handle() const { return ekf_; }
 private:
     LarVio(const LarVio&); LarVio& operator=(const LarVio&);
-    lvk_ekf_config cfg_; lvk_context* ctx_; lvk_ekf* ekf_;
+    // the debug logs of larvio.cpp:388 and :446-453: take-off stamp once; then per update
+    //   t-take_off  qw qx qy qz  vx vy vz  px py pz  bgx bgy bgz  bax bay baz  qbc(w x y z)  t_cam0_imu      ("%g" = the ostream default)
+    void write_logs()
+    {
+        if (!f_state_ && !f_takeoff_) return;
+        double s[30]; lvk_ekf_get_state(ekf_, s);
+        const double t0 = lvk_ekf_take_off_stamp(ekf_);
+        if (f_takeoff_ && !takeoff_written_) { std::fprintf(f_takeoff_, "%.9f\n", t0); std::fflush(f_takeoff_); takeoff_written_ = true; }
+        if (!f_state_) return;
+        double qbc[4]; rot_to_quat_wxyz(s + 17, qbc);
+        std::fprintf(f_state_, "%g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g %g\n", s[0] - t0, s[4], s[1], s[2], s[3],
+                     s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15], s[16], qbc[0], qbc[1], qbc[2], qbc[3], s[26], s[27], s[28]);
+    }
+    // Eigen::Quaterniond(Matrix3d) (larvio.cpp:436): Shepperd's branch on the trace, w >= 0 in the first branch only
+    static void rot_to_quat_wxyz(const double* R, double q[4])
+    {
+        const double t = R[0] + R[4] + R[8];
+        if (t > 0) {
+            double r = std::sqrt(t + 1.0); q[0] = 0.5 * r; r = 0.5 / r;
+            q[1] = (R[7] - R[5]) * r; q[2] = (R[2] - R[6]) * r; q[3] = (R[3] - R[1]) * r;
+        } else {
+            int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            double r = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+            q[1 + i] = 0.5 * r; r = 0.5 / r;
+            q[0] = (R[3 * k + j] - R[3 * j + k]) * r; q[1 + j] = (R[3 * j + i] + R[3 * i + j]) * r; q[1 + k] = (R[3 * k + i] + R[3 * i + k]) * r;
+        }
+    }
+    lvk_ekf_config cfg_; std::string config_file_; lvk_context* ctx_; lvk_ekf* ekf_;
+    FILE* f_state_; FILE* f_takeoff_; bool takeoff_written_;
 };
 
 }  // namespace lvk

@@ -1520,6 +1520,7 @@ int lvk_ekf_dim(const lvk_ekf* e) { return e ? e->N : 0; }
 lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* o24) { if (!e || !o24) return LVK_ERR_ARG; memcpy(o24, e->imx, sizeof e->imx); return LVK_OK; }
 lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* i24) { if (!e || !i24) return LVK_ERR_ARG; memcpy(e->imx, i24, sizeof e->imx); update_imu_mx(e); return LVK_OK; }
 int lvk_ekf_is_initialized(const lvk_ekf* e) { return e && e->is_gravity_set ? 1 : 0; }
+double lvk_ekf_take_off_stamp(const lvk_ekf* e) { return e ? e->take_off_stamp : 0.0; }
 lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* o)
 {
     if (!e || !o) return LVK_ERR_ARG;

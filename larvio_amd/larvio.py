@@ -46,6 +46,7 @@ def _L():
         L.lvk_ekf_set_state.argtypes = [vp, d, vp, vp, vp, vp, vp, vp, vp]; L.lvk_ekf_set_state.restype = i
         L.lvk_ekf_dim.argtypes = [vp]; L.lvk_ekf_dim.restype = i
         L.lvk_ekf_is_initialized.argtypes = [vp]; L.lvk_ekf_is_initialized.restype = i
+        L.lvk_ekf_take_off_stamp.argtypes = [vp]; L.lvk_ekf_take_off_stamp.restype = C.c_double
         L.lvk_ekf_get_state.argtypes = [vp, vp]; L.lvk_ekf_get_state.restype = i
         L.lvk_ekf_get_cov.argtypes = [vp, vp]; L.lvk_ekf_get_cov.restype = i
         L.lvk_ekf_get_imu_intrinsics.argtypes = [vp, vp]; L.lvk_ekf_get_imu_intrinsics.restype = i
@@ -169,6 +170,11 @@ class LarVio:
     @property
     def initialized(self):
         return bool(_L().lvk_ekf_is_initialized(self._h))
+
+    @property
+    def take_off_stamp(self):
+        """larvio.cpp:380 — state time at which the initializer succeeded"""
+        return float(_L().lvk_ekf_take_off_stamp(self._h))
 
     def state(self):
         o = np.zeros(30); self.ctx.check(_L().lvk_ekf_get_state(self._h, _p(o)))

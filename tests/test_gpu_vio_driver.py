@@ -241,3 +241,64 @@ def test_cpp_driver_matches_python_driver_bit_for_bit(gpu_ctx, tmp_path):
     assert np.array_equal(cpp_state, py_state)
     assert n_upd >= 15
     be.close(); fe.close()
+
+
+def test_cpp_dataset_driver_on_an_asl_directory(gpu_ctx, tmp_path):
+    """examples/larvio_euroc — the reference's command line (app/larvioMain.cpp:27-31): IMU csv, image csv, image directory,
+    configuration file — on the synthetic sequence written as an ASL/EuRoC directory (PNG files, CRLF csv, OpenCV-style YAML).
+    Starts at rest (static initializer).  The trajectory it logs must equal, double for double, what the Python mirror produces
+    from the same stamps and pixels; the reference's own two log files (larvio.cpp:388,446-453) must be there as well."""
+    import os, subprocess, sys
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver
+    from tests.conftest import synth_frames
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    sys.path.insert(0, os.path.join(root, "examples")); sys.path.insert(0, os.path.join(root, "tools"))
+    from make_euroc_dir import write_euroc_dir, rot_to_quat_wxyz
+    import traj_rmse
+    cam = dict(TUMVI_LIKE); cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
+    frames = synth_frames(0, 64, cam=cam)                       # the frames of the config-4 test above (cached)
+    seq = S.imu_only_sequence(cam=cam)
+    ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    fcfg = S.frontend_config(cam=cam, max_features_num=300, min_distance=15)
+    bcfg = S.backend_config(cam=cam, sw_size=12, if_zupt_valid=1)
+    out_dir = str(tmp_path / "logs") + "/"; os.makedirs(out_dir)
+    d = str(tmp_path / "seq")
+    gt = [(t, seq.traj.p_wb(t), rot_to_quat_wxyz(seq.traj.R_wb(t))) for t in np.arange(ts[0], ts[-1] + 0.0051, 0.005)]
+    t_img, t_imu = write_euroc_dir(d, frames, imu_all, fcfg, bcfg, ground_truth=gt, output_dir=out_dir)
+    tum = str(tmp_path / "traj.txt")
+    r = subprocess.run([os.path.join(root, "examples", "larvio_euroc"), d + "/mav0/imu0/data.csv", d + "/mav0/cam0/data.csv", d + "/mav0/cam0/data",
+                        d + "/config.yaml", "--tum", tum], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    print(r.stdout)
+    cpp = np.loadtxt(tum, ndmin=2)
+    # the same loop through the Python mirror, on the stamps as the readers deliver them (1e-9 * integer ns)
+    fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
+    be = larvio_amd.LarVio(dict(bcfg, max_features=300), gpu_ctx); assert be.initialize()
+    imu2 = imu_all.copy(); imu2["t"] = t_imu
+    drv = VioDriver(fe, be, imu2)
+    rows = []
+    for t, (_, img) in zip(t_img, frames):
+        has, upd = drv.step(float(t), drv.visible_end(float(t)), img=img)
+        if upd:
+            s = be.state(); rows.append(np.concatenate([[s["t"]], s["p"], s["q"]]))
+    py = np.array(rows)
+    assert len(py) >= 15 and cpp.shape == py.shape
+    assert np.array_equal(cpp[:, 1:], py[:, 1:]) and np.abs(cpp[:, 0] - py[:, 0]).max() < 1e-8          # stamps are printed with 9 decimals
+    # the reference's logs
+    log = np.loadtxt(out_dir + "msckf_2_state.txt", ndmin=2)
+    t0 = float(open(out_dir + "msckf_2_takeoff.txt").read())
+    assert log.shape == (len(py), 24) and abs(t0 - be.take_off_stamp) < 1e-8
+    assert np.allclose(log[:, 0] + t0, py[:, 0], atol=1e-4) and np.allclose(log[:, 8:11], py[:, 1:4], rtol=1e-5, atol=1e-6)
+    assert np.allclose(log[:, [2, 3, 4, 1]], py[:, 4:8], rtol=1e-5, atol=1e-6)
+    # and the error tool on both forms of the output
+    t_gt, p_gt = traj_rmse.load_trajectory(d + "/mav0/state_groundtruth_estimate0/data.csv")
+    e1, n1 = traj_rmse.ate_rmse(cpp[:, 0], cpp[:, 1:4], t_gt, p_gt)
+    tl, pl = traj_rmse.load_trajectory(out_dir + "msckf_2_state.txt")
+    e2, n2 = traj_rmse.ate_rmse(tl, pl, t_gt, p_gt)
+    print("ATE RMSE", e1, e2, "poses", n1)
+    assert n1 == n2 == len(py) and e1 < 0.05 and abs(e1 - e2) < 1e-3
+    be.close(); fe.close()
