@@ -302,3 +302,20 @@ def test_cpp_dataset_driver_on_an_asl_directory(gpu_ctx, tmp_path):
     print("ATE RMSE", e1, e2, "poses", n1)
     assert n1 == n2 == len(py) and e1 < 0.05 and abs(e1 - e2) < 1e-3
     be.close(); fe.close()
+    # BASELINE.json's trajectory clause, on the data at hand: the CPU oracle over the same files' contents, RMSE within 1 mm
+    from oracle import lvo, lvo_be
+    ofe = lvo.Frontend(fcfg); obe = lvo_be.Ekf(bcfg)
+    lo = 0; rows = []
+    for t, (_, img) in zip(t_img, frames):
+        hi = int(np.searchsorted(t_imu, float(t) + 0.05, side="left"))
+        have, m = ofe.process(img, float(t), imu2[lo:hi])
+        if have:
+            upd, used = obe.process(float(t), m, imu2[lo:hi]); lo += used
+            if upd:
+                so = obe.state(); rows.append(np.concatenate([[so["t"]], so["p"]]))
+    orc = np.array(rows)
+    assert orc.shape[0] == len(py)
+    e3, n3 = traj_rmse.ate_rmse(orc[:, 0], orc[:, 1:4], t_gt, p_gt)
+    print("ATE RMSE: HIP %.6f m, CPU oracle %.6f m, difference %.4f mm; largest position difference %.3e m"
+          % (e1, e3, 1e3 * (e1 - e3), np.abs(orc[:, 1:4] - py[:, 1:4]).max()))
+    assert abs(e1 - e3) < 1e-3
