@@ -1715,7 +1715,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
         std::unique_lock<std::mutex> lk(p->mu);
         p->ev(0);
         pipe_wait(p, lk, p->cv_state, [&] { return p->unknown_consume == 0; });
-        if (p->st != LVK_OK) return p->st;
+        if (p->st != LVK_OK) { lvk_frontend_release_image(p->fe); return p->st; }
         head = p->head; end = p->imu.size();
         p->ev(1);
     }

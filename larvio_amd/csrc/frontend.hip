@@ -421,6 +421,7 @@ struct lvk_frontend {
     // the data flow allows: ev_pyr (pyramid of this frame ready; being recorded on the main stream it also orders everything the
     // previous frame left there), ev_orb, ev_new (side stream -> main), ev_commit (main -> side), ev_tail (bootstrap only)
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
+    bool host_img_pending = false;   // an asynchronous copy out of the caller's (pageable) image buffer is in flight
     // HIP-event profiling of stages
     unsigned prof_mask;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -642,6 +643,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const uint8_t* img, int strid
     const lvk_fe_config& c = fe->cfg;
     const uint8_t* d_img = img; int d_stride = stride;
     if (!img_is_device) {
+        fe->host_img_pending = true;    // the runtime may pin the caller's pages and read them after this call returns
         LVK_HIP(ctx, hipMemcpy2DAsync(fe->d_img, c.width, img, stride, c.width, c.height, hipMemcpyHostToDevice, ctx->stream));
         d_img = fe->d_img; d_stride = c.width;
     }
@@ -670,8 +672,31 @@ lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, 
     return LVK_OK;
 }
 
+static lvk_status frontend_process_frame(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
+                                         lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg);
+
+// processImage is synchronous in the reference: when it returns the caller may free or overwrite the image.  Here the frame's
+// kernels keep running after the return, but the caller's buffer is only read by the upload at the head of the main stream; the
+// pyramid event behind it has normally fired long before the host has finished queueing the rest of the frame.
 lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
                                 lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
+{
+    const lvk_status st = frontend_process_frame(fe, img, stride, img_is_device, ts, h_imu, n_imu, h_out, cap, n_out, has_msg);
+    const lvk_status st2 = lvk_frontend_release_image(fe);
+    return st != LVK_OK ? st : st2;
+}
+
+// wait until the upload queued by lvk_frontend_begin / lvk_frontend_process no longer needs the caller's image buffer
+lvk_status lvk_frontend_release_image(lvk_frontend* fe)
+{
+    if (!fe || !fe->host_img_pending) return LVK_OK;
+    fe->host_img_pending = false;
+    const hipError_t e = hipEventSynchronize(fe->ev_pyr);
+    return e == hipSuccess ? LVK_OK : lvk_set_error(fe->ctx, LVK_ERR_DEVICE, "image upload: %s", hipGetErrorString(e));
+}
+
+static lvk_status frontend_process_frame(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
+                                         lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
 {
     if (!fe || !img || !n_out || !has_msg || (n_imu > 0 && !h_imu)) return lvk_set_error(fe ? fe->ctx : nullptr, LVK_ERR_ARG, "lvk_frontend_process: bad argument");
     lvk_context* ctx = fe->ctx;

@@ -24,6 +24,7 @@ void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
 struct lvk_frontend;
 lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
 extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts);   // image stage only (internal)
+extern "C" lvk_status lvk_frontend_release_image(lvk_frontend* fe);   // blocks until the queued upload is done with the caller's host image (internal)
 
 struct lvk_pyramid {
     lvk_context* ctx;
