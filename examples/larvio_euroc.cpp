@@ -2,9 +2,11 @@
 // Pangolin): same command line, same loop, same log files (msckf_2_state.txt / msckf_2_takeoff.txt in the configuration's
 // output_dir, written by lvk::LarVio as larvio.cpp:388,446-453 does), running on liblvk_hip.so.
 //
-//   larvio_euroc path_to_imu/data.csv path_to_cam0/data.csv path_to_cam0/data config_file_path [--tum traj.txt] [--max-frames N]
+//   larvio_euroc path_to_imu/data.csv path_to_cam0/data.csv path_to_cam0/data config_file_path [--tum traj.txt] [--max-frames N] [--pipelined]
 //
 // --tum writes "t x y z qx qy qz qw" (body in world, absolute stamps, 17 significant digits) for tools/traj_rmse.py.
+// --pipelined runs the same loop through lvk::VioPipeline: the filter update of a message overlaps the front-end of the next
+// frames on a second HIP stream; the trajectory is the same, written from the filter thread's odometry callback.
 // The filter starts with the static initializer (StaticInitializer.cpp); the dynamic (SfM) initializer is outside the hot path.
 #include "lvk_dataset.hpp"
 #include "lvk_png.hpp"
@@ -15,16 +17,66 @@
 #include <string>
 #include <vector>
 
+static void write_tum(FILE* tum, const lvk::LarVio& Estimator)
+{
+    double s[30]; lvk_ekf_get_state(Estimator.handle(), s);                                        // q stored [x y z w]; p = s[8..10]
+    std::fprintf(tum, "%.9f %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", s[0], s[8], s[9], s[10], s[1], s[2], s[3], s[4]);
+}
+
+struct OdometrySink { FILE* tum; long n_odo; };
+static void on_odometry(void* user, double, const lvk::LarVio& Estimator)
+{
+    OdometrySink* o = static_cast<OdometrySink*>(user);
+    ++o->n_odo;
+    if (o->tum) write_tum(o->tum, Estimator);
+}
+
+static int run_pipelined(const char* image_dir, const std::vector<lvk::ImuData>& allImuData, const std::vector<lvk::ImgInfo>& allImgInfo, long max_frames,
+                         lvk::ImageProcessor& ImgProcesser, lvk::LarVio& Estimator, FILE* tum)
+{
+    typedef std::chrono::steady_clock Clock;
+    lvk::VioPipeline pipe(ImgProcesser, Estimator);
+    if (!pipe.ok()) { std::fprintf(stderr, "cannot create the pipeline\n"); return 1; }
+    OdometrySink sink = {tum, 0};
+    pipe.onOdometry(on_odometry, &sink);
+    const size_t n_frames = max_frames >= 0 && (size_t)max_frames < allImgInfo.size() ? (size_t)max_frames : allImgInfo.size();
+    size_t k = 0; double t_proc = 0, t_io = 0; long n_msgs = 0, n_upd = 0;
+    for (size_t j = 0; j < n_frames; ++j) {
+        const Clock::time_point t0 = Clock::now();
+        const std::string fullPath = std::string(image_dir) + "/" + allImgInfo[j].imgName;
+        lvk::GreyImage image; std::string err;
+        if (!lvk::read_png_grey(fullPath, &image, &err)) { std::fprintf(stderr, "%s: %s\n", fullPath.c_str(), err.c_str()); return 1; }
+        const double ts = allImgInfo[j].timeStampToSec;
+        const size_t k0 = k;
+        while (k < allImuData.size() && allImuData[k].timeStampToSec - ts < 0.05) ++k;
+        const Clock::time_point t1 = Clock::now();
+        if (k > k0) pipe.pushImu(&allImuData[k0], k - k0);
+        lvk::ImageData msg = {ts, image.data.data(), image.width, image.height, image.width};
+        pipe.processImage(msg);
+        t_io += std::chrono::duration<double>(t1 - t0).count();
+        t_proc += std::chrono::duration<double>(Clock::now() - t1).count();
+    }
+    const Clock::time_point t2 = Clock::now();
+    if (!pipe.drain(&n_upd, &n_msgs)) { std::fprintf(stderr, "pipeline: %s\n", "an update failed"); return 1; }
+    t_proc += std::chrono::duration<double>(Clock::now() - t2).count();
+    if (tum) std::fclose(tum);
+    std::printf("frames %zu  feature messages %ld  odometry updates %ld  state dim %d\n", n_frames, n_msgs, sink.n_odo, lvk_ekf_dim(Estimator.handle()));
+    std::printf("pipelined: %.3f ms/frame in the driver thread   image read+decode %.3f ms/frame\n", n_frames ? 1e3 * t_proc / n_frames : 0.0, n_frames ? 1e3 * t_io / n_frames : 0.0);
+    if (t_proc > 0) std::printf("processing rate %.1f frames/s (pipelined, host buffers)\n", n_frames / t_proc);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 5) {
-        std::fprintf(stderr, "Usage: %s path_to_imu/data.csv path_to_cam0/data.csv path_to_cam0/data config_file_path [--tum traj.txt] [--max-frames N]\n", argv[0]);
+        std::fprintf(stderr, "Usage: %s path_to_imu/data.csv path_to_cam0/data.csv path_to_cam0/data config_file_path [--tum traj.txt] [--max-frames N] [--pipelined]\n", argv[0]);
         return 1;
     }
-    std::string tum_path; long max_frames = -1;
+    std::string tum_path; long max_frames = -1; bool pipelined = false;
     for (int a = 5; a < argc; ++a) {
         if (!std::strcmp(argv[a], "--tum") && a + 1 < argc) tum_path = argv[++a];
         else if (!std::strcmp(argv[a], "--max-frames") && a + 1 < argc) max_frames = std::atol(argv[++a]);
+        else if (!std::strcmp(argv[a], "--pipelined")) pipelined = true;
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 1; }
     }
 
@@ -38,11 +90,14 @@ int main(int argc, char** argv)
     if (!ctx.ok()) { std::fprintf(stderr, "larvio_euroc: %s\n", ctx.error()); return 3; }
     lvk::ImageProcessor ImgProcesser(config_file, ctx.get());                                      // :42-48
     if (!ImgProcesser.initialize()) { std::fprintf(stderr, "Image Processer initialization failed!\n"); return 1; }
-    lvk::LarVio Estimator(config_file, ctx.get());                                                  // :50-56
+    lvk::Context ctx2(0);                                                                           // the filter's own stream when pipelined
+    if (pipelined && !ctx2.ok()) { std::fprintf(stderr, "larvio_euroc: %s\n", ctx2.error()); return 3; }
+    lvk::LarVio Estimator(config_file, pipelined ? ctx2.get() : ctx.get());                         // :50-56
     if (!Estimator.initialize()) { std::fprintf(stderr, "Estimator initialization failed!\n"); return 1; }
 
     FILE* tum = nullptr;
     if (!tum_path.empty() && !(tum = std::fopen(tum_path.c_str(), "w"))) { std::perror(tum_path.c_str()); return 1; }
+    if (pipelined) return run_pipelined(argv[3], allImuData, allImgInfo, max_frames, ImgProcesser, Estimator, tum);
 
     typedef std::chrono::steady_clock Clock;
     double t_fe = 0, t_be = 0, t_io = 0; long n_fe = 0, n_be = 0, n_odo = 0;
@@ -73,10 +128,7 @@ int main(int argc, char** argv)
         if (bProcess) { t_be += std::chrono::duration<double>(t3 - t2).count(); ++n_be; }
         if (bPubOdo) {
             ++n_odo;
-            if (tum) {
-                double s[30]; lvk_ekf_get_state(Estimator.handle(), s);                            // q stored [x y z w]; p = s[8..10]
-                std::fprintf(tum, "%.9f %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", s[0], s[8], s[9], s[10], s[1], s[2], s[3], s[4]);
-            }
+            if (tum) write_tum(tum, Estimator);
         }
     }
     if (tum) std::fclose(tum);

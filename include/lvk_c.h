@@ -269,6 +269,12 @@ void       lvk_vio_pipe_destroy(lvk_vio_pipe* p);
 lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n);
 lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, int img_is_device, double ts, int* has_msg);
 lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs);
+/* Called on the filter's thread after every update that processFeatures would have answered with true — the point at which the
+ * reference's drivers publish odometry (app/larvioMain.cpp:117-, ros_wrapper System.cpp:177-193).  ts = the message's stamp,
+ * state30 as lvk_ekf_get_state.  The filter is quiescent for the duration of the call: lvk_ekf_get_* are allowed inside it.
+ * Set before the first submit (or after a drain); fn = NULL removes it. */
+typedef void (*lvk_odometry_fn)(void* user, double ts, const double* state30);
+lvk_status lvk_vio_pipe_on_update(lvk_vio_pipe* p, lvk_odometry_fn fn, void* user);
 /* host wall time in microseconds since the last reset: [0] caller thread inside the front-end, [1] caller waiting for an erase
  * count, [2] worker inside filter updates, [3] worker waiting for a message */
 lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* h_out4, int reset);

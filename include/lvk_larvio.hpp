@@ -150,6 +150,7 @@ public:
     }
     lvk_ekf* handle() const { return ekf_; }
 private:
+    friend class VioPipeline;
     LarVio(const LarVio&); LarVio& operator=(const LarVio&);
     // the debug logs of larvio.cpp:388 and :446-453: take-off stamp once; then per update
     //   t-take_off  qw qx qy qz  vx vy vz  px py pz  bgx bgy bgz  bax bay baz  qbc(w x y z)  t_cam0_imu      ("%g" = the ostream default)
@@ -181,6 +182,43 @@ private:
     }
     lvk_ekf_config cfg_; std::string config_file_; lvk_context* ctx_; lvk_ekf* ekf_;
     FILE* f_state_; FILE* f_takeoff_; bool takeoff_written_;
+};
+
+// The driver loop with the filter update of message k overlapping the front-end of the following frames (lvk_vio_pipe_*): same
+// results as calling processImage / processFeatures in turn, but processFeatures' answer arrives through a callback on the filter's
+// thread — the place to publish odometry.  The two halves must have been created on DIFFERENT Contexts (= HIP streams).
+//     pipe.pushImu(...)            samples with t < t_img + 0.05, as larvioMain.cpp:98-102 fills imu_msg_buffer
+//     pipe.processImage(img)       true = this frame produced a feature message (its update runs in the background)
+//     pipe.drain()                 wait for the updates in flight before reading the estimator
+class VioPipeline {
+public:
+    typedef void (*OdometryFn)(void* user, double ts, const LarVio& estimator);
+    VioPipeline(ImageProcessor& fe, LarVio& be) : be_(be), pipe_(nullptr), fn_(nullptr), user_(nullptr)
+    {
+        if (lvk_vio_pipe_create(fe.handle(), be.handle(), &pipe_) != LVK_OK) pipe_ = nullptr;
+        else lvk_vio_pipe_on_update(pipe_, &VioPipeline::trampoline, this);
+    }
+    ~VioPipeline() { if (pipe_) lvk_vio_pipe_destroy(pipe_); }
+    bool ok() const { return pipe_ != nullptr; }
+    void onOdometry(OdometryFn fn, void* user) { drain(); fn_ = fn; user_ = user; }
+    bool pushImu(const ImuData* v, size_t n) { return pipe_ && lvk_vio_pipe_push_imu(pipe_, reinterpret_cast<const lvk_imu*>(v), (int)n) == LVK_OK; }
+    bool processImage(const ImageData& msg)
+    {
+        int has = 0;
+        if (!pipe_ || lvk_vio_pipe_submit(pipe_, msg.data, msg.step, 0, msg.timeStampToSec, &has) != LVK_OK) return false;
+        return has != 0;
+    }
+    bool drain(long* n_updates = nullptr, long* n_msgs = nullptr) { return pipe_ && lvk_vio_pipe_drain(pipe_, n_updates, n_msgs) == LVK_OK; }
+    lvk_vio_pipe* handle() const { return pipe_; }
+private:
+    VioPipeline(const VioPipeline&); VioPipeline& operator=(const VioPipeline&);
+    static void trampoline(void* self, double ts, const double*)
+    {
+        VioPipeline* p = static_cast<VioPipeline*>(self);
+        p->be_.write_logs();                                      // the reference's state log, as processFeatures writes it
+        if (p->fn_) p->fn_(p->user_, ts, p->be_);
+    }
+    LarVio& be_; lvk_vio_pipe* pipe_; OdometryFn fn_; void* user_;
 };
 
 }  // namespace lvk

@@ -1593,6 +1593,7 @@ struct lvk_vio_pipe {
     lvk_status st = LVK_OK;
     bool stop = false;
     std::vector<lvk_feature_obs> msg;
+    lvk_odometry_fn on_update = nullptr; void* on_update_user = nullptr;
     double t_busy = 0, t_idle = 0, t_submit_wait = 0, t_fe = 0;
     struct Ev { double t; int what; };                    // LVK_PIPE_LOG=<file>: event log (0 submit begin, 1 wait done, 2 front-end done,
     std::vector<Ev> log; bool logging = false;            //  3 job queued [4 precounted], 5 job start, 6 job end)
@@ -1653,6 +1654,7 @@ static void pipe_worker(lvk_vio_pipe* p)
         { std::lock_guard<std::mutex> lk(p->mu); p->ev(5); }
         int used = 0, upd = 0;
         lvk_status st = lvk_ekf_process(p->ekf, job.ts, job.feats.data(), (int)job.feats.size(), job.view.data(), (int)job.view.size(), &used, &upd);
+        if (st == LVK_OK && upd && p->on_update) { double s30[30]; lvk_ekf_get_state(p->ekf, s30); p->on_update(p->on_update_user, job.ts, s30); }
         {
             std::lock_guard<std::mutex> lk(p->mu);
             p->t_idle += t1 - t0; p->t_busy += now_us() - t1; p->ev(6);
@@ -1752,6 +1754,15 @@ lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* out4, int reset)
     std::lock_guard<std::mutex> lk(p->mu);
     out4[0] = p->t_fe; out4[1] = p->t_submit_wait; out4[2] = p->t_busy; out4[3] = p->t_idle;
     if (reset) p->t_busy = p->t_idle = p->t_fe = p->t_submit_wait = 0;
+    return LVK_OK;
+}
+
+lvk_status lvk_vio_pipe_on_update(lvk_vio_pipe* p, lvk_odometry_fn fn, void* user)
+{
+    if (!p) return LVK_ERR_ARG;
+    std::unique_lock<std::mutex> lk(p->mu);
+    pipe_wait(p, lk, p->cv_state, [&] { return p->in_flight == 0; });      // the worker reads the pair without the lock
+    p->on_update = fn; p->on_update_user = user;
     return LVK_OK;
 }
 

@@ -275,6 +275,14 @@ def test_cpp_dataset_driver_on_an_asl_directory(gpu_ctx, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     print(r.stdout)
     cpp = np.loadtxt(tum, ndmin=2)
+    # --pipelined: lvk::VioPipeline (filter on its own stream and thread, odometry through the callback) — the same numbers
+    seq_log = open(out_dir + "msckf_2_state.txt").read()
+    tum2 = str(tmp_path / "traj_pipelined.txt")
+    r2 = subprocess.run(r.args[:-2] + ["--tum", tum2, "--pipelined"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    print(r2.stdout)
+    assert open(tum2).read() == open(tum).read() and open(out_dir + "msckf_2_state.txt").read() == seq_log
+    assert r2.stdout.splitlines()[0] == r.stdout.splitlines()[0]
     # the same loop through the Python mirror, on the stamps as the readers deliver them (1e-9 * integer ns)
     fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
     be = larvio_amd.LarVio(dict(bcfg, max_features=300), gpu_ctx); assert be.initialize()
