@@ -125,13 +125,18 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx):
         assert np.array_equal(a[7][k], b[7][k])
 
 
+def S_EUROC():
+    from larvio_amd import synthetic as S
+    return dict(S.EUROC)
+
+
 TUMVI_LIKE = dict(
     width=512, height=512, intrinsics=(190.978, 190.973, 254.932, 256.897), distortion_model=1,      # equidistant (config 4 shape)
     distortion=(0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367),
     T_cam_imu=None)
 
 
-def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates):
+def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates, mutate=None):
     """oracle loop vs VioDriver on frames [first, first+count) of the synthetic sequence seen through `cam`"""
     import larvio_amd
     from larvio_amd import synthetic as S
@@ -142,6 +147,8 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
     if cam.get("T_cam_imu") is None:
         cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
     frames = synth_frames(first, count, cam=cam)
+    if mutate is not None:
+        frames = mutate(list(frames))
     seq = S.imu_only_sequence(cam=cam)
     ts = [f[0] for f in frames]
     imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
@@ -192,6 +199,25 @@ def test_driver_loop_config4_shape_equidistant_static_start_zupt(gpu_ctx):
                                              dict(sw_size=12, if_zupt_valid=1), init_from_gt=False, min_updates=15)
     assert c["zupt"] >= 1 and n_tracks > 60
     print("config-4 shape: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
+
+
+def test_driver_loop_blackout_noise_and_frozen_frames(gpu_ctx):
+    """The whole loop through disturbances: a black frame (every track lost at once: one large MSCKF update, then a window without
+    features), two frames of unrelated noise, and a camera that freezes for five frames while the IMU keeps moving (repeated image:
+    zero parallax, the ZUPT test sees no feature motion).  The filter may well degrade — the oracle and the HIP path have to do so
+    together."""
+    def mutate(frames):
+        h, w = frames[0][1].shape
+        rng = np.random.default_rng(9)
+        frames[22] = (frames[22][0], np.zeros((h, w), np.uint8))
+        for k in (36, 37):
+            frames[k] = (frames[k][0], rng.integers(0, 256, (h, w)).astype(np.uint8))
+        for k in range(50, 55):
+            frames[k] = (frames[k][0], frames[49][1])
+        return frames
+    n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, S_EUROC(), 40, 70, dict(max_features_num=150), dict(sw_size=20, if_zupt_valid=1),
+                                             init_from_gt=True, min_updates=25, mutate=mutate)
+    print("disturbed run: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
 
 
 def test_driver_loop_config5_shape_1080p_many_tracks(gpu_ctx):
