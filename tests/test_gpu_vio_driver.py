@@ -77,7 +77,21 @@ def test_driver_loop_matches_oracle(gpu_ctx, device_frames):
     print("driver loop parity: updates", n_upd, "worst rel", worst)
 
 
-def test_pipelined_driver_is_identical_to_sequential(gpu_ctx):
+def _disturb(frames):
+    """a black frame, two frames of unrelated noise, a camera frozen for five frames"""
+    frames = list(frames)
+    h, w = frames[0][1].shape
+    rng = np.random.default_rng(9)
+    frames[22] = (frames[22][0], np.zeros((h, w), np.uint8))
+    for k in (36, 37):
+        frames[k] = (frames[k][0], rng.integers(0, 256, (h, w)).astype(np.uint8))
+    for k in range(50, 55):
+        frames[k] = (frames[k][0], frames[49][1])
+    return frames
+
+
+@pytest.mark.parametrize("disturbed", [False, True])
+def test_pipelined_driver_is_identical_to_sequential(gpu_ctx, disturbed):
     """lvk_vio_pipe_*: front-end of frame k+1 overlapping the update of frame k on a second stream gives the same bits as the
     sequential driver step (same library, same kernels — only the schedule differs), hence the same parity with the oracle."""
     import larvio_amd
@@ -85,11 +99,13 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx):
     from larvio_amd.vio import VioDriver, VioPipeline
     from tests.conftest import synth_frames
     frames = synth_frames(40, 70)
+    if disturbed:
+        frames = _disturb(frames)
     seq = S.imu_only_sequence()
     ts = [f[0] for f in frames]
     imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
     fcfg = S.frontend_config(max_features_num=150)
-    bcfg = S.backend_config(sw_size=15, if_zupt_valid=0)
+    bcfg = S.backend_config(sw_size=20, if_zupt_valid=1) if disturbed else S.backend_config(sw_size=15, if_zupt_valid=0)
     ctx2 = larvio_amd.Context(0)                                    # second context = second stream, for the filter
     out = []
     for mode in ("seq", "pipe"):
@@ -206,17 +222,8 @@ def test_driver_loop_blackout_noise_and_frozen_frames(gpu_ctx):
     features), two frames of unrelated noise, and a camera that freezes for five frames while the IMU keeps moving (repeated image:
     zero parallax, the ZUPT test sees no feature motion).  The filter may well degrade — the oracle and the HIP path have to do so
     together."""
-    def mutate(frames):
-        h, w = frames[0][1].shape
-        rng = np.random.default_rng(9)
-        frames[22] = (frames[22][0], np.zeros((h, w), np.uint8))
-        for k in (36, 37):
-            frames[k] = (frames[k][0], rng.integers(0, 256, (h, w)).astype(np.uint8))
-        for k in range(50, 55):
-            frames[k] = (frames[k][0], frames[49][1])
-        return frames
     n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, S_EUROC(), 40, 70, dict(max_features_num=150), dict(sw_size=20, if_zupt_valid=1),
-                                             init_from_gt=True, min_updates=25, mutate=mutate)
+                                             init_from_gt=True, min_updates=25, mutate=_disturb)
     print("disturbed run: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
 
 
