@@ -545,6 +545,16 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     if (cfg->max_features_num <= 0 || cfg->max_features_num > FM_MAX_N) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "max_features_num must be in 1..%d", FM_MAX_N);
     if (cfg->distortion_model != 0 && cfg->distortion_model != 1) return lvk_set_error(ctx, LVK_ERR_ARG, "distortion_model must be 0 (radtan) or 1 (equidistant)");
     if (cfg->min_distance < 1 || cfg->pub_frequency <= 0) return lvk_set_error(ctx, LVK_ERR_ARG, "min_distance >= 1 and pub_frequency > 0 required");
+    if (cfg->patch_size != 15 && cfg->patch_size != 21 && cfg->patch_size != 31)
+        return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "patch_size %d not instantiated (15, 21, 31)", cfg->patch_size);
+    if (cfg->max_iteration < 1 || cfg->max_iteration > 100)      // cv::calcOpticalFlowPyrLK clamps the count to 0..100; 0 iterations is not a tracker
+        return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "max_iteration must be in 1..100");
+    if (cfg->pyramid_levels < 0) return lvk_set_error(ctx, LVK_ERR_ARG, "pyramid_levels must be >= 0");
+    {   // more levels than buffers exist only matter if the image is large enough for OpenCV's stop rule to build them
+        const int small = cfg->width < cfg->height ? cfg->width : cfg->height;
+        if (cfg->pyramid_levels >= LVK_MAX_LEVELS && (small >> (LVK_MAX_LEVELS - 1)) > cfg->patch_size)
+            return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "pyramid_levels %d: at most %d levels are buffered", cfg->pyramid_levels, LVK_MAX_LEVELS - 1);
+    }
     lvk_frontend* fe = new (std::nothrow) lvk_frontend();     // value-initialised: all PODs zero
     if (!fe) return LVK_ERR_DEVICE;
     fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
