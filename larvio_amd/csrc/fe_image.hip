@@ -5,6 +5,7 @@
 // is GEMM-shaped, so no MFMA here: the rules that matter are coalesced row access, LDS tiles for
 // the stencils and as few dependent launches as possible (each costs ~1.5-2 us on MI355X).
 #include "lvk_internal.h"
+#include <vector>
 #include <stdarg.h>
 #include <algorithm>
 
@@ -702,6 +703,72 @@ lvk_status lvk_pyramid_build_clahe(lvk_context* ctx, lvk_pyramid* p, const uint8
 }
 
 int lvk_pyramid_levels(const lvk_pyramid* p) { return p ? p->n_levels : 0; }
+
+}  // extern "C"
+
+// ---- the pyramid build of one pyramid object as a captured graph: 5 fixed-shape launches become one graph launch; the two
+// kernels that read the caller's image get their (pointer, stride) arguments patched when the image moves.
+struct lvk_pyr_graph {
+    hipGraph_t g; hipGraphExec_t x;
+    hipGraphNode_t node[2]; hipKernelNodeParams prm[2]; void* args[2][12]; int n_img_nodes;
+    const uint8_t* img; int stride;
+};
+
+void lvk_pyramid_graph_destroy(lvk_pyr_graph* G)
+{
+    if (!G) return;
+    if (G->x) hipGraphExecDestroy(G->x);
+    if (G->g) hipGraphDestroy(G->g);
+    delete G;
+}
+
+lvk_status lvk_pyramid_graph_capture(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride, int clahe, double clip_limit,
+                                     int tiles_x, int tiles_y, lvk_pyr_graph** out)
+{
+    if (!ctx || !p || !d_img || !out) return LVK_ERR_ARG;
+    lvk_pyr_graph* G = new lvk_pyr_graph(); memset(G, 0, sizeof *G);
+    // thread-local mode: the filter's thread keeps making HIP calls on its own stream while this one records
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete G; return lvk_set_error(ctx, LVK_ERR_DEVICE, "stream capture refused"); }
+    lvk_status st = clahe ? lvk_pyramid_build_clahe(ctx, p, d_img, stride, clip_limit, tiles_x, tiles_y) : lvk_pyramid_build(ctx, p, d_img, stride);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &G->g);
+    if (st != LVK_OK || e != hipSuccess || !G->g) { lvk_pyramid_graph_destroy(G); return st != LVK_OK ? st : lvk_set_error(ctx, LVK_ERR_DEVICE, "stream capture failed: %s", hipGetErrorString(e)); }
+    if (hipGraphInstantiate(&G->x, G->g, nullptr, nullptr, 0) != hipSuccess) { lvk_pyramid_graph_destroy(G); return lvk_set_error(ctx, LVK_ERR_DEVICE, "graph instantiation failed"); }
+    size_t n = 0; hipGraphGetNodes(G->g, nullptr, &n);
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) hipGraphGetNodes(G->g, nodes.data(), &n);
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams prm;
+        if (hipGraphKernelNodeGetParams(nodes[i], &prm) != hipSuccess) continue;
+        int n_args = 0;
+        if (prm.func == (void*)k_clahe_lut) n_args = 10;
+        else if (prm.func == (void*)k_level0_pad<true> || prm.func == (void*)k_level0_pad<false>) n_args = 12;
+        if (!n_args || G->n_img_nodes >= 2 || !prm.kernelParams) continue;
+        const int k = G->n_img_nodes++;
+        G->node[k] = nodes[i]; G->prm[k] = prm;
+        for (int a = 0; a < n_args; ++a) G->args[k][a] = prm.kernelParams[a];      // the node's own copies (alive as long as the graph)
+        G->args[k][0] = &G->img; G->args[k][3] = &G->stride;                        // src, sstride: ours
+        G->prm[k].kernelParams = G->args[k]; G->prm[k].extra = nullptr;
+    }
+    const int want = clahe ? 2 : 1;
+    if (G->n_img_nodes != want) { lvk_pyramid_graph_destroy(G); return lvk_set_error(ctx, LVK_ERR_DEVICE, "captured graph: image-reading nodes not found"); }
+    G->img = d_img; G->stride = stride;
+    *out = G;
+    return LVK_OK;
+}
+
+lvk_status lvk_pyramid_graph_launch(lvk_context* ctx, lvk_pyr_graph* G, const uint8_t* d_img, int stride)
+{
+    if (d_img != G->img || stride != G->stride) {
+        G->img = d_img; G->stride = stride;
+        for (int k = 0; k < G->n_img_nodes; ++k) LVK_HIP(ctx, hipGraphExecKernelNodeSetParams(G->x, G->node[k], &G->prm[k]));
+    }
+    LVK_HIP(ctx, hipGraphLaunch(G->x, ctx->stream));
+    return LVK_OK;
+}
+
+extern "C" {
 
 lvk_status lvk_pyramid_level(const lvk_pyramid* p, int level, int* w, int* h, int* pad, int* istride, int* dstride,
                              const uint8_t** d_img, const int16_t** d_der)

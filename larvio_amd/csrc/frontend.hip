@@ -421,6 +421,8 @@ struct lvk_frontend {
     // the data flow allows: ev_pyr (pyramid of this frame ready; being recorded on the main stream it also orders everything the
     // previous frame left there), ev_orb, ev_new (side stream -> main), ev_commit (main -> side), ev_tail (bootstrap only)
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
+    lvk_pyr_graph* pyr_graph[2] = {nullptr, nullptr}; lvk_pyramid* pyr_graph_of[2] = {nullptr, nullptr};
+    int use_graph = 0;                // LVK_FE_GRAPH=1: steady-state pyramid build as one graph launch per frame
     bool host_img_pending = false;   // an asynchronous copy out of the caller's (pageable) image buffer is in flight
     // HIP-event profiling of stages
     unsigned prof_mask;
@@ -532,6 +534,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (int i = 0; i < 2; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
     if (fe->h_msg) hipHostFree(fe->h_msg);
     if (fe->h_nmsg) hipHostFree(fe->h_nmsg);
     if (fe->h_dev) hipHostFree(fe->h_dev);
@@ -558,6 +561,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     lvk_frontend* fe = new (std::nothrow) lvk_frontend();     // value-initialised: all PODs zero
     if (!fe) return LVK_ERR_DEVICE;
     fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
+    { const char* g = getenv("LVK_FE_GRAPH"); fe->use_graph = g && atoi(g) != 0; }
     const int w = cfg->width, h = cfg->height, cap = fe->cap;
     const size_t esz = (size_t)(w + 64) * (h + 64);
     bool ok = true;
@@ -661,8 +665,19 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const uint8_t* img, int strid
     hipStream_t S1 = ctx->stream;
     lvk_context* orb_cx = fe->image_state == 3 ? fe->side[0] : ctx;
     hipStream_t S3 = orb_cx->stream;
-    { ProfScope ps(fe, 0);
-      st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride); }
+    if (fe->use_graph && fe->image_state == 3 && !((fe->prof_mask >> 0) & 1u)) {
+        int slot = fe->pyr_graph_of[0] == fe->pyr[1] ? 0 : fe->pyr_graph_of[1] == fe->pyr[1] ? 1 : -1;
+        if (slot < 0) {
+            slot = fe->pyr_graph_of[0] ? 1 : 0;
+            st = lvk_pyramid_graph_capture(ctx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, &fe->pyr_graph[slot]);
+            if (st != LVK_OK) return st;
+            fe->pyr_graph_of[slot] = fe->pyr[1];
+        }
+        st = lvk_pyramid_graph_launch(ctx, fe->pyr_graph[slot], d_img, d_stride);
+    } else {
+        ProfScope ps(fe, 0);
+        st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride);
+    }
     if (st != LVK_OK) return st;
     hipEventRecord(fe->ev_pyr, S1);
     if (S3 != S1) hipStreamWaitEvent(S3, fe->ev_pyr, 0);

@@ -26,6 +26,13 @@ lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
 extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts);   // image stage only (internal)
 extern "C" lvk_status lvk_frontend_release_image(lvk_frontend* fe);   // blocks until the queued upload is done with the caller's host image (internal)
 
+struct lvk_pyr_graph;                                     // fe_image.hip: the pyramid build of one pyramid object as a captured hipGraph
+struct lvk_pyramid;
+lvk_status lvk_pyramid_graph_capture(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride, int clahe, double clip_limit,
+                                     int tiles_x, int tiles_y, lvk_pyr_graph** out);
+lvk_status lvk_pyramid_graph_launch(lvk_context* ctx, lvk_pyr_graph* g, const uint8_t* d_img, int stride);
+void lvk_pyramid_graph_destroy(lvk_pyr_graph* g);
+
 struct lvk_pyramid {
     lvk_context* ctx;
     int n_levels, pad, max_level;
