@@ -62,6 +62,25 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
     args = ap.parse_args()
 
+    # Dual-socket hosts: keep the whole process - Python, the HIP runtime's own threads and queues, our two driver threads - on ONE
+    # socket, before anything initialises HIP.  Which socket made no difference in A/B runs; a process whose threads straddle both
+    # did (0.30 vs 0.35 ms per filter update).  LVK_BENCH_BIND=0 disables.
+    if os.environ.get("LVK_BENCH_BIND", "1") != "0" and hasattr(os, "sched_setaffinity"):
+        try:
+            cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else min(os.sched_getaffinity(0))
+            import glob as _glob
+            for node in _glob.glob("/sys/devices/system/node/node*/cpulist"):
+                cpus = set()
+                for part in open(node).read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+                if cpu in cpus:
+                    keep = cpus & os.sched_getaffinity(0)
+                    if keep:
+                        os.sched_setaffinity(0, keep)
+                    break
+        except (OSError, ValueError):
+            pass
     # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch

@@ -10,6 +10,7 @@
 // (image_processor.h:215-230); the one order-preserving compaction happens inside the RANSAC
 // workgroup, which needs the compacted order anyway (OpenCV's RNG draws indices into it).
 #include "lvk_internal.h"
+#include <sched.h>
 #include "fe_track_dev.h"
 #include <math.h>
 #include <float.h>
@@ -26,12 +27,60 @@ extern "C" {
 
 const char* lvk_version(void) { return "lvk-hip 0.1 (gfx950)"; }
 
+// Optional placement help for dual-socket hosts (LVK_NUMA_BIND=1): restrict the thread that creates a context (and the threads it
+// starts later: the pipelined filter's worker) to the CPUs of the device's NUMA node.  Off by default: a library should not move
+// its caller's threads, and on the 2 x EPYC 9575F boxes measured here the node itself made no difference — what did was having
+// the WHOLE process (HIP runtime initialisation included) on one socket, which is the launcher's business (bench.py does it,
+// INTEGRATION.md says how: taskset / numactl).
+static void bind_thread_to_device_node(int device)
+{
+    const char* on = getenv("LVK_NUMA_BIND");
+    if (!(on && !strcmp(on, "1"))) return;
+    int node = -1;
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device) != hipSuccess) { (void)hipGetLastError(); node = -1; }
+    char path[160];
+    if (node < 0) {                                         // older runtimes: ask sysfs through the PCI address
+        char bdf[32] = {0};
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return; }
+        for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+        if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+        if (node < 0) return;
+    }
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    char list[1024] = {0};
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t allowed, want; CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    int n_want = 0;
+    for (char* p = list; *p && *p != '\n';) {               // "0-63,128-191"
+        char* end = nullptr;
+        long a = strtol(p, &end, 10); if (end == p) break;
+        long b = a; p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &want); ++n_want; }
+        if (*p == ',') ++p;
+    }
+    if (n_want > 0) sched_setaffinity(0, sizeof want, &want);
+}
+
 lvk_status lvk_context_create(int device, lvk_context** out)
 {
     if (!out) return LVK_ERR_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LVK_ERR_DEVICE;   // no CPU fallback
     if (hipSetDevice(device) != hipSuccess) return LVK_ERR_DEVICE;
+    // LVK_WAIT_POLICY=spin: keep waiting host threads spinning on the completion signal (the runtime's default spins for 100 us,
+    // then sleeps until the interrupt).  Process-wide, so opt-in; two A/B pairs of bench runs showed no consistent difference.
+    {
+        const char* wp = getenv("LVK_WAIT_POLICY");
+        if (wp && !strcmp(wp, "spin")) { if (hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError(); }
+    }
+    bind_thread_to_device_node(device);
     lvk_context* c = new (std::nothrow) lvk_context();
     if (!c) return LVK_ERR_DEVICE;
     memset(c, 0, sizeof *c);
