@@ -88,7 +88,7 @@ def _messages(first, count, max_features=150):
     return msgs, imu_all, seq
 
 
-def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True):
+def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True, init_args=None):
     from oracle import lvo_be
     import larvio_amd
     ora = lvo_be.Ekf(cfg)
@@ -96,6 +96,8 @@ def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True):
     assert gpu.initialize()
     buf_o = imu_all.copy(); buf_g = imu_all.copy()
     inited = not init_from_gt
+    if init_args is not None:
+        ora.set_state(*init_args); gpu.set_state(*init_args); inited = True
     n_upd, worst_x, worst_P = 0, 0.0, 0.0
     for ts, msg in msgs:
         bo = buf_o[:int(np.searchsorted(buf_o["t"], ts + 0.05))]
@@ -284,6 +286,23 @@ def test_sharded_update_equals_unsharded_on_device(gpu_ctx):
         Hf, rf = lv.compress_qr(gpu_ctx, Hst, rst)
         dx, Pn = lv.ekf_update(gpu_ctx, P, Hf, rf, sigma2)
         assert _rel(dx, dx_ref) < 1e-8 and _rel(Pn, P_ref) < 1e-9, (world, _rel(dx, dx_ref), _rel(Pn, P_ref))
+
+
+@pytest.mark.parametrize("seed,kw", [(4, dict()), (5, dict(sigma=2e-3, imu_noise=30.0, sw_size=12, max_feat=60)),
+                                     (6, dict(calib_imu_instrinsic=1, estimate_td=1, estimate_extrin=1, max_feat=220))])
+def test_backend_parity_on_simulated_feature_messages(gpu_ctx, seed, kw):
+    """tests/feature_sim.py: landmark cloud + trajectory -> feature messages, no front-end involved.  A different input
+    distribution from the tracker's (every feature lives until it leaves the field of view, a full budget in every message, no
+    initial-frame observations), 6 s = 60 updates; the second case is the stressed one (noisy IMU, 2/3 of the features gated out,
+    short window), the third calibrates IMU intrinsics, extrinsics and time offset with a larger budget."""
+    from tests import feature_sim as F
+    sim = F.simulate(seed, **kw)
+
+    class _Seq:
+        traj = sim["traj"]
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, sim["msgs"], sim["imu"], _Seq, sim["cfg"], init_args=sim["init"])
+    assert n_upd == 60 and c["hybrid"] >= 20
+    print("simulated features", seed, kw, "worst rel state", wx, "cov", wP, c)
 
 
 def test_backend_accepts_empty_feature_messages(gpu_ctx):
