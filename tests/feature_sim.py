@@ -85,10 +85,12 @@ def simulate(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=150, pert
     return dict(cfg=cfg, imu=imu, init=init, msgs=msgs, traj=tr)
 
 
-def drive(ekf, sim, on_update=None):
-    """feed a simulated run to an object with the oracle's / the mirror's set_state and process; returns the number of updates"""
+def drive(ekf, sim, on_update=None, set_state=True):
+    """feed a simulated run to an object with the oracle's set_state and process; returns the number of updates.
+    set_state=False leaves the start to the filter's own (static) initializer."""
     imu = sim["imu"]; lo = 0; n = 0
-    ekf.set_state(*sim["init"])
+    if set_state:
+        ekf.set_state(*sim["init"])
     for ts, m in sim["msgs"]:
         hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
         upd, used = ekf.process(ts, m, imu[lo:hi]); lo += used
