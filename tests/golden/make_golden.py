@@ -28,3 +28,23 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "frontend_small.npz"),
                     lvl2=p0.image(2), der1=p0.deriv(1), corners=pts, lk_status=st, lk_pts=out, desc=d, x1=x1, x2=x2,
                     ransac_mask=mask, ransac_iters=iters)
 print("frontend_small.npz written:", len(pts), "corners,", int(st.sum()), "tracked,", int(mask.sum()), "ransac inliers")
+
+# ---- back-end: a short simulated run (tests/feature_sim.py), inputs AND the oracle's outputs, so that the regression check does not
+# depend on the random generator that made the inputs
+from tests import feature_sim as F  # noqa: E402
+sim = F.simulate(11, t0=2.0, t1=3.9, max_feat=48, sw_size=8, estimate_td=1, estimate_extrin=1)
+ekf = lvo_be.Ekf(sim["cfg"])
+trace = []
+n_upd = F.drive(ekf, sim, lambda ts: trace.append(np.concatenate([[ekf.state()["t"]], ekf.state()["q"], ekf.state()["p"], ekf.state()["v"], [ekf.dim]])))
+s = ekf.state(); ids, idp, pos = ekf.features()
+cfg_keys = sorted(k for k in sim["cfg"] if k not in ("intrinsics", "T_cam_imu"))
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "backend_sim.npz"),
+                    cfg_keys=np.array(cfg_keys), cfg_vals=np.array([float(sim["cfg"][k]) for k in cfg_keys]),
+                    intrinsics=np.array(sim["cfg"]["intrinsics"], np.float64), T_cam_imu=np.asarray(sim["cfg"]["T_cam_imu"], np.float64),
+                    imu=sim["imu"], init=np.concatenate([[sim["init"][0]]] + [np.asarray(x, np.float64) for x in sim["init"][1:]]),
+                    msg_ts=np.array([m[0] for m in sim["msgs"]]), msg_len=np.array([len(m[1]) for m in sim["msgs"]]),
+                    msg_obs=np.concatenate([m[1] for m in sim["msgs"]]),
+                    trace=np.array(trace), cov=ekf.cov(), clone_ids=ekf.clones()["id"], feat_ids=ids, feat_idp=idp,
+                    bg=s["bg"], ba=s["ba"], R_b2c=s["R_b2c"], t_c_b=s["t_c_b"], td=s["td"],
+                    counters=np.array([ekf.counters()[k] for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map")]))
+print("backend_sim.npz written:", n_upd, "updates, dim", ekf.dim, ekf.counters())

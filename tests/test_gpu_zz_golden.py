@@ -1,0 +1,47 @@
+"""HIP path against the COMMITTED golden fixtures (tests/golden/, generated from the oracle by make_golden.py): the same bytes
+the oracle is held to in tests/test_oracle_frontend.py::test_golden_fixtures and tests/test_oracle_backend.py::
+test_backend_golden_fixture, without the oracle in the loop for the front-end stages."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_frontend_stages_against_the_committed_golden_fixture(gpu_ctx):
+    from larvio_amd import ops
+    z = np.load(os.path.join(GOLDEN, "frontend_small.npz"))
+    img0, img1 = z["img0"], z["img1"]
+    h, w = img0.shape
+    assert np.array_equal(ops.clahe(gpu_ctx, img0), z["clahe0"])
+    p0 = ops.Pyramid(gpu_ctx, w, h, 21, 2).build(img0, clahe=True)
+    p1 = ops.Pyramid(gpu_ctx, w, h, 21, 2).build(img1, clahe=True)
+    assert np.array_equal(p0.image(2), z["lvl2"]) and np.array_equal(p0.deriv(1), z["der1"])
+    pts = p0.good_features(40, 0.01, 10.0)
+    assert np.array_equal(pts, z["corners"])
+    out, st, it = ops.lk_track(gpu_ctx, p0, p1, pts, pts)
+    assert np.array_equal(st, z["lk_status"])
+    assert np.array_equal(np.ascontiguousarray(out, np.float32).view(np.uint32), np.ascontiguousarray(z["lk_pts"], np.float32).view(np.uint32))
+    p0.orb_prepare()
+    d, a = ops.orb_describe(gpu_ctx, p0, pts)
+    assert np.array_equal(d, z["desc"])
+    mask, iters = ops.ransac_fundamental(gpu_ctx, z["x1"], z["x2"])
+    assert np.array_equal(mask, z["ransac_mask"]) and iters == int(z["ransac_iters"])
+
+
+def test_filter_against_the_committed_golden_fixture(gpu_ctx):
+    """stored inputs of a short simulated run -> lvk_ekf_process; every update is compared with the live oracle (1e-5 relative,
+    measured ~1e-9) by the pair runner, and the oracle's end state with the stored one"""
+    from tests.test_oracle_backend import _load_backend_golden
+    from tests.test_gpu_backend import _run_pair
+    z, cfg, init, msgs = _load_backend_golden()
+
+    class _Seq:
+        traj = None
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, msgs, z["imu"], _Seq, cfg, init_args=init)
+    assert n_upd == len(z["trace"])
+    s = ora.state()
+    assert np.allclose(np.concatenate([[s["t"]], s["q"], s["p"], s["v"]]), z["trace"][-1][:-1], rtol=1e-9, atol=1e-12)
+    assert [c[k] for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map")] == list(z["counters"])

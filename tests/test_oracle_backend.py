@@ -263,3 +263,46 @@ def test_calibrating_filter_tracks_ground_truth_and_keeps_intrinsics_near_identi
     assert np.linalg.norm(s["p"] - seq.traj.p_wb(s["t"])) < 0.08
     ident = np.zeros(24); ident[3:6] = 1; ident[21:24] = 1
     assert np.abs(obe.imu_intrinsics() - ident).max() < 0.02
+
+
+def _load_backend_golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backend_sim.npz"))
+    cfg = {}
+    for k, v in zip(z["cfg_keys"], z["cfg_vals"]):
+        k = str(k)
+        cfg[k] = int(v) if (k in lvo_be._CFG_INT or k in ("calib_imu_instrinsic", "feature_idp_dim", "use_schmidt", "max_features")) else float(v)
+    cfg["intrinsics"] = tuple(z["intrinsics"]); cfg["T_cam_imu"] = z["T_cam_imu"]
+    i = z["init"]
+    init = (float(i[0]), i[1:5], i[5:8], i[8:11], i[11:14], i[14:17], i[17:20], i[20:23])
+    off = np.concatenate([[0], np.cumsum(z["msg_len"])])
+    msgs = [(float(t), z["msg_obs"][off[k]:off[k + 1]]) for k, t in enumerate(z["msg_ts"])]
+    return z, cfg, init, msgs
+
+
+def test_backend_golden_fixture():
+    """tests/golden/backend_sim.npz (make_golden.py): stored inputs of a short simulated run AND what the oracle made of them — 19
+    updates with hybrid, MSCKF and pruning steps, td and extrinsics estimated.  Any later edit of the oracle that moves a number
+    shows here (1e-9: the same C code on another libm may differ in the last bits)."""
+    z, cfg, init, msgs = _load_backend_golden()
+    ekf = lvo_be.Ekf(cfg)
+    ekf.set_state(*init)
+    imu = z["imu"]; lo = 0; trace = []
+    for ts, m in msgs:
+        hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
+        upd, used = ekf.process(ts, m, imu[lo:hi]); lo += used
+        if upd:
+            s = ekf.state(); trace.append(np.concatenate([[s["t"]], s["q"], s["p"], s["v"], [ekf.dim]]))
+    trace = np.array(trace)
+    assert trace.shape == z["trace"].shape
+    assert np.allclose(trace, z["trace"], rtol=1e-9, atol=1e-12)
+    s = ekf.state()
+    for k in ("bg", "ba", "R_b2c", "t_c_b"):
+        assert np.allclose(s[k], z[k], rtol=1e-9, atol=1e-13), k
+    assert abs(s["td"] - float(z["td"])) < 1e-12
+    assert np.allclose(ekf.cov(), z["cov"], rtol=1e-8, atol=1e-16)
+    assert np.array_equal(ekf.clones()["id"], z["clone_ids"])
+    ids, idp, _ = ekf.features()
+    assert np.array_equal(ids, z["feat_ids"]) and np.allclose(idp, z["feat_idp"], rtol=1e-9)
+    c = ekf.counters()
+    assert [c[k] for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map")] == list(z["counters"])
