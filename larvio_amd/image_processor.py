@@ -6,6 +6,7 @@ the reference's ``haveFeatures`` and the feature list is the ``MonoCameraMeasure
 (include/larvio/feature_msg.h:15-52).  All arithmetic happens in liblvk_hip.so on the GPU.
 """
 import ctypes as C
+import os
 import numpy as np
 from ._lib import lib, _p, Context, FeConfig, LvkError, IMU, OBS
 
@@ -34,8 +35,11 @@ class ImageProcessor:
     FIRST_IMAGE, SECOND_IMAGE, OTHER_IMAGES = 1, 2, 3
 
     def __init__(self, config, ctx=None):
-        """config: dict with the keys ImageProcessor::loadParameters reads (image_processor.cpp:44-113);
-        see larvio_amd.synthetic.frontend_config."""
+        """config: dict with the keys ImageProcessor::loadParameters reads (image_processor.cpp:44-113; see
+        larvio_amd.synthetic.frontend_config), or the path of a LARVIO configuration file."""
+        if isinstance(config, (str, os.PathLike)):          # the reference's constructor argument: the YAML path
+            from .config import load_config
+            config = load_config(config)[0]
         self.config = dict(config)
         self.ctx = ctx
         self._h = None

@@ -6,6 +6,7 @@ covariance / sliding window / map points.  The arithmetic runs in liblvk_hip.so 
 ``processFeatures`` erases the IMU samples it consumed from the caller's buffer (larvio.cpp:511-512).
 """
 import ctypes as C
+import os
 import numpy as np
 from ._lib import lib, _p, Context, LvkError, IMU, OBS
 
@@ -132,7 +133,11 @@ def make_ekf_config(config):
 
 class LarVio:
     def __init__(self, config, ctx=None):
-        """config: dict with the keys LarVio::loadParameters reads (larvio.cpp:58-311); see synthetic.backend_config."""
+        """config: dict with the keys LarVio::loadParameters reads (larvio.cpp:58-311; see synthetic.backend_config), or the path
+        of a LARVIO configuration file (the reference's constructor argument)."""
+        if isinstance(config, (str, os.PathLike)):
+            from .config import load_config
+            config = load_config(config)[1]
         self.config = dict(config)
         self.ctx = ctx
         self._h = None

@@ -362,3 +362,46 @@ def test_traj_rmse_tool(tmp_path, capsys):
     lines = out.splitlines()
     assert abs(float(lines[0].split()[4]) - want) < 1.5e-3 and abs(float(lines[1].split()[4]) - want) < 1.5e-3
     assert abs(float(lines[2].split()[1])) < 0.01                                # the two files hold the same trajectory: < 0.01 mm apart
+
+
+# ------------------------------------------------------------------ the Python twin of the configuration reader
+def test_python_config_reader_agrees_with_the_cpp_reader(host_tools, tmp_path):
+    from larvio_amd import synthetic as S
+    from larvio_amd.config import load_config, parse
+    from larvio_amd.image_processor import make_fe_config
+    from larvio_amd.larvio import make_ekf_config
+    from make_euroc_dir import write_config_yaml
+    paths = []
+    p = tmp_path / "a.yaml"
+    write_config_yaml(str(p), S.frontend_config(max_features_num=150, pyramid_levels=3), S.backend_config(sw_size=30, calib_imu_instrinsic=1, td=-0.004),
+                      output_dir="/tmp/o/")
+    paths.append(str(p))
+    for ref in ("/root/reference/config/euroc.yaml", "/root/reference/config/mynteye.yaml"):
+        if os.path.exists(ref):
+            paths.append(ref)
+    for path in paths:
+        rc, out, err = _run("config", path); assert rc == 0, err
+        got = _parse_fields(out)
+        fe, be, out_dir = load_config(path)
+        assert " ".join(got["output_dir"]) == out_dir
+        a, b = make_fe_config(fe), make_ekf_config(be)
+        for struct, prefix in ((a, "fe."), (b, "ekf.")):
+            for name, _ in struct._fields_:
+                v = getattr(struct, name)
+                want = list(v) if hasattr(v, "__len__") else [v]
+                assert [float(x) for x in got[prefix + name]] == [float(x) for x in want], (path, name)
+    d = parse("a: 1.\nb: .5e1\nc: 'x # y'   # c\nm: !!opencv-matrix\n   rows: 1\n   cols: 2\n   data: [ 1,\n      2 ]\nn:\n   k: v\n")
+    assert d["a"] == 1.0 and d["b"] == 5.0 and d["c"] == "x # y" and d["m.data"] == [1.0, 2.0] and d["n.k"] == "v"
+    bad = tmp_path / "bad.yaml"; bad.write_text(p.read_text().replace("feature_idp_dim: 1", "feature_idp_dim: 3"))
+    with pytest.raises(ValueError):
+        load_config(str(bad))
+
+
+def test_mirror_classes_accept_a_configuration_file_path(tmp_path):
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from make_euroc_dir import write_config_yaml
+    p = tmp_path / "c.yaml"
+    write_config_yaml(str(p), S.frontend_config(max_features_num=123), S.backend_config(sw_size=17))
+    fe = larvio_amd.ImageProcessor(str(p)); be = larvio_amd.LarVio(str(p))
+    assert fe.config["max_features_num"] == 123 and be.config["sw_size"] == 17 and be.config["max_features"] == 123
