@@ -228,6 +228,9 @@ lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* h_in24);
 lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P);           /* N*N row-major, synchronises (getPpose/getPvel read blocks of it) */
 int        lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* h_out, int cap);       /* getSwPoses */
 int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_depth, double* h_pos_w, int cap);  /* getActiveeMapPointPositions */
+/* getStableMapPointPositions (larvio.cpp:2717-2722): in-state features that were lost since the last call, with their last world
+ * position; the entries handed out are removed, as the reference clears lost_slam_features on read.  Returns the count (<= cap). */
+int        lvk_ekf_take_lost_features(lvk_ekf* e, int64_t* h_ids, double* h_pos_w, int cap);
 /* [0] hybrid updates [1] msckf updates [2] rows of the last update [3] zupt updates [4] gated in [5] gated out [6] map size [7] triangulations */
 void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
 /* HIP-event bracket around the H P GEMM (the P H^T contraction, FP64 MFMA) of every update: enable/disable; h_out3 (optional) receives

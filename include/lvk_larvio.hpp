@@ -148,6 +148,12 @@ public:
         const int n = lvk_ekf_get_features(ekf_, ids.data(), idp.data(), xyz.data(), 1024);
         ids.resize((size_t)n); xyz.resize((size_t)3 * n);
     }
+    void getStableMapPointPositions(std::vector<int64_t>& ids, std::vector<double>& xyz)                                                 // :2717-2722
+    {
+        ids.resize(4096); xyz.resize(3 * 4096);
+        const int n = lvk_ekf_take_lost_features(ekf_, ids.data(), xyz.data(), 4096);
+        ids.resize((size_t)n); xyz.resize((size_t)3 * n);
+    }
     lvk_ekf* handle() const { return ekf_; }
 private:
     friend class VioPipeline;

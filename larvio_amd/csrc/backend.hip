@@ -93,6 +93,8 @@ struct lvk_ekf {
     bool is_gravity_set = false, b_first_features = false, if_fej = false, if_zupt = false;
     double m_gyro_old[3], m_acc_old[3];
     double take_off_stamp = 0, last_update_time = 0, last_zupt_time = 0, tracking_rate = 0;
+    struct LostPoint { long long id; double p[3]; };
+    std::vector<LostPoint> lost_slam;                   // in-state features that were lost, with their last world position (drained on read)
     double sigma2, zupt_v2, zupt_p2, zupt_q2, imu_img_time_th, Qc[12];
     double x_min, y_min, grid_w, grid_h;
     std::vector<int> grid_count;
@@ -824,7 +826,12 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         for (int i = 0; i < e->N; ++i) if (!drop[i]) idx.push_back(i);
         st = cov_gather(e, idx);
         if (st != LVK_OK) return st;
-        for (long long id : ekf_lost) { e->feature_states.erase(e->feature_states.begin() + fs_rank(e, id)); e->map.erase(id); }
+        for (long long id : ekf_lost) {
+            const Feature& f = e->map.at(id);                    // lost_slam_features (:3342): kept for getStableMapPointPositions
+            if (e->lost_slam.size() >= (size_t)1 << 16) e->lost_slam.erase(e->lost_slam.begin(), e->lost_slam.begin() + (1 << 15));
+            e->lost_slam.push_back({id, {f.position[0], f.position[1], f.position[2]}});
+            e->feature_states.erase(e->feature_states.begin() + fs_rank(e, id)); e->map.erase(id);
+        }
     }
     if (cells) {                                                 // updateGridMap (:3351-3370)
         std::fill(e->grid_count.begin(), e->grid_count.end(), 0);
@@ -1553,6 +1560,14 @@ int lvk_ekf_get_features(const lvk_ekf* e, int64_t* ids, double* inv_depth, doub
         const Feature& f = e->map.at(e->feature_states[i]);
         ids[i] = f.id; inv_depth[i] = f.inv_depth; memcpy(pos_w + 3 * i, f.position, 24);
     }
+    return n;
+}
+int lvk_ekf_take_lost_features(lvk_ekf* e, int64_t* ids, double* pos_w, int cap)
+{
+    if (!e || !ids || !pos_w || cap <= 0) return 0;
+    const int n = std::min((int)e->lost_slam.size(), cap);
+    for (int i = 0; i < n; ++i) { ids[i] = e->lost_slam[i].id; memcpy(pos_w + 3 * i, e->lost_slam[i].p, 24); }
+    e->lost_slam.erase(e->lost_slam.begin(), e->lost_slam.begin() + n);
     return n;
 }
 void lvk_ekf_counters(const lvk_ekf* e, long* out8) { if (e && out8) memcpy(out8, e->counters, sizeof e->counters); }

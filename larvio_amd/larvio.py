@@ -48,6 +48,7 @@ def _L():
         L.lvk_ekf_dim.argtypes = [vp]; L.lvk_ekf_dim.restype = i
         L.lvk_ekf_is_initialized.argtypes = [vp]; L.lvk_ekf_is_initialized.restype = i
         L.lvk_ekf_take_off_stamp.argtypes = [vp]; L.lvk_ekf_take_off_stamp.restype = C.c_double
+        L.lvk_ekf_take_lost_features.argtypes = [vp, vp, vp, i]; L.lvk_ekf_take_lost_features.restype = i
         L.lvk_ekf_get_state.argtypes = [vp, vp]; L.lvk_ekf_get_state.restype = i
         L.lvk_ekf_get_cov.argtypes = [vp, vp]; L.lvk_ekf_get_cov.restype = i
         L.lvk_ekf_get_imu_intrinsics.argtypes = [vp, vp]; L.lvk_ekf_get_imu_intrinsics.restype = i
@@ -185,6 +186,12 @@ class LarVio:
         o = np.zeros(30); self.ctx.check(_L().lvk_ekf_get_state(self._h, _p(o)))
         return dict(t=o[0], q=o[1:5].copy(), v=o[5:8].copy(), p=o[8:11].copy(), bg=o[11:14].copy(), ba=o[14:17].copy(),
                     R_b2c=o[17:26].reshape(3, 3).copy(), t_c_b=o[26:29].copy(), td=o[29])
+
+    def stable_map_points(self):
+        """getStableMapPointPositions (larvio.cpp:2717-2722): (ids, positions) of in-state features lost since the last call"""
+        ids = np.zeros(4096, np.int64); pos = np.zeros((4096, 3))
+        n = _L().lvk_ekf_take_lost_features(self._h, _p(ids), _p(pos), 4096)
+        return ids[:n].copy(), pos[:n].copy()
 
     def profile(self, enable=True):
         """HIP-event time of the H P GEMM since the last call: dict(ms, flops, launches); enables/disables the bracket"""
