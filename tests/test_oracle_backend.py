@@ -306,3 +306,57 @@ def test_backend_golden_fixture():
     assert np.array_equal(ids, z["feat_ids"]) and np.allclose(idp, z["feat_idp"], rtol=1e-9)
     c = ekf.counters()
     assert [c[k] for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map")] == list(z["counters"])
+
+
+def test_transition_matrix_of_the_plain_model_vs_finite_differences():
+    """calib_imu_instrinsic = 0 (LEG_DIM 22, the north-star configuration): after ONE IMU step from the diagonal initial covariance
+    P0, the covariance must be Phi P0 Phi^T + Q with Phi = d(error state after) / d(error state before).  Phi's rows for
+    (theta, v, p) are taken numerically — perturb the initial orientation (left-multiplied small rotation), velocity, position and
+    the two biases, push each through the oracle's own state predictor — and the oracle's covariance block is compared with
+    Phi_num P0 Phi_num^T; what may remain is Q (sigma^2 dt on the diagonal) and the second-order terms of LARVIO's closed-form blocks."""
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    cfg = S.backend_config(sw_size=10, if_fej=0)
+    seq = S.imu_only_sequence()
+    imu = seq.imu_array(600, 604)
+    tr = seq.traj; t0 = imu["t"][0]
+    q0, p0, v0 = _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0)
+    bg0, ba0 = np.array([0.01, -0.02, 0.005]), np.array([0.05, 0.02, -0.03])
+
+    def step(q, p, v, bg, ba):
+        e = lvo_be.Ekf(cfg)
+        e.set_state(t0, q, p, v, bg, ba, imu["gyro"][0], imu["acc"][0])
+        e.process(float(imu["t"][1]), np.zeros(0, lvo.OBS), imu[1:2])
+        return e
+    e0 = step(q0, p0, v0, bg0, ba0)
+    s0, P = e0.state(), e0.cov()
+    assert e0.dim == 22 + 6
+
+    def err_state(s1):
+        qi = s0["q"] * np.array([-1, -1, -1, 1]); dq = _qmul(s1["q"], qi)
+        return np.concatenate([2 * dq[:3] * np.sign(dq[3]), s1["v"] - s0["v"], s1["p"] - s0["p"]])
+    eps = 1e-6
+    Phi = np.zeros((9, 15))
+    for c in range(15):
+        q, p, v, bg, ba = q0.copy(), p0.copy(), v0.copy(), bg0.copy(), ba0.copy()
+        if c < 3:
+            d = np.zeros(4); d[c] = 0.5 * eps; d[3] = 1.0; q = _qmul(d, q0); q /= np.linalg.norm(q)
+        elif c < 6: v[c - 3] += eps
+        elif c < 9: p[c - 6] += eps
+        elif c < 12: bg[c - 9] += eps
+        else: ba[c - 12] += eps
+        Phi[:, c] = err_state(step(q, p, v, bg, ba).state()) / eps
+    D = np.zeros(15)
+    D[0:3] = cfg["initial_covariance_orientation"]; D[3:6] = cfg["initial_covariance_velocity"]; D[6:9] = cfg["initial_covariance_position"]
+    D[9:12] = cfg["initial_covariance_gyro_bias"]; D[12:15] = cfg["initial_covariance_acc_bias"]
+    want = Phi @ np.diag(D) @ Phi.T
+    got = P[0:9, 0:9]
+    dt = float(imu["t"][1] - t0)
+    q_bound = 4 * max(cfg["noise_gyro"], cfg["noise_acc"]) ** 2 * dt
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+    assert np.abs(got - want).max() <= q_bound + 2e-3 * scale.max(), (np.abs(got - want).max(), q_bound)
+    assert (np.abs(got - want) <= q_bound + 2e-2 * scale).all()
+    # and the cross-covariance with the biases gives Phi's bias columns directly (their own rows are identity rows)
+    for c in range(9, 15):
+        col = P[0:9, c] / D[c]
+        assert np.abs(col - Phi[:, c]).max() <= 0.05 * np.abs(Phi[:, c]).max() + 1e-12, (c, col, Phi[:, c])
