@@ -360,3 +360,6 @@ def test_transition_matrix_of_the_plain_model_vs_finite_differences():
     for c in range(9, 15):
         col = P[0:9, c] / D[c]
         assert np.abs(col - Phi[:, c]).max() <= 0.05 * np.abs(Phi[:, c]).max() + 1e-12, (c, col, Phi[:, c])
+    # stateAugmentation (larvio.cpp:752-798): the clone is the IMU pose, J selects (theta, p): its covariance rows are copies
+    sel = [0, 1, 2, 6, 7, 8]
+    assert np.array_equal(P[22:28, 0:22], P[sel, 0:22]) and np.array_equal(P[22:28, 22:28], P[np.ix_(sel, sel)])
