@@ -1,0 +1,35 @@
+"""The JSON line bench.py prints, as committed under profiles/ from the last MI355X run: every field of the driver's contract is
+there with the right type (bench.py itself needs a GPU; this keeps the contract from drifting unnoticed)."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                 ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) * d["n_gpus"]) < 0.01 * d["value"]
+
+
+def test_bench_source_keeps_the_timed_region_bracketed():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i0 = src.index("t_begin = time.perf_counter()"); i1 = src.index("elapsed = time.perf_counter() - t_begin")
+    before, timed = src[:i0], src[i0:i1]
+    assert "dist.barrier()" in before[-400:] and "torch.cuda.synchronize()" in before[-400:]
+    assert "torch.cuda.synchronize()" in timed and "dist.barrier()" in timed and "drv.drain()" in timed
+    assert "oracle" not in timed                                   # the CPU baseline is timed outside
