@@ -405,3 +405,30 @@ def test_mirror_classes_accept_a_configuration_file_path(tmp_path):
     write_config_yaml(str(p), S.frontend_config(max_features_num=123), S.backend_config(sw_size=17))
     fe = larvio_amd.ImageProcessor(str(p)); be = larvio_amd.LarVio(str(p))
     assert fe.config["max_features_num"] == 123 and be.config["sw_size"] == 17 and be.config["max_features"] == 123
+
+
+def test_dataset_driver_fails_loudly_without_a_gpu_and_on_bad_input(host_tools, tmp_path):
+    """examples/larvio_euroc: usage error = 1 (as the reference's driver), unreadable inputs = 1 with a message, and on a machine
+    without a gfx950 device status 3 'no usable device' — never a silent CPU run"""
+    from larvio_amd import synthetic as S
+    from make_euroc_dir import write_euroc_dir
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "larvio_euroc"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = os.path.join(ROOT, "examples", "larvio_euroc")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr
+    r = subprocess.run([exe, "/nonexistent/imu.csv", "/nonexistent/cam.csv", "/nonexistent", "/nonexistent.yaml"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot read IMU samples" in r.stderr
+    seq = S.imu_only_sequence()
+    frames = [(seq.frame_time(i), np.zeros((48, 64), np.uint8)) for i in range(2)]
+    write_euroc_dir(str(tmp_path / "d"), frames, seq.imu_array(0, 30), S.frontend_config(), S.backend_config())
+    d = str(tmp_path / "d")
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present: the no-device path cannot be shown here")
+    r = subprocess.run([exe, d + "/mav0/imu0/data.csv", d + "/mav0/cam0/data.csv", d + "/mav0/cam0/data", d + "/config.yaml"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no usable gfx950 device" in r.stderr, r.stderr
