@@ -82,7 +82,7 @@ def simulate(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=150, pert
                 m[r] = (j, uvn[j, 0], uvn[j, 1], -1.0, -1.0, (uvn[j, 0] - pv[0]) / 0.05, (uvn[j, 1] - pv[1]) / 0.05, 0.0, 0.0)
             msgs.append((ts, m))
         prev_uv = uvn
-    return dict(cfg=cfg, imu=imu, init=init, msgs=msgs, traj=tr)
+    return dict(cfg=cfg, imu=imu, init=init, msgs=msgs, traj=tr, landmarks=cloud.pts)      # feature id = row of `landmarks`
 
 
 def drive(ekf, sim, on_update=None, set_state=True):

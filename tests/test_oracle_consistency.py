@@ -32,6 +32,44 @@ def test_noise_free_run_stays_on_the_truth():
     assert rec[:, 0].max() < 0.01 and rec[:, 1].max() < 1e-3 and rec[:, 2].max() < 0.01, rec.max(0)
 
 
+def test_in_state_landmarks_stay_on_the_true_points_through_re_anchoring():
+    """noise-free again, looking at the EKF-SLAM half: after every update each in-state feature's world position (anchor pose x
+    inverse depth, re-anchored whenever its anchor clone is pruned — updateFeatureCov_1didp, larvio.cpp:3125-3293; with a 10-clone
+    window that is every few updates) must be the landmark the simulator projected.  A freshly initialised distant point carries the
+    depth error of its short baseline (measured: up to 1.5 % at 11 m, shrinking to millimetres), so the checks are: the bearing from
+    the current camera is right to a milliradian, the depth to a few percent, and the error moves smoothly from one update to the
+    next (measured: at most 4.5 cm per update, the drift of a low-parallax point's depth) — a wrong re-anchoring transform would show
+    as a jump of decimetres and break the depth bound."""
+    sim = F.simulate(2, sigma=0.0, imu_noise=0.0, perturb=False, sw_size=10)
+    ekf = lvo_be.Ekf(sim["cfg"])
+    last, stats = {}, dict(bearing=0.0, rel=0.0, jump=0.0, n=0, seen=set())
+
+    def on_update(ts):
+        ids, idp, pos = ekf.features()
+        if not len(ids):
+            return
+        assert (idp > 0).all()
+        _, p_wc = sim["traj"].cam_pose(ekf.state()["t"])
+        true = sim["landmarks"][ids]
+        depth = np.linalg.norm(true - p_wc, axis=1)
+        err = np.linalg.norm(pos - true, axis=1)
+        b1 = (pos - p_wc) / np.linalg.norm(pos - p_wc, axis=1)[:, None]; b2 = (true - p_wc) / depth[:, None]
+        stats["bearing"] = max(stats["bearing"], float(np.arccos(np.clip((b1 * b2).sum(1), -1, 1)).max()))
+        stats["rel"] = max(stats["rel"], float((err / depth).max()))
+        now = {}
+        for i, e in zip(ids.tolist(), err.tolist()):
+            if i in last:
+                stats["jump"] = max(stats["jump"], abs(e - last[i]))
+            now[i] = e
+        last.clear(); last.update(now)
+        stats["n"] += len(ids); stats["seen"].update(ids.tolist())
+    n = F.drive(ekf, sim, on_update)
+    print("in-state landmarks: bearing %.2e rad, depth %.2f %%, largest step %.4f m; %d feature-updates, %d distinct features"
+          % (stats["bearing"], 100 * stats["rel"], stats["jump"], stats["n"], len(stats["seen"])))
+    assert n == 60 and len(stats["seen"]) >= 30 and stats["n"] > 1000
+    assert stats["bearing"] < 2.5e-3 and stats["rel"] < 0.03 and stats["jump"] < 0.07, stats
+
+
 def test_monte_carlo_consistency_in_the_reference_regime():
     """IMU noise at the simulator's densities, observation noise of a sub-pixel tracker, the filter configured as config/euroc.yaml
     is (its sigmas are several times the actual ones, and its gate is the 5 % quantile): errors stay at the centimetre level and the
