@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — the reference's headline metric on MI355X: VIO frames/sec + p50 ms/frame on EuRoC-shaped
-synthetic input (752x480 @20 Hz, ~150 tracks, 30-clone window; BASELINE.json / SURVEY.md §8d).
+"""bench.py — the reference's headline metric on MI355X: VIO frames/sec + p50 ms/frame on EuRoC-shaped synthetic input
+(BASELINE.json: 752x480, ~150 tracks, 30-clone window).
 
-A "step" is one camera frame through the hot path, timed the way the reference times it
-(app/larvioMain.cpp:106-116: processImage, then processFeatures when a message was produced), with the
-frames already resident in HBM.  Each step ends with a stream synchronise (a VIO consumes frame k's
-result before frame k+1 exists), so value = K / sum(frame latencies).
+A "step" is one camera frame through the hot path, timed the way the reference times it (app/larvioMain.cpp:106-116: processImage,
+then processFeatures when a message was produced).  The image is handed over as a HOST buffer (the reference's cv::Mat): the copy
+into the front-end's pinned staging and the H2D transfer are inside the timed region.  A second pass over the same frames with the
+images already resident in HBM is reported beside it (`device_resident`).
 
-  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run)
+The timed region always starts from the STATED steady state, whatever --steps/--warmup say: an untimed pre-roll runs until the
+sliding window has filled and cycled (clones >= sw_size - 2 and >= 2 pruning MSCKF updates, larvio.cpp:2316-2320), then >= 20 more
+updates with the H P GEMM bracketed by HIP events (MFMA utilisation); only then come the W warm-up and the K timed steps.  If the
+steady state is not reached no value is printed.
 
-N>1 at this configuration runs N independent estimators, one camera stream per GPU ("replicas only",
-DESIGN.md §multi-GPU: at 150 tracks the R-factor all-gather costs more than the whole update);
-value = frames of all ranks / max-over-ranks time, scaling "weak".
+  python bench.py --gpus N --steps K --warmup W [--config A|3|4|5] [--sequential] [--sharded]
+  (N>1: launched by torch.distributed.run; --sharded needs --config 5)
+
+N>1 without --sharded runs N independent estimators, one camera stream per GPU (replicas: at 150 tracks the R-factor all-gather
+costs more than the whole update); with --sharded every rank sees the same stream, builds the measurement rows of its
+contiguous slice of the features and the compressed R factors are all-gathered over RCCL before the replicated update.
+value = frames of all ranks / max-over-ranks time.
 """
 import argparse
 import json
@@ -24,50 +31,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (datasheet)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (datasheet; profiles/README.md holds the measured saturation figure)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
 
 
-def render_frames(first, count, seed_offset=0):
-    from larvio_amd import synthetic as S
-    path = "/tmp/lvk_bench_frames_%d_%d_%d.npz" % (first, count, seed_offset)
-    if os.path.exists(path):
-        z = np.load(path)
-        return z["ts"], z["img"]
-    seq = S.Sequence(seed=S.MASTER_SEED + seed_offset)
-    ts = np.empty(count); img = np.empty((count, S.EUROC["height"], S.EUROC["width"]), np.uint8)
-    for i in range(count):
-        ts[i], img[i] = seq.frame(first + i)
-    try:
-        np.savez(path, ts=ts, img=img)
-    except OSError:
-        pass
-    return ts, img
+def R2q(R):
+    t = np.trace(R); s_ = np.sqrt(t + 1) * 2
+    return np.array([(R[2, 1] - R[1, 2]) / s_, (R[0, 2] - R[2, 0]) / s_, (R[1, 0] - R[0, 1]) / s_, 0.25 * s_])
 
 
-def imu_stream(seed_offset=0):
-    from larvio_amd import synthetic as S
-    seq = S.imu_only_sequence(S.MASTER_SEED + seed_offset)
-    return seq
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=80, help="untimed frames; >= 70 so the 30-clone window is full when timing starts")
-    ap.add_argument("--sw-size", type=int, default=30)
-    ap.add_argument("--max-features", type=int, default=150, help="tracker budget (holds ~150 live tracks)")
-    ap.add_argument("--cpu-baseline-frames", type=int, default=2000, help="frames of the same sequence the 1-thread CPU oracle is timed on (capped at steps+warmup)")
-    ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
-    args = ap.parse_args()
-
-    # Dual-socket hosts: keep the whole process - Python, the HIP runtime's own threads and queues, our two driver threads - on ONE
-    # socket, before anything initialises HIP.  Which socket made no difference in A/B runs; a process whose threads straddle both
-    # did (0.30 vs 0.35 ms per filter update).  LVK_BENCH_BIND=0 disables.
+def bind_one_socket():
+    """Dual-socket hosts: keep the whole process - Python, the HIP runtime's own threads and queues, our two driver threads - on ONE
+    socket, before anything initialises HIP (a process whose threads straddle both ran the filter at 0.35 instead of 0.30 ms per
+    update; which socket made no difference).  LVK_BENCH_BIND=0 disables.  Returns the affinity set before binding."""
+    before = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
     if os.environ.get("LVK_BENCH_BIND", "1") != "0" and hasattr(os, "sched_setaffinity"):
         try:
-            cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else min(os.sched_getaffinity(0))
+            cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else min(before)
             import glob as _glob
             for node in _glob.glob("/sys/devices/system/node/node*/cpulist"):
                 cpus = set()
@@ -75,101 +55,141 @@ def main():
                     a, _, b = part.partition("-")
                     cpus.update(range(int(a), int(b or a) + 1))
                 if cpu in cpus:
-                    keep = cpus & os.sched_getaffinity(0)
+                    keep = cpus & before
                     if keep:
                         os.sched_setaffinity(0, keep)
                     break
         except (OSError, ValueError):
             pass
-    # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    import torch
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return before
 
-    import larvio_amd
-    from larvio_amd import synthetic as S
-    K, W = args.steps, args.warmup
-    first = 40                                           # t = 2.0 s: the trajectory is moving
-    ts, frames = render_frames(first, K + W, seed_offset=rank)
-    seq = imu_stream(seed_offset=rank)
-    d_frames = torch.from_numpy(frames).cuda()           # inputs resident in HBM before the timed region
-    stream = torch.cuda.current_stream()
-    ctx = larvio_amd.Context(local_rank, stream=stream.cuda_stream)
-    cfg = S.frontend_config(max_features_num=args.max_features)
-    fe = larvio_amd.ImageProcessor(cfg, ctx)
-    assert fe.initialize()
-    bcfg = S.backend_config(sw_size=args.sw_size, max_features=args.max_features)
-    # the filter gets its own context (= its own HIP stream): its update overlaps the next frames' front-end
-    ctx_be = ctx if args.sequential else larvio_amd.Context(local_rank)
-    be = larvio_amd.LarVio(bcfg, ctx_be)
-    assert be.initialize()
-    stride = frames.shape[2]
-    fsz = frames.shape[1] * frames.shape[2]
-    # the driver's IMU buffer (app/larvioMain.cpp:98-102): samples with t < t_img + 0.05 are appended, processFeatures erases
-    k_lo = max(int(ts[0] * 200) - 4, 0)
-    imu_all = seq.imu_array(k_lo, int(ts[-1] * 200) + 40)
-    state = {"inited": False, "n_be": 0}
 
-    def R2q(R):
-        t = np.trace(R); s_ = np.sqrt(t + 1) * 2
-        return np.array([(R[2, 1] - R[1, 2]) / s_, (R[0, 2] - R[2, 0]) / s_, (R[1, 0] - R[0, 1]) / s_, 0.25 * s_])
+class Run:
+    """One estimator (front-end + filter + driver) fed frame by frame; the same object drives the pre-roll, the warm-up and the
+    timed steps."""
 
-    from larvio_amd.vio import VioDriver, VioPipeline
-    drv = VioDriver(fe, be, imu_all) if args.sequential else VioPipeline(fe, be, imu_all)
-    his = [drv.visible_end(float(t)) for t in ts]
+    def __init__(self, wl, args, local_rank, imu_all, seq, ts, sequential, torch_stream=None, shard=None):
+        import larvio_amd
+        from larvio_amd.vio import VioDriver, VioPipeline
+        self.wl, self.seq, self.ts, self.imu_all, self.sequential = wl, seq, ts, imu_all, sequential
+        self.ctx = larvio_amd.Context(local_rank, stream=torch_stream)
+        self.fe = larvio_amd.ImageProcessor(wl["fcfg"], self.ctx)
+        assert self.fe.initialize()
+        # the filter gets its own context (= its own HIP stream): its update overlaps the next frames' front-end
+        self.ctx_be = self.ctx if sequential else larvio_amd.Context(local_rank)
+        self.be = larvio_amd.LarVio(wl["bcfg"], self.ctx_be)
+        assert self.be.initialize()
+        if shard is not None:
+            self.be.set_shard(*shard)
+        self.drv = VioDriver(self.fe, self.be, imu_all) if sequential else VioPipeline(self.fe, self.be, imu_all)
+        self.his = [self.drv.visible_end(float(t)) for t in ts]
+        self.inited = False
+        self.i = 0                      # next frame
 
-    def step(i):
-        # one C-ABI call = the reference driver's loop body (processImage; processFeatures when a message came out)
-        if not state["inited"] and i >= 1:
-            # the initializers are a cold path outside the scope: the filter starts from ground truth at the
-            # second frame, before the front-end's first feature message
+    def step(self, host_img=None, dev_ptr=None, stride=None):
+        i = self.i; ts = self.ts
+        if not self.inited and i >= 1:
+            # the initializers are a cold path (SURVEY §8f N4): the filter starts from ground truth at the second frame,
+            # before the front-end's first feature message
+            imu_all = self.imu_all
             k = int(np.searchsorted(imu_all["t"], ts[i], side="right")) - 1
-            t_i = imu_all["t"][k]; tr = seq.traj
-            if not args.sequential:
-                drv.drain()
-            be.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
-            state["inited"] = True
-        if args.sequential:
-            has, upd = drv.step(float(ts[i]), his[i], device_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
-            ctx.sync()
+            t_i = imu_all["t"][k]; tr = self.seq.traj
+            if not self.sequential:
+                self.drv.drain()
+            self.be.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            self.inited = True
+        if self.sequential:
+            has, _ = self.drv.step(float(ts[i]), self.his[i], img=host_img, device_ptr=dev_ptr, stride=stride)
+            self.ctx.sync()
         else:
             # returns when this frame's front-end is done (tracks + message); the update it triggers runs behind it
-            has = upd = drv.step(float(ts[i]), his[i], device_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
-        if upd:
-            state["n_be"] += 1
-        return has, upd
-    for i in range(W):
-        if i == W // 2:
-            be.profile(True)                             # H P GEMM bracket (MFMA utilisation): second half of the warm-up only,
-        step(i)                                          # its event records would add ~10% to the filter chain of the timed region
-    if not args.sequential:
-        drv.drain(); drv.stats(reset=True)
-    hp = be.profile(False)
-    pl0, it0 = fe.lk_stats()
-    fe.profile_enable((1 << 2) | (1 << 3))               # HIP events around the LK launches only (dominant kernel)
-    state["n_be"] = 0
+            has = self.drv.step(float(ts[i]), self.his[i], img=host_img, device_ptr=dev_ptr, stride=stride)
+        self.i += 1
+        return has
+
+    def drain(self):
+        if not self.sequential:
+            self.drv.drain()
+        self.ctx.sync(); self.ctx_be.sync()
+
+    def close(self):
+        self.drain()
+        if not self.sequential:
+            self.drv.close()
+        self.be.close(); self.fe.close()
+        if self.ctx_be is not self.ctx:
+            self.ctx_be.close()
+        self.ctx.close()
+
+
+def preroll(run, frames, d_frames, n_max, sw_size, extra_updates):
+    """Untimed: run until the window has filled and cycled, then `extra_updates` more updates with the H P GEMM bracketed.
+    Returns (frames consumed, H P profile) or raises SystemExit when the steady state is not reached."""
+    fsz = frames.shape[1] * frames.shape[2]; stride = frames.shape[2]
+
+    def feed():
+        i = run.i
+        if d_frames is not None:
+            run.step(dev_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
+        else:
+            run.step(host_img=frames[i])
+    steady_at = None
+    while run.i < n_max:
+        feed()
+        if run.i % 4 == 0 and run.i >= 2 * (sw_size - 4):
+            run.drain()
+            c = run.be.counters()
+            if len(run.be.clones()) >= sw_size - 2 and c["msckf"] >= 2:
+                steady_at = run.i
+                break
+    if steady_at is None:
+        run.drain()
+        raise SystemExit("bench.py: steady state not reached in %d pre-roll frames (clones %d of sw_size %d, msckf updates %d): no value printed"
+                         % (n_max, len(run.be.clones()), sw_size, run.be.counters()["msckf"]))
+    run.be.profile(True)
+    u0 = run.be.counters(); u0 = u0["hybrid"] + u0["msckf"]
+    hp = None
+    while run.i < n_max:
+        feed()
+        if run.i % 4 == 0:
+            run.drain()
+            c = run.be.counters()
+            if c["hybrid"] + c["msckf"] - u0 >= 2 * extra_updates:       # hybrid + pruning update per message in the steady state
+                break
+    run.drain()
+    hp = run.be.profile(False)
+    if hp["launches"] < extra_updates:
+        raise SystemExit("bench.py: only %d bracketed H P launches in the pre-roll (need %d): no value printed" % (hp["launches"], extra_updates))
+    return run.i, hp
+
+
+def timed(run, frames, d_frames, W, K, dist, torch):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns a dict of measurements."""
+    fsz = frames.shape[1] * frames.shape[2]; stride = frames.shape[2]
+
+    def feed():
+        i = run.i
+        if d_frames is not None:
+            return run.step(dev_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
+        return run.step(host_img=frames[i])
+    for _ in range(W):
+        feed()
+    run.drain()
+    if not run.sequential:
+        run.drv.stats(reset=True); run.drv.latencies(reset=True)
+    pl0, it0 = run.fe.lk_stats()
+    c0 = run.be.counters()
+    run.fe.profile_enable(1 << 2)                        # HIP events around the LK launches only (dominant kernel family)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    lat = np.empty(K); n_msgs = 0; n_tracks = []; upd_mask = np.zeros(K, bool)
+    lat = np.empty(K); msg_mask = np.zeros(K, bool)
     t_begin = time.perf_counter()
     for k in range(K):
         t0 = time.perf_counter()
-        have, upd = step(W + k)
+        msg_mask[k] = feed()
         lat[k] = time.perf_counter() - t0
-        n_msgs += int(have); upd_mask[k] = upd
-    if not args.sequential:
-        drv.drain()                                      # every queued filter update has completed
-    ctx.sync(); ctx_be.sync()
+    run.drain()                                          # every queued filter update has completed
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -178,85 +198,234 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = fe.profile_read()
-    pl1, it1 = fe.lk_stats()
-    pst = None if args.sequential else drv.stats()
+    prof = run.fe.profile_read()
+    pl1, it1 = run.fe.lk_stats()
+    c1 = run.be.counters()
+    out = dict(elapsed=elapsed, lat=lat, msg_mask=msg_mask, lk_pl=pl1 - pl0, lk_it=it1 - it0, lk_prof=prof["lk_fwd_rev"],
+               n_updates=(c1["hybrid"] + c1["msckf"]) - (c0["hybrid"] + c0["msckf"]), n_hybrid=c1["hybrid"] - c0["hybrid"], n_msckf=c1["msckf"] - c0["msckf"],
+               pst=None, e2e=None)
+    if not run.sequential:
+        out["pst"] = run.drv.stats()
+        e2e = lat.copy() * 1e6                           # image-in -> state-out: front-end completion, or the end of the update it triggered
+        pl = run.drv.latencies()
+        idx = np.flatnonzero(msg_mask)
+        n = min(len(pl), len(idx))
+        e2e[idx[:n]] = pl[:n]
+        out["e2e"] = e2e * 1e-6
+    else:
+        out["e2e"] = lat.copy()
+    run.fe.profile_enable(0)
+    return out
+
+
+def cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_sample, all_cpus):
+    """The CPU oracle (a restatement: kind "port") on this box's host cores: pre-roll with all cores (untimed, same results for any
+    thread count), then n_sample steady-state frames on ONE thread (LARVIO is single-threaded) and the next n_sample frames with
+    the loops over rows / tiles / tracks / key points spread over all cores."""
+    from oracle import lvo, lvo_be
+    if hasattr(os, "sched_setaffinity") and all_cpus:
+        try:
+            os.sched_setaffinity(0, all_cpus)
+        except OSError:
+            pass
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ora = lvo.Frontend(wl["fcfg"]); orb = lvo_be.Ekf(wl["bcfg"])
+    st = dict(lo=0, inited=False)
+
+    def one(i):
+        buf = imu_all[st["lo"]:his[i]]
+        if not st["inited"] and i >= 1:
+            k = int(np.searchsorted(imu_all["t"], ts[i], side="right")) - 1
+            t_i = imu_all["t"][k]; tr = seq.traj
+            orb.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            st["inited"] = True
+        ta = time.perf_counter()
+        have, m = ora.process(frames[i], float(ts[i]), buf)
+        tb = time.perf_counter()
+        if have:
+            ok, used = orb.process(float(ts[i]), m, buf); st["lo"] += used
+        return tb - ta, time.perf_counter() - tb
+    lvo.set_threads(min(ncores, 64))
+    for i in range(n_pre):
+        one(i)
+    legs = {}
+    i = n_pre
+    for name, nt in (("one_thread", 1), ("all_cores", ncores)):
+        lvo.set_threads(nt)
+        c_fe = c_be = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n_sample):
+            a, b = one(i); c_fe += a; c_be += b; i += 1
+        dt = time.perf_counter() - t0
+        legs[name] = dict(value=round(n_sample / dt, 2), cores=nt, seconds=round(dt, 2), front_end_ms_per_frame=round(c_fe / n_sample * 1e3, 3),
+                          back_end_ms_per_frame=round(c_be / n_sample * 1e3, 3))
+    lvo.set_threads(1)
+    dim_cpu = orb.dim
+    one_t = legs["one_thread"]
+    return {"value": one_t["value"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "front_end_ms_per_frame": one_t["front_end_ms_per_frame"], "back_end_ms_per_frame": one_t["back_end_ms_per_frame"],
+            "all_cores": {"value": legs["all_cores"]["value"], "cores": ncores, "front_end_ms_per_frame": legs["all_cores"]["front_end_ms_per_frame"],
+                          "back_end_ms_per_frame": legs["all_cores"]["back_end_ms_per_frame"],
+                          "note": "OpenMP over image rows, CLAHE tiles, tracks, key points and the dense update's rows/columns; bit-identical results"},
+            "state_dim": dim_cpu, "host": cpu_model(),
+            "sample": "%d steady-state frames of the same synthetic sequence per leg (window full after a %d-frame pre-roll; %.1f s + %.1f s of CPU work), "
+                      "CPU oracle front-end + back-end: 1 thread (LARVIO is single-threaded), then all %d cores; a restatement, not the Eigen/OpenCV build"
+                      % (n_sample, n_pre, one_t["seconds"], legs["all_cores"]["seconds"], ncores)}
+
+
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps right before the timed ones (the window is already full: see the pre-roll)")
+    ap.add_argument("--config", default="A", choices=["A", "3", "4", "5"], help="BASELINE.json configs[1..4]; the metric is quoted on A")
+    ap.add_argument("--sw-size", type=int, default=None)
+    ap.add_argument("--max-features", type=int, default=None, help="tracker budget")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=None, help="steady-state frames per CPU leg (default 300 at A/3/4, 24 at 5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-device-pass", action="store_true", help="skip the second (device-resident) pass")
+    ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
+    ap.add_argument("--sharded", action="store_true", help="config 5 across ranks: per-rank feature rows, RCCL all-gather of the compressed R")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.sharded and args.config != "5":
+        raise SystemExit("--sharded is the configs[4] path (2000 tracks): use --config 5")
+
+    from larvio_amd import synthetic as S
+    wl = S.workload(args.config, args.max_features, args.sw_size)
+    K, W = args.steps, args.warmup
+    sw = wl["sw_size"]
+    n_pre_max = 2 * sw + 40 + 48                         # fill (one clone per message, every other frame) + cycle + 20 bracketed updates
+    n_cpu = 0 if (args.no_cpu_baseline or world > 1) else (args.cpu_baseline_frames or (24 if args.config == "5" else 300))
+    n_frames = n_pre_max + max(W + K, 2 * n_cpu) + 2
+    first = int(2.0 * wl["img_rate"])                    # t = 2.0 s: the trajectory is moving
+    all_cpus = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+    seed_off = 0 if args.sharded else rank               # sharded: every rank sees the same camera
+    procs = max(1, min(32, (len(all_cpus) or os.cpu_count() or 1) // max(world, 1)))
+    ts, frames = S.render_frames(first, n_frames, cam=wl["cam"], seed=S.MASTER_SEED + seed_off, img_rate=wl["img_rate"], procs=procs)
+    seq = S.imu_only_sequence(S.MASTER_SEED + seed_off, cam=wl["cam"])
+    k_lo = max(int(ts[0] * 200) - 4, 0)
+    imu_all = seq.imu_array(k_lo, int(ts[-1] * 200) + 40)
+
+    bind_one_socket()
+    # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    shard = None
+    if args.sharded:
+        from larvio_amd import sharding
+        shard = sharding.make_shard(rank, world, dist, local_rank)
+
+    stream = torch.cuda.current_stream()
+    # ---- pass 1 (headline): host images, H2D inside the timed region
+    run = Run(wl, args, local_rank, imu_all, seq, ts, args.sequential, torch_stream=stream.cuda_stream, shard=shard)
+    n_pre, hp = preroll(run, frames, None, n_pre_max, sw, 20)
+    m = timed(run, frames, None, W, K, dist, torch)
+    state_dim = run.be.dim; n_clones = len(run.be.clones()); counters = run.be.counters(); live = int(len(run.fe.tracks()["ids"]))
+    run.close()
+    # ---- pass 2: the same frames already resident in HBM (camera DMA case)
+    md = None
+    if not args.no_device_pass:
+        d_frames = torch.from_numpy(frames[:n_pre_max + W + K + 2]).cuda()
+        run2 = Run(wl, args, local_rank, imu_all, seq, ts, args.sequential, torch_stream=stream.cuda_stream, shard=shard)
+        while run2.i < n_pre:                            # same pre-roll length as pass 1: the timed frames are the same frames
+            i = run2.i
+            run2.step(dev_ptr=d_frames.data_ptr() + i * frames.shape[1] * frames.shape[2], stride=frames.shape[2])
+        md = timed(run2, frames, d_frames, W, K, dist, torch)
+        run2.close()
+        del d_frames
 
     if rank == 0:
+        win = wl["fcfg"]["patch_size"]
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
-        win = cfg["patch_size"]
-        lk_bytes = (pl1 - pl0) * (win + 3) ** 2 + (it1 - it0) * (win + 1) ** 2
-        lk_ms = prof["lk_fwd_rev"][0]
-        lk_launches = prof["lk_fwd_rev"][1]
+        lk_bytes = m["lk_pl"] * (win + 3) ** 2 + m["lk_it"] * (win + 1) ** 2
+        lk_ms, lk_launches = m["lk_prof"]
         achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_launches, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         # HBM traffic per launch: not measurable inside this process (PMC needs rocprofv3) - taken from the committed counter pass
-        # of this same command (profiles/*_pmc_fetch_size.csv, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        # of this same command (profiles/*_pmc_fetch_size.csv; FETCH_SIZE corrected as profiles/README.md's calibration states)
         traffic, traffic_src = None, None
         import glob
-        pm = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_fetch_size.csv")))
+        tag = "c5" if args.config == "5" else "a"
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_fetch_size.csv" % tag))) or \
+             (sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_size.csv"))) if args.config == "A" else [])
         if pm:
             with open(pm[-1]) as f:
                 rows = [l.strip().split(",") for l in f.readlines()[1:]]
             lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_lk_")]
             if lk:
                 traffic = round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1); traffic_src = os.path.basename(pm[-1])
-        roofline = {"kernel": "k_fe_lk_both<21> (forward + reverse LK of every track)", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+        roofline = {"kernel": "k_fe_lk_both<%d> (forward + reverse LK of every track)" % win, "bound": "hbm", "achieved": round(achieved, 3),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
                     "launches": lk_launches}
-        # ---- CPU baseline: the oracle (a restatement, "port") on this box's host cores, 1 thread, bounded sample
-        from oracle import lvo, lvo_be
-        nb = min(args.cpu_baseline_frames, K + W) if world == 1 else 0       # rank 0 at N = 1 only
-        ora = lvo.Frontend(cfg); orb = lvo_be.Ekf(bcfg)
-        lo, inited, c_fe, c_be = 0, False, 0.0, 0.0
-        t0 = time.perf_counter()
-        for i in range(nb):
-            buf = imu_all[lo:his[i]]
-            if not inited and i >= 1:
-                k = int(np.searchsorted(imu_all["t"], ts[i], side="right")) - 1
-                t_i = imu_all["t"][k]; tr = seq.traj
-                orb.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
-                inited = True
-            ta = time.perf_counter()
-            have, m = ora.process(frames[i], float(ts[i]), buf)
-            tb = time.perf_counter(); c_fe += tb - ta
-            if have:
-                ok, used = orb.process(float(ts[i]), m, buf); lo += used
-                c_be += time.perf_counter() - tb
-        cpu_s = time.perf_counter() - t0
-        cpu_baseline = None if nb == 0 else {"value": round(nb / cpu_s, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                        "front_end_ms_per_frame": round(c_fe / nb * 1e3, 3), "back_end_ms_per_frame": round(c_be / nb * 1e3, 3),
-                        "sample": f"the first {nb} frames of the same synthetic sequence ({cpu_s:.1f} s of CPU work), CPU oracle front-end + back-end, "
-                                  f"1 thread of {os.cpu_count()} (LARVIO is single-threaded); a restatement, not the Eigen/OpenCV build"}
-        value = world * K / elapsed
-        out = {"metric": "VIO frames/sec (752x480, ~150 tracks, 30-clone window)", "value": round(value, 2), "unit": "frames/s",
-               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
-               "p50_ms_per_frame": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_frame": round(float(np.percentile(lat, 95)) * 1e3, 4),
-               "p50_ms_frame_without_update": round(float(np.median(lat[~upd_mask])) * 1e3, 4) if (~upd_mask).any() else None,
-               "p50_ms_frame_with_update": round(float(np.median(lat[upd_mask])) * 1e3, 4) if upd_mask.any() else None,
+        cpu = None
+        if n_cpu:
+            his = [int(np.searchsorted(imu_all["t"], float(t) + 0.05, side="left")) for t in ts]
+            cpu = cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_cpu, all_cpus)
+        value = world * K / m["elapsed"]
+        lat, e2e = m["lat"], m["e2e"]; mm = m["msg_mask"]; pst = m["pst"]
+
+        def pct(a, q):
+            return round(float(np.percentile(a, q)) * 1e3, 4) if len(a) else None
+        metric = "VIO frames/sec (%dx%d, %d live tracks, %d-clone window)" % (wl["cam"]["width"], wl["cam"]["height"], live, n_clones)
+        out = {"metric": metric, "value": round(value, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(m["elapsed"] / K * 1e3, 4),
+               "p50_ms_per_frame": pct(e2e, 50), "p95_ms_per_frame": pct(e2e, 95),
+               "p50_ms_frame_without_message": pct(e2e[~mm], 50), "p50_ms_frame_with_message": pct(e2e[mm], 50), "p95_ms_frame_with_message": pct(e2e[mm], 95),
+               "latency_definition": "image-in -> state-out per frame: front-end completion for frames without a feature message, the end of the "
+                                     "filter update the frame triggered otherwise (host wall time, lvk_vio_pipe_latency)",
+               "p50_ms_front_end_completion": pct(lat, 50),
                "front_end_ms_per_frame": None if pst is None else round(pst["front_end_us"] / K * 1e-3, 4),
-               "back_end_ms_per_update": None if pst is None else round(pst["filter_us"] / max(state["n_be"], 1) * 1e-3, 4),
+               "back_end_ms_per_message": None if pst is None else round(pst["filter_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
                "caller_wait_ms_per_frame": None if pst is None else round(pst["caller_wait_us"] / K * 1e-3, 4),
-               "worker_idle_ms_per_update": None if pst is None else round(pst["worker_idle_us"] / max(state["n_be"], 1) * 1e-3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
+               "worker_idle_ms_per_message": None if pst is None else round(pst["worker_idle_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
+               "device_resident": None if md is None else {"value": round(world * K / md["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(md["elapsed"] / K * 1e3, 4),
+                                                           "p50_ms_per_frame": pct(md["e2e"], 50),
+                                                           "note": "same frames, already in HBM when the timed region starts (no staging copy, no H2D)"},
+               "higher_is_better": True, "scaling": ("strong" if args.sharded else "weak"), "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
-               "config": {"workload": "configs[1] shape: EuRoC-shaped synthetic 752x480 @20Hz, max_features %d, pyramid 3 levels, win 21, pub 10 Hz" % args.max_features,
+               "config": {"workload": wl["label"] + ", pyramid 3 levels, win %d, pub %g Hz" % (win, wl["fcfg"]["pub_frequency"]),
+                          "input": "host images (pageable numpy, as a cv::Mat): staging copy + H2D inside the timed region",
                           "schedule": ("sequential: one blocking lvk_vio_process per frame" if args.sequential else
                                        "pipelined: filter update of frame k (own stream + worker thread) overlaps the front-end of frames k+1..; "
-                                       "identical results (tests/test_gpu_vio_driver.py); per-frame times are front-end completion times, "
-                                       "all updates drained inside the timed region"),
-                          "stages": "processImage every frame + processFeatures on every feature message (10 Hz), as app/larvioMain.cpp:106-116",
-                          "sw_size": args.sw_size, "state_dim": be.dim, "backend": be.counters(),
-                          "live_tracks": int(len(fe.tracks()["ids"])), "messages": n_msgs,
-                          "parallelism": "replicas x%d" % world},
+                                       "identical results (tests/test_gpu_vio_driver.py); all updates drained inside the timed region"),
+                          "stages": "processImage every frame + processFeatures on every feature message, as app/larvioMain.cpp:106-116",
+                          "pre_roll_frames": n_pre, "sw_size": sw, "clones": n_clones, "state_dim": state_dim, "backend": counters,
+                          "timed_region": {"messages": int(mm.sum()), "hybrid_updates": m["n_hybrid"], "msckf_pruning_updates": m["n_msckf"]},
+                          "live_tracks": live,
+                          "parallelism": ("sharded x%d: contiguous feature ranges per rank, RCCL all-gather of the packed R factors" % world) if args.sharded
+                                         else "replicas x%d" % world},
                "roofline": roofline,
                # the one GEMM-shaped contraction of the path (P H^T as H P, FP64 MFMA 16x16x4): utilisation against the dense FP64 matrix peak
                "roofline_mfma": {"kernel": "k_dgemm<false,false> (H P)", "bound": "mfma", "achieved": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9, 4),
                                  "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 6),
                                  "flops_per_launch": round(hp["flops"] / max(hp["launches"], 1), 1),
                                  "avg_launch_us": round(hp["ms"] / max(hp["launches"], 1) * 1e3, 3), "launches": hp["launches"],
-                                 "measured_over": "the second half of the warm-up frames (same workload; kept out of the timed region)"},
-               "cpu_baseline": cpu_baseline}
+                                 "measured_over": "the last >= 20 updates of the pre-roll (window full and cycling; kept out of the timed region: "
+                                                  "its event records would add ~10% to the filter chain)"},
+               "cpu_baseline": cpu}
+        if cpu:
+            out["x_cpu_one_thread"] = round(value / cpu["value"], 2)
+            out["x_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 2)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

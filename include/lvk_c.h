@@ -38,6 +38,10 @@ typedef struct lvk_pyramid  lvk_pyramid;
 typedef struct lvk_frontend lvk_frontend;
 
 typedef struct { float x, y; } lvk_pt2f;
+/* One 8-bit grey image as the reference's ImageData carries it (include/sensors/ImageData.hpp: a cv::Mat knows its own size and
+ * step).  stride = bytes between rows (cv::Mat::step); is_device: 0 = data is a host pointer (copied in through the front-end's
+ * pinned staging, the caller may reuse the buffer as soon as the call returns), 1 = data is a device pointer. */
+typedef struct { const uint8_t* data; int width, height, stride; int is_device; } lvk_image;
 /* include/sensors/ImuData.hpp:17-43 */
 typedef struct { double t; double gyro[3]; double acc[3]; } lvk_imu;
 /* include/larvio/feature_msg.h:15-44 (MonoFeatureMeasurement, 72 bytes) */
@@ -137,9 +141,10 @@ typedef struct {
 
 lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_frontend** out);
 void       lvk_frontend_destroy(lvk_frontend* fe);
-/* img_is_device: 0 = img is a host pointer (copied in), 1 = device pointer.
- * h_out receives up to cap features when *has_msg = 1 (the reference's `return haveFeatures`). */
-lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device,
+/* img->width/height must equal the configured resolution and img->stride >= width (LVK_ERR_ARG otherwise: the reference cannot
+ * read past a cv::Mat, neither does this).  h_out receives up to cap features when *has_msg = 1 (the reference's
+ * `return haveFeatures`). */
+lvk_status lvk_frontend_process(lvk_frontend* fe, const lvk_image* img,
                                 double ts, const lvk_imu* h_imu, int n_imu,
                                 lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg);
 /* introspection (synchronises): live tracks after the last call = the reference's
@@ -182,11 +187,11 @@ typedef struct {
     int if_fej, estimate_extrin, estimate_td, if_zupt_valid;
     int sw_size, max_track_len, least_observation_number;
     int max_features_in_one_grid, aug_grid_rows, aug_grid_cols;
-    int pub_frequency, imu_rate;
     int width, height;
     double intrinsics[4];
     double T_cam_imu[16];
     double td;
+    double pub_frequency, imu_rate;   /* features_rate / imu_rate are doubles in the reference (larvio.h:256-259, larvio.cpp:65-67,224) */
     double noise_gyro, noise_acc, noise_gyro_bias, noise_acc_bias, noise_feature;      /* standard deviations */
     double initial_covariance_orientation, initial_covariance_velocity, initial_covariance_position,
            initial_covariance_gyro_bias, initial_covariance_acc_bias, initial_covariance_extrin_rot, initial_covariance_extrin_trans;
@@ -258,7 +263,7 @@ lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* h_clones, i
  * (app/larvioMain.cpp:104-116: processImage, then processFeatures when it returned true), with the driver's IMU buffer
  * semantics (samples with t < t_img + 0.05 are visible, processFeatures erases what it consumed, :98-102 and larvio.cpp:511-512).
  * h_imu[0..n_imu) is the CURRENT buffer; *n_consumed tells the caller how many leading samples to drop. */
-lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, int stride, int img_is_device, double ts,
+lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img, double ts,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated);
 
 /* The same loop, pipelined across two HIP streams: the filter update of frame k (worker thread, ekf's context) overlaps the
@@ -270,7 +275,7 @@ typedef struct lvk_vio_pipe lvk_vio_pipe;
 lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** out);
 void       lvk_vio_pipe_destroy(lvk_vio_pipe* p);
 lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n);
-lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, int img_is_device, double ts, int* has_msg);
+lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts, int* has_msg);
 lvk_status lvk_vio_pipe_drain(lvk_vio_pipe* p, long* n_updates, long* n_msgs);
 /* Called on the filter's thread after every update that processFeatures would have answered with true — the point at which the
  * reference's drivers publish odometry (app/larvioMain.cpp:117-, ros_wrapper System.cpp:177-193).  ts = the message's stamp,
@@ -281,6 +286,10 @@ lvk_status lvk_vio_pipe_on_update(lvk_vio_pipe* p, lvk_odometry_fn fn, void* use
 /* host wall time in microseconds since the last reset: [0] caller thread inside the front-end, [1] caller waiting for an erase
  * count, [2] worker inside filter updates, [3] worker waiting for a message */
 lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* h_out4, int reset);
+/* image-in -> state-out latency (microseconds of host wall time, entry of lvk_vio_pipe_submit to the end of the update it triggered)
+ * of every frame that produced a feature message since the last reset, in order; *n_out <= cap entries are written.  For a VIO this
+ * is the latency that matters (the reference's timing window app/larvioMain.cpp:106-116 spans both calls). */
+lvk_status lvk_vio_pipe_latency(lvk_vio_pipe* p, float* h_out_us, int cap, int* n_out, int reset);
 
 #ifdef __cplusplus
 }

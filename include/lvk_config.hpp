@@ -199,7 +199,7 @@ inline bool load_ekf_config(const ConfigFile& f, lvk_ekf_config* c, std::string*
     c->least_observation_number = f.integer("least_observation_number");
     c->max_features_in_one_grid = f.integer("max_features_in_one_grid");
     c->aug_grid_rows = f.integer("aug_grid_rows"); c->aug_grid_cols = f.integer("aug_grid_cols");
-    c->pub_frequency = f.integer("pub_frequency"); c->imu_rate = f.integer("imu_rate");
+    c->pub_frequency = f.real("pub_frequency"); c->imu_rate = f.real("imu_rate");
     c->width = f.integer("resolution_width"); c->height = f.integer("resolution_height");
     static const char* ik[4] = {"intrinsics.fx", "intrinsics.fy", "intrinsics.cx", "intrinsics.cy"};
     for (int i = 0; i < 4; ++i) c->intrinsics[i] = f.real(ik[i]);

@@ -66,7 +66,8 @@ public:
         if (!fe_ || !features) return false;
         int n = 0, has = 0;
         const lvk_imu* imu = imu_msg_buffer.empty() ? nullptr : reinterpret_cast<const lvk_imu*>(imu_msg_buffer.data());
-        if (lvk_frontend_process(fe_, msg.data, msg.step, /*img_is_device=*/0, msg.timeStampToSec, imu, (int)imu_msg_buffer.size(),
+        const lvk_image im = {msg.data, msg.width, msg.height, msg.step, /*is_device=*/0};     // a cv::Mat's own size and step
+        if (lvk_frontend_process(fe_, &im, msg.timeStampToSec, imu, (int)imu_msg_buffer.size(),
                                  out_.data(), (int)out_.size(), &n, &has) != LVK_OK) {
             std::fprintf(stderr, "ImageProcessor::processImage: %s\n", lvk_last_error(ctx_));
             return false;
@@ -211,7 +212,8 @@ public:
     bool processImage(const ImageData& msg)
     {
         int has = 0;
-        if (!pipe_ || lvk_vio_pipe_submit(pipe_, msg.data, msg.step, 0, msg.timeStampToSec, &has) != LVK_OK) return false;
+        const lvk_image im = {msg.data, msg.width, msg.height, msg.step, /*is_device=*/0};
+        if (!pipe_ || lvk_vio_pipe_submit(pipe_, &im, msg.timeStampToSec, &has) != LVK_OK) return false;
         return has != 0;
     }
     bool drain(long* n_updates = nullptr, long* n_msgs = nullptr) { return pipe_ && lvk_vio_pipe_drain(pipe_, n_updates, n_msgs) == LVK_OK; }

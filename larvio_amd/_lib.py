@@ -27,13 +27,32 @@ ABI_SYMBOLS = [
     "lvk_frontend_stage_name",
     "lvk_ekf_compress_qr", "lvk_ekf_update", "lvk_dgemm", "lvk_ekf_create", "lvk_ekf_destroy", "lvk_ekf_process", "lvk_ekf_set_state",
     "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_take_off_stamp", "lvk_ekf_get_state", "lvk_ekf_get_imu_intrinsics", "lvk_ekf_set_imu_intrinsics", "lvk_ekf_get_cov", "lvk_ekf_get_clones", "lvk_ekf_get_features", "lvk_ekf_take_lost_features",
-    "lvk_ekf_counters", "lvk_ekf_profile", "lvk_triangulate", "lvk_ekf_gate_and_stack", "lvk_vio_process", "lvk_vio_pipe_create", "lvk_vio_pipe_destroy", "lvk_vio_pipe_push_imu", "lvk_vio_pipe_submit", "lvk_vio_pipe_drain", "lvk_vio_pipe_on_update", "lvk_vio_pipe_stats",
+    "lvk_ekf_counters", "lvk_ekf_profile", "lvk_triangulate", "lvk_ekf_gate_and_stack", "lvk_vio_process", "lvk_vio_pipe_create", "lvk_vio_pipe_destroy", "lvk_vio_pipe_push_imu", "lvk_vio_pipe_submit", "lvk_vio_pipe_drain", "lvk_vio_pipe_on_update", "lvk_vio_pipe_stats", "lvk_vio_pipe_latency",
 ]
 FE_STAGES = 9
 
 
 class LvkError(RuntimeError):
     pass
+
+
+class Image(C.Structure):
+    """lvk_image: pointer + the size and step a cv::Mat carries (include/lvk_c.h)"""
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("is_device", C.c_int)]
+
+
+def make_image(img=None, device_ptr=None, stride=None, shape=None):
+    """lvk_image for a host array (H, W) uint8 — or for a device pointer with an explicit (H, W) shape and row stride.
+    Returns (Image, keepalive): hold the second value until the call that consumes the image has returned."""
+    if device_ptr is not None:
+        h, w = shape
+        return Image(int(device_ptr), int(w), int(h), int(stride if stride is not None else w), 1), None
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim != 2:
+            raise ValueError("image must be a 2-D uint8 array")
+    return Image(img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], 0), img
 
 
 class FeConfig(C.Structure):
@@ -75,7 +94,7 @@ def lib():
             "lvk_ransac_fundamental": ([vp, vp, vp, i, d, d, i, vp, vp], i),
             "lvk_predict_homography": ([vp, i, d, d, vp, vp, vp], i),
             "lvk_frontend_create": ([vp, C.POINTER(FeConfig), C.POINTER(vp)], i), "lvk_frontend_destroy": ([vp], None),
-            "lvk_frontend_process": ([vp, vp, i, i, d, vp, i, vp, i, pi, pi], i),
+            "lvk_frontend_process": ([vp, C.POINTER(Image), d, vp, i, vp, i, pi, pi], i),
             "lvk_frontend_tracks": ([vp, vp, vp, vp, vp, vp, i, pi], i),
             "lvk_frontend_new_pts": ([vp, vp, i, pi], i), "lvk_frontend_state": ([vp], i),
             "lvk_frontend_lk_stats": ([vp, vp, vp], i),

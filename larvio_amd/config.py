@@ -101,8 +101,8 @@ def load_config(path):
     be = dict(if_fej=1 if _int(d, "if_FEJ") else 0, estimate_extrin=1 if _int(d, "estimate_extrin") else 0, estimate_td=1 if _int(d, "estimate_td") else 0,
               if_zupt_valid=1 if _int(d, "if_ZUPT_valid") else 0, sw_size=_int(d, "sw_size"), max_track_len=_int(d, "max_track_len"),
               least_observation_number=_int(d, "least_observation_number"), max_features_in_one_grid=_int(d, "max_features_in_one_grid"),
-              aug_grid_rows=_int(d, "aug_grid_rows"), aug_grid_cols=_int(d, "aug_grid_cols"), pub_frequency=_int(d, "pub_frequency"),
-              imu_rate=_int(d, "imu_rate"), width=fe["width"], height=fe["height"], intrinsics=intr, T_cam_imu=T, td=_num(d, "td"),
+              aug_grid_rows=_int(d, "aug_grid_rows"), aug_grid_cols=_int(d, "aug_grid_cols"), pub_frequency=_num(d, "pub_frequency"),
+              imu_rate=_num(d, "imu_rate"), width=fe["width"], height=fe["height"], intrinsics=intr, T_cam_imu=T, td=_num(d, "td"),
               feature_idp_dim=_int(d, "feature_idp_dim"), use_schmidt=1 if _int(d, "use_schmidt") else 0,
               calib_imu_instrinsic=1 if _int(d, "calib_imu_instrinsic") else 0, max_features=fe["max_features_num"])
     for k in ("noise_gyro", "noise_acc", "noise_gyro_bias", "noise_acc_bias", "noise_feature", "initial_covariance_orientation",

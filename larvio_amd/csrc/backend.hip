@@ -102,6 +102,7 @@ struct lvk_ekf {
     int static_counter = 0, static_num = 0; double lower_time_bound = 0;
     std::map<long long, std::pair<double, double>> init_features;
     long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    lvk_status failed = LVK_OK; char failed_msg[256] = {0};   // sticky: set by the first lvk_ekf_process that returned an error
     // per-frame composed transition (processModel): Phi_tot, Q_tot
     double Phi_tot[LEG_MAX * LEG_MAX], Q_tot[LEG_MAX * LEG_MAX]; bool have_prop = false;
     // device
@@ -530,8 +531,8 @@ static lvk_status state_augmentation(lvk_ekf* e)
         for (int i = 0; i < 3; ++i) c.p_cam[i] = e->s.p[i] + t[i];
     }
     const int pose_rows = LEG + 6 * (int)e->clones.size();
-    e->clones.push_back(c); e->ranks_dirty = true;
     if (e->N + 6 > e->nmax) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "state dimension %d exceeds capacity %d", e->N + 6, e->nmax);
+    e->clones.push_back(c); e->ranks_dirty = true;
     static const int sel[6] = {0, 1, 2, 6, 7, 8};
     std::vector<int> idx; idx.reserve(e->N + 6);
     for (int i = 0; i < pose_rows; ++i) idx.push_back(i);
@@ -1455,10 +1456,26 @@ lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const doub
     return LVK_OK;
 }
 
+static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated);
+
 lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated)
 {
     if (!e || !n_consumed || !updated || (n_feats > 0 && !feats) || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
     *n_consumed = 0; *updated = 0;
+    // An update that failed half way (capacity, device error) leaves clone list, feature map and covariance layout out of step with
+    // each other: the handle stays failed and says so, instead of computing on with wrong column offsets.
+    if (e->failed != LVK_OK) return lvk_set_error(e->ctx, e->failed, "lvk_ekf_process: the filter is in a failed state after an earlier error (%s); destroy and re-create it", e->failed_msg);
+    const lvk_status st = ekf_process_impl(e, ts, feats, n_feats, imu, n_imu, n_consumed, updated);
+    if (st != LVK_OK) {
+        e->failed = st;
+        snprintf(e->failed_msg, sizeof e->failed_msg, "%s", e->ctx->err);
+        hipStreamSynchronize(e->ctx->stream);            // queued kernels may still read the pinned upload arena the next call would reset
+    }
+    return st;
+}
+
+static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated)
+{
     struct Notify {                                     // every return path reports the consumption exactly once
         lvk_ekf* e; int* n; bool fired = false;
         void fire() { if (!fired) { fired = true; if (e->on_consumed) e->on_consumed(e->on_consumed_user, *n); } }
@@ -1572,7 +1589,7 @@ int lvk_ekf_take_lost_features(lvk_ekf* e, int64_t* ids, double* pos_w, int cap)
 }
 void lvk_ekf_counters(const lvk_ekf* e, long* out8) { if (e && out8) memcpy(out8, e->counters, sizeof e->counters); }
 
-lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, int stride, int img_is_device, double ts,
+lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img, double ts,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated)
 {
     if (!fe || !ekf || !n_consumed || !has_msg || !updated) return LVK_ERR_ARG;
@@ -1580,7 +1597,7 @@ lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const uint8_t* img, i
     static thread_local std::vector<lvk_feature_obs> msg;
     if (msg.size() < 8192) msg.resize(8192);
     int n_out = 0;
-    lvk_status st = lvk_frontend_process(fe, img, stride, img_is_device, ts, h_imu, n_imu, msg.data(), (int)msg.size(), &n_out, has_msg);
+    lvk_status st = lvk_frontend_process(fe, img, ts, h_imu, n_imu, msg.data(), (int)msg.size(), &n_out, has_msg);
     if (st != LVK_OK || !*has_msg) return st;
     return lvk_ekf_process(ekf, ts, msg.data(), n_out, h_imu, n_imu, n_consumed, updated);
 }
@@ -1597,7 +1614,8 @@ static double now_us_fwd();
 struct lvk_vio_pipe {
     lvk_frontend* fe; lvk_ekf* ekf;
     std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..)
-    struct Job { double ts; std::vector<lvk_feature_obs> feats; std::vector<lvk_imu> view; bool precounted = false; };
+    struct Job { double ts; std::vector<lvk_feature_obs> feats; std::vector<lvk_imu> view; bool precounted = false; double t_submit = 0; };
+    std::vector<float> lat_us;                          // image-in -> state-out of every message-carrying frame (submit entry to update done)
     bool cur_precounted = false;                        // the running job's erase count was already applied by submit()
     std::deque<Job> q;
     std::thread worker; std::mutex mu; std::condition_variable cv_job, cv_state;
@@ -1672,7 +1690,9 @@ static void pipe_worker(lvk_vio_pipe* p)
         if (st == LVK_OK && upd && p->on_update) { double s30[30]; lvk_ekf_get_state(p->ekf, s30); p->on_update(p->on_update_user, job.ts, s30); }
         {
             std::lock_guard<std::mutex> lk(p->mu);
-            p->t_idle += t1 - t0; p->t_busy += now_us() - t1; p->ev(6);
+            const double t2 = now_us();
+            p->t_idle += t1 - t0; p->t_busy += t2 - t1; p->ev(6);
+            if (p->lat_us.size() < (size_t)1 << 20) p->lat_us.push_back((float)(t2 - job.t_submit));
             if (st != LVK_OK && p->st == LVK_OK) p->st = st;
             p->n_updates += upd; p->in_flight -= 1;
             p->gen.fetch_add(1, std::memory_order_release);
@@ -1717,14 +1737,14 @@ lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n)
     return LVK_OK;
 }
 
-lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, int img_is_device, double ts, int* has_msg)
+lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts, int* has_msg)
 {
     if (!p || !has_msg) return LVK_ERR_ARG;
     *has_msg = 0;
     size_t head, end;
     // the image stage (upload, pyramid, ORB planes) does not look at the IMU buffer: queue it before waiting for the erase count
     const double tb = now_us();
-    lvk_status st0 = lvk_frontend_begin(p->fe, img, stride, img_is_device, ts);
+    lvk_status st0 = lvk_frontend_begin(p->fe, img, ts);
     if (st0 != LVK_OK) return st0;
     const double t0 = now_us();
     p->t_fe += t0 - tb;
@@ -1732,7 +1752,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
         std::unique_lock<std::mutex> lk(p->mu);
         p->ev(0);
         pipe_wait(p, lk, p->cv_state, [&] { return p->unknown_consume == 0; });
-        if (p->st != LVK_OK) { lvk_frontend_release_image(p->fe); return p->st; }
+        if (p->st != LVK_OK) return p->st;
         head = p->head; end = p->imu.size();
         p->ev(1);
     }
@@ -1740,11 +1760,12 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const uint8_t* img, int stride, 
     p->t_submit_wait += t1 - t0;
     // only this thread appends to imu, and no update can move `head` until a new job is queued below
     int n_out = 0;
-    lvk_status st = lvk_frontend_process(p->fe, img, stride, img_is_device, ts, p->imu.data() + head, (int)(end - head), p->msg.data(), (int)p->msg.size(), &n_out, has_msg);
+    lvk_status st = lvk_frontend_process(p->fe, img, ts, p->imu.data() + head, (int)(end - head), p->msg.data(), (int)p->msg.size(), &n_out, has_msg);
     p->t_fe += now_us() - t1;
     if (p->logging) { std::lock_guard<std::mutex> lk(p->mu); p->ev(2); }
     if (st != LVK_OK || !*has_msg) return st;
     lvk_vio_pipe::Job job;
+    job.t_submit = tb;
     job.ts = ts; job.feats.assign(p->msg.begin(), p->msg.begin() + n_out);
     job.view.assign(p->imu.begin() + (long)head, p->imu.begin() + (long)end);
     {
@@ -1769,6 +1790,17 @@ lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* out4, int reset)
     std::lock_guard<std::mutex> lk(p->mu);
     out4[0] = p->t_fe; out4[1] = p->t_submit_wait; out4[2] = p->t_busy; out4[3] = p->t_idle;
     if (reset) p->t_busy = p->t_idle = p->t_fe = p->t_submit_wait = 0;
+    return LVK_OK;
+}
+
+lvk_status lvk_vio_pipe_latency(lvk_vio_pipe* p, float* h_out_us, int cap, int* n_out, int reset)
+{
+    if (!p || !n_out || (cap > 0 && !h_out_us)) return LVK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    const int n = std::min((int)p->lat_us.size(), cap);
+    for (int i = 0; i < n; ++i) h_out_us[i] = p->lat_us[i];
+    *n_out = n;
+    if (reset) p->lat_us.clear();
     return LVK_OK;
 }
 

@@ -380,8 +380,7 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<true>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
                            d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host);
     } else {
-        static size_t attr_set = 0;
-        if (attr_set < shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_feature_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
+        LVK_LDS_OPTIN(ctx, 1, k_feature_rows<false>, shmem);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<false>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
                            d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host);
     }

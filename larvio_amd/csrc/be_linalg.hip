@@ -197,11 +197,6 @@ __global__ void k_dx_new(const double* __restrict__ H1, int ldh, const double* _
 
 
 // ------------------------------------------------------------------------- blocked Cholesky + forward substitution, multi-workgroup
-// Right-looking, panel width 32, two launches per panel:
-//   k_chol_panel : every workgroup factors the 32x32 diagonal block in LDS (redundantly, it is tiny), then
-//                  S-workgroups solve X = A21 L11^-T for 256 rows each, B-workgroups solve W_p = L11^-1 B_p for 256 columns each
-//   k_chol_update: trailing S22 -= X X^T (lower tiles) and B2 -= X W_p on the FP64 matrix cores (K = 32 => 8 MFMAs per tile)
-// so the O(m^3) work runs on all CUs and the dependent chain is 2*ceil(m/32) short launches instead of one workgroup.
 #define CP_NB 32
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {   // lane is a compile-time constant after unrolling: two v_readlane_b32
@@ -215,119 +210,14 @@ __device__ __forceinline__ double rsqrt_refined(double x)
     y = y * (1.5 - 0.5 * x * y * y);
     return y;
 }
-// One wavefront factors the nb x nb (nb <= 32) diagonal block held in LDS: lane i keeps row i in registers, column j of L is
-// broadcast with v_readlane (all indices compile-time after unrolling), no barriers and no LDS traffic on the pivot chain.
-__device__ __forceinline__ void chol32_wave(double (*Ld)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
-{
-    double a[CP_NB];
-#pragma unroll
-    for (int c = 0; c < CP_NB; ++c) a[c] = (lane < nb && c < nb) ? Ld[lane][c] : ((lane == c) ? 1.0 : 0.0);
-#pragma unroll
-    for (int j = 0; j < CP_NB; ++j) {
-        double piv = readlane_f64(a[j], j);
-        if (!(piv > 0.)) { if (report && lane == 0 && j < nb && info[0] == 0) info[0] = j0 + j + 1; piv = 1.0; }
-        const double rinv = rsqrt_refined(piv);
-        const double l = (lane == j) ? piv * rinv : a[j] * rinv;      // L[i][j]; the diagonal is sqrt(piv)
-        a[j] = l;
-#pragma unroll
-        for (int k = j + 1; k < CP_NB; ++k) { const double lk = readlane_f64(l, k); a[k] -= l * lk; }
-    }
-#pragma unroll
-    for (int c = 0; c < CP_NB; ++c) if (lane < nb && c < nb && c <= lane) Ld[lane][c] = a[c];
-}
-__global__ void __launch_bounds__(256) k_chol_panel(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
-                                                   int j0, int n_sblocks, int* __restrict__ info)
-{
-    __shared__ double Ld[CP_NB][CP_NB + 1];
-    const int t = threadIdx.x;
-    const int nb = min(CP_NB, m - j0);
-    for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; Ld[a][b] = S[(size_t)(j0 + a) * lds_ + j0 + b]; }
-    __syncthreads();
-    if (t < 64) chol32_wave(Ld, nb, t, info, j0, blockIdx.x == 0);
-    __syncthreads();
-    if (blockIdx.x == 0) for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * lds_ + j0 + b] = Ld[a][b]; }
-    if ((int)blockIdx.x < n_sblocks) {
-        const int rix = j0 + nb + blockIdx.x * 256 + t;
-        if (rix < m) {
-            double x[CP_NB];
-            double* arow = S + (size_t)rix * lds_ + j0;
-#pragma unroll
-            for (int c = 0; c < CP_NB; ++c) {                 // compile-time bounds: x[] stays in registers
-                double s = c < nb ? arow[c] : 0.;
-#pragma unroll
-                for (int k = 0; k < c; ++k) s -= x[k] * Ld[c][k];
-                x[c] = c < nb ? s / Ld[c][c] : 0.;
-            }
-#pragma unroll
-            for (int c = 0; c < CP_NB; ++c) if (c < nb) arow[c] = x[c];
-        }
-    } else {
-        const int col = (blockIdx.x - n_sblocks) * 256 + t;
-        if (col < nbcols) {
-            double w[CP_NB];
-#pragma unroll
-            for (int a = 0; a < CP_NB; ++a) {
-                double s = a < nb ? B[(size_t)(j0 + a) * ldb + col] : 0.;
-#pragma unroll
-                for (int k = 0; k < a; ++k) s -= Ld[a][k] * w[k];
-                w[a] = a < nb ? s / Ld[a][a] : 0.;
-            }
-#pragma unroll
-            for (int a = 0; a < CP_NB; ++a) if (a < nb) B[(size_t)(j0 + a) * ldb + col] = w[a];
-        }
-    }
-}
 
-__global__ void __launch_bounds__(256) k_chol_update(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols, int j0)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rest = m - j0 - CP_NB;
-    const int tr = (rest + 15) / 16, tcs = tr, tcb = (nbcols + 15) / 16;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= tr * (tcs + tcb)) return;
-    const int ti = tile / (tcs + tcb), tj = tile - ti * (tcs + tcb);
-    const bool is_s = tj < tcs;
-    if (is_s && tj > ti) return;                               // lower triangle of S only
-    const int i = lane & 15, kk = lane >> 4;
-    const int row0 = j0 + CP_NB + ti * 16;
-    const int ar = row0 + i;
-    d4 acc = {0., 0., 0., 0.};
-    if (is_s) {
-        const int cr = j0 + CP_NB + tj * 16 + i;               // row of X that supplies column (tj*16+i) of X^T
-#pragma unroll
-        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
-            const double a = ar < m ? S[(size_t)ar * lds_ + j0 + k0 + kk] : 0.;
-            const double b = cr < m ? S[(size_t)cr * lds_ + j0 + k0 + kk] : 0.;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + kk + 4 * r, col = j0 + CP_NB + tj * 16 + i;
-            if (row < m && col <= row) S[(size_t)row * lds_ + col] -= acc[r];
-        }
-    } else {
-        const int bc = (tj - tcs) * 16 + i;
-#pragma unroll
-        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
-            const double a = ar < m ? S[(size_t)ar * lds_ + j0 + k0 + kk] : 0.;
-            const double b = bc < nbcols ? B[(size_t)(j0 + k0 + kk) * ldb + bc] : 0.;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + kk + 4 * r, col = (tj - tcs) * 16 + i;
-            if (row < m && col < nbcols) B[(size_t)row * ldb + col] -= acc[r];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------- left-looking variant: ONE launch per 32-column panel
+// Left-looking, ONE launch per 32-column panel.
 // Every workgroup first brings its own piece up to date with all previous panels on the FP64 matrix cores
 // (S rows: A[R, p] -= L[R, 0:j0] L[p, 0:j0]^T ; B columns: B[p, C] -= L[p, 0:j0] W[0:j0, C]) and, redundantly, the 32x32 diagonal
 // block; one wavefront factors the block in registers AND inverts the factor (column c of L11^-1 in lane c, L broadcast with
 // v_readlane); the triangular solves then become two small MFMA products with L11^-1 (X = A L11^-T, W_p = L11^-1 B_p).
-// Compared with the right-looking pair (panel + trailing update) this halves the launches on the dependent chain and removes
-// the per-thread forward substitutions (496 dependent FMAs each).
+// Compared with a right-looking pair (panel + trailing update) this halves the launches on the dependent chain and has no
+// per-thread forward substitutions (496 dependent FMAs each).
 #ifdef LVK_CHOL_TIMING
 static __device__ unsigned long long g_ch_tick[16];
 #define CH_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ch_tick[k] = wall_clock64(); } while (0)
@@ -617,8 +507,7 @@ lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, 
 {
     const size_t shmem = sizeof(double) * ((size_t)3 * L * L + (size_t)L * n);
     if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n);
-    static size_t attr_set = 0;                                      // beyond 64 KB the launch needs the attribute (exactly the launched size)
-    if (shmem > 64 * 1024 && attr_set != shmem) { attr_set = shmem; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_cov_propagate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); }
+    if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 0, k_cov_propagate, shmem);      // beyond 64 KB the launch needs the attribute
     hipLaunchKernelGGL(k_cov_propagate, dim3(1), dim3(CPR_THREADS), shmem, ctx->stream, P, ld, n, L, d_phiq);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;

@@ -818,8 +818,7 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
     hipLaunchKernelGGL(k_masked_max, dim3(128), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch);
     hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, (h - 2 + GC_ROWS - 1) / GC_ROWS), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
     const size_t shm = (size_t)GF_SURV * 8 + (size_t)gw * gh * 8 + (size_t)GF_MAX_OUT * 4;
-    static size_t attr_set = 0;       // the opt-in must leave room for the kernel's static LDS: ask for exactly what is launched
-    if (attr_set < shm) { attr_set = shm; LVK_HIP(ctx, hipFuncSetAttribute((const void*)k_gftt_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); }
+    LVK_LDS_OPTIN(ctx, 2, k_gftt_select, shm);   // the opt-in must leave room for the kernel's static LDS: ask for what is launched
     hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), shm, ctx->stream, (const unsigned long long*)d_cands, cand_cap, w, h, max_corners, cell,
                        (float)(min_distance * min_distance), (const unsigned*)d_scratch, d_out, cap, d_n_out, d_sub);
     LVK_LAUNCH_CHECK(ctx);

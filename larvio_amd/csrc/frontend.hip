@@ -450,7 +450,13 @@ struct lvk_frontend {
     int cur;                   // track set holding prev_pts_ (written by the previous frame)
     lvk_pyramid* pyr[2];       // [0] = prev, [1] = curr (swapped every frame)
     uint8_t *ext[2], *blur[2];
-    uint8_t* d_img;            // staging for host images
+    uint8_t* d_img;            // device copy of a host image
+    // Host images (the reference's cv::Mat, pageable) are copied by the calling thread into a ring of pinned, device-mapped staging
+    // slots; the GPU side is either one asynchronous H2D copy into d_img (default) or, with LVK_FE_ZEROCOPY=1, the first two image
+    // kernels reading the slot in place over PCIe.  The caller's buffer is free as soon as the call returns (as in the reference).
+    uint8_t* h_stage[3] = {nullptr, nullptr, nullptr}; uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_stage[3] = {nullptr, nullptr, nullptr}; bool stage_busy[3] = {false, false, false};
+    int stage_next = 0; int zero_copy = 0;
     TrackSet set[2];
     lvk_pt2f *w_curr, *wn_curr, *new_pts;
     uint8_t *w_status, *wn_status;
@@ -472,7 +478,6 @@ struct lvk_frontend {
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
     lvk_pyr_graph* pyr_graph[2] = {nullptr, nullptr}; lvk_pyramid* pyr_graph_of[2] = {nullptr, nullptr};
     int use_graph = 0;                // LVK_FE_GRAPH=1: steady-state pyramid build as one graph launch per frame
-    bool host_img_pending = false;   // an asynchronous copy out of the caller's (pageable) image buffer is in flight
     // HIP-event profiling of stages
     unsigned prof_mask;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -584,6 +589,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 2; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
+    for (int i = 0; i < 3; ++i) { if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]); if (fe->ev_stage[i]) hipEventDestroy(fe->ev_stage[i]); }
     if (fe->h_msg) hipHostFree(fe->h_msg);
     if (fe->h_nmsg) hipHostFree(fe->h_nmsg);
     if (fe->h_dev) hipHostFree(fe->h_dev);
@@ -631,6 +637,13 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
         void *dm = nullptr, *dn = nullptr;
         ok = hipHostGetDevicePointer(&dm, fe->h_msg, 0) == hipSuccess && hipHostGetDevicePointer(&dn, fe->h_nmsg, 0) == hipSuccess && dm && dn;
         fe->d_msg = (lvk_feature_obs*)dm; fe->d_nmsg = (int*)dn;
+    }
+    { const char* z = getenv("LVK_FE_ZEROCOPY"); fe->zero_copy = z && atoi(z) != 0; }
+    for (int i = 0; i < 3 && ok; ++i) {
+        void* dp = nullptr;
+        ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess && hipHostGetDevicePointer(&dp, fe->h_stage[i], 0) == hipSuccess && dp &&
+             hipEventCreateWithFlags(&fe->ev_stage[i], hipEventDisableTiming) == hipSuccess;
+        fe->d_stage[i] = (uint8_t*)dp;
     }
     for (int i = 0; i < 1 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
     hipEvent_t* evs[] = {&fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_tail};
@@ -700,35 +713,55 @@ static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_o
 // The IMU-independent part of a frame: image upload, createImagePyramids (:318-334) on the main stream, ORBdescriptor ctor (:150)
 // on the side stream as soon as level 0 exists (steady state) or in line (bootstrap frames).  Split out so that a pipelined
 // driver can queue it before it knows which IMU samples the previous update erased (lvk_frontend_begin).
-static lvk_status fe_image_stage(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device)
+static lvk_status fe_check_image(lvk_frontend* fe, const lvk_image* img)
+{   // a cv::Mat carries its own size; a caller that hands over anything but the configured resolution gets an error, not a read
+    // past its buffer (e.g. TUM-VI 512x512 images under a 752x480 configuration)
+    const lvk_fe_config& c = fe->cfg;
+    if (!img || !img->data) return lvk_set_error(fe->ctx, LVK_ERR_ARG, "image: null pointer");
+    if (img->width != c.width || img->height != c.height)
+        return lvk_set_error(fe->ctx, LVK_ERR_ARG, "image is %dx%d, the front-end is configured for %dx%d", img->width, img->height, c.width, c.height);
+    if (img->stride < c.width) return lvk_set_error(fe->ctx, LVK_ERR_ARG, "image stride %d is smaller than the width %d", img->stride, c.width);
+    return LVK_OK;
+}
+
+static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image)
 {
     lvk_context* ctx = fe->ctx;
     const lvk_fe_config& c = fe->cfg;
-    const uint8_t* d_img = img; int d_stride = stride;
-    if (!img_is_device) {
-        fe->host_img_pending = true;    // the runtime may pin the caller's pages and read them after this call returns
-        LVK_HIP(ctx, hipMemcpy2DAsync(fe->d_img, c.width, img, stride, c.width, c.height, hipMemcpyHostToDevice, ctx->stream));
-        d_img = fe->d_img; d_stride = c.width;
+    lvk_status stc = fe_check_image(fe, image);
+    if (stc != LVK_OK) return stc;
+    const uint8_t* d_img = image->data; int d_stride = image->stride;
+    int slot = -1;
+    if (!image->is_device) {
+        slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
+        if (fe->stage_busy[slot]) { LVK_HIP(ctx, hipEventSynchronize(fe->ev_stage[slot])); fe->stage_busy[slot] = false; }   // three frames back: long done
+        uint8_t* hs = fe->h_stage[slot];
+        if (image->stride == c.width) memcpy(hs, image->data, (size_t)c.width * c.height);
+        else for (int y = 0; y < c.height; ++y) memcpy(hs + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
+        if (fe->zero_copy) d_img = fe->d_stage[slot];
+        else { LVK_HIP(ctx, hipMemcpyAsync(fe->d_img, hs, (size_t)c.width * c.height, hipMemcpyHostToDevice, ctx->stream)); d_img = fe->d_img; }
+        d_stride = c.width;
     }
     lvk_status st;
     hipStream_t S1 = ctx->stream;
     lvk_context* orb_cx = fe->image_state == 3 ? fe->side[0] : ctx;
     hipStream_t S3 = orb_cx->stream;
     if (fe->use_graph && fe->image_state == 3 && !((fe->prof_mask >> 0) & 1u)) {
-        int slot = fe->pyr_graph_of[0] == fe->pyr[1] ? 0 : fe->pyr_graph_of[1] == fe->pyr[1] ? 1 : -1;
-        if (slot < 0) {
-            slot = fe->pyr_graph_of[0] ? 1 : 0;
-            st = lvk_pyramid_graph_capture(ctx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, &fe->pyr_graph[slot]);
+        int gs = fe->pyr_graph_of[0] == fe->pyr[1] ? 0 : fe->pyr_graph_of[1] == fe->pyr[1] ? 1 : -1;
+        if (gs < 0) {
+            gs = fe->pyr_graph_of[0] ? 1 : 0;
+            st = lvk_pyramid_graph_capture(ctx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, &fe->pyr_graph[gs]);
             if (st != LVK_OK) return st;
-            fe->pyr_graph_of[slot] = fe->pyr[1];
+            fe->pyr_graph_of[gs] = fe->pyr[1];
         }
-        st = lvk_pyramid_graph_launch(ctx, fe->pyr_graph[slot], d_img, d_stride);
+        st = lvk_pyramid_graph_launch(ctx, fe->pyr_graph[gs], d_img, d_stride);
     } else {
         ProfScope ps(fe, 0);
         st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride);
     }
     if (st != LVK_OK) return st;
     hipEventRecord(fe->ev_pyr, S1);
+    if (slot >= 0) { hipEventRecord(fe->ev_stage[slot], S1); fe->stage_busy[slot] = true; }
     if (S3 != S1) hipStreamWaitEvent(S3, fe->ev_pyr, 0);
     { ProfScope ps(fe, 1, S3); st = lvk_orb_prepare(orb_cx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
     if (st != LVK_OK) return orb_cx == ctx ? st : lvk_set_error(ctx, st, "%s", orb_cx->err);
@@ -736,41 +769,20 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const uint8_t* img, int strid
     return LVK_OK;
 }
 
-lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts)
+lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts)
 {
     if (!fe || !img) return LVK_ERR_ARG;
-    if (!fe->b_first_img) return LVK_OK;                 // the first-image gate needs the IMU buffer (:134-142): nothing to do early
-    lvk_status st = fe_image_stage(fe, img, stride, img_is_device);
+    if (!fe->b_first_img) return fe_check_image(fe, img);   // the first-image gate needs the IMU buffer (:134-142): nothing to do early
+    lvk_status st = fe_image_stage(fe, img);
     if (st != LVK_OK) return st;
     fe->image_done = true; fe->image_done_ts = ts;
     return LVK_OK;
 }
 
-static lvk_status frontend_process_frame(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
-                                         lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg);
-
-// processImage is synchronous in the reference: when it returns the caller may free or overwrite the image.  Here the frame's
-// kernels keep running after the return, but the caller's buffer is only read by the upload at the head of the main stream; the
-// pyramid event behind it has normally fired long before the host has finished queueing the rest of the frame.
-lvk_status lvk_frontend_process(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
+// processImage is synchronous in the reference: when it returns the caller may free or overwrite the image.  Same here: a host
+// image has been copied into the pinned staging ring by the time the call returns (the frame's kernels keep running).
+lvk_status lvk_frontend_process(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu,
                                 lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
-{
-    const lvk_status st = frontend_process_frame(fe, img, stride, img_is_device, ts, h_imu, n_imu, h_out, cap, n_out, has_msg);
-    const lvk_status st2 = lvk_frontend_release_image(fe);
-    return st != LVK_OK ? st : st2;
-}
-
-// wait until the upload queued by lvk_frontend_begin / lvk_frontend_process no longer needs the caller's image buffer
-lvk_status lvk_frontend_release_image(lvk_frontend* fe)
-{
-    if (!fe || !fe->host_img_pending) return LVK_OK;
-    fe->host_img_pending = false;
-    const hipError_t e = hipEventSynchronize(fe->ev_pyr);
-    return e == hipSuccess ? LVK_OK : lvk_set_error(fe->ctx, LVK_ERR_DEVICE, "image upload: %s", hipGetErrorString(e));
-}
-
-static lvk_status frontend_process_frame(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts, const lvk_imu* h_imu, int n_imu,
-                                         lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
 {
     if (!fe || !img || !n_out || !has_msg || (n_imu > 0 && !h_imu)) return lvk_set_error(fe ? fe->ctx : nullptr, LVK_ERR_ARG, "lvk_frontend_process: bad argument");
     lvk_context* ctx = fe->ctx;
@@ -778,10 +790,10 @@ static lvk_status frontend_process_frame(lvk_frontend* fe, const uint8_t* img, i
     *n_out = 0; *has_msg = 0;
     if (!fe->b_first_img) {                                          // :134-142
         if (n_imu > 0 && h_imu[0].t - ts <= 0.0) fe->b_first_img = true;
-        else return LVK_OK;
+        else return fe_check_image(fe, img);
     }
     lvk_status st = LVK_OK;
-    if (!(fe->image_done && fe->image_done_ts == ts)) st = fe_image_stage(fe, img, stride, img_is_device);
+    if (!(fe->image_done && fe->image_done_ts == ts)) st = fe_image_stage(fe, img);
     fe->image_done = false;
     if (st != LVK_OK) return st;
     hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;

@@ -19,12 +19,23 @@ struct lvk_context {
     // pool block handed out mid-stream was observed to corrupt an in-flight launch sequence)
     void* scratch[LVK_SCRATCH_SLOTS];
     size_t scratch_bytes[LVK_SCRATCH_SLOTS];
+    // dynamic-LDS opt-ins (hipFuncAttributeMaxDynamicSharedMemorySize) already made through THIS context: function attributes are
+    // per device, so the cache lives here and not in a process-wide static (slots: 0 k_cov_propagate, 1 k_feature_rows<false>,
+    // 2 k_gftt_select, 3 k_qr_panel)
+    size_t lds_optin[8];
 };
+// opt in to `bytes` of dynamic LDS for `fn` if this context has not already asked for at least that much
+#define LVK_LDS_OPTIN(ctx, slot, fn, bytes)                                                                             \
+    do {                                                                                                                \
+        if ((ctx)->lds_optin[slot] < (size_t)(bytes)) {                                                                 \
+            LVK_HIP(ctx, hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            (ctx)->lds_optin[slot] = (size_t)(bytes);                                                                   \
+        }                                                                                                               \
+    } while (0)
 void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
 struct lvk_frontend;
 lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
-extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const uint8_t* img, int stride, int img_is_device, double ts);   // image stage only (internal)
-extern "C" lvk_status lvk_frontend_release_image(lvk_frontend* fe);   // blocks until the queued upload is done with the caller's host image (internal)
+extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts);   // image stage only (internal)
 
 struct lvk_pyr_graph;                                     // fe_image.hip: the pyramid build of one pyramid object as a captured hipGraph
 struct lvk_pyramid;

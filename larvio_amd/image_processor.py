@@ -8,7 +8,7 @@ the reference's ``haveFeatures`` and the feature list is the ``MonoCameraMeasure
 import ctypes as C
 import os
 import numpy as np
-from ._lib import lib, _p, Context, FeConfig, LvkError, IMU, OBS
+from ._lib import lib, _p, Context, FeConfig, LvkError, IMU, OBS, make_image
 
 
 class MonoCameraMeasurement:
@@ -59,19 +59,16 @@ class ImageProcessor:
         self._out = np.zeros(self._cap, OBS)
         return True
 
-    def processImage(self, img, imu_msg_buffer, ts=None, device_ptr=None, stride=None):
-        """img: (H,W) uint8 array (host) — or pass device_ptr/stride for an image already in HBM.
+    def processImage(self, img, imu_msg_buffer, ts=None, device_ptr=None, stride=None, shape=None):
+        """img: (H,W) uint8 array (host; its shape is checked against the configured resolution, as a cv::Mat's would be) — or pass
+        device_ptr/stride (and shape=(H,W) if it is not the configured one) for an image already in HBM.
         imu_msg_buffer: structured array (t, gyro[3], acc[3]).  Returns (haveFeatures, MonoCameraMeasurement|None)."""
         if self._h is None:
             raise LvkError("ImageProcessor.initialize() has not succeeded")
         imu = np.ascontiguousarray(imu_msg_buffer, IMU)
         n_out, has = C.c_int(0), C.c_int(0)
-        if device_ptr is not None:
-            ptr, s, is_dev = C.c_void_p(device_ptr), stride, 1
-        else:
-            img = np.ascontiguousarray(img, np.uint8)
-            ptr, s, is_dev = _p(img), img.shape[1], 0
-        st = lib().lvk_frontend_process(self._h, ptr, s, is_dev, float(ts), _p(imu), len(imu), _p(self._out), self._cap,
+        im, keep = make_image(img, device_ptr, stride, shape if shape is not None else (self.config["height"], self.config["width"]))
+        st = lib().lvk_frontend_process(self._h, C.byref(im), float(ts), _p(imu), len(imu), _p(self._out), self._cap,
                                         C.byref(n_out), C.byref(has))
         self.ctx.check(st)
         if not has.value:

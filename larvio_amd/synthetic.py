@@ -269,3 +269,69 @@ def imu_only_sequence(seed=MASTER_SEED, cam=EUROC, imu_rate=200.0, noise_scale=1
     seq.cam = cam; seq.traj = Trajectory(cam); seq.t0 = 0.0; seq.img_rate = 20.0; seq.imu_rate = imu_rate; seq.seed = seed
     seq.sg = IMU_NOISE_GYRO * np.sqrt(imu_rate) * noise_scale; seq.sa = IMU_NOISE_ACC * np.sqrt(imu_rate) * noise_scale
     return seq
+
+
+# ------------------------------------------------------------------ the configurations BASELINE.json names
+CAM_TUMVI_LIKE = dict(width=512, height=512, intrinsics=(190.978, 190.973, 254.932, 256.897), distortion_model=1,
+                      distortion=(0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367), T_cam_imu=EUROC["T_cam_imu"])
+CAM_1080P = dict(width=1920, height=1080, intrinsics=(1100.0, 1100.0, 960.0, 540.0), distortion_model=0,
+                 distortion=(-0.12, 0.03, 0.0002, -0.0001), T_cam_imu=EUROC["T_cam_imu"])
+
+
+def workload(name, max_features=None, sw_size=None):
+    """-> dict(cam, img_rate, fcfg, bcfg, label) for BASELINE.json's configs[1..4] ('A', '3', '4', '5')."""
+    if name == "A":       # configs[1]: EuRoC-shaped 752x480 @20 Hz, ~150 tracks, 30-clone window, 1-D hybrid
+        cam, rate, mf, sw, fo, bo = EUROC, 20.0, 150, 30, {}, {}
+        label = "configs[1]: EuRoC-shaped synthetic 752x480 @20 Hz, 1d-hybrid"
+    elif name == "3":     # configs[2]: as A with online imu-cam extrinsic + td + IMU-intrinsic calibration (LEG_DIM 46)
+        cam, rate, mf, sw, fo, bo = EUROC, 20.0, 150, 30, {}, dict(calib_imu_instrinsic=1)
+        label = "configs[2]: 752x480 @20 Hz, 1d-hybrid + online extrinsic/td/IMU-intrinsic calibration"
+    elif name == "4":     # configs[3]: TUM-VI-shaped 512x512 equidistant, ~300 tracks, ZUPT
+        cam, rate, mf, sw, fo, bo = CAM_TUMVI_LIKE, 20.0, 300, 30, dict(min_distance=15), dict(if_zupt_valid=1)
+        label = "configs[3]: TUM-VI-shaped synthetic 512x512 equidistant @20 Hz, 1d-hybrid + ZUPT"
+    elif name == "5":     # configs[4]: 1920x1080 @60 Hz, 2000 tracks, 60-clone window (messages at 30 Hz: every other frame, as EuRoC's 20 -> 10)
+        cam, rate, mf, sw, fo, bo = CAM_1080P, 60.0, 2000, 60, dict(pub_frequency=30), dict(pub_frequency=30, max_features_in_one_grid=2)
+        label = "configs[4]: synthetic 1920x1080 @60 Hz, 1d-hybrid, messages at 30 Hz"
+    else:
+        raise ValueError("workload must be one of A, 3, 4, 5")
+    mf = max_features or mf; sw = sw_size or sw
+    fcfg = frontend_config(cam=cam, max_features_num=mf, **fo)
+    bcfg = backend_config(cam=cam, sw_size=sw, max_features=mf, **bo)
+    return dict(name=name, cam=cam, img_rate=rate, fcfg=fcfg, bcfg=bcfg, max_features=mf, sw_size=sw,
+                label="%s, max_features %d, sw_size %d" % (label, mf, sw))
+
+
+_RENDER_SEQ = None
+
+
+def _render_one(i):
+    return _RENDER_SEQ.frame(i)
+
+
+def render_frames(first, count, cam=EUROC, seed=MASTER_SEED, img_rate=20.0, procs=None, cache_dir="/tmp"):
+    """(ts[count], img[count, H, W] u8) of frames [first, first+count), rendered on `procs` forked workers (frames are independent)
+    and cached on disk one file per frame, so overlapping ranges share work.  Call BEFORE anything initialises HIP in this process
+    when frames are missing (the workers are forked)."""
+    import os
+    d = os.path.join(cache_dir, "lvk_frames_%dx%d_m%d_r%g_s%d" % (cam["width"], cam["height"], cam["distortion_model"], img_rate, seed))
+    os.makedirs(d, exist_ok=True)
+    idx = list(range(first, first + count))
+    fn = lambda i: os.path.join(d, "f%06d.npy" % i)
+    missing = [i for i in idx if not os.path.exists(fn(i))]
+    if missing:
+        global _RENDER_SEQ
+        _RENDER_SEQ = Sequence(cam=cam, seed=seed, img_rate=img_rate)
+        procs = procs or min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        if procs > 1 and len(missing) > 4:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(procs) as pool:
+                res = pool.map(_render_one, missing, chunksize=max(1, len(missing) // (4 * procs)))
+        else:
+            res = [_render_one(i) for i in missing]
+        _RENDER_SEQ = None
+        for i, (t, im) in zip(missing, res):
+            tmp = fn(i) + ".tmp%d.npy" % os.getpid()
+            np.save(tmp, im); os.replace(tmp, fn(i))
+    ts = np.array([i / img_rate for i in idx])               # Sequence.frame_time with t0 = 0
+    img = np.stack([np.load(fn(i)) for i in idx])
+    return ts, img

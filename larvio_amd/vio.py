@@ -2,7 +2,7 @@
 LarVio.processFeatures — the loop body of app/larvioMain.cpp:87-117 — as ONE C-ABI call (lvk_vio_process)."""
 import ctypes as C
 import numpy as np
-from ._lib import lib, _p, IMU
+from ._lib import lib, _p, IMU, Image, make_image
 
 _done = False
 
@@ -13,15 +13,16 @@ def _L():
     if not _done:
         vp, i, d = C.c_void_p, C.c_int, C.c_double
         pi = C.POINTER(C.c_int)
-        L.lvk_vio_process.argtypes = [vp, vp, vp, i, i, d, vp, i, pi, pi, pi]
+        L.lvk_vio_process.argtypes = [vp, vp, C.POINTER(Image), d, vp, i, pi, pi, pi]
         L.lvk_vio_process.restype = i
         pl = C.POINTER(C.c_long)
         L.lvk_vio_pipe_create.argtypes = [vp, vp, C.POINTER(vp)]; L.lvk_vio_pipe_create.restype = i
         L.lvk_vio_pipe_destroy.argtypes = [vp]; L.lvk_vio_pipe_destroy.restype = None
         L.lvk_vio_pipe_push_imu.argtypes = [vp, vp, i]; L.lvk_vio_pipe_push_imu.restype = i
-        L.lvk_vio_pipe_submit.argtypes = [vp, vp, i, i, d, pi]; L.lvk_vio_pipe_submit.restype = i
+        L.lvk_vio_pipe_submit.argtypes = [vp, C.POINTER(Image), d, pi]; L.lvk_vio_pipe_submit.restype = i
         L.lvk_vio_pipe_drain.argtypes = [vp, pl, pl]; L.lvk_vio_pipe_drain.restype = i
         L.lvk_vio_pipe_stats.argtypes = [vp, C.POINTER(C.c_double), i]; L.lvk_vio_pipe_stats.restype = i
+        L.lvk_vio_pipe_latency.argtypes = [vp, vp, i, pi, i]; L.lvk_vio_pipe_latency.restype = i
         _done = True
     return L
 
@@ -35,6 +36,7 @@ class VioDriver:
         self.imu = np.ascontiguousarray(imu_all, IMU)
         self.t = self.imu["t"].copy()
         self.lo = 0
+        self._shape = (image_processor.config["height"], image_processor.config["width"])
         self._c = (C.c_int(0), C.c_int(0), C.c_int(0))
         self._base = self.imu.ctypes.data
         self._isz = self.imu.dtype.itemsize
@@ -42,15 +44,11 @@ class VioDriver:
     def visible_end(self, ts):
         return int(np.searchsorted(self.t, ts + 0.05, side="left"))
 
-    def step(self, ts, hi, img=None, device_ptr=None, stride=None):
+    def step(self, ts, hi, img=None, device_ptr=None, stride=None, shape=None):
         """hi = visible_end(ts) (precomputable).  Returns (has_msg, updated)."""
         used, has, upd = self._c
-        if device_ptr is not None:
-            ptr, s, is_dev = C.c_void_p(device_ptr), stride, 1
-        else:
-            img = np.ascontiguousarray(img, np.uint8)
-            ptr, s, is_dev = _p(img), img.shape[1], 0
-        st = _L().lvk_vio_process(self.fe._h, self.be._h, ptr, s, is_dev, float(ts), C.c_void_p(self._base + self.lo * self._isz), hi - self.lo,
+        im, keep = make_image(img, device_ptr, stride, shape if shape is not None else self._shape)
+        st = _L().lvk_vio_process(self.fe._h, self.be._h, C.byref(im), float(ts), C.c_void_p(self._base + self.lo * self._isz), hi - self.lo,
                                   C.byref(used), C.byref(has), C.byref(upd))
         self.fe.ctx.check(st)
         self.lo += used.value
@@ -69,6 +67,7 @@ class VioPipeline:
         self.imu = np.ascontiguousarray(imu_all, IMU)
         self.t = self.imu["t"].copy()
         self.pushed = 0
+        self._shape = (image_processor.config["height"], image_processor.config["width"])
         self._has = C.c_int(0)
         self._base = self.imu.ctypes.data
         self._isz = self.imu.dtype.itemsize
@@ -80,18 +79,14 @@ class VioPipeline:
     def visible_end(self, ts):
         return int(np.searchsorted(self.t, ts + 0.05, side="left"))
 
-    def step(self, ts, hi, img=None, device_ptr=None, stride=None):
+    def step(self, ts, hi, img=None, device_ptr=None, stride=None, shape=None):
         """hi = visible_end(ts).  Returns has_msg; the update it triggers completes asynchronously (drain())."""
         L = _L()
         if hi > self.pushed:
             L.lvk_vio_pipe_push_imu(self._h, C.c_void_p(self._base + self.pushed * self._isz), hi - self.pushed)
             self.pushed = hi
-        if device_ptr is not None:
-            ptr, s, is_dev = C.c_void_p(device_ptr), stride, 1
-        else:
-            img = np.ascontiguousarray(img, np.uint8)
-            ptr, s, is_dev = _p(img), img.shape[1], 0
-        st = L.lvk_vio_pipe_submit(self._h, ptr, s, is_dev, float(ts), C.byref(self._has))
+        im, keep = make_image(img, device_ptr, stride, shape if shape is not None else self._shape)
+        st = L.lvk_vio_pipe_submit(self._h, C.byref(im), float(ts), C.byref(self._has))
         if st != 0:
             self.fe.ctx.check(st); self.be.ctx.check(st)
         return bool(self._has.value)
@@ -108,6 +103,12 @@ class VioPipeline:
         o = (C.c_double * 4)()
         _L().lvk_vio_pipe_stats(self._h, o, 1 if reset else 0)
         return dict(front_end_us=o[0], caller_wait_us=o[1], filter_us=o[2], worker_idle_us=o[3])
+
+    def latencies(self, reset=True, cap=1 << 20):
+        """image-in -> state-out latency [us] of every message-carrying frame since the last reset (drain() first)"""
+        out = np.empty(cap, np.float32); n = C.c_int(0)
+        _L().lvk_vio_pipe_latency(self._h, _p(out), cap, C.byref(n), 1 if reset else 0)
+        return out[:n.value].copy()
 
     def close(self):
         if self._h:

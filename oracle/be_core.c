@@ -257,6 +257,8 @@ int lvo_msckf_feature_jacobian(const lvo_clone* clones, const int* clone_rank, c
 }
 
 /* ------------------------------------------------------------------------ dense helpers */
+extern int lvo_threads_;     /* fe_image.c: host threads for loops with independent iterations (same bits for any count) */
+#define LVO_PAR _Pragma("omp parallel for schedule(static) num_threads(lvo_threads_) if(lvo_threads_ > 1)")
 /* Cholesky A = L L^T in place (lower), n x n, ld.  Returns 0 on success. */
 static int chol_lower(double* A, int n, int ld)
 {
@@ -276,22 +278,28 @@ static int chol_lower(double* A, int n, int ld)
 }
 /* solve L Y = B in place, B is n x nb (ld ldb) */
 static void trsm_lower(const double* L, int n, int ld, double* B, int nb, int ldb)
-{
-    for (int i = 0; i < n; ++i) {
-        double* bi = B + (size_t)i * ldb;
-        for (int k = 0; k < i; ++k) {
-            const double l = L[(size_t)i * ld + k];
-            if (l == 0.) continue;
-            const double* bk = B + (size_t)k * ldb;
-            for (int c = 0; c < nb; ++c) bi[c] -= l * bk[c];
+{   /* columns of B are independent: chunks of 64 columns may run on different threads */
+    const int nchunk = (nb + 63) / 64;
+    LVO_PAR
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = ch * 64, c1 = c0 + 64 < nb ? c0 + 64 : nb;
+        for (int i = 0; i < n; ++i) {
+            double* bi = B + (size_t)i * ldb;
+            for (int k = 0; k < i; ++k) {
+                const double l = L[(size_t)i * ld + k];
+                if (l == 0.) continue;
+                const double* bk = B + (size_t)k * ldb;
+                for (int c = c0; c < c1; ++c) bi[c] -= l * bk[c];
+            }
+            const double inv = 1.0 / L[(size_t)i * ld + i];
+            for (int c = c0; c < c1; ++c) bi[c] *= inv;
         }
-        const double inv = 1.0 / L[(size_t)i * ld + i];
-        for (int c = 0; c < nb; ++c) bi[c] *= inv;
     }
 }
 /* C (m x n) = A (m x k) * B (k x n), row-major, contiguous inner loop */
 static void gemm_nn(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int k, int n)
 {
+    LVO_PAR
     for (int i = 0; i < m; ++i) {
         double* ci = C + (size_t)i * ldc;
         for (int j = 0; j < n; ++j) ci[j] = 0.;
@@ -338,6 +346,7 @@ void lvo_qr_compress(double* H, double* r, int rows, int cols)
         double vn2 = 0.; for (int i = k; i < rows; ++i) vn2 += v[i] * v[i];
         if (vn2 == 0.) continue;
         double beta = 2. / vn2;
+        LVO_PAR
         for (int c = k; c < cols; ++c) {
             double s = 0.; for (int i = k; i < rows; ++i) s += v[i] * H[(size_t)i * cols + c];
             if (s == 0.) continue;
@@ -357,6 +366,7 @@ void lvo_ekf_update(double* P, int N, int ldp, const double* H, int m, const dou
     double* S = (double*)malloc(sizeof(double) * (size_t)m * m);
     double* W = (double*)malloc(sizeof(double) * (size_t)m * (N + 1));
     gemm_nn(H, N, P, ldp, HP, N, m, N, N);
+    LVO_PAR
     for (int i = 0; i < m; ++i) for (int j = 0; j <= i; ++j) {
         double s = 0.; for (int p = 0; p < N; ++p) s += HP[(size_t)i * N + p] * H[(size_t)j * N + p];
         S[(size_t)i * m + j] = S[(size_t)j * m + i] = s + (i == j ? sigma2 : 0.);
@@ -373,12 +383,13 @@ void lvo_ekf_update(double* P, int N, int ldp, const double* H, int m, const dou
     }
     /* (I-KH)P = P - (HP)^T S^-1 (HP) computed as in the reference order K = (S^-1 HP)^T, then symmetrised */
     double* KHP = (double*)calloc((size_t)N * N, sizeof(double));
-    for (int i = 0; i < m; ++i) {
-        const double* wi = W + (size_t)i * (N + 1);
-        for (int a = 0; a < N; ++a) {
+    LVO_PAR
+    for (int a = 0; a < N; ++a) {                       /* row a of W^T W; every element sums over i in ascending order */
+        double* row = KHP + (size_t)a * N;
+        for (int i = 0; i < m; ++i) {
+            const double* wi = W + (size_t)i * (N + 1);
             const double wa = wi[a];
             if (wa == 0.) continue;
-            double* row = KHP + (size_t)a * N;
             for (int b = 0; b < N; ++b) row[b] += wa * wi[b];
         }
     }

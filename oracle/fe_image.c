@@ -6,9 +6,18 @@
  */
 #include "lvo.h"
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+
+/* All-core leg of the CPU baseline (bench.py cpu_baseline): loops whose iterations are independent (image rows,
+ * CLAHE tiles, tracks, key points) may be spread over host threads.  Same arithmetic per iteration, so results are bit-identical
+ * for any thread count (tests/test_oracle_frontend.py).  Default 1 = LARVIO's own single-threaded design. */
+int lvo_threads_ = 1;
+void lvo_set_threads(int n) { lvo_threads_ = n < 1 ? 1 : n; }
+int lvo_get_threads(void) { return lvo_threads_; }
+#define LVO_PAR _Pragma("omp parallel for schedule(static) num_threads(lvo_threads_) if(lvo_threads_ > 1)")
 
 static inline int cv_round_f(float v) { return (int)rintf(v); }   /* cvRound: half-to-even */
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
@@ -53,6 +62,7 @@ void lvo_clahe_u8(const uint8_t* src, int w, int h, int sstride,
         if (clip < 1) clip = 1;
     }
     uint8_t* lut = (uint8_t*)malloc((size_t)tiles_x * tiles_y * hist_size);
+    LVO_PAR
     for (int k = 0; k < tiles_x * tiles_y; ++k) {
         const int ty = k / tiles_x, tx = k % tiles_x;
         int hist[256];
@@ -82,6 +92,7 @@ void lvo_clahe_u8(const uint8_t* src, int w, int h, int sstride,
     }
     /* interpolation */
     const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    LVO_PAR
     for (int y = 0; y < h; ++y) {
         float tyf = y * inv_th - 0.5f;
         int ty1 = cv_floor_f(tyf), ty2 = ty1 + 1;
@@ -111,8 +122,10 @@ void lvo_clahe_u8(const uint8_t* src, int w, int h, int sstride,
 void lvo_pyr_down_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride)
 {
     const int dw = (w + 1) / 2, dh = (h + 1) / 2;
-    int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
+    int* rows_all = (int*)malloc(sizeof(int) * (size_t)dw * 5 * (size_t)lvo_threads_);
+    LVO_PAR
     for (int y = 0; y < dh; ++y) {
+        int* rows = rows_all + (size_t)dw * 5 * (size_t)omp_get_thread_num();
         for (int k = 0; k < 5; ++k) {
             int sy = reflect101(2 * y - 2 + k, h);
             const uint8_t* s = src + (size_t)sy * sstride;
@@ -128,16 +141,18 @@ void lvo_pyr_down_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst
             dst[(size_t)y * dstride + x] = (uint8_t)((v + 128) >> 8);
         }
     }
-    free(rows);
+    free(rows_all);
 }
 
 /* ------------------------------------------------------------------------ Scharr
  * [upstream lkpyramid.cpp calcSharrDeriv] Ix = [3 10 3]^T (x) [-1 0 1], Iy transposed, int16. */
 void lvo_scharr_deriv(const uint8_t* src, int w, int h, int sstride, int16_t* dst, int dstride)
 {
-    int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2));
-    int* t1 = (int*)malloc(sizeof(int) * (size_t)(w + 2));
+    int* t_all = (int*)malloc(sizeof(int) * (size_t)(w + 2) * 2 * (size_t)lvo_threads_);
+    LVO_PAR
     for (int y = 0; y < h; ++y) {
+        int* t0 = t_all + (size_t)(w + 2) * 2 * (size_t)omp_get_thread_num();
+        int* t1 = t0 + (w + 2);
         const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * sstride;
         const uint8_t* r1 = src + (size_t)y * sstride;
         const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * sstride;
@@ -155,7 +170,7 @@ void lvo_scharr_deriv(const uint8_t* src, int w, int h, int sstride, int16_t* ds
             d[2 * x + 1] = (int16_t)((b[x + 1] + b[x - 1]) * 3 + b[x] * 10);
         }
     }
-    free(t0); free(t1);
+    free(t_all);
 }
 
 /* ------------------------------------------------------------------------ LK pyramid
@@ -221,6 +236,7 @@ void lvo_orb_prepare(const lvo_pyramid* pyr, uint8_t* ext, uint8_t* blur)
     const int es = w + 2 * B, eh = h + 2 * B;
     const int grow = pad < B ? pad : B;                 /* pixels taken from the parent buffer */
     const int gw = w + 2 * grow, gh = h + 2 * grow;
+    LVO_PAR
     for (int y = 0; y < eh; ++y) {
         int gy = reflect101(y - B + grow, gh) - grow;   /* coordinate in level-0 frame, in [-grow, h+grow) */
         const uint8_t* s = pyr->img[0] + (size_t)(gy + pad) * pyr->istride[0] + pad;
@@ -232,6 +248,7 @@ void lvo_orb_prepare(const lvo_pyramid* pyr, uint8_t* ext, uint8_t* blur)
     memcpy(blur, ext, (size_t)es * eh);
     static const int K[7] = {18, 34, 49, 55, 49, 34, 18};
     int* rows = (int*)malloc(sizeof(int) * (size_t)w * (h + 6));
+    LVO_PAR
     for (int y = -3; y < h + 3; ++y) {
         const uint8_t* s = ext + (size_t)(y + B) * es + B;
         int* r = rows + (size_t)(y + 3) * w;
@@ -241,6 +258,7 @@ void lvo_orb_prepare(const lvo_pyramid* pyr, uint8_t* ext, uint8_t* blur)
             r[x] = acc;
         }
     }
+    LVO_PAR
     for (int y = 0; y < h; ++y) {
         uint8_t* d = blur + (size_t)(y + B) * es + B;
         for (int x = 0; x < w; ++x) {
@@ -270,6 +288,7 @@ void lvo_min_eigen_map(const lvo_pyramid* pyr, float* eig)
     const int w = pyr->w[0], h = pyr->h[0];
     const float ke = (float)(1.0 / 3060.0), kc = 2.0f * ke;
     float* cov = (float*)malloc(sizeof(float) * 3 * (size_t)w * h);
+    LVO_PAR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             float r0 = px(pyr, x + 1, y - 1) - px(pyr, x - 1, y - 1);
@@ -283,6 +302,7 @@ void lvo_min_eigen_map(const lvo_pyramid* pyr, float* eig)
             c[0] = dx * dx; c[1] = dx * dy; c[2] = dy * dy;
         }
     float* hs = (float*)malloc(sizeof(float) * 3 * (size_t)w * h);
+    LVO_PAR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
@@ -290,6 +310,7 @@ void lvo_min_eigen_map(const lvo_pyramid* pyr, float* eig)
                 hs[3 * ((size_t)y * w + x) + c] =
                     (cov[3 * ((size_t)y * w + xm) + c] + cov[3 * ((size_t)y * w + x) + c]) + cov[3 * ((size_t)y * w + xp) + c];
         }
+    LVO_PAR
     for (int y = 0; y < h; ++y) {
         int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
         for (int x = 0; x < w; ++x) {

@@ -5,6 +5,7 @@
  */
 #include "lvo.h"
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
@@ -34,8 +35,8 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
     epsilon *= epsilon;
     const float FLT_SCALE = 1.f / (1 << 20);
     const double min_eig_threshold = 1e-4;
-    short* Iwin = (short*)malloc(sizeof(short) * (size_t)win * win * 3);
-    short* dIwin = Iwin + (size_t)win * win;
+    extern int lvo_threads_;
+    short* Iwin_all = (short*)malloc(sizeof(short) * (size_t)win * win * 3 * (size_t)lvo_threads_);
     for (int i = 0; i < n; ++i) status[i] = 1;
     if (iters_out) memset(iters_out, 0, sizeof(int) * (size_t)n * n_levels);
 
@@ -46,7 +47,11 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
         const uint8_t* Jbase = next->img[level] + (size_t)next->pad * stepJ + next->pad;
         const int16_t* Dbase = prev->der[level] + (size_t)prev->pad * dstep + 2 * prev->pad;
         const float lscale = (float)(1. / (1 << level));
+        /* tracks are independent (each has its own template window): the all-core baseline spreads them over threads */
+        _Pragma("omp parallel for schedule(dynamic, 4) num_threads(lvo_threads_) if(lvo_threads_ > 1)")
         for (int p = 0; p < n; ++p) {
+            short* Iwin = Iwin_all + (size_t)win * win * 3 * (size_t)omp_get_thread_num();
+            short* dIwin = Iwin + (size_t)win * win;
             float prx = prev_pts[p].x * lscale, pry = prev_pts[p].y * lscale;
             float nx, ny;
             if (level == max_level) { nx = next_pts[p].x * lscale; ny = next_pts[p].y * lscale; }
@@ -130,7 +135,7 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
             }
         }
     }
-    free(Iwin);
+    free(Iwin_all);
 }
 
 /* ======================================================================== ORB
@@ -206,6 +211,8 @@ void lvo_orb_describe(const uint8_t* ext, const uint8_t* blur, int w, int h,
     int umax[16];
     orb_umax(umax);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    extern int lvo_threads_;
+    _Pragma("omp parallel for schedule(static) num_threads(lvo_threads_) if(lvo_threads_ > 1)")
     for (int i = 0; i < n; ++i) {
         /* IC_Angle (ORBDescriptor.cpp:486-514); pt * mvInvScaleFactor[0] (=1.0f) */
         float px = pts[i].x * 1.0f, py = pts[i].y * 1.0f;

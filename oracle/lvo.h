@@ -44,6 +44,10 @@ typedef struct {
 
 /* cv::createCLAHE(clip, Size(tiles_x,tiles_y))->apply  [upstream clahe.cpp];
  * call site image_processor.cpp:322-325 (clip 3.0, 8x8). */
+/* host threads for the loops with independent iterations (rows, tiles, tracks, key points, features); 1 = the reference's
+ * single-threaded design.  Results do not depend on the count.  Used by bench.py's all-core cpu_baseline leg. */
+void lvo_set_threads(int n);
+int lvo_get_threads(void);
 void lvo_clahe_u8(const uint8_t* src, int w, int h, int sstride,
                   uint8_t* dst, int dstride, double clip, int tiles_x, int tiles_y);
 
@@ -216,11 +220,11 @@ typedef struct {
     int if_fej, estimate_extrin, estimate_td, if_zupt_valid;
     int sw_size, max_track_len, least_observation_number;
     int max_features_in_one_grid, aug_grid_rows, aug_grid_cols;
-    int pub_frequency, imu_rate;
     int width, height;
     double intrinsics[4];
     double T_cam_imu[16];
     double td;
+    double pub_frequency, imu_rate;   /* features_rate / imu_rate are doubles in the reference (larvio.h:256-259, larvio.cpp:65-67,224) */
     double noise_gyro, noise_acc, noise_gyro_bias, noise_acc_bias, noise_feature;      /* standard deviations */
     double initial_covariance_orientation, initial_covariance_velocity, initial_covariance_position,
            initial_covariance_gyro_bias, initial_covariance_acc_bias, initial_covariance_extrin_rot, initial_covariance_extrin_trans;

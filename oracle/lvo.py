@@ -99,8 +99,20 @@ def lib():
         L.lvo_frontend_state.argtypes = [vp]
         L.lvo_frontend_state.restype = i
         L.lvo_frontend_lk_stats.argtypes = [vp, vp, vp]
+        L.lvo_set_threads.argtypes = [i]; L.lvo_set_threads.restype = None
+        L.lvo_get_threads.argtypes = []; L.lvo_get_threads.restype = i
         _LIB = L
     return _LIB
+
+
+def set_threads(n):
+    """host threads for the oracle's loops with independent iterations (bench.py's all-core cpu_baseline leg); results do not
+    depend on the count.  1 = the reference's single-threaded design (the default)."""
+    lib().lvo_set_threads(int(n))
+
+
+def get_threads():
+    return lib().lvo_get_threads()
 
 
 def _p(a):

@@ -9,8 +9,8 @@ CLONE = np.dtype([("id", np.int64), ("time", np.float64), ("dt", np.float64), ("
                   ("p_cam", np.float64, 3)])
 
 _CFG_INT = ["if_fej", "estimate_extrin", "estimate_td", "if_zupt_valid", "sw_size", "max_track_len", "least_observation_number",
-            "max_features_in_one_grid", "aug_grid_rows", "aug_grid_cols", "pub_frequency", "imu_rate", "width", "height"]
-_CFG_DBL = ["td", "noise_gyro", "noise_acc", "noise_gyro_bias", "noise_acc_bias", "noise_feature",
+            "max_features_in_one_grid", "aug_grid_rows", "aug_grid_cols", "width", "height"]
+_CFG_DBL = ["td", "pub_frequency", "imu_rate", "noise_gyro", "noise_acc", "noise_gyro_bias", "noise_acc_bias", "noise_feature",
             "initial_covariance_orientation", "initial_covariance_velocity", "initial_covariance_position",
             "initial_covariance_gyro_bias", "initial_covariance_acc_bias", "initial_covariance_extrin_rot",
             "initial_covariance_extrin_trans", "rotation_threshold", "translation_threshold", "tracking_rate_threshold",

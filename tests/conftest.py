@@ -15,24 +15,24 @@ def pytest_configure(config):
 _FRAME_CACHE = {}
 
 
-def synth_frames(first, count, t0=0.0, cam=None):
-    """Rendered synthetic frames [(ts, img)], cached on disk (rendering costs ~0.7 s/frame)."""
+def synth_frames(first, count, t0=0.0, cam=None, img_rate=20.0):
+    """Rendered synthetic frames [(ts, img)], cached on disk.  Rendering (~0.25 s/frame/core) happens in a fresh subprocess that
+    forks one worker per core (larvio_amd.synthetic.render_frames): this process may already have initialised HIP, after which
+    forking is not safe."""
+    import pickle
+    import subprocess
     from larvio_amd import synthetic as S
     cam = cam or S.EUROC
-    key = (first, count, t0, cam["width"], cam["height"], cam["distortion_model"])
+    assert t0 == 0.0
+    key = (first, count, cam["width"], cam["height"], cam["distortion_model"], img_rate)
     if key in _FRAME_CACHE:
         return _FRAME_CACHE[key]
-    path = os.path.join("/tmp", "lvk_frames_%d_%d_%g_%dx%d_%d_s%d.npz" % (first, count, t0, cam["width"], cam["height"], cam["distortion_model"], S.MASTER_SEED))
-    if os.path.exists(path):
-        z = np.load(path)
-        out = list(zip(z["ts"].tolist(), list(z["img"])))
-    else:
-        seq = S.Sequence(cam=cam, t0=t0)
-        out = [seq.frame(i) for i in range(first, first + count)]
-        try:
-            np.savez(path, ts=np.array([o[0] for o in out]), img=np.stack([o[1] for o in out]))
-        except OSError:
-            pass
+    code = ("import pickle, sys; sys.path.insert(0, %r); from larvio_amd import synthetic as S; "
+            "cam = pickle.loads(bytes.fromhex(%r)); S.render_frames(%d, %d, cam=cam, img_rate=%r)"
+            % (ROOT, pickle.dumps(dict(cam)).hex(), first, count, img_rate))
+    subprocess.check_call([sys.executable, "-c", code])
+    ts, img = S.render_frames(first, count, cam=cam, img_rate=img_rate, procs=1)      # now a cache hit
+    out = list(zip(ts.tolist(), list(img)))
     _FRAME_CACHE[key] = out
     return out
 

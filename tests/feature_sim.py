@@ -41,14 +41,14 @@ INIT_COV = dict(initial_covariance_orientation=1e-6, initial_covariance_velocity
                 initial_covariance_gyro_bias=1e-8, initial_covariance_acc_bias=1e-6)
 
 
-def simulate(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=150, perturb=True, **cfg_over):
+def simulate(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=150, perturb=True, n_per_batch=120, **cfg_over):
     """-> dict(cfg, imu, init=(t, q, p, v, bg, ba, gyro_old, acc_old), msgs=[(ts, OBS array)], traj)
     sigma: observation noise in normalised image units (3e-4 ~ 0.14 px at f = 458: what sub-pixel LK delivers);
     imu_noise: scale on the simulator's IMU noise densities (1.0 = synthetic.IMU_NOISE_*).  The initial state is the truth plus a
     draw from the (small) initial covariance the configuration states."""
     tr = S.Trajectory(); seq = S.imu_only_sequence(seed=seed, noise_scale=imu_noise)
     rng = np.random.default_rng([seed, 5])
-    cloud = LandmarkCloud(tr, t0, t1, seed)
+    cloud = LandmarkCloud(tr, t0, t1, seed, n_per_batch=n_per_batch)
     over = dict(sw_size=20, estimate_td=0, estimate_extrin=0, if_zupt_valid=0, **INIT_COV)
     over.update(cfg_over)
     cfg = S.backend_config(**over)

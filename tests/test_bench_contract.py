@@ -31,5 +31,18 @@ def test_bench_source_keeps_the_timed_region_bracketed():
     i0 = src.index("t_begin = time.perf_counter()"); i1 = src.index("elapsed = time.perf_counter() - t_begin")
     before, timed = src[:i0], src[i0:i1]
     assert "dist.barrier()" in before[-400:] and "torch.cuda.synchronize()" in before[-400:]
-    assert "torch.cuda.synchronize()" in timed and "dist.barrier()" in timed and "drv.drain()" in timed
+    assert "torch.cuda.synchronize()" in timed and "dist.barrier()" in timed and "run.drain()" in timed      # every queued update completes inside
     assert "oracle" not in timed                                   # the CPU baseline is timed outside
+
+
+def test_bench_source_reaches_the_stated_steady_state_before_timing():
+    """The timed region must not depend on --warmup to fill the window (round-1 finding): the pre-roll is a separate, untimed phase
+    that refuses to hand over until the window has cycled and the H P GEMM was bracketed over >= 20 updates; the image is handed
+    over as a host buffer in the headline pass."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main()"):]
+    assert main.index("preroll(run, frames, None") < main.index("timed(run, frames, None")
+    pre = src[src.index("def preroll("):src.index("def timed(")]
+    assert "sw_size - 2" in pre and 'c["msckf"] >= 2' in pre and "raise SystemExit" in pre and "no value printed" in pre
+    assert "preroll(run, frames, None, n_pre_max, sw, 20)" in main
+    assert "n_cpu = 0 if" in main and "else 300" in main                       # >= 200 steady-state CPU frames at the metric's configuration

@@ -305,6 +305,85 @@ def test_backend_parity_on_simulated_feature_messages(gpu_ctx, seed, kw):
     print("simulated features", seed, kw, "worst rel state", wx, "cov", wP, c)
 
 
+def test_backend_parity_config5_depth(gpu_ctx):
+    """BASELINE.json configs[4] at real depth, without rendering 1080p frames: 2000 features per message, a 60-clone window (N up to
+    22 + 360 + 60), 72 updates.  Every sixth message all features of a generation reach max_track_len together: ~18,000 raw rows
+     >> N columns, so the QR compression (larvio.cpp:1430-1445) runs at its largest shape, then the window fills and the
+    pruning update + re-anchoring run at 60 clones.  State and covariance within 1e-5 after every update; gate counters identical."""
+    import os
+    from oracle import lvo
+    from tests import feature_sim as F
+    sim = F.simulate(8, t0=2.0, t1=9.2, max_feat=2000, n_per_batch=500, sw_size=60, max_features_in_one_grid=2, estimate_td=1, estimate_extrin=1,
+                     max_features=2000)
+
+    class _Seq:
+        traj = sim["traj"]
+    assert min(len(m) for _, m in sim["msgs"][2:]) >= 1800
+    lvo.set_threads(min(32, os.cpu_count() or 1))
+    try:
+        n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, sim["msgs"], sim["imu"], _Seq, sim["cfg"], init_args=sim["init"])
+    finally:
+        lvo.set_threads(1)
+    assert n_upd >= 70 and len(ora.clones()) >= 58 and ora.dim >= 22 + 6 * 58 + 30 and c["msckf"] >= 3, (n_upd, ora.dim, c)
+    print("config-5 depth: updates", n_upd, "N", ora.dim, "worst rel state", wx, "cov", wP, c)
+
+
+def test_gate_quirk_for_dof_100_and_more(gpu_ctx):
+    """larvio.cpp:353-357 fills chi_squared_test_table for dof 1..99 only; gatingTest (:1873) reads table[dof] through std::map's
+    operator[], i.e. 0.0 for dof >= 100, so a feature with >= 52 observations can never pass.  With max_track_len 58 in a 60-clone
+    window the long tracks hit exactly that: both sides must reject them (and keep accepting the short ones)."""
+    from tests import feature_sim as F
+    sim = F.simulate(9, t0=2.0, t1=9.4, max_feat=40, sw_size=60, max_track_len=58, max_features_in_one_grid=0)
+
+    class _Seq:
+        traj = sim["traj"]
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, sim["msgs"], sim["imu"], _Seq, sim["cfg"], init_args=sim["init"])
+    assert n_upd >= 70 and c["gated_out"] >= 5 and c["gated_in"] >= 20, c
+    print("dof >= 100 quirk: updates", n_upd, "worst rel", wx, wP, c)
+
+
+def test_take_lost_features_hands_out_every_lost_in_state_feature_once(gpu_ctx):
+    """lvk_ekf_take_lost_features = getStableMapPointPositions (larvio.cpp:2717-2722, filled at :3342): every in-state feature that
+    leaves the state because its track was lost shows up exactly once, with the last world position the filter held for it, and the
+    list is cleared by the read."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    msgs, imu_all, seq = _messages(40, 110)
+    cfg = S.backend_config(sw_size=20, if_zupt_valid=0)
+    gpu = larvio_amd.LarVio(cfg, gpu_ctx); assert gpu.initialize()
+    buf = imu_all.copy(); first = True
+    prev = {}; lost_expected = {}; got = {}
+    for ts, msg in msgs:
+        b = buf[:int(np.searchsorted(buf["t"], ts + 0.05))]
+        if first:
+            k = int(np.searchsorted(imu_all["t"], ts, side="right")) - 1
+            t0 = imu_all["t"][k]; tr = seq.traj
+            gpu.set_state(t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k]); first = False
+        upd, rest = gpu.processFeatures((ts, msg), b)
+        buf = buf[len(b) - len(rest):]
+        ids, _, pos = gpu.features()
+        now = {int(i): p for i, p in zip(ids, pos)}
+        tracked = set(int(x) for x in msg["id"])
+        for i in prev:
+            if i not in now and i not in tracked:
+                lost_expected[i] = prev[i]                                   # dropped because the tracker lost it (rmLostFeaturesCov)
+        prev = now
+        if len(lost_expected) and len(got) < len(lost_expected) and (len(lost_expected) % 2 == 0):
+            li, lp = gpu.stable_map_points()
+            for i, p in zip(li, lp):
+                assert int(i) not in got
+                got[int(i)] = p
+            assert len(gpu.stable_map_points()[0]) == 0                      # cleared by the read
+    li, lp = gpu.stable_map_points()
+    for i, p in zip(li, lp):
+        assert int(i) not in got
+        got[int(i)] = p
+    assert len(lost_expected) >= 3 and set(got) == set(lost_expected), (sorted(got), sorted(lost_expected))
+    for i in got:                                                            # the position at the last update before the loss
+        assert np.abs(got[i] - lost_expected[i]).max() < 1e-9
+    gpu.close()
+
+
 def test_backend_accepts_empty_feature_messages(gpu_ctx):
     """messages with zero features between normal ones (the ABI allows them): pure propagation + augmentation + pruning"""
     from larvio_amd import synthetic as S

@@ -65,3 +65,39 @@ def test_oversized_feature_message_is_an_error_not_a_crash(gpu_ctx):
     assert raised
     be.close()
     be2 = larvio_amd.LarVio(S.backend_config(sw_size=8), gpu_ctx); assert be2.initialize(); be2.close()      # the context survives
+
+
+def test_image_of_the_wrong_size_is_refused_not_read_past(gpu_ctx):
+    """A cv::Mat carries its own size; lvk_image does too.  A 512x512 (TUM-VI) image under a 752x480 (EuRoC) configuration, a stride
+    smaller than the width, or a null pointer are LVK_ERR_ARG from every image entry point - before and after the first-image gate -
+    and the front-end keeps working afterwards."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd._lib import IMU, Image, lib
+    from larvio_amd.vio import VioDriver, VioPipeline
+    fe = larvio_amd.ImageProcessor(S.frontend_config(max_features_num=100), gpu_ctx); assert fe.initialize()
+    imu = np.zeros(3, IMU); imu["t"] = [0.9, 0.95, 1.0]
+    small = np.zeros((512, 512), np.uint8)
+    for ts in (0.5, 1.0):                                                            # 0.5: gate still closed (no IMU sample older than the image)
+        with pytest.raises(larvio_amd.LvkError, match="configured for 752x480"):
+            fe.processImage(small, imu, ts=ts)
+    good = np.zeros((480, 752), np.uint8)
+    n_out, has = C.c_int(0), C.c_int(0)
+    for bad in (Image(good.ctypes.data, 752, 480, 700, 0), Image(None, 752, 480, 752, 0)):
+        st = lib().lvk_frontend_process(fe._h, C.byref(bad), 1.0, imu.ctypes.data_as(C.c_void_p), 3, fe._out.ctypes.data_as(C.c_void_p), fe._cap,
+                                        C.byref(n_out), C.byref(has))
+        assert st == 1, st                                                           # LVK_ERR_ARG
+    be = larvio_amd.LarVio(S.backend_config(sw_size=8), gpu_ctx); assert be.initialize()
+    with pytest.raises(larvio_amd.LvkError):
+        VioDriver(fe, be, imu).step(1.0, 3, img=small)
+    ctx2 = larvio_amd.Context(0)
+    be2 = larvio_amd.LarVio(S.backend_config(sw_size=8), ctx2); assert be2.initialize()
+    pipe = VioPipeline(fe, be2, imu)
+    with pytest.raises(larvio_amd.LvkError):
+        pipe.step(1.0, 3, img=small)
+    pipe.close()
+    # a strided view of a wider buffer (cv::Mat ROI) of the right size is fine
+    wide = np.zeros((480, 800), np.uint8)
+    has_msg, _ = fe.processImage(wide[:, 24:776], imu, ts=1.0)
+    assert has_msg is False and fe.state in (1, 2)
+    be.close(); be2.close(); fe.close(); ctx2.close()

@@ -90,7 +90,7 @@ def _disturb(frames):
     return frames
 
 
-@pytest.mark.parametrize("disturbed", [False, True])
+@pytest.mark.parametrize("disturbed", [False, True, "headline"])
 def test_pipelined_driver_is_identical_to_sequential(gpu_ctx, disturbed):
     """lvk_vio_pipe_*: front-end of frame k+1 overlapping the update of frame k on a second stream gives the same bits as the
     sequential driver step (same library, same kernels — only the schedule differs), hence the same parity with the oracle."""
@@ -98,14 +98,16 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx, disturbed):
     from larvio_amd import synthetic as S
     from larvio_amd.vio import VioDriver, VioPipeline
     from tests.conftest import synth_frames
-    frames = synth_frames(40, 70)
-    if disturbed:
+    headline = disturbed == "headline"            # BASELINE.json's configuration: 150-feature budget, sw_size 30, window full and cycling
+    frames = synth_frames(40, 140 if headline else 70)
+    if disturbed is True:
         frames = _disturb(frames)
     seq = S.imu_only_sequence()
     ts = [f[0] for f in frames]
     imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
     fcfg = S.frontend_config(max_features_num=150)
-    bcfg = S.backend_config(sw_size=20, if_zupt_valid=1) if disturbed else S.backend_config(sw_size=15, if_zupt_valid=0)
+    bcfg = (S.backend_config(sw_size=30, max_features=150) if headline else
+            S.backend_config(sw_size=20, if_zupt_valid=1) if disturbed else S.backend_config(sw_size=15, if_zupt_valid=0))
     ctx2 = larvio_amd.Context(0)                                    # second context = second stream, for the filter
     out = []
     for mode in ("seq", "pipe"):
@@ -132,6 +134,8 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx, disturbed):
         be.close(); fe.close()
     ctx2.close()
     a, b = out
+    if headline:
+        assert len(a[4]) >= 28 and a[6]["msckf"] >= 5, (len(a[4]), a[6])       # the 28 -> 30 cycle ran, with pruning MSCKF updates
     assert a[0] == b[0] and a[1] == b[1] and a[0] >= 30
     for k in a[2]:
         assert np.array_equal(a[2][k], b[2][k]), k
@@ -152,7 +156,7 @@ TUMVI_LIKE = dict(
     T_cam_imu=None)
 
 
-def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates, mutate=None):
+def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates, mutate=None, oracle_threads=1):
     """oracle loop vs VioDriver on frames [first, first+count) of the synthetic sequence seen through `cam`"""
     import larvio_amd
     from larvio_amd import synthetic as S
@@ -173,6 +177,7 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
     fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
     be = larvio_amd.LarVio(bcfg, gpu_ctx); assert be.initialize()
     ofe = lvo.Frontend(fcfg); obe = lvo_be.Ekf(bcfg)
+    lvo.set_threads(oracle_threads)                # same bits for any count (tests/test_oracle_frontend.py); only the wall time changes
     drv = VioDriver(fe, be, imu_all)
     lo = 0; n_upd = 0; worst = 0.0
     for i, (t, img) in enumerate(frames):
@@ -206,6 +211,7 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
     for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map"):
         assert cg[k] == co[k], (k, cg, co)
     be.close(); fe.close()
+    lvo.set_threads(1)
     return n_upd, worst, co, len(to["ids"])
 
 
@@ -227,12 +233,24 @@ def test_driver_loop_blackout_noise_and_frozen_frames(gpu_ctx):
     print("disturbed run: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
 
 
+def test_driver_loop_headline_config_sw30(gpu_ctx):
+    """BASELINE.json's metric configuration end to end against the oracle: 752x480, 150-feature budget, sw_size 30, 140 frames = 70
+    messages, so the window fills (28 -> 30 clones cycle, larvio.cpp:2316-2320) and the pruning MSCKF update + re-anchoring run many
+    times.  State and covariance within 1e-5 after EVERY update, ids / clone lists / gate counters identical."""
+    n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, S_EUROC(), 40, 140, dict(max_features_num=150), dict(sw_size=30, max_features=150),
+                                             init_from_gt=True, min_updates=60)
+    assert c["msckf"] >= 5 and c["hybrid"] >= 55 and n_tracks >= 100, c
+    print("headline config (sw_size 30): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
+
+
 def test_driver_loop_config5_shape_1080p_many_tracks(gpu_ctx):
     """1920x1080, 2000-feature budget, long window: capacities and the tall-H (QR compression) path at the largest configuration"""
     cam = dict(width=1920, height=1080, intrinsics=(1100.0, 1100.0, 960.0, 540.0), distortion_model=0,
                distortion=(-0.12, 0.03, 0.0002, -0.0001), T_cam_imu=None)
+    import os
     n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, cam, 40, 14, dict(max_features_num=2000, min_distance=20),
-                                             dict(sw_size=40, max_features_in_one_grid=2, if_zupt_valid=0, max_features=2000), init_from_gt=True, min_updates=5)
+                                             dict(sw_size=40, max_features_in_one_grid=2, if_zupt_valid=0, max_features=2000), init_from_gt=True, min_updates=5,
+                                             oracle_threads=min(32, os.cpu_count() or 1))
     assert n_tracks > 600
     print("config-5 shape: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
 
