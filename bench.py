@@ -250,27 +250,44 @@ def cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_sample, all_cpus):
         one(i)
     legs = {}
     i = n_pre
-    for name, nt in (("one_thread", 1), ("all_cores", ncores)):
+
+    def leg(nt, n):
+        nonlocal i
         lvo.set_threads(nt)
         c_fe = c_be = 0.0
         t0 = time.perf_counter()
-        for _ in range(n_sample):
+        for _ in range(n):
             a, b = one(i); c_fe += a; c_be += b; i += 1
         dt = time.perf_counter() - t0
-        legs[name] = dict(value=round(n_sample / dt, 2), cores=nt, seconds=round(dt, 2), front_end_ms_per_frame=round(c_fe / n_sample * 1e3, 3),
-                          back_end_ms_per_frame=round(c_be / n_sample * 1e3, 3))
+        return dict(value=round(n / dt, 2), cores=nt, seconds=round(dt, 2), front_end_ms_per_frame=round(c_fe / n * 1e3, 3),
+                    back_end_ms_per_frame=round(c_be / n * 1e3, 3))
+    legs["one_thread"] = leg(1, n_sample)
+    # The multi-threaded leg: at these sizes (0.36 MB images, ~150 tracks) fork/join of hundreds of threads costs more than the loops
+    # it spreads, so the thread count is swept on short samples and the best one is timed over the full sample; the all-core figure
+    # is reported beside it.
+    n_short = max(16, n_sample // 8)
+    sweep = {}
+    for nt in sorted(set(x for x in (4, 8, 16, 32, 64, ncores) if x <= ncores)):
+        sweep[nt] = leg(nt, n_short)
+    best_nt = max(sweep, key=lambda k: sweep[k]["value"])
+    legs["best"] = leg(best_nt, n_sample)
+    legs["all_cores"] = sweep[ncores]
     lvo.set_threads(1)
     dim_cpu = orb.dim
     one_t = legs["one_thread"]
     return {"value": one_t["value"], "unit": "frames/s", "cores": 1, "kind": "port",
             "front_end_ms_per_frame": one_t["front_end_ms_per_frame"], "back_end_ms_per_frame": one_t["back_end_ms_per_frame"],
-            "all_cores": {"value": legs["all_cores"]["value"], "cores": ncores, "front_end_ms_per_frame": legs["all_cores"]["front_end_ms_per_frame"],
-                          "back_end_ms_per_frame": legs["all_cores"]["back_end_ms_per_frame"],
-                          "note": "OpenMP over image rows, CLAHE tiles, tracks, key points and the dense update's rows/columns; bit-identical results"},
+            "all_cores": {"value": legs["best"]["value"], "cores": legs["best"]["cores"], "front_end_ms_per_frame": legs["best"]["front_end_ms_per_frame"],
+                          "back_end_ms_per_frame": legs["best"]["back_end_ms_per_frame"], "host_cores": ncores,
+                          "every_core": {"value": legs["all_cores"]["value"], "cores": ncores},
+                          "sweep_frames_per_s": {str(k): v["value"] for k, v in sweep.items()},
+                          "note": "OpenMP over image rows, CLAHE tiles, tracks, key points and the dense update's rows/columns (bit-identical results); "
+                                  "thread count swept over 4..all host cores on short samples, the best one timed over the full sample"},
             "state_dim": dim_cpu, "host": cpu_model(),
             "sample": "%d steady-state frames of the same synthetic sequence per leg (window full after a %d-frame pre-roll; %.1f s + %.1f s of CPU work), "
-                      "CPU oracle front-end + back-end: 1 thread (LARVIO is single-threaded), then all %d cores; a restatement, not the Eigen/OpenCV build"
-                      % (n_sample, n_pre, one_t["seconds"], legs["all_cores"]["seconds"], ncores)}
+                      "CPU oracle front-end + back-end: 1 thread (LARVIO is single-threaded), then OpenMP with the best thread count of a sweep up to all %d "
+                      "host cores; a restatement, not the Eigen/OpenCV build"
+                      % (n_sample, n_pre, one_t["seconds"], legs["best"]["seconds"], ncores)}
 
 
 def cpu_model():
@@ -308,7 +325,7 @@ def main():
     sw = wl["sw_size"]
     n_pre_max = 2 * sw + 40 + 48                         # fill (one clone per message, every other frame) + cycle + 20 bracketed updates
     n_cpu = 0 if (args.no_cpu_baseline or world > 1) else (args.cpu_baseline_frames or (24 if args.config == "5" else 300))
-    n_frames = n_pre_max + max(W + K, 2 * n_cpu) + 2
+    n_frames = n_pre_max + max(W + K, 3 * n_cpu + 8 * 16) + 2
     first = int(2.0 * wl["img_rate"])                    # t = 2.0 s: the trajectory is moving
     all_cpus = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
     seed_off = 0 if args.sharded else rank               # sharded: every rank sees the same camera

@@ -175,6 +175,17 @@ typedef struct lvk_ekf lvk_ekf;
 /* stage level (device pointers): the dense algebra of measurementUpdate_msckf / _hybrid (larvio.cpp:1430-1460,1578-1594) */
 /* [H | r] (rows x cols) -> top `cols` rows of Q^T [H | r], in place (SPQR replacement, larvio.cpp:1430-1445). */
 lvk_status lvk_ekf_compress_qr(lvk_context* ctx, double* d_H, int ld, int rows, int cols, double* d_r, int* rows_out);
+/* The same compression when the caller knows the block structure of H (as the filter does: a feature's rows touch the extrinsics / td
+ * columns and the 6-column blocks of the clones that observed it - the sparsity SPQR exploits in the reference).  The rows come in
+ * n_groups consecutive groups; group i has h_rows[i] rows that are zero outside the ascending columns
+ * h_cols[h_col_off[i] .. h_col_off[i+1]).  A TSQR tree over consecutive groups whose column union fits one workgroup's LDS is planned on
+ * the host and run level by level (work ~ 2 r c^2 with c = columns per node instead of 2 r cols^2).  Result in place at the top of
+ * d_H / d_r, *rows_out rows (>= cols possible: finish with lvk_ekf_compress_qr).  lvk_ekf_qr_plan is the host-only planning step
+ * (no device needed): blocks as 8 ints {in_start, in_rows, out_start, out_rows, ncols, col_off, copy, 0} level after level. */
+lvk_status lvk_ekf_compress_qr_groups(lvk_context* ctx, double* d_H, int ld, int rows, int cols, double* d_r, int n_groups,
+                                      const int* h_rows, const int* h_col_off, const int* h_cols, int* rows_out);
+int        lvk_ekf_qr_plan(int N, int n_groups, const int* h_rows, const int* h_col_off, const int* h_cols, int* h_blocks, int cap_blocks,
+                           int* h_block_cols, int cap_cols, int* h_level_blocks, int* h_level_cols, int cap_levels, int* final_rows);
 /* S = H P H^T + sigma2 I ; dx = P H^T S^-1 r ; P <- (I - K H) P symmetrised.  H is m x n (ldh), P n x n (ldp). */
 lvk_status lvk_ekf_update(lvk_context* ctx, double* d_P, int ldp, int n, const double* d_H, int ldh, int m,
                           const double* d_r, double sigma2, double* d_dx);

@@ -13,9 +13,11 @@
 #include "lvk_internal.h"
 #include "be_dev.h"
 #include "be_host_math.h"
+#include "be_qr.h"
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <iterator>
 #include <new>
 #include <float.h>
 #include <sched.h>
@@ -43,6 +45,7 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out, FeatResult* d_out_host);
 lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
+
 double lvk_chi2_005(int dof);
 
 // ------------------------------------------------------------------------- host records
@@ -113,6 +116,9 @@ struct lvk_ekf {
     int* d_rank = nullptr; double *d_z = nullptr, *d_zv = nullptr; CamPose* d_cams = nullptr; CloneDev* d_clones = nullptr;
     double* d_staging = nullptr; size_t staging_cap = 0; int* d_ccols = nullptr; size_t ccols_cap = 0; StackRow* d_map = nullptr;
     double *d_H = nullptr, *d_r = nullptr, *d_H1 = nullptr, *d_H2 = nullptr, *d_r1 = nullptr;
+    double *d_Hb = nullptr, *d_rb = nullptr;            // ping-pong partner of d_H / d_r for the levels of the structure-aware compression
+    int sparse_qr = 1;                                  // LVK_SPARSE_QR=0 disables the structure-aware compression (A/B runs)
+    long qr_stats[4] = {0, 0, 0, 0};                    // [0] updates compressed [1] levels run [2] rows in [3] rows out
     UpdateWs ws;
     // pinned host arenas
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
@@ -760,9 +766,26 @@ static bool gate_ok(lvk_ekf* e, const RowJob& j)
     e->counters[ok ? 4 : 5]++;
     return ok;
 }
-// rows [first, first+count) of a job's compact block -> consecutive dense rows starting at dst
-static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst, int gate_job = -1)
+// A run of consecutive stacked rows that share one column set (the rows of one feature job): what the structure-aware compression
+// plans its TSQR tree from.  cols = the dense columns the rows can be non-zero in (ascending), as k_feature_rows lays them out:
+// extrinsics + td 15..21, the observing clones' 6-blocks, the anchor's block and the feature's own column for in-state features.
+static void job_dense_cols(const lvk_ekf* e, const RowJob& j, int ncols, std::vector<int>& out)
 {
+    out.clear();
+    for (int k = 15; k < 22; ++k) out.push_back(k);
+    auto block = [&](int rank) { for (int k = 0; k < 6; ++k) out.push_back(LEG + 6 * rank + k); };
+    if (j.type != JOB_MSCKF) block(j.dev.anchor_rank);
+    for (long long sid : j.sids) block(clone_rank(e, sid));
+    if (j.type != JOB_MSCKF) out.push_back(j.dev.fcol);
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    while (!out.empty() && out.back() >= ncols) out.pop_back();      // a new feature's own column is not part of H_o (k_stack_rows drops it)
+}
+// rows [first, first+count) of a job's compact block -> consecutive dense rows starting at dst
+static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst, int gate_job = -1,
+                      std::vector<RowGroup>* groups = nullptr, const lvk_ekf* e = nullptr, int ncols = 0)
+{
+    if (groups && count > 0) { groups->emplace_back(); groups->back().start = dst; groups->back().rows = count; job_dense_cols(e, j, ncols, groups->back().cols); }
     const int M = j.dev.n_obs, c = job_cols(j);
     for (int k = 0; k < count; ++k) {
         StackRow s; s.g_off = j.dev.stage_off; s.r_off = j.dev.stage_off + (long long)2 * M * c * 2; s.src_row = first + k; s.c = c; s.ccol_off = j.dev.ccol_off; s.dst_row = dst + k;
@@ -779,13 +802,34 @@ static lvk_status stack_rows(lvk_ekf* e, const std::vector<StackRow>& map, doubl
     const StackRow* d_map = dev(e, h); const int n = (int)map.size();
     return run_or_defer(e, [=]() { return lvk_launch_stack_rows(e->ctx, e->d_fout, d_map, n, e->d_staging, e->d_ccols, dH, e->ld, ncols, dr); });
 }
-// dense update with m stacked rows already in d_H/d_r: compress when too tall, update P, fetch dx
-static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int extra)
+// dense update with m stacked rows already in d_H/d_r: compress (structure-aware when the row groups are known and it pays, dense
+// Householder TSQR when the block is still too tall), update P, fetch dx
+static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int extra, const std::vector<RowGroup>* groups = nullptr)
 {
     lvk_status st = LVK_OK;
+    double* H = e->d_H; double* r = e->d_r;
+    if (groups && e->sparse_qr && m >= 96) {
+        std::vector<QrPlanLevel> levels; int m2 = m;
+        lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
+        if (!levels.empty() && m2 + 32 <= m) {
+            for (QrPlanLevel& L : levels) {
+                QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
+                if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+                memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
+                st = flush_uploads(e);
+                double* Ho = (H == e->d_H) ? e->d_Hb : e->d_H; double* ro = (r == e->d_r) ? e->d_rb : e->d_r;
+                if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, H, e->ld, r, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), e->N, L.lds);
+                if (st != LVK_OK) return st;
+                H = Ho; r = ro;
+                e->qr_stats[1]++;
+            }
+            e->qr_stats[0]++; e->qr_stats[2] += m; e->qr_stats[3] += m2;
+            m = m2;
+        }
+    }
     if (m > e->rows_cap - 32) {
         int m2 = m;
-        st = lvk_qr_compress_dev(e->ctx, e->d_H, e->ld, m, e->N, e->d_r, &m2);
+        st = lvk_qr_compress_dev(e->ctx, H, e->ld, m, e->N, r, &m2);
         if (st != LVK_OK) return st;
         m = m2;
     }
@@ -796,7 +840,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
         ws.ev_a = take(); ws.ev_b = take();
         e->prof_pending.push_back({ws.ev_a, ws.ev_b, 2.0 * m * (double)e->N * (double)e->N});
     }
-    st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, e->d_H, e->ld, m, e->d_r, e->sigma2, e->d_dx, ws);
+    st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, H, e->ld, m, r, e->sigma2, e->d_dx, ws);
     if (st != LVK_OK) return st;
     dx.assign((size_t)e->N + extra, 0.0);
     e->counters[2] = m;
@@ -945,16 +989,16 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             begin_defer(e);                             // the jobs and the stacking map go up in one copy
             st = launch_feature_rows(e, jobs);
             if (st != LVK_OK) { end_defer(e); return st; }
-            std::vector<StackRow> map_o;
+            std::vector<StackRow> map_o; std::vector<RowGroup> grp;
             int rows_m = 0, rows_e = 0;
-            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k); rows_m += r; }
-            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k); rows_e += 2; }
+            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N); rows_m += r; }
+            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N); rows_e += 2; }
             const int m = rows_m + rows_e;
             if (m > e->hrows) { end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
             st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
             std::vector<double> dx;
-            if (st == LVK_OK) st = dense_update(e, m, dx, 0);
+            if (st == LVK_OK) st = dense_update(e, m, dx, 0, &grp);
             TR(TR_RLF_UPD);
             if (st == LVK_OK) st = fetch_feature_results(e, jobs, dx.data(), (size_t)N);
             if (st != LVK_OK) return st;
@@ -976,10 +1020,10 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         if (st != LVK_OK) return st;
         TR(TR_RLF_ROWS);
         // ---- accepted sets and row layout: H_o = [H_msckf ; H_ekf ; top rows of the new block] (:1612-1626)
-        std::vector<StackRow> map_o, map_1;
+        std::vector<StackRow> map_o, map_1; std::vector<RowGroup> grp;
         int rows_m = 0, rows_e = 0, top = 0;
-        for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m); rows_m += jobs[k].res.rows; }
-        for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e); rows_e += 2; }
+        for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m, -1, &grp, e, N); rows_m += jobs[k].res.rows; }
+        for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, -1, &grp, e, N); rows_e += 2; }
         std::vector<long long> acc_ids; std::vector<double> h2;
         std::vector<size_t> acc_jobs;
         for (size_t k = 0; k < j_ekf; k += 2) {
@@ -989,7 +1033,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         }
         for (size_t a = 0; a < acc_jobs.size(); ++a) {
             const RowJob& j = jobs[acc_jobs[a]];
-            push_rows(map_o, j, 1, j.res.rows, rows_m + rows_e + top); top += j.res.rows;
+            push_rows(map_o, j, 1, j.res.rows, rows_m + rows_e + top, -1, &grp, e, N); top += j.res.rows;
             push_rows(map_1, j, 0, 1, (int)a);
         }
         e->feature_states.resize(n_fs_old);
@@ -1001,7 +1045,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             if (st == LVK_OK && n_acc) st = stack_rows(e, map_1, e->d_H1, N, e->d_r1);
             if (st != LVK_OK) return st;
             std::vector<double> dx;
-            st = dense_update(e, m, dx, n_acc);
+            st = dense_update(e, m, dx, n_acc, &grp);
             if (st != LVK_OK) return st;
             if (n_acc) {
                 double* hh = up_alloc<double>(e, n_acc);
@@ -1194,14 +1238,14 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         st = launch_feature_rows(e, jobs);
         if (st != LVK_OK) { end_defer(e); return st; }
         TR(TR_PR_ROWS);
-        std::vector<StackRow> map_o; int rows = 0;
-        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k); rows += r; }
+        std::vector<StackRow> map_o; std::vector<RowGroup> grp; int rows = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N); rows += r; }
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
         {
             st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
             std::vector<double> dx;
-            if (st == LVK_OK) st = dense_update(e, rows, dx, 0);
+            if (st == LVK_OK) st = dense_update(e, rows, dx, 0, &grp);
             TR(TR_PR_UPD);
             if (st == LVK_OK) st = fetch_feature_results(e, jobs, dx.data(), (size_t)e->N);
             if (st != LVK_OK) return st;
@@ -1350,7 +1394,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
         g_tr = EkfTrace();
     }
     void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
-                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info, e->zero_copy ? nullptr : (void*)e->d_up};
+                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_Hb, e->d_rb, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info, e->zero_copy ? nullptr : (void*)e->d_up};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_up) hipHostFree(e->h_up);
     if (e->h_down) hipHostFree(e->h_down);
@@ -1366,6 +1410,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     g_tr.on = getenv("LVK_EKF_TRACE") != nullptr;
     lvk_ekf* e = new (std::nothrow) lvk_ekf();
     if (!e) return LVK_ERR_DEVICE;
+    { const char* sq = getenv("LVK_SPARSE_QR"); if (sq) e->sparse_qr = atoi(sq) != 0; }
     e->ctx = ctx; e->cfg = *cfg;
     const lvk_ekf_config& c = e->cfg;
     e->leg = c.calib_imu_instrinsic ? 46 : 22;
@@ -1409,7 +1454,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
               dalloc(&e->d_tri, (size_t)2 * e->feat_cap) && dalloc(&e->d_fj, (size_t)2 * e->feat_cap) && dalloc(&e->d_fout, (size_t)2 * e->feat_cap) &&
               dalloc(&e->d_rank, e->obs_cap) && dalloc(&e->d_z, (size_t)2 * e->obs_cap) && dalloc(&e->d_zv, (size_t)2 * e->obs_cap) &&
               dalloc(&e->d_cams, c.sw_size + 4) && dalloc(&e->d_clones, c.sw_size + 4) && dalloc(&e->d_staging, e->staging_cap) && dalloc(&e->d_ccols, e->ccols_cap) &&
-              dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
+              dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_Hb, hrows * e->ld) && dalloc(&e->d_rb, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
     e->ws.ldb = ((e->ld + 8 + 7) & ~7) | 8; e->ws.lds = e->rows_cap + 8;      // odd multiples of 64 B: power-of-two row strides pile onto one L2 channel
     ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds) && dalloc(&e->ws.info, 16);
     e->up_cap = (size_t)32 << 20;

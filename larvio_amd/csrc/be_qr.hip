@@ -7,7 +7,10 @@
 // At the north-star size (a few hundred rows, ~200 columns) that is a single workgroup; at 18,000 rows (config 5)
 // the first level runs ~36 workgroups in parallel.
 #include "lvk_internal.h"
+#include "be_qr.h"
 #include "chi2_table.inc"
+#include <algorithm>
+#include <iterator>
 
 double lvk_chi2_005(int dof) { return (dof >= 1 && dof <= 99) ? k_chi2_005[dof] : 0.0; }
 
@@ -74,6 +77,166 @@ __global__ void __launch_bounds__(QR_THREADS) k_qr_block(double* __restrict__ H,
     }
 }
 
+// ------------------------------------------------------------------------- structure-aware compression (the product path)
+// The stacked MSCKF rows are block-sparse: a feature's rows touch the extrinsics/td columns and the 6-column blocks of the few clones
+// that observed it (7 + 6 M columns of N), and features tracked over the same stretch of the window share those columns - which is
+// what lets SPQR (larvio.cpp:1430-1445) beat a dense factorisation in the reference.  The host knows every row group's column set
+// (it built the stacking map), so it plans a TSQR tree over CONSECUTIVE row groups whose column union fits one workgroup's LDS:
+// each node gathers its rows restricted to the union columns into LDS (column-major, one wavefront per row on the way in), runs a
+// Householder QR there (one wavefront per column on the apply step, wave reductions for the dot products, ONE barrier per step: the
+// wavefront that updates column k+1 also prepares its reflector) and writes min(rows, columns) rows of R back, expanded to the dense
+// column layout.  Work drops from 2 r N^2 to ~2 r c^2 (c ~ 50 of N ~ 220..450) and every level is a single launch.
+// Blocks that would not shrink (rows <= columns, e.g. the two rows of each in-state feature with their scattered anchor columns)
+// are passed through by a copy.
+#define QS_THREADS 1024
+#define QS_WAVES (QS_THREADS / 64)
+
+__device__ __forceinline__ void qs_prep_column(double* __restrict__ colk, int R, int k, int lane, double* __restrict__ diag, double* __restrict__ scal)
+{   // one wavefront: reflector of column k below row k.  v overwrites the column (v_k = a_kk - alpha), R's diagonal goes to diag[k]
+    double part = 0.;
+    for (int i = k + lane; i < R; i += 64) { const double a = colk[i]; part += a * a; }
+    const double s = wave_sum_f64(part);
+    if (lane == 0) {
+        const double akk = colk[k];
+        const double nrm = sqrt(s);
+        const double alpha = akk >= 0. ? -nrm : nrm;
+        const double vn2 = 2. * (s - alpha * akk);                 // |x - alpha e_k|^2
+        const double beta = (nrm == 0. || vn2 == 0.) ? 0. : 2. / vn2;
+        diag[k] = beta != 0. ? alpha : akk;
+        if (beta != 0.) colk[k] = akk - alpha;
+        scal[k & 1] = beta;
+    }
+}
+
+__global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
+                                                         double* __restrict__ Hout, int ldout, double* __restrict__ rout,
+                                                         const QrBlock* __restrict__ blocks, const int* __restrict__ col_lists, int N)
+{
+    extern __shared__ double sm[];
+    const QrBlock b = blocks[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (b.copy) {
+        for (int i = wave; i < b.in_rows; i += QS_WAVES) {
+            const double* src = Hin + (size_t)(b.in_start + i) * ldin; double* dst = Hout + (size_t)(b.out_start + i) * ldout;
+            for (int j = lane; j < N; j += 64) dst[j] = src[j];
+            if (lane == 0) rout[b.out_start + i] = rin[b.in_start + i];
+        }
+        return;
+    }
+    const int nc = b.ncols, R = b.in_rows, Rp = R | 1;               // odd column stride: the row-wise fill does not pile onto one bank
+    double* A = sm;                                                    // (nc + 1) columns of Rp doubles; column nc is the residual
+    double* diag = A + (size_t)(nc + 1) * Rp;                          // nc
+    double* scal = diag + nc;                                          // 2 (beta of the current / the next step)
+    int* inv = (int*)(scal + 2);                                       // N: dense column -> position in the union (or -1)
+    const int* cols = col_lists + b.col_off;
+    for (int j = t; j < N; j += QS_THREADS) inv[j] = -1;
+    for (int i = wave; i < R; i += QS_WAVES) {
+        const double* src = Hin + (size_t)(b.in_start + i) * ldin;
+        for (int c = lane; c <= nc; c += 64) A[(size_t)c * Rp + i] = c < nc ? src[cols[c]] : rin[b.in_start + i];
+    }
+    __syncthreads();
+    for (int c = t; c < nc; c += QS_THREADS) inv[cols[c]] = c;
+    const int steps = nc < R - 1 ? nc : R - 1;
+    if (wave == 0 && steps > 0) qs_prep_column(A, R, 0, lane, diag, scal);
+    __syncthreads();
+    for (int k = 0; k < steps; ++k) {
+        const double beta = scal[k & 1];
+        const double* v = A + (size_t)k * Rp;
+        for (int j = k + 1 + wave; j <= nc; j += QS_WAVES) {
+            double* col = A + (size_t)j * Rp;
+            if (beta != 0.) {
+                double s = 0.;
+                for (int i = k + lane; i < R; i += 64) s += v[i] * col[i];
+                s = wave_sum_f64(s) * beta;
+                if (s != 0.) for (int i = k + lane; i < R; i += 64) col[i] -= s * v[i];
+            }
+            if (j == k + 1 && k + 1 < steps) {                        // always wave 0: the next reflector, in the shadow of the other columns' updates
+                __builtin_amdgcn_wave_barrier();
+                qs_prep_column(col, R, k + 1, lane, diag, scal);
+            }
+        }
+        __syncthreads();
+    }
+    // R (upper trapezoid in the union's column order) expanded to the dense layout: one wavefront per output row, coalesced
+    for (int i = wave; i < b.out_rows; i += QS_WAVES) {
+        double* dst = Hout + (size_t)(b.out_start + i) * ldout;
+        for (int j = lane; j < N; j += 64) {
+            const int c = inv[j];
+            double val = 0.;
+            if (c >= i && i < R) val = (c == i) ? (i < steps ? diag[i] : A[(size_t)i * Rp + i]) : A[(size_t)c * Rp + i];
+            dst[j] = val;
+        }
+        if (lane == 0) rout[b.out_start + i] = i < R ? A[(size_t)nc * Rp + i] : 0.;
+    }
+}
+
+// LDS a node needs (bytes): the planner's fit test and the launch use the same formula
+size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N)
+{
+    const size_t Rp = (size_t)(rows | 1);
+    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2) + sizeof(int) * (size_t)N + 16;
+}
+lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
+                               const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds)
+{
+    if (n_blocks <= 0) return LVK_OK;
+    if (max_lds > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "QR node needs %zu bytes of LDS", max_lds);
+    if (max_lds > 64 * 1024) LVK_LDS_OPTIN(ctx, 3, k_qr_sparse, max_lds);
+    hipLaunchKernelGGL(k_qr_sparse, dim3(n_blocks), dim3(QS_THREADS), max_lds, ctx->stream, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, d_cols, N);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+// ---- structure-aware compression: the TSQR tree over consecutive row groups (be_qr.hip, k_qr_sparse)
+static void merge_cols(const std::vector<int>& a, const std::vector<int>& b, std::vector<int>& out)
+{
+    out.clear(); out.reserve(a.size() + b.size());
+    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
+}
+// Greedy, level by level: consecutive groups are merged into one node while the node still fits the workgroup's LDS; a node that
+// already shrinks (rows > columns) does not take in a group that brings more new columns than rows (the two rows of an in-state
+// feature with its own anchor block).  A node with rows <= columns is passed through.  A level is kept only if it removes at
+// least a fifth of the rows.  Everything here is known on the host before any kernel runs: no counts come back from the device.
+void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLevel>& levels, int* final_rows)
+{
+    const size_t LDS_CAP = (size_t)152 * 1024;
+    levels.clear();
+    int total = 0; for (auto& g : cur) { g.start = total; total += g.rows; }
+    std::vector<int> uni, merged;
+    for (int lvl = 0; lvl < 8 && cur.size() > 0; ++lvl) {
+        QrPlanLevel L; std::vector<RowGroup> next;
+        size_t i = 0; int out_row = 0; bool any = false;
+        while (i < cur.size()) {
+            uni = cur[i].cols; int rows = cur[i].rows; size_t j = i + 1;
+            while (j < cur.size()) {
+                merge_cols(uni, cur[j].cols, merged);
+                const int r2 = rows + cur[j].rows;
+                if (lvk_qr_sparse_lds_bytes(r2, (int)merged.size(), N) > LDS_CAP) break;
+                if (rows > (int)uni.size() && (int)(merged.size() - uni.size()) > cur[j].rows) break;
+                uni.swap(merged); rows = r2; ++j;
+            }
+            QrBlock b; b.in_start = cur[i].start; b.in_rows = rows; b.out_start = out_row; b.pad = 0;
+            if (rows > (int)uni.size() && lvk_qr_sparse_lds_bytes(rows, (int)uni.size(), N) <= LDS_CAP) {
+                b.copy = 0; b.ncols = (int)uni.size(); b.out_rows = b.ncols; b.col_off = (int)L.cols.size();
+                L.cols.insert(L.cols.end(), uni.begin(), uni.end());
+                L.lds = std::max(L.lds, lvk_qr_sparse_lds_bytes(rows, b.ncols, N));
+                next.emplace_back(); next.back().start = out_row; next.back().rows = b.out_rows; next.back().cols = uni;
+                any = true;
+            } else {
+                b.copy = 1; b.ncols = 0; b.out_rows = rows; b.col_off = 0;
+                for (size_t g = i; g < j; ++g) { next.push_back(cur[g]); next.back().start = out_row + (cur[g].start - cur[i].start); }
+            }
+            L.blocks.push_back(b);
+            out_row += b.out_rows; i = j;
+        }
+        L.in_rows = total; L.out_rows = out_row;
+        if (!any || out_row * 5 > total * 4) break;
+        levels.push_back(std::move(L));
+        cur.swap(next); total = out_row;
+    }
+    *final_rows = total;
+}
+
 // move the first `keep` rows of every block to the front (block b -> rows [b*keep, ...))
 __global__ void k_qr_pack(const double* __restrict__ H, int ld, int cols, const double* __restrict__ r, int total_rows, int block_rows, int keep,
                           double* __restrict__ Hout, double* __restrict__ rout)
@@ -122,4 +285,76 @@ extern "C" lvk_status lvk_ekf_compress_qr(lvk_context* ctx, double* d_H, int ld,
     if (!ctx || !d_H || !d_r || !rows_out || rows < 0 || cols <= 0 || ld < cols) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr: bad argument");
     if (rows <= cols) { *rows_out = rows; return LVK_OK; }
     return lvk_qr_compress_dev(ctx, d_H, ld, rows, cols, d_r, rows_out);
+}
+
+// ---- stage-level C ABI of the structure-aware compression
+static void groups_from_arrays(int n_groups, const int* rows, const int* col_off, const int* cols, std::vector<RowGroup>& g)
+{
+    g.resize((size_t)n_groups);
+    for (int i = 0; i < n_groups; ++i) { g[i].start = 0; g[i].rows = rows[i]; g[i].cols.assign(cols + col_off[i], cols + col_off[i + 1]); }
+}
+// host-only: the TSQR tree for `n_groups` consecutive row groups (group i: h_rows[i] rows, columns h_cols[h_col_off[i] .. h_col_off[i+1]),
+// ascending).  Blocks come back as 8 ints each (QrBlock), level after level; h_level_blocks[l] / h_level_cols[l] = blocks / column-list
+// entries of level l.  Returns the number of levels (0: not worth compressing), or -1 on a bad argument / too small an output buffer.
+extern "C" int lvk_ekf_qr_plan(int N, int n_groups, const int* h_rows, const int* h_col_off, const int* h_cols, int* h_blocks, int cap_blocks,
+                               int* h_block_cols, int cap_cols, int* h_level_blocks, int* h_level_cols, int cap_levels, int* final_rows)
+{
+    if (N <= 0 || n_groups < 0 || !h_rows || !h_col_off || !h_cols || !final_rows) return -1;
+    std::vector<RowGroup> g; groups_from_arrays(n_groups, h_rows, h_col_off, h_cols, g);
+    std::vector<QrPlanLevel> levels;
+    lvk_qr_sparse_plan(g, N, levels, final_rows);
+    int nb = 0, ncl = 0;
+    if ((int)levels.size() > cap_levels) return -1;
+    for (size_t l = 0; l < levels.size(); ++l) {
+        if (nb + (int)levels[l].blocks.size() > cap_blocks || ncl + (int)levels[l].cols.size() > cap_cols) return -1;
+        memcpy(h_blocks + 8 * nb, levels[l].blocks.data(), sizeof(QrBlock) * levels[l].blocks.size());
+        if (!levels[l].cols.empty()) memcpy(h_block_cols + ncl, levels[l].cols.data(), sizeof(int) * levels[l].cols.size());
+        h_level_blocks[l] = (int)levels[l].blocks.size(); h_level_cols[l] = (int)levels[l].cols.size();
+        nb += (int)levels[l].blocks.size(); ncl += (int)levels[l].cols.size();
+    }
+    return (int)levels.size();
+}
+// device: [H | r] (rows x cols, leading dimension ld) whose rows come in `n_groups` consecutive groups with known column sets ->
+// rows_out rows that carry the same H^T H and H^T r, in place at the top of d_H / d_r (the levels ping-pong through scratch memory).
+// rows_out < rows only if the plan found something to remove; follow with lvk_ekf_compress_qr for the dense finish when
+// rows_out > cols.
+extern "C" lvk_status lvk_ekf_compress_qr_groups(lvk_context* ctx, double* d_H, int ld, int rows, int cols, double* d_r, int n_groups,
+                                                 const int* h_rows, const int* h_col_off, const int* h_cols, int* rows_out)
+{
+    if (!ctx || !d_H || !d_r || !rows_out || rows < 0 || cols <= 0 || ld < cols || n_groups < 0 || !h_rows || !h_col_off || !h_cols)
+        return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr_groups: bad argument");
+    std::vector<RowGroup> g; groups_from_arrays(n_groups, h_rows, h_col_off, h_cols, g);
+    int tot = 0; for (auto& x : g) tot += x.rows;
+    if (tot != rows) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr_groups: the groups hold %d rows, the matrix %d", tot, rows);
+    for (auto& x : g) for (size_t k = 0; k < x.cols.size(); ++k)
+        if (x.cols[k] < 0 || x.cols[k] >= cols || (k > 0 && x.cols[k] <= x.cols[k - 1])) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr_groups: column lists must be ascending and < cols");
+    std::vector<QrPlanLevel> levels; int m2 = rows;
+    lvk_qr_sparse_plan(g, cols, levels, &m2);
+    *rows_out = rows;
+    if (levels.empty()) return LVK_OK;
+    double* Hb = (double*)lvk_ctx_scratch(ctx, 7, sizeof(double) * (size_t)rows * ld);
+    double* rb = (double*)lvk_ctx_scratch(ctx, 8, sizeof(double) * (size_t)rows);
+    size_t nb = 0, ncl = 0; for (auto& L : levels) { nb += L.blocks.size(); ncl += L.cols.size() + 1; }
+    char* meta = (char*)lvk_ctx_scratch(ctx, 9, sizeof(QrBlock) * nb + sizeof(int) * ncl);
+    if (!Hb || !rb || !meta) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
+    QrBlock* d_blocks = (QrBlock*)meta; int* d_cols = (int*)(meta + sizeof(QrBlock) * nb);
+    std::vector<QrBlock> hb; std::vector<int> hc;
+    for (auto& L : levels) { hb.insert(hb.end(), L.blocks.begin(), L.blocks.end()); hc.insert(hc.end(), L.cols.begin(), L.cols.end()); hc.push_back(0); }
+    LVK_HIP(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(QrBlock) * nb, hipMemcpyHostToDevice, ctx->stream));
+    LVK_HIP(ctx, hipMemcpyAsync(d_cols, hc.data(), sizeof(int) * ncl, hipMemcpyHostToDevice, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // hb / hc are stack-local
+    double* H = d_H; double* r = d_r; size_t ob = 0, oc = 0;
+    for (auto& L : levels) {
+        double* Ho = (H == d_H) ? Hb : d_H; double* ro = (r == d_r) ? rb : d_r;
+        lvk_status st = lvk_qr_sparse_level(ctx, H, ld, r, Ho, ld, ro, d_blocks + ob, (int)L.blocks.size(), d_cols + oc, cols, L.lds);
+        if (st != LVK_OK) return st;
+        ob += L.blocks.size(); oc += L.cols.size() + 1;
+        H = Ho; r = ro;
+    }
+    if (H != d_H) {
+        LVK_HIP(ctx, hipMemcpy2DAsync(d_H, sizeof(double) * ld, H, sizeof(double) * ld, sizeof(double) * cols, m2, hipMemcpyDeviceToDevice, ctx->stream));
+        LVK_HIP(ctx, hipMemcpyAsync(d_r, r, sizeof(double) * m2, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    *rows_out = m2;
+    return LVK_OK;
 }

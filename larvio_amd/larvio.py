@@ -40,6 +40,8 @@ def _L():
         pi = C.POINTER(C.c_int)
         L.lvk_ekf_compress_qr.argtypes = [vp, vp, i, i, i, vp, pi]; L.lvk_ekf_compress_qr.restype = i
         L.lvk_ekf_update.argtypes = [vp, vp, i, i, vp, i, i, vp, d, vp]; L.lvk_ekf_update.restype = i
+        L.lvk_ekf_compress_qr_groups.argtypes = [vp, vp, i, i, i, vp, i, vp, vp, vp, pi]; L.lvk_ekf_compress_qr_groups.restype = i
+        L.lvk_ekf_qr_plan.argtypes = [i, i, vp, vp, vp, vp, i, vp, i, vp, vp, i, pi]; L.lvk_ekf_qr_plan.restype = i
         L.lvk_dgemm.argtypes = [vp, i, i, i, i, i, d, vp, i, vp, i, d, vp, i]; L.lvk_dgemm.restype = i
         L.lvk_ekf_create.argtypes = [vp, C.POINTER(EkfConfig), C.POINTER(vp)]; L.lvk_ekf_create.restype = i
         L.lvk_ekf_destroy.argtypes = [vp]; L.lvk_ekf_destroy.restype = None
@@ -116,6 +118,45 @@ def compress_qr(ctx, H, r):
     dH, dr = ctx.to_device(H), ctx.to_device(r)
     out = C.c_int(0)
     ctx.check(_L().lvk_ekf_compress_qr(ctx.h, _p(dH), cols, rows, cols, _p(dr), C.byref(out)))
+    k = out.value
+    return ctx.to_host(dH, np.float64, (rows, cols))[:k].copy(), ctx.to_host(dr, np.float64, (rows,))[:k].copy()
+
+
+def _group_arrays(groups):
+    rows = np.ascontiguousarray([g[0] for g in groups], np.int32)
+    off = np.zeros(len(groups) + 1, np.int32)
+    for k, g in enumerate(groups):
+        off[k + 1] = off[k] + len(g[1])
+    cols = np.ascontiguousarray(np.concatenate([np.asarray(g[1], np.int32) for g in groups]) if groups else np.zeros(0, np.int32), np.int32)
+    return rows, off, cols
+
+
+def qr_plan(N, groups):
+    """lvk_ekf_qr_plan (host only): groups = [(rows, ascending column list), ...] in stacking order ->
+    (levels, final_rows), levels = [dict(blocks=[dict(in_start, in_rows, out_start, out_rows, ncols, col_off, copy)], cols=int array)]"""
+    rows, off, cols = _group_arrays(groups)
+    cap_b, cap_c, cap_l = 4 * len(groups) + 16, 8 * (len(cols) + 16), 16
+    blocks = np.zeros((cap_b, 8), np.int32); bcols = np.zeros(cap_c, np.int32); lb = np.zeros(cap_l, np.int32); lc = np.zeros(cap_l, np.int32)
+    fin = C.c_int(0)
+    n = _L().lvk_ekf_qr_plan(int(N), len(groups), _p(rows), _p(off), _p(cols), _p(blocks), cap_b, _p(bcols), cap_c, _p(lb), _p(lc), cap_l, C.byref(fin))
+    if n < 0:
+        raise LvkError("lvk_ekf_qr_plan failed")
+    levels = []; ob = oc = 0
+    keys = ("in_start", "in_rows", "out_start", "out_rows", "ncols", "col_off", "copy")
+    for l in range(n):
+        levels.append(dict(blocks=[dict(zip(keys, map(int, b[:7]))) for b in blocks[ob:ob + lb[l]]], cols=bcols[oc:oc + lc[l]].copy()))
+        ob += lb[l]; oc += lc[l]
+    return levels, fin.value
+
+
+def compress_qr_groups(ctx, H, r, groups):
+    """lvk_ekf_compress_qr_groups on host arrays: H (rows x cols), r, groups = [(rows, ascending column list), ...] -> (H', r')"""
+    H = np.ascontiguousarray(H, np.float64); r = np.ascontiguousarray(r, np.float64)
+    rows, cols = H.shape
+    gr, off, gc = _group_arrays(groups)
+    dH = ctx.to_device(H); dr = ctx.to_device(r)
+    out = C.c_int(0)
+    ctx.check(_L().lvk_ekf_compress_qr_groups(ctx.h, _p(dH), cols, rows, cols, _p(dr), len(groups), _p(gr), _p(off), _p(gc), C.byref(out)))
     k = out.value
     return ctx.to_host(dH, np.float64, (rows, cols))[:k].copy(), ctx.to_host(dr, np.float64, (rows,))[:k].copy()
 

@@ -64,6 +64,34 @@ def test_qr_compression_preserves_information(gpu_ctx, rows, cols):
         assert np.abs(np.tril(R, -1)).max() < 1e-12 * np.abs(R).max()
 
 
+@pytest.mark.parametrize("case", ["steady_A", "burst_5", "steady_5", "ragged"])
+def test_structure_aware_qr_preserves_information(gpu_ctx, case):
+    """lvk_ekf_compress_qr_groups (k_qr_sparse: LDS-resident Householder TSQR over row groups with known column sets) against numpy's
+    H^T H and H^T r on the shapes of tests/test_qr_plan.py, including the 17,000-row burst of configs[4]; then the dense finish."""
+    from larvio_amd import larvio as lv
+    from tests.test_qr_plan import _msckf_like
+    if case == "steady_A":
+        N, groups, H, r = _msckf_like(1, 25, 30, n_state_feat=30)
+    elif case == "burst_5":
+        N, groups, H, r = _msckf_like(2, 1900, 60, n_state_feat=60, burst=True)
+    elif case == "steady_5":
+        N, groups, H, r = _msckf_like(3, 330, 60, n_state_feat=60)
+    else:                                                                    # single-row groups, a rank-deficient node, an all-zero group
+        N, groups, H, r = _msckf_like(6, 120, 24, track=3)
+        H[10:13] = 0.0; r[10:13] = 0.0
+        H[40:49, 15:22] = 0.0
+    G0, g0 = H.T @ H, H.T @ r
+    Hc, rc = lv.compress_qr_groups(gpu_ctx, H, r, groups)
+    levels, final_rows = lv.qr_plan(N, groups)
+    assert len(Hc) == final_rows < len(H)
+    G1, g1 = Hc.T @ Hc, Hc.T @ rc
+    assert np.abs(G1 - G0).max() <= 1e-11 * np.abs(G0).max() * np.sqrt(len(H)), np.abs(G1 - G0).max() / np.abs(G0).max()
+    assert np.abs(g1 - g0).max() <= 1e-11 * np.abs(g0).max() * np.sqrt(len(H))
+    Hd, rd = lv.compress_qr(gpu_ctx, Hc, rc)                                 # dense finish (a no-op when rows <= cols)
+    assert len(Hd) <= N and np.abs(Hd.T @ Hd - G0).max() <= 1e-10 * np.abs(G0).max() * np.sqrt(len(H))
+    print(case, len(H), "->", len(Hc), "->", len(Hd), "rel", np.abs(G1 - G0).max() / np.abs(G0).max())
+
+
 def _R2q(R):
     t = np.trace(R); s = np.sqrt(t + 1) * 2
     return np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
