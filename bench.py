@@ -79,8 +79,11 @@ class Run:
         self.ctx_be = self.ctx if sequential else larvio_amd.Context(local_rank)
         self.be = larvio_amd.LarVio(wl["bcfg"], self.ctx_be)
         assert self.be.initialize()
-        if shard is not None:
-            self.be.set_shard(*shard)
+        self.shard = None
+        if shard is not None:                            # (rank, world, dist): RCCL communicator for THIS filter's context
+            from larvio_amd import sharding
+            self.shard = sharding.make_shard(self.ctx_be, *shard)
+            self.be.set_shard(*self.shard.args())
         self.drv = VioDriver(self.fe, self.be, imu_all) if sequential else VioPipeline(self.fe, self.be, imu_all)
         self.his = [self.drv.visible_end(float(t)) for t in ts]
         self.inited = False
@@ -117,6 +120,8 @@ class Run:
         if not self.sequential:
             self.drv.close()
         self.be.close(); self.fe.close()
+        if self.shard is not None:
+            self.shard.close()
         if self.ctx_be is not self.ctx:
             self.ctx_be.close()
         self.ctx.close()
@@ -290,6 +295,85 @@ def cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_sample, all_cpus):
                       % (n_sample, n_pre, one_t["seconds"], legs["best"]["seconds"], ncores)}
 
 
+def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sharded=None):
+    """The filter alone at configs[4] depth, fed by the feature-level simulator (larvio_amd.synthetic.simulate_features: 2000
+    features per message, 60-clone window): one step = one feature message through processFeatures.  With --sharded every rank
+    runs the same filter on the same messages, does the per-feature device work of its slice and the compressed blocks are
+    all-gathered over RCCL (strong scaling of the update); otherwise rank r runs its own stream (replicas)."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    K = args.steps if K is None else K; W = args.warmup if W is None else W
+    sharded = args.sharded if sharded is None else sharded
+
+    class _A:
+        pass
+    a_ = _A(); a_.sharded = sharded; a_.max_features = args.max_features if args.backend_only else None; a_.sw_size = args.sw_size if args.backend_only else None
+    args = a_
+    n_pre = 2 * 60 + 12
+    sim = S.simulate_features(21 + (0 if args.sharded else rank), t0=2.0, t1=2.0 + 0.1 * (n_pre + W + K + 2), max_feat=args.max_features or 2000,
+                              n_per_batch=500, sw_size=args.sw_size or 60, max_features_in_one_grid=2, estimate_td=1, estimate_extrin=1,
+                              max_features=args.max_features or 2000)
+    ctx = larvio_amd.Context(local_rank)
+    be = larvio_amd.LarVio(sim["cfg"], ctx); assert be.initialize()
+    shard = None
+    if args.sharded and world > 1:
+        from larvio_amd import sharding
+        shard = sharding.make_shard(ctx, rank, world, dist)
+        be.set_shard(*shard.args())
+    imu = sim["imu"]; msgs = sim["msgs"]
+    be.set_state(*sim["init"])
+    lo = 0
+
+    def one(i):
+        nonlocal lo
+        ts, m = msgs[i]
+        hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
+        upd, rest = be.processFeatures((ts, m), imu[lo:hi]); lo = hi - len(rest)
+    i = 0
+    while i < n_pre + W:
+        one(i); i += 1
+    if len(be.clones()) < sim["cfg"]["sw_size"] - 2:
+        raise SystemExit("bench.py --backend-only: the window did not fill in the pre-roll: no value printed")
+    c0 = be.counters(); s0 = be.shard_stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = np.empty(K)
+    t_begin = time.perf_counter()
+    for k in range(K):
+        t0 = time.perf_counter(); one(i); i += 1; lat[k] = time.perf_counter() - t0
+    ctx.sync(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    c1 = be.counters(); s1 = be.shard_stats()
+    streams = 1 if args.sharded else world
+    if rank == 0:
+        out = {"metric": "EKF feature messages/sec (filter only, %d features per message, %d-clone window, state dim %d)" % (len(msgs[i - 1][1]), len(be.clones()), be.dim),
+               "value": round(streams * K / elapsed, 2), "unit": "messages/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
+               "p50_ms_per_message": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_message": round(float(np.percentile(lat, 95)) * 1e3, 4),
+               "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[4] depth, back-end only: simulated feature messages (no images), max_features %d, sw_size %d, 1d-hybrid"
+                                      % (sim["cfg"]["max_features"], sim["cfg"]["sw_size"]),
+                          "parallelism": ("sharded x%d: contiguous feature ranges per rank, one RCCL all-gather of the compressed blocks + gate results per update" % world)
+                                         if args.sharded else "replicas x%d" % world,
+                          "state_dim": be.dim, "clones": len(be.clones()),
+                          "timed_region": {k: c1[k] - c0[k] for k in ("hybrid", "msckf", "gated_in", "gated_out", "triangulations")},
+                          "shard": {k: s1[k] - s0[k] for k in s1}},
+               "roofline": None, "cpu_baseline": None}
+    else:
+        out = None
+    be.close()
+    if shard is not None:
+        shard.close()
+    ctx.close()
+    return out
+
+
 def cpu_model():
     try:
         for l in open("/proc/cpuinfo"):
@@ -313,11 +397,32 @@ def main():
     ap.add_argument("--no-device-pass", action="store_true", help="skip the second (device-resident) pass")
     ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
     ap.add_argument("--sharded", action="store_true", help="config 5 across ranks: per-rank feature rows, RCCL all-gather of the compressed R")
+    ap.add_argument("--no-shard-probe", action="store_true", help="skip the configs[4]-depth (sharded) filter probe appended to the default line")
+    ap.add_argument("--backend-only", action="store_true", help="the filter alone at configs[4] depth on simulated feature messages (no images): "
+                                                                  "the cheap way to time the (sharded) update at 2000 features")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.sharded and args.config != "5":
-        raise SystemExit("--sharded is the configs[4] path (2000 tracks): use --config 5")
+    if args.sharded and args.config != "5" and not args.backend_only:
+        raise SystemExit("--sharded is the configs[4] path (2000 tracks): use --config 5 (or --backend-only)")
+    if args.backend_only:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        bind_one_socket()
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dist = None
+        if world > 1:
+            import torch.distributed as dist_
+            dist = dist_
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        out = backend_only(args, rank, world, local_rank, dist, torch)
+        if out is not None:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from larvio_amd import synthetic as S
     wl = S.workload(args.config, args.max_features, args.sw_size)
@@ -347,10 +452,7 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    shard = None
-    if args.sharded:
-        from larvio_amd import sharding
-        shard = sharding.make_shard(rank, world, dist, local_rank)
+    shard = (rank, world, dist) if (args.sharded and world > 1) else None
 
     stream = torch.cuda.current_stream()
     # ---- pass 1 (headline): host images, H2D inside the timed region
@@ -371,6 +473,16 @@ def main():
         run2.close()
         del d_frames
 
+    # The sharded update at configs[4] depth, measured in the same invocation (filter only, simulated feature messages - seconds, no
+    # rendering): at N > 1 the per-feature work is split over the N ranks with one RCCL all-gather per update, at N = 1 it is the
+    # unsharded baseline of the same workload.  This is the strong-scaling curve north_star asks for "when the tracked-feature count
+    # justifies it"; the headline value above stays the metric's own configuration.
+    probe = None
+    if not args.no_shard_probe and args.config == "A" and not args.sequential:
+        try:
+            probe = backend_only(args, rank, world, local_rank, dist, torch, K=40, W=4, sharded=(world > 1))
+        except SystemExit as exc:
+            probe = {"error": str(exc)} if rank == 0 else None
     if rank == 0:
         win = wl["fcfg"]["patch_size"]
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
@@ -398,7 +510,8 @@ def main():
         if n_cpu:
             his = [int(np.searchsorted(imu_all["t"], float(t) + 0.05, side="left")) for t in ts]
             cpu = cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_cpu, all_cpus)
-        value = world * K / m["elapsed"]
+        streams = 1 if args.sharded else world            # sharded: every rank works on the SAME camera stream
+        value = streams * K / m["elapsed"]
         lat, e2e = m["lat"], m["e2e"]; mm = m["msg_mask"]; pst = m["pst"]
 
         def pct(a, q):
@@ -415,7 +528,7 @@ def main():
                "back_end_ms_per_message": None if pst is None else round(pst["filter_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
                "caller_wait_ms_per_frame": None if pst is None else round(pst["caller_wait_us"] / K * 1e-3, 4),
                "worker_idle_ms_per_message": None if pst is None else round(pst["worker_idle_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
-               "device_resident": None if md is None else {"value": round(world * K / md["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(md["elapsed"] / K * 1e3, 4),
+               "device_resident": None if md is None else {"value": round(streams * K / md["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(md["elapsed"] / K * 1e3, 4),
                                                            "p50_ms_per_frame": pct(md["e2e"], 50),
                                                            "note": "same frames, already in HBM when the timed region starts (no staging copy, no H2D)"},
                "higher_is_better": True, "scaling": ("strong" if args.sharded else "weak"), "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
@@ -439,7 +552,7 @@ def main():
                                  "avg_launch_us": round(hp["ms"] / max(hp["launches"], 1) * 1e3, 3), "launches": hp["launches"],
                                  "measured_over": "the last >= 20 updates of the pre-roll (window full and cycling; kept out of the timed region: "
                                                   "its event records would add ~10% to the filter chain)"},
-               "cpu_baseline": cpu}
+               "cpu_baseline": cpu, "sharded_update_probe": probe}
         if cpu:
             out["x_cpu_one_thread"] = round(value / cpu["value"], 2)
             out["x_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 2)

@@ -253,6 +253,27 @@ void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
  * [milliseconds, flops = sum 2 m N^2, launches] accumulated since the previous call */
 lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* h_out3);
 
+/* ---- sharded measurement update (BASELINE.json configs[4]).  Every rank runs the same filter on the same messages; the
+ * per-feature device work of an update (Jacobian rows, null-space projection, chi-square gate, stacking, first compression) is split
+ * into `world` contiguous feature ranges in the reference's stacking order (larvio.cpp:2185-2201), rank `rank` doing its own; one
+ * all-gather per update hands every rank all compressed blocks and all gate results, in rank order, and the rest of the update is
+ * replicated - identical bits on every rank.  The collective is a callback so that the transport is the caller's choice:
+ * lvk_shard_allgather_rccl (below) runs ncclAllGather on the filter's stream, device buffers in place; a test may move the bytes
+ * through the host.  fn must deliver, in d_recv, the `world` send buffers of bytes_per_rank bytes each in rank order, ordered on
+ * hip_stream.  world = 1 switches sharding off. */
+typedef int /* lvk_status */ (*lvk_exchange_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
+lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn, void* user);
+/* [0] exchanges [1] bytes sent by this rank [2] sharded updates [3] rows this rank stacked; [4] updates the structure-aware
+ * compression ran in [5] its levels [6] rows in [7] rows out */
+void       lvk_ekf_shard_stats(const lvk_ekf* e, long* h_out8);
+/* RCCL transport: one communicator per rank (ncclCommInitRank with the 128-byte id rank 0 obtained from lvk_shard_unique_id and
+ * distributed out of band, e.g. torch.distributed.broadcast); pass lvk_shard_allgather_rccl + the communicator to lvk_ekf_set_shard. */
+typedef struct lvk_shard_comm lvk_shard_comm;
+lvk_status lvk_shard_unique_id(char* h_out128);
+lvk_status lvk_shard_comm_create(lvk_context* ctx, const char* h_uid128, int rank, int world, lvk_shard_comm** out);
+void       lvk_shard_comm_destroy(lvk_shard_comm* c);
+lvk_status lvk_shard_allgather_rccl(void* comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
+
 /* ---- per-feature stages of the update, one call each (parity tests; callers that want a single stage).  Host buffers.
  * lvk_triangulate: Feature::initializePosition (use_position 0) / the LM refinement from a given position (1), feature.hpp:383-890,
  *   n views = camera-to-world poses + normalised observations; *ok_out = the reference's return value.

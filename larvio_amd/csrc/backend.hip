@@ -47,6 +47,10 @@ lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, con
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
 
 double lvk_chi2_005(int dof);
+struct ShardMeta { int job_lo, job_n, k, row_off; };
+lvk_status lvk_shard_pack(lvk_context* ctx, const FeatResult* d_res, int n_res, const double* d_X, int ld, const double* d_rX, int k, int ncols, char* d_send, size_t res_bytes);
+lvk_status lvk_shard_unpack(lvk_context* ctx, const char* d_recv, size_t bytes_per_rank, size_t res_bytes, const ShardMeta* d_meta, int world, int ncols, int k_max,
+                            FeatResult* d_fout, FeatResult* d_fout_host, double* d_H, int ld, double* d_r);
 
 // ------------------------------------------------------------------------- host records
 struct Obs { long long sid; double z[2], zv[2]; };
@@ -119,6 +123,10 @@ struct lvk_ekf {
     double *d_Hb = nullptr, *d_rb = nullptr;            // ping-pong partner of d_H / d_r for the levels of the structure-aware compression
     int sparse_qr = 1;                                  // LVK_SPARSE_QR=0 disables the structure-aware compression (A/B runs)
     long qr_stats[4] = {0, 0, 0, 0};                    // [0] updates compressed [1] levels run [2] rows in [3] rows out
+    // sharded measurement update: this rank builds the feature rows of its contiguous slice, one all-gather of the
+    // compressed blocks (+ every feature's gate result), replicated update.  world 1 = off.
+    struct Shard { int rank = 0, world = 1; lvk_exchange_fn fn = nullptr; void* user = nullptr; char *d_send = nullptr, *d_recv = nullptr; size_t cap = 0;
+                   long stats[4] = {0, 0, 0, 0}; } shard;     // stats: [0] exchanges [1] bytes sent per rank (sum) [2] sharded updates [3] rows this rank stacked
     UpdateWs ws;
     // pinned host arenas
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
@@ -700,8 +708,10 @@ static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracke
 // One feature-rows job (rows on the device) ------------------------------------------------------------
 struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; };
 
-static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
-{   // stages the jobs and queues k_feature_rows; nothing is read back (fetch_feature_results does that)
+typedef std::vector<std::pair<size_t, size_t>> JobRanges;
+static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, const JobRanges* ranges = nullptr)
+{   // stages the jobs and queues k_feature_rows (for the given index ranges only, in the sharded update); nothing is read back
+    // (fetch_feature_results does that)
     if (jobs.empty()) return LVK_OK;
     if ((int)jobs.size() > 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
     size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2;
@@ -737,7 +747,14 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs)
     const FeatJob* d_j = dev(e, hj); const int* d_r = dev(e, hr); const double* d_z = dev(e, hz); const double* d_v = dev(e, hv);
     const int nj = (int)jobs.size(); const CloneDev* d_cl = e->dv_clones; double* P = e->dP[e->cur];
     FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
-    return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh); });
+    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh); });
+    for (const auto& rg : *ranges) {                    // jobs carry absolute offsets into the observation / staging / column arrays
+        const size_t lo = rg.first; const int n = (int)(rg.second - rg.first);
+        if (n <= 0) continue;
+        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo); });
+        if (st != LVK_OK) return st;
+    }
+    return LVK_OK;
 }
 // results of the queued jobs (+ optionally n_dx doubles of d_dx in the same sync)
 static lvk_status fetch_feature_results(lvk_ekf* e, std::vector<RowJob>& jobs, double* dx = nullptr, size_t n_dx = 0)
@@ -783,9 +800,9 @@ static void job_dense_cols(const lvk_ekf* e, const RowJob& j, int ncols, std::ve
 }
 // rows [first, first+count) of a job's compact block -> consecutive dense rows starting at dst
 static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst, int gate_job = -1,
-                      std::vector<RowGroup>* groups = nullptr, const lvk_ekf* e = nullptr, int ncols = 0)
+                      std::vector<RowGroup>* groups = nullptr, const lvk_ekf* e = nullptr, int ncols = 0, int owner = 0)
 {
-    if (groups && count > 0) { groups->emplace_back(); groups->back().start = dst; groups->back().rows = count; job_dense_cols(e, j, ncols, groups->back().cols); }
+    if (groups && count > 0) { groups->emplace_back(); RowGroup& g = groups->back(); g.start = dst; g.rows = count; g.owner = owner; job_dense_cols(e, j, ncols, g.cols); }
     const int M = j.dev.n_obs, c = job_cols(j);
     for (int k = 0; k < count; ++k) {
         StackRow s; s.g_off = j.dev.stage_off; s.r_off = j.dev.stage_off + (long long)2 * M * c * 2; s.src_row = first + k; s.c = c; s.ccol_off = j.dev.ccol_off; s.dst_row = dst + k;
@@ -802,6 +819,90 @@ static lvk_status stack_rows(lvk_ekf* e, const std::vector<StackRow>& map, doubl
     const StackRow* d_map = dev(e, h); const int n = (int)map.size();
     return run_or_defer(e, [=]() { return lvk_launch_stack_rows(e->ctx, e->d_fout, d_map, n, e->d_staging, e->d_ccols, dH, e->ld, ncols, dr); });
 }
+// ---- sharded update: job ownership, stage 1 (own rows -> compressed block), the exchange, the rank-ordered stack
+// contiguous split of jobs [first, last) into `world` ranges of about equal raw row counts (the reference's stacking order is kept:
+// rank g's rows precede rank g+1's)
+static void shard_bounds(const std::vector<RowJob>& jobs, size_t first, size_t last, int world, std::vector<size_t>& b)
+{
+    b.assign((size_t)world + 1, last); b[0] = first;
+    long total = 0; for (size_t k = first; k < last; ++k) total += 2 * (long)jobs[k].sids.size();
+    long cum = 0; int g = 1;
+    for (size_t k = first; k < last && g < world; ++k) {
+        cum += 2 * (long)jobs[k].sids.size();
+        while (g < world && cum * world >= total * g) { b[(size_t)g] = k + 1; ++g; }
+    }
+}
+static int shard_owner(const std::vector<size_t>& b, size_t job) { int g = 0; while ((size_t)g + 2 < b.size() && job >= b[(size_t)g + 1]) ++g; return g; }
+// Stage 1 + exchange.  `map` / `groups` describe ALL stacked rows (every rank computes the same description); this rank stacks the
+// rows of the groups it owns, compresses them (structure-aware TSQR), packs the block together with the gate results of its jobs
+// (job_b != nullptr), all-gathers, and unpacks every rank's block into d_H / d_r in rank order.  On return `groups` describes the
+// stacked blocks (the input of the replicated second stage) and *m_out is their row count.
+static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std::vector<RowGroup>& groups, int ncols, const std::vector<size_t>* job_b, int* m_out)
+{
+    auto& S = e->shard; const int W = S.world, me = S.rank;
+    std::vector<std::vector<RowGroup>> gr((size_t)W), outg((size_t)W);
+    std::vector<StackRow> lmap;
+    { size_t mi = 0; int lrow = 0;
+      for (const RowGroup& g : groups) {
+          gr[(size_t)g.owner].push_back(g);
+          if (g.owner == me) for (int k = 0; k < g.rows; ++k) { StackRow sr = map[mi + (size_t)k]; sr.dst_row = lrow++; lmap.push_back(sr); }
+          mi += (size_t)g.rows;
+      } }
+    std::vector<int> kk((size_t)W, 0); std::vector<QrPlanLevel> my_levels;
+    for (int g = 0; g < W; ++g) {
+        std::vector<QrPlanLevel> lv;
+        lvk_qr_sparse_plan(gr[(size_t)g], ncols, lv, &kk[(size_t)g], &outg[(size_t)g]);
+        if (g == me) my_levels.swap(lv);
+    }
+    const int m_loc = (int)lmap.size();
+    if (m_loc > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m_loc);
+    lvk_status st = stack_rows(e, lmap, e->d_H, ncols, e->d_r);
+    if (st != LVK_OK) return st;
+    double* X = e->d_H; double* rX = e->d_r;
+    for (QrPlanLevel& L : my_levels) {
+        QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
+        if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+        memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
+        st = flush_uploads(e);
+        double* Ho = (X == e->d_H) ? e->d_Hb : e->d_H; double* ro = (rX == e->d_r) ? e->d_rb : e->d_r;
+        if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, X, e->ld, rX, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), ncols, L.lds);
+        if (st != LVK_OK) return st;
+        X = Ho; rX = ro;
+    }
+    int k_max = 0, j_max = 0, m_tot = 0;
+    ShardMeta* hm = up_alloc<ShardMeta>(e, (size_t)W);
+    if (!hm) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    for (int g = 0; g < W; ++g) {
+        hm[g].job_lo = job_b ? (int)(*job_b)[(size_t)g] : 0; hm[g].job_n = job_b ? (int)((*job_b)[(size_t)g + 1] - (*job_b)[(size_t)g]) : 0;
+        hm[g].k = kk[(size_t)g]; hm[g].row_off = m_tot; m_tot += kk[(size_t)g];
+        k_max = std::max(k_max, kk[(size_t)g]); j_max = std::max(j_max, hm[g].job_n);
+    }
+    if (m_tot > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m_tot);
+    const size_t res_bytes = ((size_t)j_max * sizeof(FeatResult) + 255) & ~(size_t)255;
+    const size_t bytes = std::max(res_bytes + (size_t)k_max * (size_t)(ncols + 1) * sizeof(double), (size_t)256);
+    if (bytes > S.cap) {                                 // grow-only exchange buffers (a sync, then never again at this size)
+        EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+        if (S.d_send) hipFree(S.d_send); if (S.d_recv) hipFree(S.d_recv);
+        S.cap = bytes + bytes / 2; S.d_send = S.d_recv = nullptr;
+        if (hipMalloc((void**)&S.d_send, S.cap) != hipSuccess || hipMalloc((void**)&S.d_recv, S.cap * (size_t)W) != hipSuccess)
+            return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "exchange buffers: allocation of %zu bytes failed", S.cap * (size_t)(W + 1));
+    }
+    st = flush_uploads(e);
+    if (st == LVK_OK) st = lvk_shard_pack(e->ctx, e->d_fout + hm[me].job_lo, hm[me].job_n, X, e->ld, rX, kk[(size_t)me], ncols, S.d_send, res_bytes);
+    if (st != LVK_OK) return st;
+    st = S.fn(S.user, S.d_send, S.d_recv, bytes, (void*)e->ctx->stream);
+    if (st != LVK_OK) return lvk_set_error(e->ctx, st, "sharded update: the exchange callback failed");
+    FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
+    st = lvk_shard_unpack(e->ctx, S.d_recv, bytes, res_bytes, dev(e, hm), W, ncols, k_max, e->d_fout, d_fh, e->d_H, e->ld, e->d_r);
+    if (st != LVK_OK) return st;
+    S.stats[0]++; S.stats[1] += (long)bytes; S.stats[3] += m_loc;
+    groups.clear();
+    int off = 0;
+    for (int g = 0; g < W; ++g) for (RowGroup& og : outg[(size_t)g]) { groups.push_back(og); groups.back().start = off; groups.back().owner = 0; off += og.rows; }
+    *m_out = m_tot;
+    return LVK_OK;
+}
+
 // dense update with m stacked rows already in d_H/d_r: compress (structure-aware when the row groups are known and it pays, dense
 // Householder TSQR when the block is still too tall), update P, fetch dx
 static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int extra, const std::vector<RowGroup>* groups = nullptr)
@@ -986,17 +1087,22 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             // No feature enters the state in this update, so nothing on the host depends on the gate before the update is
             // launched: every candidate row gets its slot, the device zeroes the rows of rejected features, and gate results and
             // dx come back in ONE sync.
+            const bool sharded = e->shard.world > 1;
+            std::vector<size_t> jb; JobRanges own;
+            if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
             begin_defer(e);                             // the jobs and the stacking map go up in one copy
-            st = launch_feature_rows(e, jobs);
+            st = launch_feature_rows(e, jobs, sharded ? &own : nullptr);
             if (st != LVK_OK) { end_defer(e); return st; }
             std::vector<StackRow> map_o; std::vector<RowGroup> grp;
             int rows_m = 0, rows_e = 0;
-            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N); rows_m += r; }
-            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N); rows_e += 2; }
-            const int m = rows_m + rows_e;
+            auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
+            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, own_of(k)); rows_m += r; }
+            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); rows_e += 2; }
+            int m = rows_m + rows_e;
             if (m > e->hrows) { end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
-            st = stack_rows(e, map_o, e->d_H, N, e->d_r);
+            if (!sharded) st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
+            if (sharded && st == LVK_OK) { st = shard_stage1(e, map_o, grp, N, &jb, &m); e->shard.stats[2]++; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, m, dx, 0, &grp);
             TR(TR_RLF_UPD);
@@ -1016,14 +1122,27 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             TR(TR_RLF_INJ);
             return LVK_OK;
         }
-        st = run_feature_rows(e, jobs);
+        // A feature is about to enter the state: the gate has to be read before the rows are laid out.  Sharded: the (few) new
+        // features' jobs run on every rank (their first rows initialise the new covariance columns everywhere), the rest is split;
+        // a first exchange carries only the gate results, the second one (below) the compressed blocks.
+        const bool sharded = e->shard.world > 1;
+        std::vector<size_t> jb; JobRanges rgs;
+        if (sharded) {
+            shard_bounds(jobs, j_ekf, jobs.size(), e->shard.world, jb);
+            rgs.push_back({0, j_ekf}); rgs.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]});
+            st = launch_feature_rows(e, jobs, &rgs);
+            std::vector<StackRow> none; std::vector<RowGroup> gnone; int m0 = 0;
+            if (st == LVK_OK) st = shard_stage1(e, none, gnone, N, &jb, &m0);
+            if (st == LVK_OK) st = fetch_feature_results(e, jobs);
+        } else st = run_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
+        auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
         TR(TR_RLF_ROWS);
         // ---- accepted sets and row layout: H_o = [H_msckf ; H_ekf ; top rows of the new block] (:1612-1626)
         std::vector<StackRow> map_o, map_1; std::vector<RowGroup> grp;
         int rows_m = 0, rows_e = 0, top = 0;
-        for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m, -1, &grp, e, N); rows_m += jobs[k].res.rows; }
-        for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, -1, &grp, e, N); rows_e += 2; }
+        for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m, -1, &grp, e, N, own_of(k)); rows_m += jobs[k].res.rows; }
+        for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, -1, &grp, e, N, own_of(k)); rows_e += 2; }
         std::vector<long long> acc_ids; std::vector<double> h2;
         std::vector<size_t> acc_jobs;
         for (size_t k = 0; k < j_ekf; k += 2) {
@@ -1038,10 +1157,11 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         }
         e->feature_states.resize(n_fs_old);
         for (long long id : acc_ids) e->feature_states.push_back(id);
-        const int m = rows_m + rows_e + top, n_acc = (int)acc_ids.size();
+        int m = rows_m + rows_e + top; const int n_acc = (int)acc_ids.size();
         if (m + n_acc > 0) {
             if (m > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
-            st = stack_rows(e, map_o, e->d_H, N, e->d_r);
+            if (sharded) { st = shard_stage1(e, map_o, grp, N, nullptr, &m); e->shard.stats[2]++; }      // the new features' top rows belong to rank 0 (owner 0)
+            else st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             if (st == LVK_OK && n_acc) st = stack_rows(e, map_1, e->d_H1, N, e->d_r1);
             if (st != LVK_OK) return st;
             std::vector<double> dx;
@@ -1234,16 +1354,20 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         std::vector<RowJob> jobs;
         for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
         // measurementUpdate_msckf (:1420-1602), gate decided on the device (see remove_lost_features): one sync for gate + dx
+        const bool sharded = e->shard.world > 1;
+        std::vector<size_t> jb; JobRanges own;
+        if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
         begin_defer(e);
-        st = launch_feature_rows(e, jobs);
+        st = launch_feature_rows(e, jobs, sharded ? &own : nullptr);
         if (st != LVK_OK) { end_defer(e); return st; }
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; std::vector<RowGroup> grp; int rows = 0;
-        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N); rows += r; }
+        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N, sharded ? shard_owner(jb, k) : 0); rows += r; }
         for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
         {
-            st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
+            if (!sharded) st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
+            if (sharded && st == LVK_OK) { st = shard_stage1(e, map_o, grp, e->N, &jb, &rows); e->shard.stats[2]++; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, rows, dx, 0, &grp);
             TR(TR_PR_UPD);
@@ -1398,6 +1522,8 @@ void lvk_ekf_destroy(lvk_ekf* e)
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_up) hipHostFree(e->h_up);
     if (e->h_down) hipHostFree(e->h_down);
+    if (e->shard.d_send) hipFree(e->shard.d_send);
+    if (e->shard.d_recv) hipFree(e->shard.d_recv);
     delete e;
 }
 
@@ -1576,6 +1702,18 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     g_tr.n++;
     *updated = 1;
     return LVK_OK;
+}
+
+lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn, void* user)
+{
+    if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_set_shard: bad argument");
+    e->shard.rank = rank; e->shard.world = world; e->shard.fn = fn; e->shard.user = user;
+    return LVK_OK;
+}
+void lvk_ekf_shard_stats(const lvk_ekf* e, long* out8)
+{
+    if (!e || !out8) return;
+    memcpy(out8, e->shard.stats, sizeof e->shard.stats); memcpy(out8 + 4, e->qr_stats, sizeof e->qr_stats);
 }
 
 lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* out3)

@@ -91,23 +91,14 @@ __global__ void __launch_bounds__(QR_THREADS) k_qr_block(double* __restrict__ H,
 #define QS_THREADS 1024
 #define QS_WAVES (QS_THREADS / 64)
 
-__device__ __forceinline__ void qs_prep_column(double* __restrict__ colk, int R, int k, int lane, double* __restrict__ diag, double* __restrict__ scal)
-{   // one wavefront: reflector of column k below row k.  v overwrites the column (v_k = a_kk - alpha), R's diagonal goes to diag[k]
-    double part = 0.;
-    for (int i = k + lane; i < R; i += 64) { const double a = colk[i]; part += a * a; }
-    const double s = wave_sum_f64(part);
-    if (lane == 0) {
-        const double akk = colk[k];
-        const double nrm = sqrt(s);
-        const double alpha = akk >= 0. ? -nrm : nrm;
-        const double vn2 = 2. * (s - alpha * akk);                 // |x - alpha e_k|^2
-        const double beta = (nrm == 0. || vn2 == 0.) ? 0. : 2. / vn2;
-        diag[k] = beta != 0. ? alpha : akk;
-        if (beta != 0.) colk[k] = akk - alpha;
-        scal[k & 1] = beta;
-    }
-}
-
+// Mapping inside a node: wavefront w owns the rows i = w (mod 16), lane l the columns k+1+l, k+1+l+64, ...  A Householder step is
+//   phase 1: partial dot products v . A[:, c] over the wavefront's rows (no cross-lane traffic: lanes hold different columns, the
+//            reflector entry v_i is an LDS broadcast, A[c][i] is conflict-free because the column stride is odd)      -> barrier
+//   phase 2: every thread sums the 16 partials of its columns, updates its rows of them; lane 0 (column k+1) also accumulates the
+//            squared norm of the next reflector over its rows                                                           -> barrier
+// and every thread then derives alpha / beta of step k+1 from the 16 norm partials.  The reflector is never stored: v_i is column k
+// itself with alpha subtracted on the fly at i = k.  (The first version - one wavefront per column, wave-wide shuffles for every dot
+// product - spent 130 us per 430 x 44 node, most of it in ds_bpermute latency; this one has no shuffles in the loop.)
 __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
                                                          double* __restrict__ Hout, int ldout, double* __restrict__ rout,
                                                          const QrBlock* __restrict__ blocks, const int* __restrict__ col_lists, int N)
@@ -123,11 +114,13 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restri
         }
         return;
     }
-    const int nc = b.ncols, R = b.in_rows, Rp = R | 1;               // odd column stride: the row-wise fill does not pile onto one bank
+    const int nc = b.ncols, R = b.in_rows, Rp = R | 1;               // odd column stride
+    const int pw = nc + 1;
     double* A = sm;                                                    // (nc + 1) columns of Rp doubles; column nc is the residual
-    double* diag = A + (size_t)(nc + 1) * Rp;                          // nc
-    double* scal = diag + nc;                                          // 2 (beta of the current / the next step)
-    int* inv = (int*)(scal + 2);                                       // N: dense column -> position in the union (or -1)
+    double* diag = A + (size_t)pw * Rp;                                // nc : R's diagonal
+    double* part = diag + nc;                                          // QS_WAVES x (nc + 1) partial dot products
+    double* nrm2 = part + (size_t)QS_WAVES * pw;                       // QS_WAVES partial squared norms of the next reflector
+    int* inv = (int*)(nrm2 + QS_WAVES);                                // N: dense column -> position in the union (or -1)
     const int* cols = col_lists + b.col_off;
     for (int j = t; j < N; j += QS_THREADS) inv[j] = -1;
     for (int i = wave; i < R; i += QS_WAVES) {
@@ -137,25 +130,57 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restri
     __syncthreads();
     for (int c = t; c < nc; c += QS_THREADS) inv[cols[c]] = c;
     const int steps = nc < R - 1 ? nc : R - 1;
-    if (wave == 0 && steps > 0) qs_prep_column(A, R, 0, lane, diag, scal);
+    {   // squared norm of column 0, by row class
+        double sq = 0.;
+        for (int i = wave + QS_WAVES * lane; i < R; i += QS_WAVES * 64) { const double a = A[i]; sq += a * a; }
+        sq = wave_sum_f64(sq);
+        if (lane == 0) nrm2[wave] = sq;
+    }
     __syncthreads();
+    double alpha = 0., beta = 0.;
+    auto reflector = [&](int k) {
+        double s = 0.;
+#pragma unroll
+        for (int w = 0; w < QS_WAVES; ++w) s += nrm2[w];
+        const double akk = A[(size_t)k * Rp + k];
+        const double nrm = sqrt(s);
+        alpha = akk >= 0. ? -nrm : nrm;
+        const double vn2 = 2. * (s - alpha * akk);                     // |x - alpha e_k|^2
+        beta = (nrm == 0. || vn2 == 0.) ? 0. : 2. / vn2;
+    };
+    if (steps > 0) reflector(0);
     for (int k = 0; k < steps; ++k) {
-        const double beta = scal[k & 1];
-        const double* v = A + (size_t)k * Rp;
-        for (int j = k + 1 + wave; j <= nc; j += QS_WAVES) {
-            double* col = A + (size_t)j * Rp;
-            if (beta != 0.) {
-                double s = 0.;
-                for (int i = k + lane; i < R; i += 64) s += v[i] * col[i];
-                s = wave_sum_f64(s) * beta;
-                if (s != 0.) for (int i = k + lane; i < R; i += 64) col[i] -= s * v[i];
-            }
-            if (j == k + 1 && k + 1 < steps) {                        // always wave 0: the next reflector, in the shadow of the other columns' updates
-                __builtin_amdgcn_wave_barrier();
-                qs_prep_column(col, R, k + 1, lane, diag, scal);
+        const double* vk = A + (size_t)k * Rp;
+        const int i0 = k + ((wave - k) & (QS_WAVES - 1));             // first row >= k of this wavefront's class
+        // phase 1
+        if (beta != 0.) {
+            for (int c = k + 1 + lane; c <= nc; c += 64) {
+                const double* col = A + (size_t)c * Rp;
+                double p = 0.;
+                for (int i = i0; i < R; i += QS_WAVES) { double vi = vk[i]; if (i == k) vi -= alpha; p += vi * col[i]; }
+                part[(size_t)wave * pw + c] = p;
             }
         }
         __syncthreads();
+        // phase 2
+        for (int c = k + 1 + lane; c <= nc; c += 64) {
+            double* col = A + (size_t)c * Rp;
+            if (beta != 0.) {
+                double s = 0.;
+#pragma unroll
+                for (int w = 0; w < QS_WAVES; ++w) s += part[(size_t)w * pw + c];
+                s *= beta;
+                if (s != 0.) for (int i = i0; i < R; i += QS_WAVES) { double vi = vk[i]; if (i == k) vi -= alpha; col[i] -= s * vi; }
+            }
+            if (c == k + 1) {                                          // lane 0 of every wavefront: the next reflector's norm over its rows
+                double sq = 0.;
+                for (int i = (i0 == k ? k + QS_WAVES : i0); i < R; i += QS_WAVES) { const double a = col[i]; sq += a * a; }
+                nrm2[wave] = sq;
+            }
+        }
+        if (t == 0) diag[k] = beta != 0. ? alpha : vk[k];
+        __syncthreads();
+        if (k + 1 < steps) reflector(k + 1);
     }
     // R (upper trapezoid in the union's column order) expanded to the dense layout: one wavefront per output row, coalesced
     for (int i = wave; i < b.out_rows; i += QS_WAVES) {
@@ -174,7 +199,7 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restri
 size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N)
 {
     const size_t Rp = (size_t)(rows | 1);
-    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2) + sizeof(int) * (size_t)N + 16;
+    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + (size_t)QS_WAVES * (ncols + 1) + QS_WAVES) + sizeof(int) * (size_t)N + 16;
 }
 lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
                                const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds)
@@ -197,7 +222,7 @@ static void merge_cols(const std::vector<int>& a, const std::vector<int>& b, std
 // already shrinks (rows > columns) does not take in a group that brings more new columns than rows (the two rows of an in-state
 // feature with its own anchor block).  A node with rows <= columns is passed through.  A level is kept only if it removes at
 // least a fifth of the rows.  Everything here is known on the host before any kernel runs: no counts come back from the device.
-void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLevel>& levels, int* final_rows)
+void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups)
 {
     const size_t LDS_CAP = (size_t)152 * 1024;
     levels.clear();
@@ -235,6 +260,7 @@ void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLeve
         cur.swap(next); total = out_row;
     }
     *final_rows = total;
+    if (final_groups) final_groups->swap(cur);
 }
 
 // move the first `keep` rows of every block to the front (block b -> rows [b*keep, ...))

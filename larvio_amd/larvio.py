@@ -59,6 +59,8 @@ def _L():
         L.lvk_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvk_ekf_get_features.restype = i
         L.lvk_ekf_counters.argtypes = [vp, vp]; L.lvk_ekf_counters.restype = None
         L.lvk_ekf_profile.argtypes = [vp, i, vp]; L.lvk_ekf_profile.restype = i
+        L.lvk_ekf_set_shard.argtypes = [vp, i, i, vp, vp]; L.lvk_ekf_set_shard.restype = i
+        L.lvk_ekf_shard_stats.argtypes = [vp, vp]; L.lvk_ekf_shard_stats.restype = None
         L.lvk_triangulate.argtypes = [vp, vp, vp, i, i, vp, pi, vp, vp, vp, vp]; L.lvk_triangulate.restype = i
         L.lvk_ekf_gate_and_stack.argtypes = [vp, vp, i, vp, i, vp, vp, vp, vp, i, i, i, d, vp, vp, i, pi, vp, vp]; L.lvk_ekf_gate_and_stack.restype = i
         _sig_done = True
@@ -233,6 +235,17 @@ class LarVio:
         ids = np.zeros(4096, np.int64); pos = np.zeros((4096, 3))
         n = _L().lvk_ekf_take_lost_features(self._h, _p(ids), _p(pos), 4096)
         return ids[:n].copy(), pos[:n].copy()
+
+    def set_shard(self, rank, world, fn, user, keepalive=None):
+        """lvk_ekf_set_shard: this filter does the per-feature device work of rank `rank` of `world`; fn/user = the all-gather
+        (larvio_amd.sharding.RcclShard(...).args() or HostExchange(...).args())."""
+        self._shard_keep = keepalive
+        self.ctx.check(_L().lvk_ekf_set_shard(self._h, int(rank), int(world), fn, user))
+
+    def shard_stats(self):
+        o = np.zeros(8, np.int64); _L().lvk_ekf_shard_stats(self._h, _p(o))
+        return dict(exchanges=int(o[0]), bytes_sent=int(o[1]), sharded_updates=int(o[2]), rows_stacked=int(o[3]),
+                    qr_updates=int(o[4]), qr_levels=int(o[5]), qr_rows_in=int(o[6]), qr_rows_out=int(o[7]))
 
     def profile(self, enable=True):
         """HIP-event time of the H P GEMM since the last call: dict(ms, flops, launches); enables/disables the bracket"""

@@ -9,10 +9,101 @@ once; latency-bound), and every rank QR-reduces the rank-ordered stack [R_0; ...
 identical update on its replica of P.  Rank order fixes the reduction order, so replicas stay bit-identical.
 At the north-star size (150 tracks) this does not pay: bench.py runs replicas instead.
 
-This module is pure host logic over torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU in tests);
-the per-rank numerical work is liblvk_hip.so's lvk_ekf_compress_qr / lvk_ekf_update.
+The PRODUCT path is inside liblvk_hip.so (lvk_ekf_set_shard, backend.hip shard_stage1, be_shard.hip): per-rank feature rows ->
+structure-aware TSQR -> pack kernel -> ncclAllGather on the filter's stream, device buffers in place -> unpack kernel -> replicated
+second stage and update.  What crosses the wire is the rank's compressed block as rows (k_g x (N + 1) doubles, k_g ~ 50..200 at
+configs[4]) plus the gate results of its features - smaller than the n x n triangle above, which the early-design helpers at the
+bottom of this module still describe (kept for the CPU gloo test).  This module makes the transports:
+
+  make_shard(rank, world, dist, device)   RCCL: the 128-byte ncclUniqueId is broadcast over torch.distributed, every rank creates
+                                          its communicator in the library (lvk_shard_comm_create) -> arguments for LarVio.set_shard
+  HostExchange(ctx, dist)                 a transport for tests: device -> host, torch.distributed.all_gather (gloo), host -> device
 """
+import ctypes as C
+
 import numpy as np
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class RcclShard:
+    """One rank's RCCL communicator inside liblvk_hip.so; pass .args() to LarVio.set_shard."""
+
+    def __init__(self, ctx, rank, world, uid):
+        from ._lib import lib
+        L = lib()
+        L.lvk_shard_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]; L.lvk_shard_comm_create.restype = C.c_int
+        L.lvk_shard_comm_destroy.argtypes = [C.c_void_p]; L.lvk_shard_comm_destroy.restype = None
+        h = C.c_void_p()
+        ctx.check(L.lvk_shard_comm_create(ctx.h, bytes(uid), rank, world, C.byref(h)))
+        self._h, self.rank, self.world, self._L = h, rank, world, L
+
+    def args(self):
+        fn = C.cast(self._L.lvk_shard_allgather_rccl, C.c_void_p)
+        return self.rank, self.world, fn, self._h, self
+
+    def close(self):
+        if self._h:
+            self._L.lvk_shard_comm_destroy(self._h); self._h = None
+
+
+def unique_id():
+    from ._lib import lib, LvkError
+    L = lib()
+    L.lvk_shard_unique_id.argtypes = [C.c_char_p]; L.lvk_shard_unique_id.restype = C.c_int
+    buf = C.create_string_buffer(128)
+    st = L.lvk_shard_unique_id(buf)
+    if st != 0:
+        raise LvkError("lvk_shard_unique_id failed with status %d (librccl not available?)" % st)
+    return buf.raw
+
+
+def make_shard(ctx, rank, world, dist):
+    """RCCL transport for the filter on `ctx`: rank 0 draws the unique id, torch.distributed carries it to the others."""
+    import torch
+    if rank == 0:
+        uid = torch.tensor(list(unique_id()), dtype=torch.uint8)
+    else:
+        uid = torch.zeros(128, dtype=torch.uint8)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    uid = uid.to(dev)
+    dist.broadcast(uid, src=0)
+    return RcclShard(ctx, rank, world, bytes(uid.cpu().tolist()))
+
+
+class HostExchange:
+    """All-gather through host memory and torch.distributed (any backend) - the transport of the two-process single-GPU test
+    (RCCL refuses two ranks on one device).  Same contract as lvk_shard_allgather_rccl, just slower."""
+
+    def __init__(self, ctx, dist, rank, world):
+        self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
+        self.calls = 0; self.bytes = 0
+        self._cb = EXCHANGE_FN(self._call)
+
+    def _call(self, user, d_send, d_recv, nbytes, stream):
+        import torch
+        from ._lib import lib
+        try:
+            L = lib()
+            self.ctx.sync()                                                   # everything queued before the exchange has run
+            mine = np.empty(nbytes, np.uint8)
+            self.ctx.check(L.lvk_memcpy_d2h(self.ctx.h, mine.ctypes.data_as(C.c_void_p), C.c_void_p(d_send), nbytes))
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            self.dist.all_gather(parts, torch.from_numpy(mine))
+            allb = np.concatenate([p.numpy() for p in parts])
+            self.ctx.check(L.lvk_memcpy_h2d(self.ctx.h, C.c_void_p(d_recv), allb.ctypes.data_as(C.c_void_p), allb.nbytes))
+            self.ctx.sync()
+            self.calls += 1; self.bytes += nbytes
+            return 0
+        except Exception as exc:                                             # never let an exception cross the C frame
+            print("HostExchange failed:", exc)
+            return 2
+
+    def args(self):
+        return self.rank, self.world, C.cast(self._cb, C.c_void_p), None, self
+
+
+# ------------------------------------------------------------------ early-design helpers (packed-triangle wire format; CPU gloo test)
 
 
 def shard_ranges(row_counts, world_size):

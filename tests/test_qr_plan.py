@@ -30,7 +30,7 @@ def _msckf_like(seed, n_feat, n_clones, leg=22, track=6, n_state_feat=0, burst=F
 
 
 def _lds_bytes(rows, ncols, N):
-    return 8 * ((ncols + 1) * (rows | 1) + ncols + 2) + 4 * N + 16
+    return 8 * ((ncols + 1) * (rows | 1) + ncols + 16 * (ncols + 1) + 16) + 4 * N + 16
 
 
 def emulate(levels, H, r):
