@@ -860,12 +860,14 @@ static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std
     if (st != LVK_OK) return st;
     double* X = e->d_H; double* rX = e->d_r;
     for (QrPlanLevel& L : my_levels) {
-        QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
-        if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+        QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1); QrChunk* hk = up_alloc<QrChunk>(e, L.chunks.size() + 1);
+        if (!hb || !hc || !hk) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
         memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
+        memcpy(hk, L.chunks.data(), sizeof(QrChunk) * L.chunks.size());
         st = flush_uploads(e);
         double* Ho = (X == e->d_H) ? e->d_Hb : e->d_H; double* ro = (rX == e->d_r) ? e->d_rb : e->d_r;
-        if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, X, e->ld, rX, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), ncols, L.lds);
+        if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, X, e->ld, rX, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hk), (int)L.chunks.size(), dev(e, hc), ncols,
+                                                   L.max_nc, L.part_tiles * 256);
         if (st != LVK_OK) return st;
         X = Ho; rX = ro;
     }
@@ -914,12 +916,14 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
         lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
         if (!levels.empty() && m2 + 32 <= m) {
             for (QrPlanLevel& L : levels) {
-                QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
-                if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+                QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1); QrChunk* hk = up_alloc<QrChunk>(e, L.chunks.size() + 1);
+                if (!hb || !hc || !hk) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
                 memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
+                memcpy(hk, L.chunks.data(), sizeof(QrChunk) * L.chunks.size());
                 st = flush_uploads(e);
                 double* Ho = (H == e->d_H) ? e->d_Hb : e->d_H; double* ro = (r == e->d_r) ? e->d_rb : e->d_r;
-                if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, H, e->ld, r, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), e->N, L.lds);
+                if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, H, e->ld, r, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hk), (int)L.chunks.size(), dev(e, hc), e->N,
+                                                           L.max_nc, L.part_tiles * 256);
                 if (st != LVK_OK) return st;
                 H = Ho; r = ro;
                 e->qr_stats[1]++;

@@ -334,6 +334,19 @@ def test_cpp_dataset_driver_on_an_asl_directory(gpu_ctx, tmp_path):
     print(r2.stdout)
     assert open(tum2).read() == open(tum).read() and open(out_dir + "msckf_2_state.txt").read() == seq_log
     assert r2.stdout.splitlines()[0] == r.stdout.splitlines()[0]
+    # the ADAPTER (adapter/: larvio::ImageProcessor / larvio::LarVio with the reference's exact signatures, cv::Mat / Eigen / boost
+    # from stub headers) driven by the loop of app/larvioMain.cpp:84-117: the same positions, and every getter the reference's
+    # drivers call answers (getPpose / getPvel / getSwPoses / both map-point getters / getVisualImg)
+    subprocess.check_call(["make", "-C", os.path.join(root, "adapter"), "-s"])
+    tum3 = str(tmp_path / "traj_adapter.txt")
+    r3 = subprocess.run([os.path.join(root, "adapter", "adapter_main")] + r.args[1:5] + ["--tum", tum3], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    print(r3.stdout)
+    ad = np.loadtxt(tum3, ndmin=2)
+    assert ad.shape[0] == cpp.shape[0] and np.array_equal(ad[:, 1:4], cpp[:, 1:4])
+    assert (ad[:, 7] > 0).all() and (ad[:, 8] > 0).all()                        # P_pose(0,0) = position variance, P_vel(0,0)
+    assert ad[-1, 9] >= 5 and (ad[:, 10] == 512 * 512 * 3).all()                # sliding-window poses; RGB visual image of the right size
+    assert f"odometry updates {cpp.shape[0]}" in r3.stdout
     # the same loop through the Python mirror, on the stamps as the readers deliver them (1e-9 * integer ns)
     fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
     be = larvio_amd.LarVio(dict(bcfg, max_features=300), gpu_ctx); assert be.initialize()

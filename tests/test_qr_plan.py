@@ -1,7 +1,7 @@
-"""The structure-aware compression of the stacked measurement rows (larvio_amd/csrc/be_qr.hip): the TSQR tree is planned on the host
-(lvk_ekf_qr_plan - no device needed), so the plan itself is checked here on CPU: an emulation of every node in numpy (QR of the rows
-restricted to the node's columns) must preserve H^T H and H^T r exactly as the kernel has to, and the plan must respect the
-workgroup's LDS budget.  tests/test_gpu_backend.py runs the same shapes through the kernel."""
+"""The structure-aware compression of the stacked measurement rows (larvio_amd/csrc/be_qr.hip): the tree of nodes is planned on the
+host (lvk_ekf_qr_plan - no device needed), so the plan itself is checked here on CPU: an emulation of every node in numpy (any
+factor R of the node's rows restricted to its columns with R^T R = A^T A) must preserve H^T H and H^T r exactly as the kernels have
+to, and every node's column union must fit the Gram a workgroup holds in LDS.  tests/test_gpu_backend.py runs the same shapes through the kernel."""
 import numpy as np
 import pytest
 
@@ -27,10 +27,6 @@ def _msckf_like(seed, n_feat, n_clones, leg=22, track=6, n_state_feat=0, burst=F
         groups.append((2, cols)); rows_H.append(B)
     H = np.vstack(rows_H); r = rng.normal(0, 1, len(H))
     return N, groups, H, r
-
-
-def _lds_bytes(rows, ncols, N):
-    return 8 * ((ncols + 1) * (rows | 1) + ncols + 16 * (ncols + 1) + 16) + 4 * N + 16
 
 
 def emulate(levels, H, r):
@@ -64,7 +60,7 @@ def test_plan_preserves_the_information_and_fits_the_lds(case):
         N, groups, H, r = _msckf_like(2, 1900, 60, n_state_feat=60, burst=True)
     elif case == "steady_5":
         N, groups, H, r = _msckf_like(3, 330, 60, n_state_feat=60)
-    else:                           # 20-observation tracks: 127-column unions, nodes barely shrink
+    else:                           # 20-observation tracks: unions of up to 127 columns
         N, groups, H, r = _msckf_like(4, 200, 40, track=20)
     levels, final_rows = lv.qr_plan(N, groups)
     rows = len(H)
@@ -75,7 +71,7 @@ def test_plan_preserves_the_information_and_fits_the_lds(case):
             assert b["in_start"] == start and b["out_start"] == out         # consecutive, nothing skipped
             start += b["in_rows"]; out += b["out_rows"]
             if not b["copy"]:
-                assert b["in_rows"] > b["ncols"] and _lds_bytes(b["in_rows"], b["ncols"], N) <= 152 * 1024
+                assert b["in_rows"] > b["ncols"] and b["ncols"] <= 127        # a node's Gram (ncols + 1)^2 lives in one workgroup's LDS
                 c = L["cols"][b["col_off"]:b["col_off"] + b["ncols"]]
                 assert np.all(np.diff(c) > 0) and c[-1] < N
         assert start == rows and out * 5 <= rows * 4                        # a level removes at least a fifth of the rows
@@ -88,7 +84,7 @@ def test_plan_preserves_the_information_and_fits_the_lds(case):
     if case == "steady_A":
         assert levels and final_rows <= 60 + 60                             # MSCKF part <= its column union (7 + 6 * 8), in-state rows pass through
     if case == "burst_5":
-        assert final_rows <= 43 + 120 and len(levels) <= 5
+        assert final_rows <= 43 + 120 and len(levels) == 1                   # no row limit per node: one level
     if case == "steady_5":
         assert final_rows <= 61 + 120
     print(case, "rows", len(H), "->", final_rows, "levels", [(len(L["blocks"]), sum(b["out_rows"] for b in L["blocks"])) for L in levels])
