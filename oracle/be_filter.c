@@ -60,7 +60,9 @@ struct lvo_ekf {
     int static_counter, static_num; double lower_time_bound;
     int64_t* init_ids; double* init_uv; int n_init;
     long counters[7];
+    FILE* trace;                           /* LVO_TRACE=<file>: decision trace for the pins in tests/test_oracle_decisions.py */
 };
+#define TR(e, ...) do { if ((e)->trace) fprintf((e)->trace, __VA_ARGS__); } while (0)
 
 /* ------------------------------------------------------------------------ small utilities */
 static feat_t* map_find(lvo_ekf* e, int64_t id)
@@ -201,6 +203,7 @@ lvo_ekf* lvo_ekf_create(const lvo_ekf_config* cfg)
     if (c->aug_grid_rows * c->aug_grid_cols != 0) { e->grid_w = (x_max - e->x_min) / c->aug_grid_cols; e->grid_h = (y_max - e->y_min) / c->aug_grid_rows; }
     else { e->grid_w = x_max - e->x_min; e->grid_h = y_max - e->y_min; }
     e->grid_count = (int*)calloc((size_t)(c->aug_grid_rows * c->aug_grid_cols + 1), sizeof(int));
+    { const char* tp = getenv("LVO_TRACE"); e->trace = (tp && tp[0]) ? fopen(tp, "w") : NULL; }
     e->static_num = (int)((float)c->static_duration * (double)c->pub_frequency);
     return e;
 }
@@ -209,6 +212,7 @@ void lvo_ekf_destroy(lvo_ekf* e)
 {
     if (!e) return;
     for (int i = 0; i < e->n_map; ++i) free(e->map[i]);
+    if (e->trace) fclose(e->trace);
     free(e->map); free(e->clones); free(e->feature_states); free(e->P); free(e->grid_count); free(e->coarse_dis);
     free(e->init_ids); free(e->init_uv);
     free(e);
@@ -758,7 +762,10 @@ static void update_grid_map(lvo_ekf* e)
         if (oi >= 0) { xy[0] = f->z[oi][0]; xy[1] = f->z[oi][1]; }
         int code = grid_code(e, xy);
         if (code >= 0 && code < cells) e->grid_count[code]++;
+        TR(e, "GRIDF %lld %.17g %.17g\n", (long long)f->id, xy[0], xy[1]);
     }
+    if (e->trace) { TR(e, "GRID %d %d %.17g %.17g %.17g %.17g", e->cfg.aug_grid_rows, e->cfg.aug_grid_cols, e->x_min, e->y_min, e->grid_w, e->grid_h);
+                    for (int i = 0; i < cells; ++i) TR(e, " %d", e->grid_count[i]); TR(e, "\n"); }
 }
 
 static void remove_lost_features(lvo_ekf* e)
@@ -779,41 +786,53 @@ static void remove_lost_features(lvo_ekf* e)
     int64_t* ekf_new = (int64_t*)malloc(sizeof(int64_t) * (size_t)(e->n_map + 1)); int n_new = 0;
     int rows_msckf = 0, rows_new = 0;
     const int cells = c->aug_grid_rows * c->aug_grid_cols;
+    /* trace record per feature not in state (tests/test_oracle_decisions.py): TRI id tracked n_obs init_before ekf_feature x y motion
+     * tri_ok -> category (0 untouched, 1 invalid, 2 msckf, 3 ekf_new, 4 failed initialisation) ; motion / tri_ok = -1 when the
+     * reference's control flow does not evaluate them */
+    TR(e, "TRIAGE %d %d %d %d %d %.17g\n", c->least_observation_number, c->max_track_len, c->max_features_in_one_grid, cells, e->n_fs, e->s.t - e->last_zupt_time);
     for (int i = 0; i < e->n_map; ++i) {
         feat_t* f = e->map[i];
         if (f->in_state) continue;
         int tracked = feat_obs_find(f, e->imu_id) >= 0;
+        const int init0 = f->is_initialized, ekf0 = f->ekf_feature; int mot = -1, tri = -1, cat = 0; double tx = 0, ty = 0;
         if (!tracked) {
-            if (f->n_obs < c->least_observation_number) { invalid[n_invalid++] = f->id; continue; }
+            if (f->n_obs < c->least_observation_number) { invalid[n_invalid++] = f->id; cat = 1; goto rec; }
             if (!f->is_initialized) {
-                if (!feat_check_motion(e, f, tracked)) { invalid[n_invalid++] = f->id; continue; }
-                if (!feat_initialize(e, f, 0)) { invalid[n_invalid++] = f->id; continue; }
+                mot = feat_check_motion(e, f, tracked);
+                if (!mot) { invalid[n_invalid++] = f->id; cat = 1; goto rec; }
+                tri = feat_initialize(e, f, 0);
+                if (!tri) { invalid[n_invalid++] = f->id; cat = 1; goto rec; }
             }
             rows_msckf += 2 * f->n_obs - 3;
-            msckf[n_msckf++] = f->id;
+            msckf[n_msckf++] = f->id; cat = 2;
         } else {
-            if (!(f->n_obs >= c->max_track_len)) continue;
+            if (!(f->n_obs >= c->max_track_len)) goto rec;
             int oi = feat_obs_find(f, e->imu_id);
             int code = grid_code(e, f->z[oi]);
+            tx = f->z[oi][0]; ty = f->z[oi][1];
             int gcount = (code >= 0 && code < cells) ? e->grid_count[code] : 0;
             if (gcount < c->max_features_in_one_grid && e->s.t - e->last_zupt_time > 5 &&
                 (e->n_fs + n_new) < c->max_features_in_one_grid * cells) {
                 if (!f->ekf_feature) {
                     f->is_initialized = 0;
-                    if (feat_check_motion(e, f, tracked)) feat_initialize(e, f, 2);
+                    mot = feat_check_motion(e, f, tracked);
+                    if (mot) tri = feat_initialize(e, f, 2);
                 }
-                if (!f->is_initialized) continue;
+                if (!f->is_initialized) { cat = 4; goto rec; }
                 rows_new += 2 * (f->n_obs - 1);
-                ekf_new[n_new++] = f->id;
+                ekf_new[n_new++] = f->id; cat = 3;
                 if (code >= 0 && code < cells) e->grid_count[code]++;
             } else {
-                if (!f->is_initialized) { if (feat_check_motion(e, f, tracked)) feat_initialize(e, f, 0); }
-                if (!f->is_initialized) continue;
+                if (!f->is_initialized) { mot = feat_check_motion(e, f, tracked); if (mot) tri = feat_initialize(e, f, 0); }
+                if (!f->is_initialized) { cat = 4; goto rec; }
                 rows_msckf += 2 * f->n_obs - 3;
-                msckf[n_msckf++] = f->id;
+                msckf[n_msckf++] = f->id; cat = 2;
             }
         }
+    rec:
+        TR(e, "TRI %lld %d %d %d %d %.17g %.17g %d %d %d %d\n", (long long)f->id, tracked, f->n_obs, init0, ekf0, tx, ty, mot, tri, cat, f->is_initialized);
     }
+    TR(e, "TRIEND\n");
     for (int i = 0; i < n_invalid; ++i) map_erase(e, invalid[i]);
     if (n_msckf == 0 && n_new == 0 && n_ekf == 0) goto done;
     if (!e->if_zupt) {
@@ -969,6 +988,12 @@ static void find_redundant(lvo_ekf* e, int64_t* rm)
         }
     }
     if (rm[0] > rm[1]) { int64_t t = rm[0]; rm[0] = rm[1]; rm[1] = t; }
+    if (e->trace) {
+        TR(e, "REDUNDANT %d %.17g %.17g %.17g %.17g", e->n_clones, e->tracking_rate, e->cfg.rotation_threshold, e->cfg.translation_threshold, e->cfg.tracking_rate_threshold);
+        for (int i = 0; i < e->n_clones; ++i) { const lvo_clone* c = &e->clones[i];
+            TR(e, " %lld %.17g %.17g %.17g %.17g %.17g %.17g %.17g", (long long)c->id, c->q_cam[0], c->q_cam[1], c->q_cam[2], c->q_cam[3], c->p_cam[0], c->p_cam[1], c->p_cam[2]); }
+        TR(e, " -> %lld %lld\n", (long long)rm[0], (long long)rm[1]);
+    }
 }
 
 static int64_t get_new_anchor_id(lvo_ekf* e, feat_t* f, const int64_t* rm, int nrm)
@@ -987,6 +1012,15 @@ static int64_t get_new_anchor_id(lvo_ekf* e, feat_t* f, const int64_t* rm, int n
         double a = pn[0] / pn[2] - f->z[oi][0], b = pn[1] / pn[2] - f->z[oi][1];
         double dis = sqrt(a * a + b * b);
         if (min_dis > dis) { min_dis = dis; id_min = c->id; valid = 1; }
+    }
+    if (e->trace) {
+        TR(e, "ANCHOR %lld %.17g %.17g %.17g %d", (long long)f->id, f->position[0], f->position[1], f->position[2], nrm);
+        for (int k = 0; k < nrm; ++k) TR(e, " %lld", (long long)rm[k]);
+        TR(e, " %d", size);
+        for (int i = 0; i < size; ++i) { const lvo_clone* c = &e->clones[i]; int oi = feat_obs_find(f, c->id);
+            TR(e, " %lld %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %.17g %.17g", (long long)c->id, c->q_cam[0], c->q_cam[1], c->q_cam[2], c->q_cam[3], c->p_cam[0], c->p_cam[1], c->p_cam[2],
+               oi >= 0, oi >= 0 ? f->z[oi][0] : 0.0, oi >= 0 ? f->z[oi][1] : 0.0); }
+        TR(e, " -> %lld\n", (long long)(valid ? id_min : e->clones[size - 1].id));
     }
     return valid ? id_min : e->clones[size - 1].id;
 }
