@@ -122,6 +122,7 @@ struct lvk_ekf {
     double *d_H = nullptr, *d_r = nullptr, *d_H1 = nullptr, *d_H2 = nullptr, *d_r1 = nullptr;
     double *d_Hb = nullptr, *d_rb = nullptr;            // ping-pong partner of d_H / d_r for the levels of the structure-aware compression
     int sparse_qr = 1;                                  // LVK_SPARSE_QR=0 disables the structure-aware compression (A/B runs)
+    int sparse_qr_min_rows = 480;
     long qr_stats[4] = {0, 0, 0, 0};                    // [0] updates compressed [1] levels run [2] rows in [3] rows out
     // sharded measurement update: this rank builds the feature rows of its contiguous slice, one all-gather of the
     // compressed blocks (+ every feature's gate result), replicated update.  world 1 = off.
@@ -860,14 +861,12 @@ static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std
     if (st != LVK_OK) return st;
     double* X = e->d_H; double* rX = e->d_r;
     for (QrPlanLevel& L : my_levels) {
-        QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1); QrChunk* hk = up_alloc<QrChunk>(e, L.chunks.size() + 1);
-        if (!hb || !hc || !hk) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+        QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
+        if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
         memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
-        memcpy(hk, L.chunks.data(), sizeof(QrChunk) * L.chunks.size());
         st = flush_uploads(e);
         double* Ho = (X == e->d_H) ? e->d_Hb : e->d_H; double* ro = (rX == e->d_r) ? e->d_rb : e->d_r;
-        if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, X, e->ld, rX, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hk), (int)L.chunks.size(), dev(e, hc), ncols,
-                                                   L.max_nc, L.part_tiles * 256);
+        if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, X, e->ld, rX, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), ncols, L.lds);
         if (st != LVK_OK) return st;
         X = Ho; rX = ro;
     }
@@ -911,19 +910,20 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
 {
     lvk_status st = LVK_OK;
     double* H = e->d_H; double* r = e->d_r;
-    if (groups && e->sparse_qr && m >= 96) {
+    // The nodes cost ~1 us per column of their union (one barrier-separated Householder step each, ~50..60 steps): measured on MI355X
+    // the compression pays once it saves more than a few 32-row Cholesky panels - not at the north-star size (m ~ 110..260 rows),
+    // decisively at configs[4] (thousands of rows).  LVK_SPARSE_QR_MIN_ROWS overrides the threshold.
+    if (groups && e->sparse_qr && m >= e->sparse_qr_min_rows) {
         std::vector<QrPlanLevel> levels; int m2 = m;
         lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
         if (!levels.empty() && m2 + 32 <= m) {
             for (QrPlanLevel& L : levels) {
-                QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1); QrChunk* hk = up_alloc<QrChunk>(e, L.chunks.size() + 1);
-                if (!hb || !hc || !hk) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+                QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
+                if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
                 memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
-                memcpy(hk, L.chunks.data(), sizeof(QrChunk) * L.chunks.size());
                 st = flush_uploads(e);
                 double* Ho = (H == e->d_H) ? e->d_Hb : e->d_H; double* ro = (r == e->d_r) ? e->d_rb : e->d_r;
-                if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, H, e->ld, r, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hk), (int)L.chunks.size(), dev(e, hc), e->N,
-                                                           L.max_nc, L.part_tiles * 256);
+                if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, H, e->ld, r, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), e->N, L.lds);
                 if (st != LVK_OK) return st;
                 H = Ho; r = ro;
                 e->qr_stats[1]++;
@@ -1541,6 +1541,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     lvk_ekf* e = new (std::nothrow) lvk_ekf();
     if (!e) return LVK_ERR_DEVICE;
     { const char* sq = getenv("LVK_SPARSE_QR"); if (sq) e->sparse_qr = atoi(sq) != 0; }
+    { const char* sq = getenv("LVK_SPARSE_QR_MIN_ROWS"); if (sq && atoi(sq) > 0) e->sparse_qr_min_rows = atoi(sq); }
     e->ctx = ctx; e->cfg = *cfg;
     const lvk_ekf_config& c = e->cfg;
     e->leg = c.calib_imu_instrinsic ? 46 : 22;

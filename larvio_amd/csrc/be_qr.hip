@@ -17,11 +17,28 @@ double lvk_chi2_005(int dof) { return (dof >= 1 && dof <= 99) ? k_chi2_005[dof] 
 #define QR_THREADS 1024
 #define QR_BLOCK_ROWS 1024
 
+// FP64 all-reduce over the wavefront without LDS traffic: four DPP row rotations (every lane ends up with its 16-lane row sum; a
+// 64-bit value moves as two 32-bit DPP movs), then the four row sums are read with v_readlane and added.  (__shfl_xor on a double is
+// two ds_bpermute per stage, ~12 LDS round trips per reduction: it dominated the first version of the LDS-resident QR nodes.)
+__device__ __forceinline__ double dpp_ror_f64(double v, const int ctrl_sel)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_sel) {
+        case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false); break;
+        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, false); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xF, 0xF, false); break;
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false); break;
+    }
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
+    v += dpp_ror_f64(v, 8); v += dpp_ror_f64(v, 4); v += dpp_ror_f64(v, 2); v += dpp_ror_f64(v, 1);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double s = 0.;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    for (int r = 0; r < 4; ++r) s += __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * r), __builtin_amdgcn_readlane(lo, 16 * r));
+    return s;
 }
 
 // one workgroup reduces rows [row0, row0+nrows) of H (ld) and r; result: its first min(nrows, cols) rows hold R.
@@ -81,154 +98,108 @@ __global__ void __launch_bounds__(QR_THREADS) k_qr_block(double* __restrict__ H,
 // The stacked MSCKF rows are block-sparse: a feature's rows touch the extrinsics/td columns and the 6-column blocks of the few clones
 // that observed it (7 + 6 M columns of N), and features tracked over the same stretch of the window share those columns - which is
 // what lets SPQR (larvio.cpp:1430-1445) beat a dense factorisation in the reference.  The host knows every row group's column set
-// (it built the stacking map), so it merges CONSECUTIVE row groups into nodes whose column union stays small (<= 127 columns, any
-// number of rows) and each node is reduced to `union` rows:
-//     G = [A | r]^T [A | r]   (A = the node's rows restricted to its columns)   on the FP64 matrix cores, one workgroup per 256-row
-//                             chunk, partial Grams summed in a fixed order (no atomics: results are reproducible bit for bit)
-//     G = L L^T               in LDS, one workgroup per node; R = L^T, the last row of L is Q^T r
-// The update downstream consumes the measurement only through H^T H and H^T r (information form: P+ = (P^-1 + H^T H / s^2)^-1,
-// dx = P+ H^T r / s^2), so ANY (R, rho) with R^T R = H^T H and R^T rho = H^T r is equivalent to the Householder factor - and forming
-// the Gram perturbs H^T H by O(eps |H|^2), the same order as a backward-stable QR does.  Directions whose pivot falls below the
-// rounding noise of G (exactly-zero columns such as td when it is not estimated, or information below eps |G|) are dropped as zero
-// rows.  Work: one streaming pass over the rows (2 r c^2 flops on MFMA, c ~ 50 of N ~ 220..450) + c^3 / 3 in LDS; ONE level reduces
-// 17,000 rows at configs[4].  (Two LDS-resident Householder versions of the nodes were measured first: 130-250 us per 430 x 44 node -
-// one barrier-separated level-2 step per column, bound by LDS round trips - against ~10 + 20 us here.)
+// (it built the stacking map), so it plans a TSQR tree over CONSECUTIVE row groups whose column union fits one workgroup's LDS:
+// each node gathers its rows restricted to the union columns into LDS (column-major, one wavefront per row on the way in), runs a
+// Householder QR there (one wavefront per column on the apply step, wave reductions for the dot products, ONE barrier per step: the
+// wavefront that updates column k+1 also prepares its reflector) and writes min(rows, columns) rows of R back, expanded to the dense
+// column layout.  Work drops from 2 r N^2 to ~2 r c^2 (c ~ 50 of N ~ 220..450) and every level is a single launch.
 // Blocks that would not shrink (rows <= columns, e.g. the two rows of each in-state feature with their scattered anchor columns)
-// are passed through by a copy.  Unions wider than 127 columns (tracks longer than ~20 clones) fall back to the dense TSQR above.
-#define QG_THREADS 256
-#define QG_MAX_NC 127
+// are passed through by a copy.
+#define QS_THREADS 1024
+#define QS_WAVES (QS_THREADS / 64)
 
-// leading dimension of a staged chunk: 16 per column tile + 16 so that the four k-groups of an MFMA operand read fall on two
-// disjoint bank halves (2 LDS passes per 512-byte read instead of 4); rows per chunk so that the chunk fits 128 KB
-__host__ __device__ static inline int qg_lda(int ncols) { return ((ncols + 1 + 15) / 16) * 16 + 16; }
-static inline int qg_chunk_rows(int ncols) { int r = 16384 / qg_lda(ncols); r &= ~3; return r > 256 ? 256 : r; }
-
-// one workgroup per chunk: partial Gram of rows [row_start, row_start + rows) of the level's input, restricted to the node's columns
-// (+ the residual as column nc), as upper-triangular 16x16 tiles (ti <= tj)
-__global__ void __launch_bounds__(QG_THREADS) k_gram_partial(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
-                                                            const QrBlock* __restrict__ blocks, const QrChunk* __restrict__ chunks,
-                                                            const int* __restrict__ col_lists, double* __restrict__ part)
-{
-    extern __shared__ double sA[];
-    const QrChunk ch = chunks[blockIdx.x];
-    const QrBlock b = blocks[ch.block];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i16 = lane & 15, kk = lane >> 4;
-    const int nc = b.ncols, T = (nc + 1 + 15) / 16, lda = qg_lda(nc);
-    const int rp = (ch.rows + 3) & ~3;
-    const int* cols = col_lists + b.col_off;
-    // stage the chunk (row-major, one wavefront per row, gathered columns: mostly runs of 6-7 consecutive doubles)
-    for (int i = wave; i < rp; i += QG_THREADS / 64) {
-        const bool ok = i < ch.rows;
-        const double* src = Hin + (size_t)(ch.row_start + (ok ? i : 0)) * ldin;
-        for (int c = lane; c < 16 * T; c += 64) sA[(size_t)i * lda + c] = !ok ? 0. : c < nc ? src[cols[c]] : c == nc ? rin[ch.row_start + i] : 0.;
-    }
-    __syncthreads();
-    const int npairs = T * (T + 1) / 2;
-    double* out = part + ((size_t)ch.part_first) * 256;
-    int ti = 0, tj = 0;                                                 // pair index p -> (ti <= tj), row-major over the upper triangle
-    for (int p = 0; p < npairs; ++p) {
-        if ((p & 3) == wave) {
-            typedef double d4 __attribute__((ext_vector_type(4)));
-            d4 acc = {0., 0., 0., 0.};
-            const double* pa = sA + 16 * ti + i16; const double* pb = sA + 16 * tj + i16;
-            for (int k0 = 0; k0 < rp; k0 += 4) {
-                const double av = pa[(size_t)(k0 + kk) * lda], bv = pb[(size_t)(k0 + kk) * lda];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(size_t)p * 256 + (kk + 4 * r) * 16 + i16] = acc[r];
-        }
-        if (++tj == T) { ++ti; tj = ti; }
+__device__ __forceinline__ void qs_prep_column(double* __restrict__ colk, int R, int k, int lane, double* __restrict__ diag, double* __restrict__ scal)
+{   // one wavefront: reflector of column k below row k.  v overwrites the column (v_k = a_kk - alpha), R's diagonal goes to diag[k]
+    double part = 0.;
+    for (int i = k + lane; i < R; i += 64) { const double a = colk[i]; part += a * a; }
+    const double s = wave_sum_f64(part);
+    if (lane == 0) {
+        const double akk = colk[k];
+        const double nrm = sqrt(s);
+        const double alpha = akk >= 0. ? -nrm : nrm;
+        const double vn2 = 2. * (s - alpha * akk);                 // |x - alpha e_k|^2
+        const double beta = (nrm == 0. || vn2 == 0.) ? 0. : 2. / vn2;
+        diag[k] = beta != 0. ? alpha : akk;
+        if (beta != 0.) colk[k] = akk - alpha;
+        scal[k & 1] = beta;
     }
 }
 
-// one workgroup per node: sum the chunk partials (fixed order), Cholesky of the (nc + 1) x (nc + 1) Gram in LDS, write nc rows of
-// R = L^T and Q^T r = the last row of L expanded to the dense column layout; pass-through blocks are copied
-__global__ void __launch_bounds__(QG_THREADS) k_gram_chol(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
+__global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
                                                          double* __restrict__ Hout, int ldout, double* __restrict__ rout,
-                                                         const QrBlock* __restrict__ blocks, const int* __restrict__ col_lists,
-                                                         const double* __restrict__ part, int N)
+                                                         const QrBlock* __restrict__ blocks, const int* __restrict__ col_lists, int N)
 {
-    extern __shared__ double sG[];
+    extern __shared__ double sm[];
     const QrBlock b = blocks[blockIdx.x];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (b.copy) {
-        for (int i = wave; i < b.in_rows; i += QG_THREADS / 64) {
+        for (int i = wave; i < b.in_rows; i += QS_WAVES) {
             const double* src = Hin + (size_t)(b.in_start + i) * ldin; double* dst = Hout + (size_t)(b.out_start + i) * ldout;
             for (int j = lane; j < N; j += 64) dst[j] = src[j];
             if (lane == 0) rout[b.out_start + i] = rin[b.in_start + i];
         }
         return;
     }
-    const int nc = b.ncols, n = nc + 1, T = (n + 15) / 16, ldg = 16 * T + 1, npairs = T * (T + 1) / 2;
-    double* G = sG;                                                     // (16 T) x ldg, lower triangle becomes L
-    double* dmax = G + (size_t)16 * T * ldg;                            // [0] tolerance
-    int* inv = (int*)(dmax + 2);                                        // N: dense column -> position in the union (or -1)
+    const int nc = b.ncols, R = b.in_rows, Rp = R | 1;               // odd column stride: the row-wise fill does not pile onto one bank
+    double* A = sm;                                                    // (nc + 1) columns of Rp doubles; column nc is the residual
+    double* diag = A + (size_t)(nc + 1) * Rp;                          // nc
+    double* scal = diag + nc;                                          // 2 (beta of the current / the next step)
+    int* inv = (int*)(scal + 2);                                       // N: dense column -> position in the union (or -1)
     const int* cols = col_lists + b.col_off;
-    for (int j = t; j < N; j += QG_THREADS) inv[j] = -1;
-    {
-        int ti = 0, tj = 0;
-        for (int p = 0; p < npairs; ++p) {
-            double s = 0.;
-            const double* src = part + ((size_t)b.part_first + p) * 256 + t;
-            for (int c = 0; c < b.n_chunks; ++c) s += src[(size_t)c * npairs * 256];
-            const int i = 16 * ti + (t >> 4), j = 16 * tj + (t & 15);
-            G[(size_t)j * ldg + i] = s;                                 // G[j][i], j >= i side (lower) ...
-            if (ti == tj) G[(size_t)i * ldg + j] = s;                   // ... diagonal tiles hold both halves
-            if (++tj == T) { ++ti; tj = ti; }
-        }
+    for (int j = t; j < N; j += QS_THREADS) inv[j] = -1;
+    for (int i = wave; i < R; i += QS_WAVES) {
+        const double* src = Hin + (size_t)(b.in_start + i) * ldin;
+        for (int c = lane; c <= nc; c += 64) A[(size_t)c * Rp + i] = c < nc ? src[cols[c]] : rin[b.in_start + i];
     }
     __syncthreads();
-    for (int c = t; c < nc; c += QG_THREADS) inv[cols[c]] = c;
-    if (t == 0) {
-        double m = 0.; for (int i = 0; i < nc; ++i) m = fmax(m, G[(size_t)i * ldg + i]);
-        dmax[0] = m * (double)n * 1.8e-15;                              // ~ 8 n eps |G|: below this a pivot is rounding noise of the Gram
-    }
+    for (int c = t; c < nc; c += QS_THREADS) inv[cols[c]] = c;
+    const int steps = nc < R - 1 ? nc : R - 1;
+    if (wave == 0 && steps > 0) qs_prep_column(A, R, 0, lane, diag, scal);
     __syncthreads();
-    const double tol = dmax[0];
-    // right-looking Cholesky on the lower triangle, columns 0..nc-1 (row nc = the residual's row rides along)
-    for (int j = 0; j < nc; ++j) {
-        __syncthreads();                                                // the trailing update of column j-1 is complete
-        const double d = G[(size_t)j * ldg + j];
-        const bool ok = d > tol;
-        const double s = ok ? 1.0 / sqrt(d) : 0.0;
-        __syncthreads();                                                // everyone has read the pivot before it is overwritten
-        for (int i = j + t; i < n; i += QG_THREADS) G[(size_t)i * ldg + j] = ok ? (i == j ? sqrt(d) : G[(size_t)i * ldg + j] * s) : 0.0;
-        __syncthreads();
-        if (ok) {
-            const int m = n - j - 1;                                    // trailing rows j+1..n-1; element (a, c), c <= a
-            for (int e = t; e < m * m; e += QG_THREADS) {
-                const int a = j + 1 + e / m, c = j + 1 + e % m;
-                if (c <= a) G[(size_t)a * ldg + c] -= G[(size_t)a * ldg + j] * G[(size_t)c * ldg + j];
+    for (int k = 0; k < steps; ++k) {
+        const double beta = scal[k & 1];
+        const double* v = A + (size_t)k * Rp;
+        for (int j = k + 1 + wave; j <= nc; j += QS_WAVES) {
+            double* col = A + (size_t)j * Rp;
+            if (beta != 0.) {
+                double s = 0.;
+                for (int i = k + lane; i < R; i += 64) s += v[i] * col[i];
+                s = wave_sum_f64(s) * beta;
+                if (s != 0.) for (int i = k + lane; i < R; i += 64) col[i] -= s * v[i];
+            }
+            if (j == k + 1 && k + 1 < steps) {                        // always wave 0: the next reflector, in the shadow of the other columns' updates
+                __builtin_amdgcn_wave_barrier();
+                qs_prep_column(col, R, k + 1, lane, diag, scal);
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = wave; i < b.out_rows; i += QG_THREADS / 64) {          // row i of R = column i of L, expanded
+    // R (upper trapezoid in the union's column order) expanded to the dense layout: one wavefront per output row, coalesced
+    for (int i = wave; i < b.out_rows; i += QS_WAVES) {
         double* dst = Hout + (size_t)(b.out_start + i) * ldout;
-        for (int j = lane; j < N; j += 64) { const int c = inv[j]; dst[j] = (c >= i && i < nc) ? G[(size_t)c * ldg + i] : 0.; }
-        if (lane == 0) rout[b.out_start + i] = i < nc ? G[(size_t)nc * ldg + i] : 0.;
+        for (int j = lane; j < N; j += 64) {
+            const int c = inv[j];
+            double val = 0.;
+            if (c >= i && i < R) val = (c == i) ? (i < steps ? diag[i] : A[(size_t)i * Rp + i]) : A[(size_t)c * Rp + i];
+            dst[j] = val;
+        }
+        if (lane == 0) rout[b.out_start + i] = i < R ? A[(size_t)nc * Rp + i] : 0.;
     }
 }
 
+// LDS a node needs (bytes): the planner's fit test and the launch use the same formula
+size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N)
+{
+    const size_t Rp = (size_t)(rows | 1);
+    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2) + sizeof(int) * (size_t)N + 16;
+}
 lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
-                               const QrBlock* d_blocks, int n_blocks, const QrChunk* d_chunks, int n_chunks, const int* d_cols, int N, int max_nc,
-                               size_t part_doubles)
+                               const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds)
 {
     if (n_blocks <= 0) return LVK_OK;
-    double* part = nullptr;
-    if (n_chunks > 0) {
-        part = (double*)lvk_ctx_scratch(ctx, 11, sizeof(double) * part_doubles);
-        if (!part) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
-        const size_t lds1 = sizeof(double) * 16384;                   // every chunk is sized to fit 128 KB (qg_chunk_rows)
-        LVK_LDS_OPTIN(ctx, 3, k_gram_partial, lds1);
-        hipLaunchKernelGGL(k_gram_partial, dim3(n_chunks), dim3(QG_THREADS), lds1, ctx->stream, d_Hin, ldin, d_rin, d_blocks, d_chunks, d_cols, part);
-    }
-    const int T = (max_nc + 1 + 15) / 16;
-    const size_t lds2 = sizeof(double) * ((size_t)16 * T * (16 * T + 1) + 2) + sizeof(int) * (size_t)N + 16;
-    if (lds2 > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "Gram node needs %zu bytes of LDS", lds2);
-    if (lds2 > 64 * 1024) LVK_LDS_OPTIN(ctx, 4, k_gram_chol, lds2);
-    hipLaunchKernelGGL(k_gram_chol, dim3(n_blocks), dim3(QG_THREADS), lds2, ctx->stream, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, d_cols, (const double*)part, N);
+    if (max_lds > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "QR node needs %zu bytes of LDS", max_lds);
+    if (max_lds > 64 * 1024) LVK_LDS_OPTIN(ctx, 3, k_qr_sparse, max_lds);
+    hipLaunchKernelGGL(k_qr_sparse, dim3(n_blocks), dim3(QS_THREADS), max_lds, ctx->stream, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, d_cols, N);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
@@ -238,40 +209,34 @@ static void merge_cols(const std::vector<int>& a, const std::vector<int>& b, std
     out.clear(); out.reserve(a.size() + b.size());
     std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
 }
-// Greedy, level by level: consecutive groups are merged into one node while the column union stays within QG_MAX_NC; a node that
+// Greedy, level by level: consecutive groups are merged into one node while the node still fits the workgroup's LDS; a node that
 // already shrinks (rows > columns) does not take in a group that brings more new columns than rows (the two rows of an in-state
 // feature with its own anchor block).  A node with rows <= columns is passed through.  A level is kept only if it removes at
 // least a fifth of the rows.  Everything here is known on the host before any kernel runs: no counts come back from the device.
 void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups)
 {
+    const size_t LDS_CAP = (size_t)152 * 1024;
     levels.clear();
     int total = 0; for (auto& g : cur) { g.start = total; total += g.rows; }
     std::vector<int> uni, merged;
-    for (int lvl = 0; lvl < 6 && cur.size() > 0; ++lvl) {
+    for (int lvl = 0; lvl < 8 && cur.size() > 0; ++lvl) {
         QrPlanLevel L; std::vector<RowGroup> next;
         size_t i = 0; int out_row = 0; bool any = false;
         while (i < cur.size()) {
             uni = cur[i].cols; int rows = cur[i].rows; size_t j = i + 1;
             while (j < cur.size()) {
                 merge_cols(uni, cur[j].cols, merged);
-                if ((int)merged.size() > QG_MAX_NC) break;
+                const int r2 = rows + cur[j].rows;
+                if (lvk_qr_sparse_lds_bytes(r2, (int)merged.size(), N) > LDS_CAP) break;
                 if (rows > (int)uni.size() && (int)(merged.size() - uni.size()) > cur[j].rows) break;
-                uni.swap(merged); rows += cur[j].rows; ++j;
+                uni.swap(merged); rows = r2; ++j;
             }
             QrBlock b; memset(&b, 0, sizeof b);
             b.in_start = cur[i].start; b.in_rows = rows; b.out_start = out_row;
-            if (rows > (int)uni.size() && (int)uni.size() <= QG_MAX_NC && !uni.empty()) {
+            if (rows > (int)uni.size() && !uni.empty() && lvk_qr_sparse_lds_bytes(rows, (int)uni.size(), N) <= LDS_CAP) {
                 b.copy = 0; b.ncols = (int)uni.size(); b.out_rows = b.ncols; b.col_off = (int)L.cols.size();
                 L.cols.insert(L.cols.end(), uni.begin(), uni.end());
-                const int cr = qg_chunk_rows(b.ncols), T = (b.ncols + 1 + 15) / 16, npairs = T * (T + 1) / 2;
-                b.chunk_first = (int)L.chunks.size(); b.n_chunks = (rows + cr - 1) / cr; b.part_first = (int)L.part_tiles;
-                for (int c = 0; c < b.n_chunks; ++c) {
-                    QrChunk ch; ch.block = (int)L.blocks.size(); ch.row_start = b.in_start + c * cr; ch.rows = std::min(cr, rows - c * cr);
-                    ch.part_first = (int)L.part_tiles + c * npairs;
-                    L.chunks.push_back(ch);
-                }
-                L.part_tiles += (size_t)b.n_chunks * npairs;
-                L.max_nc = std::max(L.max_nc, b.ncols);
+                L.lds = std::max(L.lds, lvk_qr_sparse_lds_bytes(rows, b.ncols, N));
                 next.emplace_back(); next.back().start = out_row; next.back().rows = b.out_rows; next.back().cols = uni;
                 any = true;
             } else {
@@ -360,7 +325,7 @@ extern "C" int lvk_ekf_qr_plan(int N, int n_groups, const int* h_rows, const int
     if ((int)levels.size() > cap_levels) return -1;
     for (size_t l = 0; l < levels.size(); ++l) {
         if (nb + (int)levels[l].blocks.size() > cap_blocks || ncl + (int)levels[l].cols.size() > cap_cols) return -1;
-        for (size_t k = 0; k < levels[l].blocks.size(); ++k) memcpy(h_blocks + 8 * (nb + (int)k), &levels[l].blocks[k], 8 * sizeof(int));   // the first 8 ints of QrBlock
+        memcpy(h_blocks + 8 * nb, levels[l].blocks.data(), sizeof(QrBlock) * levels[l].blocks.size());
         if (!levels[l].cols.empty()) memcpy(h_block_cols + ncl, levels[l].cols.data(), sizeof(int) * levels[l].cols.size());
         h_level_blocks[l] = (int)levels[l].blocks.size(); h_level_cols[l] = (int)levels[l].cols.size();
         nb += (int)levels[l].blocks.size(); ncl += (int)levels[l].cols.size();
@@ -387,25 +352,21 @@ extern "C" lvk_status lvk_ekf_compress_qr_groups(lvk_context* ctx, double* d_H, 
     if (levels.empty()) return LVK_OK;
     double* Hb = (double*)lvk_ctx_scratch(ctx, 7, sizeof(double) * (size_t)rows * ld);
     double* rb = (double*)lvk_ctx_scratch(ctx, 8, sizeof(double) * (size_t)rows);
-    size_t nb = 0, ncl = 0, nch = 0; for (auto& L : levels) { nb += L.blocks.size(); ncl += L.cols.size() + 1; nch += L.chunks.size(); }
-    const size_t o_ch = (sizeof(QrBlock) * nb + 63) & ~(size_t)63, o_cl = (o_ch + sizeof(QrChunk) * nch + 63) & ~(size_t)63;
-    char* meta = (char*)lvk_ctx_scratch(ctx, 9, o_cl + sizeof(int) * ncl);
+    size_t nb = 0, ncl = 0; for (auto& L : levels) { nb += L.blocks.size(); ncl += L.cols.size() + 1; }
+    char* meta = (char*)lvk_ctx_scratch(ctx, 9, sizeof(QrBlock) * nb + sizeof(int) * ncl);
     if (!Hb || !rb || !meta) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
-    QrBlock* d_blocks = (QrBlock*)meta; QrChunk* d_chunks = (QrChunk*)(meta + o_ch); int* d_cols = (int*)(meta + o_cl);
-    std::vector<QrBlock> hb; std::vector<QrChunk> hch; std::vector<int> hc;
-    for (auto& L : levels) { hb.insert(hb.end(), L.blocks.begin(), L.blocks.end()); hch.insert(hch.end(), L.chunks.begin(), L.chunks.end());
-                             hc.insert(hc.end(), L.cols.begin(), L.cols.end()); hc.push_back(0); }
+    QrBlock* d_blocks = (QrBlock*)meta; int* d_cols = (int*)(meta + sizeof(QrBlock) * nb);
+    std::vector<QrBlock> hb; std::vector<int> hc;
+    for (auto& L : levels) { hb.insert(hb.end(), L.blocks.begin(), L.blocks.end()); hc.insert(hc.end(), L.cols.begin(), L.cols.end()); hc.push_back(0); }
     LVK_HIP(ctx, hipMemcpyAsync(d_blocks, hb.data(), sizeof(QrBlock) * nb, hipMemcpyHostToDevice, ctx->stream));
-    if (nch) LVK_HIP(ctx, hipMemcpyAsync(d_chunks, hch.data(), sizeof(QrChunk) * nch, hipMemcpyHostToDevice, ctx->stream));
     LVK_HIP(ctx, hipMemcpyAsync(d_cols, hc.data(), sizeof(int) * ncl, hipMemcpyHostToDevice, ctx->stream));
-    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // hb / hch / hc are stack-local
-    double* H = d_H; double* r = d_r; size_t ob = 0, oc = 0, och = 0;
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // hb / hc are stack-local
+    double* H = d_H; double* r = d_r; size_t ob = 0, oc = 0;
     for (auto& L : levels) {
         double* Ho = (H == d_H) ? Hb : d_H; double* ro = (r == d_r) ? rb : d_r;
-        lvk_status st = lvk_qr_sparse_level(ctx, H, ld, r, Ho, ld, ro, d_blocks + ob, (int)L.blocks.size(), d_chunks + och, (int)L.chunks.size(), d_cols + oc, cols,
-                                            L.max_nc, L.part_tiles * 256);
+        lvk_status st = lvk_qr_sparse_level(ctx, H, ld, r, Ho, ld, ro, d_blocks + ob, (int)L.blocks.size(), d_cols + oc, cols, L.lds);
         if (st != LVK_OK) return st;
-        ob += L.blocks.size(); oc += L.cols.size() + 1; och += L.chunks.size();
+        ob += L.blocks.size(); oc += L.cols.size() + 1;
         H = Ho; r = ro;
     }
     if (H != d_H) {
