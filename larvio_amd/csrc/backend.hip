@@ -90,6 +90,7 @@ struct lvk_ekf {
     double R_b2c[9], t_c_b[3], td = 0;
     std::vector<Clone> clones;
     mutable std::vector<short> rank_tab; mutable long long rank_base = 0; mutable bool ranks_dirty = true;   // see clone_rank()
+    mutable std::vector<double> rcam; mutable bool rcam_valid = false;      // camera-to-world rotation of every clone (clone_Rcam), rebuilt after poses change
     std::vector<long long> feature_states;
     std::map<long long, Feature> map;                  // map_server (ascending id)
     int leg = 22;
@@ -123,6 +124,9 @@ struct lvk_ekf {
     double *d_Hb = nullptr, *d_rb = nullptr;            // ping-pong partner of d_H / d_r for the levels of the structure-aware compression
     int sparse_qr = 1;                                  // LVK_SPARSE_QR=0 disables the structure-aware compression (A/B runs)
     int sparse_qr_min_rows = 480;
+    std::vector<int> tri_ranks; std::vector<double> tri_z;       // view pools of the triangulation requests of the current batch
+    struct ColCache { int type = -1, ncols = 0, anchor = 0, fcol = 0; std::vector<long long> sids; ColList cols; };
+    mutable ColCache colcache;                          // job_dense_cols: the column list of the previous job, reused when the next one has the same observation set
     long qr_stats[4] = {0, 0, 0, 0};                    // [0] updates compressed [1] levels run [2] rows in [3] rows out
     // sharded measurement update: this rank builds the feature rows of its contiguous slice, one all-gather of the
     // compressed blocks (+ every feature's gate result), replicated update.  world 1 = off.
@@ -179,6 +183,17 @@ static int clone_rank(const lvk_ekf* e, long long id)
     }
     const long long k = id - e->rank_base;
     return (k < 0 || k >= (long long)e->rank_tab.size()) ? -1 : e->rank_tab[(size_t)k];
+}
+// R(q_cam) of clone `rank`: checkMotion (feature.hpp:334-381) asks for it twice per feature, thousands of times per update at
+// configs[4]; the clones' poses only change at state injection and when the window changes
+static const double* clone_Rcam(const lvk_ekf* e, int rank)
+{
+    if (!e->rcam_valid || e->rcam.size() != 9 * e->clones.size()) {
+        e->rcam.resize(9 * e->clones.size());
+        for (size_t i = 0; i < e->clones.size(); ++i) quat_to_rot(e->clones[i].q_cam, &e->rcam[9 * i]);
+        e->rcam_valid = true;
+    }
+    return &e->rcam[9 * (size_t)rank];
 }
 static int fs_rank(const lvk_ekf* e, long long id) { for (size_t i = 0; i < e->feature_states.size(); ++i) if (e->feature_states[i] == id) return (int)i; return -1; }
 static void clone_refresh_cam(const lvk_ekf* e, Clone* c)
@@ -547,7 +562,7 @@ static lvk_status state_augmentation(lvk_ekf* e)
     }
     const int pose_rows = LEG + 6 * (int)e->clones.size();
     if (e->N + 6 > e->nmax) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "state dimension %d exceeds capacity %d", e->N + 6, e->nmax);
-    e->clones.push_back(c); e->ranks_dirty = true;
+    e->clones.push_back(c); e->ranks_dirty = true; e->rcam_valid = false;
     static const int sel[6] = {0, 1, 2, 6, 7, 8};
     std::vector<int> idx; idx.reserve(e->N + 6);
     for (int i = 0; i < pose_rows; ++i) idx.push_back(i);
@@ -593,6 +608,7 @@ static void add_observations(lvk_ekf* e, const lvk_feature_obs* f, int n)
 // ------------------------------------------------------------------------- state injection (larvio.cpp:1476-1575 etc.)
 static void inject(lvk_ekf* e, const double* dx)
 {
+    e->rcam_valid = false;
     double dq[4], q[4];
     small_angle_quat(dx, dq); quat_mul(dq, e->s.q, q); memcpy(e->s.q, q, 32);
     for (int i = 0; i < 3; ++i) { e->s.v[i] += dx[3 + i]; e->s.p[i] += dx[6 + i]; e->s.bg[i] += dx[9 + i]; e->s.ba[i] += dx[12 + i]; }
@@ -624,7 +640,9 @@ static void inject(lvk_ekf* e, const double* dx)
 }
 
 // ------------------------------------------------------------------------- device job batches
-struct TriReq { Feature* f; int mode; std::vector<int> ranks; std::vector<double> z; std::vector<long long> ids; bool use_pos; };
+// one triangulation request: its views live in the filter's request pools (tri_ranks / tri_z) at [off, off + n) - no per-request
+// vectors (at configs[4] an update issues hundreds of requests)
+struct TriReq { Feature* f; int mode; int off, n; long long last_id; bool use_pos; };
 struct TriAns { bool ok; double position[3], inv_depth, obs_anchor[3]; long long id_anchor; };
 
 static lvk_status upload_clones(lvk_ekf* e)
@@ -644,12 +662,12 @@ static lvk_status upload_clones(lvk_ekf* e)
 // mode 0 initializePosition(curr_id), 1 initializePosition_AssignAnchor, 2 initializeInvParamPosition(curr_id) (feature.hpp:383-890)
 static void make_tri_req(lvk_ekf* e, Feature* f, int mode, TriReq* rq)
 {
-    rq->f = f; rq->mode = mode; rq->ranks.clear(); rq->z.clear(); rq->ids.clear();
+    rq->f = f; rq->mode = mode; rq->off = (int)e->tri_ranks.size(); rq->n = 0; rq->last_id = -1;
     for (const Obs& o : f->obs) {
         int r = clone_rank(e, o.sid);
         if (r < 0) continue;
         if (mode != 1 && o.sid == e->imu_id) continue;
-        rq->ranks.push_back(r); rq->z.push_back(o.z[0]); rq->z.push_back(o.z[1]); rq->ids.push_back(o.sid);
+        e->tri_ranks.push_back(r); e->tri_z.push_back(o.z[0]); e->tri_z.push_back(o.z[1]); rq->last_id = o.sid; rq->n += 1;
     }
     rq->use_pos = (mode != 2) && f->is_initialized;
 }
@@ -667,17 +685,17 @@ static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::
 {
     ans.assign(reqs.size(), TriAns());
     if (reqs.empty()) return LVK_OK;
-    size_t tot = 0; for (auto& r : reqs) tot += r.ranks.size();
+    size_t tot = 0; for (auto& r : reqs) tot += (size_t)r.n;
     if ((int)reqs.size() > e->feat_cap || (int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "triangulation batch exceeds capacity");
     TriJob* hj = up_alloc<TriJob>(e, reqs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot);
     if (!hj || !hr || !hz) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     size_t off = 0;
     for (size_t i = 0; i < reqs.size(); ++i) {
         TriReq& r = reqs[i];
-        hj[i].n = (int)r.ranks.size(); hj[i].use_position = r.use_pos ? 1 : 0; hj[i].obs_off = (int)off; hj[i].pad = 0;
+        hj[i].n = r.n; hj[i].use_position = r.use_pos ? 1 : 0; hj[i].obs_off = (int)off; hj[i].pad = 0;
         memcpy(hj[i].position_in, r.f->position, 24);
-        for (size_t k = 0; k < r.ranks.size(); ++k) { hr[off + k] = r.ranks[k]; hz[2 * (off + k)] = r.z[2 * k]; hz[2 * (off + k) + 1] = r.z[2 * k + 1]; }
-        off += r.ranks.size();
+        memcpy(hr + off, e->tri_ranks.data() + r.off, sizeof(int) * (size_t)r.n); memcpy(hz + 2 * off, e->tri_z.data() + 2 * (size_t)r.off, sizeof(double) * 2 * (size_t)r.n);
+        off += (size_t)r.n;
     }
     lvk_status st = flush_uploads(e);
     if (st == LVK_OK) st = lvk_launch_triangulate(e->ctx, dev(e, hj), (int)reqs.size(), e->dv_cams, dev(e, hr), dev(e, hz), e->d_triout);
@@ -687,7 +705,7 @@ static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::
     if (st != LVK_OK) return st;
     for (size_t i = 0; i < reqs.size(); ++i) {
         ans[i].ok = ho[i].ok != 0; memcpy(ans[i].position, ho[i].position, 24); ans[i].inv_depth = ho[i].inv_depth; memcpy(ans[i].obs_anchor, ho[i].obs_anchor, 24);
-        ans[i].id_anchor = reqs[i].ids.empty() ? -1 : reqs[i].ids.back();
+        ans[i].id_anchor = reqs[i].last_id;
     }
     e->counters[7] += (long)reqs.size();
     return LVK_OK;
@@ -695,8 +713,9 @@ static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::
 static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracked)
 {   // Feature::checkMotion (feature.hpp:334-381)
     const int first = 0, last = if_tracked ? (int)f.obs.size() - 2 : (int)f.obs.size() - 1;
-    const Clone& a = e->clones[clone_rank(e, f.obs[first].sid)]; const Clone& b = e->clones[clone_rank(e, f.obs[last].sid)];
-    double Ra[9]; quat_to_rot(a.q_cam, Ra);
+    const int ra = clone_rank(e, f.obs[first].sid);
+    const Clone& a = e->clones[ra]; const Clone& b = e->clones[clone_rank(e, f.obs[last].sid)];
+    const double* Ra = clone_Rcam(e, ra);
     double d[3] = {f.obs[first].z[0], f.obs[first].z[1], 1.0};
     const double n = v3_norm(d); d[0] /= n; d[1] /= n; d[2] /= n;
     double dw[3]; m3_v(Ra, d, dw);
@@ -787,7 +806,7 @@ static bool gate_ok(lvk_ekf* e, const RowJob& j)
 // A run of consecutive stacked rows that share one column set (the rows of one feature job): what the structure-aware compression
 // plans its TSQR tree from.  cols = the dense columns the rows can be non-zero in (ascending), as k_feature_rows lays them out:
 // extrinsics + td 15..21, the observing clones' 6-blocks, the anchor's block and the feature's own column for in-state features.
-static void job_dense_cols(const lvk_ekf* e, const RowJob& j, int ncols, std::vector<int>& out)
+static void job_dense_cols_build(const lvk_ekf* e, const RowJob& j, int ncols, std::vector<int>& out)
 {
     out.clear();
     for (int k = 15; k < 22; ++k) out.push_back(k);
@@ -799,11 +818,21 @@ static void job_dense_cols(const lvk_ekf* e, const RowJob& j, int ncols, std::ve
     out.erase(std::unique(out.begin(), out.end()), out.end());
     while (!out.empty() && out.back() >= ncols) out.pop_back();      // a new feature's own column is not part of H_o (k_stack_rows drops it)
 }
+// the shared column list of a job: consecutive jobs with the same observation set (a generation of tracks at configs[4]) reuse one
+static ColList job_dense_cols(const lvk_ekf* e, const RowJob& j, int ncols)
+{
+    auto& c = e->colcache;
+    if (c.cols && c.type == j.type && c.ncols == ncols && c.sids == j.sids && (j.type == JOB_MSCKF || (c.anchor == j.dev.anchor_rank && c.fcol == j.dev.fcol))) return c.cols;
+    auto v = std::make_shared<std::vector<int>>();
+    job_dense_cols_build(e, j, ncols, *v);
+    c.type = j.type; c.ncols = ncols; c.sids = j.sids; c.anchor = j.dev.anchor_rank; c.fcol = j.dev.fcol; c.cols = v;
+    return c.cols;
+}
 // rows [first, first+count) of a job's compact block -> consecutive dense rows starting at dst
 static void push_rows(std::vector<StackRow>& map, const RowJob& j, int first, int count, int dst, int gate_job = -1,
                       std::vector<RowGroup>* groups = nullptr, const lvk_ekf* e = nullptr, int ncols = 0, int owner = 0)
 {
-    if (groups && count > 0) { groups->emplace_back(); RowGroup& g = groups->back(); g.start = dst; g.rows = count; g.owner = owner; job_dense_cols(e, j, ncols, g.cols); }
+    if (groups && count > 0) { groups->emplace_back(); RowGroup& g = groups->back(); g.start = dst; g.rows = count; g.owner = owner; g.cols = job_dense_cols(e, j, ncols); }
     const int M = j.dev.n_obs, c = job_cols(j);
     for (int k = 0; k < count; ++k) {
         StackRow s; s.g_off = j.dev.stage_off; s.r_off = j.dev.stage_off + (long long)2 * M * c * 2; s.src_row = first + k; s.c = c; s.ccol_off = j.dev.ccol_off; s.dst_row = dst + k;
@@ -999,6 +1028,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
     //      (a) lost, not initialised: initializePosition.  (b) tracked long, not in state: the EKF branch wants
     //      initializeInvParamPosition (always from the two-view guess), the MSCKF branch initializePosition.
     std::vector<TriReq> reqs; std::vector<TriAns> ans;
+    e->tri_ranks.clear(); e->tri_z.clear();
     struct Cand { Feature* f; int idx_pos = -1, idx_inv = -1; bool motion; };
     std::vector<Cand> cands;
     for (auto& kv : e->map) {
@@ -1294,6 +1324,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
     // pass A: re-anchoring (host + rank-1 covariance op) and collection of the features that need a triangulation
     struct Use { Feature* f; std::vector<long long> inv; int tri = -1; bool motion = true; };
     std::vector<Use> uses; std::vector<TriReq> reqs; std::vector<TriAns> ans;
+    e->tri_ranks.clear(); e->tri_z.clear();
     bool clones_uploaded = false;
     for (auto& kv : e->map) {
         Feature& f = kv.second;
@@ -1404,7 +1435,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
             for (int i = 0; i < e->N; ++i) if (!drop[i]) idx.push_back(i);
             st = cov_gather(e, idx);
             if (st != LVK_OK) return st;
-            for (int k = 0; k < nrm; ++k) { const int seq = clone_rank(e, rm[k]); if (seq >= 0) { e->clones.erase(e->clones.begin() + seq); e->ranks_dirty = true; } }
+            for (int k = 0; k < nrm; ++k) { const int seq = clone_rank(e, rm[k]); if (seq >= 0) { e->clones.erase(e->clones.begin() + seq); e->ranks_dirty = true; e->rcam_valid = false; } }
         }
     }
     return LVK_OK;
@@ -1446,7 +1477,8 @@ static lvk_status check_zupt(lvk_ekf* e, bool* out)
 {
     *out = false;
     if (e->coarse_dis.size() < 20) { e->coarse_dis.clear(); return LVK_OK; }
-    std::sort(e->coarse_dis.begin(), e->coarse_dis.end());
+    // the reference sorts the whole list and reads one order statistic (larvio.cpp:2759-2761): nth_element gives the same value
+    std::nth_element(e->coarse_dis.begin(), e->coarse_dis.end() - 9, e->coarse_dis.end());
     const double max_dis = e->coarse_dis[e->coarse_dis.size() - 9];
     e->coarse_dis.clear();
     if (max_dis < e->cfg.zupt_max_feature_dis) {
@@ -1658,6 +1690,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
         ~Notify() { fire(); }
     } notify{e, n_consumed};
     e->up_off = 0; e->up_flushed = 0;
+    e->colcache.cols.reset();                           // column lists depend on the clones' ranks, which this call changes
     if (!e->b_first_features) {
         if (n_imu > 0 && imu[0].t - ts - e->td <= 0.0) e->b_first_features = true;
         else return LVK_OK;

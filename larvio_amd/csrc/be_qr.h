@@ -1,12 +1,15 @@
 // be_qr.h — the structure-aware compression of the stacked measurement rows: plan (host) + level launcher (be_qr.hip).
 #pragma once
 #include "lvk_internal.h"
+#include <memory>
 #include <vector>
 
 // A run of consecutive stacked rows that share one column set (the rows of one feature job): what the TSQR tree is planned from.
 // cols = the dense columns the rows can be non-zero in (ascending), as k_feature_rows lays them out: extrinsics + td 15..21, the
 // observing clones' 6-blocks, the anchor's block and the feature's own column for in-state features.
-struct RowGroup { int start, rows; std::vector<int> cols; int owner = 0; };   // owner: the rank that builds these rows in the sharded update
+// (column lists are shared: at configs[4] two thousand features of one generation carry the same list)
+typedef std::shared_ptr<const std::vector<int>> ColList;
+struct RowGroup { int start, rows; ColList cols; int owner = 0; };   // owner: the rank that builds these rows in the sharded update
 // one node of one level: rows [in_start, in_start + in_rows) of the level's input, restricted to ncols columns (col_lists + col_off),
 // reduced to out_rows = min(in_rows, ncols) rows written at out_start of the level's output; copy = pass the rows through unchanged
 struct QrBlock { int in_start, in_rows, out_start, out_rows, ncols, col_off, copy, pad; };

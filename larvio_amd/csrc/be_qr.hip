@@ -223,12 +223,18 @@ void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLeve
         QrPlanLevel L; std::vector<RowGroup> next;
         size_t i = 0; int out_row = 0; bool any = false;
         while (i < cur.size()) {
-            uni = cur[i].cols; int rows = cur[i].rows; size_t j = i + 1;
+            uni = *cur[i].cols; int rows = cur[i].rows; size_t j = i + 1;
+            const std::vector<int>* same = cur[i].cols.get();        // while every merged group carries this very list the union is unchanged
             while (j < cur.size()) {
-                merge_cols(uni, cur[j].cols, merged);
                 const int r2 = rows + cur[j].rows;
+                if (cur[j].cols.get() == same) {
+                    if (lvk_qr_sparse_lds_bytes(r2, (int)uni.size(), N) > LDS_CAP) break;
+                    rows = r2; ++j; continue;
+                }
+                merge_cols(uni, *cur[j].cols, merged);
                 if (lvk_qr_sparse_lds_bytes(r2, (int)merged.size(), N) > LDS_CAP) break;
                 if (rows > (int)uni.size() && (int)(merged.size() - uni.size()) > cur[j].rows) break;
+                if (merged.size() != uni.size()) same = nullptr;
                 uni.swap(merged); rows = r2; ++j;
             }
             QrBlock b; memset(&b, 0, sizeof b);
@@ -237,7 +243,7 @@ void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLeve
                 b.copy = 0; b.ncols = (int)uni.size(); b.out_rows = b.ncols; b.col_off = (int)L.cols.size();
                 L.cols.insert(L.cols.end(), uni.begin(), uni.end());
                 L.lds = std::max(L.lds, lvk_qr_sparse_lds_bytes(rows, b.ncols, N));
-                next.emplace_back(); next.back().start = out_row; next.back().rows = b.out_rows; next.back().cols = uni;
+                next.emplace_back(); next.back().start = out_row; next.back().rows = b.out_rows; next.back().cols = std::make_shared<const std::vector<int>>(uni);
                 any = true;
             } else {
                 b.copy = 1; b.ncols = 0; b.out_rows = rows; b.col_off = 0;
@@ -309,7 +315,7 @@ extern "C" lvk_status lvk_ekf_compress_qr(lvk_context* ctx, double* d_H, int ld,
 static void groups_from_arrays(int n_groups, const int* rows, const int* col_off, const int* cols, std::vector<RowGroup>& g)
 {
     g.resize((size_t)n_groups);
-    for (int i = 0; i < n_groups; ++i) { g[i].start = 0; g[i].rows = rows[i]; g[i].cols.assign(cols + col_off[i], cols + col_off[i + 1]); }
+    for (int i = 0; i < n_groups; ++i) { g[i].start = 0; g[i].rows = rows[i]; g[i].cols = std::make_shared<const std::vector<int>>(cols + col_off[i], cols + col_off[i + 1]); }
 }
 // host-only: the TSQR tree for `n_groups` consecutive row groups (group i: h_rows[i] rows, columns h_cols[h_col_off[i] .. h_col_off[i+1]),
 // ascending).  Blocks come back as 8 ints each (QrBlock), level after level; h_level_blocks[l] / h_level_cols[l] = blocks / column-list
@@ -344,8 +350,8 @@ extern "C" lvk_status lvk_ekf_compress_qr_groups(lvk_context* ctx, double* d_H, 
     std::vector<RowGroup> g; groups_from_arrays(n_groups, h_rows, h_col_off, h_cols, g);
     int tot = 0; for (auto& x : g) tot += x.rows;
     if (tot != rows) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr_groups: the groups hold %d rows, the matrix %d", tot, rows);
-    for (auto& x : g) for (size_t k = 0; k < x.cols.size(); ++k)
-        if (x.cols[k] < 0 || x.cols[k] >= cols || (k > 0 && x.cols[k] <= x.cols[k - 1])) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr_groups: column lists must be ascending and < cols");
+    for (auto& x : g) for (size_t k = 0; k < x.cols->size(); ++k)
+        if ((*x.cols)[k] < 0 || (*x.cols)[k] >= cols || (k > 0 && (*x.cols)[k] <= (*x.cols)[k - 1])) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_ekf_compress_qr_groups: column lists must be ascending and < cols");
     std::vector<QrPlanLevel> levels; int m2 = rows;
     lvk_qr_sparse_plan(g, cols, levels, &m2);
     *rows_out = rows;
