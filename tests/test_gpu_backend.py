@@ -49,11 +49,16 @@ def test_ekf_update_matches_oracle(gpu_ctx, N, m):
     assert np.linalg.eigvalsh(P_g).min() > -1e-12
 
 
-@pytest.mark.parametrize("rows,cols", [(300, 202), (700, 202), (2500, 82), (18000, 120), (150, 202)])
+@pytest.mark.parametrize("rows,cols", [(300, 202), (700, 202), (2500, 82), (18000, 120), (150, 202), (3000, 442), (3536, 452), (9000, 300), (1500, 500),
+                                       (513, 31), (8192, 64), (8193, 64), (40000, 33), (600, 599)])
 def test_qr_compression_preserves_information(gpu_ctx, rows, cols):
+    """lvk_ekf_compress_qr (be_qr_dense.hip: CAQR, NB = 32 up to 8192 rows, NB = 16 above; one and two levels per panel; panels and
+    chunks with ragged ends; rank-deficient leading columns) against numpy's H^T H and H^T r"""
     from larvio_amd import larvio as lv
     rng = np.random.default_rng(rows)
     H = rng.normal(0, 1, (rows, cols)); H[:, :15] = 0.0
+    if cols > 100:
+        H[:, 70] = 0.0; H[:, 90] = H[:, 80] * 2.0                  # an interior zero column and an exactly dependent one
     r = rng.normal(0, 1, rows)
     R, rc = lv.compress_qr(gpu_ctx, H, r)
     assert R.shape[0] == min(rows, cols)
