@@ -19,7 +19,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // Two optional riders save launches on the update's dependent chain: (xin, xin_col) copies a vector into column xin_col of C
 // ([HP | r] in one launch); (xout, xout_col) diverts output column xout_col to a vector, unscaled (W^T [W | w] -> P update and dx).
 struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; double* xout_host = nullptr; };   // xout_host: mirror of xout in device-mapped host memory
-template <bool TA, bool TB>
+template <bool TA, bool TB, int KU>
 __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
                                               double* __restrict__ C, int ldc, double alpha, double beta, double diag_add, GemmRider rd)
 {
@@ -32,20 +32,21 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
     const bool a_ok = ar < M, b_ok = bc < N;
     // The operands come from other XCDs' L2s / the memory side (they were written by the previous kernel), so a dependent load
     // costs microseconds and the tile's time is (number of load round trips) x latency, not bytes or flops: K is walked in
-    // chunks of 64 with all 32 loads of a chunk in flight before its 16 MFMAs.  Lane (i, kk) takes k = k0 + 16 u + 4 kk + q
+    // chunks of 4 KU (64, or 128 for K >= 256: configs[4], N ~ 430) with all 2 KU loads of a chunk in flight before its KU MFMAs.
+    // Lane (i, kk) takes k = k0 + 16 u + 4 kk + q
     // (4 consecutive k per lane: contiguous for the row-major operand) - a permutation of the summation index shared by A and B.
     d4 acc = {0., 0., 0., 0.};
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        double a[16], b[16];
+    for (int k0 = 0; k0 < K; k0 += 4 * KU) {
+        double a[KU], b[KU];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < KU; ++u) {
             const int k = k0 + 16 * (u >> 2) + 4 * kk + (u & 3);
             const bool k_ok = k < K;
             a[u] = (a_ok && k_ok) ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
             b[u] = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < KU; ++u)
             if (k0 + 16 * (u >> 2) < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);   // FP64 MFMA is 64 cycles: no padded K groups
     }
 #pragma unroll
@@ -67,7 +68,8 @@ static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, in
 {
     if (M <= 0 || N <= 0) return;
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
+    if (K >= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB, 32>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB, 16>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
 }
 
 
