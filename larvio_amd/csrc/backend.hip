@@ -1835,7 +1835,7 @@ static double now_us_fwd();
 struct lvk_vio_pipe {
     lvk_frontend* fe; lvk_ekf* ekf;
     std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..)
-    struct Job { double ts; std::vector<lvk_feature_obs> feats; std::vector<lvk_imu> view; bool precounted = false; double t_submit = 0; };
+    struct Job { double ts; int slot = -1; std::vector<lvk_imu> view; bool precounted = false; double t_submit = 0; };   // slot: the front-end's message ring entry
     std::vector<float> lat_us;                          // image-in -> state-out of every message-carrying frame (submit entry to update done)
     bool cur_precounted = false;                        // the running job's erase count was already applied by submit()
     std::deque<Job> q;
@@ -1846,7 +1846,7 @@ struct lvk_vio_pipe {
     long n_updates = 0, n_msgs = 0;
     lvk_status st = LVK_OK;
     bool stop = false;
-    std::vector<lvk_feature_obs> msg;
+    std::vector<lvk_feature_obs> wmsg;                  // the worker's copy of the message it is processing
     lvk_odometry_fn on_update = nullptr; void* on_update_user = nullptr;
     double t_busy = 0, t_idle = 0, t_submit_wait = 0, t_fe = 0;
     struct Ev { double t; int what; };                    // LVK_PIPE_LOG=<file>: event log (0 submit begin, 1 wait done, 2 front-end done,
@@ -1906,8 +1906,21 @@ static void pipe_worker(lvk_vio_pipe* p)
         }
         const double t1 = now_us();
         { std::lock_guard<std::mutex> lk(p->mu); p->ev(5); }
-        int used = 0, upd = 0;
-        lvk_status st = lvk_ekf_process(p->ekf, job.ts, job.feats.data(), (int)job.feats.size(), job.view.data(), (int)job.view.size(), &used, &upd);
+        // The erase count of this update depends on time stamps, the state time and td only - all final now that the previous update
+        // is done - so it is published BEFORE this thread blocks on the message: the caller's next frame needs nothing else from here.
+        if (!job.precounted && p->ekf->b_first_features && p->ekf->is_gravity_set) {
+            const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size());
+            {
+                std::lock_guard<std::mutex> lk(p->mu);
+                p->head += (size_t)n; p->unknown_consume -= 1; p->cur_precounted = true;
+                p->gen.fetch_add(1, std::memory_order_release);
+            }
+            p->cv_state.notify_all();
+        }
+        int used = 0, upd = 0, n_feats = 0;
+        // the message itself is collected HERE, on the filter's thread: the caller's thread queued the frame and went on
+        lvk_status st = lvk_frontend_fetch_msg(p->fe, job.slot, p->wmsg.data(), (int)p->wmsg.size(), &n_feats);
+        if (st == LVK_OK) st = lvk_ekf_process(p->ekf, job.ts, p->wmsg.data(), n_feats, job.view.data(), (int)job.view.size(), &used, &upd);
         if (st == LVK_OK && upd && p->on_update) { double s30[30]; lvk_ekf_get_state(p->ekf, s30); p->on_update(p->on_update_user, job.ts, s30); }
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -1930,7 +1943,7 @@ lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** ou
     if (lvk_frontend_context(fe) == ekf->ctx)
         return lvk_set_error(ekf->ctx, LVK_ERR_ARG, "lvk_vio_pipe_create: the front-end and the filter must live on different contexts (streams)");
     lvk_vio_pipe* p = new lvk_vio_pipe();
-    p->fe = fe; p->ekf = ekf; p->msg.resize(8192);
+    p->fe = fe; p->ekf = ekf; p->wmsg.resize(8192);
     p->logging = getenv("LVK_PIPE_LOG") != nullptr; if (p->logging) p->log.reserve(1 << 16);
     ekf->on_consumed = pipe_on_consumed; ekf->on_consumed_user = p;
     p->worker = std::thread(pipe_worker, p);
@@ -1980,14 +1993,14 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
     const double t1 = now_us();
     p->t_submit_wait += t1 - t0;
     // only this thread appends to imu, and no update can move `head` until a new job is queued below
-    int n_out = 0;
-    lvk_status st = lvk_frontend_process(p->fe, img, ts, p->imu.data() + head, (int)(end - head), p->msg.data(), (int)p->msg.size(), &n_out, has_msg);
+    int slot = -1;
+    lvk_status st = lvk_frontend_process_async(p->fe, img, ts, p->imu.data() + head, (int)(end - head), has_msg, &slot);
     p->t_fe += now_us() - t1;
     if (p->logging) { std::lock_guard<std::mutex> lk(p->mu); p->ev(2); }
     if (st != LVK_OK || !*has_msg) return st;
     lvk_vio_pipe::Job job;
     job.t_submit = tb;
-    job.ts = ts; job.feats.assign(p->msg.begin(), p->msg.begin() + n_out);
+    job.ts = ts; job.slot = slot;
     job.view.assign(p->imu.begin() + (long)head, p->imu.begin() + (long)end);
     {
         std::lock_guard<std::mutex> lk(p->mu);

@@ -57,69 +57,95 @@ template <int NB> __device__ __forceinline__ int cq_rows(const CaqrGeom& g, int 
 #define CQ_FWAVES (CQ_FTHREADS / 64)
 // Factor one node's panel.  V (rows x NB, row-major, stride NB) and T (NB x NB) go to the node's workspace slots; R goes back into
 // the panel's own columns (row s < nb: R[s][s..nb); rows below: zero when they are top rows of a chunk, untouched otherwise).
+// The panel lives in REGISTERS: wavefront w owns NB / 16 columns, lane l their rows l, l + 64, ... (CH / 64 = 8 or 16 values per
+// column).  A Householder step is: everybody reads the current reflector v_k from a double-buffered LDS vector (independent loads,
+// one round trip), every wavefront updates its own columns in registers (DPP wave reduction for the dot product), the owner of
+// column k+1 derives the next reflector and publishes it - ONE barrier per step and no LDS traffic for the matrix itself.  The
+// first version kept the panel in LDS and paid ~3.4 us per step in dependent LDS round trips (110 us per 512 x 32 panel).
 template <int NB>
 __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict__ A, CaqrGeom g, int level, double* __restrict__ Vws, double* __restrict__ Tws)
 {
     extern __shared__ double sm[];
+    constexpr int CH = 16384 / NB, RPL = CH / 64, CPW = NB / CQ_FWAVES, PLD = NB + 1;
     const int node = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int R = cq_rows<NB>(g, level, node), Rp = R | 1, nb = g.nb;
-    double* P = sm;                                   // NB columns x Rp
-    double* diag = P + (size_t)NB * Rp;               // NB
+    const int R = cq_rows<NB>(g, level, node), nb = g.nb;
+    double* sP = sm;                                  // CH x PLD staging: panel in (coalesced rows), then V out
+    double* vbuf = sP + (size_t)CH * PLD;             // 2 x CH : reflector k in vbuf[k & 1]
+    double* diag = vbuf + 2 * CH;                     // NB
     double* beta = diag + NB;                         // NB
     double* Z = beta + NB;                            // NB x NB : Z[j][k] = v_j . v_k (j < k)
     double* T = Z + NB * NB;                          // NB x NB
-    for (int s = wave; s < R; s += CQ_FWAVES) {
-        const int row = cq_row<NB>(g, level, node, s);
+    for (int s = wave; s < CH; s += CQ_FWAVES) {
+        const int row = s < R ? cq_row<NB>(g, level, node, s) : g.m;
         const double* src = A + (size_t)(row < g.m ? row : 0) * g.ld + g.j0;
-        for (int c = lane; c < NB; c += 64) P[(size_t)c * Rp + s] = (row < g.m && c < nb) ? src[c] : 0.;
+        for (int c = lane; c < NB; c += 64) sP[(size_t)s * PLD + c] = (row < g.m && c < nb) ? src[c] : 0.;
     }
     for (int e = t; e < NB * NB; e += CQ_FTHREADS) { Z[e] = 0.; T[e] = 0.; }
     if (t < NB) { beta[t] = 0.; diag[t] = 0.; }
     __syncthreads();
-    const int steps = nb < R ? nb : R;                // a reflector for every column that has a row (the last row alone: beta = 0 or a sign flip)
-    auto prep = [&](int k) {                          // one wavefront: reflector of column k below row k; v overwrites the column
-        double* col = P + (size_t)k * Rp;
+    double a[CPW][RPL];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) a[c][q] = sP[(size_t)(lane + 64 * q) * PLD + wave * CPW + c];
+    const int steps = nb < R ? nb : R;
+    // reflector of own column c (global column index col) below row k, published into vbuf[k & 1]
+    auto prep = [&](int c, int k) {
         double part = 0.;
-        for (int i = k + lane; i < R; i += 64) { const double a = col[i]; part += a * a; }
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; if (i >= k) part += a[c][q] * a[c][q]; }
         const double s = cq_wave_sum(part);
-        if (lane == 0) {
-            const double akk = col[k];
-            const double nrm = sqrt(s);
-            const double tail = s - akk * akk;        // nothing below the diagonal: leave the column alone (no sign flip of an existing R)
-            const double alpha = akk >= 0. ? -nrm : nrm;
-            const double vn2 = 2. * (s - alpha * akk);
-            const double b = (nrm == 0. || vn2 == 0. || tail <= 0.) ? 0. : 2. / vn2;
-            diag[k] = b != 0. ? alpha : akk;
-            if (b != 0.) col[k] = akk - alpha;
-            beta[k] = b;
+        const int lk = k & 63, qk = k >> 6;           // row k sits in lane lk, slot qk
+        double akk = 0.;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) if (q == qk) akk = a[c][q];
+        akk = __shfl(akk, lk);                        // the diagonal element to every lane (once per step)
+        const double nrm = sqrt(s);
+        const double tail = s - akk * akk;            // nothing below the diagonal: leave the column alone (no sign flip of an existing R)
+        const double alpha = akk >= 0. ? -nrm : nrm;
+        const double vn2 = 2. * (s - alpha * akk);
+        const double bk = (nrm == 0. || vn2 == 0. || tail <= 0.) ? 0. : 2. / vn2;
+        if (lane == lk && bk != 0.) {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) if (q == qk) a[c][q] = akk - alpha;
         }
+        if (lane == 0) { diag[k] = bk != 0. ? alpha : akk; beta[k] = bk; }
+        double* vb = vbuf + (size_t)(k & 1) * CH;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; vb[i] = (i >= k && bk != 0.) ? a[c][q] : 0.; }
     };
-    if (wave == 0 && steps > 0) prep(0);
+    if (steps > 0 && wave == 0) prep(0, 0);           // column 0 belongs to wavefront 0, slot 0
     __syncthreads();
     for (int k = 0; k < steps; ++k) {
-        const double b = beta[k];
-        const double* v = P + (size_t)k * Rp;
-        for (int j = wave; j < NB; j += CQ_FWAVES) {
-            if (j == k) continue;
-            double* col = P + (size_t)j * Rp;
+        const double bk = beta[k];
+        const double* vb = vbuf + (size_t)(k & 1) * CH;
+        double vr[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) vr[q] = vb[lane + 64 * q];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int j = wave * CPW + c;
             if (j > k) {
-                if (b != 0.) {
+                if (bk != 0.) {
                     double s = 0.;
-                    for (int i = k + lane; i < R; i += 64) s += v[i] * col[i];
-                    s = cq_wave_sum(s) * b;
-                    if (s != 0.) for (int i = k + lane; i < R; i += 64) col[i] -= s * v[i];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) s += vr[q] * a[c][q];
+                    s = cq_wave_sum(s) * bk;
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) a[c][q] -= s * vr[q];
                 }
-                if (j == k + 1 && k + 1 < steps) { __builtin_amdgcn_wave_barrier(); prep(k + 1); }
-            } else if (b != 0. && beta[j] != 0.) {     // j < k: z = v_j . v_k for the compact-WY factor (v_j lives in rows >= j, v_k in rows >= k)
+                if (j == k + 1 && k + 1 < steps) prep(c, k + 1);
+            } else if (j < k && bk != 0.) {               // z = v_j . v_k for the compact-WY factor (v_k is zero above row k)
                 double s = 0.;
-                for (int i = k + lane; i < R; i += 64) s += col[i] * v[i];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) s += vr[q] * a[c][q];
                 s = cq_wave_sum(s);
-                if (lane == 0) Z[j * NB + k] = s;
+                if (lane == 0 && beta[j] != 0.) Z[j * NB + k] = s;
             }
         }
         __syncthreads();
     }
-    // T (upper triangular): T[k][k] = beta_k ; T[0:k, k] = -beta_k T[0:k, 0:k] Z[0:k, k]   (one wavefront, column by column)
+    // T (upper triangular): T[k][k] = beta_k ; T[0:k, k] = -beta_k T[0:k, 0:k] Z[0:k, k]   (one wavefront, lane i = row i)
     if (wave == 0) {
         for (int k = 0; k < steps; ++k) {
             const double bk = beta[k];
@@ -132,11 +158,17 @@ __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict_
             __builtin_amdgcn_wave_barrier();
         }
     }
+    // registers -> staging (the panel after the factorisation: R above the diagonal, the reflectors on and below it)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) sP[(size_t)(lane + 64 * q) * PLD + wave * CPW + c] = a[c][q];
     __syncthreads();
-    // outputs
-    double* Vn = Vws + (size_t)node * g.CH * NB;       // level 2 has one node; its stack is at most CH rows long (nch NB <= CH)
-    for (int s = wave; s < R; s += CQ_FWAVES)
-        for (int c = lane; c < NB; c += 64) Vn[(size_t)s * NB + c] = (c < steps && s >= c && beta[c] != 0.) ? P[(size_t)c * Rp + s] : 0.;
+    double* Vn = Vws + (size_t)node * CH * NB;         // level 2 has one node; its stack is at most CH rows long (nch NB <= CH)
+    for (int e = t; e < R * NB; e += CQ_FTHREADS) {
+        const int s = e / NB, c = e - s * NB;
+        Vn[e] = (c < steps && s >= c && beta[c] != 0.) ? sP[(size_t)s * PLD + c] : 0.;
+    }
     double* Tn = Tws + (size_t)node * NB * NB;
     for (int e = t; e < NB * NB; e += CQ_FTHREADS) Tn[e] = T[e];
     // R back into the panel: rows s < NB of the node (level 1: the chunk's top rows, read again by level 2; level 2: top rows of chunk 0 =
@@ -148,7 +180,7 @@ __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict_
         double* dst = A + (size_t)row * g.ld + g.j0;
         for (int c = lane; c < nb; c += 64) {
             double val = 0.;
-            if (s < nb && c >= s) val = (c == s) ? (s < steps ? diag[s] : P[(size_t)s * Rp + s]) : P[(size_t)c * Rp + s];
+            if (s < nb && c >= s) val = (c == s) ? (s < steps ? diag[s] : sP[(size_t)s * PLD + s]) : sP[(size_t)s * PLD + c];
             dst[c] = val;
         }
     }
@@ -157,39 +189,48 @@ __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict_
 #define CQ_ATHREADS 256
 // Apply one node's block reflector to the columns right of the panel (+ the residual as the last column):
 //   W = V^T C ; W <- T^T W ; C -= V W          C = rows of the node x [j0 + nb, n]  (column n = r)
-// grid (nodes, tile groups); a workgroup stages V once and walks its 16-column tiles.
+// grid (nodes, tile groups); a workgroup stages V once and walks its 16-column tiles.  Every global load of a phase is issued before
+// the first MFMA that needs one (C was written by other workgroups in the previous launch: a dependent load costs a microsecond).
 template <int NB>
 __global__ void __launch_bounds__(CQ_ATHREADS) k_caqr_apply(double* __restrict__ A, double* __restrict__ rv, CaqrGeom g, int level, const double* __restrict__ Vws,
                                                             const double* __restrict__ Tws)
 {
     extern __shared__ double sm[];
-    constexpr int NBp = NB + 1, MT = NB / 16;
+    constexpr int CH = 16384 / NB, NBp = NB + 1, MT = NB / 16, KIT = CH / 16, GIT = CH / 64;   // k-steps / 16-row groups per wavefront
     const int node = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, i16 = lane & 15, kk = lane >> 4;
     const int R = cq_rows<NB>(g, level, node), Rr = (R + 15) & ~15;
-    double* sV = sm;                                  // Rr x NBp
-    double* sT = sV + (size_t)Rr * NBp;               // NB x NB
+    double* sV = sm;                                  // CH x NBp
+    double* sT = sV + (size_t)CH * NBp;               // NB x NB
     double* sW = sT + NB * NB;                        // 4 partial W (one per wavefront): 4 x NB x 17, then W in slot 0
-    int* srow = (int*)(sW + 4 * NB * 17);             // Rr: matrix row of node row s (or -1)
-    const double* Vn = Vws + (size_t)node * g.CH * NB;
-    for (int e = t; e < Rr * NB; e += CQ_ATHREADS) { const int s = e / NB, c = e - s * NB; sV[(size_t)s * NBp + c] = s < R ? Vn[(size_t)s * NB + c] : 0.; }
+    int* srow = (int*)(sW + 4 * NB * 17);             // CH: matrix row of node row s (or -1)
+    const double* Vn = Vws + (size_t)node * CH * NB;
+    for (int e = t; e < CH * NB; e += CQ_ATHREADS) { const int s = e / NB, c = e - s * NB; sV[(size_t)s * NBp + c] = s < R ? Vn[e] : 0.; }
     for (int e = t; e < NB * NB; e += CQ_ATHREADS) sT[e] = Tws[(size_t)node * NB * NB + e];
-    for (int s = t; s < Rr; s += CQ_ATHREADS) { const int row = s < R ? cq_row<NB>(g, level, node, s) : -1; srow[s] = (row >= 0 && row < g.m) ? row : -1; }
+    for (int s = t; s < CH; s += CQ_ATHREADS) { const int row = s < R ? cq_row<NB>(g, level, node, s) : -1; srow[s] = (row >= 0 && row < g.m) ? row : -1; }
     __syncthreads();
     const int c0 = g.j0 + g.nb;                       // first trailing column; columns c0 .. n-1 of A, then the residual as column n
     const int ncolsC = g.n - c0 + 1, ntiles = (ncolsC + 15) / 16;
     for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
         const int col = c0 + tile * 16 + i16;         // this lane's C column (as B operand / D column)
         const bool col_ok = col <= g.n;
-        // ---- phase A: W = V^T C, rows split over the four wavefronts
+        // ---- phase A: W = V^T C, rows split over the four wavefronts (k-steps wave, wave + 4, ...)
+        double cv[KIT];
+#pragma unroll
+        for (int u = 0; u < KIT; ++u) {
+            const int s = (wave + 4 * u) * 4 + kk;
+            const int row = s < Rr ? srow[s] : -1;
+            cv[u] = (row >= 0 && col_ok) ? (col < g.n ? A[(size_t)row * g.ld + col] : rv[row]) : 0.;
+        }
         d4 acc[MT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) acc[mi] = d4{0., 0., 0., 0.};
-        for (int k0 = wave * 4; k0 < Rr; k0 += 16) {
-            const int s = k0 + kk, row = srow[s];
-            double cv = 0.;
-            if (row >= 0 && col_ok) cv = col < g.n ? A[(size_t)row * g.ld + col] : rv[row];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(size_t)s * NBp + mi * 16 + i16], cv, acc[mi], 0, 0, 0);
+        for (int u = 0; u < KIT; ++u) {
+            const int s = (wave + 4 * u) * 4 + kk;
+            if ((wave + 4 * u) * 4 < Rr) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(size_t)s * NBp + mi * 16 + i16], cv[u], acc[mi], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -216,15 +257,28 @@ __global__ void __launch_bounds__(CQ_ATHREADS) k_caqr_apply(double* __restrict__
             for (int e = t; e < NB * 16; e += CQ_ATHREADS, ++cnt) { const int i = e / 16, j = e - i * 16; sW[i * 17 + j] = wv[cnt]; }
         }
         __syncthreads();
-        // ---- phase C: C -= V W, 16-row groups dealt to the wavefronts
-        for (int gq = wave; gq < Rr / 16; gq += 4) {
+        // ---- phase C: C -= V W, 16-row groups dealt to the wavefronts (group = wave + 4 gi); old values fetched up front
+        double old[GIT][4];
+#pragma unroll
+        for (int gi = 0; gi < GIT; ++gi) {
+            const int gq = wave + 4 * gi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = gq * 16 < Rr ? srow[gq * 16 + kk + 4 * r] : -1;
+                old[gi][r] = (row >= 0 && col_ok) ? (col < g.n ? A[(size_t)row * g.ld + col] : rv[row]) : 0.;
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < GIT; ++gi) {
+            const int gq = wave + 4 * gi;
+            if (gq * 16 >= Rr) continue;
             d4 u = {0., 0., 0., 0.};
 #pragma unroll
             for (int k0 = 0; k0 < NB; k0 += 4) u = __builtin_amdgcn_mfma_f64_16x16x4f64(sV[(size_t)(gq * 16 + i16) * NBp + k0 + kk], sW[(k0 + kk) * 17 + i16], u, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = srow[gq * 16 + kk + 4 * r];
-                if (row >= 0 && col_ok) { if (col < g.n) A[(size_t)row * g.ld + col] -= u[r]; else rv[row] -= u[r]; }
+                if (row >= 0 && col_ok) { if (col < g.n) A[(size_t)row * g.ld + col] = old[gi][r] - u[r]; else rv[row] = old[gi][r] - u[r]; }
             }
         }
         __syncthreads();
@@ -248,7 +302,7 @@ static lvk_status caqr_run(lvk_context* ctx, double* d_H, int ld, int m, int n, 
     double* Tws = (double*)lvk_ctx_scratch(ctx, 8, sizeof(double) * ((size_t)(nch_max + 1) * NB * NB));
     if (!Vws || !Tws) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
     double* V2 = Vws + (size_t)nch_max * CH * NB; double* T2 = Tws + (size_t)nch_max * NB * NB;
-    const size_t lds_f = sizeof(double) * ((size_t)NB * (CH | 1) + 2 * NB + 2 * NB * NB + 2);
+    const size_t lds_f = sizeof(double) * ((size_t)CH * (NB + 1) + 2 * (size_t)CH + 2 * NB + 2 * NB * NB + 2);
     const size_t lds_a = sizeof(double) * ((size_t)CH * (NB + 1) + NB * NB + 4 * NB * 17 + 2) + sizeof(int) * (size_t)CH;
     if (lds_f > 160 * 1024 || lds_a > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "CAQR: LDS budget exceeded (%zu / %zu bytes)", lds_f, lds_a);
     LVK_LDS_OPTIN(ctx, NB == 32 ? 5 : 6, k_caqr_factor<NB>, lds_f);

@@ -10,6 +10,7 @@
 // (image_processor.h:215-230); the one order-preserving compaction happens inside the RANSAC
 // workgroup, which needs the compacted order anyway (OpenCV's RNG draws indices into it).
 #include "lvk_internal.h"
+#include <atomic>
 #include <sched.h>
 #include "fe_track_dev.h"
 #include <math.h>
@@ -439,6 +440,7 @@ __global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams c
 
 
 // =========================================================================== host object
+#define LVK_MSG_SLOTS 4
 struct lvk_frontend {
     lvk_context* ctx;
     lvk_fe_config cfg;
@@ -462,8 +464,14 @@ struct lvk_frontend {
     uint8_t *w_status, *wn_status;
     unsigned long long* wn_desc;
     float* eig; uint8_t* mask; unsigned* gf_scratch; unsigned long long* gf_cands; int gf_cand_cap;
-    lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;     // the message buffer: pinned host memory (h_msg) and its device-mapped view (d_msg)
-    int* h_nmsg; int* d_nmsg;                            // its length, same arrangement
+    // The message buffer: pinned host memory (h_msg) and its device-mapped view (d_msg), and its length, same arrangement - a ring
+    // of LVK_MSG_SLOTS messages so that a pipelined driver can let the GPU run ahead: processImage returns as soon as the frame is
+    // queued and the filter's thread picks the message up when ev_msg[slot] has fired (lvk_frontend_fetch_msg).
+    lvk_feature_obs* d_msg; lvk_feature_obs* h_msg;
+    int* h_nmsg; int* d_nmsg;
+    hipEvent_t ev_msg[LVK_MSG_SLOTS] = {};
+    std::atomic<int> msg_pending[LVK_MSG_SLOTS];         // 1 from the publish until the message has been fetched
+    int msg_next = 0;
     FeDev* dev; FeDev* h_dev;                            // device + pinned host mirror
     CamParams cam;
     // Side stream side[0] ("new points"): goodFeaturesToTrack after a publish, then the next frame's ORB planes and the LK /
@@ -590,6 +598,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 2; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
     for (int i = 0; i < 3; ++i) { if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]); if (fe->ev_stage[i]) hipEventDestroy(fe->ev_stage[i]); }
+    for (int i = 0; i < LVK_MSG_SLOTS; ++i) if (fe->ev_msg[i]) hipEventDestroy(fe->ev_msg[i]);
     if (fe->h_msg) hipHostFree(fe->h_msg);
     if (fe->h_nmsg) hipHostFree(fe->h_nmsg);
     if (fe->h_dev) hipHostFree(fe->h_dev);
@@ -631,8 +640,9 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     ok = ok && dalloc(&fe->d_img, (size_t)w * h) && dalloc(&fe->w_curr, cap) && dalloc(&fe->wn_curr, cap) && dalloc(&fe->new_pts, cap) &&
          dalloc(&fe->w_status, cap) && dalloc(&fe->wn_status, cap) && dalloc(&fe->wn_desc, (size_t)cap * 4) && dalloc(&fe->eig, (size_t)w * h) &&
          dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4 + 8192) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->dev, 1);
-    ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap) == hipSuccess &&
-         hipHostMalloc((void**)&fe->h_nmsg, 64) == hipSuccess && hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap * LVK_MSG_SLOTS) == hipSuccess &&
+         hipHostMalloc((void**)&fe->h_nmsg, 64 * LVK_MSG_SLOTS) == hipSuccess && hipHostMalloc((void**)&fe->h_dev, sizeof(FeDev)) == hipSuccess;
+    for (int i = 0; i < LVK_MSG_SLOTS && ok; ++i) { fe->msg_pending[i].store(0); ok = hipEventCreateWithFlags(&fe->ev_msg[i], hipEventDisableTiming) == hipSuccess; }
     if (ok) {
         void *dm = nullptr, *dn = nullptr;
         ok = hipHostGetDevicePointer(&dm, fe->h_msg, 0) == hipSuccess && hipHostGetDevicePointer(&dn, fe->h_nmsg, 0) == hipSuccess && dm && dn;
@@ -672,6 +682,7 @@ static lvk_status fe_read_dev(lvk_frontend* fe)
 // findNewFeaturesToBeTracked (:1005-1037).  Nothing in this frame's message depends on it, so it runs on side[0] behind the
 // commit and overlaps the message read-back, the filter update and the next frame's pyramid; the next frame's LK of the new
 // points is queued on the same stream, right behind it.
+extern "C" lvk_status lvk_frontend_fetch_msg(lvk_frontend* fe, int slot, lvk_feature_obs* h_out, int cap, int* n_out);
 static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
 {
     lvk_context* cx = fe->side[0];
@@ -687,27 +698,31 @@ static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
     if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
     return LVK_OK;
 }
-// getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172)
-static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out)
+// getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172).  async_slot == nullptr: wait for the message and copy it out (the
+// reference's synchronous processImage); otherwise return the ring slot at once - lvk_frontend_fetch_msg collects it later.
+static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out, int* async_slot)
 {
     lvk_context* ctx = fe->ctx;
     lvk_status st;
+    const int slot = fe->msg_next; fe->msg_next = (slot + 1) % LVK_MSG_SLOTS;
+    if (fe->msg_pending[slot].load(std::memory_order_acquire)) {       // four publishes ago and still not fetched: the consumer is far behind
+        LVK_HIP(ctx, hipEventSynchronize(fe->ev_msg[slot]));
+        for (int spin = 0; fe->msg_pending[slot].load(std::memory_order_acquire); ++spin) { if (spin > 2000000) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature-message ring overrun"); __builtin_ia32_pause(); }
+    }
     { ProfScope ps8(fe, 8);
     const double dt_1 = fe->curr_img_time - fe->prev_img_time;
     const int prev_is_last = fe->prev_img_time == fe->last_pub_time;
     const double dt_2 = prev_is_last ? dt_1 : fe->prev_img_time - fe->last_pub_time;
     hipLaunchKernelGGL(k_fe_msg, dim3((fe->cap + 63) / 64), dim3(64), 0, ctx->stream, fe->set[dst], (const int*)&fe->dev->n_tracks[dst], fe->cam, dt_1, dt_2,
-                       prev_is_last, fe->d_msg, fe->dev, fe->d_nmsg);
+                       prev_is_last, fe->d_msg + (size_t)slot * fe->cap, fe->dev, fe->d_nmsg + 16 * slot);
     LVK_LAUNCH_CHECK(ctx); }
-    st = fe_detect_new(fe, dst);                         // queued on side[0] before the host blocks on the message
+    hipEventRecord(fe->ev_msg[slot], ctx->stream);
+    fe->msg_pending[slot].store(1, std::memory_order_release);
+    st = fe_detect_new(fe, dst);                         // queued on side[0] before anybody blocks on the message
     if (st != LVK_OK) return st;
-    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int n = *fe->h_nmsg;
-    if (n > cap) n = cap;
-    if (h_out && n > 0) memcpy(h_out, fe->h_msg, sizeof(lvk_feature_obs) * (size_t)n);
-    *n_out = n;
     fe->last_pub_time = ts; fe->pub_counter++;
-    return LVK_OK;
+    if (async_slot) { *async_slot = slot; *n_out = 0; return LVK_OK; }
+    return lvk_frontend_fetch_msg(fe, slot, h_out, cap, n_out);
 }
 
 // The IMU-independent part of a frame: image upload, createImagePyramids (:318-334) on the main stream, ORBdescriptor ctor (:150)
@@ -781,8 +796,36 @@ lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts)
 
 // processImage is synchronous in the reference: when it returns the caller may free or overwrite the image.  Same here: a host
 // image has been copied into the pinned staging ring by the time the call returns (the frame's kernels keep running).
+static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu,
+                                   lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg, int* async_slot);
 lvk_status lvk_frontend_process(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu,
                                 lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
+{
+    return frontend_process(fe, img, ts, h_imu, n_imu, h_out, cap, n_out, has_msg, nullptr);
+}
+// the pipelined driver's variant: nothing waits for the GPU; *slot names the ring entry the message will appear in
+lvk_status lvk_frontend_process_async(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu, int* has_msg, int* slot)
+{
+    int n = 0;
+    if (!slot) return LVK_ERR_ARG;
+    *slot = -1;
+    return frontend_process(fe, img, ts, h_imu, n_imu, nullptr, 0, &n, has_msg, slot);
+}
+// wait for the message of ring entry `slot` and copy it out (any thread)
+lvk_status lvk_frontend_fetch_msg(lvk_frontend* fe, int slot, lvk_feature_obs* h_out, int cap, int* n_out)
+{
+    if (!fe || slot < 0 || slot >= LVK_MSG_SLOTS || !n_out) return LVK_ERR_ARG;
+    const hipError_t er = hipEventSynchronize(fe->ev_msg[slot]);
+    if (er != hipSuccess) return lvk_set_error(fe->ctx, LVK_ERR_DEVICE, "feature message: %s", hipGetErrorString(er));
+    int n = fe->h_nmsg[16 * slot];
+    if (n > cap) n = cap;
+    if (h_out && n > 0) memcpy(h_out, fe->h_msg + (size_t)slot * fe->cap, sizeof(lvk_feature_obs) * (size_t)n);
+    *n_out = n;
+    fe->msg_pending[slot].store(0, std::memory_order_release);
+    return LVK_OK;
+}
+static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu,
+                                   lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg, int* async_slot)
 {
     if (!fe || !img || !n_out || !has_msg || (n_imu > 0 && !h_imu)) return lvk_set_error(fe ? fe->ctx : nullptr, LVK_ERR_ARG, "lvk_frontend_process: bad argument");
     lvk_context* ctx = fe->ctx;
@@ -832,7 +875,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const lvk_image* img, double t
                 hipEventRecord(fe->ev_commit, S1);
                 if (ts - fe->last_pub_time >= pub_gate) {
                     hipStreamWaitEvent(S2, fe->ev_pyr, 0);
-                    st = fe_publish(fe, dst, ts, h_out, cap, n_out);
+                    st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                     if (st != LVK_OK) return st;
                     *has_msg = 1;
                 }
@@ -853,7 +896,7 @@ lvk_status lvk_frontend_process(lvk_frontend* fe, const lvk_image* img, double t
             curr_valid = true;
             hipEventRecord(fe->ev_commit, S1);
             if (ts - fe->last_pub_time >= pub_gate) {
-                st = fe_publish(fe, dst, ts, h_out, cap, n_out);
+                st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                 if (st != LVK_OK) return st;
                 *has_msg = 1;
             }

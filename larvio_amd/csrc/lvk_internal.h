@@ -36,6 +36,9 @@ void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
 struct lvk_frontend;
 lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
 extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts);   // image stage only (internal)
+// the pipelined driver's non-blocking processImage: *slot = ring entry of the feature message (when *has_msg), collected later
+extern "C" lvk_status lvk_frontend_process_async(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu, int* has_msg, int* slot);
+extern "C" lvk_status lvk_frontend_fetch_msg(lvk_frontend* fe, int slot, lvk_feature_obs* h_out, int cap, int* n_out);
 
 struct lvk_pyr_graph;                                     // fe_image.hip: the pyramid build of one pyramid object as a captured hipGraph
 struct lvk_pyramid;
