@@ -1664,16 +1664,30 @@ lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const doub
     return LVK_OK;
 }
 
-static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated);
+// feats == nullptr && fetch != nullptr: the message is collected through fetch() as late as the algorithm allows - after the IMU
+// samples have been integrated and the propagation / augmentation kernels are queued - so that a pipelined driver overlaps that
+// work with the front-end that is still producing the message (the static initializer needs the message first and asks at once).
+typedef lvk_status (*lvk_feats_fn)(void* user, const lvk_feature_obs** feats, int* n_feats);
+static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
+                                   lvk_feats_fn fetch, void* fetch_user);
+static lvk_status ekf_process_guarded(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
+                                      lvk_feats_fn fetch, void* fetch_user);
 
 lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated)
 {
-    if (!e || !n_consumed || !updated || (n_feats > 0 && !feats) || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
+    if (n_feats > 0 && !feats) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
+    return ekf_process_guarded(e, ts, feats, n_feats, imu, n_imu, n_consumed, updated, nullptr, nullptr);
+}
+
+static lvk_status ekf_process_guarded(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
+                                      lvk_feats_fn fetch, void* fetch_user)
+{
+    if (!e || !n_consumed || !updated || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
     *n_consumed = 0; *updated = 0;
     // An update that failed half way (capacity, device error) leaves clone list, feature map and covariance layout out of step with
     // each other: the handle stays failed and says so, instead of computing on with wrong column offsets.
     if (e->failed != LVK_OK) return lvk_set_error(e->ctx, e->failed, "lvk_ekf_process: the filter is in a failed state after an earlier error (%s); destroy and re-create it", e->failed_msg);
-    const lvk_status st = ekf_process_impl(e, ts, feats, n_feats, imu, n_imu, n_consumed, updated);
+    const lvk_status st = ekf_process_impl(e, ts, feats, n_feats, imu, n_imu, n_consumed, updated, fetch, fetch_user);
     if (st != LVK_OK) {
         e->failed = st;
         snprintf(e->failed_msg, sizeof e->failed_msg, "%s", e->ctx->err);
@@ -1682,7 +1696,8 @@ lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, 
     return st;
 }
 
-static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated)
+static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
+                                   lvk_feats_fn fetch, void* fetch_user)
 {
     struct Notify {                                     // every return path reports the consumption exactly once
         lvk_ekf* e; int* n; bool fired = false;
@@ -1697,6 +1712,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     }
     int off = 0;
     if (!e->is_gravity_set) {
+        if (fetch) { lvk_status fs = fetch(fetch_user, &feats, &n_feats); if (fs != LVK_OK) return fs; fetch = nullptr; }
         int erased = 0;
         if (static_try_init(e, ts, feats, n_feats, imu, n_imu, &erased)) {
             e->is_gravity_set = true;
@@ -1717,6 +1733,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
     if (st != LVK_OK) return st;
     TR(TR_PROP);
+    if (fetch) { lvk_status fs = fetch(fetch_user, &feats, &n_feats); if (fs != LVK_OK) return fs; }
     add_observations(e, feats, n_feats);
     TR(TR_ADDOBS);
     TR(TR_AUG);
@@ -1917,10 +1934,18 @@ static void pipe_worker(lvk_vio_pipe* p)
             }
             p->cv_state.notify_all();
         }
-        int used = 0, upd = 0, n_feats = 0;
-        // the message itself is collected HERE, on the filter's thread: the caller's thread queued the frame and went on
-        lvk_status st = lvk_frontend_fetch_msg(p->fe, job.slot, p->wmsg.data(), (int)p->wmsg.size(), &n_feats);
-        if (st == LVK_OK) st = lvk_ekf_process(p->ekf, job.ts, p->wmsg.data(), n_feats, job.view.data(), (int)job.view.size(), &used, &upd);
+        int used = 0, upd = 0;
+        // the message itself is collected on THIS thread (the caller's thread queued the frame and went on), and only when the update
+        // needs it: IMU integration, covariance propagation and clone augmentation run while the front-end is still tracking
+        struct Fetch { lvk_vio_pipe* p; int slot; bool done; } fx{p, job.slot, false};
+        auto fetch = [](void* u, const lvk_feature_obs** f, int* n) -> lvk_status {
+            Fetch* x = (Fetch*)u;
+            lvk_status fs = lvk_frontend_fetch_msg(x->p->fe, x->slot, x->p->wmsg.data(), (int)x->p->wmsg.size(), n);
+            *f = x->p->wmsg.data(); x->done = true;
+            return fs;
+        };
+        lvk_status st = ekf_process_guarded(p->ekf, job.ts, nullptr, 0, job.view.data(), (int)job.view.size(), &used, &upd, fetch, &fx);
+        if (!fx.done) { const lvk_feature_obs* f = nullptr; int n = 0; fetch(&fx, &f, &n); }     // a call that returned early still frees its ring entry
         if (st == LVK_OK && upd && p->on_update) { double s30[30]; lvk_ekf_get_state(p->ekf, s30); p->on_update(p->on_update_user, job.ts, s30); }
         {
             std::lock_guard<std::mutex> lk(p->mu);

@@ -75,10 +75,18 @@ __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict_
     double* beta = diag + NB;                         // NB
     double* Z = beta + NB;                            // NB x NB : Z[j][k] = v_j . v_k (j < k)
     double* T = Z + NB * NB;                          // NB x NB
-    for (int s = wave; s < CH; s += CQ_FWAVES) {
-        const int row = s < R ? cq_row<NB>(g, level, node, s) : g.m;
-        const double* src = A + (size_t)(row < g.m ? row : 0) * g.ld + g.j0;
-        for (int c = lane; c < NB; c += 64) sP[(size_t)s * PLD + c] = (row < g.m && c < nb) ? src[c] : 0.;
+    {   // panel in: CH x NB elements, 16 per thread, every load of a thread issued before its first LDS store (the panel was written by
+        // other workgroups in the previous launch: a dependent load is a microsecond)
+        constexpr int PER = CH * NB / CQ_FTHREADS;
+        double v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + CQ_FTHREADS * u, s_ = e / NB, c = e - s_ * NB;
+            const int row = s_ < R ? cq_row<NB>(g, level, node, s_) : g.m;
+            v[u] = (row < g.m && c < nb) ? A[(size_t)row * g.ld + g.j0 + c] : 0.;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int e = t + CQ_FTHREADS * u, s_ = e / NB, c = e - s_ * NB; sP[(size_t)s_ * PLD + c] = v[u]; }
     }
     for (int e = t; e < NB * NB; e += CQ_FTHREADS) { Z[e] = 0.; T[e] = 0.; }
     if (t < NB) { beta[t] = 0.; diag[t] = 0.; }
@@ -204,7 +212,13 @@ __global__ void __launch_bounds__(CQ_ATHREADS) k_caqr_apply(double* __restrict__
     double* sW = sT + NB * NB;                        // 4 partial W (one per wavefront): 4 x NB x 17, then W in slot 0
     int* srow = (int*)(sW + 4 * NB * 17);             // CH: matrix row of node row s (or -1)
     const double* Vn = Vws + (size_t)node * CH * NB;
-    for (int e = t; e < CH * NB; e += CQ_ATHREADS) { const int s = e / NB, c = e - s * NB; sV[(size_t)s * NBp + c] = s < R ? Vn[e] : 0.; }
+    for (int e0 = t; e0 < CH * NB; e0 += CQ_ATHREADS * 16) {          // V in, 16 loads in flight per thread
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = e0 + CQ_ATHREADS * u; v[u] = (e < CH * NB && e / NB < R) ? Vn[e] : 0.; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = e0 + CQ_ATHREADS * u; if (e < CH * NB) { const int s = e / NB, c = e - s * NB; sV[(size_t)s * NBp + c] = v[u]; } }
+    }
     for (int e = t; e < NB * NB; e += CQ_ATHREADS) sT[e] = Tws[(size_t)node * NB * NB + e];
     for (int s = t; s < CH; s += CQ_ATHREADS) { const int row = s < R ? cq_row<NB>(g, level, node, s) : -1; srow[s] = (row >= 0 && row < g.m) ? row : -1; }
     __syncthreads();
