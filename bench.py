@@ -374,6 +374,31 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
     return out
 
 
+def shard_probe(rank, world, local_rank):
+    """Run `bench.py --backend-only [--sharded]` as a CHILD process per rank (own rendezvous on MASTER_PORT + 1, own RCCL
+    communicator) with a time limit: a failure or a hang of the sharded path cannot take the headline measurement down with it."""
+    import subprocess
+    env = dict(os.environ)
+    env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    env["LVK_BENCH_BIND"] = "0"                           # the parent already bound this process tree to one socket
+    cmd = [sys.executable, os.path.abspath(__file__), "--backend-only", "--gpus", str(world), "--steps", "40", "--warmup", "4"] + (["--sharded"] if world > 1 else [])
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "the sharded-update probe did not finish within 240 s"} if rank == 0 else None
+    if rank != 0:
+        return None
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "probe exited with code %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+
+
 def cpu_model():
     try:
         for l in open("/proc/cpuinfo"):
@@ -479,10 +504,7 @@ def main():
     # justifies it"; the headline value above stays the metric's own configuration.
     probe = None
     if not args.no_shard_probe and args.config == "A" and not args.sequential:
-        try:
-            probe = backend_only(args, rank, world, local_rank, dist, torch, K=40, W=4, sharded=(world > 1))
-        except SystemExit as exc:
-            probe = {"error": str(exc)} if rank == 0 else None
+        probe = shard_probe(rank, world, local_rank)
     if rank == 0:
         win = wl["fcfg"]["patch_size"]
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d

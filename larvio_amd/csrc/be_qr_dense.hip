@@ -153,17 +153,24 @@ __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict_
         }
         __syncthreads();
     }
-    // T (upper triangular): T[k][k] = beta_k ; T[0:k, k] = -beta_k T[0:k, 0:k] Z[0:k, k]   (one wavefront, lane i = row i)
+    // T (upper triangular): T[k][k] = beta_k ; T[0:k, k] = -beta_k T[0:k, 0:k] Z[0:k, k].  One wavefront, lane i keeps row i of T in
+    // registers, Z[j][k] is an LDS broadcast: NB (NB - 1) / 2 independent reads instead of a dependent read per term (the loop form
+    // of this took longer than the whole factorisation)
     if (wave == 0) {
-        for (int k = 0; k < steps; ++k) {
+        double trow[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) trow[j] = 0.;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            double sk = 0.;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) if (j < k) sk += trow[j] * Z[j * NB + k];
             const double bk = beta[k];
-            if (lane < k && bk != 0.) {
-                double s = 0.;
-                for (int j = lane; j < k; ++j) s += T[lane * NB + j] * Z[j * NB + k];
-                T[lane * NB + k] = -bk * s;
-            }
-            if (lane == k) T[k * NB + k] = bk;
-            __builtin_amdgcn_wave_barrier();
+            trow[k] = lane == k ? bk : (lane < k ? -bk * sk : 0.);
+        }
+        if (lane < NB) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) T[lane * NB + j] = trow[j];
         }
     }
     // registers -> staging (the panel after the factorisation: R above the diagonal, the reflectors on and below it)

@@ -294,7 +294,9 @@ __global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ ei
 {
     unsigned best = 0;
     // four pixels per lane-load (16-byte response values, 4-byte mask words): the pass is a pure stream (12 MB at 1080p)
-    const int n4 = n >> 2;
+    // a caller's mask (lvk_good_features) need not be word-aligned: then everything takes the scalar tail below
+    const bool vec = (((size_t)eig & 15) | ((size_t)mask & 3)) == 0;
+    const int n4 = vec ? n >> 2 : 0;
     const float4* e4 = (const float4*)eig; const unsigned* m4 = (const unsigned*)mask;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
         const float4 v = e4[i]; const unsigned mk = mask ? m4[i] : 0xFFFFFFFFu;

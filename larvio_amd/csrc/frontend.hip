@@ -450,8 +450,8 @@ struct lvk_frontend {
     long pub_counter;
     double last_pub_time, curr_img_time, prev_img_time;
     int cur;                   // track set holding prev_pts_ (written by the previous frame)
-    lvk_pyramid* pyr[2];       // [0] = prev, [1] = curr (swapped every frame)
-    uint8_t *ext[2], *blur[2];
+    lvk_pyramid* pyr[3];       // [0] = prev, [1] = curr, [2] = spare (rotated every frame: the image stage of frame k+1 fills its
+    uint8_t *ext[3], *blur[3]; //  buffers on its own stream while frame k's tracking still reads [0] and [1])
     uint8_t* d_img;            // device copy of a host image
     // Host images (the reference's cv::Mat, pageable) are copied by the calling thread into a ring of pinned, device-mapped staging
     // slots; the GPU side is either one asynchronous H2D copy into d_img (default) or, with LVK_FE_ZEROCOPY=1, the first two image
@@ -474,17 +474,20 @@ struct lvk_frontend {
     int msg_next = 0;
     FeDev* dev; FeDev* h_dev;                            // device + pinned host mirror
     CamParams cam;
-    // Side stream side[0] ("new points"): goodFeaturesToTrack after a publish, then the next frame's ORB planes and the LK /
-    // descriptor gate of those points.  The main stream keeps the image pyramid, the old tracks and both commits.  One side
-    // stream only: HIP maps streams onto 4 hardware queues by default, and two streams sharing a queue serialise (measured: a
-    // third front-end stream slowed the filter's stream by 30%).
-    lvk_context* side[1];
+    // Side stream side[0] ("new points"): goodFeaturesToTrack after a publish, then the next frame's LK / descriptor gate of those
+    // points.  The main stream keeps the old tracks and both commits.  With the filter's stream that makes four: HIP maps streams
+    // onto 4 hardware queues by default, and two streams sharing a queue serialise (measured), so there is no fifth.
+    // side[1] ("image"): upload, CLAHE, pyramid + Scharr planes and the ORB planes of a frame.  They depend on nothing but the image,
+    // so with three buffer sets they run ahead of the tracking chain of the previous frame (~55 us per frame off the main chain).
+    lvk_context* side[2];
+    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};   // end of frame f's work on the main / side stream, by parity of f
+    long n_img = 0;                                                                // image stages queued so far
     bool image_done; double image_done_ts;       // lvk_frontend_begin already queued this frame's image stage
     // fork/join events.  Each record or wait is a barrier packet on its stream (~5 us on the frame's chain), so there are as few as
-    // the data flow allows: ev_pyr (pyramid of this frame ready; being recorded on the main stream it also orders everything the
-    // previous frame left there), ev_orb, ev_new (side stream -> main), ev_commit (main -> side), ev_tail (bootstrap only)
+    // the data flow allows: ev_pyr / ev_orb (image stream -> main and side: pyramid / ORB planes of this frame ready), ev_new (side
+    // stream -> main), ev_commit (main -> side), ev_tail (bootstrap only), ev_main / ev_side (end of a frame on either stream)
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
-    lvk_pyr_graph* pyr_graph[2] = {nullptr, nullptr}; lvk_pyramid* pyr_graph_of[2] = {nullptr, nullptr};
+    lvk_pyr_graph* pyr_graph[3] = {nullptr, nullptr, nullptr}; lvk_pyramid* pyr_graph_of[3] = {nullptr, nullptr, nullptr};
     int use_graph = 0;                // LVK_FE_GRAPH=1: steady-state pyramid build as one graph launch per frame
     // HIP-event profiling of stages
     unsigned prof_mask;
@@ -511,7 +514,7 @@ static void prof_collect(lvk_frontend* fe)
 {
     if (fe->pending.empty()) return;
     hipStreamSynchronize(fe->ctx->stream);
-    for (int i = 0; i < 1; ++i) if (fe->side[i]) hipStreamSynchronize(fe->side[i]->stream);
+    for (int i = 0; i < 2; ++i) if (fe->side[i]) hipStreamSynchronize(fe->side[i]->stream);
     for (auto& p : fe->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { fe->prof_ms[p.stage] += ms; fe->prof_n[p.stage] += 1; }
@@ -584,19 +587,19 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     if (!fe) return;
     prof_collect(fe);
     hipStreamSynchronize(fe->ctx->stream);
-    for (int i = 0; i < 1; ++i) if (fe->side[i]) { hipStreamSynchronize(fe->side[i]->stream); lvk_context_destroy(fe->side[i]); }
-    hipEvent_t evs[] = {fe->ev_pyr, fe->ev_orb, fe->ev_new, fe->ev_commit, fe->ev_tail};
+    for (int i = 0; i < 2; ++i) if (fe->side[i]) { hipStreamSynchronize(fe->side[i]->stream); lvk_context_destroy(fe->side[i]); }
+    hipEvent_t evs[] = {fe->ev_pyr, fe->ev_orb, fe->ev_new, fe->ev_commit, fe->ev_tail, fe->ev_main[0], fe->ev_main[1], fe->ev_side[0], fe->ev_side[1]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (hipEvent_t e : fe->ev_free) hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (fe->pyr[i]) lvk_pyramid_destroy(fe->pyr[i]);
         if (fe->ext[i]) hipFree(fe->ext[i]); if (fe->blur[i]) hipFree(fe->blur[i]);
-        set_free(fe->set[i]);
+        if (i < 2) set_free(fe->set[i]);
     }
     void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < 2; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
+    for (int i = 0; i < 3; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
     for (int i = 0; i < 3; ++i) { if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]); if (fe->ev_stage[i]) hipEventDestroy(fe->ev_stage[i]); }
     for (int i = 0; i < LVK_MSG_SLOTS; ++i) if (fe->ev_msg[i]) hipEventDestroy(fe->ev_msg[i]);
     if (fe->h_msg) hipHostFree(fe->h_msg);
@@ -629,9 +632,10 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     const int w = cfg->width, h = cfg->height, cap = fe->cap;
     const size_t esz = (size_t)(w + 64) * (h + 64);
     bool ok = true;
-    for (int i = 0; i < 2 && ok; ++i) {
+    for (int i = 0; i < 3 && ok; ++i) {
         ok = ok && lvk_pyramid_create(ctx, w, h, cfg->patch_size, cfg->pyramid_levels, &fe->pyr[i]) == LVK_OK;
         ok = ok && dalloc(&fe->ext[i], esz) && dalloc(&fe->blur[i], esz);
+        if (i == 2) break;
         TrackSet& s = fe->set[i];
         ok = ok && dalloc(&s.id, cap) && dalloc(&s.pts, cap) && dalloc(&s.ppts, cap) && dalloc(&s.init, cap) && dalloc(&s.life, cap) && dalloc(&s.desc, (size_t)cap * 4);
     }
@@ -655,8 +659,8 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
              hipEventCreateWithFlags(&fe->ev_stage[i], hipEventDisableTiming) == hipSuccess;
         fe->d_stage[i] = (uint8_t*)dp;
     }
-    for (int i = 0; i < 1 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
-    hipEvent_t* evs[] = {&fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_tail};
+    for (int i = 0; i < 2 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
+    hipEvent_t* evs[] = {&fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_tail, &fe->ev_main[0], &fe->ev_main[1], &fe->ev_side[0], &fe->ev_side[1]};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { lvk_frontend_destroy(fe); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_frontend_create: allocation failed"); }
     hipMemsetAsync(fe->dev, 0, sizeof(FeDev), ctx->stream);
@@ -669,7 +673,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
 
 static lvk_status fe_quiesce(lvk_frontend* fe)
 {   // the getters look at buffers the side streams may still be filling
-    for (int i = 0; i < 1; ++i) LVK_HIP(fe->ctx, hipStreamSynchronize(fe->side[i]->stream));
+    for (int i = 0; i < 2; ++i) LVK_HIP(fe->ctx, hipStreamSynchronize(fe->side[i]->stream));
     return LVK_OK;
 }
 static lvk_status fe_read_dev(lvk_frontend* fe)
@@ -754,33 +758,40 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image)
         if (image->stride == c.width) memcpy(hs, image->data, (size_t)c.width * c.height);
         else for (int y = 0; y < c.height; ++y) memcpy(hs + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
         if (fe->zero_copy) d_img = fe->d_stage[slot];
-        else { LVK_HIP(ctx, hipMemcpyAsync(fe->d_img, hs, (size_t)c.width * c.height, hipMemcpyHostToDevice, ctx->stream)); d_img = fe->d_img; }
+        else { LVK_HIP(ctx, hipMemcpyAsync(fe->d_img, hs, (size_t)c.width * c.height, hipMemcpyHostToDevice, fe->side[1]->stream)); d_img = fe->d_img; }
         d_stride = c.width;
     }
     lvk_status st;
-    hipStream_t S1 = ctx->stream;
-    lvk_context* orb_cx = fe->image_state == 3 ? fe->side[0] : ctx;
-    hipStream_t S3 = orb_cx->stream;
+    lvk_context* icx = fe->side[1];
+    hipStream_t S0 = icx->stream;
+    // The buffer set about to be written (frame f) was the spare set of frame f-1 and the "prev" set of frame f-2: its last readers are
+    // frame f-2's tracking chains and the detection queued behind frame f-3 (same side stream, earlier in order).  Waiting for the
+    // ends of frame f-2's two chains is therefore enough, and frame f-1's tracking runs concurrently with this image stage.
+    if (fe->n_img >= 2) {
+        const int par = (int)(fe->n_img & 1);            // parity of f-2
+        hipStreamWaitEvent(S0, fe->ev_main[par], 0); hipStreamWaitEvent(S0, fe->ev_side[par], 0);
+    }
     if (fe->use_graph && fe->image_state == 3 && !((fe->prof_mask >> 0) & 1u)) {
-        int gs = fe->pyr_graph_of[0] == fe->pyr[1] ? 0 : fe->pyr_graph_of[1] == fe->pyr[1] ? 1 : -1;
+        int gs = -1;
+        for (int k = 0; k < 3; ++k) if (fe->pyr_graph_of[k] == fe->pyr[1]) gs = k;
         if (gs < 0) {
-            gs = fe->pyr_graph_of[0] ? 1 : 0;
-            st = lvk_pyramid_graph_capture(ctx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, &fe->pyr_graph[gs]);
-            if (st != LVK_OK) return st;
+            for (int k = 0; k < 3; ++k) if (!fe->pyr_graph_of[k]) { gs = k; break; }
+            st = lvk_pyramid_graph_capture(icx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, &fe->pyr_graph[gs]);
+            if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
             fe->pyr_graph_of[gs] = fe->pyr[1];
         }
-        st = lvk_pyramid_graph_launch(ctx, fe->pyr_graph[gs], d_img, d_stride);
+        st = lvk_pyramid_graph_launch(icx, fe->pyr_graph[gs], d_img, d_stride);
     } else {
-        ProfScope ps(fe, 0);
-        st = c.flag_equalize ? lvk_pyramid_build_clahe(ctx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(ctx, fe->pyr[1], d_img, d_stride);
+        ProfScope ps(fe, 0, S0);
+        st = c.flag_equalize ? lvk_pyramid_build_clahe(icx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(icx, fe->pyr[1], d_img, d_stride);
     }
-    if (st != LVK_OK) return st;
-    hipEventRecord(fe->ev_pyr, S1);
-    if (slot >= 0) { hipEventRecord(fe->ev_stage[slot], S1); fe->stage_busy[slot] = true; }
-    if (S3 != S1) hipStreamWaitEvent(S3, fe->ev_pyr, 0);
-    { ProfScope ps(fe, 1, S3); st = lvk_orb_prepare(orb_cx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
-    if (st != LVK_OK) return orb_cx == ctx ? st : lvk_set_error(ctx, st, "%s", orb_cx->err);
-    hipEventRecord(fe->ev_orb, S3);
+    if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
+    hipEventRecord(fe->ev_pyr, S0);
+    if (slot >= 0) { hipEventRecord(fe->ev_stage[slot], S0); fe->stage_busy[slot] = true; }
+    { ProfScope ps(fe, 1, S0); st = lvk_orb_prepare(icx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
+    if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
+    hipEventRecord(fe->ev_orb, S0);
+    fe->n_img += 1;
     return LVK_OK;
 }
 
@@ -840,6 +851,9 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
     fe->image_done = false;
     if (st != LVK_OK) return st;
     hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
+    hipStreamWaitEvent(S1, fe->ev_pyr, 0); hipStreamWaitEvent(S2, fe->ev_pyr, 0);      // this frame's pyramid comes from the image stream
+    // the side stream reads (new points, their count) and overwrites (wn_*) what the previous frame's commits on the main stream used
+    if (fe->n_img >= 2) hipStreamWaitEvent(S2, fe->ev_main[fe->n_img & 1], 0);
     fe->curr_img_time = ts;
     const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
     const int src = fe->cur, dst = fe->cur ^ 1;
@@ -874,7 +888,6 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
                 curr_valid = true;
                 hipEventRecord(fe->ev_commit, S1);
                 if (ts - fe->last_pub_time >= pub_gate) {
-                    hipStreamWaitEvent(S2, fe->ev_pyr, 0);
                     st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                     if (st != LVK_OK) return st;
                     *has_msg = 1;
@@ -903,9 +916,11 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         }
     }
     if (!curr_valid) LVK_HIP(ctx, hipMemsetAsync(&fe->dev->n_tracks[dst], 0, sizeof(int), ctx->stream));
-    // rotation (:207-216)
-    { lvk_pyramid* p = fe->pyr[0]; fe->pyr[0] = fe->pyr[1]; fe->pyr[1] = p; }
-    { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = p; p = fe->blur[0]; fe->blur[0] = fe->blur[1]; fe->blur[1] = p; }
+    { const int par = (int)((fe->n_img - 1) & 1); hipEventRecord(fe->ev_main[par], S1); hipEventRecord(fe->ev_side[par], S2); }
+    // rotation (:207-216), three-way: curr becomes prev, the spare set becomes the next frame's curr
+    { lvk_pyramid* p = fe->pyr[0]; fe->pyr[0] = fe->pyr[1]; fe->pyr[1] = fe->pyr[2]; fe->pyr[2] = p; }
+    { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = fe->ext[2]; fe->ext[2] = p;
+      p = fe->blur[0]; fe->blur[0] = fe->blur[1]; fe->blur[1] = fe->blur[2]; fe->blur[2] = p; }
     fe->cur = dst;
     fe->prev_img_time = ts;
     if (fe->pending.size() > 4096) prof_collect(fe);

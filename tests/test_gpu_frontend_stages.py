@@ -75,6 +75,22 @@ def test_good_features_identical(gpu_ctx, two_frames, masked):
         assert len(a) > 10
 
 
+def test_good_features_with_an_unaligned_mask(gpu_ctx, two_frames):
+    """A caller's device mask need not be word aligned (k_masked_max reads it as 32-bit words only when it is)."""
+    import ctypes as C
+    from larvio_amd._lib import lib, _p
+    g, o = _pyr_pair(gpu_ctx, two_frames[0], clahe=True)
+    mask = np.full(two_frames[0].shape, 255, np.uint8)
+    mask[100:300, 200:500] = 0
+    buf = gpu_ctx.to_device(np.concatenate([np.zeros(1, np.uint8), mask.ravel()]))
+    d_out = gpu_ctx.alloc(8 * 200); d_n = gpu_ctx.alloc(4)
+    gpu_ctx.check(lib().lvk_good_features(gpu_ctx.h, g.h_, C.c_void_p(buf.ptr + 1), 200, 0.01, 20.0, _p(d_out), 200, _p(d_n)))
+    n = int(gpu_ctx.to_host(d_n, np.int32, (1,))[0])
+    a = gpu_ctx.to_host(d_out, np.float32, (200, 2))[:n]
+    b = o.good_features(200, 0.01, 20.0, mask)
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
 def _corners(o, n=200):
     return o.good_features(n, 0.01, 20.0)
 
