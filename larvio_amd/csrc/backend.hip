@@ -305,7 +305,8 @@ static void cal_phi(const lvk_ekf* e, double* Phi, double dt, const double* gyro
     double aa[3]; for (int i = 0; i < 3; ++i) aa[i] = dt * (gyro_old[i] + gyro[i]) / 2 + dt * dt * cr[i] / 12;
     double Ah[9]; skew3(aa, Ah);
     double C[9]; quat_to_rot(e->s_old.q, C);
-    for (int i = 0; i < LEG * LEG; ++i) Phi[i] = (i % (LEG + 1) == 0) ? 1.0 : 0.0;
+    memset(Phi, 0, sizeof(double) * LEG * LEG);
+    for (int i = 0; i < LEG; ++i) Phi[i * (LEG + 1)] = 1.0;
     const ImuS* so = e->if_fej ? &e->s_fej_old : &e->s_old;
     const ImuS* sn = e->if_fej ? &e->s_fej_now : &e->s;
     const double *vk = so->v, *pk = so->p, *vk1 = sn->v, *pk1 = sn->p;
@@ -366,7 +367,8 @@ static void cal_phi_calib(const lvk_ekf* e, double* Phi, double dt, const double
     double aa[3]; for (int i = 0; i < 3; ++i) aa[i] = dt * (gyro_old[i] + gyro[i]) / 2 + dt * dt * cr[i] / 12;
     double Ah[9]; skew3(aa, Ah);
     double C[9]; quat_to_rot(e->s_old.q, C);
-    for (int i = 0; i < L * L; ++i) Phi[i] = (i % (L + 1) == 0) ? 1.0 : 0.0;
+    memset(Phi, 0, sizeof(double) * L * L);
+    for (int i = 0; i < L; ++i) Phi[i * (L + 1)] = 1.0;
     double TA[9], TAMa[9]; m3_mul(e->Tg, e->As, TA); m3_mul(TA, e->Ma, TAMa);
     const ImuS* so = e->if_fej ? &e->s_fej_old : &e->s_old;
     const ImuS* sn = e->if_fej ? &e->s_fej_now : &e->s;
@@ -451,10 +453,24 @@ static void compose_transition(lvk_ekf* e, const double* Phi, double dtime)
     for (int k = 0; k < 15; ++k) nzc[k] = k;
     if (CALIB) for (int k = 22; k < 46; ++k) nzc[15 + k - 22] = k;
     constexpr int nnz = NNZ;
-    double PG[B * 12], Q[B * B];
-    for (int i = 0; i < A; ++i) for (int j = 0; j < 12; ++j) { double s = 0; for (int k = 0; k < B; ++k) s += Phi[i * L + k] * G[k * 12 + j]; PG[i * 12 + j] = s; }
+    // Every sum below runs over its summation index in ascending order, one element at a time, exactly as the plain triple loops
+    // would; the loops are only nested so that the innermost one walks independent output elements (it vectorises, the dependent
+    // scalar reductions it replaces did not).
+    double PG[B * 12], PGT[12 * B], Q[B * B], PhiT[NNZ * 12];
+    for (int i = 0; i < A; ++i) {
+        double* pg = PG + i * 12;
+        for (int j = 0; j < 12; ++j) pg[j] = 0;
+        for (int k = 0; k < B; ++k) { const double a = Phi[i * L + k]; const double* g = G + k * 12; for (int j = 0; j < 12; ++j) pg[j] += a * g[j]; }
+    }
     for (int i = A; i < B; ++i) for (int j = 0; j < 12; ++j) PG[i * 12 + j] = G[i * 12 + j];
-    for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) { double s = 0; for (int k = 0; k < 12; ++k) s += PG[i * 12 + k] * e->Qc[k] * PG[j * 12 + k]; Q[i * B + j] = s * dtime; }
+    for (int i = 0; i < B; ++i) for (int k = 0; k < 12; ++k) PGT[k * B + i] = PG[i * 12 + k];
+    for (int i = 0; i < B; ++i) {
+        double* qr = Q + i * B;
+        for (int j = 0; j < B; ++j) qr[j] = 0;
+        for (int k = 0; k < 12; ++k) { const double a = PG[i * 12 + k] * e->Qc[k]; const double* g = PGT + k * B; for (int j = 0; j < B; ++j) qr[j] += a * g[j]; }
+        for (int j = 0; j < B; ++j) qr[j] *= dtime;
+    }
+    for (int q = 0; q < nnz; ++q) for (int j = 0; j < A; ++j) PhiT[q * 12 + j] = Phi[j * L + nzc[q]];
     if (!e->have_prop) {
         memcpy(e->Phi_tot, Phi, sizeof(double) * L * L);
         memset(e->Q_tot, 0, sizeof(double) * L * L);
@@ -478,9 +494,10 @@ static void compose_transition(lvk_ekf* e, const double* Phi, double dtime)
         memcpy(e->Q_tot, T, sizeof(double) * A * L);
         for (int i = 0; i < L; ++i) {
             double u[A];
-            const double* t = e->Q_tot + i * L;
-            for (int j = 0; j < A; ++j) { double s = 0; for (int q = 0; q < nnz; ++q) { const int k = nzc[q]; s += t[k] * Phi[j * L + k]; } u[j] = s; }
-            for (int j = 0; j < A; ++j) e->Q_tot[i * L + j] = u[j];
+            double* t = e->Q_tot + i * L;
+            for (int j = 0; j < A; ++j) u[j] = 0;
+            for (int q = 0; q < nnz; ++q) { const double a = t[nzc[q]]; const double* ph = PhiT + q * 12; for (int j = 0; j < A; ++j) u[j] += a * ph[j]; }
+            for (int j = 0; j < A; ++j) t[j] = u[j];
         }
         for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * L + j] += Q[i * B + j];
     }
@@ -1646,7 +1663,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     if (c.estimate_td) P0[(size_t)21 * e->ld + 21] = 4e-6;
     if (c.calib_imu_instrinsic) for (int i = 22; i < 46; ++i) P0[(size_t)i * e->ld + i] = 1e-4;      // :183-186
     if (hipMemcpy(e->dP[0], P0.data(), sizeof(double) * P0.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(e->dP[1], 0, sizeof(double) * P0.size()) != hipSuccess) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "covariance upload failed"); }
+        hipMemsetAsync(e->dP[1], 0, sizeof(double) * P0.size(), ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "covariance upload failed"); }
     e->N = LEG; e->cur = 0;
     *out = e;
     return LVK_OK;
@@ -1722,6 +1739,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
         } else return LVK_OK;
     }
     g_tr.start();
+    const double td_before = e->td;
     *n_consumed = off + batch_imu_count(e, ts + e->td, imu + off, n_imu - off);
     notify.fire();                                      // a pipelined driver may start the next frame's front-end now
     const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
@@ -1753,6 +1771,24 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
         e->prof_free.push_back(pe.a); e->prof_free.push_back(pe.b);
     }
     e->prof_pending.clear();
+    {   // LVK_MSG_HASH=<file>: one line per processed message (time stamp, size, FNV-1a of its bytes, IMU samples used + their hash, td
+        // before, state after).  Debugging aid: the message is only COPIED here (a few us); hashing and the file are left to exit.
+        struct Rec { double ts, td, st[16]; int n, used, N, rows; std::vector<unsigned char> msg, imu; };
+        struct Log { std::vector<Rec> recs; const char* path; ~Log() {
+            if (!path) return; FILE* f = fopen(path, "a"); if (!f) return;
+            auto fnv = [](const std::vector<unsigned char>& b) { unsigned long long h = 1469598103934665603ull; for (unsigned char c : b) { h ^= c; h *= 1099511628211ull; } return h; };
+            for (auto& r : recs) { fprintf(f, "%.6f n %d msg %016llx imu %d %016llx td %.12g N %d rows %d state", r.ts, r.n, fnv(r.msg), r.used, fnv(r.imu), r.td, r.N, r.rows);
+                                   for (double v : r.st) fprintf(f, " %.17g", v); fprintf(f, "\n"); }
+            fclose(f); } };
+        static Log lg{{}, getenv("LVK_MSG_HASH")};
+        if (lg.path) {
+            Rec r; r.ts = ts; r.td = td_before; r.n = n_feats; r.used = used; r.N = e->N; r.rows = (int)e->counters[2];
+            r.msg.assign((const unsigned char*)feats, (const unsigned char*)feats + sizeof(lvk_feature_obs) * (size_t)n_feats);
+            r.imu.assign((const unsigned char*)(imu + off), (const unsigned char*)(imu + off) + sizeof(lvk_imu) * (size_t)used);
+            memcpy(r.st, e->s.q, 32); memcpy(r.st + 4, e->s.v, 24); memcpy(r.st + 7, e->s.p, 24); memcpy(r.st + 10, e->s.bg, 24); memcpy(r.st + 13, e->s.ba, 24);
+            lg.recs.push_back(std::move(r));
+        }
+    }
     TR(TR_FINAL);
     g_tr.n++;
     *updated = 1;
@@ -2032,7 +2068,8 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
         // With the worker idle the filter is quiescent: the erase count (timestamps, state time and td only) can be taken here
         // and the next frame need not wait for the worker to wake up.
         lvk_ekf* e = p->ekf;
-        if (p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
+        static const bool no_caller_precount = [] { const char* v = getenv("LVK_PIPE_NO_CALLER_PRECOUNT"); return v && atoi(v); }();   // debugging aid
+        if (!no_caller_precount && p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
             p->head += (size_t)batch_imu_count(e, ts + e->td, job.view.data(), (int)job.view.size());
             job.precounted = true; p->ev(4);
         } else { p->unknown_consume += 1; p->ev(3); }

@@ -432,7 +432,9 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
     CH_TICK(5);
     __syncthreads();
     CH_TICK(6);
-    if (blockIdx.x == 0) for (int e = t; e < nb * nb; e += 256) { int a = e / nb, b = e - a * nb; if (b <= a) S[(size_t)(j0 + a) * lds_ + j0 + b] = Ld[a][b]; }
+    // The diagonal block of the factor is NOT written back to S: every workgroup of this launch reads A_pp from there at its start, and
+    // a workgroup that is dispatched late (other streams keep CUs busy) would pick up L_pp instead - which is what happened, rarely, in
+    // the pipelined driver at configs[4] until round 2.  Nothing downstream reads the diagonal blocks (the solves use L_pp^-1 from LDS).
     // ---- triangular solves as products with L11^-1
     d4 o0 = {0., 0., 0., 0.}, o1 = {0., 0., 0., 0.};
     if (s_role) {                                                                  // X = C Y^T : X[r][c] = sum_k C[r][k] Y[c][k]
@@ -468,15 +470,220 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
 #endif
 }
 
-// S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary
-static void launch_chol_solve(hipStream_t s, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
+// ------------------------------------------------------------------------- fused Cholesky + solve, m <= 160: ONE launch
+// The per-panel launches above spend ~19 us per 32 columns, of which only ~8 us is the dependent pivot chain of the diagonal block;
+// the rest is launch latency, first-touch trips to the memory side and the left-looking re-read of S.  Here workgroup 0 keeps the whole
+// lower triangle of S in LDS (32x32 blocks) and factors it right-looking: wavefront 0 factors + inverts diagonal block p+1 while the
+// other three wavefronts finish the trailing update of panel p.  After every panel it publishes L[:, p] and L_pp^-1 to global memory and
+// raises a flag (agent-scope release); workgroups 1.. own 16 columns of B = [HP | r] per wavefront, keep their W rows in LDS, and
+// trail the factorisation by one panel: B_p -= L[p, 0:p] W[0:p] while the diagonal block is still being factored, then
+// W_p = L_pp^-1 B_p as soon as the flag arrives.  Workgroup 0 is dispatched first (workgroups of a grid are dispatched in order) and
+// never waits for anybody, so the spinning solvers cannot starve it.
+#define CF_MAXB 5                                   // m <= 160
+#define CF_LD (CP_NB + 1)
+#define CF_WLD 17
+typedef double cf_blk[CP_NB][CF_LD];
+__device__ __forceinline__ int cf_idx(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
+// C[tile tr,tc of block Cb] -= A[rows of tile tr] . Bm[rows of tile tc]^T over K = 32
+__device__ __forceinline__ void cf_tile_sub(cf_blk& Cb, const cf_blk& A, const cf_blk& Bm, int tr, int tc, int i16, int kk)
 {
+    d4 acc = {0., 0., 0., 0.};
+#pragma unroll
+    for (int k0 = 0; k0 < CP_NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * tr + i16][k0 + kk], Bm[16 * tc + i16][k0 + kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cb[16 * tr + kk + 4 * r][16 * tc + i16] -= acc[r];
+}
+__device__ __forceinline__ void cf_wait(const int* flag, int target, int lane)
+{
+    if (lane == 0) while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
+                                                   double* __restrict__ Yg, int* __restrict__ flag, int base, int* __restrict__ info)
+{
+    extern __shared__ __attribute__((aligned(32))) double cf_smem[];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
+    const int nblk = (m + CP_NB - 1) / CP_NB;
+    const d4 zero4 = {0., 0., 0., 0.};
+    if (blockIdx.x == 0) {
+        // ===================================================================== factor role
+        cf_blk* Sb = (cf_blk*)cf_smem;                                   // lower blocks, cf_idx(bi, bj)
+        cf_blk& Yi = *(cf_blk*)(cf_smem + (size_t)(CF_MAXB * (CF_MAXB + 1) / 2) * CP_NB * CF_LD);
+        if (t == 0) info[0] = 0;
+        {   // whole lower triangle: one 32-byte load per thread and block, all in flight
+            const int row = t >> 3, c4 = (t & 7) * 4;
+            d4 v[CF_MAXB * (CF_MAXB + 1) / 2];
+#pragma unroll
+            for (int bi = 0; bi < CF_MAXB; ++bi)
+#pragma unroll
+                for (int bj = 0; bj <= bi; ++bj) {
+                    const int gr = 32 * bi + row, gc = 32 * bj + c4;
+                    v[cf_idx(bi, bj)] = (bi < nblk && gr < m && gc + 3 < lds_) ? *(const d4*)(S + (size_t)gr * lds_ + gc) : zero4;
+                }
+#pragma unroll
+            for (int bi = 0; bi < CF_MAXB; ++bi)
+#pragma unroll
+                for (int bj = 0; bj <= bi; ++bj) {
+                    if (bi >= nblk) continue;
+                    const int gr = 32 * bi + row;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gc = 32 * bj + c4 + q;
+                        Sb[cf_idx(bi, bj)][row][c4 + q] = (gr < m && gc < m) ? v[cf_idx(bi, bj)][q] : (gr == gc ? 1.0 : 0.0);   // identity padding
+                    }
+                }
+        }
+        __syncthreads();
+        for (int p = 0; p < nblk; ++p) {
+            cf_blk& D = Sb[cf_idx(p, p)];
+            const int nb = min(CP_NB, m - 32 * p);
+            if (wave == 0) chol32_inv_wave(D, Yi, nb, lane, info, 32 * p, true);
+            else if (p > 0) {
+                // the rest of panel p-1's trailing update (block columns p+1..), in the shadow of the factorisation
+                int u = 0;
+                for (int bi = p + 1; bi < nblk; ++bi)
+                    for (int bj = p + 1; bj <= bi; ++bj)
+                        for (int tt = 0; tt < 4; ++tt, ++u)
+                            if (u % 3 == wave - 1) cf_tile_sub(Sb[cf_idx(bi, bj)], Sb[cf_idx(bi, p - 1)], Sb[cf_idx(bj, p - 1)], tt >> 1, tt & 1, i16, kk);
+            }
+            __syncthreads();
+            {   // publish Y_pp = L_pp^-1 (the diagonal blocks of L themselves are not stored: nothing reads them)
+                double* yg = Yg + (size_t)p * CP_NB * CP_NB;
+                for (int e = t; e < CP_NB * CP_NB; e += 256) {
+                    const int a = e >> 5, b = e & 31;
+                    yg[e] = Yi[a][b];
+                }
+            }
+            // L21: X = A Y^T for the blocks below the diagonal, 16 rows x 32 columns per unit
+            for (int u = wave; u < 2 * (nblk - p - 1); u += 4) {
+                const int bi = p + 1 + (u >> 1), tr = u & 1;
+                cf_blk& A = Sb[cf_idx(bi, p)];
+                d4 o0 = {0., 0., 0., 0.}, o1 = {0., 0., 0., 0.};
+#pragma unroll
+                for (int k0 = 0; k0 < CP_NB; k0 += 4) {
+                    const double a = A[16 * tr + i16][k0 + kk];
+                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yi[i16][k0 + kk], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yi[16 + i16][k0 + kk], o1, 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lr = 16 * tr + kk + 4 * r, gr = 32 * bi + lr;
+                    A[lr][i16] = o0[r]; A[lr][16 + i16] = o1[r];
+                    if (gr < m) { S[(size_t)gr * lds_ + 32 * p + i16] = o0[r]; S[(size_t)gr * lds_ + 32 * p + 16 + i16] = o1[r]; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(flag, base + p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // block column p+1 brought up to date with panel p (the next diagonal block and everything below it)
+            if (p + 1 < nblk) {
+                for (int u = wave; u < 4 * (nblk - p - 1); u += 4) {
+                    const int bi = p + 1 + (u >> 2), tt = u & 3;
+                    cf_tile_sub(Sb[cf_idx(bi, p + 1)], Sb[cf_idx(bi, p)], Sb[cf_idx(p + 1, p)], tt >> 1, tt & 1, i16, kk);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ========================================================================= solver role: 16 columns of B per wavefront
+    double (*Wl)[CF_WLD] = (double (*)[CF_WLD])(cf_smem + (size_t)wave * (CF_MAXB * CP_NB + CP_NB) * CF_WLD);    // W rows of the finished panels
+    double (*Cs)[CF_WLD] = Wl + CF_MAXB * CP_NB;                                                              // staging of the current panel
+    const int col = (blockIdx.x - 1) * 64 + wave * 16 + i16;
+    const bool colok = col < nbcols;
+    if ((blockIdx.x - 1) * 64 + wave * 16 >= nbcols) return;
+    double own[CF_MAXB][2][4];
+#pragma unroll
+    for (int q = 0; q < CF_MAXB; ++q)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 32 * q + 16 * tl + kk + 4 * r;
+                own[q][tl][r] = (q < nblk && row < m && colok) ? B[(size_t)row * ldb + col] : 0.;
+            }
+#pragma unroll
+    for (int p = 0; p < CF_MAXB; ++p) {
+        if (p >= nblk) break;
+        d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
+        if (p > 0) {
+            // B_p -= L[p, 0:32p] W[0:32p]; the flag of panel p-1 (waited for below) covers every block of this row of L
+            const int r0 = 32 * p + i16, r1 = r0 + 16;
+            d4 a0[2 * (CF_MAXB - 1)], a1[2 * (CF_MAXB - 1)];
+#pragma unroll
+            for (int u = 0; u < 2 * (CF_MAXB - 1); ++u) {
+                a0[u] = (u < 2 * p && r0 < m) ? *(const d4*)(S + (size_t)r0 * lds_ + 16 * u + 4 * kk) : zero4;
+                a1[u] = (u < 2 * p && r1 < m) ? *(const d4*)(S + (size_t)r1 * lds_ + 16 * u + 4 * kk) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * (CF_MAXB - 1); ++u) {
+                if (u >= 2 * p) break;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double b = Wl[16 * u + 4 * kk + q][i16];
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u][q], b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u][q], b, c1, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Cs[kk + 4 * r][i16] = own[p][0][r] - c0[r]; Cs[16 + kk + 4 * r][i16] = own[p][1][r] - c1[r]; }
+        cf_wait(flag, base + p + 1, lane);
+        const double* yg = Yg + (size_t)p * CP_NB * CP_NB;
+        d4 y0[2], y1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { y0[u] = *(const d4*)(yg + (size_t)i16 * CP_NB + 16 * u + 4 * kk); y1[u] = *(const d4*)(yg + (size_t)(16 + i16) * CP_NB + 16 * u + 4 * kk); }
+        __builtin_amdgcn_wave_barrier();
+        d4 o0 = {0., 0., 0., 0.}, o1 = {0., 0., 0., 0.};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double b = Cs[16 * u + 4 * kk + q][i16];
+                o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[u][q], b, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[u][q], b, o1, 0, 0, 0);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l0 = kk + 4 * r, l1 = 16 + l0, g0 = 32 * p + l0, g1 = 32 * p + l1;
+            Wl[g0][i16] = o0[r]; Wl[g1][i16] = o1[r];
+            if (colok && g0 < m) B[(size_t)g0 * ldb + col] = o0[r];
+            if (colok && g1 < m) B[(size_t)g1 * ldb + col] = o1[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary
+static lvk_status launch_chol_solve(lvk_context* ctx, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
+{
+    hipStream_t s = ctx->stream;
+    if (ctx->chol_mode == 0) { const char* v = getenv("LVK_CHOL_FUSED"); ctx->chol_mode = (v && atoi(v) == 0) ? 2 : 1; }
+    if (ctx->chol_mode == 1 && m <= CF_MAXB * CP_NB) {
+        const size_t ybytes = sizeof(double) * CF_MAXB * CP_NB * CP_NB;
+        const bool fresh = ctx->scratch_bytes[12] < ybytes + 64;
+        char* ws = (char*)lvk_ctx_scratch(ctx, 12, ybytes + 64);
+        if (!ws) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
+        int* flag = (int*)(ws + ybytes);
+        if (fresh || ctx->chol_epoch > (1 << 27)) { LVK_HIP(ctx, hipMemsetAsync(flag, 0, 64, s)); ctx->chol_epoch = 0; }
+        const int base = 8 * ctx->chol_epoch++;
+        const size_t lds_f = sizeof(double) * (size_t)(CF_MAXB * (CF_MAXB + 1) / 2 + 1) * CP_NB * CF_LD;
+        const size_t lds_s = sizeof(double) * (size_t)4 * (CF_MAXB * CP_NB + CP_NB) * CF_WLD;
+        const size_t shm = lds_f > lds_s ? lds_f : lds_s;
+        LVK_LDS_OPTIN(ctx, 8, k_chol_fused, shm);
+        hipLaunchKernelGGL(k_chol_fused, dim3(1 + (nbcols + 63) / 64), dim3(256), shm, s, S, lds_, m, B, ldb, nbcols, (double*)ws, flag, base, info);
+        return LVK_OK;
+    }
     for (int j0 = 0; j0 < m; j0 += CP_NB) {
         const int nb = (m - j0) < CP_NB ? (m - j0) : CP_NB;
         const int rest = m - j0 - nb;
         const int n_sblocks = (rest + 63) / 64, n_bblocks = (nbcols + 63) / 64;
         hipLaunchKernelGGL(k_chol_left, dim3(n_sblocks + n_bblocks), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0, n_sblocks, info);
     }
+    return LVK_OK;
 }
 
 // ------------------------------------------------------------------------- host drivers (internal + C ABI)
@@ -492,7 +699,7 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
     launch_dgemm<false, false>(s, m, n, n, H, ldh, P, ldp, ws.B, ws.ldb, 1.0, 0.0, 0.0, GemmRider{r, n, nullptr, 0, nullptr});   // [HP | r]
     if (ws.ev_b) hipEventRecord(ws.ev_b, s);
     launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
-    launch_chol_solve(s, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info);                                    // S = L L^T ; W = L^-1 [HP | r]
+    { lvk_status cs = launch_chol_solve(ctx, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info); if (cs != LVK_OK) return cs; }                                    // S = L L^T ; W = L^-1 [HP | r]
     // W^T [W | w]: columns 0..n-1 update P (P -= W^T W), column n is dx = W^T w
     launch_dgemm<true, false>(s, n, n + 1, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0, GemmRider{nullptr, 0, dx, n, ws.dx_host});
     LVK_LAUNCH_CHECK(ctx);

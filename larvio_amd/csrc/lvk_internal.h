@@ -9,7 +9,7 @@
 #define LVK_MAX_LEVELS 8
 #define LVK_ORB_BORDER 32
 
-#define LVK_SCRATCH_SLOTS 12
+#define LVK_SCRATCH_SLOTS 13
 struct lvk_context {
     int device;
     hipStream_t stream;
@@ -22,7 +22,10 @@ struct lvk_context {
     // dynamic-LDS opt-ins (hipFuncAttributeMaxDynamicSharedMemorySize) already made through THIS context: function attributes are
     // per device, so the cache lives here and not in a process-wide static (slots: 0 k_cov_propagate, 1 k_feature_rows<false>,
     // 2 k_gftt_select, 3 k_qr_panel)
-    size_t lds_optin[8];
+    size_t lds_optin[12];
+    // fused Cholesky + solve (be_linalg.hip, k_chol_fused): the factor workgroup hands panels to the solver workgroups through a flag
+    // that only ever grows; chol_epoch numbers the launches, chol_ws (scratch slot 12) holds the diagonal-block inverses and the flag
+    int chol_epoch; int chol_mode;      // chol_mode: 0 = not decided yet, 1 = fused, 2 = one launch per panel (LVK_CHOL_FUSED=0)
 };
 // opt in to `bytes` of dynamic LDS for `fn` if this context has not already asked for at least that much
 #define LVK_LDS_OPTIN(ctx, slot, fn, bytes)                                                                             \

@@ -52,6 +52,45 @@ def test_orb_mosaic_and_blur_bit_exact(gpu_ctx, two_frames):
     assert np.array_equal(gb, ob)
 
 
+def _big_image(w, h, seed=3):
+    """Smooth structure + noise at a given size (no renderer needed): exercises every histogram bin and saturating blends."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = 110 + 70 * np.sin(x / 37.0) * np.cos(y / 23.0) + 40 * np.sin((x + 2 * y) / 101.0) + rng.normal(0, 12, (h, w))
+    img[h // 3:h // 3 + 40, :] = 255; img[:, w // 2:w // 2 + 25] = 0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (1280, 720), (1916, 1076), (1001, 777)])
+def test_image_stage_at_large_sizes(gpu_ctx, size):
+    """configs[4] resolution: the CLAHE histogram of a tile is split over several workgroups (global merge, last arrival finishes),
+    the mosaic blur takes its word path when the stride allows; sizes that do not divide into the 8x8 tile grid / are not multiples
+    of four take the byte paths.  Everything bit-exact against the oracle, twice in a row (the merge buffers must return to zero)."""
+    from oracle import lvo
+    from larvio_amd import ops
+    w, h = size
+    img = _big_image(w, h)
+    ref = lvo.clahe(img)
+    for _ in range(2):
+        assert np.array_equal(ops.clahe(gpu_ctx, img), ref)
+    g = ops.Pyramid(gpu_ctx, w, h, 21, 3)
+    o = lvo.LkPyramid(ref, 21, 3)
+    for rep in range(2):
+        g.build(img, clahe=True)
+        for l in range(g.n_levels):
+            assert np.array_equal(g.image(l, padded=True), o.image(l, padded=True)), (rep, l)
+            assert np.array_equal(g.deriv(l, padded=True), o.deriv(l, padded=True)), (rep, l)
+    ge, gb = g.orb_prepare()
+    oe, ob = o.orb_prepare()
+    assert np.array_equal(ge, oe)
+    assert np.array_equal(gb, ob)
+    a, b = g.min_eigen_map(), o.min_eigen_map()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    mask = np.full((h, w), 255, np.uint8); mask[h // 4:h // 2, w // 5:w // 2] = 0
+    ca, cb = g.good_features(500, 0.01, 20.0, mask), o.good_features(500, 0.01, 20.0, mask)
+    assert ca.shape == cb.shape and np.array_equal(ca, cb)
+
+
 def test_min_eigen_map_bit_exact(gpu_ctx, two_frames):
     g, o = _pyr_pair(gpu_ctx, two_frames[0], clahe=True)
     a, b = g.min_eigen_map(), o.min_eigen_map()
