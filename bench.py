@@ -73,18 +73,12 @@ class Run:
         from larvio_amd.vio import VioDriver, VioPipeline
         self.wl, self.seq, self.ts, self.imu_all, self.sequential = wl, seq, ts, imu_all, sequential
         self.ctx = larvio_amd.Context(local_rank, stream=torch_stream)
-        # the filter gets its own context (= its own HIP stream): its update overlaps the next frames' front-end
-        self.ctx_be = self.ctx if sequential else larvio_amd.Context(local_rank)
-        order = os.environ.get("LVK_BENCH_CREATE_ORDER", "fe")       # debugging aid: allocation order / padding between the two halves
-        if order != "fe":
-            self.be = larvio_amd.LarVio(wl["bcfg"], self.ctx_be)
-            assert self.be.initialize()
-            self._pad = self.ctx.alloc(256 << 20) if order == "pad" else None
         self.fe = larvio_amd.ImageProcessor(wl["fcfg"], self.ctx)
         assert self.fe.initialize()
-        if order == "fe":
-            self.be = larvio_amd.LarVio(wl["bcfg"], self.ctx_be)
-            assert self.be.initialize()
+        # the filter gets its own context (= its own HIP stream): its update overlaps the next frames' front-end
+        self.ctx_be = self.ctx if sequential else larvio_amd.Context(local_rank)
+        self.be = larvio_amd.LarVio(wl["bcfg"], self.ctx_be)
+        assert self.be.initialize()
         self.shard = None
         if shard is not None:                            # (rank, world, dist): RCCL communicator for THIS filter's context
             from larvio_amd import sharding

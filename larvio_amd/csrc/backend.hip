@@ -2068,8 +2068,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
         // With the worker idle the filter is quiescent: the erase count (timestamps, state time and td only) can be taken here
         // and the next frame need not wait for the worker to wake up.
         lvk_ekf* e = p->ekf;
-        static const bool no_caller_precount = [] { const char* v = getenv("LVK_PIPE_NO_CALLER_PRECOUNT"); return v && atoi(v); }();   // debugging aid
-        if (!no_caller_precount && p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
+        if (p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
             p->head += (size_t)batch_imu_count(e, ts + e->td, job.view.data(), (int)job.view.size());
             job.precounted = true; p->ev(4);
         } else { p->unknown_consume += 1; p->ev(3); }

@@ -771,8 +771,6 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image)
         const int par = (int)(fe->n_img & 1);            // parity of f-2
         hipStreamWaitEvent(S0, fe->ev_main[par], 0); hipStreamWaitEvent(S0, fe->ev_side[par], 0);
     }
-    static const int dbg_dep = [] { const char* v = getenv("LVK_FE_DEBUG_DEP"); return v ? atoi(v) : 0; }();      // diagnostics
-    if ((dbg_dep & 1) && fe->n_img >= 1) { const int par = (int)((fe->n_img - 1) & 1); hipStreamWaitEvent(S0, fe->ev_main[par], 0); hipStreamWaitEvent(S0, fe->ev_side[par], 0); }
     if (fe->use_graph && fe->image_state == 3 && !((fe->prof_mask >> 0) & 1u)) {
         int gs = -1;
         for (int k = 0; k < 3; ++k) if (fe->pyr_graph_of[k] == fe->pyr[1]) gs = k;
@@ -926,8 +924,6 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
     fe->cur = dst;
     fe->prev_img_time = ts;
     if (fe->pending.size() > 4096) prof_collect(fe);
-    { static const int dbg_dep = [] { const char* v = getenv("LVK_FE_DEBUG_DEP"); return v ? atoi(v) : 0; }();
-      if (dbg_dep & 2) { hipStreamSynchronize(S1); hipStreamSynchronize(S2); hipStreamSynchronize(fe->side[1]->stream); } }
     return LVK_OK;
 }
 
