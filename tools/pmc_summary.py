@@ -2,7 +2,8 @@
 """Per-kernel average of one rocprofv3 --pmc counter (csv output) -> CSV on stdout.
 usage: tools/pmc_summary.py gpurun_out/pmc_x/runc/*_counter_collection.csv FETCH_SIZE > profiles/rNN_pmc_fetch_size.csv
 FETCH_SIZE is reported by rocprofv3 in KiB-ish units of 1 KB per count / 64 B requests; on gfx950 it under-reports wide
-coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) - the corrected column doubles it."""
+coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) - the corrected column doubles it.  WRITE_SIZE needs no such factor
+(profiles/README.md, calibration): its last column is the plain byte count."""
 import collections
 import csv
 import sys
@@ -16,6 +17,7 @@ for r in rows:
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     agg[k][0] += 1
     agg[k][1] += float(r["Counter_Value"])
-print(f"kernel,launches,avg_{name}_kb,avg_bytes_corrected_x2")
+fac = 2 if name == "FETCH_SIZE" else 1
+print(f"kernel,launches,avg_{name}_kb," + ("avg_bytes_corrected_x2" if fac == 2 else "avg_bytes"))
 for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{k},{n},{v / n:.2f},{v / n * 1024 * 2:.0f}")
+    print(f"{k},{n},{v / n:.2f},{v / n * 1024 * fac:.0f}")
