@@ -1345,7 +1345,8 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
     bool clones_uploaded = false;
     for (auto& kv : e->map) {
         Feature& f = kv.second;
-        std::vector<long long> inv;
+        struct { long long v[2]; int n = 0; void push_back(long long x) { v[n++] = x; } bool empty() const { return n == 0; } size_t size() const { return (size_t)n; }
+                 const long long* data() const { return v; } const long long* begin() const { return v; } const long long* end() const { return v + n; } } inv;   // nrm <= 2: no heap traffic per feature
         for (int k = 0; k < nrm; ++k) if (f.find(rm[k]) >= 0) inv.push_back(rm[k]);
         if (inv.empty()) continue;
         const bool anchor_involved = std::find(inv.begin(), inv.end(), f.id_anchor) != inv.end();
@@ -1373,7 +1374,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
                 f.id_anchor = new_id;
             }
             if (!e->if_zupt && !f.ekf_feature && inv.size() > 1) {
-                Use u; u.f = &f; u.inv = inv;
+                Use u; u.f = &f; u.inv.assign(inv.begin(), inv.end());
                 if (!f.is_initialized) {
                     const bool tracked = f.find(e->imu_id) >= 0;
                     u.motion = feat_check_motion(e, f, tracked);

@@ -9,6 +9,7 @@
 // matrices are <= ~2 MB and the update is latency-, not bandwidth-bound at N ~ 232).
 // All matrices are ROW-MAJOR with a leading dimension in doubles.
 #include "lvk_internal.h"
+#include "lvk_wave.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -156,45 +157,68 @@ __global__ void __launch_bounds__(256) k_cov_reanchor(double* __restrict__ P, in
 
 // delayed initialisation of new in-state features (larvio.cpp:1821-1854), 1-D: HH = diag(H2)^-1 H1 (nn x n);
 // rows/cols n..n+nn-1 of P:  P_new,old = -HH P ; P_new,new = HH P HH^T + sigma2 / H2^2 (diag).  tmp: nn x n scratch.
-// step 1: tmp[j][b] = -(HH P)[j][b], written to the new rows and columns of P.  grid (ceil(n/256), nn)
+// All three pieces are dot products of length n (~200) behind a fresh P: every wavefront walks k with its lanes' loads in flight
+// and finishes with a DPP reduction, instead of one thread per output walking k alone (20-30 us each, three launches).
+// step 1: tmp[j][b] = -(HH P)[j][b], written to the new rows and columns of P; the extra workgroup column (blockIdx.x == gridDim.x - 1)
+// computes dx_new = -HH dx + H2^-1 r1.  grid (ceil(n/64) + 1, nn), 256 threads: wavefront w takes k = w, w+4, ...
 __global__ void __launch_bounds__(256) k_cov_append_rows(double* __restrict__ P, int ld, int n, int nn, const double* __restrict__ H1, int ldh,
-                                                        const double* __restrict__ H2, double* __restrict__ tmp)
+                                                        const double* __restrict__ H2, double* __restrict__ tmp,
+                                                        const double* __restrict__ r1, const double* __restrict__ dx, double* __restrict__ dx_new)
 {
-    extern __shared__ double hh[];     // row j of HH
-    const int j = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ double hh[];     // row j of HH (n), then 4 x 64 partial sums
+    double* part = hh + n;
+    const int j = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const double inv = 1.0 / H2[j];
-    for (int k = threadIdx.x; k < n; k += 256) hh[k] = H1[(size_t)j * ldh + k] * inv;
+    for (int k = t; k < n; k += 256) hh[k] = H1[(size_t)j * ldh + k] * inv;
     __syncthreads();
-    if (b >= n) return;
+    if (blockIdx.x == gridDim.x - 1) {                       // dx_new[j]
+        double s = 0.;
+        for (int k = t; k < n; k += 256) s += hh[k] * dx[k];
+        s = wave_sum_f64(s);
+        if (lane == 0) part[wave] = s;
+        __syncthreads();
+        if (t == 0) dx_new[j] = -(part[0] + part[1] + part[2] + part[3]) + r1[j] * inv;
+        return;
+    }
+    const int b = blockIdx.x * 64 + lane;
     double s = 0.;
-    for (int k = 0; k < n; ++k) s += hh[k] * P[(size_t)k * ld + b];
-    tmp[(size_t)j * n + b] = -s;
-    P[(size_t)(n + j) * ld + b] = -s; P[(size_t)b * ld + n + j] = -s;
+    if (b < n) {
+        int k = wave;
+        for (; k + 12 < n; k += 16) {                        // four loads in flight per lane
+            const double p0 = P[(size_t)k * ld + b], p1 = P[(size_t)(k + 4) * ld + b], p2 = P[(size_t)(k + 8) * ld + b], p3 = P[(size_t)(k + 12) * ld + b];
+            s += hh[k] * p0; s += hh[k + 4] * p1; s += hh[k + 8] * p2; s += hh[k + 12] * p3;
+        }
+        for (; k < n; k += 4) s += hh[k] * P[(size_t)k * ld + b];
+    }
+    part[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0 && b < n) {
+        const double v = -(((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]);
+        tmp[(size_t)j * n + b] = v;
+        P[(size_t)(n + j) * ld + b] = v; P[(size_t)b * ld + n + j] = v;
+    }
 }
-// step 2: P_new,new = HH P HH^T + sigma2 / H2^2 (symmetrised).  one workgroup, nn <= 64
+// step 2: P_new,new = HH P HH^T + sigma2 / H2^2 (symmetrised).  one workgroup; wavefront per (j, l <= j) pair, lanes over k
 __global__ void __launch_bounds__(256) k_cov_append_corner(double* __restrict__ P, int ld, int n, int nn, const double* __restrict__ H1, int ldh,
                                                           const double* __restrict__ H2, double sigma2, const double* __restrict__ tmp)
 {
-    const int t = threadIdx.x;
-    for (int e = t; e < nn * nn; e += 256) {
-        int j = e / nn, l = e - j * nn;
-        if (l > j) continue;
-        double s1 = 0., s2 = 0.;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int npair = nn * (nn + 1) / 2;
+    for (int e = wave; e < npair; e += 4) {
+        int j = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((j + 1) * (j + 2) / 2 <= e) ++j;
+        while (j * (j + 1) / 2 > e) --j;
+        const int l = e - j * (j + 1) / 2;
         const double il = 1.0 / H2[l], ij = 1.0 / H2[j];
-        for (int k = 0; k < n; ++k) { s1 += tmp[(size_t)j * n + k] * (H1[(size_t)l * ldh + k] * il); s2 += tmp[(size_t)l * n + k] * (H1[(size_t)j * ldh + k] * ij); }
-        const double dg = (j == l) ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0;
-        const double v = ((-s1 + dg) + (-s2 + dg)) / 2.0;
-        P[(size_t)(n + j) * ld + n + l] = v; P[(size_t)(n + l) * ld + n + j] = v;
+        double s1 = 0., s2 = 0.;
+        for (int k = lane; k < n; k += 64) { s1 += tmp[(size_t)j * n + k] * (H1[(size_t)l * ldh + k] * il); s2 += tmp[(size_t)l * n + k] * (H1[(size_t)j * ldh + k] * ij); }
+        s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+        if (lane == 0) {
+            const double dg = (j == l) ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0;
+            const double v = ((-s1 + dg) + (-s2 + dg)) / 2.0;
+            P[(size_t)(n + j) * ld + n + l] = v; P[(size_t)(n + l) * ld + n + j] = v;
+        }
     }
-}
-__global__ void k_dx_new(const double* __restrict__ H1, int ldh, const double* __restrict__ H2, const double* __restrict__ r1, const double* __restrict__ dx,
-                         int n, int nn, double* __restrict__ dx_new)
-{   // dx_new = -HH dx_leg + H2^-1 r1
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nn) return;
-    double s = 0.;
-    for (int k = 0; k < n; ++k) s += (H1[(size_t)j * ldh + k] * (1.0 / H2[j])) * dx[k];
-    dx_new[j] = -s + r1[j] / H2[j];
 }
 
 
@@ -731,8 +755,7 @@ lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, i
                                    const double* dx, double sigma2, double* tmp, double* dx_new)
 {
     if (nn <= 0) return LVK_OK;
-    hipLaunchKernelGGL(k_dx_new, dim3((nn + 63) / 64), dim3(64), 0, ctx->stream, H1, ldh, H2, r1, dx, n, nn, dx_new);
-    hipLaunchKernelGGL(k_cov_append_rows, dim3((n + 255) / 256, nn), dim3(256), sizeof(double) * (size_t)n, ctx->stream, P, ld, n, nn, H1, ldh, H2, tmp);
+    hipLaunchKernelGGL(k_cov_append_rows, dim3((n + 63) / 64 + 1, nn), dim3(256), sizeof(double) * ((size_t)n + 256), ctx->stream, P, ld, n, nn, H1, ldh, H2, tmp, r1, dx, dx_new);
     hipLaunchKernelGGL(k_cov_append_corner, dim3(1), dim3(256), 0, ctx->stream, P, ld, n, nn, H1, ldh, H2, sigma2, (const double*)tmp);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
