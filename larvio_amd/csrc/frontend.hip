@@ -457,7 +457,7 @@ struct lvk_frontend {
     // slots; the GPU side is either one asynchronous H2D copy into d_img (default) or, with LVK_FE_ZEROCOPY=1, the first two image
     // kernels reading the slot in place over PCIe.  The caller's buffer is free as soon as the call returns (as in the reference).
     uint8_t* h_stage[3] = {nullptr, nullptr, nullptr}; uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_stage[3] = {nullptr, nullptr, nullptr}; bool stage_busy[3] = {false, false, false};
+
     int stage_next = 0; int zero_copy = 0;
     TrackSet set[2];
     lvk_pt2f *w_curr, *wn_curr, *new_pts;
@@ -483,6 +483,7 @@ struct lvk_frontend {
     hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};   // end of frame f's work on the main / side stream, by parity of f
     long n_img = 0;                                                                // image stages queued so far
     bool image_done; double image_done_ts;       // lvk_frontend_begin already queued this frame's image stage
+    bool pyr_event = true;                       // this frame's image stage recorded ev_pyr (blocking API); false: ev_orb stands for the whole stage
     // fork/join events.  Each record or wait is a barrier packet on its stream (~5 us on the frame's chain), so there are as few as
     // the data flow allows: ev_pyr / ev_orb (image stream -> main and side: pyramid / ORB planes of this frame ready), ev_new (side
     // stream -> main), ev_commit (main -> side), ev_tail (bootstrap only), ev_main / ev_side (end of a frame on either stream)
@@ -540,7 +541,7 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
     const int W = fe->cfg.width, Hh = fe->cfg.height;
     { ProfScope ps(fe, 2, s);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
-    hipStreamWaitEvent(s, fe->ev_orb, 0);                         // the ORB planes of this frame may come from the side stream
+    if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes follow it on the image stream
     ProfScope ps(fe, 4, s);
     hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
                        (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new);
@@ -600,7 +601,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 3; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
-    for (int i = 0; i < 3; ++i) { if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]); if (fe->ev_stage[i]) hipEventDestroy(fe->ev_stage[i]); }
+    for (int i = 0; i < 3; ++i) if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]);
     for (int i = 0; i < LVK_MSG_SLOTS; ++i) if (fe->ev_msg[i]) hipEventDestroy(fe->ev_msg[i]);
     if (fe->h_msg) hipHostFree(fe->h_msg);
     if (fe->h_nmsg) hipHostFree(fe->h_nmsg);
@@ -655,8 +656,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     { const char* z = getenv("LVK_FE_ZEROCOPY"); fe->zero_copy = z && atoi(z) != 0; }
     for (int i = 0; i < 3 && ok; ++i) {
         void* dp = nullptr;
-        ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess && hipHostGetDevicePointer(&dp, fe->h_stage[i], 0) == hipSuccess && dp &&
-             hipEventCreateWithFlags(&fe->ev_stage[i], hipEventDisableTiming) == hipSuccess;
+        ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess && hipHostGetDevicePointer(&dp, fe->h_stage[i], 0) == hipSuccess && dp;
         fe->d_stage[i] = (uint8_t*)dp;
     }
     for (int i = 0; i < 2 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
@@ -743,7 +743,7 @@ static lvk_status fe_check_image(lvk_frontend* fe, const lvk_image* img)
     return LVK_OK;
 }
 
-static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image)
+static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool early)
 {
     lvk_context* ctx = fe->ctx;
     const lvk_fe_config& c = fe->cfg;
@@ -753,7 +753,9 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image)
     int slot = -1;
     if (!image->is_device) {
         slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
-        if (fe->stage_busy[slot]) { LVK_HIP(ctx, hipEventSynchronize(fe->ev_stage[slot])); fe->stage_busy[slot] = false; }   // three frames back: long done
+        // The slot was last used three frames back.  Its upload precedes frame f-2's image stage on the image stream, which the
+        // main stream waited for before it recorded the end of frame f-2: that event covers it (and has long fired) - no per-slot event.
+        if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_main[fe->n_img & 1]));
         uint8_t* hs = fe->h_stage[slot];
         if (image->stride == c.width) memcpy(hs, image->data, (size_t)c.width * c.height);
         else for (int y = 0; y < c.height; ++y) memcpy(hs + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
@@ -786,8 +788,10 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image)
         st = c.flag_equalize ? lvk_pyramid_build_clahe(icx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(icx, fe->pyr[1], d_img, d_stride);
     }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
-    hipEventRecord(fe->ev_pyr, S0);
-    if (slot >= 0) { hipEventRecord(fe->ev_stage[slot], S0); fe->stage_busy[slot] = true; }
+    // queued ahead of the frame's tracking (pipelined driver): the ORB planes are done long before anybody asks, one event (ev_orb)
+    // stands for the whole stage; queued together with the tracking (blocking API): LK may start as soon as the pyramid exists
+    if (!early) hipEventRecord(fe->ev_pyr, S0);
+    fe->pyr_event = !early;
     { ProfScope ps(fe, 1, S0); st = lvk_orb_prepare(icx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
     hipEventRecord(fe->ev_orb, S0);
@@ -799,7 +803,7 @@ lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts)
 {
     if (!fe || !img) return LVK_ERR_ARG;
     if (!fe->b_first_img) return fe_check_image(fe, img);   // the first-image gate needs the IMU buffer (:134-142): nothing to do early
-    lvk_status st = fe_image_stage(fe, img);
+    lvk_status st = fe_image_stage(fe, img, true);
     if (st != LVK_OK) return st;
     fe->image_done = true; fe->image_done_ts = ts;
     return LVK_OK;
@@ -847,11 +851,14 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         else return fe_check_image(fe, img);
     }
     lvk_status st = LVK_OK;
-    if (!(fe->image_done && fe->image_done_ts == ts)) st = fe_image_stage(fe, img);
+    if (!(fe->image_done && fe->image_done_ts == ts)) st = fe_image_stage(fe, img, false);
     fe->image_done = false;
     if (st != LVK_OK) return st;
     hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
-    hipStreamWaitEvent(S1, fe->ev_pyr, 0); hipStreamWaitEvent(S2, fe->ev_pyr, 0);      // this frame's pyramid comes from the image stream
+    {   // this frame's pyramid (and ORB planes) come from the image stream
+        hipEvent_t ready = fe->pyr_event ? fe->ev_pyr : fe->ev_orb;
+        hipStreamWaitEvent(S1, ready, 0); hipStreamWaitEvent(S2, ready, 0);
+    }
     // the side stream reads (new points, their count) and overwrites (wn_*) what the previous frame's commits on the main stream used
     if (fe->n_img >= 2) hipStreamWaitEvent(S2, fe->ev_main[fe->n_img & 1], 0);
     fe->curr_img_time = ts;
