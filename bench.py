@@ -376,7 +376,7 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
 
 def shard_probe(rank, world, local_rank):
     """Run `bench.py --backend-only [--sharded]` as a CHILD process per rank (own rendezvous on MASTER_PORT + 1, own RCCL
-    communicator) with a time limit: a failure or a hang of the sharded path cannot take the headline measurement down with it."""
+    communicator) with a 150 s time limit: a failure or a hang of the sharded path cannot take the headline measurement down with it."""
     import subprocess
     env = dict(os.environ)
     env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
@@ -385,9 +385,9 @@ def shard_probe(rank, world, local_rank):
     env["LVK_BENCH_BIND"] = "0"                           # the parent already bound this process tree to one socket
     cmd = [sys.executable, os.path.abspath(__file__), "--backend-only", "--gpus", str(world), "--steps", "40", "--warmup", "4"] + (["--sharded"] if world > 1 else [])
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
     except subprocess.TimeoutExpired:
-        return {"error": "the sharded-update probe did not finish within 240 s"} if rank == 0 else None
+        return {"error": "the sharded-update probe did not finish within 150 s"} if rank == 0 else None
     if rank != 0:
         return None
     for line in reversed(r.stdout.strip().splitlines()):

@@ -63,13 +63,23 @@ struct Feature {
     double inv_depth = 0, obs_anchor[3] = {0, 0, 0};
     bool in_state = false, ekf_feature = false;
     int total_obs = 0;
-    int find(long long sid) const { for (size_t i = 0; i < obs.size(); ++i) if (obs[i].sid == sid) return (int)i; return -1; }
+    int find(long long sid) const
+    {   // obs is sorted by state id and almost every query asks for the newest one or two: look there first, then bisect
+        const int n = (int)obs.size();
+        if (n == 0) return -1;
+        if (obs[n - 1].sid == sid) return n - 1;
+        if (obs[n - 1].sid < sid) return -1;
+        if (n >= 2 && obs[n - 2].sid == sid) return n - 2;
+        int lo = 0, hi = n - 2;                                   // first index with sid >= wanted, in [0, n-2)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (obs[mid].sid < sid) lo = mid + 1; else hi = mid; }
+        return (lo < n && obs[lo].sid == sid) ? lo : -1;
+    }
     void set(long long sid, double u, double v, double uv, double vv)
     {
         int i = find(sid);
         if (i < 0) {
             Obs o; o.sid = sid;
-            auto it = obs.begin(); while (it != obs.end() && it->sid < sid) ++it;
+            auto it = obs.end(); while (it != obs.begin() && (it - 1)->sid > sid) --it;     // appended at the end in the normal case
             it = obs.insert(it, o); i = (int)(it - obs.begin());
         }
         obs[i].z[0] = u; obs[i].z[1] = v; obs[i].zv[0] = uv; obs[i].zv[1] = vv;
@@ -595,11 +605,21 @@ static void add_observations(lvk_ekf* e, const lvk_feature_obs* f, int n)
     int tracked = 0;
     const double dt = e->imu_dt;
     const int prev_rank = clone_rank(e, sid - 1);
+    // The message lists the tracks in table order, i.e. by ascending id: a cursor walks the (ordered) map alongside - one step per
+    // feature instead of a tree descent; an id out of order falls back to find().
+    auto cur = e->map.begin();
+    long long last_id = -1;
     for (int i = 0; i < n; ++i) {
         const long long id = (long long)f[i].id;
-        auto it = e->map.find(id);
+        decltype(cur) it;
+        if (id > last_id) { while (cur != e->map.end() && cur->first < id) ++cur; it = (cur != e->map.end() && cur->first == id) ? cur : e->map.end(); }
+        else it = e->map.find(id);
+        const bool ordered = id > last_id;
+        last_id = ordered ? id : last_id;
         if (it == e->map.end()) {
-            Feature& ft = e->map[id]; ft.id = id;
+            auto ins = ordered ? e->map.emplace_hint(cur, id, Feature()) : e->map.emplace(id, Feature()).first;
+            if (ordered) cur = ins;
+            Feature& ft = ins->second; ft.id = id;
             ft.set(sid, f[i].u + f[i].u_vel * dt, f[i].v + f[i].v_vel * dt, f[i].u_vel, f[i].v_vel);
             ft.total_obs++;
             if (!(f[i].u_init == -1 && f[i].v_init == -1) && prev_rank >= 0) {
