@@ -3,6 +3,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r2t; mkdir -p $O
+( time timeout 1800 python -m pytest tests -m gpu -q --durations=6 ) > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log
 timeout 900 python bench.py > $O/bench_a.json 2> $O/bench_a.err; echo "rc $?" >> $O/bench_a.err
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "rc $?" >> $O/bench_driver.err
 timeout 900 python bench.py --sequential --no-cpu-baseline > $O/bench_a_seq.json 2> $O/bench_a_seq.err
@@ -23,4 +25,4 @@ for c in $(find $O/pmc_c5 -name "*counter_collection.csv" | head -1); do python 
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_c5 -- python bench.py --config 5 --steps 100 --warmup 10 --no-cpu-baseline --no-device-pass > $O/pmcw_c5.log 2>&1
 for c in $(find $O/pmcw_c5 -name "*counter_collection.csv" | head -1); do python tools/pmc_summary.py $c WRITE_SIZE > $O/c5_pmc_write_size.csv; done
 find $O -name "*.db" -size +20M -delete; find $O -name "*kernel_trace.csv" -size +10M -delete; find $O -name "*counter_collection.csv" -size +20M -delete
-for f in a driver a_seq c3 c4 c5 be; do cut -c1-160 $O/bench_$f.json; done
+tail -3 $O/pytest.log; tail -2 $O/smoke.log; for f in a driver a_seq c3 c4 c5 be; do cut -c1-160 $O/bench_$f.json; done
