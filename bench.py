@@ -200,9 +200,7 @@ def timed(run, frames, d_frames, W, K, dist, torch):
         dist.barrier()
     elapsed = time.perf_counter() - t_begin
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(dist, torch, elapsed)
     prof = run.fe.profile_read()
     pl1, it1 = run.fe.lk_stats()
     c1 = run.be.counters()
@@ -347,9 +345,7 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
         dist.barrier()
     elapsed = time.perf_counter() - t_begin
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(dist, torch, elapsed)
     c1 = be.counters(); s1 = be.shard_stats()
     streams = 1 if args.sharded else world
     if rank == 0:
@@ -359,7 +355,7 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
                "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "configs[4] depth, back-end only: simulated feature messages (no images), max_features %d, sw_size %d, 1d-hybrid"
                                       % (sim["cfg"]["max_features"], sim["cfg"]["sw_size"]),
-                          "parallelism": ("sharded x%d: contiguous feature ranges per rank, one RCCL all-gather of the compressed blocks + gate results per update" % world)
+                          "rehearsal_one_gpu_gloo": bool(os.environ.get("LVK_BENCH_ONE_GPU")), "parallelism": ("sharded x%d: contiguous feature ranges per rank, one RCCL all-gather of the compressed blocks + gate results per update" % world)
                                          if args.sharded else "replicas x%d" % world,
                           "state_dim": be.dim, "clones": len(be.clones()),
                           "timed_region": {k: c1[k] - c0[k] for k in ("hybrid", "msckf", "gated_in", "gated_out", "triangulations")},
@@ -383,6 +379,9 @@ def shard_probe(rank, world, local_rank):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
     env["LVK_BENCH_BIND"] = "0"                           # the parent already bound this process tree to one socket
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")]:
+        del env[k]                                       # the children rendezvous among themselves: with torchrun's TORCHELASTIC_USE_AGENT_STORE
+                                                         # rank 0 would wait for an agent-hosted store on the new port instead of creating it
     cmd = [sys.executable, os.path.abspath(__file__), "--backend-only", "--gpus", str(world), "--steps", "40", "--warmup", "4"] + (["--sharded"] if world > 1 else [])
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
@@ -397,6 +396,28 @@ def shard_probe(rank, world, local_rank):
             except ValueError:
                 break
     return {"error": "probe exited with code %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+
+
+def dist_setup(torch, world, local_rank):
+    """One process per GPU over RCCL (backend "nccl").  LVK_BENCH_BACKEND=gloo + LVK_BENCH_ONE_GPU=1 is a rehearsal of the multi-rank
+    control flow on a single-GPU box (every rank on device 0, collectives through the host): not a measurement mode."""
+    dev = 0 if os.environ.get("LVK_BENCH_ONE_GPU") else local_rank
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        if os.environ.get("LVK_BENCH_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    return dist, dev
+
+
+def max_over_ranks(dist, torch, elapsed):
+    t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def cpu_model():
@@ -436,12 +457,7 @@ def main():
         import torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
-        torch.cuda.set_device(local_rank)
-        dist = None
-        if world > 1:
-            import torch.distributed as dist_
-            dist = dist_
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist, local_rank = dist_setup(torch, world, local_rank)
         out = backend_only(args, rank, world, local_rank, dist, torch)
         if out is not None:
             print(json.dumps(out))
@@ -471,12 +487,7 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist, local_rank = dist_setup(torch, world, local_rank)
     shard = (rank, world, dist) if (args.sharded and world > 1) else None
 
     stream = torch.cuda.current_stream()
@@ -564,7 +575,7 @@ def main():
                           "pre_roll_frames": n_pre, "sw_size": sw, "clones": n_clones, "state_dim": state_dim, "backend": counters,
                           "timed_region": {"messages": int(mm.sum()), "hybrid_updates": m["n_hybrid"], "msckf_pruning_updates": m["n_msckf"]},
                           "live_tracks": live,
-                          "parallelism": ("sharded x%d: contiguous feature ranges per rank, RCCL all-gather of the packed R factors" % world) if args.sharded
+                          "rehearsal_one_gpu_gloo": bool(os.environ.get("LVK_BENCH_ONE_GPU")), "parallelism": ("sharded x%d: contiguous feature ranges per rank, RCCL all-gather of the packed R factors" % world) if args.sharded
                                          else "replicas x%d" % world},
                "roofline": roofline,
                # the one GEMM-shaped contraction of the path (P H^T as H P, FP64 MFMA 16x16x4): utilisation against the dense FP64 matrix peak

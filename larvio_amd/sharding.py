@@ -61,6 +61,10 @@ def unique_id():
 def make_shard(ctx, rank, world, dist):
     """RCCL transport for the filter on `ctx`: rank 0 draws the unique id, torch.distributed carries it to the others."""
     import torch
+    if dist.get_backend() != "nccl":                      # rehearsal on one GPU (bench.py LVK_BENCH_BACKEND=gloo): RCCL refuses two ranks per device
+        hx = HostExchange(ctx, dist, rank, world)
+        hx.close = lambda: None
+        return hx
     if rank == 0:
         uid = torch.tensor(list(unique_id()), dtype=torch.uint8)
     else:
