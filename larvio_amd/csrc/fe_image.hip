@@ -33,10 +33,12 @@ void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes)
 
 // =========================================================================== CLAHE
 // Histogram of one tile in LDS (one sub-histogram per wave), clip + redistribute, inclusive scan -> LUT.  [cv::CLAHE CLAHE_CalcLut_Body]
-// A tile is covered by S workgroups (S = 1 for small tiles: 752x480 has 5,640 pixels per tile; S = 4 at 1920x1080, where one
-// workgroup per tile meant 64 workgroups x 32,400 pixels on a 256-CU part): each counts a band of rows, adds its 256 counts to the
-// tile's histogram in global memory, and the workgroup that arrives last (ticket counter) finishes the tile and leaves histogram and
-// ticket zeroed for the next frame.  Counts are integers, so the result does not depend on the order of arrival.
+// One workgroup per tile; when the tiles divide the image (every supported camera) the pixels come in as 32-bit words, four per load:
+// 33 -> 13 us at 1920x1080, where a tile has 32,400 pixels.  The kernel can also cover a tile with S workgroups (each counts a band of
+// rows, adds its 256 counts to the tile's histogram in global memory, the last arrival - ticket counter - finishes the tile and leaves
+// histogram and ticket zeroed; integer counts, so the order of arrival does not matter), but that was measured SLOWER at every S
+// (S = 2: 25 us, 4: 34 us, 8: 57 us at 1080p): the device-scope atomics and fences of the merge cost more than the idle CUs.  S stays 1;
+// LVK_CLAHE_S overrides it for experiments.
 __global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int sstride,
                                                   int tw, int th, int tiles_x, int clip, float lut_scale,
                                                   uint8_t* __restrict__ lut, int S, int* __restrict__ ghist, int* __restrict__ tickets, int vec4)
@@ -133,10 +135,12 @@ static void clahe_launch_shape(const uint8_t* src, int w, int h, int sstride, in
 {
     static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();   // A/B switch
     if (legacy) { *S = 1; *vec4 = 0; return; }
-    const int px = tw * th;
-    int s = (px + 8191) / 8192; if (s > 8) s = 8; if (s < 1) s = 1; if (s > th) s = th;
-    *S = s;
+    *S = 1;
     *vec4 = (tiles_x * tw == w && tiles_y * th == h && (tw & 3) == 0 && (sstride & 3) == 0 && ((size_t)src & 3) == 0) ? 1 : 0;
+    static const int force_s = [] { const char* v = getenv("LVK_CLAHE_S"); return v ? atoi(v) : 0; }();          // experiments
+    static const int force_v = [] { const char* v = getenv("LVK_CLAHE_VEC"); return v ? atoi(v) : -1; }();
+    if (force_s > 0) *S = force_s > th ? th : force_s;
+    if (force_v == 0) *vec4 = 0;
 }
 
 // CLAHE bilinear LUT blend at image coordinate (x,y)  [CLAHE_Interpolation_Body]

@@ -63,9 +63,10 @@ def _big_image(w, h, seed=3):
 
 @pytest.mark.parametrize("size", [(1920, 1080), (1280, 720), (1916, 1076), (1001, 777)])
 def test_image_stage_at_large_sizes(gpu_ctx, size):
-    """configs[4] resolution: the CLAHE histogram of a tile is split over several workgroups (global merge, last arrival finishes),
-    the mosaic blur takes its word path when the stride allows; sizes that do not divide into the 8x8 tile grid / are not multiples
-    of four take the byte paths.  Everything bit-exact against the oracle, twice in a row (the merge buffers must return to zero)."""
+    """configs[4] resolution: the CLAHE histogram reads four pixels per load when the tiles divide the image, the mosaic blur takes its
+    word path when the stride allows; sizes that do not divide into the 8x8 tile grid / are not multiples of four take the byte paths.
+    Everything bit-exact against the oracle, twice in a row; the (disabled by default) several-workgroups-per-tile variant of the CLAHE
+    kernel is run through the same check by test_clahe_split_variant."""
     from oracle import lvo
     from larvio_amd import ops
     w, h = size
@@ -89,6 +90,17 @@ def test_image_stage_at_large_sizes(gpu_ctx, size):
     mask = np.full((h, w), 255, np.uint8); mask[h // 4:h // 2, w // 5:w // 2] = 0
     ca, cb = g.good_features(500, 0.01, 20.0, mask), o.good_features(500, 0.01, 20.0, mask)
     assert ca.shape == cb.shape and np.array_equal(ca, cb)
+
+
+def test_clahe_split_variant():
+    """LVK_CLAHE_S=4: tiles covered by four workgroups, global merge, last arrival finishes and re-zeroes (kept for experiments)."""
+    import os, subprocess, sys
+    code = ("import numpy as np, larvio_amd; from larvio_amd import ops; from oracle import lvo; from tests.test_gpu_frontend_stages import _big_image\n"
+            "ctx = larvio_amd.Context(0); img = _big_image(1920, 1080); ref = lvo.clahe(img)\n"
+            "assert all(np.array_equal(ops.clahe(ctx, img), ref) for _ in range(3)); print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LVK_CLAHE_S="4", PYTHONPATH=root), capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-800:]
 
 
 def test_min_eigen_map_bit_exact(gpu_ctx, two_frames):
