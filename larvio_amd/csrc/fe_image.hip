@@ -186,6 +186,28 @@ __global__ void k_level0_pad(const uint8_t* __restrict__ src, int w, int h, int 
     dst[(size_t)ey * dstride + ex] = o;
 }
 
+// Level 0 of the LK pyramid AND the ORB mosaic (k_orb_ext) in one pass over the larger of the two frames: both are the same equalised
+// image under two border rules, and the mosaic's rule goes through the pyramid's own frame (non-isolated copyMakeBorder: reflect about the
+// frame-grown image, then the frame pixel is the image pixel at its reflect-101 coordinate).  Requires pad <= LVK_ORB_BORDER (always:
+// patch sizes above the ORB border are refused), so the pyramid's padded domain lies inside the mosaic's.  One launch and one read of the
+// camera image instead of two on the frame's image stage.
+template <bool EQ>
+__global__ void k_level0_pad_ext(const uint8_t* __restrict__ src, int w, int h, int sstride,
+                                 const uint8_t* __restrict__ lut, int tiles_x, int tiles_y, float inv_tw, float inv_th,
+                                 uint8_t* __restrict__ dst /*padded base*/, int pad, int dstride, uint8_t* __restrict__ ext, int estride)
+{
+    const int B = LVK_ORB_BORDER;
+    const int ex = blockIdx.x * blockDim.x + threadIdx.x, ey = blockIdx.y;
+    if (ex >= w + 2 * B) return;
+    const int gx = d_reflect101(ex - B + pad, w + 2 * pad) - pad, gy = d_reflect101(ey - B + pad, h + 2 * pad) - pad;     // grow == pad
+    const int x = d_reflect101(gx, w), y = d_reflect101(gy, h);
+    const int v = src[(size_t)y * sstride + x];
+    const uint8_t o = EQ ? clahe_pixel(lut, tiles_x, tiles_y, inv_tw, inv_th, x, y, v) : (uint8_t)v;
+    ext[(size_t)ey * estride + ex] = o;
+    const int px = ex - B + pad, py = ey - B + pad;            // inside the pyramid's frame gx == ex - B: the same value
+    if (px >= 0 && px < w + 2 * pad && py >= 0 && py < h + 2 * pad) dst[(size_t)py * dstride + px] = o;
+}
+
 // =========================================================================== pyrDown (+ frame) and Scharr planes
 // [cv::pyrDown u8]  dst(x,y) = (sum_{5x5} w_i w_j src(2x-2+i, 2y-2+j) + 128) >> 8, w = [1 4 6 4 1].
 // The source's own reflect-101 frame (pad >= 2) supplies the border taps, so no index math.
@@ -843,6 +865,58 @@ lvk_status lvk_pyramid_build_clahe(lvk_context* ctx, lvk_pyramid* p, const uint8
 }
 
 int lvk_pyramid_levels(const lvk_pyramid* p) { return p ? p->n_levels : 0; }
+
+}  // extern "C"
+
+// internal (frontend.hip): lvk_pyramid_build[_clahe] + the mosaic half of lvk_orb_prepare for one frame, level 0 and the ORB mosaic
+// written by ONE kernel; same bytes as the public entry points produce.  The blur follows with lvk_orb_blur_only.
+lvk_status lvk_pyramid_build_with_orb(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride, int clahe, double clip_limit,
+                                      int tiles_x, int tiles_y, uint8_t* d_ext, int* mosaic_done)
+{
+    if (!ctx || !p || !d_img || !d_ext || !mosaic_done) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_pyramid_build_with_orb: bad argument");
+    const int w = p->w[0], h = p->h[0], B = LVK_ORB_BORDER, es = w + 2 * B, eh = h + 2 * B;
+    static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();
+    *mosaic_done = 0;
+    if (p->pad > B || legacy)                                     // the caller follows up with lvk_orb_prepare
+        return clahe ? lvk_pyramid_build_clahe(ctx, p, d_img, stride, clip_limit, tiles_x, tiles_y) : lvk_pyramid_build(ctx, p, d_img, stride);
+    *mosaic_done = 1;
+    float inv_tw = 1.f, inv_th = 1.f;
+    if (clahe) {
+        if (tiles_x <= 0 || tiles_y <= 0) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_pyramid_build_with_orb: bad tile grid");
+        if (tiles_x * tiles_y * 256 > p->clahe_lut_cap) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "too many CLAHE tiles");
+        int ew = w, eh2 = h;
+        if (!(w % tiles_x == 0 && h % tiles_y == 0)) { ew = w + (tiles_x - (w % tiles_x)); eh2 = h + (tiles_y - (h % tiles_y)); }
+        const int tw = ew / tiles_x, th = eh2 / tiles_y, total = tw * th;
+        const float lut_scale = (float)(255) / total;
+        int clip = 0;
+        if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
+        int S, vec4; clahe_launch_shape(d_img, w, h, stride, tw, th, tiles_x, tiles_y, &S, &vec4);
+        int* ghist = (int*)(p->clahe_lut + p->clahe_lut_cap);
+        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y * S), dim3(256), 0, ctx->stream, d_img, w, h, stride, tw, th, tiles_x, clip, lut_scale, p->clahe_lut,
+                           S, ghist, ghist + p->clahe_lut_cap, vec4);
+        inv_tw = 1.0f / tw; inv_th = 1.0f / th;
+        hipLaunchKernelGGL(k_level0_pad_ext<true>, dim3((es + 255) / 256, eh), dim3(256), 0, ctx->stream, d_img, w, h, stride, (const uint8_t*)p->clahe_lut,
+                           tiles_x, tiles_y, inv_tw, inv_th, p->img[0], p->pad, p->istride[0], d_ext, es);
+    } else {
+        hipLaunchKernelGGL(k_level0_pad_ext<false>, dim3((es + 255) / 256, eh), dim3(256), 0, ctx->stream, d_img, w, h, stride, (const uint8_t*)nullptr,
+                           1, 1, 1.f, 1.f, p->img[0], p->pad, p->istride[0], d_ext, es);
+    }
+    return build_levels(ctx, p);
+}
+// the blur half of lvk_orb_prepare, for a mosaic that lvk_pyramid_build_with_orb already wrote (*mosaic_done == 1)
+lvk_status lvk_orb_blur_only(lvk_context* ctx, const lvk_pyramid* p, const uint8_t* d_ext, uint8_t* d_blur)
+{
+    const int w = p->w[0], h = p->h[0], B = LVK_ORB_BORDER, es = w + 2 * B, eh = h + 2 * B;
+    static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();
+    if (!legacy && (es & 3) == 0 && (((size_t)d_ext | (size_t)d_blur) & 3) == 0 && es >= 8)
+        hipLaunchKernelGGL(k_orb_blur_w, dim3((es + BW_TX - 1) / BW_TX, (eh + BW_TY - 1) / BW_TY), dim3(256), 0, ctx->stream, d_ext, w, h, es, d_blur);
+    else
+        hipLaunchKernelGGL(k_orb_blur, dim3((es + BL_TX - 1) / BL_TX, (eh + BL_TY - 1) / BL_TY), dim3(256), 0, ctx->stream, d_ext, w, h, es, d_blur);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
+extern "C" {
 
 }  // extern "C"
 

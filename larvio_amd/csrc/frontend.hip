@@ -773,6 +773,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         const int par = (int)(fe->n_img & 1);            // parity of f-2
         hipStreamWaitEvent(S0, fe->ev_main[par], 0); hipStreamWaitEvent(S0, fe->ev_side[par], 0);
     }
+    int mosaic_done = 0;
     if (fe->use_graph && fe->image_state == 3 && !((fe->prof_mask >> 0) & 1u)) {
         int gs = -1;
         for (int k = 0; k < 3; ++k) if (fe->pyr_graph_of[k] == fe->pyr[1]) gs = k;
@@ -785,14 +786,14 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         st = lvk_pyramid_graph_launch(icx, fe->pyr_graph[gs], d_img, d_stride);
     } else {
         ProfScope ps(fe, 0, S0);
-        st = c.flag_equalize ? lvk_pyramid_build_clahe(icx, fe->pyr[1], d_img, d_stride, 3.0, 8, 8) : lvk_pyramid_build(icx, fe->pyr[1], d_img, d_stride);
+        st = lvk_pyramid_build_with_orb(icx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, fe->ext[1], &mosaic_done);
     }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
     // queued ahead of the frame's tracking (pipelined driver): the ORB planes are done long before anybody asks, one event (ev_orb)
     // stands for the whole stage; queued together with the tracking (blocking API): LK may start as soon as the pyramid exists
     if (!early) hipEventRecord(fe->ev_pyr, S0);
     fe->pyr_event = !early;
-    { ProfScope ps(fe, 1, S0); st = lvk_orb_prepare(icx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
+    { ProfScope ps(fe, 1, S0); st = mosaic_done ? lvk_orb_blur_only(icx, fe->pyr[1], fe->ext[1], fe->blur[1]) : lvk_orb_prepare(icx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
     hipEventRecord(fe->ev_orb, S0);
     fe->n_img += 1;

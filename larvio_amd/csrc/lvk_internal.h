@@ -36,6 +36,10 @@ struct lvk_context {
         }                                                                                                               \
     } while (0)
 void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes);
+struct lvk_pyramid;
+lvk_status lvk_pyramid_build_with_orb(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride, int clahe, double clip_limit,
+                                      int tiles_x, int tiles_y, uint8_t* d_ext, int* mosaic_done);
+lvk_status lvk_orb_blur_only(lvk_context* ctx, const lvk_pyramid* p, const uint8_t* d_ext, uint8_t* d_blur);
 struct lvk_frontend;
 lvk_context* lvk_frontend_context(lvk_frontend* fe);      // frontend.hip
 extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts);   // image stage only (internal)
