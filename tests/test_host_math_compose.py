@@ -1,0 +1,25 @@
+"""Host arithmetic of the product that runs on the CPU by design (larvio.cpp:520-578: the IMU samples of a frame are integrated on
+the host and composed into one (Phi, Q) pair that a single kernel applies).  The product's composition skips structurally-zero
+blocks and nests its loops for vectorisation; tests/host/imu_compose_check.hip recompiles backend.hip's host code (no GPU is touched)
+and requires it to equal the dense recurrences bit for bit, with and without IMU-intrinsics calibration (L = 22 / 46)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (host compile only)")
+def test_imu_composition_equals_dense_recurrence_bit_for_bit(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "larvio_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-j8", "-s"])                      # the objects the check links against (no-op when built)
+    obj = str(tmp_path / "icc.o"); exe = str(tmp_path / "icc")
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Xarch_host", "-mavx2", "-w", "-I", csrc]
+    subprocess.check_call([hipcc] + flags + ["-c", os.path.join(ROOT, "tests", "host", "imu_compose_check.hip"), "-o", obj])
+    objs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".o") and f != "backend.o"]
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", obj] + objs + ["-pthread", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.count("ok L=") == 2, r.stdout + r.stderr
