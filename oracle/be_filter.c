@@ -1298,6 +1298,51 @@ int lvo_ekf_process(lvo_ekf* e, double ts, const lvo_feature_obs* feats, int n_f
 }
 
 /* ------------------------------------------------------------------------ getters */
+/* ------------------------------------------------------------------------ stage-level views for the pins in tests/test_oracle_backend.py
+ * (no FEJ: the linearisation point is the estimate, so numeric differentiation of the measurement / re-parametrisation applies) */
+int lvo_stage_ekf1d_obs_jacobian(const lvo_clone* k, const lvo_clone* a, const double* p_w, double inv_depth, const double* obs_anchor,
+                                 const double* z, double* Hf2, double* Ha12, double* Hx12, double* He12, double* r2)
+{   /* measurementJacobian_ekf_1didp (larvio.cpp:1117-1244) for ONE observation of an in-state feature anchored in clone a */
+    lvo_ekf e; memset(&e, 0, sizeof e); e.leg = 22; e.if_fej = 0;
+    feat_t* f = (feat_t*)calloc(1, sizeof(feat_t));
+    memcpy(f->position, p_w, 24); memcpy(f->position_fej, p_w, 24);
+    f->inv_depth = inv_depth; f->obs_anchor[0] = obs_anchor[0]; f->obs_anchor[1] = obs_anchor[1]; f->obs_anchor[2] = 1.0;
+    f->id_anchor = a->id;
+    const int ok = ekf_obs_jacobian(&e, f, k, a, z, Hf2, Ha12, Hx12, He12, r2);
+    free(f);
+    return ok;
+}
+
+int lvo_stage_reanchor_row(const lvo_clone* c_old, const lvo_clone* c_new, const double* R_b2c, const double* t_c_b, const double* p_w,
+                           double inv_depth_new, double* J19)
+{   /* updateFeatureCov_1didp (larvio.cpp:3125-3293): the row J that maps the error state to the error of the new inverse depth, read
+     * back through the covariance it produces.  Layout of J19: [0] old rho, [1..6] old anchor clone, [7..12] new anchor clone,
+     * [13..18] extrinsics (rotation, translation).  P = I gives every entry but the feature's own; a second run with one
+     * off-diagonal entry set gives that one. */
+    lvo_ekf e; memset(&e, 0, sizeof e); e.leg = 22; e.if_fej = 0;
+    memcpy(e.R_b2c, R_b2c, 72); memcpy(e.t_c_b, t_c_b, 24);
+    lvo_clone cl[2]; cl[0] = *c_old; cl[1] = *c_new;
+    if (cl[0].id == cl[1].id) return 0;
+    e.clones = cl; e.n_clones = 2;
+    int64_t fs[1] = {7}; e.feature_states = fs; e.n_fs = 1;
+    const int N = 22 + 12 + 1, fc = N - 1;
+    e.N = N; e.P = (double*)malloc(sizeof(double) * (size_t)N * N);
+    feat_t* f = (feat_t*)calloc(1, sizeof(feat_t));
+    f->id = 7; memcpy(f->position, p_w, 24); memcpy(f->position_fej, p_w, 24); f->inv_depth = inv_depth_new;
+    double row0[64], row1[64];
+    const double c = 0.125; const int b0 = 22;                      /* couples the feature with the first old-clone column in the second run */
+    for (int run = 0; run < 2; ++run) {
+        for (int i = 0; i < N * N; ++i) e.P[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
+        if (run) { e.P[(size_t)fc * N + b0] = c; e.P[(size_t)b0 * N + fc] = c; }
+        update_feature_cov_1d(&e, f, cl[0].id, cl[1].id);
+        memcpy(run ? row1 : row0, e.P + (size_t)fc * N, sizeof(double) * (size_t)N);
+    }
+    J19[0] = (row1[b0] - row0[b0]) / c;                              /* (J P)_b0 = J_b0 + c J_fc */
+    for (int j = 0; j < 6; ++j) { J19[1 + j] = row0[22 + j]; J19[7 + j] = row0[28 + j]; J19[13 + j] = row0[15 + j]; }
+    free(f); free(e.P);
+    return 1;
+}
+
 int lvo_ekf_dim(const lvo_ekf* e) { return e->N; }
 int lvo_ekf_is_initialized(const lvo_ekf* e) { return e->is_gravity_set; }
 void lvo_ekf_get_state(const lvo_ekf* e, double* o)

@@ -245,6 +245,11 @@ int lvo_ekf_process(lvo_ekf* e, double ts, const lvo_feature_obs* feats, int n_f
 /* bypass the initializer (tests): IMU state at time t; gyro/acc = last IMU sample (m_gyro_old/m_acc_old) */
 void lvo_ekf_set_state(lvo_ekf* e, double t, const double q[4], const double p[3], const double v[3], const double bg[3], const double ba[3],
                        const double gyro_old[3], const double acc_old[3]);
+/* stage-level views of two first-party formulas for the pins (tests only) */
+int lvo_stage_ekf1d_obs_jacobian(const lvo_clone* k, const lvo_clone* a, const double* p_w, double inv_depth, const double* obs_anchor,
+                                 const double* z, double* Hf2, double* Ha12, double* Hx12, double* He12, double* r2);
+int lvo_stage_reanchor_row(const lvo_clone* c_old, const lvo_clone* c_new, const double* R_b2c, const double* t_c_b, const double* p_w,
+                           double inv_depth_new, double* J19);
 int lvo_ekf_dim(const lvo_ekf* e);                                  /* N */
 int lvo_ekf_is_initialized(const lvo_ekf* e);
 /* IMU state block: t, q[4], v[3], p[3], bg[3], ba[3], R_b2c[9], t_c_b[3], td  (27 doubles after t) */

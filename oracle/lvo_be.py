@@ -61,6 +61,8 @@ def _lib():
         L.lvo_ekf_get_clones.argtypes = [vp, vp, i]; L.lvo_ekf_get_clones.restype = i
         L.lvo_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvo_ekf_get_features.restype = i
         L.lvo_ekf_counters.argtypes = [vp, vp]
+        L.lvo_stage_ekf1d_obs_jacobian.argtypes = [vp, vp, vp, d, vp, vp, vp, vp, vp, vp, vp]; L.lvo_stage_ekf1d_obs_jacobian.restype = i
+        L.lvo_stage_reanchor_row.argtypes = [vp, vp, vp, vp, vp, d, vp]; L.lvo_stage_reanchor_row.restype = i
         _done = True
     return L
 
@@ -105,6 +107,25 @@ def ekf_update(P, H, r, sigma2):
     N = P.shape[0]; dx = np.zeros(N)
     _lib().lvo_ekf_update(_p(P), N, N, _p(H), H.shape[0], _p(r), sigma2, _p(dx))
     return dx, P
+
+
+def ekf1d_obs_jacobian(clone_k, clone_a, p_w, inv_depth, obs_anchor, z):
+    """measurementJacobian_ekf_1didp (larvio.cpp:1117-1244), one observation, no FEJ: (is_not_anchor, Hf 2, Ha 2x6, Hx 2x6, He 2x6, r 2)"""
+    k = np.ascontiguousarray(clone_k, CLONE).reshape(1); a = np.ascontiguousarray(clone_a, CLONE).reshape(1)
+    pw = np.ascontiguousarray(p_w, np.float64); oa = np.ascontiguousarray(obs_anchor, np.float64); zz = np.ascontiguousarray(z, np.float64)
+    Hf = np.zeros(2); Ha = np.zeros((2, 6)); Hx = np.zeros((2, 6)); He = np.zeros((2, 6)); r = np.zeros(2)
+    ok = _lib().lvo_stage_ekf1d_obs_jacobian(_p(k), _p(a), _p(pw), float(inv_depth), _p(oa), _p(zz), _p(Hf), _p(Ha), _p(Hx), _p(He), _p(r))
+    return bool(ok), Hf, Ha, Hx, He, r
+
+
+def reanchor_row(clone_old, clone_new, R_b2c, t_c_b, p_w, inv_depth_new):
+    """updateFeatureCov_1didp (larvio.cpp:3125-3293), no FEJ: J = [d rho_new / d rho_old, d/d(old clone) 6, d/d(new clone) 6, d/d(extrinsics) 6]"""
+    o = np.ascontiguousarray(clone_old, CLONE).reshape(1); n = np.ascontiguousarray(clone_new, CLONE).reshape(1)
+    R = np.ascontiguousarray(R_b2c, np.float64); t = np.ascontiguousarray(t_c_b, np.float64); pw = np.ascontiguousarray(p_w, np.float64)
+    J = np.zeros(19)
+    ok = _lib().lvo_stage_reanchor_row(_p(o), _p(n), _p(R), _p(t), _p(pw), float(inv_depth_new), _p(J))
+    assert ok
+    return J
 
 
 class Ekf:

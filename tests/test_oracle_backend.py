@@ -363,3 +363,90 @@ def test_transition_matrix_of_the_plain_model_vs_finite_differences():
     # stateAugmentation (larvio.cpp:752-798): the clone is the IMU pose, J selects (theta, p): its covariance rows are copies
     sel = [0, 1, 2, 6, 7, 8]
     assert np.array_equal(P[22:28, 0:22], P[sel, 0:22]) and np.array_equal(P[22:28, 22:28], P[np.ix_(sel, sel)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# In-state (1-D inverse depth) features: the measurement Jacobian and the re-anchoring Jacobian against numeric differentiation
+# of the geometry they linearise.  Error-state conventions as in the MSCKF pin above: rotation error multiplies from the left
+# (R <- R(d) R), positions add, the extrinsic rotation error acts as R_b2c <- R_b2c R(d)^T (larvio.cpp:1476-1575).
+
+
+def _camera(R_b2w, p_b, R_b2c, t_c_b):
+    """camera-to-world rotation and camera position of a clone (larvio.cpp:1529-1541)"""
+    return R_b2w @ R_b2c.T, p_b + R_b2w @ t_c_b
+
+
+def _idp_point(R_a, p_a, R_b2c, t_c_b, f_an, rho):
+    """world position of a feature with bearing f_an = (alpha, beta, 1) and inverse depth rho in the camera of anchor clone a"""
+    Rc, tc = _camera(R_a, p_a, R_b2c, t_c_b)
+    return Rc @ (f_an / rho) + tc
+
+
+def _project(R_k, p_k, R_b2c, t_c_b, pw):
+    Rc, tc = _camera(R_k, p_k, R_b2c, t_c_b)
+    pc = Rc.T @ (pw - tc)
+    return pc[:2] / pc[2]
+
+
+def _two_clones(seed):
+    clones, ranks, obs, vel, p_w, from_q = _scene(seed, M=6, n_clones=10)
+    a, k = clones[2].copy(), clones[7].copy()
+    R_b2c = a["R_b2c"].reshape(3, 3).copy(); t_c_b = np.array(a["t_c_b"])
+    Ra, pa, Rk, pk = from_q(a["q"]), np.array(a["p"]), from_q(k["q"]), np.array(k["p"])
+    Rca, tca = _camera(Ra, pa, R_b2c, t_c_b)
+    pc = Rca.T @ (p_w - tca)
+    f_an = np.array([pc[0] / pc[2], pc[1] / pc[2], 1.0]); rho = 1.0 / pc[2]
+    return a, k, R_b2c, t_c_b, Ra, pa, Rk, pk, f_an, rho, p_w
+
+
+def test_in_state_feature_jacobian_vs_numeric():
+    """measurementJacobian_ekf_1didp (larvio.cpp:1117-1244): H_f (inverse depth), H_a (anchor clone), H_x (observing clone), H_e (extrinsics)"""
+    for seed in (4, 5, 6):
+        a, k, R_b2c, t_c_b, Ra, pa, Rk, pk, f_an, rho, p_w = _two_clones(seed)
+        z = _project(Rk, pk, R_b2c, t_c_b, p_w) + np.array([0.003, -0.002])
+        ok, Hf, Ha, Hx, He, r = lvo_be.ekf1d_obs_jacobian(k, a, p_w, rho, f_an[:2], z)
+        assert ok
+
+        def h(dth_a=np.zeros(3), dp_a=np.zeros(3), dth_k=np.zeros(3), dp_k=np.zeros(3), dth_e=np.zeros(3), dp_e=np.zeros(3), drho=0.0):
+            Rbc = R_b2c @ _rot(dth_e).T; tcb = t_c_b + dp_e
+            pw = _idp_point(_rot(dth_a) @ Ra, pa + dp_a, Rbc, tcb, f_an, rho + drho)
+            return _project(_rot(dth_k) @ Rk, pk + dp_k, Rbc, tcb, pw)
+        assert np.allclose(r, z - h(), atol=1e-12)
+        eps = 1e-6
+        num = lambda name, i: (h(**{name: np.eye(3)[i] * eps}) - h(**{name: -np.eye(3)[i] * eps})) / (2 * eps)
+        nHa = np.column_stack([num("dth_a", i) for i in range(3)] + [num("dp_a", i) for i in range(3)])
+        nHx = np.column_stack([num("dth_k", i) for i in range(3)] + [num("dp_k", i) for i in range(3)])
+        nHe = np.column_stack([num("dth_e", i) for i in range(3)] + [num("dp_e", i) for i in range(3)])
+        nHf = (h(drho=eps * rho) - h(drho=-eps * rho)) / (2 * eps * rho)
+        scale = max(np.abs(nHx).max(), 1.0)
+        assert np.allclose(Hf, nHf, atol=2e-6 * max(np.abs(nHf).max(), 1.0)), (seed, Hf, nHf)
+        assert np.allclose(Ha, nHa, atol=2e-6 * scale), (seed, Ha - nHa)
+        assert np.allclose(Hx, nHx, atol=2e-6 * scale), (seed, Hx - nHx)
+        assert np.allclose(He, nHe, atol=2e-6 * scale), (seed, He - nHe)
+    # the anchor's own observation carries no information in 1-D mode (larvio.cpp:1199-1207): flagged, residual still returned
+    ok, *_rest, r = lvo_be.ekf1d_obs_jacobian(a, a, p_w, rho, f_an[:2], f_an[:2])
+    assert not ok and np.allclose(r, 0, atol=1e-12)
+
+
+def test_reanchoring_jacobian_vs_numeric():
+    """updateFeatureCov_1didp (larvio.cpp:3125-3293): the new inverse depth as a function of the old one, both anchor clones and the extrinsics"""
+    for seed in (7, 8, 9):
+        a, k, R_b2c, t_c_b, Ra, pa, Rk, pk, f_an, rho, p_w = _two_clones(seed)
+        Rck, tck = _camera(Rk, pk, R_b2c, t_c_b)
+        rho_new0 = 1.0 / (Rck.T @ (p_w - tck))[2]
+        o, n = a.copy(), k.copy()
+        J = lvo_be.reanchor_row(o, n, R_b2c, t_c_b, p_w, rho_new0)
+
+        def g(dth_o=np.zeros(3), dp_o=np.zeros(3), dth_n=np.zeros(3), dp_n=np.zeros(3), dth_e=np.zeros(3), dp_e=np.zeros(3), drho=0.0):
+            Rbc = R_b2c @ _rot(dth_e).T; tcb = t_c_b + dp_e
+            pw = _idp_point(_rot(dth_o) @ Ra, pa + dp_o, Rbc, tcb, f_an, rho + drho)
+            Rc, tc = _camera(_rot(dth_n) @ Rk, pk + dp_n, Rbc, tcb)
+            return 1.0 / (Rc.T @ (pw - tc))[2]
+        assert g() == pytest.approx(rho_new0, rel=1e-12)
+        eps = 1e-6
+        num = lambda name, i: (g(**{name: np.eye(3)[i] * eps}) - g(**{name: -np.eye(3)[i] * eps})) / (2 * eps)
+        nJ = np.array([(g(drho=eps * rho) - g(drho=-eps * rho)) / (2 * eps * rho)]
+                      + [num("dth_o", i) for i in range(3)] + [num("dp_o", i) for i in range(3)]
+                      + [num("dth_n", i) for i in range(3)] + [num("dp_n", i) for i in range(3)]
+                      + [num("dth_e", i) for i in range(3)] + [num("dp_e", i) for i in range(3)])
+        assert np.allclose(J, nJ, atol=3e-6 * max(np.abs(nJ).max(), 1.0)), (seed, J - nJ)
