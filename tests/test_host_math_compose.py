@@ -11,15 +11,28 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (host compile only)")
-def test_imu_composition_equals_dense_recurrence_bit_for_bit(tmp_path):
+def _run_host_check(tmp_path, name):
+    """compile tests/host/<name>.hip (it #includes backend.hip: host code only is exercised) against the built objects and run it"""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     csrc = os.path.join(ROOT, "larvio_amd", "csrc")
     subprocess.check_call(["make", "-C", csrc, "-j8", "-s"])                      # the objects the check links against (no-op when built)
-    obj = str(tmp_path / "icc.o"); exe = str(tmp_path / "icc")
+    obj = str(tmp_path / (name + ".o")); exe = str(tmp_path / name)
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Xarch_host", "-mavx2", "-w", "-I", csrc]
-    subprocess.check_call([hipcc] + flags + ["-c", os.path.join(ROOT, "tests", "host", "imu_compose_check.hip"), "-o", obj])
+    subprocess.check_call([hipcc] + flags + ["-c", os.path.join(ROOT, "tests", "host", name + ".hip"), "-o", obj])
     objs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".o") and f != "backend.o"]
     subprocess.check_call([hipcc, "--offload-arch=gfx950", obj] + objs + ["-pthread", "-o", exe])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    return subprocess.run([exe], capture_output=True, text=True, timeout=120)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (host compile only)")
+def test_imu_composition_equals_dense_recurrence_bit_for_bit(tmp_path):
+    r = _run_host_check(tmp_path, "imu_compose_check")
     assert r.returncode == 0 and r.stdout.count("ok L=") == 2, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (host compile only)")
+def test_observation_lists_and_map_cursor_against_std_map_models(tmp_path):
+    """Feature::find / set / erase (sorted vector, newest-first + bisection) and add_observations' cursor walk of the ordered feature map
+    (incl. out-of-order messages and features erased in between) against plain std::map models over random operation sequences."""
+    r = _run_host_check(tmp_path, "feature_obs_check")
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
