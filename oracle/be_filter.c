@@ -768,6 +768,36 @@ static void update_grid_map(lvo_ekf* e)
                     for (int i = 0; i < cells; ++i) TR(e, " %d", e->grid_count[i]); TR(e, "\n"); }
 }
 
+/* delayed initialisation of new in-state features (larvio.cpp:1821-1854), 1-D: HH = H_2^-1 H_1 (H_2 diagonal) */
+static void delayed_init_dx(int N, int n_acc, const double* H1, const double* H2, const double* r1, double* dx /* N + n_acc */)
+{   /* dx_new = -HH dx_leg + H_2^-1 r_1 */
+    for (int j = 0; j < n_acc; ++j) {
+        double s = 0;
+        for (int cc = 0; cc < N; ++cc) s += (H1[(size_t)j * N + cc] / H2[j]) * dx[cc];
+        dx[N + j] = -s + r1[j] / H2[j];
+    }
+}
+static double* delayed_init_cov(const double* P, int N, int n_acc, const double* H1, const double* H2, double sigma2)
+{   /* nHHP = -HH P ; P22 = -nHHP HH^T + sigma2 (H_2^T H_2)^-1 ; append ; symmetrise.  Returns the (N + n_acc)^2 matrix (malloc) */
+    double* HH = (double*)malloc(sizeof(double) * (size_t)(n_acc + 1) * N);
+    for (int j = 0; j < n_acc; ++j) for (int cc = 0; cc < N; ++cc) HH[(size_t)j * N + cc] = H1[(size_t)j * N + cc] / H2[j];
+    double* nHHP = (double*)malloc(sizeof(double) * (size_t)(n_acc + 1) * N);
+    for (int j = 0; j < n_acc; ++j) for (int b = 0; b < N; ++b) { double s = 0; for (int k = 0; k < N; ++k) s += HH[(size_t)j * N + k] * P[(size_t)k * N + b]; nHHP[(size_t)j * N + b] = -s; }
+    const int newN = N + n_acc;
+    double* Q = (double*)calloc((size_t)newN * newN, sizeof(double));
+    for (int a = 0; a < N; ++a) memcpy(Q + (size_t)a * newN, P + (size_t)a * N, sizeof(double) * (size_t)N);
+    for (int j = 0; j < n_acc; ++j) {
+        for (int b = 0; b < N; ++b) { Q[(size_t)(N + j) * newN + b] = nHHP[(size_t)j * N + b]; Q[(size_t)b * newN + N + j] = nHHP[(size_t)j * N + b]; }
+        for (int l = 0; l < n_acc; ++l) {
+            double s = 0; for (int k = 0; k < N; ++k) s += nHHP[(size_t)j * N + k] * HH[(size_t)l * N + k];
+            Q[(size_t)(N + j) * newN + N + l] = -s + (j == l ? sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0);
+        }
+    }
+    P_symmetrize(Q, newN);
+    free(nHHP); free(HH);
+    return Q;
+}
+
 static void remove_lost_features(lvo_ekf* e)
 {   /* larvio.cpp:1883-2256 */
     const lvo_ekf_config* c = &e->cfg;
@@ -928,36 +958,17 @@ static void remove_lost_features(lvo_ekf* e)
             /* the pre-update P is needed for nothing else: K, dx_leg and (I-KH)P all come from lvo_ekf_update */
             lvo_ekf_update(e->P, N, N, Ho, m, ro, e->sigma2, dx);
             /* delayed initialisation: HH = H_2^-1 H_1 (diag), dx_new = -HH dx_leg + H_2^-1 r_1 */
-            double* HH = (double*)malloc(sizeof(double) * (size_t)(n_acc + 1) * N);
-            for (int j = 0; j < n_acc; ++j) {
-                double s = 0;
-                for (int cc = 0; cc < N; ++cc) { HH[(size_t)j * N + cc] = H1[(size_t)j * N + cc] / H2[j]; s += HH[(size_t)j * N + cc] * dx[cc]; }
-                dx[N + j] = -s + r1[j] / H2[j];
-            }
+            delayed_init_dx(N, n_acc, H1, H2, r1, dx);
             {   /* inject with the new features already in feature_states (their dx index is N + j == base + i) */
                 inject(e, dx, n_fs_old);
             }
             if (n_acc > 0) {
-                /* nHHP = -HH P ; P22 = -nHHP HH^T + sigma2 (H_2^T H_2)^-1 ; append ; symmetrise */
-                double* nHHP = (double*)malloc(sizeof(double) * (size_t)n_acc * N);
-                for (int j = 0; j < n_acc; ++j) for (int b = 0; b < N; ++b) { double s = 0; for (int k = 0; k < N; ++k) s += HH[(size_t)j * N + k] * e->P[(size_t)k * N + b]; nHHP[(size_t)j * N + b] = -s; }
-                const int newN = N + n_acc;
-                double* Q = (double*)calloc((size_t)newN * newN, sizeof(double));
-                for (int a = 0; a < N; ++a) memcpy(Q + (size_t)a * newN, e->P + (size_t)a * N, sizeof(double) * (size_t)N);
-                for (int j = 0; j < n_acc; ++j) {
-                    for (int b = 0; b < N; ++b) { Q[(size_t)(N + j) * newN + b] = nHHP[(size_t)j * N + b]; Q[(size_t)b * newN + N + j] = nHHP[(size_t)j * N + b]; }
-                    for (int l = 0; l < n_acc; ++l) {
-                        double s = 0; for (int k = 0; k < N; ++k) s += nHHP[(size_t)j * N + k] * HH[(size_t)l * N + k];
-                        Q[(size_t)(N + j) * newN + N + l] = -s + (j == l ? e->sigma2 * (1.0 / (H2[j] * H2[j])) : 0.0);
-                    }
-                }
-                free(e->P); e->P = Q; e->N = newN;
-                P_symmetrize(e->P, e->N);
-                free(nHHP);
+                double* Q = delayed_init_cov(e->P, N, n_acc, H1, H2, e->sigma2);
+                free(e->P); e->P = Q; e->N = N + n_acc;
             }
             e->last_update_time = e->s.t;
             e->counters[0]++; e->counters[2] = m;
-            free(Ho); free(ro); free(dx); free(HH);
+            free(Ho); free(ro); free(dx);
         }
         free(Hn_top); free(rn_top); free(H1); free(H2); free(r1); free(acc_ids); free(He); free(re); free(Hm); free(rm);
     } else {
@@ -1311,6 +1322,20 @@ int lvo_stage_ekf1d_obs_jacobian(const lvo_clone* k, const lvo_clone* a, const d
     const int ok = ekf_obs_jacobian(&e, f, k, a, z, Hf2, Ha12, Hx12, He12, r2);
     free(f);
     return ok;
+}
+
+int lvo_stage_hybrid_update_with_new(double* P /* N x N in, updated in place */, int N, const double* Ho, int m, const double* ro,
+                                     const double* H1 /* n_acc x N */, const double* H2 /* n_acc */, const double* r1, int n_acc, double sigma2,
+                                     double* P_out /* (N + n_acc)^2 */, double* dx_out /* N + n_acc */)
+{   /* measurementUpdate_hybrid with delayed initialisation (larvio.cpp:1605-1862) on given matrices: the update with H_o, then the new
+     * features' correction and covariance blocks - the same three calls remove_lost_features makes */
+    double* dx = (double*)calloc((size_t)N + n_acc + 1, sizeof(double));
+    lvo_ekf_update(P, N, N, Ho, m, ro, sigma2, dx);
+    delayed_init_dx(N, n_acc, H1, H2, r1, dx);
+    double* Q = delayed_init_cov(P, N, n_acc, H1, H2, sigma2);
+    memcpy(P_out, Q, sizeof(double) * (size_t)(N + n_acc) * (N + n_acc)); memcpy(dx_out, dx, sizeof(double) * (size_t)(N + n_acc));
+    free(Q); free(dx);
+    return 1;
 }
 
 int lvo_stage_reanchor_row(const lvo_clone* c_old, const lvo_clone* c_new, const double* R_b2c, const double* t_c_b, const double* p_w,

@@ -248,6 +248,8 @@ void lvo_ekf_set_state(lvo_ekf* e, double t, const double q[4], const double p[3
 /* stage-level views of two first-party formulas for the pins (tests only) */
 int lvo_stage_ekf1d_obs_jacobian(const lvo_clone* k, const lvo_clone* a, const double* p_w, double inv_depth, const double* obs_anchor,
                                  const double* z, double* Hf2, double* Ha12, double* Hx12, double* He12, double* r2);
+int lvo_stage_hybrid_update_with_new(double* P, int N, const double* Ho, int m, const double* ro, const double* H1, const double* H2,
+                                     const double* r1, int n_acc, double sigma2, double* P_out, double* dx_out);
 int lvo_stage_reanchor_row(const lvo_clone* c_old, const lvo_clone* c_new, const double* R_b2c, const double* t_c_b, const double* p_w,
                            double inv_depth_new, double* J19);
 int lvo_ekf_dim(const lvo_ekf* e);                                  /* N */

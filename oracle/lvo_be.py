@@ -62,6 +62,7 @@ def _lib():
         L.lvo_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvo_ekf_get_features.restype = i
         L.lvo_ekf_counters.argtypes = [vp, vp]
         L.lvo_stage_ekf1d_obs_jacobian.argtypes = [vp, vp, vp, d, vp, vp, vp, vp, vp, vp, vp]; L.lvo_stage_ekf1d_obs_jacobian.restype = i
+        L.lvo_stage_hybrid_update_with_new.argtypes = [vp, i, vp, i, vp, vp, vp, vp, i, d, vp, vp]; L.lvo_stage_hybrid_update_with_new.restype = i
         L.lvo_stage_reanchor_row.argtypes = [vp, vp, vp, vp, vp, d, vp]; L.lvo_stage_reanchor_row.restype = i
         _done = True
     return L
@@ -116,6 +117,16 @@ def ekf1d_obs_jacobian(clone_k, clone_a, p_w, inv_depth, obs_anchor, z):
     Hf = np.zeros(2); Ha = np.zeros((2, 6)); Hx = np.zeros((2, 6)); He = np.zeros((2, 6)); r = np.zeros(2)
     ok = _lib().lvo_stage_ekf1d_obs_jacobian(_p(k), _p(a), _p(pw), float(inv_depth), _p(oa), _p(zz), _p(Hf), _p(Ha), _p(Hx), _p(He), _p(r))
     return bool(ok), Hf, Ha, Hx, He, r
+
+
+def hybrid_update_with_new(P, Ho, ro, H1, H2, r1, sigma2):
+    """measurementUpdate_hybrid incl. delayed initialisation of len(H2) new in-state features (larvio.cpp:1605-1862): (P_new, dx)"""
+    P = np.array(P, np.float64, order="C"); N = P.shape[0]; n_acc = len(H2)
+    Ho = np.ascontiguousarray(Ho, np.float64); ro = np.ascontiguousarray(ro, np.float64)
+    H1 = np.ascontiguousarray(H1, np.float64); H2 = np.ascontiguousarray(H2, np.float64); r1 = np.ascontiguousarray(r1, np.float64)
+    Po = np.zeros((N + n_acc, N + n_acc)); dx = np.zeros(N + n_acc)
+    _lib().lvo_stage_hybrid_update_with_new(_p(P), N, _p(Ho), Ho.shape[0], _p(ro), _p(H1), _p(H2), _p(r1), n_acc, sigma2, _p(Po), _p(dx))
+    return Po, dx
 
 
 def reanchor_row(clone_old, clone_new, R_b2c, t_c_b, p_w, inv_depth_new):

@@ -450,3 +450,28 @@ def test_reanchoring_jacobian_vs_numeric():
                       + [num("dth_n", i) for i in range(3)] + [num("dp_n", i) for i in range(3)]
                       + [num("dth_e", i) for i in range(3)] + [num("dp_e", i) for i in range(3)])
         assert np.allclose(J, nJ, atol=3e-6 * max(np.abs(nJ).max(), 1.0)), (seed, J - nJ)
+
+
+def test_delayed_initialisation_equals_a_diffuse_prior_update():
+    """measurementUpdate_hybrid with new in-state features (larvio.cpp:1605-1862, delayed initialisation :1821-1854): update with the
+    rows that do not involve the new features, then dx_new = -HH dx + H2^-1 r1, P_new,old = -HH P, P_new,new = HH P HH^T + sigma^2 H2^-2.
+    Independent statement of the same estimate: ONE standard EKF update on the state augmented by the new features under a diffuse
+    (variance -> infinity) prior, with all rows at once."""
+    rng = np.random.default_rng(12)
+    N, m, n_acc, sigma2 = 40, 25, 3, 0.01 ** 2
+    B = rng.normal(0, 1, (N, N)); P = B @ B.T * 1e-3 + np.eye(N) * 1e-5
+    Ho = rng.normal(0, 1, (m, N)); ro = rng.normal(0, 0.02, m)
+    H1 = rng.normal(0, 1, (n_acc, N)); H2 = rng.uniform(0.5, 3.0, n_acc) * rng.choice([-1, 1], n_acc); r1 = rng.normal(0, 0.02, n_acc)
+    Pn, dx = lvo_be.hybrid_update_with_new(P, Ho, ro, H1, H2, r1, sigma2)
+    kappa = 1e9
+    Pa = np.zeros((N + n_acc, N + n_acc)); Pa[:N, :N] = P; Pa[N:, N:] = np.eye(n_acc) * kappa
+    Ha = np.zeros((m + n_acc, N + n_acc)); Ha[:m, :N] = Ho; Ha[m:, :N] = H1; Ha[m:, N:] = np.diag(H2)
+    ra = np.concatenate([ro, r1])
+    S = Ha @ Pa @ Ha.T + sigma2 * np.eye(m + n_acc)
+    K = Pa @ Ha.T @ np.linalg.inv(S)
+    dxa = K @ ra
+    Pp = (np.eye(N + n_acc) - K @ Ha) @ Pa
+    Pp = (Pp + Pp.T) / 2
+    assert np.allclose(dx, dxa, atol=1e-6 * np.abs(dxa).max())
+    assert np.allclose(Pn, Pp, atol=1e-6 * np.abs(Pp).max())
+    assert np.allclose(Pn, Pn.T, atol=0)
