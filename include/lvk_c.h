@@ -155,6 +155,9 @@ lvk_status lvk_frontend_new_pts(lvk_frontend* fe, lvk_pt2f* h_pts, int cap, int*
 int        lvk_frontend_state(const lvk_frontend* fe);   /* 1 FIRST_IMAGE 2 SECOND_IMAGE 3 OTHER_IMAGES */
 /* cumulative LK work: point-levels processed and iterations executed (SURVEY §8d byte model) */
 lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint64_t* iterations);
+/* feature messages published so far (getFeatureMsg, image_processor.cpp:1076-1128) and the features they carried in total:
+   features / messages = the tracks the tracker holds per published frame (the "~150 tracks" of BASELINE.json's metric) */
+lvk_status lvk_frontend_msg_stats(lvk_frontend* fe, uint64_t* messages, uint64_t* features);
 
 /* Per-stage GPU time measured with HIP events on the context's stream (the reference only times the
  * whole call, app/larvioMain.cpp:106-109).  stage_mask bit i enables stage i; reading synchronises.

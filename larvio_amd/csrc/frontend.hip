@@ -204,6 +204,7 @@ struct FeDev {
     int n_msg;           // features in the last message
     int boot_ok;         // result of the last bootstrap attempt
     int pad_;
+    unsigned long long msg_features, msg_count;   // features in all published messages / messages published (mean tracks per message)
 };
 
 struct TrackSet {       // structure of arrays, capacity cap
@@ -415,7 +416,7 @@ __global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams c
 {   // `out` and `n_host` are device-mapped pinned host memory: the message needs no copy command, only the stream sync
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *n_ptr;
-    if (i == 0) { dev->n_msg = n; *n_host = n; }
+    if (i == 0) { dev->n_msg = n; *n_host = n; dev->msg_features += (unsigned long long)n; dev->msg_count += 1ull; }
     if (i >= n) return;
     const double unit[4] = {1, 1, 0, 0};
     const lvk_pt2f uc = undistort_point(ts.pts[i], cam, unit);
@@ -1002,6 +1003,17 @@ lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint6
     if (st != LVK_OK) return st;
     if (point_levels) *point_levels = fe->h_dev->lk_point_levels;
     if (iterations) *iterations = fe->h_dev->lk_iterations;
+    return LVK_OK;
+}
+
+lvk_status lvk_frontend_msg_stats(lvk_frontend* fe, uint64_t* messages, uint64_t* features)
+{
+    if (!fe) return LVK_ERR_ARG;
+    { lvk_status qs = fe_quiesce(fe); if (qs != LVK_OK) return qs; }
+    lvk_status st = fe_read_dev(fe);
+    if (st != LVK_OK) return st;
+    if (messages) *messages = fe->h_dev->msg_count;
+    if (features) *features = fe->h_dev->msg_features;
     return LVK_OK;
 }
 

@@ -98,6 +98,12 @@ class ImageProcessor:
         self.ctx.check(lib().lvk_frontend_lk_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def msg_stats(self):
+        """-> (messages published, features they carried in total) since the front-end was created"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.ctx.check(lib().lvk_frontend_msg_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def profile_enable(self, stage_mask=0x1FF):
         self.ctx.check(lib().lvk_frontend_profile_enable(self._h, stage_mask))
 

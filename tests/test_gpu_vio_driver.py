@@ -156,24 +156,31 @@ TUMVI_LIKE = dict(
     T_cam_imu=None)
 
 
-def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates, mutate=None, oracle_threads=1):
-    """oracle loop vs VioDriver on frames [first, first+count) of the synthetic sequence seen through `cam`"""
+def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates, mutate=None, oracle_threads=1, workload=None):
+    """oracle loop vs VioDriver on frames [first, first+count) of the synthetic sequence seen through `cam`
+    (workload: a larvio_amd.synthetic.workload() dict - camera, frame rate and both configurations exactly as bench.py runs them)"""
     import larvio_amd
     from larvio_amd import synthetic as S
     from larvio_amd.vio import VioDriver
     from oracle import lvo, lvo_be
     from tests.conftest import synth_frames
+    img_rate = 20.0
+    if workload is not None:
+        cam, img_rate = workload["cam"], workload["img_rate"]
     cam = dict(cam)
     if cam.get("T_cam_imu") is None:
         cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
-    frames = synth_frames(first, count, cam=cam)
+    frames = synth_frames(first, count, cam=cam, img_rate=img_rate)
     if mutate is not None:
         frames = mutate(list(frames))
     seq = S.imu_only_sequence(cam=cam)
     ts = [f[0] for f in frames]
     imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
-    fcfg = S.frontend_config(cam=cam, **fcfg_over)
-    bcfg = S.backend_config(cam=cam, **bcfg_over)
+    if workload is not None:
+        fcfg, bcfg = dict(workload["fcfg"], **fcfg_over), dict(workload["bcfg"], **bcfg_over)
+    else:
+        fcfg = S.frontend_config(cam=cam, **fcfg_over)
+        bcfg = S.backend_config(cam=cam, **bcfg_over)
     fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
     be = larvio_amd.LarVio(bcfg, gpu_ctx); assert be.initialize()
     ofe = lvo.Frontend(fcfg); obe = lvo_be.Ekf(bcfg)
@@ -210,8 +217,11 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
     co, cg = obe.counters(), be.counters()
     for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map"):
         assert cg[k] == co[k], (k, cg, co)
+    n_clones = len(obe.clones()["id"]); dim = obe.dim
     be.close(); fe.close()
     lvo.set_threads(1)
+    if workload is not None:
+        return n_upd, worst, co, len(to["ids"]), n_clones, dim
     return n_upd, worst, co, len(to["ids"])
 
 
@@ -241,6 +251,53 @@ def test_driver_loop_headline_config_sw30(gpu_ctx):
                                              init_from_gt=True, min_updates=60)
     assert c["msckf"] >= 5 and c["hybrid"] >= 55 and n_tracks >= 100, c
     print("headline config (sw_size 30): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks)
+
+
+def _oracle_threads():
+    import os
+    return min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+
+def test_whole_loop_configs1_as_benchmarked_150_live_tracks(gpu_ctx):
+    """BASELINE.json configs[1] exactly as bench.py runs it (larvio_amd.synthetic.workload("A")): the tracker budget is sized so that
+    the tracker HOLDS ~150 tracks, sw_size 30, 150 frames from t = 2 s: HIP vs oracle after every update."""
+    from larvio_amd import synthetic as S
+    wl = S.workload("A")
+    n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, int(2.0 * wl["img_rate"]), 150, {}, {}, init_from_gt=True, min_updates=70, workload=wl)
+    assert n_clones >= 28 and c["msckf"] >= 5 and 140 <= n_tracks <= wl["max_features"], (n_clones, c, n_tracks)
+    print("configs[1] as benchmarked: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+
+
+def test_whole_loop_configs2_imu_intrinsics_sw30(gpu_ctx):
+    """configs[2]: online extrinsic + td + IMU-intrinsics calibration (46-dimensional legacy block, larvio.cpp:158-161, 3528-3800) as a
+    WHOLE loop at sw_size 30: 140 frames, the window fills and cycles."""
+    from larvio_amd import synthetic as S
+    wl = S.workload("3")
+    n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, int(2.0 * wl["img_rate"]), 140, {}, {}, init_from_gt=True, min_updates=65, workload=wl)
+    assert wl["bcfg"]["calib_imu_instrinsic"] == 1 and n_clones >= 28 and c["msckf"] >= 5 and dim >= 46 + 6 * 28, (n_clones, c, dim)
+    print("configs[2] (IMU intrinsics, sw 30): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+
+
+def test_whole_loop_configs3_tumvi_300_tracks_sw30_zupt(gpu_ctx):
+    """configs[3] at its real shape: 512x512 equidistant, 300-feature budget, sw_size 30, ZUPT on, from rest (static initializer, then
+    zero-velocity updates, then motion): 170 frames so that the window fills (28 -> 30 cycle, larvio.cpp:2316-2320)."""
+    from larvio_amd import synthetic as S
+    wl = S.workload("4")
+    n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, 0, 170, {}, {}, init_from_gt=False, min_updates=60, workload=wl)
+    assert n_clones >= 28 and c["zupt"] >= 1 and c["msckf"] >= 5 and n_tracks >= 200, (n_clones, c, n_tracks)
+    print("configs[3] (300 tracks, sw 30, ZUPT): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+
+
+def test_whole_loop_configs4_1080p_2000_tracks_sw60(gpu_ctx):
+    """configs[4] at its real shape: 1920x1080 @60 Hz, 2000-feature budget, sw_size 60, 140 frames = 70 messages: the front-end at
+    ~2000 tracks, the 58 -> 60 window cycle with pruning updates, and the tall-H compression (larvio.cpp:1430-1445: thousands of stacked
+    rows per update) compared with the oracle after EVERY update."""
+    from larvio_amd import synthetic as S
+    wl = S.workload("5")
+    n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, int(2.0 * wl["img_rate"]), 140, {}, {}, init_from_gt=True, min_updates=65,
+                                                             workload=wl, oracle_threads=_oracle_threads())
+    assert n_clones >= 58 and c["msckf"] >= 3 and n_tracks >= 1800 and dim >= 22 + 6 * 58, (n_clones, c, n_tracks, dim)
+    print("configs[4] (1080p, 2000 tracks, sw 60): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
 
 
 def test_driver_loop_config5_shape_1080p_many_tracks(gpu_ctx):
