@@ -299,82 +299,147 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
     """The filter alone at configs[4] depth, fed by the feature-level simulator (larvio_amd.synthetic.simulate_features: 2000
     features per message, 60-clone window): one step = one feature message through processFeatures.  With --sharded every rank
     runs the same filter on the same messages, does the per-feature device work of its slice and the compressed blocks are
-    all-gathered over RCCL (strong scaling of the update); otherwise rank r runs its own stream (replicas)."""
+    all-gathered over RCCL (strong scaling of the update); otherwise rank r runs its own stream (replicas).
+    At N = 1, --sharded runs the sharded branch through RCCL with a one-rank communicator (loop-back: pack -> ncclAllGather -> unpack
+    -> second stage on one GPU); without it the line carries that run as `rccl_loopback` next to the unsharded value.
+    The last 40 messages of the pre-roll run with HIP events around every level of the structure-aware TSQR compression (k_qr_sparse)
+    and around the H P GEMM: `roofline` (TSQR) and `roofline_mfma` of this workload."""
     import larvio_amd
     from larvio_amd import synthetic as S
     K = args.steps if K is None else K; W = args.warmup if W is None else W
     sharded = args.sharded if sharded is None else sharded
-
-    class _A:
-        pass
-    a_ = _A(); a_.sharded = sharded; a_.max_features = args.max_features if args.backend_only else None; a_.sw_size = args.sw_size if args.backend_only else None
-    args = a_
+    max_features = (args.max_features if args.backend_only else None) or 2000
+    sw_size = (args.sw_size if args.backend_only else None) or 60
+    want_cpu = rank == 0 and world == 1 and not getattr(args, "no_cpu_baseline", False)
     n_pre = 2 * 60 + 12
-    sim = S.simulate_features(21 + (0 if args.sharded else rank), t0=2.0, t1=2.0 + 0.1 * (n_pre + W + K + 2), max_feat=args.max_features or 2000,
-                              n_per_batch=500, sw_size=args.sw_size or 60, max_features_in_one_grid=2, estimate_td=1, estimate_extrin=1,
-                              max_features=args.max_features or 2000)
-    ctx = larvio_amd.Context(local_rank)
-    be = larvio_amd.LarVio(sim["cfg"], ctx); assert be.initialize()
-    shard = None
-    if args.sharded and world > 1:
-        from larvio_amd import sharding
-        shard = sharding.make_shard(ctx, rank, world, dist)
-        be.set_shard(*shard.args())
+    sim = S.simulate_features(21 + (0 if sharded else rank), t0=2.0, t1=2.0 + 0.1 * (n_pre + W + K + 2), max_feat=max_features,
+                              n_per_batch=500, sw_size=sw_size, max_features_in_one_grid=2, estimate_td=1, estimate_extrin=1,
+                              max_features=max_features)
     imu = sim["imu"]; msgs = sim["msgs"]
-    be.set_state(*sim["init"])
-    lo = 0
 
-    def one(i):
-        nonlocal lo
+    def run_filter(use_shard, profile):
+        ctx = larvio_amd.Context(local_rank)
+        be = larvio_amd.LarVio(sim["cfg"], ctx); assert be.initialize()
+        shard = None
+        if use_shard:
+            from larvio_amd import sharding
+            shard = sharding.make_shard(ctx, rank, world, dist) if world > 1 else sharding.RcclShard(ctx, 0, 1, sharding.unique_id())
+            be.set_shard(*shard.args())
+        be.set_state(*sim["init"])
+        st = dict(lo=0)
+
+        def one(i):
+            ts, m = msgs[i]
+            hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
+            upd, rest = be.processFeatures((ts, m), imu[st["lo"]:hi]); st["lo"] = hi - len(rest)
+        i = 0; qr = hp = None
+        while i < n_pre + W:
+            if profile and i == n_pre - 40:
+                be.profile(True); be.profile_qr()
+            if profile and i == n_pre:
+                qr = be.profile_qr(); hp = be.profile(False)
+            one(i); i += 1
+        if len(be.clones()) < sim["cfg"]["sw_size"] - 2:
+            raise SystemExit("bench.py --backend-only: the window did not fill in the pre-roll: no value printed")
+        c0 = be.counters(); s0 = be.shard_stats()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lat = np.empty(K)
+        t_begin = time.perf_counter()
+        for k in range(K):
+            t0 = time.perf_counter(); one(i); i += 1; lat[k] = time.perf_counter() - t0
+        ctx.sync(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_begin
+        if dist is not None:
+            elapsed = max_over_ranks(dist, torch, elapsed)
+        c1 = be.counters(); s1 = be.shard_stats()
+        r = dict(elapsed=elapsed, lat=lat, dim=be.dim, clones=len(be.clones()), n_feat=len(msgs[i - 1][1]), qr=qr, hp=hp,
+                 timed={k: c1[k] - c0[k] for k in ("hybrid", "msckf", "gated_in", "gated_out", "triangulations")}, shard={k: s1[k] - s0[k] for k in s1})
+        be.close()
+        if shard is not None:
+            shard.close()
+        ctx.close()
+        return r
+
+    m = run_filter(sharded, True)
+    loop = None
+    if world == 1 and not sharded and getattr(args, "loopback_probe", False):      # the probe of the default line: also execute the RCCL transport (one-rank communicator)
+        try:
+            lb = run_filter(True, False)
+            loop = {"value": round(K / lb["elapsed"], 2), "unit": "messages/s", "ms_per_step": round(lb["elapsed"] / K * 1e3, 4), "shard": lb["shard"],
+                    "note": "the same filter through the SHARDED branch with RCCL as the transport and a one-rank communicator: per-rank rows -> "
+                            "first compression stage -> k_shard_pack -> ncclAllGather on the filter's stream -> k_shard_unpack -> replicated second stage"}
+        except Exception as exc:                                   # the transport probe must not take the line down
+            loop = {"error": str(exc)[:300]}
+    cpu = None
+    if want_cpu:
+        cpu = cpu_baseline_backend(sim, n_pre, 12)
+    streams = 1 if sharded else world
+    if rank != 0:
+        return None
+    qr, hp = m["qr"], m["hp"]
+    roof_qr = None
+    if qr and qr["launches"] > 0 and qr["ms"] > 0:
+        ach = qr["flops"] / qr["ms"] / 1e9
+        roof_qr = {"kernel": "k_qr_sparse (one level of the structure-aware TSQR compression of the stacked measurement rows; FP64 Householder nodes in LDS)",
+                   "bound": "fp64-valu", "achieved": round(ach, 4), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 6),
+                   "traffic": None, "flops_per_launch": round(qr["flops"] / qr["launches"], 1), "avg_launch_us": round(qr["ms"] / qr["launches"] * 1e3, 3),
+                   "launches": qr["launches"], "rows_in_per_launch": round(qr["rows"] / qr["launches"], 1),
+                   "flops_definition": "Householder flops on the structure actually factored: sum over nodes (r rows restricted to their c columns + residual) "
+                                       "and reflectors j < min(r, c) of 4 (r - j)(c + 1 - j) ~ 2 r c^2 - 2/3 c^3 per node (SURVEY 8d)",
+                   "peak_note": "MI355X FP64 vector peak = FP64 matrix peak = 78.6 TFLOP/s (datasheet)",
+                   "measured_over": "the last 40 messages of the pre-roll (window full), HIP events on the filter's stream around every level launch"}
+    roof_hp = None
+    if hp and hp["launches"] > 0 and hp["ms"] > 0:
+        ach = hp["flops"] / hp["ms"] / 1e9
+        roof_hp = {"kernel": "k_dgemm<false,false> (H P)", "bound": "mfma", "achieved": round(ach, 4), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 6), "flops_per_launch": round(hp["flops"] / hp["launches"], 1),
+                   "avg_launch_us": round(hp["ms"] / hp["launches"] * 1e3, 3), "launches": hp["launches"]}
+    lat = m["lat"]
+    out = {"metric": "EKF feature messages/sec (filter only, %d features per message, %d-clone window, state dim %d)" % (m["n_feat"], m["clones"], m["dim"]),
+           "value": round(streams * K / m["elapsed"], 2), "unit": "messages/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(m["elapsed"] / K * 1e3, 4),
+           "p50_ms_per_message": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_message": round(float(np.percentile(lat, 95)) * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "configs[4] depth, back-end only: simulated feature messages (no images), max_features %d, sw_size %d, 1d-hybrid"
+                                  % (sim["cfg"]["max_features"], sim["cfg"]["sw_size"]),
+                      "rehearsal_one_gpu_gloo": bool(os.environ.get("LVK_BENCH_ONE_GPU")),
+                      "parallelism": ("sharded x%d: contiguous feature ranges per rank, one RCCL all-gather of the compressed blocks + gate results per update" % world)
+                                     if sharded else "replicas x%d" % world,
+                      "state_dim": m["dim"], "clones": m["clones"], "timed_region": m["timed"], "shard": m["shard"]},
+           "roofline": roof_qr, "roofline_mfma": roof_hp, "cpu_baseline": cpu, "rccl_loopback": loop}
+    if cpu:
+        out["x_cpu_one_thread"] = round(out["value"] / cpu["value"], 2)
+    return out
+
+
+def cpu_baseline_backend(sim, n_pre, n_sample):
+    """The CPU oracle's filter (kind "port") on the same simulated messages: pre-roll with OpenMP (same results for any thread count),
+    then n_sample steady-state messages on ONE thread."""
+    from oracle import lvo, lvo_be
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    be = lvo_be.Ekf(sim["cfg"]); be.set_state(*sim["init"])
+    imu = sim["imu"]; msgs = sim["msgs"]; lo = 0
+    lvo.set_threads(min(ncores, 16))
+    t1 = 0.0
+    for i in range(min(n_pre + n_sample, len(msgs))):
+        if i == n_pre:
+            lvo.set_threads(1); t1 = time.perf_counter()
         ts, m = msgs[i]
         hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
-        upd, rest = be.processFeatures((ts, m), imu[lo:hi]); lo = hi - len(rest)
-    i = 0
-    while i < n_pre + W:
-        one(i); i += 1
-    if len(be.clones()) < sim["cfg"]["sw_size"] - 2:
-        raise SystemExit("bench.py --backend-only: the window did not fill in the pre-roll: no value printed")
-    c0 = be.counters(); s0 = be.shard_stats()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lat = np.empty(K)
-    t_begin = time.perf_counter()
-    for k in range(K):
-        t0 = time.perf_counter(); one(i); i += 1; lat[k] = time.perf_counter() - t0
-    ctx.sync(); torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_begin
-    if dist is not None:
-        elapsed = max_over_ranks(dist, torch, elapsed)
-    c1 = be.counters(); s1 = be.shard_stats()
-    streams = 1 if args.sharded else world
-    if rank == 0:
-        out = {"metric": "EKF feature messages/sec (filter only, %d features per message, %d-clone window, state dim %d)" % (len(msgs[i - 1][1]), len(be.clones()), be.dim),
-               "value": round(streams * K / elapsed, 2), "unit": "messages/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
-               "p50_ms_per_message": round(float(np.median(lat)) * 1e3, 4), "p95_ms_per_message": round(float(np.percentile(lat, 95)) * 1e3, 4),
-               "higher_is_better": True, "scaling": "strong" if args.sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "configs[4] depth, back-end only: simulated feature messages (no images), max_features %d, sw_size %d, 1d-hybrid"
-                                      % (sim["cfg"]["max_features"], sim["cfg"]["sw_size"]),
-                          "rehearsal_one_gpu_gloo": bool(os.environ.get("LVK_BENCH_ONE_GPU")), "parallelism": ("sharded x%d: contiguous feature ranges per rank, one RCCL all-gather of the compressed blocks + gate results per update" % world)
-                                         if args.sharded else "replicas x%d" % world,
-                          "state_dim": be.dim, "clones": len(be.clones()),
-                          "timed_region": {k: c1[k] - c0[k] for k in ("hybrid", "msckf", "gated_in", "gated_out", "triangulations")},
-                          "shard": {k: s1[k] - s0[k] for k in s1}},
-               "roofline": None, "cpu_baseline": None}
-    else:
-        out = None
-    be.close()
-    if shard is not None:
-        shard.close()
-    ctx.close()
-    return out
+        upd, used = be.process(ts, m, imu[lo:hi]); lo += used
+    dt = time.perf_counter() - t1
+    n = min(n_pre + n_sample, len(msgs)) - n_pre
+    return {"value": round(n / dt, 3), "unit": "messages/s", "cores": 1, "kind": "port", "state_dim": be.dim, "host": cpu_model(),
+            "sample": "%d steady-state messages of the same simulated stream (%.1f s of CPU work on one thread, after a %d-message OpenMP pre-roll): "
+                      "the CPU oracle's filter (dense Householder compression); a restatement, not the Eigen/SuiteSparse build" % (n, dt, n_pre)}
 
 
 def shard_probe(rank, world, local_rank):
     """Run `bench.py --backend-only [--sharded]` as a CHILD process per rank (own rendezvous on MASTER_PORT + 1, own RCCL
-    communicator) with a 150 s time limit: a failure or a hang of the sharded path cannot take the headline measurement down with it."""
+    communicator) with a 240 s time limit: a failure or a hang of the sharded path cannot take the headline measurement down with it."""
     import subprocess
     env = dict(os.environ)
     env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"] = str(rank), str(world), str(local_rank)
@@ -384,11 +449,11 @@ def shard_probe(rank, world, local_rank):
     for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")]:
         del env[k]                                       # the children rendezvous among themselves: with torchrun's TORCHELASTIC_USE_AGENT_STORE
                                                          # rank 0 would wait for an agent-hosted store on the new port instead of creating it
-    cmd = [sys.executable, os.path.abspath(__file__), "--backend-only", "--gpus", str(world), "--steps", "40", "--warmup", "4"] + (["--sharded"] if world > 1 else [])
+    cmd = [sys.executable, os.path.abspath(__file__), "--backend-only", "--gpus", str(world), "--steps", "40", "--warmup", "4"] + (["--sharded"] if world > 1 else ["--loopback-probe"])
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     except subprocess.TimeoutExpired:
-        return {"error": "the sharded-update probe did not finish within 150 s"} if rank == 0 else None
+        return {"error": "the sharded-update probe did not finish within 240 s"} if rank == 0 else None
     if rank != 0:
         return None
     for line in reversed(r.stdout.strip().splitlines()):
@@ -446,6 +511,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
     ap.add_argument("--sharded", action="store_true", help="config 5 across ranks: per-rank feature rows, RCCL all-gather of the compressed R")
     ap.add_argument("--no-shard-probe", action="store_true", help="skip the configs[4]-depth (sharded) filter probe appended to the default line")
+    ap.add_argument("--loopback-probe", action="store_true", help="with --backend-only at N=1: run the filter a second time through the sharded branch with a one-rank RCCL communicator")
     ap.add_argument("--backend-only", action="store_true", help="the filter alone at configs[4] depth on simulated feature messages (no images): "
                                                                   "the cheap way to time the (sharded) update at 2000 features")
     args = ap.parse_args()
@@ -591,7 +657,9 @@ def main():
                                  "avg_launch_us": round(hp["ms"] / max(hp["launches"], 1) * 1e3, 3), "launches": hp["launches"],
                                  "measured_over": "the last >= 20 updates of the pre-roll (window full and cycling; kept out of the timed region: "
                                                   "its event records would add ~10% to the filter chain)"},
-               "cpu_baseline": cpu, "sharded_update_probe": probe}
+               "cpu_baseline": cpu, "sharded_update_probe": probe,
+               # the TSQR compression north_star names, measured where it runs (configs[4] depth; at configs[1] the stack is < 480 rows and is not compressed)
+               "roofline_qr": (probe or {}).get("roofline") if isinstance(probe, dict) else None}
         if cpu:
             out["x_cpu_one_thread"] = round(value / cpu["value"], 2)
             out["x_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 2)

@@ -55,6 +55,7 @@ lvk_status  lvk_context_create(int device, lvk_context** out);
 void        lvk_context_destroy(lvk_context* ctx);
 /* use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 lvk_status  lvk_context_set_stream(lvk_context* ctx, void* hip_stream);
+void*       lvk_context_get_stream(const lvk_context* ctx);   /* the hipStream_t every call on this context is ordered on */
 lvk_status  lvk_sync(lvk_context* ctx);
 const char* lvk_last_error(const lvk_context* ctx);
 const char* lvk_version(void);
@@ -255,6 +256,10 @@ void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
 /* HIP-event bracket around the H P GEMM (the P H^T contraction, FP64 MFMA) of every update: enable/disable; h_out3 (optional) receives
  * [milliseconds, flops = sum 2 m N^2, launches] accumulated since the previous call */
 lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* h_out3);
+/* the same switch brackets every level of the structure-aware TSQR compression (k_qr_sparse; replaces the SPQR calls at
+ * larvio.cpp:1430-1445, 2209-2229): h_out4 = [milliseconds, Householder flops on the structure actually factored (sum over nodes
+ * and reflectors j of 4 (r - j)(c + 1 - j)), launches, rows entering the levels] since the previous call */
+lvk_status lvk_ekf_profile_qr(lvk_ekf* e, double* h_out4);
 
 /* ---- sharded measurement update (BASELINE.json configs[4]).  Every rank runs the same filter on the same messages; the
  * per-feature device work of an update (Jacobian rows, null-space projection, chi-square gate, stacking, first compression) is split
@@ -263,7 +268,11 @@ lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* h_out3);
  * replicated - identical bits on every rank.  The collective is a callback so that the transport is the caller's choice:
  * lvk_shard_allgather_rccl (below) runs ncclAllGather on the filter's stream, device buffers in place; a test may move the bytes
  * through the host.  fn must deliver, in d_recv, the `world` send buffers of bytes_per_rank bytes each in rank order, ordered on
- * hip_stream.  world = 1 switches sharding off. */
+ * hip_stream.  fn = NULL (world 1) switches sharding off; with a transport the sharded path runs at any world size, world 1 included
+ * (a loop-back through pack -> all-gather -> unpack -> second stage: validates a transport on one GPU).  The exchange buffers are
+ * allocated by this call.  Every capacity test of the sharded update has the same outcome on all ranks (each rank plans every rank's
+ * share), so a capacity error is raised everywhere before anybody enters the collective; a rank that fails locally afterwards still
+ * enters it, with a poisoned block header, and its peers return LVK_ERR_DEVICE at their next sync instead of waiting. */
 typedef int /* lvk_status */ (*lvk_exchange_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
 lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn, void* user);
 /* [0] exchanges [1] bytes sent by this rank [2] sharded updates [3] rows this rank stacked; [4] updates the structure-aware
@@ -275,6 +284,7 @@ typedef struct lvk_shard_comm lvk_shard_comm;
 lvk_status lvk_shard_unique_id(char* h_out128);
 lvk_status lvk_shard_comm_create(lvk_context* ctx, const char* h_uid128, int rank, int world, lvk_shard_comm** out);
 void       lvk_shard_comm_destroy(lvk_shard_comm* c);
+const char* lvk_shard_comm_error(const lvk_shard_comm* c);    /* text of the last RCCL error lvk_shard_allgather_rccl returned on it */
 lvk_status lvk_shard_allgather_rccl(void* comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
 
 /* ---- per-feature stages of the update, one call each (parity tests; callers that want a single stage).  Host buffers.

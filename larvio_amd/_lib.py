@@ -16,7 +16,7 @@ OBS = np.dtype([("id", np.uint64), ("u", np.float64), ("v", np.float64), ("u_ini
 
 # every symbol include/lvk_c.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
-    "lvk_context_create", "lvk_context_destroy", "lvk_context_set_stream", "lvk_sync", "lvk_last_error", "lvk_version",
+    "lvk_context_create", "lvk_context_destroy", "lvk_context_set_stream", "lvk_context_get_stream", "lvk_sync", "lvk_last_error", "lvk_version",
     "lvk_malloc", "lvk_free", "lvk_memcpy_h2d", "lvk_memcpy_d2h", "lvk_memset",
     "lvk_clahe_u8", "lvk_pyramid_create", "lvk_pyramid_destroy", "lvk_pyramid_build", "lvk_pyramid_build_clahe",
     "lvk_pyramid_levels", "lvk_pyramid_level", "lvk_orb_prepare", "lvk_min_eigen_map", "lvk_good_features",
@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "lvk_frontend_stage_name",
     "lvk_ekf_compress_qr", "lvk_ekf_compress_qr_groups", "lvk_ekf_qr_plan", "lvk_ekf_update", "lvk_dgemm", "lvk_ekf_create", "lvk_ekf_destroy", "lvk_ekf_process", "lvk_ekf_set_state",
     "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_take_off_stamp", "lvk_ekf_get_state", "lvk_ekf_get_imu_intrinsics", "lvk_ekf_set_imu_intrinsics", "lvk_ekf_get_cov", "lvk_ekf_get_clones", "lvk_ekf_get_features", "lvk_ekf_take_lost_features",
-    "lvk_ekf_counters", "lvk_ekf_profile", "lvk_ekf_set_shard", "lvk_ekf_shard_stats", "lvk_shard_unique_id", "lvk_shard_comm_create", "lvk_shard_comm_destroy", "lvk_shard_allgather_rccl", "lvk_triangulate", "lvk_ekf_gate_and_stack", "lvk_vio_process", "lvk_vio_pipe_create", "lvk_vio_pipe_destroy", "lvk_vio_pipe_push_imu", "lvk_vio_pipe_submit", "lvk_vio_pipe_drain", "lvk_vio_pipe_on_update", "lvk_vio_pipe_stats", "lvk_vio_pipe_latency",
+    "lvk_ekf_counters", "lvk_ekf_profile", "lvk_ekf_profile_qr", "lvk_ekf_set_shard", "lvk_ekf_shard_stats", "lvk_shard_unique_id", "lvk_shard_comm_create", "lvk_shard_comm_destroy", "lvk_shard_comm_error", "lvk_shard_allgather_rccl", "lvk_triangulate", "lvk_ekf_gate_and_stack", "lvk_vio_process", "lvk_vio_pipe_create", "lvk_vio_pipe_destroy", "lvk_vio_pipe_push_imu", "lvk_vio_pipe_submit", "lvk_vio_pipe_drain", "lvk_vio_pipe_on_update", "lvk_vio_pipe_stats", "lvk_vio_pipe_latency",
 ]
 FE_STAGES = 9
 
@@ -145,6 +145,13 @@ class Context:
 
     def sync(self):
         self.check(lib().lvk_sync(self.h))
+
+    @property
+    def stream(self):
+        """the hipStream_t (as an integer) the context's calls are ordered on"""
+        L = lib()
+        L.lvk_context_get_stream.argtypes = [C.c_void_p]; L.lvk_context_get_stream.restype = C.c_void_p
+        return L.lvk_context_get_stream(self.h) or 0
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

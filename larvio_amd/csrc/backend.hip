@@ -48,9 +48,10 @@ lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows,
 
 double lvk_chi2_005(int dof);
 struct ShardMeta { int job_lo, job_n, k, row_off; };
-lvk_status lvk_shard_pack(lvk_context* ctx, const FeatResult* d_res, int n_res, const double* d_X, int ld, const double* d_rX, int k, int ncols, char* d_send, size_t res_bytes);
+#define LVK_SHARD_HDR 256
+lvk_status lvk_shard_pack(lvk_context* ctx, const FeatResult* d_res, int n_res, const double* d_X, int ld, const double* d_rX, int k, int ncols, char* d_send, size_t res_bytes, int rank);
 lvk_status lvk_shard_unpack(lvk_context* ctx, const char* d_recv, size_t bytes_per_rank, size_t res_bytes, const ShardMeta* d_meta, int world, int ncols, int k_max,
-                            FeatResult* d_fout, FeatResult* d_fout_host, double* d_H, int ld, double* d_r);
+                            FeatResult* d_fout, FeatResult* d_fout_host, double* d_H, int ld, double* d_r, int* d_peer_fail);
 
 // ------------------------------------------------------------------------- host records
 struct Obs { long long sid; double z[2], zv[2]; };
@@ -139,9 +140,13 @@ struct lvk_ekf {
     mutable ColCache colcache;                          // job_dense_cols: the column list of the previous job, reused when the next one has the same observation set
     long qr_stats[4] = {0, 0, 0, 0};                    // [0] updates compressed [1] levels run [2] rows in [3] rows out
     // sharded measurement update: this rank builds the feature rows of its contiguous slice, one all-gather of the
-    // compressed blocks (+ every feature's gate result), replicated update.  world 1 = off.
-    struct Shard { int rank = 0, world = 1; lvk_exchange_fn fn = nullptr; void* user = nullptr; char *d_send = nullptr, *d_recv = nullptr; size_t cap = 0;
+    // compressed blocks (+ every feature's gate result), replicated update.  fn == nullptr = off; with a transport the sharded path
+    // runs at any world size, world 1 included (a loop-back that exercises pack -> all-gather -> unpack -> second stage on one GPU).
+    // The exchange buffers are allocated once, in lvk_ekf_set_shard, for xk_cap block rows per rank: nothing that can fail on one
+    // rank only sits between the ranks and their collective.
+    struct Shard { int rank = 0, world = 1; lvk_exchange_fn fn = nullptr; void* user = nullptr; char *d_send = nullptr, *d_recv = nullptr; size_t cap = 0; int xk_cap = 0;
                    long stats[4] = {0, 0, 0, 0}; } shard;     // stats: [0] exchanges [1] bytes sent per rank (sum) [2] sharded updates [3] rows this rank stacked
+    size_t down_flag = 0;                               // offset in h_down of the word k_shard_unpack raises when a peer's block arrives poisoned
     UpdateWs ws;
     // pinned host arenas
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
@@ -157,7 +162,8 @@ struct lvk_ekf {
     void (*on_consumed)(void*, int) = nullptr; void* on_consumed_user = nullptr;
     // optional HIP-event bracket around the H P GEMM of every update (bench: MFMA utilisation of the P H^T contraction)
     bool prof_on = false; double prof_ms = 0, prof_flops = 0; long prof_n = 0;
-    struct ProfEv { hipEvent_t a, b; double flops; };
+    double prof_qr_ms = 0, prof_qr_flops = 0, prof_qr_rows = 0; long prof_qr_n = 0;     // the same bracket around every k_qr_sparse level (kind 1)
+    struct ProfEv { hipEvent_t a, b; double flops; int kind = 0; double rows = 0; };
     std::vector<ProfEv> prof_pending; std::vector<hipEvent_t> prof_free;
 };
 
@@ -252,6 +258,7 @@ static lvk_status d2h_sync(lvk_ekf* e, void* dst, const void* src, size_t bytes)
 {
     if (bytes) EKF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->ctx->stream));
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    if (e->shard.fn) { int* f = (int*)(e->h_down + e->down_flag); if (*f) { const int mask = *f; *f = 0; return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "sharded update: the block of a peer rank (mask 0x%x) arrived invalid - that rank failed before the exchange", mask); } }
     return LVK_OK;
 }
 // P <- P[idx, idx] (ping-pong)
@@ -813,11 +820,13 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
     }
     return LVK_OK;
 }
+static lvk_status shard_peer_check(lvk_ekf* e);
 // results of the queued jobs (+ optionally n_dx doubles of d_dx in the same sync)
 static lvk_status fetch_feature_results(lvk_ekf* e, std::vector<RowJob>& jobs, double* dx = nullptr, size_t n_dx = 0)
 {
     const FeatResult* ho = (const FeatResult*)(e->h_down + e->down_feat);
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    { lvk_status ps = shard_peer_check(e); if (ps != LVK_OK) return ps; }
     for (size_t i = 0; i < jobs.size(); ++i) jobs[i].res = ho[i];
     if (n_dx) memcpy(dx, e->h_down + e->down_dx, sizeof(double) * n_dx);      // written by the W^T[W|w] launch of the update
     return LVK_OK;
@@ -904,63 +913,108 @@ static int shard_owner(const std::vector<size_t>& b, size_t job) { int g = 0; wh
 // rows of the groups it owns, compresses them (structure-aware TSQR), packs the block together with the gate results of its jobs
 // (job_b != nullptr), all-gathers, and unpacks every rank's block into d_H / d_r in rank order.  On return `groups` describes the
 // stacked blocks (the input of the replicated second stage) and *m_out is their row count.
+// Householder flops of one level of the structure-aware compression, on the structure actually factored (2 r c^2 - 2/3 c^3
+// per node, here summed exactly): a node of r rows restricted to its c columns (+ the residual column) applies min(r, c) reflectors,
+// reflector j costing 4 (r - j)(c + 1 - j) flops (dot products + updates of the trailing columns).  Pass-through nodes cost nothing.
+static double qr_level_flops(const QrPlanLevel& L)
+{
+    double f = 0;
+    for (const QrBlock& b : L.blocks) {
+        if (b.copy) continue;
+        const int k = std::min(b.in_rows, b.ncols);
+        for (int j = 0; j < k; ++j) f += 4.0 * (double)(b.in_rows - j) * (double)(b.ncols + 1 - j);
+    }
+    return f;
+}
+// one level of the compression, bracketed by HIP events on the filter's stream when profiling is on (bench: roofline of the TSQR)
+static lvk_status qr_level_launch(lvk_ekf* e, const QrPlanLevel& L, const double* Hin, const double* rin, double* Hout, double* rout, const QrBlock* d_blocks, const int* d_cols, int ncols)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e->prof_on) {
+        auto take = [&]() { hipEvent_t ev; if (!e->prof_free.empty()) { ev = e->prof_free.back(); e->prof_free.pop_back(); } else hipEventCreate(&ev); return ev; };
+        a = take(); b = take();
+        hipEventRecord(a, e->ctx->stream);
+    }
+    lvk_status st = lvk_qr_sparse_level(e->ctx, Hin, e->ld, rin, Hout, e->ld, rout, d_blocks, (int)L.blocks.size(), d_cols, ncols, L.lds);
+    if (a) { hipEventRecord(b, e->ctx->stream); e->prof_pending.push_back({a, b, qr_level_flops(L), 1, (double)L.in_rows}); }
+    return st;
+}
+static lvk_status shard_peer_check(lvk_ekf* e)
+{   // call after a stream sync: did k_shard_unpack find a peer's block poisoned (that rank failed before the exchange)?
+    if (!e->shard.fn) return LVK_OK;
+    int* f = (int*)(e->h_down + e->down_flag);
+    if (*f == 0) return LVK_OK;
+    const int mask = *f; *f = 0;
+    return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "sharded update: the block of a peer rank (mask 0x%x) arrived invalid - that rank failed before the exchange", mask);
+}
 static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std::vector<RowGroup>& groups, int ncols, const std::vector<size_t>* job_b, int* m_out)
 {
     auto& S = e->shard; const int W = S.world, me = S.rank;
     std::vector<std::vector<RowGroup>> gr((size_t)W), outg((size_t)W);
-    std::vector<StackRow> lmap;
+    std::vector<StackRow> lmap; std::vector<int> m_of((size_t)W, 0);
     { size_t mi = 0; int lrow = 0;
       for (const RowGroup& g : groups) {
-          gr[(size_t)g.owner].push_back(g);
+          gr[(size_t)g.owner].push_back(g); m_of[(size_t)g.owner] += g.rows;
           if (g.owner == me) for (int k = 0; k < g.rows; ++k) { StackRow sr = map[mi + (size_t)k]; sr.dst_row = lrow++; lmap.push_back(sr); }
           mi += (size_t)g.rows;
       } }
-    std::vector<int> kk((size_t)W, 0); std::vector<QrPlanLevel> my_levels;
+    std::vector<int> kk((size_t)W, 0); std::vector<QrPlanLevel> my_levels; std::vector<size_t> need((size_t)W, 0);
     for (int g = 0; g < W; ++g) {
         std::vector<QrPlanLevel> lv;
         lvk_qr_sparse_plan(gr[(size_t)g], ncols, lv, &kk[(size_t)g], &outg[(size_t)g]);
+        need[(size_t)g] = sizeof(StackRow) * (size_t)m_of[(size_t)g] + 64;
+        for (const QrPlanLevel& L : lv) need[(size_t)g] += sizeof(QrBlock) * L.blocks.size() + sizeof(int) * (L.cols.size() + 1) + 128;
         if (g == me) my_levels.swap(lv);
     }
-    const int m_loc = (int)lmap.size();
-    if (m_loc > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m_loc);
-    lvk_status st = stack_rows(e, lmap, e->d_H, ncols, e->d_r);
-    if (st != LVK_OK) return st;
-    double* X = e->d_H; double* rX = e->d_r;
-    for (QrPlanLevel& L : my_levels) {
-        QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
-        if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
-        memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
-        st = flush_uploads(e);
-        double* Ho = (X == e->d_H) ? e->d_Hb : e->d_H; double* ro = (rX == e->d_r) ? e->d_rb : e->d_r;
-        if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, X, e->ld, rX, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), ncols, L.lds);
-        if (st != LVK_OK) return st;
-        X = Ho; rX = ro;
-    }
+    // ---- capacity checks.  Every rank plans every rank's share from the same inputs, so each test below has the same outcome on
+    //      all ranks: a capacity error is raised everywhere, BEFORE anybody enters the collective (nobody is left waiting in it).
     int k_max = 0, j_max = 0, m_tot = 0;
-    ShardMeta* hm = up_alloc<ShardMeta>(e, (size_t)W);
-    if (!hm) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     for (int g = 0; g < W; ++g) {
-        hm[g].job_lo = job_b ? (int)(*job_b)[(size_t)g] : 0; hm[g].job_n = job_b ? (int)((*job_b)[(size_t)g + 1] - (*job_b)[(size_t)g]) : 0;
-        hm[g].k = kk[(size_t)g]; hm[g].row_off = m_tot; m_tot += kk[(size_t)g];
-        k_max = std::max(k_max, kk[(size_t)g]); j_max = std::max(j_max, hm[g].job_n);
+        if (m_of[(size_t)g] > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: rank %d would stack %d measurement rows (capacity %d)", g, m_of[(size_t)g], e->hrows);
+        if (kk[(size_t)g] > S.xk_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: rank %d's compressed block has %d rows (exchange capacity %d)", g, kk[(size_t)g], S.xk_cap);
+        if (e->up_off + need[(size_t)g] + sizeof(ShardMeta) * (size_t)W + 256 > e->up_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: upload arena too small for rank %d's plan", g);
+        k_max = std::max(k_max, kk[(size_t)g]); m_tot += kk[(size_t)g];
+        if (job_b) j_max = std::max(j_max, (int)((*job_b)[(size_t)g + 1] - (*job_b)[(size_t)g]));
     }
     if (m_tot > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m_tot);
     const size_t res_bytes = ((size_t)j_max * sizeof(FeatResult) + 255) & ~(size_t)255;
-    const size_t bytes = std::max(res_bytes + (size_t)k_max * (size_t)(ncols + 1) * sizeof(double), (size_t)256);
-    if (bytes > S.cap) {                                 // grow-only exchange buffers (a sync, then never again at this size)
-        EKF_HIP(hipStreamSynchronize(e->ctx->stream));
-        if (S.d_send) hipFree(S.d_send); if (S.d_recv) hipFree(S.d_recv);
-        S.cap = bytes + bytes / 2; S.d_send = S.d_recv = nullptr;
-        if (hipMalloc((void**)&S.d_send, S.cap) != hipSuccess || hipMalloc((void**)&S.d_recv, S.cap * (size_t)W) != hipSuccess)
-            return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "exchange buffers: allocation of %zu bytes failed", S.cap * (size_t)(W + 1));
-    }
-    st = flush_uploads(e);
-    if (st == LVK_OK) st = lvk_shard_pack(e->ctx, e->d_fout + hm[me].job_lo, hm[me].job_n, X, e->ld, rX, kk[(size_t)me], ncols, S.d_send, res_bytes);
-    if (st != LVK_OK) return st;
-    st = S.fn(S.user, S.d_send, S.d_recv, bytes, (void*)e->ctx->stream);
+    const size_t bytes = LVK_SHARD_HDR + res_bytes + std::max((size_t)k_max * (size_t)(ncols + 1) * sizeof(double), (size_t)256);
+    if (bytes > S.cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: %zu bytes per rank exceed the exchange buffers (%zu)", bytes, S.cap);
+    ShardMeta* hm = up_alloc<ShardMeta>(e, (size_t)W);
+    if (!hm) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    { int off = 0;
+      for (int g = 0; g < W; ++g) {
+          hm[g].job_lo = job_b ? (int)(*job_b)[(size_t)g] : 0; hm[g].job_n = job_b ? (int)((*job_b)[(size_t)g + 1] - (*job_b)[(size_t)g]) : 0;
+          hm[g].k = kk[(size_t)g]; hm[g].row_off = off; off += kk[(size_t)g];
+      } }
+    // ---- this rank's share.  From here on a failure is local (a launch error, a broken device): the rank still enters the
+    //      collective, with a poisoned header, so that its peers get an error from k_shard_unpack instead of waiting forever.
+    const int m_loc = (int)lmap.size();
+    double* X = e->d_H; double* rX = e->d_r;
+    auto local = [&]() -> lvk_status {
+        lvk_status st = stack_rows(e, lmap, e->d_H, ncols, e->d_r);
+        if (st != LVK_OK) return st;
+        for (QrPlanLevel& L : my_levels) {
+            QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
+            if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+            memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
+            st = flush_uploads(e);
+            double* Ho = (X == e->d_H) ? e->d_Hb : e->d_H; double* ro = (rX == e->d_r) ? e->d_rb : e->d_r;
+            if (st == LVK_OK) st = qr_level_launch(e, L, X, rX, Ho, ro, dev(e, hb), dev(e, hc), ncols);
+            if (st != LVK_OK) return st;
+            X = Ho; rX = ro;
+        }
+        st = flush_uploads(e);
+        if (st == LVK_OK) st = lvk_shard_pack(e->ctx, e->d_fout + hm[me].job_lo, hm[me].job_n, X, e->ld, rX, kk[(size_t)me], ncols, S.d_send, res_bytes, me);
+        return st;
+    };
+    const lvk_status st_local = local();
+    if (st_local != LVK_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(S.d_send, 0xFF, LVK_SHARD_HDR, e->ctx->stream); }
+    lvk_status st = S.fn(S.user, S.d_send, S.d_recv, bytes, (void*)e->ctx->stream);
+    if (st_local != LVK_OK) return st_local;
     if (st != LVK_OK) return lvk_set_error(e->ctx, st, "sharded update: the exchange callback failed");
     FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
-    st = lvk_shard_unpack(e->ctx, S.d_recv, bytes, res_bytes, dev(e, hm), W, ncols, k_max, e->d_fout, d_fh, e->d_H, e->ld, e->d_r);
+    st = lvk_shard_unpack(e->ctx, S.d_recv, bytes, res_bytes, dev(e, hm), W, ncols, k_max, e->d_fout, d_fh, e->d_H, e->ld, e->d_r, (int*)(e->dh_down + e->down_flag));
     if (st != LVK_OK) return st;
     S.stats[0]++; S.stats[1] += (long)bytes; S.stats[3] += m_loc;
     groups.clear();
@@ -989,7 +1043,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
                 memcpy(hb, L.blocks.data(), sizeof(QrBlock) * L.blocks.size()); memcpy(hc, L.cols.data(), sizeof(int) * L.cols.size());
                 st = flush_uploads(e);
                 double* Ho = (H == e->d_H) ? e->d_Hb : e->d_H; double* ro = (r == e->d_r) ? e->d_rb : e->d_r;
-                if (st == LVK_OK) st = lvk_qr_sparse_level(e->ctx, H, e->ld, r, Ho, e->ld, ro, dev(e, hb), (int)L.blocks.size(), dev(e, hc), e->N, L.lds);
+                if (st == LVK_OK) st = qr_level_launch(e, L, H, r, Ho, ro, dev(e, hb), dev(e, hc), e->N);
                 if (st != LVK_OK) return st;
                 H = Ho; r = ro;
                 e->qr_stats[1]++;
@@ -1009,7 +1063,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     if (e->prof_on && m > 0) {
         auto take = [&]() { hipEvent_t ev; if (!e->prof_free.empty()) { ev = e->prof_free.back(); e->prof_free.pop_back(); } else hipEventCreate(&ev); return ev; };
         ws.ev_a = take(); ws.ev_b = take();
-        e->prof_pending.push_back({ws.ev_a, ws.ev_b, 2.0 * m * (double)e->N * (double)e->N});
+        e->prof_pending.push_back({ws.ev_a, ws.ev_b, 2.0 * m * (double)e->N * (double)e->N, 0, 0.0});
     }
     st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, H, e->ld, m, r, e->sigma2, e->d_dx, ws);
     if (st != LVK_OK) return st;
@@ -1158,7 +1212,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             // No feature enters the state in this update, so nothing on the host depends on the gate before the update is
             // launched: every candidate row gets its slot, the device zeroes the rows of rejected features, and gate results and
             // dx come back in ONE sync.
-            const bool sharded = e->shard.world > 1;
+            const bool sharded = e->shard.fn != nullptr;
             std::vector<size_t> jb; JobRanges own;
             if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
             begin_defer(e);                             // the jobs and the stacking map go up in one copy
@@ -1193,18 +1247,18 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             TR(TR_RLF_INJ);
             return LVK_OK;
         }
-        // A feature is about to enter the state: the gate has to be read before the rows are laid out.  Sharded: the (few) new
-        // features' jobs run on every rank (their first rows initialise the new covariance columns everywhere), the rest is split;
-        // a first exchange carries only the gate results, the second one (below) the compressed blocks.
-        const bool sharded = e->shard.world > 1;
+        // A feature is about to enter the state: its gate has to be read before the rows are laid out.  Sharded: the (few) new
+        // features' jobs run on every rank (their first rows initialise the new covariance columns everywhere, and every rank reads
+        // their gate from its own results), the rest is split.  The other jobs' rows all get their slot and the device zeroes the
+        // rows of rejected features - exactly as in the branch above - so their gate results travel WITH the compressed blocks:
+        // one exchange per update, and the host reads them after the update together with dx.
+        const bool sharded = e->shard.fn != nullptr;
         std::vector<size_t> jb; JobRanges rgs;
         if (sharded) {
             shard_bounds(jobs, j_ekf, jobs.size(), e->shard.world, jb);
             rgs.push_back({0, j_ekf}); rgs.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]});
             st = launch_feature_rows(e, jobs, &rgs);
-            std::vector<StackRow> none; std::vector<RowGroup> gnone; int m0 = 0;
-            if (st == LVK_OK) st = shard_stage1(e, none, gnone, N, &jb, &m0);
-            if (st == LVK_OK) st = fetch_feature_results(e, jobs);
+            if (st == LVK_OK) st = fetch_feature_results(e, jobs);          // local sync: only jobs [0, j_ekf) are looked at before the exchange
         } else st = run_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
         auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
@@ -1212,8 +1266,13 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         // ---- accepted sets and row layout: H_o = [H_msckf ; H_ekf ; top rows of the new block] (:1612-1626)
         std::vector<StackRow> map_o, map_1; std::vector<RowGroup> grp;
         int rows_m = 0, rows_e = 0, top = 0;
-        for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m, -1, &grp, e, N, own_of(k)); rows_m += jobs[k].res.rows; }
-        for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, -1, &grp, e, N, own_of(k)); rows_e += 2; }
+        if (sharded) {
+            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, own_of(k)); rows_m += r; }
+            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); rows_e += 2; }
+        } else {
+            for (size_t k = j_msckf; k < jobs.size(); ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], jobs[k].res.first_row, jobs[k].res.rows, rows_m, -1, &grp, e, N, own_of(k)); rows_m += jobs[k].res.rows; }
+            for (size_t k = j_ekf; k < j_msckf; ++k) if (gate_ok(e, jobs[k])) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, -1, &grp, e, N, own_of(k)); rows_e += 2; }
+        }
         std::vector<long long> acc_ids; std::vector<double> h2;
         std::vector<size_t> acc_jobs;
         for (size_t k = 0; k < j_ekf; k += 2) {
@@ -1231,7 +1290,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         int m = rows_m + rows_e + top; const int n_acc = (int)acc_ids.size();
         if (m + n_acc > 0) {
             if (m > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m);
-            if (sharded) { st = shard_stage1(e, map_o, grp, N, nullptr, &m); e->shard.stats[2]++; }      // the new features' top rows belong to rank 0 (owner 0)
+            if (sharded) { st = shard_stage1(e, map_o, grp, N, &jb, &m); e->shard.stats[2]++; }         // the new features' top rows belong to rank 0 (owner 0)
             else st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             if (st == LVK_OK && n_acc) st = stack_rows(e, map_1, e->d_H1, N, e->d_r1);
             if (st != LVK_OK) return st;
@@ -1251,10 +1310,19 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             st = d2h_sync(e, dx.data(), e->d_dx, sizeof(double) * (size_t)(N + n_acc));
             if (st != LVK_OK) return st;
             TR(TR_RLF_DX);
-            inject(e, dx.data());
-            e->N = N + n_acc;
-            e->last_update_time = e->s.t;
-            e->counters[0]++;
+            bool effective = true;
+            if (sharded) {                              // every rank's gate results arrived with the blocks (k_shard_unpack wrote the host mirror)
+                const FeatResult* ho = (const FeatResult*)(e->h_down + e->down_feat);
+                int accepted = top;
+                for (size_t k = j_ekf; k < jobs.size(); ++k) { jobs[k].res = ho[k]; if (gate_ok(e, jobs[k])) accepted += k >= j_msckf ? job_rows(jobs[k]) : 2; }
+                effective = accepted + n_acc > 0;       // everything gated out: all stacked rows were zero, the update changed nothing (as the unsharded filter, which skips it)
+            }
+            if (effective) {
+                inject(e, dx.data());
+                e->N = N + n_acc;
+                e->last_update_time = e->s.t;
+                e->counters[0]++;
+            }
         }
     } else {
         for (long long id : msckf) { auto it = e->map.find(id); if (it != e->map.end()) it->second.is_initialized = false; }
@@ -1427,7 +1495,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         std::vector<RowJob> jobs;
         for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
         // measurementUpdate_msckf (:1420-1602), gate decided on the device (see remove_lost_features): one sync for gate + dx
-        const bool sharded = e->shard.world > 1;
+        const bool sharded = e->shard.fn != nullptr;
         std::vector<size_t> jb; JobRanges own;
         if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
         begin_defer(e);
@@ -1661,7 +1729,8 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     e->up_cap = (size_t)32 << 20;
     e->down_feat = (sizeof(TriResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_dx = (e->down_feat + sizeof(FeatResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
-    e->down_cap = e->down_dx + sizeof(double) * (size_t)(e->ld + 64);
+    e->down_flag = (e->down_dx + sizeof(double) * (size_t)(e->ld + 64) + 255) & ~(size_t)255;
+    e->down_cap = e->down_flag + 256;
     ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
     if (ok) {
         // both arenas are read / written by the kernels in place (device-mapped pinned memory): a few KB per update over PCIe
@@ -1788,7 +1857,10 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
     for (auto& pe : e->prof_pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) { e->prof_ms += ms; e->prof_flops += pe.flops; e->prof_n += 1; }
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            if (pe.kind == 0) { e->prof_ms += ms; e->prof_flops += pe.flops; e->prof_n += 1; }
+            else { e->prof_qr_ms += ms; e->prof_qr_flops += pe.flops; e->prof_qr_rows += pe.rows; e->prof_qr_n += 1; }
+        }
         e->prof_free.push_back(pe.a); e->prof_free.push_back(pe.b);
     }
     e->prof_pending.clear();
@@ -1819,7 +1891,25 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
 lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn, void* user)
 {
     if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_set_shard: bad argument");
-    e->shard.rank = rank; e->shard.world = world; e->shard.fn = fn; e->shard.user = user;
+    auto& S = e->shard;
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    if (S.d_send) hipFree(S.d_send); if (S.d_recv) hipFree(S.d_recv);
+    S.d_send = S.d_recv = nullptr; S.cap = 0; S.xk_cap = 0;
+    S.rank = rank; S.world = world; S.fn = fn; S.user = user;
+    if (!fn) return LVK_OK;                             // world 1 without a transport: the unsharded filter
+    // Exchange buffers for the largest block a rank may send: every job's gate result + xk_cap rows of R.  Allocated here, once, so
+    // that an allocation failure is a set-up error on the rank it happens on and never a rank missing from a collective later.
+    S.xk_cap = std::min(e->hrows, 4 * e->nmax);
+    const size_t res_cap = (sizeof(FeatResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
+    S.cap = LVK_SHARD_HDR + res_cap + (size_t)S.xk_cap * (size_t)(e->nmax + 1) * sizeof(double);
+    if (hipMalloc((void**)&S.d_send, S.cap) != hipSuccess || hipMalloc((void**)&S.d_recv, S.cap * (size_t)world) != hipSuccess) {
+        (void)hipGetLastError();
+        if (S.d_send) hipFree(S.d_send);
+        const size_t want = S.cap;
+        S.d_send = S.d_recv = nullptr; S.cap = 0; S.fn = nullptr; S.world = 1; S.rank = 0;
+        return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "lvk_ekf_set_shard: exchange buffers (%zu bytes x %d) could not be allocated", want, world + 1);
+    }
+    *(int*)(e->h_down + e->down_flag) = 0;
     return LVK_OK;
 }
 void lvk_ekf_shard_stats(const lvk_ekf* e, long* out8)
@@ -1833,6 +1923,13 @@ lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* out3)
     if (!e) return LVK_ERR_ARG;
     if (out3) { out3[0] = e->prof_ms; out3[1] = e->prof_flops; out3[2] = (double)e->prof_n; }
     e->prof_ms = e->prof_flops = 0; e->prof_n = 0; e->prof_on = enable != 0;
+    return LVK_OK;
+}
+lvk_status lvk_ekf_profile_qr(lvk_ekf* e, double* out4)
+{   // [ms inside k_qr_sparse levels, their Householder flops on the structure factored, launches, rows entering the levels] since the last call, then reset
+    if (!e || !out4) return LVK_ERR_ARG;
+    out4[0] = e->prof_qr_ms; out4[1] = e->prof_qr_flops; out4[2] = (double)e->prof_qr_n; out4[3] = e->prof_qr_rows;
+    e->prof_qr_ms = e->prof_qr_flops = e->prof_qr_rows = 0; e->prof_qr_n = 0;
     return LVK_OK;
 }
 int lvk_ekf_dim(const lvk_ekf* e) { return e ? e->N : 0; }

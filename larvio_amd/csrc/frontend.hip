@@ -109,6 +109,7 @@ lvk_status lvk_context_set_stream(lvk_context* ctx, void* hip_stream)
     return LVK_OK;
 }
 
+void* lvk_context_get_stream(const lvk_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 lvk_status lvk_sync(lvk_context* ctx) { if (!ctx) return LVK_ERR_ARG; LVK_HIP(ctx, hipStreamSynchronize(ctx->stream)); return LVK_OK; }
 const char* lvk_last_error(const lvk_context* ctx) { return ctx ? ctx->err : "null context"; }
 

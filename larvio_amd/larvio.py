@@ -252,6 +252,13 @@ class LarVio:
         o = np.zeros(3); self.ctx.check(_L().lvk_ekf_profile(self._h, int(enable), _p(o)))
         return dict(ms=o[0], flops=o[1], launches=int(o[2]))
 
+    def profile_qr(self):
+        """HIP-event time of the structure-aware TSQR levels (k_qr_sparse) since the last call, while profile(True) is on:
+        dict(ms, flops on the structure factored, launches, rows entering the levels)"""
+        L = _L(); L.lvk_ekf_profile_qr.argtypes = [C.c_void_p, C.c_void_p]; L.lvk_ekf_profile_qr.restype = C.c_int
+        o = np.zeros(4); self.ctx.check(L.lvk_ekf_profile_qr(self._h, _p(o)))
+        return dict(ms=o[0], flops=o[1], launches=int(o[2]), rows=o[3])
+
     def imu_intrinsics(self):
         """T1 T2 T3 A1 A2 A3 M1 M2 (24 numbers; state columns 22..45 when calib_imu_instrinsic = 1)"""
         o = np.zeros(24); self.ctx.check(_L().lvk_ekf_get_imu_intrinsics(self._h, _p(o))); return o

@@ -99,6 +99,57 @@ def test_two_ranks_on_one_gpu_are_bit_identical_and_match_the_unsharded_filter(g
         assert a[6][k] == cnt_ref[k], (k, a[6], cnt_ref)
     for r in (a, b):
         st = r[7]
-        assert st["sharded_updates"] >= 30 and st["exchanges"] >= st["sharded_updates"] and st["exchanges"] == r[8] and st["bytes_sent"] > 0
+        # ONE all-gather per sharded update, also when new features enter the state (their gate is computed on every rank)
+        assert st["sharded_updates"] >= 30 and st["exchanges"] == st["sharded_updates"] and st["exchanges"] == r[8] and st["bytes_sent"] > 0
     assert 0.25 < a[7]["rows_stacked"] / max(a[7]["rows_stacked"] + b[7]["rows_stacked"], 1) < 0.75   # the rows really were split
     print("sharded x2 on one GPU: updates", n_ref, "worst rel vs unsharded", worst, rel(a[3], P_ref), a[7], b[7])
+
+
+def test_rccl_transport_executes_at_world_one(gpu_ctx):
+    """The built-in transport on hardware: lvk_shard_unique_id -> lvk_shard_comm_create(rank 0, world 1) (ncclCommInitRank through the
+    late-bound librccl) -> lvk_shard_allgather_rccl on device buffers, enqueued on the context's own stream; the bytes must arrive."""
+    import ctypes as C
+    from larvio_amd import sharding
+    from larvio_amd._lib import lib
+    uid = sharding.unique_id()
+    assert len(uid) == 128 and any(uid)
+    sh = sharding.RcclShard(gpu_ctx, 0, 1, uid)
+    L = lib()
+    L.lvk_shard_allgather_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]; L.lvk_shard_allgather_rccl.restype = C.c_int
+    L.lvk_shard_comm_error.argtypes = [C.c_void_p]; L.lvk_shard_comm_error.restype = C.c_char_p
+    rng = np.random.default_rng(3)
+    for n in (256, 600_000):
+        src = rng.integers(0, 256, n).astype(np.uint8)
+        d_s = gpu_ctx.to_device(src); d_r = gpu_ctx.to_device(np.zeros(n, np.uint8))
+        rc = L.lvk_shard_allgather_rccl(sh._h, C.c_void_p(d_s.ptr), C.c_void_p(d_r.ptr), n, C.c_void_p(gpu_ctx.stream))
+        assert rc == 0, L.lvk_shard_comm_error(sh._h)
+        gpu_ctx.sync()
+        assert np.array_equal(gpu_ctx.to_host(d_r, np.uint8, (n,)), src)
+    sh.close()
+
+
+def test_sharded_filter_through_rccl_at_world_one_equals_the_unsharded_filter(gpu_ctx):
+    """lvk_ekf_set_shard(rank 0, world 1, lvk_shard_allgather_rccl): the filter takes the sharded branch - per-rank rows, first
+    compression stage, k_shard_pack -> ncclAllGather -> k_shard_unpack, replicated second stage - with RCCL as the transport on one
+    GPU, through 40 updates including the ones that admit new in-state features, and must agree with the unsharded filter
+    (another reduction tree, same information) with identical discrete decisions; one exchange per sharded update."""
+    import larvio_amd
+    from larvio_amd import sharding
+    sim = _sim()
+    ref = larvio_amd.LarVio(sim["cfg"], gpu_ctx); assert ref.initialize()
+    n_ref, s_ref, P_ref, cid_ref, fid_ref, cnt_ref = _run(ref, sim)
+    ref.close()
+    be = larvio_amd.LarVio(sim["cfg"], gpu_ctx); assert be.initialize()
+    sh = sharding.RcclShard(gpu_ctx, 0, 1, sharding.unique_id())
+    be.set_shard(*sh.args())
+    n, s, P, cid, fid, cnt = _run(be, sim)
+    st = be.shard_stats()
+    be.close(); sh.close()
+    rel = lambda x, y: float(np.abs(np.asarray(x) - np.asarray(y)).max() / max(np.abs(np.asarray(y)).max(), 1e-300))
+    worst = max(rel(s[k], s_ref[k]) for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"))
+    assert n == n_ref and worst < 1e-7 and rel(P, P_ref) < 1e-7, (n, n_ref, worst, rel(P, P_ref))
+    assert np.array_equal(cid, cid_ref) and np.array_equal(fid, fid_ref)
+    for k in ("hybrid", "msckf", "gated_in", "gated_out", "map"):
+        assert cnt[k] == cnt_ref[k], (k, cnt, cnt_ref)
+    assert st["sharded_updates"] >= 30 and st["exchanges"] == st["sharded_updates"] and st["bytes_sent"] > 0 and st["rows_stacked"] > 0, st
+    print("sharded through RCCL at world 1: updates", n, "worst rel vs unsharded", worst, rel(P, P_ref), st)
