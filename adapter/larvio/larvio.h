@@ -47,12 +47,14 @@ class LarVio {
 
   private:
     void writeLogs();
+    void finish();                                        // waits for a deferred update, then the logs / map points that follow it
     std::string config_file;
     lvk_ekf_config cfg;
     lvk_context* ctx;
     lvk_ekf* ekf;
     std::FILE *f_state, *f_takeoff;
     bool takeoff_written;
+    bool blocking, pending;                               // LVK_ADAPTER_BLOCKING=1: processFeatures runs the update before it returns
     std::map<FeatureIDType, Eigen::Vector3d> active_slam_features;   // refreshed after every update (larvio.cpp:455-458), cleared on read
 };
 

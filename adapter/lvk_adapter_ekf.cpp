@@ -5,14 +5,28 @@
 #include "lvk_config.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace larvio {
 
-LarVio::LarVio(std::string& config_file_) : config_file(config_file_), cfg(), ctx(nullptr), ekf(nullptr), f_state(nullptr), f_takeoff(nullptr), takeoff_written(false) {}
+// processFeatures is DEFERRED by default: it returns as soon as its return value and the IMU samples to erase are known (both are
+// final before any arithmetic: lvk_ekf_process_async) and the update runs on the filter's worker thread and stream; every getter,
+// the next processFeatures and the destructor wait for it first, so callers see exactly the values the blocking call gives.  With the
+// reference's drivers this lets processImage of frame k+1 run while the update of frame k is still in flight whenever the driver
+// does not ask for the pose in between (the ROS nodelet with no odometry subscriber, a logger that reads the pose one frame late);
+// a driver that calls getTbw() right after processFeatures (app/larvioMain.cpp:139) simply waits there instead.
+// LVK_ADAPTER_BLOCKING=1 restores the blocking call.
+LarVio::LarVio(std::string& config_file_) : config_file(config_file_), cfg(), ctx(nullptr), ekf(nullptr), f_state(nullptr), f_takeoff(nullptr), takeoff_written(false),
+                                            blocking(false), pending(false)
+{
+    const char* b = std::getenv("LVK_ADAPTER_BLOCKING");
+    blocking = b && std::atoi(b) != 0;
+}
 
 LarVio::~LarVio()
 {   // larvio.cpp:47-55
+    finish();
     if (ekf) lvk_ekf_destroy(ekf);
     if (ctx) lvk_context_destroy(ctx);
     if (f_state) std::fclose(f_state);
@@ -33,6 +47,7 @@ bool LarVio::initialize()
 
 void LarVio::reset()
 {
+    finish();
     if (ekf) { lvk_ekf_destroy(ekf); ekf = nullptr; }
     active_slam_features.clear(); takeoff_written = false;
     initialize();
@@ -56,19 +71,33 @@ bool LarVio::processFeatures(MonoCameraMeasurementPtr msg, std::vector<ImuData>&
     }
     static_assert(sizeof(MonoFeatureMeasurement) == sizeof(lvk_feature_obs), "MonoFeatureMeasurement is the 72-byte wire record");
     const lvk_feature_obs* feats = msg->features.empty() ? nullptr : reinterpret_cast<const lvk_feature_obs*>(msg->features.data());
+    finish();                                                                         // the previous update's logs and map points, before this one changes the state
     int used = 0, updated = 0;
-    if (lvk_ekf_process(ekf, msg->timeStampToSec, feats, (int)msg->features.size(), imu, (int)imu_msg_buffer.size(), &used, &updated) != LVK_OK) {
+    const lvk_status st = blocking ? lvk_ekf_process(ekf, msg->timeStampToSec, feats, (int)msg->features.size(), imu, (int)imu_msg_buffer.size(), &used, &updated)
+                                   : lvk_ekf_process_async(ekf, msg->timeStampToSec, feats, (int)msg->features.size(), imu, (int)imu_msg_buffer.size(), &used, &updated);
+    if (st != LVK_OK) {
         std::printf("LarVio::processFeatures: %s\n", lvk_last_error(ctx));
         return false;
     }
     imu_msg_buffer.erase(imu_msg_buffer.begin(), imu_msg_buffer.begin() + used);      // larvio.cpp:511-512, StaticInitializer.cpp:146-147
     if (!updated) return false;
+    pending = true;                                                                   // logs + active_slam_features follow the update: finish()
+    if (blocking) finish();
+    return true;
+}
+
+// what the reference does at the end of processFeatures (:388, :446-458), once the (possibly deferred) update is done
+void LarVio::finish()
+{
+    if (!pending || !ekf) return;
+    pending = false;
+    int upd = 0;
+    if (lvk_ekf_wait(ekf, &upd) != LVK_OK) { std::printf("LarVio::processFeatures (deferred): %s\n", lvk_last_error(ctx)); return; }
     writeLogs();                                                                      // :388, :446-453
     // active_slam_features (:455-458): the in-state features after this update
     std::vector<int64_t> ids(4096); std::vector<double> idp(4096), pos(3 * 4096);
     const int n = lvk_ekf_get_features(ekf, ids.data(), idp.data(), pos.data(), 4096);
     for (int i = 0; i < n; ++i) active_slam_features[(FeatureIDType)ids[(size_t)i]] = Eigen::Vector3d(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]);
-    return true;
 }
 
 static Eigen::Matrix3d quat_to_rot(const double* q /* x y z w */)
@@ -84,6 +113,7 @@ static Eigen::Matrix3d quat_to_rot(const double* q /* x y z w */)
 // IMUState::T_imu_body is the identity in the reference (larvio.cpp:35) and nothing sets it: T_b_w = T_i_w, H_pose = H_vel = I.
 Eigen::Isometry3d LarVio::getTbw()
 {
+    finish();
     double s[30]; lvk_ekf_get_state(ekf, s);
     Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
     T.linear() = quat_to_rot(s + 1);
@@ -93,12 +123,14 @@ Eigen::Isometry3d LarVio::getTbw()
 
 Eigen::Vector3d LarVio::getVel()
 {
+    finish();
     double s[30]; lvk_ekf_get_state(ekf, s);
     return Eigen::Vector3d(s[5], s[6], s[7]);
 }
 
 Eigen::Matrix<double, 6, 6> LarVio::getPpose()
-{   // P_imu_pose << P_pp, P_po, P_op, P_oo  (position block first), larvio.cpp:2673-2679
+{
+    finish();   // P_imu_pose << P_pp, P_po, P_op, P_oo  (position block first), larvio.cpp:2673-2679
     const int N = lvk_ekf_dim(ekf);
     std::vector<double> P((size_t)N * N); lvk_ekf_get_cov(ekf, P.data());
     static const int idx[6] = {6, 7, 8, 0, 1, 2};
@@ -109,6 +141,7 @@ Eigen::Matrix<double, 6, 6> LarVio::getPpose()
 
 Eigen::Matrix3d LarVio::getPvel()
 {
+    finish();
     const int N = lvk_ekf_dim(ekf);
     std::vector<double> P((size_t)N * N); lvk_ekf_get_cov(ekf, P.data());
     Eigen::Matrix3d out;
@@ -118,6 +151,7 @@ Eigen::Matrix3d LarVio::getPvel()
 
 void LarVio::getSwPoses(std::vector<Eigen::Isometry3d>& swPoses)
 {
+    finish();
     swPoses.clear();
     std::vector<lvk_clone> c(128);
     const int n = lvk_ekf_get_clones(ekf, c.data(), 128);
@@ -131,6 +165,7 @@ void LarVio::getSwPoses(std::vector<Eigen::Isometry3d>& swPoses)
 
 void LarVio::getStableMapPointPositions(std::map<larvio::FeatureIDType, Eigen::Vector3d>& mMapPoints)
 {
+    finish();
     std::vector<int64_t> ids(4096); std::vector<double> pos(3 * 4096);
     for (;;) {                                                       // the library hands them out in chunks and forgets them, as the reference clears its map
         const int n = lvk_ekf_take_lost_features(ekf, ids.data(), pos.data(), 4096);
@@ -141,6 +176,7 @@ void LarVio::getStableMapPointPositions(std::map<larvio::FeatureIDType, Eigen::V
 
 void LarVio::getActiveeMapPointPositions(std::map<larvio::FeatureIDType, Eigen::Vector3d>& mMapPoints)
 {
+    finish();
     for (const auto& item : active_slam_features) mMapPoints[item.first] = item.second;
     active_slam_features.clear();
 }

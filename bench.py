@@ -68,15 +68,21 @@ class Run:
     """One estimator (front-end + filter + driver) fed frame by frame; the same object drives the pre-roll, the warm-up and the
     timed steps."""
 
-    def __init__(self, wl, args, local_rank, imu_all, seq, ts, sequential, torch_stream=None, shard=None):
+    def __init__(self, wl, args, local_rank, imu_all, seq, ts, sequential, torch_stream=None, shard=None, deferred=None):
+        """sequential: one blocking lvk_vio_process per frame.  deferred ("immediate" | "late"): the adapter's schedule under a blocking
+        driver - lvk_vio_process_deferred per frame (processImage waits for its message, processFeatures queues the update and returns),
+        the pose (lvk_ekf_get_state = getTbw + getVel) read right after processFeatures as app/larvioMain.cpp:139 does, or one frame late."""
         import larvio_amd
-        from larvio_amd.vio import VioDriver, VioPipeline
+        from larvio_amd.vio import VioDriver, VioPipeline, VioDeferred
+        self.deferred = deferred; self.owed = False
+        if deferred:
+            sequential = True                            # same per-frame call shape as the blocking step: no pipeline object
         self.wl, self.seq, self.ts, self.imu_all, self.sequential = wl, seq, ts, imu_all, sequential
         self.ctx = larvio_amd.Context(local_rank, stream=torch_stream)
         self.fe = larvio_amd.ImageProcessor(wl["fcfg"], self.ctx)
         assert self.fe.initialize()
         # the filter gets its own context (= its own HIP stream): its update overlaps the next frames' front-end
-        self.ctx_be = self.ctx if sequential else larvio_amd.Context(local_rank)
+        self.ctx_be = self.ctx if (sequential and not deferred) else larvio_amd.Context(local_rank)
         self.be = larvio_amd.LarVio(wl["bcfg"], self.ctx_be)
         assert self.be.initialize()
         self.shard = None
@@ -84,7 +90,7 @@ class Run:
             from larvio_amd import sharding
             self.shard = sharding.make_shard(self.ctx_be, *shard)
             self.be.set_shard(*self.shard.args())
-        self.drv = VioDriver(self.fe, self.be, imu_all) if sequential else VioPipeline(self.fe, self.be, imu_all)
+        self.drv = VioDeferred(self.fe, self.be, imu_all) if deferred else VioDriver(self.fe, self.be, imu_all) if sequential else VioPipeline(self.fe, self.be, imu_all)
         self.his = [self.drv.visible_end(float(t)) for t in ts]
         self.inited = False
         self.i = 0                      # next frame
@@ -101,7 +107,16 @@ class Run:
                 self.drv.drain()
             self.be.set_state(t_i, R2q(tr.R_wb(t_i)), tr.p_wb(t_i), tr.vel(t_i), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
             self.inited = True
-        if self.sequential:
+        if self.deferred:
+            has, upd = self.drv.step(float(ts[i]), self.his[i], img=host_img, device_ptr=dev_ptr, stride=stride)
+            if self.deferred == "immediate":
+                if upd:
+                    self.be.state()                      # getTbw / getVel right after processFeatures: waits for the update
+            elif upd:
+                self.owed = True
+            elif self.owed:
+                self.be.state(); self.owed = False       # the pose of the previous frame's update, read after this frame's processImage
+        elif self.sequential:
             has, _ = self.drv.step(float(ts[i]), self.his[i], img=host_img, device_ptr=dev_ptr, stride=stride)
             self.ctx.sync()
         else:
@@ -111,6 +126,8 @@ class Run:
         return has
 
     def drain(self):
+        if self.deferred:
+            self.be.wait()
         if not self.sequential:
             self.drv.drain()
         self.ctx.sync(); self.ctx_be.sync()
@@ -508,6 +525,7 @@ def main():
     ap.add_argument("--cpu-baseline-frames", type=int, default=None, help="steady-state frames per CPU leg (default 300 at A/3/4, 24 at 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-pass", action="store_true", help="skip the second (device-resident) pass")
+    ap.add_argument("--no-adapter-pass", action="store_true", help="skip the passes through the adapter's schedule (deferred processFeatures under a blocking driver)")
     ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
     ap.add_argument("--sharded", action="store_true", help="config 5 across ranks: per-rank feature rows, RCCL all-gather of the compressed R")
     ap.add_argument("--no-shard-probe", action="store_true", help="skip the configs[4]-depth (sharded) filter probe appended to the default line")
@@ -581,6 +599,19 @@ def main():
         run2.close()
         del d_frames
 
+    # ---- the schedule the reference's own blocking drivers reach through the adapter classes (adapter/): processImage waits for its
+    #      message, processFeatures is deferred (lvk_ekf_process_async), the pose is read (a) right after processFeatures, as
+    #      app/larvioMain.cpp:139 does, (b) one frame late.  Same frames, same pre-roll, same K timed steps.
+    adapter = None
+    if not args.sequential and not args.no_adapter_pass and shard is None:
+        adapter = {}
+        for getters in ("immediate", "late"):
+            run3 = Run(wl, args, local_rank, imu_all, seq, ts, True, torch_stream=stream.cuda_stream, deferred=getters)
+            while run3.i < n_pre:
+                run3.step(host_img=frames[run3.i])
+            ma = timed(run3, frames, None, W, K, dist, torch)
+            run3.close()
+            adapter[getters] = ma
     # The sharded update at configs[4] depth, measured in the same invocation (filter only, simulated feature messages - seconds, no
     # rendering): at N > 1 the per-feature work is split over the N ranks with one RCCL all-gather per update, at N = 1 it is the
     # unsharded baseline of the same workload.  This is the strong-scaling curve north_star asks for "when the tracked-feature count
@@ -636,6 +667,15 @@ def main():
                "device_resident": None if md is None else {"value": round(streams * K / md["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(md["elapsed"] / K * 1e3, 4),
                                                            "p50_ms_per_frame": pct(md["e2e"], 50),
                                                            "note": "same frames, already in HBM when the timed region starts (no staging copy, no H2D)"},
+               "adapter_path": None if not adapter else {
+                   "value": round(streams * K / adapter["immediate"]["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(adapter["immediate"]["elapsed"] / K * 1e3, 4),
+                   "p50_ms_per_frame": pct(adapter["immediate"]["lat"], 50),
+                   "pose_read_one_frame_late": {"value": round(streams * K / adapter["late"]["elapsed"], 2), "ms_per_step": round(adapter["late"]["elapsed"] / K * 1e3, 4),
+                                                "p50_ms_per_frame": pct(adapter["late"]["lat"], 50)},
+                   "note": "what an UNCHANGED blocking driver (app/larvioMain.cpp:104-116 + getters at :139) gets through the adapter classes: "
+                           "lvk_frontend_process (waits for its message) + lvk_ekf_process_async per frame, pose read right after processFeatures "
+                           "(value) or after the next frame's processImage (pose_read_one_frame_late); identical results "
+                           "(tests/test_gpu_vio_driver.py::test_deferred_update_is_identical_to_blocking)"},
                "higher_is_better": True, "scaling": ("strong" if args.sharded else "weak"), "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
                "config": {"workload": wl["label"] + ", pyramid 3 levels, win %d, pub %g Hz" % (win, wl["fcfg"]["pub_frequency"]),

@@ -233,6 +233,18 @@ void       lvk_ekf_destroy(lvk_ekf* e);
  * reference would erase from it (larvio.cpp:511-512, StaticInitializer.cpp:146-147); *updated = the bool it returns. */
 lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* h_feats, int n_feats,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* updated);
+/* The same update, deferred: the call returns as soon as what the caller needs from processFeatures is known - *n_consumed (the
+ * samples to erase from the driver's buffer: a function of time stamps, the state time and td only) and *will_update (the bool
+ * processFeatures will return: always true once the filter is initialized; the cold paths - first IMU sample, static initializer,
+ * a failed filter - run synchronously inside this call and report their real result) - and the update itself runs on a worker
+ * thread of the filter, on the filter's stream.  The buffers are copied before the call returns.  Every other entry point of the
+ * filter (all getters, the next update, set_state, destroy) first waits for the queued update, so callers always see the state
+ * AFTER it: results are identical to lvk_ekf_process.  This is what lets the reference's blocking drivers
+ * (app/larvioMain.cpp:104-116: processImage; processFeatures; getters) overlap the next frame's front-end with this frame's update.
+ * lvk_ekf_wait blocks until the queued update is done and returns ITS status (*updated as lvk_ekf_process would have set it). */
+lvk_status lvk_ekf_process_async(lvk_ekf* e, double ts, const lvk_feature_obs* h_feats, int n_feats,
+                                 const lvk_imu* h_imu, int n_imu, int* n_consumed, int* will_update);
+lvk_status lvk_ekf_wait(lvk_ekf* e, int* updated);
 /* bypass the initializer (tests, benchmarks): IMU state at time t, last IMU sample (m_gyro_old / m_acc_old) */
 lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const double p[3], const double v[3],
                              const double bg[3], const double ba[3], const double gyro_old[3], const double acc_old[3]);
@@ -284,6 +296,7 @@ typedef struct lvk_shard_comm lvk_shard_comm;
 lvk_status lvk_shard_unique_id(char* h_out128);
 lvk_status lvk_shard_comm_create(lvk_context* ctx, const char* h_uid128, int rank, int world, lvk_shard_comm** out);
 void       lvk_shard_comm_destroy(lvk_shard_comm* c);
+const char* lvk_shard_rccl_path(void);                        /* which librccl the transport bound (the one next to the HIP runtime in use) */
 const char* lvk_shard_comm_error(const lvk_shard_comm* c);    /* text of the last RCCL error lvk_shard_allgather_rccl returned on it */
 lvk_status lvk_shard_allgather_rccl(void* comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
 
@@ -310,6 +323,11 @@ lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* h_clones, i
  * h_imu[0..n_imu) is the CURRENT buffer; *n_consumed tells the caller how many leading samples to drop. */
 lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img, double ts,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated);
+/* the same step with the update deferred (lvk_frontend_process, then lvk_ekf_process_async): returns when the front-end is done and
+ * the update is queued; any getter of the filter (or the next step) waits for it.  This is the schedule the adapter classes
+ * (adapter/: larvio::ImageProcessor / larvio::LarVio) give an unchanged blocking driver. */
+lvk_status lvk_vio_process_deferred(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img, double ts,
+                                    const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* will_update);
 
 /* The same loop, pipelined across two HIP streams: the filter update of frame k (worker thread, ekf's context) overlaps the
  * front-end of frame k+1 (caller's thread, fe's context).  fe and ekf must have been created on DIFFERENT lvk_contexts.

@@ -164,8 +164,30 @@ struct lvk_ekf {
     bool prof_on = false; double prof_ms = 0, prof_flops = 0; long prof_n = 0;
     double prof_qr_ms = 0, prof_qr_flops = 0, prof_qr_rows = 0; long prof_qr_n = 0;     // the same bracket around every k_qr_sparse level (kind 1)
     struct ProfEv { hipEvent_t a, b; double flops; int kind = 0; double rows = 0; };
+    struct Async;                                       // lvk_ekf_process_async: the worker that runs a queued update (created on first use)
+    Async* async = nullptr;
     std::vector<ProfEv> prof_pending; std::vector<hipEvent_t> prof_free;
 };
+
+// ------------------------------------------------------------------------- deferred updates
+// lvk_ekf_process_async hands an update to this worker and returns; the next call that looks at the filter (any getter, the next
+// update, destroy) waits for it.  A blocking driver (app/larvioMain.cpp:104-116: processImage, processFeatures, getters) then gets
+// the front-end of the next frame running while the update of this one is still in flight, as far as its own getter calls allow.
+struct lvk_ekf::Async {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    std::atomic<int> state{0};                          // 0 idle, 1 an update is queued or running
+    std::atomic<bool> stop{false};
+    double ts = 0; std::vector<lvk_feature_obs> feats; std::vector<lvk_imu> imu; int expect_used = 0;
+    lvk_status st = LVK_OK; int updated = 0; long n_deferred = 0;
+};
+static void ekf_quiesce(const lvk_ekf* e)
+{
+    lvk_ekf::Async* a = e->async;
+    if (!a || a->state.load(std::memory_order_acquire) == 0) return;
+    for (int spin = 0; spin < 40000; ++spin) { if (a->state.load(std::memory_order_acquire) == 0) return; __builtin_ia32_pause(); }
+    std::unique_lock<std::mutex> lk(a->mu);
+    a->cv.wait(lk, [&] { return a->state.load(std::memory_order_acquire) == 0; });
+}
 
 // ------------------------------------------------------------------------- host-side phase tracer (LVK_EKF_TRACE=1)
 #include <chrono>
@@ -182,6 +204,9 @@ struct EkfTrace {
 };
 static EkfTrace g_tr;
 #define TR(slot) g_tr.mark(slot)
+
+// Deferred updates (lvk_ekf_process_async): every entry point that reads or changes the filter first waits for the queued update.
+static void ekf_quiesce(const lvk_ekf* e);
 
 // ------------------------------------------------------------------------- small helpers
 // rank of a clone in the window by state id: direct-address table over [first id, last id] (ids only grow; the window spans a few
@@ -1650,6 +1675,13 @@ extern "C" {
 void lvk_ekf_destroy(lvk_ekf* e)
 {
     if (!e) return;
+    if (e->async) {
+        ekf_quiesce(e);
+        { std::lock_guard<std::mutex> lk(e->async->mu); e->async->stop.store(true); }
+        e->async->cv.notify_all();
+        if (e->async->th.joinable()) e->async->th.join();
+        delete e->async; e->async = nullptr;
+    }
     hipStreamSynchronize(e->ctx->stream);
     for (auto& pe : e->prof_pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (hipEvent_t ev : e->prof_free) hipEventDestroy(ev);
@@ -1763,6 +1795,7 @@ lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const doub
                              const double gyro_old[3], const double acc_old[3])
 {
     if (!e) return LVK_ERR_ARG;
+    ekf_quiesce(e);
     e->s.t = t; memcpy(e->s.q, q, 32); memcpy(e->s.p, p, 24); memcpy(e->s.v, v, 24); memcpy(e->s.bg, bg, 24); memcpy(e->s.ba, ba, 24);
     memcpy(e->m_gyro_old, gyro_old, 24); memcpy(e->m_acc_old, acc_old, 24);
     e->is_gravity_set = true; e->b_first_features = true;
@@ -1783,7 +1816,62 @@ static lvk_status ekf_process_guarded(lvk_ekf* e, double ts, const lvk_feature_o
 lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated)
 {
     if (n_feats > 0 && !feats) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process: bad argument");
+    if (e) ekf_quiesce(e);
     return ekf_process_guarded(e, ts, feats, n_feats, imu, n_imu, n_consumed, updated, nullptr, nullptr);
+}
+
+static void ekf_async_worker(lvk_ekf* e)
+{
+    hipSetDevice(e->ctx->device);
+    lvk_ekf::Async* a = e->async;
+    for (;;) {
+        for (int spin = 0; spin < 40000 && a->state.load(std::memory_order_acquire) != 1 && !a->stop.load(); ++spin) __builtin_ia32_pause();
+        {
+            std::unique_lock<std::mutex> lk(a->mu);
+            a->cv.wait(lk, [&] { return a->stop.load() || a->state.load(std::memory_order_acquire) == 1; });
+            if (a->stop.load()) return;
+        }
+        int used = 0, upd = 0;
+        lvk_status st = ekf_process_guarded(e, a->ts, a->feats.data(), (int)a->feats.size(), a->imu.data(), (int)a->imu.size(), &used, &upd, nullptr, nullptr);
+        if (st == LVK_OK && used != a->expect_used) {
+            st = lvk_set_error(e->ctx, LVK_ERR_DEVICE, "internal: the deferred update consumed %d IMU samples, %d were announced", used, a->expect_used);
+            e->failed = st; snprintf(e->failed_msg, sizeof e->failed_msg, "%s", e->ctx->err);
+        }
+        { std::lock_guard<std::mutex> lk(a->mu); a->st = st; a->updated = upd; a->state.store(0, std::memory_order_release); }
+        a->cv.notify_all();
+    }
+}
+
+lvk_status lvk_ekf_process_async(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* will_update)
+{
+    if (!e || !n_consumed || !will_update || (n_feats > 0 && !feats) || (n_imu > 0 && !imu)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_process_async: bad argument");
+    ekf_quiesce(e);
+    // Cold paths (before the first usable IMU sample, the static initializer, a failed filter) decide their return value from the
+    // message itself: they run here, synchronously.  Once the filter is initialized an update always consumes the samples up to
+    // ts + td (a count that depends on time stamps, the state time and td only - all final now) and always reports `true`.
+    if (!e->b_first_features || !e->is_gravity_set || e->failed != LVK_OK)
+        return ekf_process_guarded(e, ts, feats, n_feats, imu, n_imu, n_consumed, will_update, nullptr, nullptr);
+    if (!e->async) {
+        e->async = new (std::nothrow) lvk_ekf::Async();
+        if (!e->async) return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "lvk_ekf_process_async: out of memory");
+        e->async->th = std::thread(ekf_async_worker, e);
+    }
+    lvk_ekf::Async* a = e->async;
+    *n_consumed = batch_imu_count(e, ts + e->td, imu, n_imu);
+    *will_update = 1;
+    a->ts = ts; a->feats.assign(feats, feats + n_feats); a->imu.assign(imu, imu + n_imu); a->expect_used = *n_consumed;
+    { std::lock_guard<std::mutex> lk(a->mu); a->st = LVK_OK; a->updated = 0; a->n_deferred += 1; a->state.store(1, std::memory_order_release); }
+    a->cv.notify_all();
+    return LVK_OK;
+}
+
+lvk_status lvk_ekf_wait(lvk_ekf* e, int* updated)
+{
+    if (!e) return LVK_ERR_ARG;
+    ekf_quiesce(e);
+    if (updated) *updated = e->async ? e->async->updated : 0;
+    if (e->async && e->async->st != LVK_OK) return e->async->st;
+    return LVK_OK;
 }
 
 static lvk_status ekf_process_guarded(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
@@ -1892,6 +1980,7 @@ lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn
 {
     if (!e || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return lvk_set_error(e ? e->ctx : nullptr, LVK_ERR_ARG, "lvk_ekf_set_shard: bad argument");
     auto& S = e->shard;
+    ekf_quiesce(e);
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
     if (S.d_send) hipFree(S.d_send); if (S.d_recv) hipFree(S.d_recv);
     S.d_send = S.d_recv = nullptr; S.cap = 0; S.xk_cap = 0;
@@ -1915,12 +2004,14 @@ lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn
 void lvk_ekf_shard_stats(const lvk_ekf* e, long* out8)
 {
     if (!e || !out8) return;
+    ekf_quiesce(e);
     memcpy(out8, e->shard.stats, sizeof e->shard.stats); memcpy(out8 + 4, e->qr_stats, sizeof e->qr_stats);
 }
 
 lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* out3)
 {   // out3 (optional): [ms inside the H P GEMM, its flops 2 m N^2, launches] since the last call, then reset
     if (!e) return LVK_ERR_ARG;
+    ekf_quiesce(e);
     if (out3) { out3[0] = e->prof_ms; out3[1] = e->prof_flops; out3[2] = (double)e->prof_n; }
     e->prof_ms = e->prof_flops = 0; e->prof_n = 0; e->prof_on = enable != 0;
     return LVK_OK;
@@ -1928,18 +2019,20 @@ lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* out3)
 lvk_status lvk_ekf_profile_qr(lvk_ekf* e, double* out4)
 {   // [ms inside k_qr_sparse levels, their Householder flops on the structure factored, launches, rows entering the levels] since the last call, then reset
     if (!e || !out4) return LVK_ERR_ARG;
+    ekf_quiesce(e);
     out4[0] = e->prof_qr_ms; out4[1] = e->prof_qr_flops; out4[2] = (double)e->prof_qr_n; out4[3] = e->prof_qr_rows;
     e->prof_qr_ms = e->prof_qr_flops = e->prof_qr_rows = 0; e->prof_qr_n = 0;
     return LVK_OK;
 }
-int lvk_ekf_dim(const lvk_ekf* e) { return e ? e->N : 0; }
-lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* o24) { if (!e || !o24) return LVK_ERR_ARG; memcpy(o24, e->imx, sizeof e->imx); return LVK_OK; }
-lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* i24) { if (!e || !i24) return LVK_ERR_ARG; memcpy(e->imx, i24, sizeof e->imx); update_imu_mx(e); return LVK_OK; }
-int lvk_ekf_is_initialized(const lvk_ekf* e) { return e && e->is_gravity_set ? 1 : 0; }
-double lvk_ekf_take_off_stamp(const lvk_ekf* e) { return e ? e->take_off_stamp : 0.0; }
+int lvk_ekf_dim(const lvk_ekf* e) { if (!e) return 0; ekf_quiesce(e); return e->N; }
+lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* o24) { if (!e || !o24) return LVK_ERR_ARG; ekf_quiesce(e); memcpy(o24, e->imx, sizeof e->imx); return LVK_OK; }
+lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* i24) { if (!e || !i24) return LVK_ERR_ARG; ekf_quiesce(e); memcpy(e->imx, i24, sizeof e->imx); update_imu_mx(e); return LVK_OK; }
+int lvk_ekf_is_initialized(const lvk_ekf* e) { if (!e) return 0; ekf_quiesce(e); return e->is_gravity_set ? 1 : 0; }
+double lvk_ekf_take_off_stamp(const lvk_ekf* e) { if (!e) return 0.0; ekf_quiesce(e); return e->take_off_stamp; }
 lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* o)
 {
     if (!e || !o) return LVK_ERR_ARG;
+    ekf_quiesce(e);
     o[0] = e->s.t; memcpy(o + 1, e->s.q, 32); memcpy(o + 5, e->s.v, 24); memcpy(o + 8, e->s.p, 24); memcpy(o + 11, e->s.bg, 24); memcpy(o + 14, e->s.ba, 24);
     memcpy(o + 17, e->R_b2c, 72); memcpy(o + 26, e->t_c_b, 24); o[29] = e->td;
     return LVK_OK;
@@ -1947,12 +2040,14 @@ lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* o)
 lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P)
 {
     if (!e || !h_P) return LVK_ERR_ARG;
+    ekf_quiesce(e);
     EKF_HIP(hipMemcpy2D(h_P, sizeof(double) * e->N, e->dP[e->cur], sizeof(double) * e->ld, sizeof(double) * e->N, e->N, hipMemcpyDeviceToHost));
     return LVK_OK;
 }
 int lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* out, int cap)
 {
     if (!e || !out) return 0;
+    ekf_quiesce(e);
     int n = std::min((int)e->clones.size(), cap);
     for (int i = 0; i < n; ++i) {
         const Clone& c = e->clones[i]; lvk_clone& o = out[i];
@@ -1964,6 +2059,7 @@ int lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* out, int cap)
 int lvk_ekf_get_features(const lvk_ekf* e, int64_t* ids, double* inv_depth, double* pos_w, int cap)
 {
     if (!e) return 0;
+    ekf_quiesce(e);
     int n = std::min((int)e->feature_states.size(), cap);
     for (int i = 0; i < n; ++i) {
         const Feature& f = e->map.at(e->feature_states[i]);
@@ -1974,12 +2070,13 @@ int lvk_ekf_get_features(const lvk_ekf* e, int64_t* ids, double* inv_depth, doub
 int lvk_ekf_take_lost_features(lvk_ekf* e, int64_t* ids, double* pos_w, int cap)
 {
     if (!e || !ids || !pos_w || cap <= 0) return 0;
+    ekf_quiesce(e);
     const int n = std::min((int)e->lost_slam.size(), cap);
     for (int i = 0; i < n; ++i) { ids[i] = e->lost_slam[i].id; memcpy(pos_w + 3 * i, e->lost_slam[i].p, 24); }
     e->lost_slam.erase(e->lost_slam.begin(), e->lost_slam.begin() + n);
     return n;
 }
-void lvk_ekf_counters(const lvk_ekf* e, long* out8) { if (e && out8) memcpy(out8, e->counters, sizeof e->counters); }
+void lvk_ekf_counters(const lvk_ekf* e, long* out8) { if (e && out8) { ekf_quiesce(e); memcpy(out8, e->counters, sizeof e->counters); } }
 
 lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img, double ts,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* updated)
@@ -1992,6 +2089,21 @@ lvk_status lvk_vio_process(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img,
     lvk_status st = lvk_frontend_process(fe, img, ts, h_imu, n_imu, msg.data(), (int)msg.size(), &n_out, has_msg);
     if (st != LVK_OK || !*has_msg) return st;
     return lvk_ekf_process(ekf, ts, msg.data(), n_out, h_imu, n_imu, n_consumed, updated);
+}
+
+// The same two calls with the update deferred (lvk_ekf_process_async): what the adapter classes do under the reference's blocking
+// drivers.  The front-end half still waits for its feature message (processImage returns it to the caller).
+lvk_status lvk_vio_process_deferred(lvk_frontend* fe, lvk_ekf* ekf, const lvk_image* img, double ts,
+                                    const lvk_imu* h_imu, int n_imu, int* n_consumed, int* has_msg, int* will_update)
+{
+    if (!fe || !ekf || !n_consumed || !has_msg || !will_update) return LVK_ERR_ARG;
+    *n_consumed = 0; *will_update = 0; *has_msg = 0;
+    static thread_local std::vector<lvk_feature_obs> msg;
+    if (msg.size() < 8192) msg.resize(8192);
+    int n_out = 0;
+    lvk_status st = lvk_frontend_process(fe, img, ts, h_imu, n_imu, msg.data(), (int)msg.size(), &n_out, has_msg);
+    if (st != LVK_OK || !*has_msg) return st;
+    return lvk_ekf_process_async(ekf, ts, msg.data(), n_out, h_imu, n_imu, n_consumed, will_update);
 }
 
 }  // extern "C"

@@ -8,6 +8,9 @@
 #include "lvk_internal.h"
 #include "be_dev.h"
 #include <dlfcn.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <string>
 
 struct ShardMeta { int job_lo, job_n, k, row_off; };
 
@@ -92,13 +95,26 @@ struct RcclApi {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclGetErrorString) err_string = nullptr;
     char why[160] = {0};
+    char path[512] = {0};                               // the librccl that was bound
 };
 static const RcclApi* rccl_api()
 {   // opened once per process and kept (a communicator may outlive any single call)
     static const RcclApi api = [] {
         RcclApi a;
+        // The RCCL that belongs to the HIP runtime THIS library runs on: a process may hold two ROCm stacks (PyTorch wheels bundle
+        // their own libamdhip64 / librccl next to /opt/rocm's; which libamdhip64 serves liblvk_hip.so depends on the load order), and
+        // a librccl bound to the other runtime fails in ncclCommInitRank ("unhandled cuda error").  So: first the librccl in the
+        // directory our hipMalloc comes from, then the loader's default search.
+        Dl_info di;
+        if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            char real[4096];
+            if (realpath(di.dli_fname, real)) {
+                std::string dir(real); const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? std::string(".") : dir.substr(0, sl);
+                for (const char* n : {"/librccl.so.1", "/librccl.so"}) if ((a.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL)) != nullptr) { snprintf(a.path, sizeof a.path, "%s%s", dir.c_str(), n); break; }
+            }
+        }
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) if ((a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+        if (!a.lib) for (const char* n : names) if ((a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) { snprintf(a.path, sizeof a.path, "%s", n); break; }
         if (!a.lib) { const char* er = dlerror(); snprintf(a.why, sizeof a.why, "librccl not found: %s", er ? er : "?"); return a; }
         a.get_unique_id = (decltype(a.get_unique_id))dlsym(a.lib, "ncclGetUniqueId");
         a.comm_init_rank = (decltype(a.comm_init_rank))dlsym(a.lib, "ncclCommInitRank");
@@ -137,7 +153,7 @@ lvk_status lvk_shard_comm_create(lvk_context* ctx, const char* h_uid128, int ran
     ncclUniqueId id; memcpy(id.internal, h_uid128, 128);
     if (hipSetDevice(ctx->device) != hipSuccess) { delete c; return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_shard_comm_create: hipSetDevice(%d) failed", ctx->device); }
     const ncclResult_t rc = a->comm_init_rank(&c->comm, world, id, rank);
-    if (rc != ncclSuccess) { const char* es = a->err_string ? a->err_string(rc) : "?"; delete c; return lvk_set_error(ctx, LVK_ERR_DEVICE, "ncclCommInitRank: %s", es); }
+    if (rc != ncclSuccess) { const char* es = a->err_string ? a->err_string(rc) : "?"; delete c; return lvk_set_error(ctx, LVK_ERR_DEVICE, "ncclCommInitRank (%s): %s", a->path, es); }
     *out = c;
     return LVK_OK;
 }
@@ -150,6 +166,7 @@ void lvk_shard_comm_destroy(lvk_shard_comm* c)
 }
 
 const char* lvk_shard_comm_error(const lvk_shard_comm* c) { return c ? c->err : "null communicator"; }
+const char* lvk_shard_rccl_path(void) { const RcclApi* a = rccl_api(); return a->why[0] ? a->why : a->path; }
 
 // lvk_exchange_fn over RCCL: user = lvk_shard_comm*.  The collective is enqueued on the caller's stream; nothing blocks the host.
 lvk_status lvk_shard_allgather_rccl(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream)

@@ -208,6 +208,25 @@ class LarVio:
         self.ctx.check(_L().lvk_ekf_process(self._h, float(ts), _p(feats), len(feats), _p(imu), len(imu), C.byref(used), C.byref(upd)))
         return bool(upd.value), imu[used.value:]
 
+    def processFeaturesAsync(self, msg, imu_msg_buffer):
+        """lvk_ekf_process_async: same arguments and return value as processFeatures, but the update itself runs on the filter's
+        worker thread and stream; any getter (or the next update, or wait()) waits for it."""
+        ts, feats = (msg.timeStampToSec, msg.features) if hasattr(msg, "features") else msg
+        feats = np.ascontiguousarray(feats, OBS); imu = np.ascontiguousarray(imu_msg_buffer, IMU)
+        used, upd = C.c_int(0), C.c_int(0)
+        L = _L()
+        L.lvk_ekf_process_async.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]; L.lvk_ekf_process_async.restype = C.c_int
+        self.ctx.check(L.lvk_ekf_process_async(self._h, float(ts), _p(feats), len(feats), _p(imu), len(imu), C.byref(used), C.byref(upd)))
+        return bool(upd.value), imu[used.value:]
+
+    def wait(self):
+        """lvk_ekf_wait: block until the deferred update is done; raises if it failed; -> whether it updated"""
+        L = _L()
+        L.lvk_ekf_wait.argtypes = [C.c_void_p, C.c_void_p]; L.lvk_ekf_wait.restype = C.c_int
+        upd = C.c_int(0)
+        self.ctx.check(L.lvk_ekf_wait(self._h, C.byref(upd)))
+        return bool(upd.value)
+
     def set_state(self, t, q, p, v, bg, ba, gyro_old, acc_old):
         a = [np.ascontiguousarray(x, np.float64) for x in (q, p, v, bg, ba, gyro_old, acc_old)]
         self.ctx.check(_L().lvk_ekf_set_state(self._h, float(t), *[_p(x) for x in a]))

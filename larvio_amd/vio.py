@@ -15,6 +15,8 @@ def _L():
         pi = C.POINTER(C.c_int)
         L.lvk_vio_process.argtypes = [vp, vp, C.POINTER(Image), d, vp, i, pi, pi, pi]
         L.lvk_vio_process.restype = i
+        L.lvk_vio_process_deferred.argtypes = [vp, vp, C.POINTER(Image), d, vp, i, pi, pi, pi]
+        L.lvk_vio_process_deferred.restype = i
         pl = C.POINTER(C.c_long)
         L.lvk_vio_pipe_create.argtypes = [vp, vp, C.POINTER(vp)]; L.lvk_vio_pipe_create.restype = i
         L.lvk_vio_pipe_destroy.argtypes = [vp]; L.lvk_vio_pipe_destroy.restype = None
@@ -50,6 +52,21 @@ class VioDriver:
         im, keep = make_image(img, device_ptr, stride, shape if shape is not None else self._shape)
         st = _L().lvk_vio_process(self.fe._h, self.be._h, C.byref(im), float(ts), C.c_void_p(self._base + self.lo * self._isz), hi - self.lo,
                                   C.byref(used), C.byref(has), C.byref(upd))
+        self.fe.ctx.check(st)
+        self.lo += used.value
+        return bool(has.value), bool(upd.value)
+
+
+class VioDeferred(VioDriver):
+    """The adapter's schedule under a blocking driver (lvk_vio_process_deferred): processImage waits for its message, processFeatures
+    queues the update on the filter's worker thread and returns; LarVio getters (state(), cov(), ...) or the next step wait for it.
+    Same results as VioDriver.  step() returns (has_msg, will_update)."""
+
+    def step(self, ts, hi, img=None, device_ptr=None, stride=None, shape=None):
+        used, has, upd = self._c
+        im, keep = make_image(img, device_ptr, stride, shape if shape is not None else self._shape)
+        st = _L().lvk_vio_process_deferred(self.fe._h, self.be._h, C.byref(im), float(ts), C.c_void_p(self._base + self.lo * self._isz), hi - self.lo,
+                                           C.byref(used), C.byref(has), C.byref(upd))
         self.fe.ctx.check(st)
         self.lo += used.value
         return bool(has.value), bool(upd.value)

@@ -145,6 +145,57 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx, disturbed):
         assert np.array_equal(a[7][k], b[7][k])
 
 
+def test_deferred_update_is_identical_to_blocking(gpu_ctx):
+    """lvk_ekf_process_async / lvk_vio_process_deferred - what the adapter classes do under the reference's blocking drivers
+    (processImage; processFeatures returns at once, the update runs on the filter's worker thread; getters wait): the headline
+    configuration through 140 frames, (a) reading the pose right after every processFeatures as app/larvioMain.cpp:139 does and (b) one
+    frame late, against the blocking driver step: every pose read, the final state, covariance, id lists, counters and tracks identical."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver, VioDeferred
+    wl = S.workload("A")
+    first = int(2.0 * wl["img_rate"]); n = 140
+    from tests.conftest import synth_frames
+    fr = synth_frames(first, n, cam=wl["cam"], img_rate=wl["img_rate"])
+    seq = S.imu_only_sequence(cam=wl["cam"])
+    imu_all = seq.imu_array(max(int(fr[0][0] * 200) - 4, 0), int(fr[-1][0] * 200) + 40)
+    ctx2 = larvio_amd.Context(0)
+    out = []
+    for mode in ("blocking", "immediate", "late"):
+        fe = larvio_amd.ImageProcessor(wl["fcfg"], gpu_ctx); assert fe.initialize()
+        be = larvio_amd.LarVio(wl["bcfg"], gpu_ctx if mode == "blocking" else ctx2); assert be.initialize()
+        drv = (VioDriver if mode == "blocking" else VioDeferred)(fe, be, imu_all)
+        poses = []; owed = False
+        for i, (t, img) in enumerate(fr):
+            if i == 1:
+                k = int(np.searchsorted(imu_all["t"], t, side="right")) - 1
+                t0 = imu_all["t"][k]; tr = seq.traj
+                be.set_state(t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+            has, upd = drv.step(t, drv.visible_end(t), img=img)
+            if mode == "late":
+                if upd:
+                    owed = True
+                elif owed:                                # the frame after an update: its front-end ran while the update was in flight
+                    be.state(); owed = False
+            elif upd:
+                st = be.state(); poses.append(np.concatenate([st["q"], st["p"], st["v"]]))
+        if mode != "blocking":
+            be.wait()                                     # raises if the last deferred update failed
+        st = be.state()
+        out.append((np.array(poses), {k: np.array(v, copy=True) for k, v in st.items()}, be.cov(), be.clones()["id"].copy(), be.features()[0].copy(), be.counters(), fe.tracks()))
+        be.close(); fe.close()
+    ctx2.close()
+    a = out[0]
+    assert len(a[0]) >= 65 and len(a[3]) >= 28 and a[5]["msckf"] >= 5
+    for b in out[1:]:
+        for k in a[1]:
+            assert np.array_equal(a[1][k], b[1][k]), k
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[5] == b[5]
+        for k in ("ids", "pts", "lifetime"):
+            assert np.array_equal(a[6][k], b[6][k])
+    assert np.array_equal(out[0][0], out[1][0])          # pose after EVERY update, read immediately: identical to the blocking call
+
+
 def S_EUROC():
     from larvio_amd import synthetic as S
     return dict(S.EUROC)
@@ -444,6 +495,12 @@ def test_cpp_dataset_driver_on_an_asl_directory(gpu_ctx, tmp_path):
     print(r3.stdout)
     ad = np.loadtxt(tum3, ndmin=2)
     assert ad.shape[0] == cpp.shape[0] and np.array_equal(ad[:, 1:4], cpp[:, 1:4])
+    # the adapter defers processFeatures by default (lvk_ekf_process_async; getters wait): LVK_ADAPTER_BLOCKING=1 = the blocking call,
+    # every number printed must be the same
+    tum4 = str(tmp_path / "traj_adapter_blocking.txt")
+    r4 = subprocess.run(r3.args[:-1] + [tum4], capture_output=True, text=True, timeout=300, env=dict(os.environ, LVK_ADAPTER_BLOCKING="1"))
+    assert r4.returncode == 0, r4.stdout + r4.stderr
+    assert open(tum4).read() == open(tum3).read()
     assert (ad[:, 7] > 0).all() and (ad[:, 8] > 0).all()                        # P_pose(0,0) = position variance, P_vel(0,0)
     assert ad[-1, 9] >= 5 and (ad[:, 10] == 512 * 512 * 3).all()                # sliding-window poses; RGB visual image of the right size
     assert f"odometry updates {cpp.shape[0]}" in r3.stdout
