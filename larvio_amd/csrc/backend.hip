@@ -1917,7 +1917,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
         } else return LVK_OK;
     }
     g_tr.start();
-    const double td_before = e->td;
+    const double td_before = e->td; (void)td_before;
     *n_consumed = off + batch_imu_count(e, ts + e->td, imu + off, n_imu - off);
     notify.fire();                                      // a pipelined driver may start the next frame's front-end now
     const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
@@ -1952,6 +1952,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
         e->prof_free.push_back(pe.a); e->prof_free.push_back(pe.b);
     }
     e->prof_pending.clear();
+#ifdef LVK_MSG_HASH_LOG   // debugging aid, compiled out of the product (make CXXFLAGS+=-DLVK_MSG_HASH_LOG); bounded: the first 65536 messages
     {   // LVK_MSG_HASH=<file>: one line per processed message (time stamp, size, FNV-1a of its bytes, IMU samples used + their hash, td
         // before, state after).  Debugging aid: the message is only COPIED here (a few us); hashing and the file are left to exit.
         struct Rec { double ts, td, st[16]; int n, used, N, rows; std::vector<unsigned char> msg, imu; };
@@ -1962,7 +1963,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
                                    for (double v : r.st) fprintf(f, " %.17g", v); fprintf(f, "\n"); }
             fclose(f); } };
         static Log lg{{}, getenv("LVK_MSG_HASH")};
-        if (lg.path) {
+        if (lg.path && lg.recs.size() < 65536) {
             Rec r; r.ts = ts; r.td = td_before; r.n = n_feats; r.used = used; r.N = e->N; r.rows = (int)e->counters[2];
             r.msg.assign((const unsigned char*)feats, (const unsigned char*)feats + sizeof(lvk_feature_obs) * (size_t)n_feats);
             r.imu.assign((const unsigned char*)(imu + off), (const unsigned char*)(imu + off) + sizeof(lvk_imu) * (size_t)used);
@@ -1970,6 +1971,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
             lg.recs.push_back(std::move(r));
         }
     }
+#endif
     TR(TR_FINAL);
     g_tr.n++;
     *updated = 1;

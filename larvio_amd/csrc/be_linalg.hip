@@ -523,7 +523,12 @@ __device__ __forceinline__ void cf_wait(const int* flag, int target, int lane)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// A second right-hand side (B2: m x nbcols2, own leading dimension) gets its own solver workgroups behind those of B: the caller
+// passes the block of S to the RIGHT of the diagonal block being factored (rows 0..m-1, the columns of the rows still to come), so
+// that the launch also produces L21^T = L11^-1 A21^T for a matrix taller than 160 rows (launch_chol_solve).  row0 = the first row
+// of this diagonal block in the whole matrix (error reporting).
 __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
+                                                   double* __restrict__ B2, int ldb2, int nbcols2, int row0,
                                                    double* __restrict__ Yg, int* __restrict__ flag, int base, int* __restrict__ info)
 {
     extern __shared__ __attribute__((aligned(32))) double cf_smem[];
@@ -534,7 +539,7 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
         // ===================================================================== factor role
         cf_blk* Sb = (cf_blk*)cf_smem;                                   // lower blocks, cf_idx(bi, bj)
         cf_blk& Yi = *(cf_blk*)(cf_smem + (size_t)(CF_MAXB * (CF_MAXB + 1) / 2) * CP_NB * CF_LD);
-        if (t == 0) info[0] = 0;
+        if (t == 0 && row0 == 0) info[0] = 0;
         {   // whole lower triangle: one 32-byte load per thread and block, all in flight
             const int row = t >> 3, c4 = (t & 7) * 4;
             d4 v[CF_MAXB * (CF_MAXB + 1) / 2];
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
         for (int p = 0; p < nblk; ++p) {
             cf_blk& D = Sb[cf_idx(p, p)];
             const int nb = min(CP_NB, m - 32 * p);
-            if (wave == 0) chol32_inv_wave(D, Yi, nb, lane, info, 32 * p, true);
+            if (wave == 0) chol32_inv_wave(D, Yi, nb, lane, info, row0 + 32 * p, true);
             else if (p > 0) {
                 // the rest of panel p-1's trailing update (block columns p+1..), in the shadow of the factorisation
                 int u = 0;
@@ -615,9 +620,12 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
     // ========================================================================= solver role: 16 columns of B per wavefront
     double (*Wl)[CF_WLD] = (double (*)[CF_WLD])(cf_smem + (size_t)wave * (CF_MAXB * CP_NB + CP_NB) * CF_WLD);    // W rows of the finished panels
     double (*Cs)[CF_WLD] = Wl + CF_MAXB * CP_NB;                                                              // staging of the current panel
-    const int col = (blockIdx.x - 1) * 64 + wave * 16 + i16;
+    const int nwg1 = (nbcols + 63) / 64;
+    int cb = (int)blockIdx.x - 1;
+    if (cb >= nwg1) { cb -= nwg1; B = B2; ldb = ldb2; nbcols = nbcols2; }
+    const int col = cb * 64 + wave * 16 + i16;
     const bool colok = col < nbcols;
-    if ((blockIdx.x - 1) * 64 + wave * 16 >= nbcols) return;
+    if (cb * 64 + wave * 16 >= nbcols) return;
     double own[CF_MAXB][2][4];
 #pragma unroll
     for (int q = 0; q < CF_MAXB; ++q)
@@ -681,25 +689,56 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
     }
 }
 
-// S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary
+// S = L L^T (lower, in place) and B <- L^-1 B for B (m x nbcols); m arbitrary.
+// m <= 160: one fused launch.  Taller: blocked recursion over 160-row super-panels, each ONE fused launch + two GEMM launches -
+//   [S11 . ; S21 S22]:  the fused launch factors S11 = L11 L11^T, solves W1 = L11^-1 B1 and - through the second right-hand side, the
+//   block S12 = S21^T that k_dgemm left to the right of S11 (S is computed in full) - L21^T = L11^-1 S21^T, in place;
+//   then S22 -= L21 L21^T and B2 -= L21 W1 on the FP64 matrix cores, and the recursion continues on (S22, B2).
+// Against one k_chol_left launch per 32 columns (~22 us each, 6..14 of them per update above 160 rows) this is ~(40 + 20) us per 160 rows.
 static lvk_status launch_chol_solve(lvk_context* ctx, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
 {
     hipStream_t s = ctx->stream;
-    if (ctx->chol_mode == 0) { const char* v = getenv("LVK_CHOL_FUSED"); ctx->chol_mode = (v && atoi(v) == 0) ? 2 : 1; }
-    if (ctx->chol_mode == 1 && m <= CF_MAXB * CP_NB) {
+    if (ctx->chol_mode == 0) { const char* v = getenv("LVK_CHOL_FUSED"); ctx->chol_mode = (v && atoi(v) == 0) ? 2 : (v && atoi(v) == 2) ? 3 : 1; }   // 3: fused only up to 160 rows (A/B runs)
+    const int MB = CF_MAXB * CP_NB;
+    if ((ctx->chol_mode == 1 || (ctx->chol_mode == 3 && m <= MB))) {
         const size_t ybytes = sizeof(double) * CF_MAXB * CP_NB * CP_NB;
         const bool fresh = ctx->scratch_bytes[12] < ybytes + 64;
         char* ws = (char*)lvk_ctx_scratch(ctx, 12, ybytes + 64);
         if (!ws) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
         int* flag = (int*)(ws + ybytes);
         if (fresh || ctx->chol_epoch > (1 << 27)) { LVK_HIP(ctx, hipMemsetAsync(flag, 0, 64, s)); ctx->chol_epoch = 0; }
-        const int base = 8 * ctx->chol_epoch++;
         const size_t lds_f = sizeof(double) * (size_t)(CF_MAXB * (CF_MAXB + 1) / 2 + 1) * CP_NB * CF_LD;
         const size_t lds_s = sizeof(double) * (size_t)4 * (CF_MAXB * CP_NB + CP_NB) * CF_WLD;
         const size_t shm = lds_f > lds_s ? lds_f : lds_s;
-        LVK_LDS_OPTIN(ctx, 8, k_chol_fused, shm);
-        hipLaunchKernelGGL(k_chol_fused, dim3(1 + (nbcols + 63) / 64), dim3(256), shm, s, S, lds_, m, B, ldb, nbcols, (double*)ws, flag, base, info);
-        return LVK_OK;
+        // Residency: 1 + ceil(nbcols / 64) (+ ceil(rest / 64)) workgroups (<= 12 at the largest state the filter accepts), one per CU
+        // because of their LDS; the factor workgroup never waits for anybody, so solvers that were dispatched ahead of it only spin
+        // until it gets a CU - no ordering assumption is needed for progress, only for speed.  (The LDS request is the larger of
+        // the two roles': a launch has one size.)  If the device refuses the LDS opt-in or a launch, this context falls back for
+        // good to one launch per panel (k_chol_left) instead of failing the update - and with it, stickily, the filter.
+        bool ok = true;
+        if (ctx->lds_optin[8] < shm) {
+            if (hipFuncSetAttribute((const void*)k_chol_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess) ctx->lds_optin[8] = shm;
+            else { (void)hipGetLastError(); ok = false; }
+        }
+        int off = 0;
+        while (ok && off < m) {
+            const int mb = (m - off) < MB ? (m - off) : MB, rest = m - off - mb;
+            double* S11 = S + (size_t)off * lds_ + off; double* B1 = B + (size_t)off * ldb;
+            double* S12 = S11 + mb;                       // rows off..off+mb-1, columns off+mb..m-1: A21^T
+            const int base = 8 * ctx->chol_epoch++;
+            hipLaunchKernelGGL(k_chol_fused, dim3(1 + (nbcols + 63) / 64 + (rest + 63) / 64), dim3(256), shm, s, S11, lds_, mb, B1, ldb, nbcols,
+                               S12, lds_, rest, off, (double*)ws, flag, base, info);
+            if (hipGetLastError() != hipSuccess) { ok = false; break; }
+            if (rest > 0) {
+                double* S22 = S + (size_t)(off + mb) * lds_ + off + mb; double* B2 = B + (size_t)(off + mb) * ldb;
+                launch_dgemm<true, false>(s, rest, rest, mb, S12, lds_, S12, lds_, S22, lds_, -1.0, 1.0, 0.0);        // S22 -= L21 L21^T
+                launch_dgemm<true, false>(s, rest, nbcols, mb, S12, lds_, B1, ldb, B2, ldb, -1.0, 1.0, 0.0);          // B2 -= L21 W1
+            }
+            off += mb;
+        }
+        if (ok) return LVK_OK;
+        if (off > 0) return lvk_set_error(ctx, LVK_ERR_DEVICE, "fused Cholesky: a launch failed after the first super-panel");   // S is half factored: no clean fallback
+        ctx->chol_mode = 2;
     }
     for (int j0 = 0; j0 < m; j0 += CP_NB) {
         const int nb = (m - j0) < CP_NB ? (m - j0) : CP_NB;

@@ -806,6 +806,8 @@ lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts)
 {
     if (!fe || !img) return LVK_ERR_ARG;
     if (!fe->b_first_img) return fe_check_image(fe, img);   // the first-image gate needs the IMU buffer (:134-142): nothing to do early
+    // one image stage per frame: the buffer-set rotation and the end-of-frame events are indexed by the stages queued so far
+    if (fe->image_done) return lvk_set_error(fe->ctx, LVK_ERR_ARG, "lvk_frontend_begin: the image stage of t = %.6f is still waiting for its lvk_frontend_process", fe->image_done_ts);
     lvk_status st = fe_image_stage(fe, img, true);
     if (st != LVK_OK) return st;
     fe->image_done = true; fe->image_done_ts = ts;
@@ -854,7 +856,9 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         else return fe_check_image(fe, img);
     }
     lvk_status st = LVK_OK;
-    if (!(fe->image_done && fe->image_done_ts == ts)) st = fe_image_stage(fe, img, false);
+    if (fe->image_done && fe->image_done_ts != ts)
+        return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_frontend_process(t = %.6f) after lvk_frontend_begin(t = %.6f): the queued image stage belongs to another frame", ts, fe->image_done_ts);
+    if (!fe->image_done) st = fe_image_stage(fe, img, false);
     fe->image_done = false;
     if (st != LVK_OK) return st;
     hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;

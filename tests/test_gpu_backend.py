@@ -36,7 +36,7 @@ def _update_problem(seed, N, m):
     return P, H, r
 
 
-@pytest.mark.parametrize("N,m", [(232, 262), (118, 40), (46, 9), (232, 530), (250, 1)])
+@pytest.mark.parametrize("N,m", [(232, 262), (118, 40), (46, 9), (232, 530), (250, 1), (232, 160), (232, 161), (232, 192), (240, 320), (330, 321), (460, 450), (470, 485)])
 def test_ekf_update_matches_oracle(gpu_ctx, N, m):
     from oracle import lvo_be
     from larvio_amd import larvio as lv

@@ -330,11 +330,14 @@ def test_whole_loop_configs2_imu_intrinsics_sw30(gpu_ctx):
 
 
 def test_whole_loop_configs3_tumvi_300_tracks_sw30_zupt(gpu_ctx):
-    """configs[3] at its real shape: 512x512 equidistant, 300-feature budget, sw_size 30, ZUPT on, from rest (static initializer, then
-    zero-velocity updates, then motion): 170 frames so that the window fills (28 -> 30 cycle, larvio.cpp:2316-2320)."""
+    """configs[3] at its real shape: 512x512 equidistant, ~300 live tracks (budget 350), sw_size 30, ZUPT on, starting AT REST: zero-velocity
+    updates while the platform stands still, then motion; 170 frames so that the window fills (28 -> 30 cycle, larvio.cpp:2316-2320).
+    The state is handed over at the second frame: with this many tracks the static initializer's 19th-largest-displacement test
+    (StaticInitializer.cpp:60-75) never passes on this sequence - in the oracle either; the initializer itself is covered at a 300-feature
+    budget by test_driver_loop_config4_shape_equidistant_static_start_zupt."""
     from larvio_amd import synthetic as S
     wl = S.workload("4")
-    n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, 0, 170, {}, {}, init_from_gt=False, min_updates=60, workload=wl)
+    n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, 0, 170, {}, {}, init_from_gt=True, min_updates=60, workload=wl)
     assert n_clones >= 28 and c["zupt"] >= 1 and c["msckf"] >= 5 and n_tracks >= 200, (n_clones, c, n_tracks)
     print("configs[3] (300 tracks, sw 30, ZUPT): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
 
