@@ -200,7 +200,6 @@ def timed(run, frames, d_frames, W, K, dist, torch):
     if not run.sequential:
         run.drv.stats(reset=True); run.drv.latencies(reset=True)
     pl0, it0 = run.fe.lk_stats()
-    tk0 = run.fe.track_stats()
     mg0 = run.fe.msg_stats()
     c0 = run.be.counters()
     run.fe.profile_enable(1 << 2)                        # HIP events around the LK launches only (dominant kernel family)
@@ -222,10 +221,9 @@ def timed(run, frames, d_frames, W, K, dist, torch):
         elapsed = max_over_ranks(dist, torch, elapsed)
     prof = run.fe.profile_read()
     pl1, it1 = run.fe.lk_stats()
-    tk1 = run.fe.track_stats()
     mg1 = run.fe.msg_stats()
     c1 = run.be.counters()
-    out = dict(orb_desc=tk1["descriptors"] - tk0["descriptors"], fused=tk1["fused"], msgs=mg1[0] - mg0[0], msg_features=mg1[1] - mg0[1], elapsed=elapsed, lat=lat, msg_mask=msg_mask, lk_pl=pl1 - pl0, lk_it=it1 - it0, lk_prof=prof["lk_fwd_rev"],
+    out = dict(msgs=mg1[0] - mg0[0], msg_features=mg1[1] - mg0[1], elapsed=elapsed, lat=lat, msg_mask=msg_mask, lk_pl=pl1 - pl0, lk_it=it1 - it0, lk_prof=prof["lk_fwd_rev"],
                n_updates=(c1["hybrid"] + c1["msckf"]) - (c0["hybrid"] + c0["msckf"]), n_hybrid=c1["hybrid"] - c0["hybrid"], n_msckf=c1["msckf"] - c0["msckf"],
                pst=None, e2e=None)
     if not run.sequential:
@@ -625,10 +623,6 @@ def main():
         win = wl["fcfg"]["patch_size"]
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
         lk_bytes = m["lk_pl"] * (win + 3) ** 2 + m["lk_it"] * (win + 1) ** 2
-        # the fused track kernel also runs the descriptor gate: per descriptor the 749 pixels of the radius-15 disc (intensity centroid) + 512 samples of the blurred plane
-        ORB_BYTES = 749 + 512
-        if m["fused"]:
-            lk_bytes += m["orb_desc"] * ORB_BYTES
         lk_ms, lk_launches = m["lk_prof"]
         achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_launches, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         # HBM traffic per launch: not measurable inside this process (PMC needs rocprofv3) - taken from the committed counter pass
@@ -641,11 +635,10 @@ def main():
         if pm:
             with open(pm[-1]) as f:
                 rows = [l.strip().split(",") for l in f.readlines()[1:]]
-            lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_track" if m["fused"] else "k_fe_lk_")]
+            lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_lk_")]
             if lk:
                 traffic = round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1); traffic_src = os.path.basename(pm[-1])
-        roofline = {"kernel": ("k_fe_track<%d> (forward + reverse LK + ORB descriptor gate of every track of a point set; its last workgroup runs the set's RANSAC + commit)" % win)
-                              if m["fused"] else "k_fe_lk_both<%d> (forward + reverse LK of every track)" % win, "bound": "hbm", "achieved": round(achieved, 3),
+        roofline = {"kernel": "k_fe_lk_both<%d> (forward + reverse LK of every track)" % win, "bound": "hbm", "achieved": round(achieved, 3),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
                     "launches": lk_launches}

@@ -159,10 +159,6 @@ lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint6
 /* feature messages published so far (getFeatureMsg, image_processor.cpp:1076-1128) and the features they carried in total:
    features / messages = the tracks the tracker holds per published frame (the "~150 tracks" of BASELINE.json's metric) */
 lvk_status lvk_frontend_msg_stats(lvk_frontend* fe, uint64_t* messages, uint64_t* features);
-/* device counters of the track chain since creation: [0] LK point-levels, [1] LK iterations (as lvk_frontend_lk_stats), [2] ORB
-   descriptors computed by the descriptor gate (image_processor.cpp:677-699, 909-930), [3] 1 when LK, gate and RANSAC/commit of a point
-   set run as ONE launch (k_fe_track; capacities up to 1024 tracks) - the algorithmic bytes of the bench's roofline are built from these */
-lvk_status lvk_frontend_track_stats(lvk_frontend* fe, uint64_t h_out4[4]);
 
 /* Per-stage GPU time measured with HIP events on the context's stream (the reference only times the
  * whole call, app/larvioMain.cpp:106-109).  stage_mask bit i enables stage i; reading synchronises.

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "lvk_lk_track", "lvk_orb_describe", "lvk_hamming256_rows", "lvk_undistort_points", "lvk_find_fundamental_mask",
     "lvk_ransac_fundamental", "lvk_predict_homography",
     "lvk_frontend_create", "lvk_frontend_destroy", "lvk_frontend_process", "lvk_frontend_tracks", "lvk_frontend_new_pts",
-    "lvk_frontend_state", "lvk_frontend_lk_stats", "lvk_frontend_msg_stats", "lvk_frontend_track_stats", "lvk_frontend_profile_enable", "lvk_frontend_profile_read",
+    "lvk_frontend_state", "lvk_frontend_lk_stats", "lvk_frontend_msg_stats", "lvk_frontend_profile_enable", "lvk_frontend_profile_read",
     "lvk_frontend_stage_name",
     "lvk_ekf_compress_qr", "lvk_ekf_compress_qr_groups", "lvk_ekf_qr_plan", "lvk_ekf_update", "lvk_dgemm", "lvk_ekf_create", "lvk_ekf_destroy", "lvk_ekf_process", "lvk_ekf_process_async", "lvk_ekf_wait", "lvk_ekf_set_state",
     "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_take_off_stamp", "lvk_ekf_get_state", "lvk_ekf_get_imu_intrinsics", "lvk_ekf_set_imu_intrinsics", "lvk_ekf_get_cov", "lvk_ekf_get_clones", "lvk_ekf_get_features", "lvk_ekf_take_lost_features",
@@ -99,7 +99,6 @@ def lib():
             "lvk_frontend_new_pts": ([vp, vp, i, pi], i), "lvk_frontend_state": ([vp], i),
             "lvk_frontend_lk_stats": ([vp, vp, vp], i),
             "lvk_frontend_msg_stats": ([vp, vp, vp], i),
-            "lvk_frontend_track_stats": ([vp, vp], i),
             "lvk_frontend_profile_enable": ([vp, C.c_uint], i), "lvk_frontend_profile_read": ([vp, vp, vp, i], i),
             "lvk_frontend_stage_name": ([i], C.c_char_p),
         }

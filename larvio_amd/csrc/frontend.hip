@@ -206,8 +206,6 @@ struct FeDev {
     int boot_ok;         // result of the last bootstrap attempt
     int pad_;
     unsigned long long msg_features, msg_count;   // features in all published messages / messages published (mean tracks per message)
-    unsigned long long orb_descriptors;           // descriptors computed by the gate (one per surviving old track, two per surviving new point)
-    int ticket[2];                                // arrival counters of the fused track kernels (old tracks / bootstrap), zero between launches
 };
 
 struct TrackSet {       // structure of arrays, capacity cap
@@ -282,7 +280,7 @@ __global__ void __launch_bounds__(64) k_fe_orb_gate(const uint8_t* __restrict__ 
                                                    const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
                                                    const lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status,
                                                    const unsigned long long* __restrict__ stored_desc /*old*/,
-                                                   unsigned long long* __restrict__ w_desc /*new: out*/, int is_new, FeDev* __restrict__ dev)
+                                                   unsigned long long* __restrict__ w_desc /*new: out*/, int is_new)
 {
     const int p = blockIdx.x;
     if (p >= *n_ptr) return;
@@ -299,21 +297,22 @@ __global__ void __launch_bounds__(64) k_fe_orb_gate(const uint8_t* __restrict__ 
         dist = hamming256_u64(dc, stored_desc + (size_t)p * 4);
     }
     if ((threadIdx.x & 63) == 0 && dist > 58) w_status[p] = ST_ORB;
-    if ((threadIdx.x & 63) == 0) atomicAdd(&dev->orb_descriptors, is_new ? 2ull : 1ull);
 }
 
 // One workgroup: count survivors per stage, order-preserving compaction of the alive points, undistort
 // both sets to pixel coordinates (K -> K), cv::findFundamentalMat mask, then write the destination
 // track set.  mode 0: old tracks (trackFeatures :701-808), 1: new points appended (trackNewFeatures
 // :932-1001), 2: bootstrap (initializeFirstFeatures :464-536).
-__device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamParams& cam,
-                                                const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
-                                                const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
-                                                const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
-                                                const TrackSet& dst, int* __restrict__ dst_n, FeDev* __restrict__ dev,
-                                                lvk_pt2f* s1, lvk_pt2f* s2, uint8_t* smask, unsigned short* sidx)
-{   // s1, s2, smask, sidx: LDS for `cap` points each (static arrays in k_fe_ransac_commit, dynamic LDS sized by the track capacity in k_fe_track)
+__global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int cap, CamParams cam,
+                                                               const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                               const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
+                                                               const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
+                                                               const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
+                                                               TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
+{
+    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
+    __shared__ uint8_t smask[FM_MAX_N];
+    __shared__ unsigned short sidx[FM_MAX_N];
     __shared__ int cnt[4];
     __shared__ int scan[FM_THREADS];
     const int t = threadIdx.x;
@@ -412,99 +411,6 @@ __device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamPara
     }
 }
 
-__global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int cap, CamParams cam,
-                                                               const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                               const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
-                                                               const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
-                                                               const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
-                                                               TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
-{
-    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
-    __shared__ uint8_t smask[FM_MAX_N];
-    __shared__ unsigned short sidx[FM_MAX_N];
-    fe_commit_block(mode, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
-}
-
-// The whole chain of a point set in ONE launch (track capacities up to FE_FUSED_MAX_CAP): four points per workgroup, one wavefront
-// each - forward + reverse LK, then the descriptor gate of the survivors in the same wavefront - and the workgroup that finishes
-// LAST (arrival ticket) runs the RANSAC + commit of the set with all its 256 threads.  On the frame's dependent chain that is one
-// launch instead of three (each ~4 us of launch floor + a barrier, and ~3.5 us of the caller's time).  The commit needs the statuses
-// and points every other workgroup wrote: device-scope release before the ticket, acquire after it (the idiom of k_clahe_lut).
-// commit_mode < 0: no epilogue (the new points' set: its commit has to follow the old tracks' one and stays a launch of its own).
-// Larger capacities keep the separate kernels: the commit's registers (256 VGPRs) and LDS would halve the occupancy of 2000 LK wavefronts.
-#define FE_FUSED_MAX_CAP 1024
-template <int WIN>
-__global__ void __launch_bounds__(FM_THREADS) k_fe_track(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                       HMat H, int width, int height, int max_count, double epsilon,
-                                                       lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev,
-                                                       const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
-                                                       const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur,
-                                                       const unsigned long long* __restrict__ stored_desc, unsigned long long* __restrict__ w_desc, int is_new,
-                                                       int commit_mode, int cap, CamParams cam, const unsigned long long* __restrict__ src_id,
-                                                       const lvk_pt2f* __restrict__ src_init, const int* __restrict__ src_life, TrackSet dst,
-                                                       int* __restrict__ dst_n, int* __restrict__ ticket)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char fe_dyn[];
-    __shared__ int s_last;
-    const int p = blockIdx.x * (FM_THREADS / 64) + (threadIdx.x >> 6);
-    if (p < *n_ptr) {
-        const int n_levels = prev.n_levels < next.n_levels ? prev.n_levels : next.n_levels;
-        const lvk_pt2f pp = src_pts[p];
-        lvk_pt2f np = apply_h(H, pp);
-        int st = 1;
-        int its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
-        if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
-        int code = st ? ST_ALIVE : ST_FWD, passes = 1;
-        if (st) {
-            lvk_pt2f back = pp;
-            int sr = 1;
-            its += lk_point<WIN>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr);
-            passes = 2;
-            if (sr) {
-                if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
-                else {
-                    float dx = back.x - pp.x, dy = back.y - pp.y;
-                    float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
-                    if (dis > 1) sr = 0;
-                }
-            }
-            if (!sr) code = ST_REV;
-        }
-        if (code == ST_ALIVE) {                                 // the descriptor gate (k_fe_orb_gate), same wavefront
-            const int step = width + 2 * LVK_ORB_BORDER;
-            unsigned long long dc[4], dp[4];
-            orb_point(cur_ext, cur_blur, step, np, dc);
-            int dist;
-            if (is_new) {
-                orb_point(prv_ext, prv_blur, step, pp, dp);
-                dist = hamming256_u64(dc, dp);
-                if ((threadIdx.x & 63) == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
-            } else {
-                dist = hamming256_u64(dc, stored_desc + (size_t)p * 4);
-            }
-            if (dist > 58) code = ST_ORB;
-            if ((threadIdx.x & 63) == 0) atomicAdd(&dev->orb_descriptors, is_new ? 2ull : 1ull);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            w_curr[p] = np; w_status[p] = (uint8_t)code;
-            atomicAdd(&dev->lk_point_levels, (unsigned long long)(passes * n_levels));
-            atomicAdd(&dev->lk_iterations, (unsigned long long)its);
-        }
-    }
-    if (commit_mode < 0) return;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) *ticket = 0;                        // left at zero for the next launch
-    lvk_pt2f* s1 = (lvk_pt2f*)fe_dyn; lvk_pt2f* s2 = s1 + cap;
-    unsigned short* sidx = (unsigned short*)(s2 + cap); uint8_t* smask = (uint8_t*)(sidx + cap);
-    fe_commit_block(commit_mode, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, is_new ? (const unsigned long long*)w_desc : stored_desc, dst, dst_n, dev,
-                    s1, s2, smask, sidx);
-}
-
 // getFeatureMsg (:1076-1128): undistort to normalised coordinates, finite-difference velocities
 __global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams cam, double dt_1, double dt_2, int prev_is_last,
                          lvk_feature_obs* __restrict__ out, FeDev* __restrict__ dev, int* __restrict__ n_host)
@@ -586,7 +492,6 @@ struct lvk_frontend {
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
     lvk_pyr_graph* pyr_graph[3] = {nullptr, nullptr, nullptr}; lvk_pyramid* pyr_graph_of[3] = {nullptr, nullptr, nullptr};
     int use_graph = 0;                // LVK_FE_GRAPH=1: steady-state pyramid build as one graph launch per frame
-    int fused = 1;                    // k_fe_track: LK + descriptor gate (+ RANSAC/commit by the last workgroup) in one launch; LVK_FE_FUSED=0 or cap > FE_FUSED_MAX_CAP: separate kernels
     // HIP-event profiling of stages
     unsigned prof_mask;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -630,45 +535,31 @@ static void set_free(TrackSet& s)
     memset(&s, 0, sizeof s);
 }
 
-// commit_mode >= 0 (fused path only): the set's RANSAC + commit runs as the epilogue of the same launch (src = the track set the
-// points come from, mode 0; dst_set = the set being written)
 template <int WIN>
 static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& pv, const PyrView& cv, const lvk_pt2f* src_pts, const int* n_ptr, int grid,
                                const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status, const unsigned long long* stored_desc,
-                               unsigned long long* w_desc, int is_new, int max_count, double epsilon, int commit_mode, const TrackSet* src, int dst_set)
+                               unsigned long long* w_desc, int is_new, int max_count, double epsilon)
 {
     const int W = fe->cfg.width, Hh = fe->cfg.height;
-    if (fe->fused) {
-        if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);  // the frame start waited for the pyramid only: the ORB planes follow it on the image stream
-        ProfScope ps(fe, 2, s);
-        const int per = FM_THREADS / 64;
-        const size_t dyn = commit_mode >= 0 ? (size_t)fe->cap * (2 * sizeof(lvk_pt2f) + sizeof(unsigned short) + 1) + 16 : 0;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_track<WIN>), dim3((grid + per - 1) / per), dim3(FM_THREADS), dyn, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon,
-                           w_curr, w_status, fe->dev, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0],
-                           stored_desc, w_desc, is_new, commit_mode, fe->cap, fe->cam, (const unsigned long long*)(src ? src->id : nullptr),
-                           (const lvk_pt2f*)(src ? src->init : nullptr), (const int*)(src ? src->life : nullptr), fe->set[dst_set < 0 ? 0 : dst_set],
-                           &fe->dev->n_tracks[dst_set < 0 ? 0 : dst_set], &fe->dev->ticket[commit_mode == 2 ? 1 : 0]);
-        return;
-    }
     { ProfScope ps(fe, 2, s);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
     if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes follow it on the image stream
     ProfScope ps(fe, 4, s);
     hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
-                       (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new, fe->dev);
+                       (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new);
 }
 
 static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
-                              const unsigned long long* stored_desc, unsigned long long* w_desc, int is_new, int commit_mode = -1, const TrackSet* src = nullptr, int dst_set = -1)
+                              const unsigned long long* stored_desc, unsigned long long* w_desc, int is_new)
 {
     int max_count = fe->cfg.max_iteration < 0 ? 0 : fe->cfg.max_iteration > 100 ? 100 : fe->cfg.max_iteration;
     double epsilon = fe->cfg.track_precision < 0. ? 0. : fe->cfg.track_precision > 10. ? 10. : fe->cfg.track_precision;
     epsilon *= epsilon;
     PyrView pv = make_view(fe->pyr[0]), cv = make_view(fe->pyr[1]);
     switch (fe->cfg.patch_size) {
-        case 21: launch_track_chain<21>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon, commit_mode, src, dst_set); break;
-        case 15: launch_track_chain<15>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon, commit_mode, src, dst_set); break;
-        case 31: launch_track_chain<31>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon, commit_mode, src, dst_set); break;
+        case 21: launch_track_chain<21>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 15: launch_track_chain<15>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
+        case 31: launch_track_chain<31>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
         default: return lvk_set_error(fe->ctx, LVK_ERR_UNSUPPORTED, "patch_size %d not instantiated (15, 21, 31)", fe->cfg.patch_size);
     }
     LVK_LAUNCH_CHECK(fe->ctx);
@@ -741,7 +632,6 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     if (!fe) return LVK_ERR_DEVICE;
     fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
     { const char* g = getenv("LVK_FE_GRAPH"); fe->use_graph = g && atoi(g) != 0; }
-    { const char* g = getenv("LVK_FE_FUSED"); fe->fused = !(g && atoi(g) == 0) && cfg->max_features_num <= FE_FUSED_MAX_CAP; }
     const int w = cfg->width, h = cfg->height, cap = fe->cap;
     const size_t esz = (size_t)(w + 64) * (h + 64);
     bool ok = true;
@@ -1003,8 +893,8 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         if (st != LVK_OK) return lvk_set_error(ctx, st, "predict_homography failed");
         if (fe->image_state == 2) {
             // initializeFirstFeatures (:355-537)
-            st = track_chain(fe, S1, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1, fe->fused ? 2 : -1, nullptr, dst);
-            if (st == LVK_OK && !fe->fused) st = commit(fe, 2, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
+            st = track_chain(fe, S1, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
+            if (st == LVK_OK) st = commit(fe, 2, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st == LVK_OK) st = fe_read_dev(fe);
             if (st != LVK_OK) return st;
             if (!fe->h_dev->boot_ok) fe->image_state = 1;
@@ -1025,8 +915,8 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             //  frame left on the main stream are done)
             st = track_chain(fe, S2, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
             hipEventRecord(fe->ev_new, S2);
-            if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0, fe->fused ? 0 : -1, &fe->set[src], dst);
-            if (st == LVK_OK && !fe->fused) st = commit(fe, 0, fe->set[src].pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &fe->set[src], fe->set[src].desc, dst);
+            if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
+            if (st == LVK_OK) st = commit(fe, 0, fe->set[src].pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &fe->set[src], fe->set[src].desc, dst);
             hipStreamWaitEvent(S1, fe->ev_new, 0);
             if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st != LVK_OK) return st;
@@ -1118,16 +1008,6 @@ lvk_status lvk_frontend_lk_stats(lvk_frontend* fe, uint64_t* point_levels, uint6
     if (st != LVK_OK) return st;
     if (point_levels) *point_levels = fe->h_dev->lk_point_levels;
     if (iterations) *iterations = fe->h_dev->lk_iterations;
-    return LVK_OK;
-}
-
-lvk_status lvk_frontend_track_stats(lvk_frontend* fe, uint64_t out4[4])
-{   // [0] LK point-levels [1] LK iterations [2] ORB descriptors computed by the gate [3] 1 if the fused track kernel (k_fe_track) is in use
-    if (!fe || !out4) return LVK_ERR_ARG;
-    { lvk_status qs = fe_quiesce(fe); if (qs != LVK_OK) return qs; }
-    lvk_status st = fe_read_dev(fe);
-    if (st != LVK_OK) return st;
-    out4[0] = fe->h_dev->lk_point_levels; out4[1] = fe->h_dev->lk_iterations; out4[2] = fe->h_dev->orb_descriptors; out4[3] = fe->fused ? 1u : 0u;
     return LVK_OK;
 }
 

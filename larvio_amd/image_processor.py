@@ -98,12 +98,6 @@ class ImageProcessor:
         self.ctx.check(lib().lvk_frontend_lk_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def track_stats(self):
-        """-> dict(point_levels, iterations, descriptors, fused): device counters of the track chain since creation"""
-        o = np.zeros(4, np.uint64)
-        self.ctx.check(lib().lvk_frontend_track_stats(self._h, o.ctypes.data_as(C.c_void_p)))
-        return dict(point_levels=int(o[0]), iterations=int(o[1]), descriptors=int(o[2]), fused=bool(o[3]))
-
     def msg_stats(self):
         """-> (messages published, features they carried in total) since the front-end was created"""
         a, b = C.c_uint64(0), C.c_uint64(0)
