@@ -35,7 +35,7 @@ __device__ __forceinline__ long long wave_sum_i64(int v)
 // loads; requesting all levels' template/gradient runs up front.
 #define LK_W_BITS 14
 template <int WIN>
-__device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
+__device__ __forceinline__ int lk_point_generic(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
                                         int& status, int max_count, double epsilon, int* __restrict__ iters_out)
 {
     int total_it = 0;
@@ -142,6 +142,150 @@ __device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next
         total_it += n_it;
     }
     return total_it;
+}
+
+// ---- row-segment variant for WIN = 21 (every configuration of the reference uses patch_size 21).
+// Lane l owns SEVEN CONSECUTIVE pixels of window row l / 3 (segment l % 3): 63 lanes cover the 21 x 21 window.  The bilinear taps
+// of 7 neighbouring pixels are 8 consecutive bytes of two image rows, so a lane's share of the template is 2 eight-byte loads (I)
+// + 4 sixteen-byte loads ((Ix, Iy) pairs) instead of 84 one- and two-byte loads, and an iteration is 2 eight-byte loads instead
+// of 28 byte loads - all of a phase's loads in flight at once.  (gfx950 runs with unaligned access enabled: a dwordx2 load at any
+// byte address is one instruction.)  The per-pixel integer arithmetic is exactly that of the generic path and the 2x2 system is
+// made of exact integer sums, so which lane holds which pixel changes no bit of the result.
+#define LK_RS_SEG 7
+__device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
+                                             int& status, int max_count, double epsilon, int* __restrict__ iters_out)
+{
+    constexpr int WIN = 21;
+    int total_it = 0;
+    const int lane = threadIdx.x & 63;
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int max_level = n_levels - 1;
+    const int wrow = lane / 3, x0 = (lane - 3 * wrow) * LK_RS_SEG;
+    const bool act = lane < 3 * WIN;
+
+    for (int level = max_level; level >= 0; --level) {
+        const int cols = prev.w[level], rows = prev.h[level];
+        const int stepI = prev.istride[level], stepJ = next.istride[level], dstep = prev.dstride[level];
+        const uint8_t* __restrict__ Ibase = prev.img[level];
+        const uint8_t* __restrict__ Jbase = next.img[level];
+        const int16_t* __restrict__ Dbase = prev.der[level];
+        const float lscale = (float)(1. / (1 << level));
+        float prx = prev_pt.x * lscale, pry = prev_pt.y * lscale;
+        float nx, ny;
+        if (level == max_level) { nx = next_pt.x * lscale; ny = next_pt.y * lscale; }
+        else { nx = next_pt.x * 2.f; ny = next_pt.y * 2.f; }
+        next_pt.x = nx; next_pt.y = ny;
+        int n_it = 0;
+
+        prx -= half; pry -= half;
+        const int ipx = d_cv_floor(prx), ipy = d_cv_floor(pry);
+        if (ipx < -WIN || ipx >= cols || ipy < -WIN || ipy >= rows) {
+            if (level == 0) status = 0;
+            if (iters_out && lane == 0) iters_out[level] = 0;
+            continue;
+        }
+        float a = prx - ipx, b = pry - ipy;
+        int iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+        int iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+        int iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+        int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+
+        short Iv[LK_RS_SEG], Ixv[LK_RS_SEG], Iyv[LK_RS_SEG];
+        int pA11 = 0, pA12 = 0, pA22 = 0;
+        {
+            unsigned long long i0 = 0, i1 = 0;
+            uint4 d00 = {0, 0, 0, 0}, d01 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
+            if (act) {
+                const uint8_t* src = Ibase + (ptrdiff_t)(wrow + ipy) * stepI + (x0 + ipx);
+                const int16_t* ds = Dbase + (ptrdiff_t)(wrow + ipy) * dstep + 2 * (x0 + ipx);
+                __builtin_memcpy(&i0, src, 8); __builtin_memcpy(&i1, src + stepI, 8);
+                __builtin_memcpy(&d00, ds, 16); __builtin_memcpy(&d01, ds + 8, 16);
+                __builtin_memcpy(&d10, ds + dstep, 16); __builtin_memcpy(&d11, ds + dstep + 8, 16);
+            }
+            const unsigned dr0[8] = {d00.x, d00.y, d00.z, d00.w, d01.x, d01.y, d01.z, d01.w};
+            const unsigned dr1[8] = {d10.x, d10.y, d10.z, d10.w, d11.x, d11.y, d11.z, d11.w};
+#pragma unroll
+            for (int j = 0; j < LK_RS_SEG; ++j) {
+                const int s00 = (int)((i0 >> (8 * j)) & 0xFF), s01 = (int)((i0 >> (8 * j + 8)) & 0xFF);
+                const int s10 = (int)((i1 >> (8 * j)) & 0xFF), s11 = (int)((i1 >> (8 * j + 8)) & 0xFF);
+                const int x00 = (short)(dr0[j] & 0xFFFF), y00 = (short)(dr0[j] >> 16), x01 = (short)(dr0[j + 1] & 0xFFFF), y01 = (short)(dr0[j + 1] >> 16);
+                const int x10 = (short)(dr1[j] & 0xFFFF), y10 = (short)(dr1[j] >> 16), x11 = (short)(dr1[j + 1] & 0xFFFF), y11 = (short)(dr1[j + 1] >> 16);
+                int ival = (s00 * iw00 + s01 * iw01 + s10 * iw10 + s11 * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+                int ixval = (x00 * iw00 + x01 * iw01 + x10 * iw10 + x11 * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int iyval = (y00 * iw00 + y01 * iw01 + y10 * iw10 + y11 * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                if (!act) { ival = 0; ixval = 0; iyval = 0; }
+                Iv[j] = (short)ival; Ixv[j] = (short)ixval; Iyv[j] = (short)iyval;
+                pA11 += ixval * ixval; pA12 += ixval * iyval; pA22 += iyval * iyval;
+            }
+        }
+        const long long sA11 = wave_sum_i64(pA11), sA12 = wave_sum_i64(pA12), sA22 = wave_sum_i64(pA22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if ((double)min_eig < 1e-4 || D < FLT_EPSILON) {
+            if (level == 0) status = 0;
+            if (iters_out && lane == 0) iters_out[level] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; ++j) {
+            const int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
+            if (inx < -WIN || inx >= cols || iny < -WIN || iny >= rows) {
+                if (level == 0) status = 0;
+                break;
+            }
+            ++n_it;
+            a = nx - inx; b = ny - iny;
+            iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+            iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+            iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+            iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            int pb1 = 0, pb2 = 0;
+            unsigned long long j0 = 0, j1 = 0;
+            if (act) {
+                const uint8_t* Jp = Jbase + (ptrdiff_t)(wrow + iny) * stepJ + (x0 + inx);
+                __builtin_memcpy(&j0, Jp, 8); __builtin_memcpy(&j1, Jp + stepJ, 8);
+            }
+#pragma unroll
+            for (int k = 0; k < LK_RS_SEG; ++k) {
+                const int s00 = (int)((j0 >> (8 * k)) & 0xFF), s01 = (int)((j0 >> (8 * k + 8)) & 0xFF);
+                const int s10 = (int)((j1 >> (8 * k)) & 0xFF), s11 = (int)((j1 >> (8 * k + 8)) & 0xFF);
+                int diff = ((s00 * iw00 + s01 * iw01 + s10 * iw10 + s11 * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
+                if (!act) diff = 0;
+                pb1 += diff * Ixv[k]; pb2 += diff * Iyv[k];
+            }
+            const long long sb1 = wave_sum_i64(pb1), sb2 = wave_sum_i64(pb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx; ny += dy;
+            next_pt.x = nx + half; next_pt.y = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                next_pt.x -= dx * 0.5f; next_pt.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (iters_out && lane == 0) iters_out[level] = n_it;
+        total_it += n_it;
+    }
+    return total_it;
+}
+
+// LVK_LK_GENERIC (compile-time, A/B builds): the one-pixel-per-lane-slot path for every window size
+template <int WIN>
+__device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
+                                        int& status, int max_count, double epsilon, int* __restrict__ iters_out)
+{
+#ifndef LVK_LK_GENERIC
+    if constexpr (WIN == 21) return lk_point_rs21(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out);
+    else
+#endif
+    return lk_point_generic<WIN>(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out);
 }
 
 // ------------------------------------------------------------------------- ORB
