@@ -16,6 +16,7 @@
 #include "be_qr.h"
 #include <vector>
 #include <map>
+#include <stdexcept>
 #include <algorithm>
 #include <iterator>
 #include <new>
@@ -86,6 +87,101 @@ struct Feature {
         obs[i].z[0] = u; obs[i].z[1] = v; obs[i].zv[0] = uv; obs[i].zv[1] = vv;
     }
     void erase(long long sid) { int i = find(sid); if (i >= 0) obs.erase(obs.begin() + i); }
+    void reset(long long new_id)
+    {   // the state of Feature() with this id; the observation list keeps its capacity (recycled objects: no allocation per new track)
+        id = new_id; obs.clear();
+        for (int k = 0; k < 3; ++k) { position[k] = 0; position_fej[k] = 0; obs_anchor[k] = 0; }
+        is_initialized = false; id_anchor = -1; inv_depth = 0; in_state = false; ekf_feature = false; total_obs = 0;
+    }
+};
+
+// map_server (std::map<FeatureIDType, Feature> in the reference, include/larvio/larvio.h:150): an id-ordered container with the slice
+// of the std::map interface the filter uses.  Ids are handed out in increasing order and features die in bulk, so the order lives
+// in ONE sorted array of (id, pointer) slots: lookups are a bisection over 16-byte entries that stay in cache, new tracks are appended,
+// a walk in id order is a linear scan (the next features' records are prefetched on the way), and erase only marks the slot -
+// the marks are swept once per message (purge()), after the message had its chance to re-create a feature that was used and erased
+// while its track lived on (every track is, every max_track_len frames; larvio.cpp:2240-2246).  Feature objects come from a free
+// list and keep their address while they are in the map (the update's row jobs hold pointers to them).
+// At configs[4] (2000 tracks) the std::map's pointer chasing was ~130 us per message in add_observations alone and as much again in the
+// scans of the update.
+class FeatureMap {
+  public:
+    struct Slot { long long id; Feature* f; bool live; };
+    struct Ref { const long long first; Feature& second; Ref* operator->() { return this; } };
+    class iterator {
+      public:
+        typedef std::forward_iterator_tag iterator_category; typedef Ref value_type; typedef long difference_type; typedef Ref* pointer; typedef Ref reference;
+        iterator() : m(nullptr), i(0) {}
+        iterator(const FeatureMap* m_, size_t i_) : m(m_), i(i_) { skip(); }
+        Ref operator*() const { const Slot& s = m->slots[i]; return Ref{s.id, *s.f}; }
+        Ref operator->() const { return **this; }
+        iterator& operator++() { ++i; skip(); return *this; }
+        iterator operator++(int) { iterator t = *this; ++*this; return t; }
+        bool operator==(const iterator& o) const { return i == o.i; }
+        bool operator!=(const iterator& o) const { return i != o.i; }
+        size_t index() const { return i; }
+      private:
+        void skip()
+        {
+            const size_t n = m->slots.size();
+            while (i < n && !m->slots[i].live) ++i;
+            if (i + 8 < n) {                                      // records a few features ahead: the object, then (one step later) its observations
+                __builtin_prefetch(m->slots[i + 8].f);
+                const Feature* g = m->slots[i + 4].f;
+                __builtin_prefetch((const char*)g + 64); __builtin_prefetch(g->obs.data());
+            }
+        }
+        const FeatureMap* m; size_t i;
+        friend class FeatureMap;
+    };
+    FeatureMap() {}
+    FeatureMap(const FeatureMap&) = delete;
+    FeatureMap& operator=(const FeatureMap&) = delete;
+    ~FeatureMap() { for (Slot& s : slots) delete s.f; for (Feature* f : spare) delete f; }
+    size_t size() const { return n_live; }
+    bool empty() const { return n_live == 0; }
+    iterator begin() const { return iterator(this, 0); }
+    iterator end() const { iterator it; it.m = this; it.i = slots.size(); return it; }
+    iterator find(long long id) const { const size_t k = lower(id); return (k < slots.size() && slots[k].id == id && slots[k].live) ? at_index(k) : end(); }
+    Feature& at(long long id) const { const size_t k = lower(id); if (!(k < slots.size() && slots[k].id == id && slots[k].live)) throw std::out_of_range("FeatureMap::at"); return *slots[k].f; }
+    Feature& operator[](long long id) { return *slots[obtain(id)].f; }
+    // both emplace forms: the feature value is always a fresh one in the callers (Feature()), so only the id is used
+    std::pair<iterator, bool> emplace(long long id, const Feature&) { const size_t before = n_live; const size_t k = obtain(id); return std::make_pair(at_index(k), n_live != before); }
+    iterator emplace_hint(const iterator&, long long id, const Feature&) { return at_index(obtain(id)); }
+    size_t erase(long long id) { const size_t k = lower(id); if (!(k < slots.size() && slots[k].id == id && slots[k].live)) return 0; slots[k].live = false; --n_live; ++n_dead; return 1; }
+    iterator erase(const iterator& it) { Slot& s = slots[it.i]; if (s.live) { s.live = false; --n_live; ++n_dead; } return iterator(this, it.i + 1); }
+    // sweep the erased slots (their objects go back to the free list); invalidates iterators, keeps the addresses of live features
+    void purge()
+    {
+        if (!n_dead) return;
+        size_t w = 0;
+        for (size_t r = 0; r < slots.size(); ++r) { if (slots[r].live) slots[w++] = slots[r]; else spare.push_back(slots[r].f); }
+        slots.resize(w); n_dead = 0;
+    }
+  private:
+    size_t lower(long long id) const
+    {   // first slot with id >= wanted; the newest ids are asked for most
+        const size_t n = slots.size();
+        if (n == 0 || slots[n - 1].id < id) return n;
+        size_t lo = 0, hi = n - 1;
+        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (slots[mid].id < id) lo = mid + 1; else hi = mid; }
+        return lo;
+    }
+    iterator at_index(size_t k) const { iterator it; it.m = this; it.i = k; return it; }
+    Feature* fresh(long long id) { Feature* f; if (!spare.empty()) { f = spare.back(); spare.pop_back(); } else f = new Feature(); f->reset(id); return f; }
+    size_t obtain(long long id)
+    {   // index of the live slot of `id`, creating it (as a default feature) if there is none
+        const size_t k = lower(id);
+        if (k < slots.size() && slots[k].id == id) {
+            if (!slots[k].live) { slots[k].f->reset(id); slots[k].live = true; ++n_live; --n_dead; }      // erased earlier in this message cycle: a new feature under the old id
+            return k;
+        }
+        Slot s; s.id = id; s.f = fresh(id); s.live = true;
+        slots.insert(slots.begin() + (long)k, s);               // k == size() for a new track (ids grow): an append
+        ++n_live;
+        return k;
+    }
+    std::vector<Slot> slots; std::vector<Feature*> spare; size_t n_live = 0, n_dead = 0;
 };
 struct Clone {
     long long id; double time, dt; double q[4], p[3], p_fej[3], R_b2c[9], t_c_b[3], q_cam[4], p_cam[3];
@@ -103,7 +199,7 @@ struct lvk_ekf {
     mutable std::vector<short> rank_tab; mutable long long rank_base = 0; mutable bool ranks_dirty = true;   // see clone_rank()
     mutable std::vector<double> rcam; mutable bool rcam_valid = false;      // camera-to-world rotation of every clone (clone_Rcam), rebuilt after poses change
     std::vector<long long> feature_states;
-    std::map<long long, Feature> map;                  // map_server (ascending id)
+    FeatureMap map;                                    // map_server (ascending id)
     int leg = 22;
     int N = 22;
     double imx[24];                                     // T1 T2 T3 A1 A2 A3 M1 M2 (larvio.cpp:129-154)
@@ -672,6 +768,7 @@ static void add_observations(lvk_ekf* e, const lvk_feature_obs* f, int n)
         }
     }
     e->tracking_rate = (double)tracked / (double)curr_num;
+    e->map.purge();                                      // features erased by the previous update and not re-created by this message
 }
 
 // ------------------------------------------------------------------------- state injection (larvio.cpp:1476-1575 etc.)
@@ -1108,7 +1205,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
     const lvk_ekf_config& c = e->cfg;
     const int cells = c.aug_grid_rows * c.aug_grid_cols;
     std::vector<long long> ekf_ids, ekf_lost;
-    for (auto& kv : e->map) {
+    for (auto kv : e->map) {
         Feature& f = kv.second;
         const bool tracked = f.find(e->imu_id) >= 0;
         if (f.in_state) { if (tracked) ekf_ids.push_back(f.id); else ekf_lost.push_back(f.id); }
@@ -1147,7 +1244,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
     e->tri_ranks.clear(); e->tri_z.clear();
     struct Cand { Feature* f; int idx_pos = -1, idx_inv = -1; bool motion; };
     std::vector<Cand> cands;
-    for (auto& kv : e->map) {
+    for (auto kv : e->map) {
         Feature& f = kv.second;
         if (f.in_state) continue;
         const bool tracked = f.find(e->imu_id) >= 0;
@@ -1175,7 +1272,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
     // ---- pass 2: sequential triage (map order) with the precomputed results
     std::vector<long long> invalid, msckf, ekf_new;
     size_t ci = 0;
-    for (auto& kv : e->map) {
+    for (auto kv : e->map) {
         Feature& f = kv.second;
         if (f.in_state) continue;
         const bool tracked = f.find(e->imu_id) >= 0;
@@ -1456,7 +1553,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
     std::vector<Use> uses; std::vector<TriReq> reqs; std::vector<TriAns> ans;
     e->tri_ranks.clear(); e->tri_z.clear();
     bool clones_uploaded = false;
-    for (auto& kv : e->map) {
+    for (auto kv : e->map) {
         Feature& f = kv.second;
         struct { long long v[2]; int n = 0; void push_back(long long x) { v[n++] = x; } bool empty() const { return n == 0; } size_t size() const { return (size_t)n; }
                  const long long* data() const { return v; } const long long* begin() const { return v; } const long long* end() const { return v + n; } } inv;   // nrm <= 2: no heap traffic per feature
@@ -1529,7 +1626,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; std::vector<RowGroup> grp; int rows = 0;
         for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N, sharded ? shard_owner(jb, k) : 0); rows += r; }
-        for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
+        for (auto kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
         {
             if (!sharded) st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
@@ -1550,7 +1647,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
             }
         }
     } else {
-        for (auto& kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
+        for (auto kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
     }
     {   // both clones' rows/columns leave P in ONE gather (the reference deletes them one after the other, :2563-2638)
         std::vector<char> drop(e->N, 0);

@@ -163,13 +163,35 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
     const int max_level = n_levels - 1;
     const int wrow = lane / 3, x0 = (lane - 3 * wrow) * LK_RS_SEG;
     const bool act = lane < 3 * WIN;
+    // The template of a level depends on prev_pt alone, not on what the iterations of the coarser level find: its raw bytes are
+    // requested ONE LEVEL AHEAD (before the coarser level's iterations start) and sit in registers when that level begins - the
+    // first-touch round trip of levels max-1..0 disappears from the dependent chain.
+    struct Raw { unsigned long long i0, i1; uint4 d00, d01, d10, d11; int ipx, ipy; bool ok; };
+    auto fetch = [&](int level) {
+        Raw r; r.i0 = 0; r.i1 = 0; r.d00 = r.d01 = r.d10 = r.d11 = uint4{0, 0, 0, 0};
+        const float lscale = (float)(1. / (1 << level));
+        const float prx = prev_pt.x * lscale - half, pry = prev_pt.y * lscale - half;
+        r.ipx = d_cv_floor(prx); r.ipy = d_cv_floor(pry);
+        const int cols = prev.w[level], rows = prev.h[level];
+        r.ok = !(r.ipx < -WIN || r.ipx >= cols || r.ipy < -WIN || r.ipy >= rows);
+        if (r.ok && act) {
+            const int stepI = prev.istride[level], dstep = prev.dstride[level];
+            const uint8_t* src = prev.img[level] + (ptrdiff_t)(wrow + r.ipy) * stepI + (x0 + r.ipx);
+            const int16_t* ds = prev.der[level] + (ptrdiff_t)(wrow + r.ipy) * dstep + 2 * (x0 + r.ipx);
+            __builtin_memcpy(&r.i0, src, 8); __builtin_memcpy(&r.i1, src + stepI, 8);
+            __builtin_memcpy(&r.d00, ds, 16); __builtin_memcpy(&r.d01, ds + 8, 16);
+            __builtin_memcpy(&r.d10, ds + dstep, 16); __builtin_memcpy(&r.d11, ds + dstep + 8, 16);
+        }
+        return r;
+    };
+    Raw cur = fetch(max_level);
 
     for (int level = max_level; level >= 0; --level) {
+        const Raw raw = cur;
+        if (level > 0) cur = fetch(level - 1);
         const int cols = prev.w[level], rows = prev.h[level];
-        const int stepI = prev.istride[level], stepJ = next.istride[level], dstep = prev.dstride[level];
-        const uint8_t* __restrict__ Ibase = prev.img[level];
+        const int stepJ = next.istride[level];
         const uint8_t* __restrict__ Jbase = next.img[level];
-        const int16_t* __restrict__ Dbase = prev.der[level];
         const float lscale = (float)(1. / (1 << level));
         float prx = prev_pt.x * lscale, pry = prev_pt.y * lscale;
         float nx, ny;
@@ -179,8 +201,8 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
         int n_it = 0;
 
         prx -= half; pry -= half;
-        const int ipx = d_cv_floor(prx), ipy = d_cv_floor(pry);
-        if (ipx < -WIN || ipx >= cols || ipy < -WIN || ipy >= rows) {
+        const int ipx = raw.ipx, ipy = raw.ipy;               // = cvFloor(prx), cvFloor(pry): the same expressions as in fetch()
+        if (!raw.ok) {
             if (level == 0) status = 0;
             if (iters_out && lane == 0) iters_out[level] = 0;
             continue;
@@ -194,15 +216,8 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
         short Iv[LK_RS_SEG], Ixv[LK_RS_SEG], Iyv[LK_RS_SEG];
         int pA11 = 0, pA12 = 0, pA22 = 0;
         {
-            unsigned long long i0 = 0, i1 = 0;
-            uint4 d00 = {0, 0, 0, 0}, d01 = {0, 0, 0, 0}, d10 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
-            if (act) {
-                const uint8_t* src = Ibase + (ptrdiff_t)(wrow + ipy) * stepI + (x0 + ipx);
-                const int16_t* ds = Dbase + (ptrdiff_t)(wrow + ipy) * dstep + 2 * (x0 + ipx);
-                __builtin_memcpy(&i0, src, 8); __builtin_memcpy(&i1, src + stepI, 8);
-                __builtin_memcpy(&d00, ds, 16); __builtin_memcpy(&d01, ds + 8, 16);
-                __builtin_memcpy(&d10, ds + dstep, 16); __builtin_memcpy(&d11, ds + dstep + 8, 16);
-            }
+            const unsigned long long i0 = raw.i0, i1 = raw.i1;
+            const uint4 d00 = raw.d00, d01 = raw.d01, d10 = raw.d10, d11 = raw.d11;
             const unsigned dr0[8] = {d00.x, d00.y, d00.z, d00.w, d01.x, d01.y, d01.z, d01.w};
             const unsigned dr1[8] = {d10.x, d10.y, d10.z, d10.w, d11.x, d11.y, d11.z, d11.w};
 #pragma unroll
