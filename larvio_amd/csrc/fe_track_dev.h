@@ -34,6 +34,16 @@ __device__ __forceinline__ long long wave_sum_i64(int v)
 // were not faster: LDS-staged search window; row-segment lanes with two unaligned 8-byte loads per iteration instead of 28 byte
 // loads; requesting all levels' template/gradient runs up front.
 #define LK_W_BITS 14
+// The bilinear blends multiply bytes (or int16 derivatives) by 14-bit weights: both operands fit 24 bits, so the full-rate 24-bit
+// multiplier gives the exact product (v_mul_lo_u32 is a quarter-rate instruction: 28 of them per iteration were ~40% of its issue time).
+__device__ __forceinline__ int lk_blend_u8(int s00, int s01, int s10, int s11, int iw00, int iw01, int iw10, int iw11)
+{
+    return (int)(__umul24((unsigned)s00, (unsigned)iw00) + __umul24((unsigned)s01, (unsigned)iw01) + __umul24((unsigned)s10, (unsigned)iw10) + __umul24((unsigned)s11, (unsigned)iw11));
+}
+__device__ __forceinline__ int lk_blend_i16(int x00, int x01, int x10, int x11, int iw00, int iw01, int iw10, int iw11)
+{
+    return __mul24(x00, iw00) + __mul24(x01, iw01) + __mul24(x10, iw10) + __mul24(x11, iw11);
+}
 template <int WIN>
 __device__ __forceinline__ int lk_point_generic(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
                                         int& status, int max_count, double epsilon, int* __restrict__ iters_out)
@@ -85,9 +95,9 @@ __device__ __forceinline__ int lk_point_generic(const PyrView& prev, const PyrVi
             if (lane + 64 * k < NPIX) {
                 const uint8_t* src = Ibase + (ptrdiff_t)(wy[k] + ipy) * stepI + (wx[k] + ipx);
                 const int16_t* ds = Dbase + (ptrdiff_t)(wy[k] + ipy) * dstep + 2 * (wx[k] + ipx);
-                int ival = (src[0] * iw00 + src[1] * iw01 + src[stepI] * iw10 + src[stepI + 1] * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
-                int ixval = (ds[0] * iw00 + ds[2] * iw01 + ds[dstep] * iw10 + ds[dstep + 2] * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
-                int iyval = (ds[1] * iw00 + ds[3] * iw01 + ds[dstep + 1] * iw10 + ds[dstep + 3] * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int ival = (lk_blend_u8(src[0], src[1], src[stepI], src[stepI + 1], iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+                int ixval = (lk_blend_i16(ds[0], ds[2], ds[dstep], ds[dstep + 2], iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int iyval = (lk_blend_i16(ds[1], ds[3], ds[dstep + 1], ds[dstep + 3], iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
                 Iv[k] = (short)ival; Ixv[k] = (short)ixval; Iyv[k] = (short)iyval;
                 pA11 += ixval * ixval; pA12 += ixval * iyval; pA22 += iyval * iyval;
             }
@@ -121,7 +131,7 @@ __device__ __forceinline__ int lk_point_generic(const PyrView& prev, const PyrVi
             for (int k = 0; k < PL; ++k) {
                 if (lane + 64 * k < NPIX) {
                     const uint8_t* Jp = Jbase + (ptrdiff_t)(wy[k] + iny) * stepJ + (wx[k] + inx);
-                    int diff = ((Jp[0] * iw00 + Jp[1] * iw01 + Jp[stepJ] * iw10 + Jp[stepJ + 1] * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
+                    int diff = ((lk_blend_u8(Jp[0], Jp[1], Jp[stepJ], Jp[stepJ + 1], iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
                     pb1 += diff * Ixv[k]; pb2 += diff * Iyv[k];
                 }
             }
@@ -226,9 +236,9 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
                 const int s10 = (int)((i1 >> (8 * j)) & 0xFF), s11 = (int)((i1 >> (8 * j + 8)) & 0xFF);
                 const int x00 = (short)(dr0[j] & 0xFFFF), y00 = (short)(dr0[j] >> 16), x01 = (short)(dr0[j + 1] & 0xFFFF), y01 = (short)(dr0[j + 1] >> 16);
                 const int x10 = (short)(dr1[j] & 0xFFFF), y10 = (short)(dr1[j] >> 16), x11 = (short)(dr1[j + 1] & 0xFFFF), y11 = (short)(dr1[j + 1] >> 16);
-                int ival = (s00 * iw00 + s01 * iw01 + s10 * iw10 + s11 * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
-                int ixval = (x00 * iw00 + x01 * iw01 + x10 * iw10 + x11 * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
-                int iyval = (y00 * iw00 + y01 * iw01 + y10 * iw10 + y11 * iw11 + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int ival = (lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+                int ixval = (lk_blend_i16(x00, x01, x10, x11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int iyval = (lk_blend_i16(y00, y01, y10, y11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
                 if (!act) { ival = 0; ixval = 0; iyval = 0; }
                 Iv[j] = (short)ival; Ixv[j] = (short)ixval; Iyv[j] = (short)iyval;
                 pA11 += ixval * ixval; pA12 += ixval * iyval; pA22 += iyval * iyval;
@@ -268,7 +278,7 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
             for (int k = 0; k < LK_RS_SEG; ++k) {
                 const int s00 = (int)((j0 >> (8 * k)) & 0xFF), s01 = (int)((j0 >> (8 * k + 8)) & 0xFF);
                 const int s10 = (int)((j1 >> (8 * k)) & 0xFF), s11 = (int)((j1 >> (8 * k + 8)) & 0xFF);
-                int diff = ((s00 * iw00 + s01 * iw01 + s10 * iw10 + s11 * iw11 + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
+                int diff = ((lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
                 if (!act) diff = 0;
                 pb1 += diff * Ixv[k]; pb2 += diff * Iyv[k];
             }
