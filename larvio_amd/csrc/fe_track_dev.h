@@ -38,7 +38,7 @@ __device__ __forceinline__ long long wave_sum_i64(int v)
 // multiplier gives the exact product (v_mul_lo_u32 is a quarter-rate instruction: 28 of them per iteration were ~40% of its issue time).
 __device__ __forceinline__ int lk_blend_u8(int s00, int s01, int s10, int s11, int iw00, int iw01, int iw10, int iw11)
 {
-    return (int)(__umul24((unsigned)s00, (unsigned)iw00) + __umul24((unsigned)s01, (unsigned)iw01) + __umul24((unsigned)s10, (unsigned)iw10) + __umul24((unsigned)s11, (unsigned)iw11));
+    return __mul24(s00, iw00) + __mul24(s01, iw01) + __mul24(s10, iw10) + __mul24(s11, iw11);     // SIGNED: iw11 = 2^14 - (the other three) can be -1 after rounding
 }
 __device__ __forceinline__ int lk_blend_i16(int x00, int x01, int x10, int x11, int iw00, int iw01, int iw10, int iw11)
 {
