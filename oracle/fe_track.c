@@ -22,6 +22,11 @@ static inline int cv_floor_f(float v) { return (int)floorf(v); }
  * correctly-rounded value of the sum every OpenCV build approximates, and is independent of
  * summation order (so a wave-parallel reduction reproduces it bit-for-bit). */
 #define W_BITS 14
+/* Sensitivity probe (tests/test_oracle_frontend.py): 1 = accumulate A11/A12/A22 and b1/b2 the way OpenCV's scalar (non-SIMD)
+ * LKTrackerInvoker does - float32 running sums, pixel by pixel in row-major order - instead of exactly.  Not used by any parity
+ * test: it measures how far a float-accumulating OpenCV build can be from the exact sums the product reproduces. */
+int lvo_lk_float_accum_ = 0;
+void lvo_set_lk_float_accum(int on) { lvo_lk_float_accum_ = on ? 1 : 0; }
 void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
                   const lvo_pt2f* prev_pts, lvo_pt2f* next_pts, uint8_t* status, int n,
                   int max_iter, double eps, int* iters_out)
@@ -70,6 +75,7 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
             int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+            float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;
             for (int y = 0; y < win; ++y) {
                 const uint8_t* src = Ibase + (ptrdiff_t)(y + ipy) * stepI + ipx;
                 const int16_t* dsrc = Dbase + (ptrdiff_t)(y + ipy) * dstep + 2 * ipx;
@@ -86,9 +92,11 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
                     sA11 += (int64_t)(ixval * ixval);
                     sA12 += (int64_t)(ixval * iyval);
                     sA22 += (int64_t)(iyval * iyval);
+                    fA11 += (float)(ixval * ixval); fA12 += (float)(ixval * iyval); fA22 += (float)(iyval * iyval);
                 }
             }
             float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+            if (lvo_lk_float_accum_) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
             float D = A11 * A22 - A12 * A12;
             float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
             if ((double)min_eig < min_eig_threshold || D < FLT_EPSILON) {
@@ -112,6 +120,7 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
                 iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
                 int64_t sb1 = 0, sb2 = 0;
+                float fb1 = 0.f, fb2 = 0.f;
                 for (int y = 0; y < win; ++y) {
                     const uint8_t* Jp = Jbase + (ptrdiff_t)(y + iny) * stepJ + inx;
                     for (int x = 0; x < win; ++x) {
@@ -119,9 +128,11 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
                                      + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Iwin[y * win + x];
                         sb1 += (int64_t)(diff * dIwin[2 * (y * win + x)]);
                         sb2 += (int64_t)(diff * dIwin[2 * (y * win + x) + 1]);
+                        fb1 += (float)(diff * dIwin[2 * (y * win + x)]); fb2 += (float)(diff * dIwin[2 * (y * win + x) + 1]);
                     }
                 }
                 float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+                if (lvo_lk_float_accum_) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
                 float dx = (A12 * b2 - A22 * b1) * D;
                 float dy = (A12 * b1 - A11 * b2) * D;
                 nx += dx; ny += dy;

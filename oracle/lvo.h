@@ -102,6 +102,7 @@ void lvo_min_eigen_map(const lvo_pyramid* pyr, float* eig);
  * [upstream lkpyramid.cpp LKTrackerInvoker]; call sites image_processor.cpp:368,405,558,618,830,870.
  * next_pts is in/out (initial flow in, result out).  iters_out (optional, n*levels ints) =
  * executed iterations per point and level (for the algorithmic-bytes figure). */
+void lvo_set_lk_float_accum(int on);   /* sensitivity probe: OpenCV's scalar float32 running sums instead of the exact ones (never on in parity tests) */
 void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
                   const lvo_pt2f* prev_pts, lvo_pt2f* next_pts, uint8_t* status, int n,
                   int max_iter, double eps, int* iters_out);

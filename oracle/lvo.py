@@ -111,6 +111,12 @@ def set_threads(n):
     lib().lvo_set_threads(int(n))
 
 
+def set_lk_float_accum(on):
+    """sensitivity probe: LK's A11/A12/A22/b1/b2 as float32 running sums in row-major order (OpenCV's scalar LKTrackerInvoker) instead of
+    the exact integer sums.  Off in every parity test."""
+    lib().lvo_set_lk_float_accum(int(bool(on)))
+
+
 def get_threads():
     return lib().lvo_get_threads()
 
