@@ -303,16 +303,12 @@ __global__ void __launch_bounds__(64) k_fe_orb_gate(const uint8_t* __restrict__ 
 // both sets to pixel coordinates (K -> K), cv::findFundamentalMat mask, then write the destination
 // track set.  mode 0: old tracks (trackFeatures :701-808), 1: new points appended (trackNewFeatures
 // :932-1001), 2: bootstrap (initializeFirstFeatures :464-536).
-__global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int cap, CamParams cam,
-                                                               const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                               const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
-                                                               const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
-                                                               const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
-                                                               TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
-{
-    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
-    __shared__ uint8_t smask[FM_MAX_N];
-    __shared__ unsigned short sidx[FM_MAX_N];
+__device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamParams& cam,
+                                                const lvk_pt2f* src_pts, const int* n_ptr, const lvk_pt2f* w_curr, const uint8_t* w_status,
+                                                const unsigned long long* src_id, const lvk_pt2f* src_init, const int* src_life, const unsigned long long* src_desc,
+                                                const TrackSet& dst, int* dst_n, FeDev* dev,
+                                                lvk_pt2f* s1, lvk_pt2f* s2, uint8_t* smask, unsigned short* sidx)
+{   // s1, s2, smask, sidx: LDS scratch for FM_MAX_N points, owned by the calling kernel (k_fe_commit_all runs two commits on the same arrays)
     __shared__ int cnt[4];
     __shared__ int scan[FM_THREADS];
     const int t = threadIdx.x;
@@ -411,14 +407,22 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int c
     }
 }
 
+__global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int cap, CamParams cam,
+                                                               const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                               const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
+                                                               const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
+                                                               const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
+                                                               TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
+{
+    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
+    __shared__ uint8_t smask[FM_MAX_N];
+    __shared__ unsigned short sidx[FM_MAX_N];
+    fe_commit_block(mode, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
+}
+
 // getFeatureMsg (:1076-1128): undistort to normalised coordinates, finite-difference velocities
-__global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams cam, double dt_1, double dt_2, int prev_is_last,
-                         lvk_feature_obs* __restrict__ out, FeDev* __restrict__ dev, int* __restrict__ n_host)
-{   // `out` and `n_host` are device-mapped pinned host memory: the message needs no copy command, only the stream sync
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = *n_ptr;
-    if (i == 0) { dev->n_msg = n; *n_host = n; dev->msg_features += (unsigned long long)n; dev->msg_count += 1ull; }
-    if (i >= n) return;
+__device__ __forceinline__ void fe_msg_one(const TrackSet& ts, int i, const CamParams& cam, double dt_1, double dt_2, int prev_is_last, lvk_feature_obs* out)
+{
     const double unit[4] = {1, 1, 0, 0};
     const lvk_pt2f uc = undistort_point(ts.pts[i], cam, unit);
     const lvk_pt2f ini = ts.init[i];
@@ -438,6 +442,43 @@ __global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams c
         else { f.u_init_vel = (up.x - ui.x) / dt_2; f.v_init_vel = (up.y - ui.y) / dt_2; }
     }
     out[i] = f;
+}
+__global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams cam, double dt_1, double dt_2, int prev_is_last,
+                         lvk_feature_obs* __restrict__ out, FeDev* __restrict__ dev, int* __restrict__ n_host)
+{   // `out` and `n_host` are device-mapped pinned host memory: the message needs no copy command, only the stream sync
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_ptr;
+    if (i == 0) { dev->n_msg = n; *n_host = n; dev->msg_features += (unsigned long long)n; dev->msg_count += 1ull; }
+    if (i >= n) return;
+    fe_msg_one(ts, i, cam, dt_1, dt_2, prev_is_last, out);
+}
+
+// The end of a steady-state frame's chain in ONE launch: RANSAC + commit of the old tracks (trackFeatures :701-808), RANSAC + append of
+// the new points (trackNewFeatures :932-1001) and - on publish frames - the feature message (getFeatureMsg :1076-1128).  All three are
+// one-workgroup stages that ran as three dependent launches; what the filter's thread waits for is the END of this chain, so the two
+// launch boundaries (each a barrier packet + ~5 us of launch floor) came straight off the image-in -> message latency.
+struct FeMsgArgs { int publish, prev_is_last; double dt_1, dt_2; lvk_feature_obs* out; int* n_host; };
+__global__ void __launch_bounds__(FM_THREADS) k_fe_commit_all(int cap, CamParams cam,
+                                                            const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                            const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
+                                                            const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
+                                                            const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
+                                                            const lvk_pt2f* __restrict__ new_pts, const int* n_new_ptr,
+                                                            const lvk_pt2f* __restrict__ wn_curr, const uint8_t* __restrict__ wn_status,
+                                                            const unsigned long long* __restrict__ wn_desc,
+                                                            TrackSet dst, int* dst_n, FeDev* dev, FeMsgArgs msg)
+{
+    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
+    __shared__ uint8_t smask[FM_MAX_N];
+    __shared__ unsigned short sidx[FM_MAX_N];
+    fe_commit_block(0, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
+    __syncthreads();                                        // *dst_n and the destination set of the old tracks are complete (one workgroup: one CU, one L1)
+    fe_commit_block(1, cap, cam, new_pts, n_new_ptr, wn_curr, wn_status, nullptr, nullptr, nullptr, wn_desc, dst, dst_n, dev, s1, s2, smask, sidx);
+    __syncthreads();
+    if (!msg.publish) return;
+    const int n = *dst_n;
+    if (threadIdx.x == 0) { dev->n_msg = n; *msg.n_host = n; dev->msg_features += (unsigned long long)n; dev->msg_count += 1ull; }
+    for (int i = threadIdx.x; i < n; i += FM_THREADS) fe_msg_one(dst, i, cam, msg.dt_1, msg.dt_2, msg.prev_is_last, msg.out);
 }
 
 
@@ -706,29 +747,53 @@ static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
 }
 // getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172).  async_slot == nullptr: wait for the message and copy it out (the
 // reference's synchronous processImage); otherwise return the ring slot at once - lvk_frontend_fetch_msg collects it later.
-static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out, int* async_slot)
+// ring entry for this frame's message (waits only if the consumer is four publishes behind)
+static lvk_status fe_publish_slot(lvk_frontend* fe, int* slot_out)
 {
     lvk_context* ctx = fe->ctx;
-    lvk_status st;
     const int slot = fe->msg_next; fe->msg_next = (slot + 1) % LVK_MSG_SLOTS;
     if (fe->msg_pending[slot].load(std::memory_order_acquire)) {       // four publishes ago and still not fetched: the consumer is far behind
         LVK_HIP(ctx, hipEventSynchronize(fe->ev_msg[slot]));
         for (int spin = 0; fe->msg_pending[slot].load(std::memory_order_acquire); ++spin) { if (spin > 2000000) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature-message ring overrun"); __builtin_ia32_pause(); }
     }
-    { ProfScope ps8(fe, 8);
-    const double dt_1 = fe->curr_img_time - fe->prev_img_time;
-    const int prev_is_last = fe->prev_img_time == fe->last_pub_time;
-    const double dt_2 = prev_is_last ? dt_1 : fe->prev_img_time - fe->last_pub_time;
-    hipLaunchKernelGGL(k_fe_msg, dim3((fe->cap + 63) / 64), dim3(64), 0, ctx->stream, fe->set[dst], (const int*)&fe->dev->n_tracks[dst], fe->cam, dt_1, dt_2,
-                       prev_is_last, fe->d_msg + (size_t)slot * fe->cap, fe->dev, fe->d_nmsg + 16 * slot);
-    LVK_LAUNCH_CHECK(ctx); }
-    hipEventRecord(fe->ev_msg[slot], ctx->stream);
+    *slot_out = slot;
+    return LVK_OK;
+}
+static FeMsgArgs fe_msg_args(lvk_frontend* fe, int slot)
+{
+    FeMsgArgs m;
+    m.publish = 1;
+    m.dt_1 = fe->curr_img_time - fe->prev_img_time;
+    m.prev_is_last = fe->prev_img_time == fe->last_pub_time;
+    m.dt_2 = m.prev_is_last ? m.dt_1 : fe->prev_img_time - fe->last_pub_time;
+    m.out = fe->d_msg + (size_t)slot * fe->cap; m.n_host = fe->d_nmsg + 16 * slot;
+    return m;
+}
+// after the kernel that writes the message has been queued on the main stream: event, detection of new corners, bookkeeping
+// (:1170-1172); async_slot == nullptr: wait for the message and copy it out (the reference's synchronous processImage)
+static lvk_status fe_publish_finish(lvk_frontend* fe, int dst, double ts, int slot, lvk_feature_obs* h_out, int cap, int* n_out, int* async_slot)
+{
+    hipEventRecord(fe->ev_msg[slot], fe->ctx->stream);
     fe->msg_pending[slot].store(1, std::memory_order_release);
-    st = fe_detect_new(fe, dst);                         // queued on side[0] before anybody blocks on the message
+    lvk_status st = fe_detect_new(fe, dst);              // queued on side[0] before anybody blocks on the message
     if (st != LVK_OK) return st;
     fe->last_pub_time = ts; fe->pub_counter++;
     if (async_slot) { *async_slot = slot; *n_out = 0; return LVK_OK; }
     return lvk_frontend_fetch_msg(fe, slot, h_out, cap, n_out);
+}
+// getFeatureMsg (:1076-1128) as a launch of its own (bootstrap frames; steady-state frames write the message at the end of k_fe_commit_all)
+static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out, int* async_slot)
+{
+    lvk_context* ctx = fe->ctx;
+    int slot = 0;
+    lvk_status st = fe_publish_slot(fe, &slot);
+    if (st != LVK_OK) return st;
+    { ProfScope ps8(fe, 8);
+    const FeMsgArgs m = fe_msg_args(fe, slot);
+    hipLaunchKernelGGL(k_fe_msg, dim3((fe->cap + 63) / 64), dim3(64), 0, ctx->stream, fe->set[dst], (const int*)&fe->dev->n_tracks[dst], fe->cam, m.dt_1, m.dt_2,
+                       m.prev_is_last, m.out, fe->dev, m.n_host);
+    LVK_LAUNCH_CHECK(ctx); }
+    return fe_publish_finish(fe, dst, ts, slot, h_out, cap, n_out, async_slot);
 }
 
 // The IMU-independent part of a frame: image upload, createImagePyramids (:318-334) on the main stream, ORBdescriptor ctor (:150)
@@ -916,14 +981,24 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             st = track_chain(fe, S2, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
             hipEventRecord(fe->ev_new, S2);
             if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
-            if (st == LVK_OK) st = commit(fe, 0, fe->set[src].pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &fe->set[src], fe->set[src].desc, dst);
-            hipStreamWaitEvent(S1, fe->ev_new, 0);
-            if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st != LVK_OK) return st;
+            // both commits and (on publish frames) the message: ONE launch behind both chains
+            const bool publish = ts - fe->last_pub_time >= pub_gate;
+            int slot = 0;
+            FeMsgArgs margs; memset(&margs, 0, sizeof margs);
+            if (publish) { st = fe_publish_slot(fe, &slot); if (st != LVK_OK) return st; margs = fe_msg_args(fe, slot); }
+            hipStreamWaitEvent(S1, fe->ev_new, 0);
+            { ProfScope ps(fe, 5);
+            const TrackSet& so = fe->set[src];
+            hipLaunchKernelGGL(k_fe_commit_all, dim3(1), dim3(FM_THREADS), 0, S1, fe->cap, fe->cam, (const lvk_pt2f*)so.pts, (const int*)&fe->dev->n_tracks[src],
+                               (const lvk_pt2f*)fe->w_curr, (const uint8_t*)fe->w_status, (const unsigned long long*)so.id, (const lvk_pt2f*)so.init, (const int*)so.life,
+                               (const unsigned long long*)so.desc, (const lvk_pt2f*)fe->new_pts, (const int*)&fe->dev->n_new, (const lvk_pt2f*)fe->wn_curr,
+                               (const uint8_t*)fe->wn_status, (const unsigned long long*)fe->wn_desc, fe->set[dst], &fe->dev->n_tracks[dst], fe->dev, margs);
+            LVK_LAUNCH_CHECK(ctx); }
             curr_valid = true;
             hipEventRecord(fe->ev_commit, S1);
-            if (ts - fe->last_pub_time >= pub_gate) {
-                st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
+            if (publish) {
+                st = fe_publish_finish(fe, dst, ts, slot, h_out, cap, n_out, async_slot);
                 if (st != LVK_OK) return st;
                 *has_msg = 1;
             }
