@@ -234,69 +234,73 @@ __device__ __forceinline__ lvk_pt2f apply_h(const HMat& H, lvk_pt2f p)
 #define ST_REV   2
 #define ST_ORB   3
 
-// forward LK (prev -> curr, seeded with the gyro-predicted point, :558-590 / :830-860) then reverse LK (curr -> prev, seeded with
-// the original point; in-image and <= 1 px tests, :616-642) of a point in ONE launch: the reverse pass needs nothing but this
-// point's forward result, and a launch less is one inter-kernel barrier less on the frame's dependent chain.
+// Forward LK (prev -> curr, seeded with the gyro-predicted point, :558-590 / :830-860), reverse LK (curr -> prev, seeded with the
+// original point; in-image and <= 1 px tests, :616-642) and the ORB descriptor gate (:677-699 old tracks: descriptor at the current
+// point vs the stored first-seen one; :909-930 new points: descriptor in the previous image vs in the current one, the previous one is
+// kept) of a point in ONE launch, TWO wavefronts per point: wavefront 0 runs the two LK passes back to back; wavefront 1 computes the
+// descriptors in their shadow - the previous-image one (new points) during the forward pass, the current-image one as soon as the
+// forward pass has produced the point, i.e. while the reverse pass runs.  The gate's launch (13 us + its barrier) leaves the frame's
+// dependent chain altogether; a descriptor computed for a point that then fails the reverse check is simply not used.
 template <int WIN>
-__global__ void __launch_bounds__(64) k_fe_lk_both(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                  HMat H, int width, int height, int max_count, double epsilon,
-                                                  lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev)
+__global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                   HMat H, int width, int height, int max_count, double epsilon,
+                                                   lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev,
+                                                   const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
+                                                   const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur,
+                                                   const unsigned long long* __restrict__ stored_desc /*old*/, unsigned long long* __restrict__ w_desc /*new: out*/, int is_new)
 {
+    __shared__ lvk_pt2f s_np;
+    __shared__ int s_st, s_dist;
     const int p = blockIdx.x;
     if (p >= *n_ptr) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_levels = prev.n_levels < next.n_levels ? prev.n_levels : next.n_levels;
+    const int step = width + 2 * LVK_ORB_BORDER;
     const lvk_pt2f pp = src_pts[p];
-    lvk_pt2f np = apply_h(H, pp);
-    int st = 1;
-    int its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
-    if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
-    int code = st ? ST_ALIVE : ST_FWD, passes = 1;
-    if (st) {
-        lvk_pt2f back = pp;
-        int sr = 1;
-        its += lk_point<WIN>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr);
-        passes = 2;
-        if (sr) {
-            if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
-            else {
-                float dx = back.x - pp.x, dy = back.y - pp.y;
-                float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
-                if (dis > 1) sr = 0;
-            }
-        }
-        if (!sr) code = ST_REV;
+    lvk_pt2f np = pp;
+    int st = 1, its = 0;
+    unsigned long long dp[4] = {0, 0, 0, 0};
+    if (wave == 0) {
+        np = apply_h(H, pp);
+        its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
+        if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
+        if (lane == 0) { s_np = np; s_st = st; }
+    } else if (is_new) {
+        orb_point(prv_ext, prv_blur, step, pp, dp);
+        if (lane == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
     }
-    if ((threadIdx.x & 63) == 0) {
+    __syncthreads();
+    int code = ST_FWD, passes = 1;
+    if (wave == 0) {
+        code = st ? ST_ALIVE : ST_FWD;
+        if (st) {
+            lvk_pt2f back = pp;
+            int sr = 1;
+            its += lk_point<WIN>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr);
+            passes = 2;
+            if (sr) {
+                if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
+                else {
+                    float dx = back.x - pp.x, dy = back.y - pp.y;
+                    float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
+                    if (dis > 1) sr = 0;
+                }
+            }
+            if (!sr) code = ST_REV;
+        }
+    } else if (s_st) {
+        unsigned long long dc[4];
+        orb_point(cur_ext, cur_blur, step, s_np, dc);
+        const int dist = is_new ? hamming256_u64(dc, dp) : hamming256_u64(dc, stored_desc + (size_t)p * 4);
+        if (lane == 0) s_dist = dist;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (code == ST_ALIVE && s_dist > 58) code = ST_ORB;
         w_curr[p] = np; w_status[p] = (uint8_t)code;
         atomicAdd(&dev->lk_point_levels, (unsigned long long)(passes * n_levels));
         atomicAdd(&dev->lk_iterations, (unsigned long long)its);
     }
-}
-
-// ORB gate.  OLD tracks: descriptor at the current point vs the stored first-seen one (:677-699).
-// NEW points: descriptor in the previous image vs in the current image, the previous one is kept (:909-930).
-__global__ void __launch_bounds__(64) k_fe_orb_gate(const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
-                                                   const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur, int width,
-                                                   const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                   const lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status,
-                                                   const unsigned long long* __restrict__ stored_desc /*old*/,
-                                                   unsigned long long* __restrict__ w_desc /*new: out*/, int is_new)
-{
-    const int p = blockIdx.x;
-    if (p >= *n_ptr) return;
-    if (w_status[p] != ST_ALIVE) return;
-    const int step = width + 2 * LVK_ORB_BORDER;
-    unsigned long long dc[4], dp[4];
-    orb_point(cur_ext, cur_blur, step, w_curr[p], dc);
-    int dist;
-    if (is_new) {
-        orb_point(prv_ext, prv_blur, step, src_pts[p], dp);
-        dist = hamming256_u64(dc, dp);
-        if ((threadIdx.x & 63) == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
-    } else {
-        dist = hamming256_u64(dc, stored_desc + (size_t)p * 4);
-    }
-    if ((threadIdx.x & 63) == 0 && dist > 58) w_status[p] = ST_ORB;
 }
 
 // One workgroup: count survivors per stage, order-preserving compaction of the alive points, undistort
@@ -582,12 +586,10 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
                                unsigned long long* w_desc, int is_new, int max_count, double epsilon)
 {
     const int W = fe->cfg.width, Hh = fe->cfg.height;
-    { ProfScope ps(fe, 2, s);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(64), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev); }
-    if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes follow it on the image stream
-    ProfScope ps(fe, 4, s);
-    hipLaunchKernelGGL(k_fe_orb_gate, dim3(grid), dim3(64), 0, s, (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0],
-                       (const uint8_t*)fe->blur[0], W, src_pts, n_ptr, (const lvk_pt2f*)w_curr, w_status, stored_desc, w_desc, is_new);
+    if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes (read by the kernel's second wavefront) follow it on the image stream
+    ProfScope ps(fe, 2, s);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
+                       (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new);
 }
 
 static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
