@@ -470,12 +470,12 @@ __global__ void __launch_bounds__(FM_THREADS) k_fe_commit_all(int cap, CamParams
                                                             const lvk_pt2f* __restrict__ new_pts, const int* n_new_ptr,
                                                             const lvk_pt2f* __restrict__ wn_curr, const uint8_t* __restrict__ wn_status,
                                                             const unsigned long long* __restrict__ wn_desc,
-                                                            TrackSet dst, int* dst_n, FeDev* dev, FeMsgArgs msg)
+                                                            TrackSet dst, int* dst_n, FeDev* dev, FeMsgArgs msg, int do_old)
 {
     __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
     __shared__ uint8_t smask[FM_MAX_N];
     __shared__ unsigned short sidx[FM_MAX_N];
-    fe_commit_block(0, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
+    if (do_old) fe_commit_block(0, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
     __syncthreads();                                        // *dst_n and the destination set of the old tracks are complete (one workgroup: one CU, one L1)
     fe_commit_block(1, cap, cam, new_pts, n_new_ptr, wn_curr, wn_status, nullptr, nullptr, nullptr, wn_desc, dst, dst_n, dev, s1, s2, smask, sidx);
     __syncthreads();
@@ -984,18 +984,34 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             hipEventRecord(fe->ev_new, S2);
             if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
             if (st != LVK_OK) return st;
-            // both commits and (on publish frames) the message: ONE launch behind both chains
+            // LVK_FE_COMMIT (temporary A/B switch): 0 = three launches (commit old, commit new, message), 1 = commit old on its own (it overlaps
+            // the wait for the new points' chain), commit new + message in one launch, 2 = all three in one launch
+            static const int commit_mode = [] { const char* v = getenv("LVK_FE_COMMIT"); return v ? atoi(v) : 1; }();
             const bool publish = ts - fe->last_pub_time >= pub_gate;
             int slot = 0;
             FeMsgArgs margs; memset(&margs, 0, sizeof margs);
+            const TrackSet& so = fe->set[src];
+            if (commit_mode == 0) {
+                st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst);
+                hipStreamWaitEvent(S1, fe->ev_new, 0);
+                if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
+                if (st != LVK_OK) return st;
+                curr_valid = true;
+                hipEventRecord(fe->ev_commit, S1);
+                if (publish) {
+                    st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
+                    if (st != LVK_OK) return st;
+                    *has_msg = 1;
+                }
+            } else {
+            if (commit_mode == 1) { st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst); if (st != LVK_OK) return st; }
             if (publish) { st = fe_publish_slot(fe, &slot); if (st != LVK_OK) return st; margs = fe_msg_args(fe, slot); }
             hipStreamWaitEvent(S1, fe->ev_new, 0);
             { ProfScope ps(fe, 5);
-            const TrackSet& so = fe->set[src];
             hipLaunchKernelGGL(k_fe_commit_all, dim3(1), dim3(FM_THREADS), 0, S1, fe->cap, fe->cam, (const lvk_pt2f*)so.pts, (const int*)&fe->dev->n_tracks[src],
                                (const lvk_pt2f*)fe->w_curr, (const uint8_t*)fe->w_status, (const unsigned long long*)so.id, (const lvk_pt2f*)so.init, (const int*)so.life,
                                (const unsigned long long*)so.desc, (const lvk_pt2f*)fe->new_pts, (const int*)&fe->dev->n_new, (const lvk_pt2f*)fe->wn_curr,
-                               (const uint8_t*)fe->wn_status, (const unsigned long long*)fe->wn_desc, fe->set[dst], &fe->dev->n_tracks[dst], fe->dev, margs);
+                               (const uint8_t*)fe->wn_status, (const unsigned long long*)fe->wn_desc, fe->set[dst], &fe->dev->n_tracks[dst], fe->dev, margs, commit_mode == 2 ? 1 : 0);
             LVK_LAUNCH_CHECK(ctx); }
             curr_valid = true;
             hipEventRecord(fe->ev_commit, S1);
@@ -1003,6 +1019,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
                 st = fe_publish_finish(fe, dst, ts, slot, h_out, cap, n_out, async_slot);
                 if (st != LVK_OK) return st;
                 *has_msg = 1;
+            }
             }
         }
     }

@@ -1,13 +1,15 @@
 #!/bin/bash
-# Same-box A/B of library variants: tools/gpu/ab.sh <tag> <rounds> "<bench args>" <lib1> <lib2> ...   (libs under variants/, selected through LVK_LIB)
+# Same-box A/B of variants, alternating:  tools/gpu/ab.sh <tag> <rounds> "<bench args>" <label>:<VAR=VAL>[,<VAR=VAL>...] ...
+# (a library built elsewhere is selected with LVK_LIB=variants/x.so; "-" = no variable)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 TAG=$1; R=$2; ARGS=$3; shift 3
 O=gpurun_out/$TAG; mkdir -p $O
 for r in $(seq 1 $R); do
-  for lib in "$@"; do
-    n=$(basename $lib .so)
-    LVK_LIB=$GRAFT_REPO_ROOT/$lib timeout 600 python bench.py $ARGS > $O/${n}_r$r.json 2> $O/${n}_r$r.err
+  for spec in "$@"; do
+    n=${spec%%:*}; envs=${spec#*:}
+    ( IFS=','; for kv in $envs; do [ "$kv" != "-" ] && export "$kv"; done; unset IFS
+      timeout 600 python bench.py $ARGS > $O/${n}_r$r.json 2> $O/${n}_r$r.err )
     python - "$O/${n}_r$r.json" "$n r$r" <<'P'
 import json, sys
 d = None
