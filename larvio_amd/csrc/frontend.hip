@@ -312,7 +312,7 @@ __device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamPara
                                                 const unsigned long long* src_id, const lvk_pt2f* src_init, const int* src_life, const unsigned long long* src_desc,
                                                 const TrackSet& dst, int* dst_n, FeDev* dev,
                                                 lvk_pt2f* s1, lvk_pt2f* s2, uint8_t* smask, unsigned short* sidx)
-{   // s1, s2, smask, sidx: LDS scratch for FM_MAX_N points, owned by the calling kernel (k_fe_commit_all runs two commits on the same arrays)
+{   // s1, s2, smask, sidx: LDS scratch for FM_MAX_N points, owned by the calling kernel
     __shared__ int cnt[4];
     __shared__ int scan[FM_THREADS];
     const int t = threadIdx.x;
@@ -457,34 +457,7 @@ __global__ void k_fe_msg(TrackSet ts, const int* __restrict__ n_ptr, CamParams c
     fe_msg_one(ts, i, cam, dt_1, dt_2, prev_is_last, out);
 }
 
-// The end of a steady-state frame's chain in ONE launch: RANSAC + commit of the old tracks (trackFeatures :701-808), RANSAC + append of
-// the new points (trackNewFeatures :932-1001) and - on publish frames - the feature message (getFeatureMsg :1076-1128).  All three are
-// one-workgroup stages that ran as three dependent launches; what the filter's thread waits for is the END of this chain, so the two
-// launch boundaries (each a barrier packet + ~5 us of launch floor) came straight off the image-in -> message latency.
 struct FeMsgArgs { int publish, prev_is_last; double dt_1, dt_2; lvk_feature_obs* out; int* n_host; };
-__global__ void __launch_bounds__(FM_THREADS) k_fe_commit_all(int cap, CamParams cam,
-                                                            const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                            const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
-                                                            const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
-                                                            const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
-                                                            const lvk_pt2f* __restrict__ new_pts, const int* n_new_ptr,
-                                                            const lvk_pt2f* __restrict__ wn_curr, const uint8_t* __restrict__ wn_status,
-                                                            const unsigned long long* __restrict__ wn_desc,
-                                                            TrackSet dst, int* dst_n, FeDev* dev, FeMsgArgs msg, int do_old)
-{
-    __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
-    __shared__ uint8_t smask[FM_MAX_N];
-    __shared__ unsigned short sidx[FM_MAX_N];
-    if (do_old) fe_commit_block(0, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
-    __syncthreads();                                        // *dst_n and the destination set of the old tracks are complete (one workgroup: one CU, one L1)
-    fe_commit_block(1, cap, cam, new_pts, n_new_ptr, wn_curr, wn_status, nullptr, nullptr, nullptr, wn_desc, dst, dst_n, dev, s1, s2, smask, sidx);
-    __syncthreads();
-    if (!msg.publish) return;
-    const int n = *dst_n;
-    if (threadIdx.x == 0) { dev->n_msg = n; *msg.n_host = n; dev->msg_features += (unsigned long long)n; dev->msg_count += 1ull; }
-    for (int i = threadIdx.x; i < n; i += FM_THREADS) fe_msg_one(dst, i, cam, msg.dt_1, msg.dt_2, msg.prev_is_last, msg.out);
-}
-
 
 // =========================================================================== host object
 #define LVK_MSG_SLOTS 4
@@ -783,7 +756,7 @@ static lvk_status fe_publish_finish(lvk_frontend* fe, int dst, double ts, int sl
     if (async_slot) { *async_slot = slot; *n_out = 0; return LVK_OK; }
     return lvk_frontend_fetch_msg(fe, slot, h_out, cap, n_out);
 }
-// getFeatureMsg (:1076-1128) as a launch of its own (bootstrap frames; steady-state frames write the message at the end of k_fe_commit_all)
+// getFeatureMsg (:1076-1128) + publish bookkeeping (:1170-1172)
 static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_obs* h_out, int cap, int* n_out, int* async_slot)
 {
     lvk_context* ctx = fe->ctx;
@@ -984,42 +957,20 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             hipEventRecord(fe->ev_new, S2);
             if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
             if (st != LVK_OK) return st;
-            // LVK_FE_COMMIT (temporary A/B switch): 0 = three launches (commit old, commit new, message), 1 = commit old on its own (it overlaps
-            // the wait for the new points' chain), commit new + message in one launch, 2 = all three in one launch
-            static const int commit_mode = [] { const char* v = getenv("LVK_FE_COMMIT"); return v ? atoi(v) : 1; }();
-            const bool publish = ts - fe->last_pub_time >= pub_gate;
-            int slot = 0;
-            FeMsgArgs margs; memset(&margs, 0, sizeof margs);
+            // the old tracks' RANSAC + commit overlaps the wait for the new points' chain; their append and the message follow.
+            // (Both commits - and all three stages - as ONE launch were measured in same-box A/B runs and were slower: the old tracks'
+            //  commit then waits for the new points' chain; profiles/r3_jk_frontend_chain_ab.json)
             const TrackSet& so = fe->set[src];
-            if (commit_mode == 0) {
-                st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst);
-                hipStreamWaitEvent(S1, fe->ev_new, 0);
-                if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
-                if (st != LVK_OK) return st;
-                curr_valid = true;
-                hipEventRecord(fe->ev_commit, S1);
-                if (publish) {
-                    st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
-                    if (st != LVK_OK) return st;
-                    *has_msg = 1;
-                }
-            } else {
-            if (commit_mode == 1) { st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst); if (st != LVK_OK) return st; }
-            if (publish) { st = fe_publish_slot(fe, &slot); if (st != LVK_OK) return st; margs = fe_msg_args(fe, slot); }
+            st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst);
             hipStreamWaitEvent(S1, fe->ev_new, 0);
-            { ProfScope ps(fe, 5);
-            hipLaunchKernelGGL(k_fe_commit_all, dim3(1), dim3(FM_THREADS), 0, S1, fe->cap, fe->cam, (const lvk_pt2f*)so.pts, (const int*)&fe->dev->n_tracks[src],
-                               (const lvk_pt2f*)fe->w_curr, (const uint8_t*)fe->w_status, (const unsigned long long*)so.id, (const lvk_pt2f*)so.init, (const int*)so.life,
-                               (const unsigned long long*)so.desc, (const lvk_pt2f*)fe->new_pts, (const int*)&fe->dev->n_new, (const lvk_pt2f*)fe->wn_curr,
-                               (const uint8_t*)fe->wn_status, (const unsigned long long*)fe->wn_desc, fe->set[dst], &fe->dev->n_tracks[dst], fe->dev, margs, commit_mode == 2 ? 1 : 0);
-            LVK_LAUNCH_CHECK(ctx); }
+            if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
+            if (st != LVK_OK) return st;
             curr_valid = true;
             hipEventRecord(fe->ev_commit, S1);
-            if (publish) {
-                st = fe_publish_finish(fe, dst, ts, slot, h_out, cap, n_out, async_slot);
+            if (ts - fe->last_pub_time >= pub_gate) {
+                st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                 if (st != LVK_OK) return st;
                 *has_msg = 1;
-            }
             }
         }
     }
