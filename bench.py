@@ -638,7 +638,8 @@ def main():
             lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_lk_")]
             if lk:
                 traffic = round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1); traffic_src = os.path.basename(pm[-1])
-        roofline = {"kernel": "k_fe_lk_both<%d> (forward + reverse LK of every track)" % win, "bound": "hbm", "achieved": round(achieved, 3),
+        roofline = {"kernel": "k_fe_lk_both<%d> (forward + reverse LK of every track; a second wavefront per track computes the ORB descriptors of the gate in their "
+                              "shadow - its bytes are NOT counted in `achieved`)" % win, "bound": "hbm", "achieved": round(achieved, 3),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
                     "launches": lk_launches}

@@ -278,9 +278,15 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             int a = e / c, j = e - a * c;
             double s = 0.;
             const int colj = cc[j];
-            for (int i = 0; i < c; ++i) {
-                const double g = Gp[(size_t)a * c + i];
-                if (g != 0.) s += g * (SMALL ? Pcc[i * FRS_PLD + j] : P[(size_t)cc[i] * ldp + colj]);
+            if (SMALL) {
+                // branch-free (a zero entry of G' adds an exact zero): the LDS reads of several steps can be in flight together
+#pragma unroll 8
+                for (int i = 0; i < c; ++i) s += Gp[(size_t)a * c + i] * Pcc[i * FRS_PLD + j];
+            } else {
+                for (int i = 0; i < c; ++i) {
+                    const double g = Gp[(size_t)a * c + i];
+                    if (g != 0.) s += g * P[(size_t)cc[i] * ldp + colj];
+                }
             }
             T[(size_t)a * c + j] = s;
         }
@@ -289,6 +295,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             int a = e / k, b = e - a * k;
             if (b > a) continue;
             double s = 0.;
+#pragma unroll 8
             for (int i = 0; i < c; ++i) s += T[(size_t)a * c + i] * Gp[(size_t)b * c + i];
             S[a * k + b] = s + (a == b ? fl.sigma2 : 0.);
         }
