@@ -294,9 +294,20 @@ static const char* const TR_NAMES[TR_N] = {"batch_imu", "propagate(launch)", "ad
     "prune:rows+sync", "prune:update(launch)", "prune:dx sync", "prune:inject+delete", "final sync"};
 struct EkfTrace {
     bool on = false; double acc[TR_N] = {0}; long n = 0;
+    double cur[TR_N] = {0};                              // this update's phases: an update above LVK_EKF_TRACE_SLOW_US is printed on its own
     std::chrono::steady_clock::time_point last;
-    void start() { if (on) last = std::chrono::steady_clock::now(); }
-    void mark(int slot) { if (!on) return; auto t = std::chrono::steady_clock::now(); acc[slot] += std::chrono::duration<double, std::micro>(t - last).count(); last = t; }
+    void start() { if (on) { last = std::chrono::steady_clock::now(); for (int i = 0; i < TR_N; ++i) cur[i] = 0; } }
+    void mark(int slot) { if (!on) return; auto t = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double, std::micro>(t - last).count(); acc[slot] += d; cur[slot] += d; last = t; }
+    void end_update(const char* const* names)
+    {
+        static const double slow = [] { const char* v = getenv("LVK_EKF_TRACE_SLOW_US"); return v ? atof(v) : 0.0; }();
+        if (!on || slow <= 0) return;
+        double tot = 0; for (int i = 0; i < TR_N; ++i) tot += cur[i];
+        if (tot < slow) return;
+        fprintf(stderr, "[lvk_ekf trace] slow update %ld: %.0f us:", n, tot);
+        for (int i = 0; i < TR_N; ++i) if (cur[i] > 0.02 * tot) fprintf(stderr, " %s %.0f;", names[i], cur[i]);
+        fprintf(stderr, "\n");
+    }
 };
 static EkfTrace g_tr;
 #define TR(slot) g_tr.mark(slot)
@@ -1153,12 +1164,26 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     lvk_status st = LVK_OK;
     double* H = e->d_H; double* r = e->d_r;
     // The nodes cost ~1 us per column of their union (one barrier-separated Householder step each, ~50..60 steps): measured on MI355X
-    // the compression pays once it saves more than a few 32-row Cholesky panels - not at the north-star size (m ~ 110..260 rows),
-    // decisively at configs[4] (thousands of rows).  LVK_SPARSE_QR_MIN_ROWS overrides the threshold.
-    if (groups && e->sparse_qr && m >= e->sparse_qr_min_rows) {
+    // the compression pays once it saves more than a few 32-row Cholesky panels - not for the typical update of the north-star size
+    // (m ~ 110..260 rows of 9-row feature blocks over ~50 columns), decisively at configs[4] (thousands of rows).  From
+    // LVK_SPARSE_QR_MIN_ROWS (480) rows on it is always taken; between one fused Cholesky launch (160 rows) and that, it is taken
+    // when a cost model of both routes says so - the case that matters is a pruning update at configs[4] depth: ~400 one-row blocks
+    // that all live in the same 19 columns compress to 19 rows in one ~40 us level instead of a 400-row factorisation.
+    if (groups && e->sparse_qr && m > 160) {
         std::vector<QrPlanLevel> levels; int m2 = m;
         lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
-        if (!levels.empty() && m2 + 32 <= m) {
+        bool take = !levels.empty() && m2 + 32 <= m;
+        if (take && m < e->sparse_qr_min_rows) {
+            double t_qr = 0;                               // microseconds: launch + the longest node's reflector chain per level
+            for (const QrPlanLevel& L : levels) {
+                double worst = 0;
+                for (const QrBlock& b : L.blocks) if (!b.copy) worst = std::max(worst, (double)std::min(b.ncols, b.in_rows) * (0.6 + 0.0025 * b.in_rows));
+                t_qr += 12.0 + worst;
+            }
+            auto t_chol = [](int rows) { const int p = (rows + 31) / 32, sp = (rows + 159) / 160; return 8.0 * p + 22.0 * (sp - 1) + 1.5e-4 * rows * rows; };
+            take = t_qr + t_chol(m2) < t_chol(m);
+        }
+        if (take) {
             for (QrPlanLevel& L : levels) {
                 QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
                 if (!hb || !hc) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
@@ -2070,6 +2095,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     }
 #endif
     TR(TR_FINAL);
+    g_tr.end_update(TR_NAMES);
     g_tr.n++;
     *updated = 1;
     return LVK_OK;
