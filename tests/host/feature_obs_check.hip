@@ -57,4 +57,54 @@ static int check_add_observations()
     return 0;
 }
 
-int main() { int r = check_feature_obs(); r |= check_add_observations(); if (!r) printf("ok\n"); return r; }
+// FeatureMap (the id-ordered flat container that replaced std::map<id, Feature>) against a std::map model: random emplace / operator[] /
+// erase by id and by iterator / find / at / purge, ids mostly growing with a few out of order, erased ids re-created before and after a
+// purge; after every step size, order, liveness and object addresses of untouched features must agree.
+static int check_feature_map()
+{
+    std::mt19937_64 rng(23);
+    for (int rep = 0; rep < 60; ++rep) {
+        FeatureMap fm; std::map<long long, std::pair<int, const Feature*>> model;      // id -> (total_obs tag, address)
+        long long next = 10;
+        for (int step = 0; step < 1500; ++step) {
+            const int op = (int)(rng() % 16);
+            if (op < 6) {                                                             // new track: growing id (append)
+                const long long id = next; next += 1 + (long long)(rng() % 3);
+                Feature& f = fm[id]; f.total_obs = (int)id;
+                if (f.id != id || !f.obs.empty() || f.in_state) { printf("MISMATCH fresh feature %lld\n", id); return 1; }
+                model[id] = {(int)id, &f};
+            } else if (op < 8) {                                                      // out-of-order / existing / erased id through emplace
+                const long long id = 10 + (long long)(rng() % (unsigned long long)(next - 9));
+                const bool had = model.count(id) != 0;
+                auto pr = fm.emplace(id, Feature());
+                if (pr.second == had || pr.first->first != id) { printf("MISMATCH emplace %lld\n", id); return 1; }
+                if (!had) { pr.first->second.total_obs = (int)id; if (!pr.first->second.obs.empty()) { printf("MISMATCH revived feature not reset\n"); return 1; } model[id] = {(int)id, &pr.first->second}; }
+            } else if (op < 12 && !model.empty()) {                                    // erase by id
+                auto it = model.begin(); std::advance(it, (long)(rng() % model.size()));
+                if (fm.erase(it->first) != 1 || fm.erase(it->first) != 0) { printf("MISMATCH erase %lld\n", it->first); return 1; }
+                model.erase(it);
+            } else if (op < 13 && !model.empty()) {                                    // erase by iterator
+                auto it = fm.begin(); std::advance(it, (long)(rng() % fm.size()));
+                const long long id = it->first; fm.erase(it); model.erase(id);
+            } else if (op < 14) {
+                fm.purge();
+            } else {                                                                  // lookups, present or not
+                const long long id = 9 + (long long)(rng() % (unsigned long long)(next - 7));
+                const bool had = model.count(id) != 0;
+                if ((fm.find(id) != fm.end()) != had) { printf("MISMATCH find %lld\n", id); return 1; }
+                bool threw = false; try { (void)fm.at(id); } catch (const std::out_of_range&) { threw = true; }
+                if (threw == had) { printf("MISMATCH at %lld\n", id); return 1; }
+            }
+            if (fm.size() != model.size() || fm.empty() != model.empty()) { printf("MISMATCH size %zu vs %zu\n", fm.size(), model.size()); return 1; }
+            auto b = model.begin();
+            for (auto kv : fm) {
+                if (b == model.end() || kv.first != b->first || kv.second.id != b->first || kv.second.total_obs != b->second.first || &kv.second != b->second.second) { printf("MISMATCH walk at id %lld\n", kv.first); return 1; }
+                ++b;
+            }
+            if (b != model.end()) { printf("MISMATCH walk ended early\n"); return 1; }
+        }
+    }
+    return 0;
+}
+
+int main() { int r = check_feature_obs(); r |= check_add_observations(); r |= check_feature_map(); if (!r) printf("ok\n"); return r; }
