@@ -24,6 +24,14 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) * d["n_gpus"]) < 0.01 * d["value"]
+    # round 3: the metric is quoted at ~150 live tracks; the adapter-reachable schedule, the TSQR roofline and the configs[4]-depth probe ride along
+    assert d["config"]["live_tracks"] >= 145
+    a = d["adapter_path"]
+    assert a["unit"] == d["unit"] and 0 < a["value"] < d["value"] and a["pose_read_one_frame_late"]["value"] >= 0.9 * a["value"]
+    q = d["roofline_qr"]
+    assert q["kernel"].startswith("k_qr_sparse") and q["flops_per_launch"] > 0 and abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-5
+    pr = d["sharded_update_probe"]
+    assert pr["cpu_baseline"]["kind"] == "port" and pr["cpu_baseline"]["value"] > 0 and pr["rccl_loopback"]["shard"]["exchanges"] == pr["rccl_loopback"]["shard"]["sharded_updates"] > 0
 
 
 def test_bench_source_keeps_the_timed_region_bracketed():
