@@ -510,6 +510,9 @@ struct lvk_frontend {
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
     lvk_pyr_graph* pyr_graph[3] = {nullptr, nullptr, nullptr}; lvk_pyramid* pyr_graph_of[3] = {nullptr, nullptr, nullptr};
     int use_graph = 0;                // LVK_FE_GRAPH=1: steady-state pyramid build as one graph launch per frame
+    // sticky: a frame that failed AFTER its image stage was queued (device error, ring overrun) leaves the buffer-set rotation and the
+    // end-of-frame events out of step with the frame count; the handle then refuses further frames instead of racing on its buffers
+    lvk_status failed = LVK_OK; char failed_msg[200] = {0};
     // HIP-event profiling of stages
     unsigned prof_mask;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -842,14 +845,30 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     return LVK_OK;
 }
 
+static lvk_status fe_check_failed(lvk_frontend* fe)
+{
+    if (fe->failed == LVK_OK) return LVK_OK;
+    return lvk_set_error(fe->ctx, fe->failed, "the front-end is in a failed state after an earlier error (%s); destroy and re-create it", fe->failed_msg);
+}
+static lvk_status fe_note_failure(lvk_frontend* fe, lvk_status st)
+{   // argument errors are raised before anything is queued and leave the handle usable; everything else is sticky
+    if (st != LVK_OK && st != LVK_ERR_ARG && fe->failed == LVK_OK) {
+        fe->failed = st; snprintf(fe->failed_msg, sizeof fe->failed_msg, "%s", fe->ctx->err);
+        hipStreamSynchronize(fe->ctx->stream);
+        for (int i = 0; i < 2; ++i) if (fe->side[i]) hipStreamSynchronize(fe->side[i]->stream);
+    }
+    return st;
+}
+
 lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img, double ts)
 {
     if (!fe || !img) return LVK_ERR_ARG;
+    { lvk_status fs = fe_check_failed(fe); if (fs != LVK_OK) return fs; }
     if (!fe->b_first_img) return fe_check_image(fe, img);   // the first-image gate needs the IMU buffer (:134-142): nothing to do early
     // one image stage per frame: the buffer-set rotation and the end-of-frame events are indexed by the stages queued so far
     if (fe->image_done) return lvk_set_error(fe->ctx, LVK_ERR_ARG, "lvk_frontend_begin: the image stage of t = %.6f is still waiting for its lvk_frontend_process", fe->image_done_ts);
     lvk_status st = fe_image_stage(fe, img, true);
-    if (st != LVK_OK) return st;
+    if (st != LVK_OK) return fe_note_failure(fe, st);
     fe->image_done = true; fe->image_done_ts = ts;
     return LVK_OK;
 }
@@ -861,7 +880,9 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
 lvk_status lvk_frontend_process(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu,
                                 lvk_feature_obs* h_out, int cap, int* n_out, int* has_msg)
 {
-    return frontend_process(fe, img, ts, h_imu, n_imu, h_out, cap, n_out, has_msg, nullptr);
+    if (fe) { lvk_status fs = fe_check_failed(fe); if (fs != LVK_OK) return fs; }
+    const lvk_status st = frontend_process(fe, img, ts, h_imu, n_imu, h_out, cap, n_out, has_msg, nullptr);
+    return fe ? fe_note_failure(fe, st) : st;
 }
 // the pipelined driver's variant: nothing waits for the GPU; *slot names the ring entry the message will appear in
 lvk_status lvk_frontend_process_async(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu, int* has_msg, int* slot)
@@ -869,7 +890,9 @@ lvk_status lvk_frontend_process_async(lvk_frontend* fe, const lvk_image* img, do
     int n = 0;
     if (!slot) return LVK_ERR_ARG;
     *slot = -1;
-    return frontend_process(fe, img, ts, h_imu, n_imu, nullptr, 0, &n, has_msg, slot);
+    if (fe) { lvk_status fs = fe_check_failed(fe); if (fs != LVK_OK) return fs; }
+    const lvk_status st = frontend_process(fe, img, ts, h_imu, n_imu, nullptr, 0, &n, has_msg, slot);
+    return fe ? fe_note_failure(fe, st) : st;
 }
 // wait for the message of ring entry `slot` and copy it out (any thread)
 lvk_status lvk_frontend_fetch_msg(lvk_frontend* fe, int slot, lvk_feature_obs* h_out, int cap, int* n_out)

@@ -101,3 +101,40 @@ def test_image_of_the_wrong_size_is_refused_not_read_past(gpu_ctx):
     has_msg, _ = fe.processImage(wide[:, 24:776], imu, ts=1.0)
     assert has_msg is False and fe.state in (1, 2)
     be.close(); be2.close(); fe.close(); ctx2.close()
+
+
+def test_deferred_update_reports_its_failure_at_the_next_call(gpu_ctx):
+    """lvk_ekf_process_async returns before the update runs: a failure of the queued update (here: a message far beyond the filter's
+    capacity) has to come back from lvk_ekf_wait, and the handle has to stay failed (sticky) for every later call - not crash, not
+    compute on with a half-updated state."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd._lib import OBS
+    seq = S.imu_only_sequence()
+    imu = seq.imu_array(380, 520)
+    be = larvio_amd.LarVio(S.backend_config(sw_size=8, max_features=16), gpu_ctx); assert be.initialize()
+    t0 = imu["t"][10]; tr = seq.traj
+    R = tr.R_wb(t0); s = np.sqrt(np.trace(R) + 1) * 2
+    q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    be.set_state(t0, q, tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu["gyro"][10], imu["acc"][10])
+    rng = np.random.default_rng(1)
+    failed_at = None
+    for k in range(14):
+        m = np.zeros(4000, OBS); m["id"] = np.arange(4000)
+        m["u"] = rng.uniform(-0.5, 0.5, 4000) + 0.002 * k; m["v"] = rng.uniform(-0.4, 0.4, 4000); m["u_init"] = -1; m["v_init"] = -1
+        ts = imu["t"][12 + 5 * k]
+        try:
+            upd, _ = be.processFeaturesAsync((ts, m), imu[imu["t"] < ts + 0.05])     # returns at once: the update is queued
+            assert upd is True
+            be.wait()                                                                 # ... and this is where its failure surfaces
+        except larvio_amd.LvkError as e:
+            failed_at = k
+            assert "capacity" in str(e) or "exceeds" in str(e) or "too many" in str(e) or "exhausted" in str(e) or "failed state" in str(e), str(e)
+            break
+    assert failed_at is not None
+    with pytest.raises(larvio_amd.LvkError, match="failed state"):
+        be.processFeaturesAsync((imu["t"][100], np.zeros(4, OBS)), imu[:110])
+    with pytest.raises(larvio_amd.LvkError, match="failed state"):
+        be.processFeatures((imu["t"][100], np.zeros(4, OBS)), imu[:110])
+    be.close()
+    be2 = larvio_amd.LarVio(S.backend_config(sw_size=8), gpu_ctx); assert be2.initialize(); be2.close()      # the context survives
