@@ -546,7 +546,7 @@ def main():
     if args.sharded and args.config != "5" and not args.backend_only:
         raise SystemExit("--sharded is the configs[4] path (2000 tracks): use --config 5 (or --backend-only)")
     if args.backend_only:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 % on these chains of small kernels (same-box A/B)
         bind_one_socket()
         import torch
         if not torch.cuda.is_available():
@@ -577,7 +577,7 @@ def main():
 
     bind_one_socket()
     # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 % on these chains of small kernels (same-box A/B)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
