@@ -198,6 +198,7 @@ def timed(run, frames, d_frames, W, K, dist, torch):
     for _ in range(W):
         feed()
     run.drain()
+    gc.collect()                                         # before the counters are reset: the collection itself is outside everything that is reported
     if not run.sequential:
         run.drv.stats(reset=True); run.drv.latencies(reset=True)
     pl0, it0 = run.fe.lk_stats()
@@ -208,7 +209,7 @@ def timed(run, frames, d_frames, W, K, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     lat = np.empty(K); msg_mask = np.zeros(K, bool)
-    gc.collect(); gc.disable()                           # the driver loop is this interpreter: a generation-2 collection inside the timed region is a 10-40 ms stall that no C++ driver has
+    gc.disable()                                         # the driver loop is this interpreter: a generation-2 collection inside the timed region is a 10-40 ms stall that no C++ driver has
     t_begin = time.perf_counter()
     for k in range(K):
         t0 = time.perf_counter()
