@@ -56,18 +56,19 @@ __global__ void k_undistort(const lvk_pt2f* __restrict__ in, int n, CamParams ca
     out[i] = undistort_point(in[i], cam, ni);
 }
 
-__global__ void __launch_bounds__(FM_THREADS) k_fundamental_mask(const lvk_pt2f* __restrict__ p1, const lvk_pt2f* __restrict__ p2, int n,
-                                                               double thresh, double conf, int max_iters, int force_ransac,
-                                                               uint8_t* __restrict__ mask, int* __restrict__ info)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_fundamental_mask(const lvk_pt2f* __restrict__ p1, const lvk_pt2f* __restrict__ p2, int n,
+                                                       double thresh, double conf, int max_iters, int force_ransac,
+                                                       uint8_t* __restrict__ mask, int* __restrict__ info)
 {
     __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
     __shared__ uint8_t smask[FM_MAX_N];
-    for (int i = threadIdx.x; i < n; i += FM_THREADS) { s1[i] = p1[i]; s2[i] = p2[i]; }
+    for (int i = threadIdx.x; i < n; i += NT) { s1[i] = p1[i]; s2[i] = p2[i]; }
     __syncthreads();
     int iters = 0;
-    int wrote = fm_mask_block(s1, s2, n, thresh, conf, max_iters, force_ransac, smask, &iters);
+    int wrote = fm_mask_block<NT>(s1, s2, n, thresh, conf, max_iters, force_ransac, smask, &iters);
     __syncthreads();
-    if (wrote) for (int i = threadIdx.x; i < n; i += FM_THREADS) mask[i] = smask[i];
+    if (wrote) for (int i = threadIdx.x; i < n; i += NT) mask[i] = smask[i];
     if (threadIdx.x == 0 && info) { info[0] = wrote; info[1] = iters; }
 }
 
@@ -141,7 +142,9 @@ static lvk_status fm_launch(lvk_context* ctx, const lvk_pt2f* p1, const lvk_pt2f
 {
     if (!ctx || n < 0 || (n > 0 && (!p1 || !p2 || !mask))) return lvk_set_error(ctx, LVK_ERR_ARG, "fundamental: bad argument");
     if (n > FM_MAX_N) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "fundamental: n=%d exceeds %d", n, FM_MAX_N);
-    hipLaunchKernelGGL(k_fundamental_mask, dim3(1), dim3(FM_THREADS), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info);
+    // same split as the frame path (frontend.hip: commit): the wide workgroup for point sets the per-point loops dominate
+    if (n > FM_WIDE_FROM) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fundamental_mask<FM_THREADS_WIDE>), dim3(1), dim3(FM_THREADS_WIDE), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fundamental_mask<FM_THREADS>), dim3(1), dim3(FM_THREADS), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

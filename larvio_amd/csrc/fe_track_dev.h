@@ -473,9 +473,12 @@ static __device__ int g_fm_on = 1;
 #define FM_TICK(k) do { } while (0)
 #endif
 #define FM_THREADS 256
+#define FM_THREADS_WIDE 512    // workgroup for large point sets (configs[4]: 2000 tracks): the per-point loops (compaction, scoring, mask) are
+#define FM_WIDE_FROM 512       // what the call costs there; the hypothesis machinery stays on the first FM_THREADS threads
 #define FM_MAX_N 4096
 #define FM_ROUND 16            // hypotheses solved and scored per round
-#define FM_FIRST 4             // ... in the first round
+#define FM_FIRST 2             // ... in the first round and
+#define FM_SECOND 6            // ... in the second (LARVIO's sets: 1 iteration in ~60 % of the calls, 2 in ~37 %, 3+ in ~3 %)
 
 __device__ inline void d_nullspace_7x9(const double* A, double* f1, double* f2)
 {   // Householder QR of A^T; last two columns of Q (same operation order as the oracle)
@@ -694,15 +697,49 @@ __device__ inline bool d_get_subset(const lvk_pt2f* m1, const lvk_pt2f* m2, int 
     return iters < max_attempts;
 }
 
-__device__ inline int d_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+// RANSACUpdateNumIters in two halves: everything that does not depend on the current iteration bound (pow, two logs, the quotient)
+// and the comparison against the bound.  The first half runs for all models of a round in parallel, the sequential replay of the
+// "better model -> fewer iterations" rule only applies the second.
+struct FmIterRule { double num, denom; int q, zero; };
+__device__ inline FmIterRule d_ransac_iter_rule(double p, double ep, int model_points)
 {
+    FmIterRule o;
     p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
     ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
     double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
     double denom = 1. - pow(1. - ep, (double)model_points);
-    if (denom < DBL_MIN) return 0;
-    num = log(num); denom = log(denom);
-    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+    o.zero = denom < DBL_MIN; o.q = 0; o.num = 0.; o.denom = 0.;
+    if (o.zero) return o;
+    o.num = log(num); o.denom = log(denom);
+    if (o.denom < 0) o.q = (int)rint(o.num / o.denom);
+    return o;
+}
+__device__ __forceinline__ int d_ransac_iter_apply(const FmIterRule& u, int max_iters)
+{
+    if (u.zero) return 0;
+    return u.denom >= 0 || -u.num >= max_iters * (-u.denom) ? max_iters : u.q;
+}
+__device__ inline int d_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    return d_ransac_iter_apply(d_ransac_iter_rule(p, ep, model_points), max_iters);
+}
+
+// Order-preserving compaction inside an NT-thread workgroup: exclusive rank of this thread's flag (wavefront ballots + one LDS
+// word per wavefront) and the total.  Two barriers; wtot has NT/64 words and is free again on return.
+template <int NT>
+__device__ __forceinline__ int block_rank(bool flag, int* wtot, int& total)
+{
+    const unsigned long long b = __ballot(flag);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int within = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[w] = __popcll(b);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { const int v = wtot[k]; tot += v; before += k < w ? v : 0; }
+    __syncthreads();
+    total = tot;
+    return before + within;
 }
 
 // d_fundamental_7pt for the hypotheses of one RANSAC round, eight lanes per hypothesis: lane c owns column c of A^T (the nine
@@ -789,18 +826,92 @@ __device__ inline void fm_solve_round(int nr, const lvk_pt2f (*sub1)[7], const l
     }
 }
 
+// LMedS (8 <= n < 15): niters from outlier ratio 0.45, one hypothesis per thread per pass (the first FM_THREADS threads).  Kept out
+// of line: its per-thread arrays (27-double model block, the sorted errors, the 7x9 null-space solve) are the register hogs of the
+// whole call, and inlined they would set the allocation of the 1024-thread RANSAC path (LARVIO's steady state never gets here:
+// fewer than 15 alive points).  LDS scratch comes from the caller.
+template <int NT>
+__device__ __noinline__ int fm_lmeds_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int n, double conf, uint8_t* smask, int* iters_out,
+                                           lvk_pt2f (*lsub1)[7], lvk_pt2f (*lsub2)[7], int* lfound, float* lm_med, int* lm_seq,
+                                           double* best_model, int* sh_ctl, unsigned long long* sh_rng_p)
+{
+    const int t = threadIdx.x;
+    const int niters = d_ransac_update_num_iters(conf, 0.45, 7, 1000);
+    float my_med = FLT_MAX; int my_seq = 0x7fffffff; double my_model[9];
+    if (t == 0) *sh_rng_p = ~0ULL;
+    __syncthreads();
+    int stop_at = niters;      // iteration at which getSubset failed (uniform via LDS)
+    for (int base = 0; base < niters; base += FM_THREADS) {
+        if (t == 0) {
+            d_rng rng; rng.state = *sh_rng_p;
+            int failed = 0;
+            for (int r = 0; r < FM_THREADS && base + r < niters; ++r) {
+                lfound[r] = failed ? 0 : (d_get_subset(s1, s2, n, lsub1[r], lsub2[r], rng, 1000) ? 1 : 0);
+                if (!lfound[r] && !failed) { failed = 1; sh_ctl[2] = base + r; }
+            }
+            *sh_rng_p = rng.state;
+            sh_ctl[0] = failed;
+        }
+        __syncthreads();
+        if (t < FM_THREADS && base + t < niters && lfound[t]) {
+            double mdl[27];
+            int nm = d_fundamental_7pt(lsub1[t], lsub2[t], mdl);
+            for (int m = 0; m < nm; ++m) {
+                float e[16];
+                for (int i = 0; i < n; ++i) e[i] = d_fm_error(s1[i], s2[i], mdl + 9 * m);
+                // median = element count/2 of the ascending order (errors are >= 0: int view == float order)
+                for (int i = 1; i < n; ++i) { float v = e[i]; int j = i - 1; while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; --j; } e[j + 1] = v; }
+                float med = e[n / 2];
+                int seq = (base + t) * 3 + m;
+                if (med < my_med) { my_med = med; my_seq = seq; for (int q = 0; q < 9; ++q) my_model[q] = mdl[9 * m + q]; }
+            }
+        }
+        int failed = sh_ctl[0];
+        if (failed) { stop_at = sh_ctl[2]; __syncthreads(); break; }
+        __syncthreads();
+    }
+    // hypotheses at or after a getSubset failure are not run by OpenCV: none were solved (lfound = 0)
+    (void)stop_at;
+    if (t < FM_THREADS) { lm_med[t] = my_med; lm_seq[t] = my_seq; }
+    __syncthreads();
+    if (t == 0) {
+        int bi = -1; float bm = FLT_MAX; int bs = 0x7fffffff;
+        for (int i = 0; i < FM_THREADS; ++i)
+            if (lm_seq[i] != 0x7fffffff && (lm_med[i] < bm || (lm_med[i] == bm && lm_seq[i] < bs))) { bm = lm_med[i]; bs = lm_seq[i]; bi = i; }
+        sh_ctl[1] = bi;
+    }
+    __syncthreads();
+    const int bi = sh_ctl[1];
+    if (bi < 0) { for (int i = t; i < n; i += NT) smask[i] = 0; __syncthreads(); *iters_out = niters; return 1; }
+    if (t == bi) { for (int q = 0; q < 9; ++q) best_model[q] = my_model[q]; }
+    __syncthreads();
+    {
+        double min_median = (double)lm_med[bi];
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(min_median);
+        sigma = sigma > 0.001 ? sigma : 0.001;
+        const float tt = (float)(sigma * sigma);
+        for (int i = t; i < n; i += NT) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tt;
+    }
+    *iters_out = niters;
+    __syncthreads();
+    return 1;
+}
+
 // The whole of cv::findFundamentalMat(..., FM_RANSAC, thresh, conf, mask) for one point set held in
-// LDS, executed by one FM_THREADS workgroup.  Returns (uniformly) 1 if smask[0..n) was written.
+// LDS, executed by one workgroup of NT threads (NT >= FM_THREADS, a multiple of 64: the per-point loops use all of them, the
+// hypothesis machinery the first FM_THREADS).  Returns (uniformly) 1 if smask[0..n) was written.
 //   n < 7: nothing;  n == 7: ones;  8..14: LMedS (300 hypotheses, all in parallel);
-//   n >= 15 (or force_ransac): RANSAC — rounds of FM_ROUND hypotheses: thread 0 draws the subsets in
-//   OpenCV's RNG order, FM_ROUND threads solve the 7-point systems, all threads score, thread 0 replays
+//   n >= 15 (or force_ransac): RANSAC — rounds of FM_FIRST, FM_SECOND, then FM_ROUND hypotheses: thread 0 draws the subsets in
+//   OpenCV's RNG order, eight lanes per hypothesis solve the 7-point systems, all threads score, thread 0 replays
 //   the sequential "better model -> shrink niters" rule over the round in order.
+template <int NT>
 __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int n, double thresh, double conf, int max_iters,
                                     int force_ransac, uint8_t* smask, int* iters_out)
 {
     __shared__ lvk_pt2f sub1[FM_ROUND][7], sub2[FM_ROUND][7];
     __shared__ double models[FM_ROUND][27];
     __shared__ int nmodels[FM_ROUND], found[FM_ROUND], good[FM_ROUND][3];
+    __shared__ FmIterRule rule[FM_ROUND][3];
     __shared__ double best_model[9];
     __shared__ int sh_ctl[4];                 // [0] stop, [1] have best, [2] iterations, [3] niters
     __shared__ unsigned long long sh_rng;
@@ -812,7 +923,7 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
     const int t = threadIdx.x;
     *iters_out = 0;
     if (n < 7) return 0;
-    if (n == 7) { for (int i = t; i < n; i += FM_THREADS) smask[i] = 1; __syncthreads(); return 1; }
+    if (n == 7) { for (int i = t; i < n; i += NT) smask[i] = 1; __syncthreads(); return 1; }
     if (thresh <= 0) thresh = 3;
     if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
 
@@ -825,7 +936,7 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
         for (int round = 0;; ++round) {
             // LARVIO's point sets are mostly inliers after the LK and descriptor gates: the first hypotheses usually end the loop
             // (niters collapses to a handful), so the first round is short
-            const int nr = round == 0 ? FM_FIRST : FM_ROUND;
+            const int nr = round == 0 ? FM_FIRST : round == 1 ? FM_SECOND : FM_ROUND;
             FM_TICK(4);
             // ---- the round's FM_ROUND subsets, in OpenCV's RNG order.  Fast path: every thread maps one table draw to a point
             // index, then works out the subset that WOULD start at its draw (7 distinct indices, duplicates redrawn one at a
@@ -838,10 +949,10 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
                 if (t == 0) { sh_rng = pos ? FM_RNG.s[pos - 1] : ~0ULL; sh_serial = 1; }
             }
             if (!serial) {
-                idxw[t] = (unsigned short)((unsigned)FM_RNG.s[pos + t] % (unsigned)n);
+                if (t < FM_WIN) idxw[t] = (unsigned short)((unsigned)FM_RNG.s[pos + t] % (unsigned)n);
                 if (t == 0) sh_anybad = 0;
                 __syncthreads();
-                {
+                if (t < FM_WIN) {
                     int sel[7] = {-1, -1, -1, -1, -1, -1, -1};
                     int c = 0, q = t;
                     while (c < 7 && q < FM_WIN) {
@@ -914,9 +1025,14 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
                 while (slot < nslots) {
                     const int r = slot / 3, m = slot - 3 * r;
                     if (m < nmodels[r] && d_fm_error(s1[i], s2[i], &models[r][9 * m]) <= tthr) atomicAdd(&good[r][m], 1);
-                    i += FM_THREADS;
+                    i += NT;
                     while (i >= n) { i -= n; ++slot; }
                 }
+            }
+            __syncthreads();
+            if (t < nr * 3) {                     // the iteration rule of every model that could become the best one
+                const int r = t / 3, m = t - 3 * r;
+                if (m < nmodels[r] && good[r][m] > 6) rule[r][m] = d_ransac_iter_rule(conf, (double)(n - good[r][m]) / n, 7);
             }
             __syncthreads();
             FM_TICK(7);
@@ -932,7 +1048,7 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
                         if (g > (max_good > 6 ? max_good : 6)) {
                             for (int q = 0; q < 9; ++q) best_model[q] = models[r][9 * m + q];
                             max_good = g; sh_ctl[1] = 1;
-                            niters = d_ransac_update_num_iters(conf, (double)(n - g) / n, 7, niters);
+                            niters = d_ransac_iter_apply(rule[r][m], niters);
                         }
                     }
                 }
@@ -945,73 +1061,15 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
             base += nr;
         }
         // iterations drawn = value of `iter` when OpenCV's loop exits
-        if (sh_ctl[1]) { for (int i = t; i < n; i += FM_THREADS) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tthr; }
-        else { for (int i = t; i < n; i += FM_THREADS) smask[i] = 0; }
+        if (sh_ctl[1]) { for (int i = t; i < n; i += NT) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tthr; }
+        else { for (int i = t; i < n; i += NT) smask[i] = 0; }
         *iters_out = sh_ctl[2];
         __syncthreads();
         return 1;
     }
 
-    // ---- LMedS (8 <= n < 15): niters from outlier ratio 0.45, one hypothesis per thread per pass
+    // ---- LMedS (8 <= n < 15)
     __shared__ lvk_pt2f lsub1[FM_THREADS][7], lsub2[FM_THREADS][7];
     __shared__ int lfound[FM_THREADS];
-    const int niters = d_ransac_update_num_iters(conf, 0.45, 7, 1000);
-    float my_med = FLT_MAX; int my_seq = 0x7fffffff; double my_model[9];
-    if (t == 0) sh_rng = ~0ULL;
-    __syncthreads();
-    int stop_at = niters;      // iteration at which getSubset failed (uniform via LDS)
-    for (int base = 0; base < niters; base += FM_THREADS) {
-        if (t == 0) {
-            d_rng rng; rng.state = sh_rng;
-            int failed = 0;
-            for (int r = 0; r < FM_THREADS && base + r < niters; ++r) {
-                lfound[r] = failed ? 0 : (d_get_subset(s1, s2, n, lsub1[r], lsub2[r], rng, 1000) ? 1 : 0);
-                if (!lfound[r] && !failed) { failed = 1; sh_ctl[2] = base + r; }
-            }
-            sh_rng = rng.state;
-            sh_ctl[0] = failed;
-        }
-        __syncthreads();
-        if (base + t < niters && lfound[t]) {
-            double mdl[27];
-            int nm = d_fundamental_7pt(lsub1[t], lsub2[t], mdl);
-            for (int m = 0; m < nm; ++m) {
-                float e[16];
-                for (int i = 0; i < n; ++i) e[i] = d_fm_error(s1[i], s2[i], mdl + 9 * m);
-                // median = element count/2 of the ascending order (errors are >= 0: int view == float order)
-                for (int i = 1; i < n; ++i) { float v = e[i]; int j = i - 1; while (j >= 0 && e[j] > v) { e[j + 1] = e[j]; --j; } e[j + 1] = v; }
-                float med = e[n / 2];
-                int seq = (base + t) * 3 + m;
-                if (med < my_med) { my_med = med; my_seq = seq; for (int q = 0; q < 9; ++q) my_model[q] = mdl[9 * m + q]; }
-            }
-        }
-        int failed = sh_ctl[0];
-        if (failed) { stop_at = sh_ctl[2]; __syncthreads(); break; }
-        __syncthreads();
-    }
-    // hypotheses at or after a getSubset failure are not run by OpenCV: none were solved (lfound = 0)
-    (void)stop_at;
-    lm_med[t] = my_med; lm_seq[t] = my_seq;
-    __syncthreads();
-    if (t == 0) {
-        int bi = -1; float bm = FLT_MAX; int bs = 0x7fffffff;
-        for (int i = 0; i < FM_THREADS; ++i)
-            if (lm_seq[i] != 0x7fffffff && (lm_med[i] < bm || (lm_med[i] == bm && lm_seq[i] < bs))) { bm = lm_med[i]; bs = lm_seq[i]; bi = i; }
-        sh_ctl[1] = bi;
-    }
-    __syncthreads();
-    const int bi = sh_ctl[1];
-    if (bi < 0) { for (int i = t; i < n; i += FM_THREADS) smask[i] = 0; __syncthreads(); *iters_out = niters; return 1; }
-    if (t == bi) { for (int q = 0; q < 9; ++q) best_model[q] = my_model[q]; }
-    __syncthreads();
-    {
-        double min_median = (double)lm_med[bi];
-        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(min_median);
-        sigma = sigma > 0.001 ? sigma : 0.001;
-        const float tt = (float)(sigma * sigma);
-        for (int i = t; i < n; i += FM_THREADS) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tt;
-    }
-    *iters_out = niters;
-    __syncthreads();
-    return 1;
+    return fm_lmeds_block<NT>(s1, s2, n, conf, smask, iters_out, lsub1, lsub2, lfound, lm_med, lm_seq, best_model, sh_ctl, &sh_rng);
 }

@@ -240,14 +240,18 @@ __device__ __forceinline__ lvk_pt2f apply_h(const HMat& H, lvk_pt2f p)
 // kept) of a point in ONE launch, TWO wavefronts per point: wavefront 0 runs the two LK passes back to back; wavefront 1 computes the
 // descriptors in their shadow - the previous-image one (new points) during the forward pass, the current-image one as soon as the
 // forward pass has produced the point, i.e. while the reverse pass runs.  The gate's launch (13 us + its barrier) leaves the frame's
-// dependent chain altogether; a descriptor computed for a point that then fails the reverse check is simply not used.
+// dependent chain altogether; a descriptor computed for a point that then fails the reverse check is simply not used.  The same
+// wavefront also undistorts the point pair (K -> K, what findFundamentalMat is fed, :701-712 / :932-943) into w_und[2p], [2p+1]:
+// two sequential double-precision fixed-point loops per point that the one-workgroup commit kernel would otherwise run for
+// every point of its set (24 us of its 120 at 2000 tracks).
 template <int WIN>
 __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
                                                    HMat H, int width, int height, int max_count, double epsilon,
                                                    lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev,
                                                    const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
                                                    const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur,
-                                                   const unsigned long long* __restrict__ stored_desc /*old*/, unsigned long long* __restrict__ w_desc /*new: out*/, int is_new)
+                                                   const unsigned long long* __restrict__ stored_desc /*old*/, unsigned long long* __restrict__ w_desc /*new: out*/, int is_new,
+                                                   CamParams cam, lvk_pt2f* __restrict__ w_und)
 {
     __shared__ lvk_pt2f s_np;
     __shared__ int s_st, s_dist;
@@ -265,9 +269,12 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
         its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
         if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
         if (lane == 0) { s_np = np; s_st = st; }
-    } else if (is_new) {
-        orb_point(prv_ext, prv_blur, step, pp, dp);
-        if (lane == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
+    } else {
+        if (is_new) {
+            orb_point(prv_ext, prv_blur, step, pp, dp);
+            if (lane == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
+        }
+        if (lane == 0) w_und[2 * (size_t)p] = undistort_point(pp, cam, cam.intr);
     }
     __syncthreads();
     int code = ST_FWD, passes = 1;
@@ -292,7 +299,7 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
         unsigned long long dc[4];
         orb_point(cur_ext, cur_blur, step, s_np, dc);
         const int dist = is_new ? hamming256_u64(dc, dp) : hamming256_u64(dc, stored_desc + (size_t)p * 4);
-        if (lane == 0) s_dist = dist;
+        if (lane == 0) { s_dist = dist; w_und[2 * (size_t)p + 1] = undistort_point(s_np, cam, cam.intr); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -303,18 +310,19 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
     }
 }
 
-// One workgroup: count survivors per stage, order-preserving compaction of the alive points, undistort
-// both sets to pixel coordinates (K -> K), cv::findFundamentalMat mask, then write the destination
+// One workgroup of NT threads: count survivors per stage, order-preserving compaction of the alive points (wavefront ballots), the
+// undistorted pairs the LK kernel left in w_und, cv::findFundamentalMat mask, then write the destination
 // track set.  mode 0: old tracks (trackFeatures :701-808), 1: new points appended (trackNewFeatures
 // :932-1001), 2: bootstrap (initializeFirstFeatures :464-536).
-__device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamParams& cam,
-                                                const lvk_pt2f* src_pts, const int* n_ptr, const lvk_pt2f* w_curr, const uint8_t* w_status,
+template <int NT>
+__device__ __forceinline__ void fe_commit_block(int mode, int cap,
+                                                const lvk_pt2f* src_pts, const int* n_ptr, const lvk_pt2f* w_curr, const uint8_t* w_status, const lvk_pt2f* w_und,
                                                 const unsigned long long* src_id, const lvk_pt2f* src_init, const int* src_life, const unsigned long long* src_desc,
                                                 const TrackSet& dst, int* dst_n, FeDev* dev,
                                                 lvk_pt2f* s1, lvk_pt2f* s2, uint8_t* smask, unsigned short* sidx)
 {   // s1, s2, smask, sidx: LDS scratch for FM_MAX_N points, owned by the calling kernel
     __shared__ int cnt[4];
-    __shared__ int scan[FM_THREADS];
+    __shared__ int wtot[NT / 64];
     const int t = threadIdx.x;
 #ifdef LVK_FM_TIMING
     if (t == 0) g_fm_on = mode == 0;
@@ -325,37 +333,34 @@ __device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamPara
     __syncthreads();
     // survivors after each stage + ordered compaction of the alive ones (block scan over chunks)
     int base = 0;
-    for (int c0 = 0; c0 < n; c0 += FM_THREADS) {
-        int i = c0 + t;
-        int st = i < n ? w_status[i] : 255;
-        int alive = st == ST_ALIVE;
-        if (i < n) {
-            if (st != ST_FWD) atomicAdd(&cnt[0], 1);                       // after forward LK
-            if (st != ST_FWD && st != ST_REV) atomicAdd(&cnt[1], 1);       // after reverse LK
-            if (alive) atomicAdd(&cnt[2], 1);                              // after the ORB gate
-        }
-        scan[t] = alive;
-        __syncthreads();
-        for (int o = 1; o < FM_THREADS; o <<= 1) { int v = t >= o ? scan[t - o] : 0; __syncthreads(); scan[t] += v; __syncthreads(); }
-        if (alive) sidx[base + scan[t] - 1] = (unsigned short)i;
-        base += scan[FM_THREADS - 1];
-        __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += NT) {
+        const int i = c0 + t;
+        const int st = i < n ? w_status[i] : 255;
+        const bool alive = st == ST_ALIVE;
+        const unsigned long long b_fwd = __ballot(i < n && st != ST_FWD);                    // after forward LK
+        const unsigned long long b_rev = __ballot(i < n && st != ST_FWD && st != ST_REV);    // after reverse LK
+        if ((t & 63) == 0) { atomicAdd(&cnt[0], (int)__popcll(b_fwd)); atomicAdd(&cnt[1], (int)__popcll(b_rev)); }
+        int tot;
+        const int rk = block_rank<NT>(alive, wtot, tot);
+        if (alive) sidx[base + rk] = (unsigned short)i;
+        base += tot;
     }
+    __syncthreads();
     FM_TICK(1);
-    const int m = cnt[2];
+    const int m = base;                                                    // after the ORB gate
     bool fail = false;
     if (mode == 2) fail = cnt[0] < 20 || cnt[1] < 20 || m < 20;
     else if (mode == 1) fail = m < 20;
     int wrote = 0, iters = 0;
     if (!fail && m > 0) {
-        for (int k = t; k < m; k += FM_THREADS) {
-            int i = sidx[k];
-            s1[k] = undistort_point(src_pts[i], cam, cam.intr);
-            s2[k] = undistort_point(w_curr[i], cam, cam.intr);
+        for (int k = t; k < m; k += NT) {
+            const int i = sidx[k];
+            s1[k] = w_und[2 * (size_t)i];
+            s2[k] = w_und[2 * (size_t)i + 1];
         }
         __syncthreads();
         FM_TICK(2);
-        wrote = fm_mask_block(s1, s2, m, 1.0, 0.99, 1000, 0, smask, &iters);
+        wrote = fm_mask_block<NT>(s1, s2, m, 1.0, 0.99, 1000, 0, smask, &iters);
         __syncthreads();
         FM_TICK(9);
     }
@@ -364,15 +369,14 @@ __device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamPara
     if (!fail) {
         int basek = 0;
         const int dst_base = (mode == 1) ? *dst_n : 0;
-        for (int c0 = 0; c0 < m; c0 += FM_THREADS) {
-            int k = c0 + t;
-            int keep = k < m ? (wrote ? smask[k] != 0 : 1) : 0;
-            scan[t] = keep;
-            __syncthreads();
-            for (int o = 1; o < FM_THREADS; o <<= 1) { int v = t >= o ? scan[t - o] : 0; __syncthreads(); scan[t] += v; __syncthreads(); }
+        for (int c0 = 0; c0 < m; c0 += NT) {
+            const int k = c0 + t;
+            const bool keep = k < m ? (wrote ? smask[k] != 0 : true) : false;
+            int tot;
+            const int rk = block_rank<NT>(keep, wtot, tot);
             if (keep) {
                 const int i = sidx[k];
-                const int d = dst_base + basek + scan[t] - 1;
+                const int d = dst_base + basek + rk;
                 if (d < cap) {
                     dst.pts[d] = w_curr[i];
                     dst.ppts[d] = src_pts[i];
@@ -381,15 +385,14 @@ __device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamPara
                     dd[0] = ds[0]; dd[1] = ds[1]; dd[2] = ds[2]; dd[3] = ds[3];
                     if (mode == 0) { dst.id[d] = src_id[i]; dst.life[d] = src_life[i] + 1; dst.init[d] = src_init[i]; }
                     else {
-                        dst.id[d] = dev->next_id + (unsigned long long)(basek + scan[t] - 1);
+                        dst.id[d] = dev->next_id + (unsigned long long)(basek + rk);
                         dst.life[d] = 2;
                         if (mode == 1) dst.init[d] = src_pts[i];
                         else { dst.init[d].x = -1.f; dst.init[d].y = -1.f; }
                     }
                 }
             }
-            basek += scan[FM_THREADS - 1];
-            __syncthreads();
+            basek += tot;
         }
         kept = basek;
     }
@@ -411,17 +414,18 @@ __device__ __forceinline__ void fe_commit_block(int mode, int cap, const CamPara
     }
 }
 
-__global__ void __launch_bounds__(FM_THREADS) k_fe_ransac_commit(int mode, int cap, CamParams cam,
-                                                               const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                               const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status,
-                                                               const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
-                                                               const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
-                                                               TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_fe_ransac_commit(int mode, int cap,
+                                                       const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                       const lvk_pt2f* __restrict__ w_curr, const uint8_t* __restrict__ w_status, const lvk_pt2f* __restrict__ w_und,
+                                                       const unsigned long long* __restrict__ src_id, const lvk_pt2f* __restrict__ src_init,
+                                                       const int* __restrict__ src_life, const unsigned long long* __restrict__ src_desc,
+                                                       TrackSet dst, int* __restrict__ dst_n, FeDev* __restrict__ dev)
 {
     __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
     __shared__ uint8_t smask[FM_MAX_N];
     __shared__ unsigned short sidx[FM_MAX_N];
-    fe_commit_block(mode, cap, cam, src_pts, n_ptr, w_curr, w_status, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
+    fe_commit_block<NT>(mode, cap, src_pts, n_ptr, w_curr, w_status, w_und, src_id, src_init, src_life, src_desc, dst, dst_n, dev, s1, s2, smask, sidx);
 }
 
 // getFeatureMsg (:1076-1128): undistort to normalised coordinates, finite-difference velocities
@@ -481,6 +485,7 @@ struct lvk_frontend {
     int stage_next = 0; int zero_copy = 0;
     TrackSet set[2];
     lvk_pt2f *w_curr, *wn_curr, *new_pts;
+    lvk_pt2f *w_und, *wn_und;  // undistorted (prev, curr) pair per point, written by the LK kernel next to w_curr / wn_curr
     uint8_t *w_status, *wn_status;
     unsigned long long* wn_desc;
     float* eig; uint8_t* mask; unsigned* gf_scratch; unsigned long long* gf_cands; int gf_cand_cap;
@@ -565,7 +570,8 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
     if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes (read by the kernel's second wavefront) follow it on the image stream
     ProfScope ps(fe, 2, s);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
-                       (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new);
+                       (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
+                       fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
 }
 
 static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
@@ -589,9 +595,16 @@ static lvk_status commit(lvk_frontend* fe, int mode, const lvk_pt2f* src_pts, co
                          const TrackSet* src, const unsigned long long* desc_src, int dst_set)
 {
     ProfScope ps(fe, 5);
-    hipLaunchKernelGGL(k_fe_ransac_commit, dim3(1), dim3(FM_THREADS), 0, fe->ctx->stream, mode, fe->cap, fe->cam, src_pts, n_ptr, w_curr, w_status,
-                       (const unsigned long long*)(src ? src->id : nullptr), (const lvk_pt2f*)(src ? src->init : nullptr),
-                       (const int*)(src ? src->life : nullptr), desc_src, fe->set[dst_set], &fe->dev->n_tracks[dst_set], fe->dev);
+    const lvk_pt2f* w_und = w_curr == fe->w_curr ? fe->w_und : fe->wn_und;
+    // one workgroup either way: 1024 threads when the per-point loops (compaction, scoring, mask) are what the call costs
+    if (fe->cap > FM_WIDE_FROM)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_ransac_commit<FM_THREADS_WIDE>), dim3(1), dim3(FM_THREADS_WIDE), 0, fe->ctx->stream, mode, fe->cap, src_pts, n_ptr, w_curr, w_status, w_und,
+                           (const unsigned long long*)(src ? src->id : nullptr), (const lvk_pt2f*)(src ? src->init : nullptr),
+                           (const int*)(src ? src->life : nullptr), desc_src, fe->set[dst_set], &fe->dev->n_tracks[dst_set], fe->dev);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_ransac_commit<FM_THREADS>), dim3(1), dim3(FM_THREADS), 0, fe->ctx->stream, mode, fe->cap, src_pts, n_ptr, w_curr, w_status, w_und,
+                           (const unsigned long long*)(src ? src->id : nullptr), (const lvk_pt2f*)(src ? src->init : nullptr),
+                           (const int*)(src ? src->life : nullptr), desc_src, fe->set[dst_set], &fe->dev->n_tracks[dst_set], fe->dev);
     LVK_LAUNCH_CHECK(fe->ctx);
     return LVK_OK;
 }
@@ -618,7 +631,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
         if (fe->ext[i]) hipFree(fe->ext[i]); if (fe->blur[i]) hipFree(fe->blur[i]);
         if (i < 2) set_free(fe->set[i]);
     }
-    void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
+    void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->w_und, fe->wn_und, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 3; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
@@ -663,7 +676,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     }
     fe->gf_cand_cap = w * h;
     size_t cand_alloc = 1; while (cand_alloc < (size_t)fe->gf_cand_cap) cand_alloc <<= 1;
-    ok = ok && dalloc(&fe->d_img, (size_t)w * h) && dalloc(&fe->w_curr, cap) && dalloc(&fe->wn_curr, cap) && dalloc(&fe->new_pts, cap) &&
+    ok = ok && dalloc(&fe->d_img, (size_t)w * h) && dalloc(&fe->w_curr, cap) && dalloc(&fe->wn_curr, cap) && dalloc(&fe->w_und, 2 * (size_t)cap) && dalloc(&fe->wn_und, 2 * (size_t)cap) && dalloc(&fe->new_pts, cap) &&
          dalloc(&fe->w_status, cap) && dalloc(&fe->wn_status, cap) && dalloc(&fe->wn_desc, (size_t)cap * 4) && dalloc(&fe->eig, (size_t)w * h) &&
          dalloc(&fe->mask, (size_t)w * h) && dalloc(&fe->gf_scratch, 4 + 8192) && dalloc(&fe->gf_cands, cand_alloc) && dalloc(&fe->dev, 1);
     ok = ok && hipHostMalloc((void**)&fe->h_msg, sizeof(lvk_feature_obs) * (size_t)cap * LVK_MSG_SLOTS) == hipSuccess &&
