@@ -145,17 +145,23 @@ class Run:
         self.ctx.close()
 
 
-def preroll(run, frames, d_frames, n_max, sw_size, extra_updates):
-    """Untimed: run until the window has filled and cycled, then `extra_updates` more updates with the H P GEMM bracketed.
+def preroll(run, frames, d_frames, n_max, sw_size, extra_updates, warmup=0, period=2):
+    """Untimed: run until the window has filled and cycled, then `extra_updates` more updates with the H P GEMM bracketed, then up to
+    period-1 more frames so that the timed region (which starts `warmup` frames later) begins with a publish frame: it then holds whole
+    publish cycles [frame with a feature message, frames without] - K/period messages either way, but a window that ENDS on a message
+    frame measures one more update's worth of pipeline fill.
     Returns (frames consumed, H P profile) or raises SystemExit when the steady state is not reached."""
     fsz = frames.shape[1] * frames.shape[2]; stride = frames.shape[2]
+    last_pub = [None]
 
     def feed():
         i = run.i
         if d_frames is not None:
-            run.step(dev_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
+            has = run.step(dev_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
         else:
-            run.step(host_img=frames[i])
+            has = run.step(host_img=frames[i])
+        if has:
+            last_pub[0] = i
     steady_at = None
     while run.i < n_max:
         feed()
@@ -179,6 +185,8 @@ def preroll(run, frames, d_frames, n_max, sw_size, extra_updates):
             c = run.be.counters()
             if c["hybrid"] + c["msckf"] - u0 >= 2 * extra_updates:       # hybrid + pruning update per message in the steady state
                 break
+    while last_pub[0] is not None and (run.i + warmup - last_pub[0]) % period != 0 and run.i < n_max + period:
+        feed()
     run.drain()
     hp = run.be.profile(False)
     if hp["launches"] < extra_updates:
@@ -195,10 +203,14 @@ def timed(run, frames, d_frames, W, K, dist, torch):
         if d_frames is not None:
             return run.step(dev_ptr=d_frames.data_ptr() + i * fsz, stride=stride)
         return run.step(host_img=frames[i])
+    # The driver loop is this interpreter: a generation-2 collection inside the timed region is a 10-40 ms stall that no C++ driver
+    # has.  Collect BEFORE the warm-up steps (a full collection walks the whole heap: it leaves the caches cold and the GPU idle for
+    # tens of milliseconds - the warm-up is there to undo exactly that) and keep the collector off until the timed region has ended.
+    gc.collect()
+    gc.disable()
     for _ in range(W):
         feed()
     run.drain()
-    gc.collect()                                         # before the counters are reset: the collection itself is outside everything that is reported
     if not run.sequential:
         run.drv.stats(reset=True); run.drv.latencies(reset=True)
     pl0, it0 = run.fe.lk_stats()
@@ -209,7 +221,6 @@ def timed(run, frames, d_frames, W, K, dist, torch):
         dist.barrier()
     torch.cuda.synchronize()
     lat = np.empty(K); msg_mask = np.zeros(K, bool)
-    gc.disable()                                         # the driver loop is this interpreter: a generation-2 collection inside the timed region is a 10-40 ms stall that no C++ driver has
     t_begin = time.perf_counter()
     for k in range(K):
         t0 = time.perf_counter()
@@ -534,6 +545,7 @@ def main():
     ap.add_argument("--cpu-baseline-frames", type=int, default=None, help="steady-state frames per CPU leg (default 300 at A/3/4, 24 at 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-pass", action="store_true", help="skip the second (device-resident) pass")
+    ap.add_argument("--dump-latencies", action="store_true", help="per-step caller time of the timed region (us) and which steps published a message, on stderr")
     ap.add_argument("--no-adapter-pass", action="store_true", help="skip the passes through the adapter's schedule (deferred processFeatures under a blocking driver)")
     ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
     ap.add_argument("--sharded", action="store_true", help="config 5 across ranks: per-rank feature rows, RCCL all-gather of the compressed R")
@@ -566,7 +578,8 @@ def main():
     sw = wl["sw_size"]
     n_pre_max = 2 * sw + 40 + 48                         # fill (one clone per message, every other frame) + cycle + 20 bracketed updates
     n_cpu = 0 if (args.no_cpu_baseline or world > 1) else (args.cpu_baseline_frames or (24 if args.config == "5" else 300))
-    n_frames = n_pre_max + max(W + K, 3 * n_cpu + 8 * 16) + 2
+    period = max(1, int(round(wl["img_rate"] / wl["fcfg"]["pub_frequency"])))      # frames per feature message
+    n_frames = n_pre_max + period + max(W + K, 3 * n_cpu + 8 * 16) + 2
     first = int(2.0 * wl["img_rate"])                    # t = 2.0 s: the trajectory is moving
     all_cpus = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
     seed_off = 0 if args.sharded else rank               # sharded: every rank sees the same camera
@@ -588,9 +601,12 @@ def main():
     stream = torch.cuda.current_stream()
     # ---- pass 1 (headline): host images, H2D inside the timed region
     run = Run(wl, args, local_rank, imu_all, seq, ts, args.sequential, torch_stream=stream.cuda_stream, shard=shard)
-    n_pre, hp = preroll(run, frames, None, n_pre_max, sw, 20)
+    n_pre, hp = preroll(run, frames, None, n_pre_max, sw, 20, warmup=W, period=period)
     m = timed(run, frames, None, W, K, dist, torch)
     state_dim = run.be.dim; n_clones = len(run.be.clones()); counters = run.be.counters()
+    if args.dump_latencies and rank == 0:
+        sys.stderr.write("caller us per step: %s\nmessage steps: %s\nelapsed %.1f us, sum of steps %.1f us\n" % (
+            " ".join("%.0f" % (x * 1e6) for x in m["lat"]), " ".join(str(int(x)) for x in m["msg_mask"]), m["elapsed"] * 1e6, m["lat"].sum() * 1e6))
     # tracks the tracker holds = mean size of the feature messages published inside the timed region (device counter)
     live = int(round(m["msg_features"] / m["msgs"])) if m["msgs"] else int(len(run.fe.tracks()["ids"]))
     run.close()
@@ -599,7 +615,7 @@ def main():
     # ---- pass 2: the same frames already resident in HBM (camera DMA case)
     md = None
     if not args.no_device_pass:
-        d_frames = torch.from_numpy(frames[:n_pre_max + W + K + 2]).cuda()
+        d_frames = torch.from_numpy(frames[:n_pre_max + period + W + K + 2]).cuda()
         run2 = Run(wl, args, local_rank, imu_all, seq, ts, args.sequential, torch_stream=stream.cuda_stream, shard=shard)
         while run2.i < n_pre:                            # same pre-roll length as pass 1: the timed frames are the same frames
             i = run2.i
@@ -694,7 +710,7 @@ def main():
                                        "pipelined: filter update of frame k (own stream + worker thread) overlaps the front-end of frames k+1..; "
                                        "identical results (tests/test_gpu_vio_driver.py); all updates drained inside the timed region"),
                           "stages": "processImage every frame + processFeatures on every feature message, as app/larvioMain.cpp:106-116",
-                          "pre_roll_frames": n_pre, "sw_size": sw, "clones": n_clones, "state_dim": state_dim, "backend": counters,
+                          "pre_roll_frames": n_pre, "timed_region_alignment": "starts on a publish frame: %d whole publish cycles of %d frames" % (K // period, period) if bool(m["msg_mask"][0]) else "starts %d frame(s) before a publish frame" % int(np.argmax(m["msg_mask"])), "sw_size": sw, "clones": n_clones, "state_dim": state_dim, "backend": counters,
                           "timed_region": {"messages": int(mm.sum()), "hybrid_updates": m["n_hybrid"], "msckf_pruning_updates": m["n_msckf"]},
                           "live_tracks": live,
                           "rehearsal_one_gpu_gloo": bool(os.environ.get("LVK_BENCH_ONE_GPU")), "parallelism": ("sharded x%d: contiguous feature ranges per rank, RCCL all-gather of the packed R factors" % world) if args.sharded

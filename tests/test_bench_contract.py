@@ -52,5 +52,5 @@ def test_bench_source_reaches_the_stated_steady_state_before_timing():
     assert main.index("preroll(run, frames, None") < main.index("timed(run, frames, None")
     pre = src[src.index("def preroll("):src.index("def timed(")]
     assert "sw_size - 2" in pre and 'c["msckf"] >= 2' in pre and "raise SystemExit" in pre and "no value printed" in pre
-    assert "preroll(run, frames, None, n_pre_max, sw, 20)" in main
+    assert "preroll(run, frames, None, n_pre_max, sw, 20, warmup=W, period=period)" in main
     assert "n_cpu = 0 if" in main and "else 300" in main                       # >= 200 steady-state CPU frames at the metric's configuration

@@ -9,7 +9,7 @@ for r in $(seq 1 $R); do
   for spec in "$@"; do
     n=${spec%%:*}; envs=${spec#*:}
     ( IFS=','; for kv in $envs; do [ "$kv" != "-" ] && export "$kv"; done; unset IFS
-      timeout 600 python bench.py $ARGS > $O/${n}_r$r.json 2> $O/${n}_r$r.err )
+      timeout 600 python ${BENCH_PY:-bench.py} $ARGS > $O/${n}_r$r.json 2> $O/${n}_r$r.err )
     python - "$O/${n}_r$r.json" "$n r$r" <<'P'
 import json, sys
 d = None
