@@ -243,6 +243,7 @@ def timed(run, frames, d_frames, W, K, dist, torch):
                pst=None, e2e=None)
     if not run.sequential:
         out["pst"] = run.drv.stats()
+        out["early"] = run.drv.early_counts()
         e2e = lat.copy() * 1e6                           # image-in -> state-out: front-end completion, or the end of the update it triggered
         pl = run.drv.latencies()
         idx = np.flatnonzero(msg_mask)
@@ -690,6 +691,9 @@ def main():
                "back_end_ms_per_message": None if pst is None else round(pst["filter_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
                "caller_wait_ms_per_frame": None if pst is None else round(pst["caller_wait_us"] / K * 1e-3, 4),
                "worker_idle_ms_per_message": None if pst is None else round(pst["worker_idle_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
+               "erase_counts_taken_early": None if pst is None else {"since_start": m["early"][0], "found_wrong": m["early"][1],
+                                                                     "note": "lvk_vio_pipe_early_counts: the caller's thread took the IMU erase count of a queued update from the last published td "
+                                                                             "(no IMU sample within 0.5 ms of the bound) instead of waiting for the running update; checked by the filter's thread"},
                "device_resident": None if md is None else {"value": round(streams * K / md["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(md["elapsed"] / K * 1e3, 4),
                                                            "p50_ms_per_frame": pct(md["e2e"], 50),
                                                            "note": "same frames, already in HBM when the timed region starts (no staging copy, no H2D)"},

@@ -353,6 +353,12 @@ lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* h_out4, int reset);
  * of every frame that produced a feature message since the last reset, in order; *n_out <= cap entries are written.  For a VIO this
  * is the latency that matters (the reference's timing window app/larvioMain.cpp:106-116 spans both calls). */
 lvk_status lvk_vio_pipe_latency(lvk_vio_pipe* p, float* h_out_us, int cap, int* n_out, int reset);
+/* Erase counts lvk_vio_pipe_submit took EARLY (from the last published camera-IMU time offset, because no IMU sample lies within
+ * LVK_PIPE_TD_MARGIN [0.5 ms] of the bound the count depends on - the caller's thread then does not wait for the running update), and
+ * how many of them the filter's thread found different when the update started (expected: 0; the reference's sequential schedule
+ * - larvio.cpp:464-517 erasing before the next processImage reads the vector - is reproduced exactly whenever it is 0).
+ * LVK_PIPE_EARLY_COUNT=0 switches the early count off (every frame after a message frame then waits for the running update). */
+lvk_status lvk_vio_pipe_early_counts(lvk_vio_pipe* p, long* n_early, long* n_wrong);
 
 #ifdef __cplusplus
 }

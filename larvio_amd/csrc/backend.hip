@@ -702,15 +702,22 @@ static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_im
     return used;
 }
 
-static int batch_imu_count(const lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
-{   // how many samples batch_imu will erase, without touching the state (timestamps only)
-    int used = 0; double t = e->s.t;
+// how many samples batch_imu will erase, without touching the state: time stamps only - the state time t0, the bound (image time +
+// td) and the threshold.  t_after = the state time batch_imu leaves behind.
+static int imu_erase_count(double t0, double time_bound, double th, const lvk_imu* imu, int n_imu, double* t_after)
+{
+    int used = 0; double t = t0;
     for (int i = 0; i < n_imu; ++i) {
         if (imu[i].t <= t) { ++used; continue; }
-        if (imu[i].t - time_bound > e->imu_img_time_th) break;
+        if (imu[i].t - time_bound > th) break;
         t = imu[i].t; ++used;
     }
+    if (t_after) *t_after = t;
     return used;
+}
+static int batch_imu_count(const lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu, double* t_after = nullptr)
+{
+    return imu_erase_count(e->s.t, time_bound, e->imu_img_time_th, imu, n_imu, t_after);
 }
 
 static lvk_status state_augmentation(lvk_ekf* e)
@@ -2239,17 +2246,30 @@ lvk_status lvk_vio_process_deferred(lvk_frontend* fe, lvk_ekf* ekf, const lvk_im
 // in a worker thread while the front-end of frame k+1 runs on the caller's thread.  The one coupling that needs care is the
 // IMU vector: processFeatures erases what it consumed and the NEXT processImage integrates gyro samples from whatever is
 // left — submit() therefore waits until the erase count of every queued update is known (it is final before any GPU work).
+// The count depends on time stamps, on the state time the previous update's IMU batch leaves behind (time stamps again) and on the
+// camera-IMU time offset td, which every update moves a little (micro-seconds).  So when the count is the same for td - margin and
+// td + margin (LVK_PIPE_TD_MARGIN, 0.5 ms: the bound "image time + td + half an IMU period" is then at least that far from any IMU
+// sample) submit() takes it at once from the last published td and the caller's thread runs on while up to two updates are in
+// flight; the filter's thread checks the count against the real td when the job starts (never different in any run here; counted in
+// lvk_vio_pipe_early_counts if it ever is, and the IMU window is put right for the frames that follow).  Otherwise - an IMU sample
+// within the margin of the bound - it waits as before.
 static double now_us_fwd();
 struct lvk_vio_pipe {
     lvk_frontend* fe; lvk_ekf* ekf;
     std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..)
-    struct Job { double ts; int slot = -1; std::vector<lvk_imu> view; bool precounted = false; double t_submit = 0; };   // slot: the front-end's message ring entry
+    struct Job { double ts; int slot = -1; std::vector<lvk_imu> view; bool precounted = false; double t_submit = 0;      // slot: the front-end's message ring entry
+                 bool early = false; int n_pre = 0; double t0_pre = 0; };                                                // early: counted by submit() from the published td (to be checked)
     std::vector<float> lat_us;                          // image-in -> state-out of every message-carrying frame (submit entry to update done)
     bool cur_precounted = false;                        // the running job's erase count was already applied by submit()
     std::deque<Job> q;
     std::thread worker; std::mutex mu; std::condition_variable cv_job, cv_state;
     std::atomic<unsigned> gen{0};                       // bumped on every state change: waiters poll it WITHOUT the mutex
     int unknown_consume = 0;                            // queued or running updates whose erase count is not final yet
+    // what submit() needs for an early count, all under mu: the filter is initialised, td after the last finished update, the state
+    // time after the IMU batch of the last COUNTED job (the filter's own s.t belongs to its thread while a job runs)
+    bool steady = false; double td_pub = 0, state_t = 0, td_margin = 5e-4; bool early_on = true;
+    int depth = 2;                                      // updates the caller may have in flight when a frame starts (LVK_PIPE_DEPTH; 1: never more than one update ahead - lower latency, the filter's thread waits for messages)
+    long n_early = 0, n_early_wrong = 0;
     int in_flight = 0;                                  // queued + running
     long n_updates = 0, n_msgs = 0;
     lvk_status st = LVK_OK;
@@ -2317,13 +2337,24 @@ static void pipe_worker(lvk_vio_pipe* p)
         // The erase count of this update depends on time stamps, the state time and td only - all final now that the previous update
         // is done - so it is published BEFORE this thread blocks on the message: the caller's next frame needs nothing else from here.
         if (!job.precounted && p->ekf->b_first_features && p->ekf->is_gravity_set) {
-            const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size());
+            double t_after = 0;
+            const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size(), &t_after);
             {
                 std::lock_guard<std::mutex> lk(p->mu);
-                p->head += (size_t)n; p->unknown_consume -= 1; p->cur_precounted = true;
+                p->head += (size_t)n; p->unknown_consume -= 1; p->cur_precounted = true; p->state_t = t_after;
                 p->gen.fetch_add(1, std::memory_order_release);
             }
             p->cv_state.notify_all();
+        } else if (job.early) {
+            // counted by submit() from an older td: the same count with the td this update starts from?
+            double t_after = 0;
+            const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size(), &t_after);
+            if (n != job.n_pre || p->ekf->s.t != job.t0_pre) {
+                std::lock_guard<std::mutex> lk(p->mu);
+                p->head = (size_t)((long)p->head + (n - job.n_pre)); p->n_early_wrong += 1;
+                if (p->q.empty()) p->state_t = t_after;                 // later jobs were counted from the wrong state time: they are checked in turn
+                p->gen.fetch_add(1, std::memory_order_release);
+            }
         }
         int used = 0, upd = 0;
         // the message itself is collected on THIS thread (the caller's thread queued the frame and went on), and only when the update
@@ -2345,6 +2376,7 @@ static void pipe_worker(lvk_vio_pipe* p)
             if (p->lat_us.size() < (size_t)1 << 20) p->lat_us.push_back((float)(t2 - job.t_submit));
             if (st != LVK_OK && p->st == LVK_OK) p->st = st;
             p->n_updates += upd; p->in_flight -= 1;
+            p->td_pub = p->ekf->td; p->steady = p->ekf->b_first_features && p->ekf->is_gravity_set;
             p->gen.fetch_add(1, std::memory_order_release);
         }
         p->cv_state.notify_all();
@@ -2361,6 +2393,9 @@ lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** ou
     lvk_vio_pipe* p = new lvk_vio_pipe();
     p->fe = fe; p->ekf = ekf; p->wmsg.resize(8192);
     p->logging = getenv("LVK_PIPE_LOG") != nullptr; if (p->logging) p->log.reserve(1 << 16);
+    if (const char* v = getenv("LVK_PIPE_EARLY_COUNT")) p->early_on = atoi(v) != 0;
+    if (const char* v = getenv("LVK_PIPE_TD_MARGIN")) { const double m = atof(v); if (m > 0) p->td_margin = m; }
+    if (const char* v = getenv("LVK_PIPE_DEPTH")) { const int d = atoi(v); if (d >= 1 && d <= 3) p->depth = d; }      // 3 = the message ring minus the entry being written
     ekf->on_consumed = pipe_on_consumed; ekf->on_consumed_user = p;
     p->worker = std::thread(pipe_worker, p);
     *out = p;
@@ -2401,7 +2436,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->ev(0);
-        pipe_wait(p, lk, p->cv_state, [&] { return p->unknown_consume == 0; });
+        pipe_wait(p, lk, p->cv_state, [&] { return p->unknown_consume == 0 && p->in_flight <= p->depth; });
         if (p->st != LVK_OK) return p->st;
         head = p->head; end = p->imu.size();
         p->ev(1);
@@ -2423,10 +2458,23 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
         // With the worker idle the filter is quiescent: the erase count (timestamps, state time and td only) can be taken here
         // and the next frame need not wait for the worker to wake up.
         lvk_ekf* e = p->ekf;
+        bool counted = false;
         if (p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
-            p->head += (size_t)batch_imu_count(e, ts + e->td, job.view.data(), (int)job.view.size());
-            job.precounted = true; p->ev(4);
-        } else { p->unknown_consume += 1; p->ev(3); }
+            double t_after = 0;
+            p->head += (size_t)batch_imu_count(e, ts + e->td, job.view.data(), (int)job.view.size(), &t_after);
+            p->state_t = t_after; p->td_pub = e->td; p->steady = true;
+            job.precounted = true; counted = true; p->ev(4);
+        } else if (p->in_flight > 0 && p->early_on && p->steady) {
+            // every queued job is counted (the wait above), so state_t is the state time this job will start from
+            double ta = 0, tb2 = 0;
+            const int n_lo = imu_erase_count(p->state_t, ts + p->td_pub - p->td_margin, e->imu_img_time_th, job.view.data(), (int)job.view.size(), &ta);
+            const int n_hi = imu_erase_count(p->state_t, ts + p->td_pub + p->td_margin, e->imu_img_time_th, job.view.data(), (int)job.view.size(), &tb2);
+            if (n_lo == n_hi) {
+                job.precounted = true; job.early = true; job.n_pre = n_lo; job.t0_pre = p->state_t;
+                p->head += (size_t)n_lo; p->state_t = ta; p->n_early += 1; counted = true; p->ev(7);
+            }
+        }
+        if (!counted) { p->unknown_consume += 1; p->ev(3); }
         p->q.push_back(std::move(job)); p->in_flight += 1; p->n_msgs += 1;
         p->gen.fetch_add(1, std::memory_order_release);
     }
@@ -2440,6 +2488,15 @@ lvk_status lvk_vio_pipe_stats(lvk_vio_pipe* p, double* out4, int reset)
     std::lock_guard<std::mutex> lk(p->mu);
     out4[0] = p->t_fe; out4[1] = p->t_submit_wait; out4[2] = p->t_busy; out4[3] = p->t_idle;
     if (reset) p->t_busy = p->t_idle = p->t_fe = p->t_submit_wait = 0;
+    return LVK_OK;
+}
+
+lvk_status lvk_vio_pipe_early_counts(lvk_vio_pipe* p, long* n_early, long* n_wrong)
+{
+    if (!p) return LVK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (n_early) *n_early = p->n_early;
+    if (n_wrong) *n_wrong = p->n_early_wrong;
     return LVK_OK;
 }
 

@@ -25,6 +25,7 @@ def _L():
         L.lvk_vio_pipe_drain.argtypes = [vp, pl, pl]; L.lvk_vio_pipe_drain.restype = i
         L.lvk_vio_pipe_stats.argtypes = [vp, C.POINTER(C.c_double), i]; L.lvk_vio_pipe_stats.restype = i
         L.lvk_vio_pipe_latency.argtypes = [vp, vp, i, pi, i]; L.lvk_vio_pipe_latency.restype = i
+        L.lvk_vio_pipe_early_counts.argtypes = [vp, pl, pl]; L.lvk_vio_pipe_early_counts.restype = i
         _done = True
     return L
 
@@ -120,6 +121,12 @@ class VioPipeline:
         o = (C.c_double * 4)()
         _L().lvk_vio_pipe_stats(self._h, o, 1 if reset else 0)
         return dict(front_end_us=o[0], caller_wait_us=o[1], filter_us=o[2], worker_idle_us=o[3])
+
+    def early_counts(self):
+        """(erase counts taken early by submit, how many of them the filter's thread found different): lvk_vio_pipe_early_counts"""
+        a, b = C.c_long(0), C.c_long(0)
+        _L().lvk_vio_pipe_early_counts(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def latencies(self, reset=True, cap=1 << 20):
         """image-in -> state-out latency [us] of every message-carrying frame since the last reset (drain() first)"""

@@ -127,6 +127,9 @@ def test_pipelined_driver_is_identical_to_sequential(gpu_ctx, disturbed):
         if mode == "pipe":
             n_upd, n_m = drv.drain()
             assert n_m == n_msg
+            early, wrong = drv.early_counts()          # erase counts taken before the running update had finished: all confirmed
+            assert wrong == 0, (early, wrong)
+            print("pipelined driver: %d messages, %d erase counts taken early, %d wrong" % (n_m, early, wrong))
             drv.close()
         st = be.state()
         out.append((n_msg, be.dim, {k: np.array(v, copy=True) for k, v in st.items()}, be.cov(), be.clones()["id"].copy(), be.features()[0].copy(),
