@@ -217,6 +217,8 @@ public:
         return has != 0;
     }
     bool drain(long* n_updates = nullptr, long* n_msgs = nullptr) { return pipe_ && lvk_vio_pipe_drain(pipe_, n_updates, n_msgs) == LVK_OK; }
+    // erase counts submit() took early / how many of them the filter's thread found different (expected 0; lvk_c.h)
+    bool earlyCounts(long* n_early, long* n_wrong) { return pipe_ && lvk_vio_pipe_early_counts(pipe_, n_early, n_wrong) == LVK_OK; }
     lvk_vio_pipe* handle() const { return pipe_; }
 private:
     VioPipeline(const VioPipeline&); VioPipeline& operator=(const VioPipeline&);
