@@ -41,25 +41,51 @@ def R2q(R):
     return np.array([(R[2, 1] - R[1, 2]) / s_, (R[0, 2] - R[2, 0]) / s_, (R[1, 0] - R[0, 1]) / s_, 0.25 * s_])
 
 
-def bind_one_socket():
-    """Dual-socket hosts: keep the whole process - Python, the HIP runtime's own threads and queues, our two driver threads - on ONE
-    socket, before anything initialises HIP (a process whose threads straddle both ran the filter at 0.35 instead of 0.30 ms per
-    update; which socket made no difference).  LVK_BENCH_BIND=0 disables.  Returns the affinity set before binding."""
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_one_socket(local_rank=0):
+    """Keep the whole process - Python, the HIP runtime's own threads and queues, our two driver threads - close together, before
+    anything initialises HIP.  Dual-socket hosts: ONE socket (a process whose threads straddle both ran the filter at 0.35 instead
+    of 0.30 ms per update; which socket made no difference).  Within the socket: the physical cores (no SMT siblings) of ONE L3
+    group - the caller's and the filter's thread hand messages and counters to each other every ~100 us; with the scheduler free to
+    put them anywhere in the socket the filter ran in two modes, 0.264 or 0.276 ms per message, from run to run.  Ranks of one node
+    take different L3 groups.  LVK_BENCH_BIND=socket: the socket only; =0: nothing.  Returns the affinity set before binding."""
     before = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
-    if os.environ.get("LVK_BENCH_BIND", "1") != "0" and hasattr(os, "sched_setaffinity"):
+    mode = os.environ.get("LVK_BENCH_BIND", "l3")
+    if mode != "0" and hasattr(os, "sched_setaffinity"):
         try:
             cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else min(before)
             import glob as _glob
+            keep = set()
             for node in _glob.glob("/sys/devices/system/node/node*/cpulist"):
-                cpus = set()
-                for part in open(node).read().strip().split(","):
-                    a, _, b = part.partition("-")
-                    cpus.update(range(int(a), int(b or a) + 1))
+                cpus = _cpulist(open(node).read())
                 if cpu in cpus:
                     keep = cpus & before
-                    if keep:
-                        os.sched_setaffinity(0, keep)
                     break
+            if keep and mode != "socket":
+                groups = {}
+                for c in sorted(keep):
+                    try:
+                        l3 = frozenset(_cpulist(open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c).read()))
+                        sib = _cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read())
+                    except OSError:
+                        groups = {}
+                        break
+                    if c == min(sib):                    # one logical CPU per physical core
+                        groups.setdefault(min(l3), set()).add(c)
+                order = [groups[k] & keep for k in sorted(groups)]
+                order = [g for g in order if len(g) >= 4]
+                if order:
+                    keep = order[local_rank % len(order)]
+            if keep:
+                os.sched_setaffinity(0, keep)
         except (OSError, ValueError):
             pass
     return before
@@ -561,7 +587,7 @@ def main():
         raise SystemExit("--sharded is the configs[4] path (2000 tracks): use --config 5 (or --backend-only)")
     if args.backend_only:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 % on these chains of small kernels (same-box A/B)
-        bind_one_socket()
+        bind_one_socket(local_rank)
         import torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
@@ -590,7 +616,7 @@ def main():
     k_lo = max(int(ts[0] * 200) - 4, 0)
     imu_all = seq.imu_array(k_lo, int(ts[-1] * 200) + 40)
 
-    bind_one_socket()
+    bind_one_socket(local_rank)
     # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 % on these chains of small kernels (same-box A/B)
     import torch
