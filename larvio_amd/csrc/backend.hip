@@ -43,7 +43,8 @@ lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, i
                                    const double* dx, double sigma2, double* tmp, double* dx_new);
 lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out);
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
-                                   const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out, FeatResult* d_out_host);
+                                   const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out, FeatResult* d_out_host,
+                                   double* d_Hout, int ldh, int ncols_out, double* d_rout);
 lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
 
@@ -253,6 +254,7 @@ struct lvk_ekf {
     // results come back WITHOUT copies: the kernels that produce them (triangulation, per-feature rows, the dx column of W^T[W|w])
     // also write them into this device-mapped pinned buffer; the host reads it after the stream sync it needs anyway
     char* h_down = nullptr; size_t down_cap = 0; char* dh_down = nullptr; size_t down_feat = 0, down_dx = 0;
+    bool rows_direct = true;                            // k_feature_rows writes the dense measurement rows itself where the slots are known before its launch (LVK_ROWS_DIRECT=0: always through k_stack_rows)
     // fired as soon as the number of IMU samples this call erases is final (before any GPU work): lets a pipelined driver
     // hand the next frame's front-end the right buffer view while this update is still running
     void (*on_consumed)(void*, int) = nullptr; void* on_consumed_user = nullptr;
@@ -910,7 +912,7 @@ static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracke
 }
 
 // One feature-rows job (rows on the device) ------------------------------------------------------------
-struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; };
+struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; FeatJob* hdev = nullptr; };   // hdev: the job's record in the upload arena (patched until the launch is flushed)
 
 typedef std::vector<std::pair<size_t, size_t>> JobRanges;
 static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, const JobRanges* ranges = nullptr)
@@ -944,18 +946,19 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
         off += M;
         stage += (size_t)2 * M * c * 2 + 2 * M; ccols += c;
         max_rows = std::max(max_rows, 2 * M);
-        hj[i] = d;
+        hj[i] = d; j.hdev = &hj[i];
     }
     if (stage > e->staging_cap || ccols > e->ccols_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "staging buffer too small (%zu doubles needed)", stage);
     FilterFlags fl; fl.leg_dim = LEG; fl.if_fej = e->if_fej ? 1 : 0; fl.estimate_td = e->cfg.estimate_td; fl.pad = 0; fl.sigma2 = e->sigma2;
     const FeatJob* d_j = dev(e, hj); const int* d_r = dev(e, hr); const double* d_z = dev(e, hz); const double* d_v = dev(e, hv);
     const int nj = (int)jobs.size(); const CloneDev* d_cl = e->dv_clones; double* P = e->dP[e->cur];
     FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
-    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh); });
+    double* Ho = e->d_H; double* ro = e->d_r; const int ldh = e->ld, ncols_out = e->N;       // direct output of the jobs that carry a destination row (set_direct_rows)
+    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh, Ho, ldh, ncols_out, ro); });
     for (const auto& rg : *ranges) {                    // jobs carry absolute offsets into the observation / staging / column arrays
         const size_t lo = rg.first; const int n = (int)(rg.second - rg.first);
         if (n <= 0) continue;
-        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo); });
+        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo, nullptr, 0, 0, nullptr); });
         if (st != LVK_OK) return st;
     }
     return LVK_OK;
@@ -1375,11 +1378,13 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             std::vector<StackRow> map_o; std::vector<RowGroup> grp;
             int rows_m = 0, rows_e = 0;
             auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
-            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, own_of(k)); rows_m += r; }
-            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); rows_e += 2; }
+            // unsharded: the row kernel (still held back by begin_defer) writes its rows straight into H_o - the slots are known now
+            const bool direct = !sharded && e->rows_direct;
+            for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + 1; rows_m += r; }
+            for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + rows_e + 1; rows_e += 2; }
             int m = rows_m + rows_e;
-            if (m > e->hrows) { end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
-            if (!sharded) st = stack_rows(e, map_o, e->d_H, N, e->d_r);
+            if (m > e->hrows) { for (RowJob& j : jobs) j.hdev->dst_row1 = 0; end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
+            if (!sharded && !direct) st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
             if (sharded && st == LVK_OK) { st = shard_stage1(e, map_o, grp, N, &jb, &m); e->shard.stats[2]++; }
             std::vector<double> dx;
@@ -1657,10 +1662,11 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         if (st != LVK_OK) { end_defer(e); return st; }
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; std::vector<RowGroup> grp; int rows = 0;
-        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N, sharded ? shard_owner(jb, k) : 0); rows += r; }
+        const bool direct = !sharded && e->rows_direct;      // as in remove_lost_features: the row kernel writes H_o itself
+        for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N, sharded ? shard_owner(jb, k) : 0); if (direct) jobs[k].hdev->dst_row1 = rows + 1; rows += r; }
         for (auto kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
         {
-            if (!sharded) st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
+            if (!sharded && !direct) st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
             if (sharded && st == LVK_OK) { st = shard_stage1(e, map_o, grp, e->N, &jb, &rows); e->shard.stats[2]++; }
             std::vector<double> dx;
@@ -1901,6 +1907,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
         void* dd = nullptr;
         ok = ok && hipHostGetDevicePointer(&dd, e->h_down, 0) == hipSuccess && dd; e->dh_down = (char*)dd;
         e->d_triout = (TriResult*)e->dh_down;
+        if (const char* v = getenv("LVK_ROWS_DIRECT")) e->rows_direct = atoi(v) != 0;
     }
     if (!ok) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_ekf_create: allocation failed"); }
     // initial covariance (larvio.cpp:163-186)

@@ -11,7 +11,7 @@ struct TriResult { int ok, pad; double position[3], solution[3], inv_depth, obs_
 enum { JOB_MSCKF = 0, JOB_EKF_NEW = 1, JOB_EKF_TRACKED = 2 };
 struct FeatJob {
     int type, n_obs, obs_off, anchor_rank, fcol, want_gate;
-    int ccol_off, pad;
+    int ccol_off, dst_row1;          // dst_row1 > 0: the job's output rows also go, expanded, to rows dst_row1-1.. of the dense measurement matrix (k_feature_rows' direct output)
     long long stage_off;
     double p_w[3], p_fej[3], inv_depth, obs_anchor[3];
     double gate_thr;                 // chi-square 5 % lower-tail threshold for this job's dof (gatingTest, larvio.cpp:1865-1880)

@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
                                                             const int* __restrict__ obs_rank, const double* __restrict__ obs_z, const double* __restrict__ obs_zv,
                                                             const double* __restrict__ P, int ldp, FilterFlags fl,
                                                             double* __restrict__ staging, int* __restrict__ ccols, FeatResult* __restrict__ out,
-                                                            FeatResult* __restrict__ out_host /* optional mirror in device-mapped host memory */)
+                                                            FeatResult* __restrict__ out_host /* optional mirror in device-mapped host memory */,
+                                                            double* __restrict__ H_out, int ldh, int ncols_out, double* __restrict__ r_out /* direct output, see the end */)
 {
     extern __shared__ double sh[];
     const int jb = blockIdx.x;
@@ -337,11 +338,29 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         for (int e = t; e < rows * c; e += FR_THREADS) Gg[e] = G[e];
         for (int e = t; e < rows; e += FR_THREADS) rrg[e] = rr[e];
     }
+    const int accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;      // gamma is the same in every thread
     if (t == 0) {
         FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2;
-        o.accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;
+        o.accept = accept;
         out[jb] = o;
         if (out_host) out_host[jb] = o;
+    }
+    // ---- direct output: when the host knows the job's slot in the stacked system before the launch (no feature enters the state
+    // in this update), the rows go straight into the dense measurement matrix - zero row, then the compact columns scattered, or a
+    // zero row with a zero residual for a rejected job (which leaves the update unchanged) - and the stacking launch (6 us + its gap
+    // on the update's dependent chain) is not needed.  Same values as k_stack_rows writes.
+    if (job.dst_row1 > 0 && H_out) {
+        const int d0 = job.dst_row1 - 1;
+        const int src0 = (job.type == JOB_EKF_TRACKED) ? 0 : first_row;
+        const int nout = (job.type == JOB_EKF_TRACKED) ? 2 : k_rows;
+        for (int e = t; e < nout * ncols_out; e += FR_THREADS) { const int a = e / ncols_out, j = e - a * ncols_out; H_out[(size_t)(d0 + a) * ldh + j] = 0.; }
+        if (t < nout) r_out[d0 + t] = accept ? rr[src0 + t] : 0.;
+        __syncthreads();
+        if (accept)
+            for (int e = t; e < nout * c; e += FR_THREADS) {
+                const int a = e / c, j = e - a * c, col = cc[j];
+                if (col >= 0 && col < ncols_out) H_out[(size_t)(d0 + a) * ldh + col] = G[(size_t)(src0 + a) * c + j];
+            }
     }
 }
 
@@ -375,7 +394,7 @@ lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_
 
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging,
-                                   int* d_ccols, FeatResult* d_out, FeatResult* d_out_host)
+                                   int* d_ccols, FeatResult* d_out, FeatResult* d_out_host, double* d_Hout, int ldh, int ncols_out, double* d_rout)
 {
     if (n_jobs <= 0) return LVK_OK;
     const size_t base = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
@@ -385,11 +404,11 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
     if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
     if (small) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<true>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout);
     } else {
         LVK_LDS_OPTIN(ctx, 1, k_feature_rows<false>, shmem);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<false>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout);
     }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -490,7 +509,7 @@ extern "C" lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* 
     double* d_staging = (double*)d_st; int* d_ccols = (int*)(d_st + ((sizeof(double) * stage + 63) & ~(size_t)63));
     FeatResult* d_fout = (FeatResult*)(d_out + o_fo);
     lvk_status st = lvk_launch_feature_rows(ctx, (const FeatJob*)(d_in + o_job), n_feats, max_rows, (const CloneDev*)(d_in + o_cl), (const int*)(d_in + o_rk),
-                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr);
+                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr, nullptr, 0, 0, nullptr);
     if (st != LVK_OK) return st;
     std::vector<FeatResult> res(n_feats);
     LVK_HIP(ctx, hipMemcpyAsync(res.data(), d_fout, sizeof(FeatResult) * n_feats, hipMemcpyDeviceToHost, ctx->stream));
