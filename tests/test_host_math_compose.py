@@ -36,3 +36,14 @@ def test_observation_lists_and_map_cursor_against_std_map_models(tmp_path):
     (incl. out-of-order messages and features erased in between) against plain std::map models over random operation sequences."""
     r = _run_host_check(tmp_path, "feature_obs_check")
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (host compile only)")
+def test_early_erase_count_equals_the_sequential_count_whenever_it_is_taken(tmp_path):
+    """lvk_vio_pipe_submit's early IMU erase count (same count for td - 0.5 ms and td + 0.5 ms => taken at once from the last published
+    td) against the sequential rule (the count with the td the update starts from, larvio.cpp:464-517) on jittered IMU streams with a
+    random phase against the image grid and a random-walk td: equal whenever it is taken, the state time it leaves behind too, waiting
+    frames in the share the geometry predicts, and never on the benchmark's grid-aligned input."""
+    r = _run_host_check(tmp_path, "erase_count_check")
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
+    print(r.stdout.strip())
