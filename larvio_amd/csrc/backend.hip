@@ -2358,7 +2358,8 @@ static void pipe_worker(lvk_vio_pipe* p)
             const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size(), &t_after);
             if (n != job.n_pre || p->ekf->s.t != job.t0_pre) {
                 std::lock_guard<std::mutex> lk(p->mu);
-                p->head = (size_t)((long)p->head + (n - job.n_pre)); p->n_early_wrong += 1;
+                const long nh = (long)p->head + (n - job.n_pre);      // (the vector may have been compacted since the count was taken: stay inside it)
+                p->head = nh < 0 ? 0 : std::min((size_t)nh, p->imu.size()); p->n_early_wrong += 1;
                 if (p->q.empty()) p->state_t = t_after;                 // later jobs were counted from the wrong state time: they are checked in turn
                 p->gen.fetch_add(1, std::memory_order_release);
             }
