@@ -30,6 +30,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert a["unit"] == d["unit"] and 0 < a["value"] < d["value"] and a["pose_read_one_frame_late"]["value"] >= 0.9 * a["value"]
     q = d["roofline_qr"]
     assert q["kernel"].startswith("k_qr_sparse") and q["flops_per_launch"] > 0 and abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-5
+    # round 3, final state: the pipelined driver's early erase counts were all confirmed; the timed region holds whole publish cycles
+    ec = d["erase_counts_taken_early"]
+    assert ec["since_start"] > 0 and ec["found_wrong"] == 0
+    assert d["config"]["timed_region_alignment"].startswith("starts on a publish frame")
     pr = d["sharded_update_probe"]
     assert pr["cpu_baseline"]["kind"] == "port" and pr["cpu_baseline"]["value"] > 0 and pr["rccl_loopback"]["shard"]["exchanges"] == pr["rccl_loopback"]["shard"]["sharded_updates"] > 0
 
