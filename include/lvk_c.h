@@ -32,6 +32,7 @@ typedef int lvk_status;
 #define LVK_ERR_DEVICE      2   /* HIP runtime error / no device */
 #define LVK_ERR_CAPACITY    3   /* a fixed capacity was exceeded */
 #define LVK_ERR_UNSUPPORTED 4   /* configuration outside what the kernels are built for */
+#define LVK_ERR_NUMERIC     5   /* the measurement update met an innovation covariance that is not positive definite: the filter has diverged */
 
 typedef struct lvk_context  lvk_context;
 typedef struct lvk_pyramid  lvk_pyramid;
@@ -190,7 +191,9 @@ lvk_status lvk_ekf_compress_qr_groups(lvk_context* ctx, double* d_H, int ld, int
                                       const int* h_rows, const int* h_col_off, const int* h_cols, int* rows_out);
 int        lvk_ekf_qr_plan(int N, int n_groups, const int* h_rows, const int* h_col_off, const int* h_cols, int* h_blocks, int cap_blocks,
                            int* h_block_cols, int cap_cols, int* h_level_blocks, int* h_level_cols, int cap_levels, int* final_rows);
-/* S = H P H^T + sigma2 I ; dx = P H^T S^-1 r ; P <- (I - K H) P symmetrised.  H is m x n (ldh), P n x n (ldp). */
+/* S = H P H^T + sigma2 I ; dx = P H^T S^-1 r ; P <- (I - K H) P symmetrised.  H is m x n (ldh), P n x n (ldp).
+ * Replaces larvio.cpp:1453-1460, 1578-1594.  Waits for the update: LVK_ERR_NUMERIC when S is not positive definite (d_P is then
+ * whatever the factorisation with that pivot replaced by 1 leaves; the reference's pivoted LDLT goes on silently). */
 lvk_status lvk_ekf_update(lvk_context* ctx, double* d_P, int ldp, int n, const double* d_H, int ldh, int m,
                           const double* d_r, double sigma2, double* d_dx);
 /* C = alpha op(A) op(B) + beta C on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) — the P H^T-class contraction */

@@ -244,6 +244,7 @@ struct lvk_ekf {
     struct Shard { int rank = 0, world = 1; lvk_exchange_fn fn = nullptr; void* user = nullptr; char *d_send = nullptr, *d_recv = nullptr; size_t cap = 0; int xk_cap = 0;
                    long stats[4] = {0, 0, 0, 0}; } shard;     // stats: [0] exchanges [1] bytes sent per rank (sum) [2] sharded updates [3] rows this rank stacked
     size_t down_flag = 0;                               // offset in h_down of the word k_shard_unpack raises when a peer's block arrives poisoned
+    size_t down_info = 0;                               // offset in h_down of the factorisation's report words (update_health)
     UpdateWs ws;
     // pinned host arenas
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
@@ -388,12 +389,24 @@ static lvk_status end_defer(lvk_ekf* e)
     e->deferred.clear();
     return st;
 }
+// The factorisation of S = H P H^T + sigma^2 I reports into device-mapped words (be_linalg.hip): a non-positive pivot means the
+// covariance has lost positive definiteness - the reference's pivoted LDLT (larvio.cpp:1456) would go on with an indefinite S and
+// produce a state nobody should fly on; here the update fails and the failure is sticky (ekf_process_guarded).  Called after a
+// stream sync that covers the update.
+static lvk_status update_health(lvk_ekf* e)
+{
+    int* w = (int*)(e->h_down + e->down_info);
+    if (w[0] == 0 && w[1] == 0) return LVK_OK;
+    const int piv = w[0], gave_up = w[1]; w[0] = 0; w[1] = 0;
+    if (gave_up) return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "measurement update: a solver workgroup waited for panel %d of the factorisation in vain", gave_up);
+    return lvk_set_error(e->ctx, LVK_ERR_NUMERIC, "measurement update: the innovation covariance is not positive definite (pivot %d of %ld rows) - the filter has diverged", piv - 1, e->counters[2]);
+}
 static lvk_status d2h_sync(lvk_ekf* e, void* dst, const void* src, size_t bytes)
 {
     if (bytes) EKF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->ctx->stream));
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
     if (e->shard.fn) { int* f = (int*)(e->h_down + e->down_flag); if (*f) { const int mask = *f; *f = 0; return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "sharded update: the block of a peer rank (mask 0x%x) arrived invalid - that rank failed before the exchange", mask); } }
-    return LVK_OK;
+    return update_health(e);
 }
 // P <- P[idx, idx] (ping-pong)
 static lvk_status cov_gather(lvk_ekf* e, const std::vector<int>& idx)
@@ -970,6 +983,7 @@ static lvk_status fetch_feature_results(lvk_ekf* e, std::vector<RowJob>& jobs, d
     const FeatResult* ho = (const FeatResult*)(e->h_down + e->down_feat);
     EKF_HIP(hipStreamSynchronize(e->ctx->stream));
     { lvk_status ps = shard_peer_check(e); if (ps != LVK_OK) return ps; }
+    { lvk_status hs = update_health(e); if (hs != LVK_OK) return hs; }
     for (size_t i = 0; i < jobs.size(); ++i) jobs[i].res = ho[i];
     if (n_dx) memcpy(dx, e->h_down + e->down_dx, sizeof(double) * n_dx);      // written by the W^T[W|w] launch of the update
     return LVK_OK;
@@ -1827,7 +1841,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
         g_tr = EkfTrace();
     }
     void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
-                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_Hb, e->d_rb, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->ws.info, e->zero_copy ? nullptr : (void*)e->d_up};
+                    e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_Hb, e->d_rb, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->zero_copy ? nullptr : (void*)e->d_up};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_up) hipHostFree(e->h_up);
     if (e->h_down) hipHostFree(e->h_down);
@@ -1892,12 +1906,13 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
               dalloc(&e->d_cams, c.sw_size + 4) && dalloc(&e->d_clones, c.sw_size + 4) && dalloc(&e->d_staging, e->staging_cap) && dalloc(&e->d_ccols, e->ccols_cap) &&
               dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_Hb, hrows * e->ld) && dalloc(&e->d_rb, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
     e->ws.ldb = ((e->ld + 8 + 7) & ~7) | 8; e->ws.lds = e->rows_cap + 8;      // odd multiples of 64 B: power-of-two row strides pile onto one L2 channel
-    ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds) && dalloc(&e->ws.info, 16);
+    ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds);
     e->up_cap = (size_t)32 << 20;
     e->down_feat = (sizeof(TriResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_dx = (e->down_feat + sizeof(FeatResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_flag = (e->down_dx + sizeof(double) * (size_t)(e->ld + 64) + 255) & ~(size_t)255;
-    e->down_cap = e->down_flag + 256;
+    e->down_info = e->down_flag + 256;                  // [0] first non-positive Cholesky pivot (+1), [1] a solver workgroup gave up waiting: written by k_chol_fused / k_chol_left
+    e->down_cap = e->down_info + 256;
     ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
     if (ok) {
         // both arenas are read / written by the kernels in place (device-mapped pinned memory): a few KB per update over PCIe
@@ -1907,6 +1922,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
         void* dd = nullptr;
         ok = ok && hipHostGetDevicePointer(&dd, e->h_down, 0) == hipSuccess && dd; e->dh_down = (char*)dd;
         e->d_triout = (TriResult*)e->dh_down;
+        e->ws.info = (int*)(e->dh_down + e->down_info); memset(e->h_down + e->down_info, 0, 256);
         if (const char* v = getenv("LVK_ROWS_DIRECT")) e->rows_direct = atoi(v) != 0;
     }
     if (!ok) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_ekf_create: allocation failed"); }

@@ -63,14 +63,73 @@ __global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double
     }
 }
 
+// Split-K form: the four wavefronts of a workgroup share ONE 16x16 tile and take every fourth K-chunk (kc <= 64 consecutive k, a
+// multiple of 16) each, so a tile of the update's products (K = N ~ 216 or K = m ~ 110..260) costs ONE load round trip per
+// wavefront instead of four dependent ones; the partial tiles meet in LDS and wavefront 0 adds them in a fixed order (chunk 0, 1,
+// 2, 3: reproducible).  Same lane <-> k permutation inside a chunk as k_dgemm.
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) k_dgemm_sk(int M, int N, int K, int kc, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                                 double* __restrict__ C, int ldc, double alpha, double beta, double diag_add, GemmRider rd)
+{
+    __shared__ double red[3][4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
+    if (wave == 0 && rd.xin && col0 == 0 && lane < 16 && row0 + lane < M) C[(size_t)(row0 + lane) * ldc + rd.xin_col] = rd.xin[row0 + lane];
+    const int i = lane & 15, kk = lane >> 4;
+    const int ar = row0 + i, bc = col0 + i;
+    const bool a_ok = ar < M, b_ok = bc < N;
+    d4 acc = {0., 0., 0., 0.};
+    // the current value of C (beta != 0: P -= W^T W, S22 -= L21 L21^T) is requested up front, in the shadow of the operand loads
+    double cin[4] = {0., 0., 0., 0.};
+    if (wave == 0 && beta != 0.) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = row0 + kk + 4 * r, col = col0 + i; if (row < M && col < N) cin[r] = C[(size_t)row * ldc + col]; }
+    }
+    for (int k0 = wave * kc; k0 < K; k0 += 4 * kc) {
+        double a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 16 * (u >> 2) + 4 * kk + (u & 3);
+            const bool k_ok = 16 * (u >> 2) < kc && k < K;
+            a[u] = (a_ok && k_ok) ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
+            b[u] = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (16 * (u >> 2) < kc && k0 + 16 * (u >> 2) < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (wave) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double sum = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+        const int row = row0 + kk + 4 * r, col = col0 + i;
+        if (row < M && col < N) {
+            if (rd.xout && col == rd.xout_col) { rd.xout[row] = sum; if (rd.xout_host) rd.xout_host[row] = sum; continue; }
+            double v = alpha * sum;
+            if (beta != 0.) v += beta * cin[r];
+            if (row == col) v += diag_add;
+            C[(size_t)row * ldc + col] = v;
+        }
+    }
+}
+
 template <bool TA, bool TB>
 static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc,
                          double alpha, double beta, double diag_add, GemmRider rd = GemmRider{nullptr, 0, nullptr, 0, nullptr})
 {
     if (M <= 0 || N <= 0) return;
+#ifdef LVK_AB_DGEMM_TILE_PER_WAVE     // A/B builds only: one tile per wavefront, K walked in dependent 64-wide phases
     dim3 grid((N + 31) / 32, (M + 31) / 32);
-    // (128-wide K chunks - 64 loads in flight per lane - were measured at N ~ 430: 19.5 / 21.9 us against 19.9 / 19.4 us: no gain)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB, 16>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
+#else
+    const int kc = K >= 193 ? 64 : 16 * ((K + 63) / 64);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm_sk<TA, TB>), dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, M, N, K, kc, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
+#endif
 }
 
 
@@ -251,84 +310,66 @@ extern "C" void lvk_debug_chol_ticks(unsigned long long* out) { hipDeviceSynchro
 #else
 #define CH_TICK(k) do { } while (0)
 #endif
-// One wavefront: Cholesky factor L of the 32x32 block in Ld (in place, lower, upper part zeroed) and Yi = L^-1.
-// Done as two 16x16 halves so that the fully unrolled register code (lane i = row i, columns broadcast with v_readlane) stays a
-// few KB - the 32-wide version was ~30 KB of straight-line code and ran at instruction-fetch speed - and is executed twice from a
-// loop; the off-diagonal blocks go through the FP64 matrix cores:
-//   L21 = A21 Y11^T ;  A22 -= L21 L21^T ;  Y21 = -Y22 (L21 Y11)
-#define CH_H 16
-__device__ __forceinline__ void chol32_inv_wave(double (*Ld)[CP_NB + 1], double (*Yi)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
+// One wavefront: Y = L^-1 for the Cholesky factor L of the 32x32 block in D (full symmetric block; identity padding beyond nb).
+// Nothing downstream reads L_pp itself (the solves are products with L_pp^-1), so only Y is produced.
+// The block lives in three FP64-MFMA accumulator tiles (lane (g = lane >> 4, c = lane & 15), register r <-> T[g + 4 r][c]):
+// a00 = D[0:16, 0:16], a01 = D[0:16, 16:32] (read from the lower triangle), a11 = D[16:32, 16:32].  Row j of a tile sits in the 16
+// lanes of group j & 3, register j >> 2 - which is exactly where v_mfma_f64_16x16x4_f64 wants K-slot j & 3 of BOTH operands - and
+// the block is symmetric, so row j IS column j: one pivot step is
+//     piv = D[j][j] (one v_readlane pair) ; rinv = rsq(piv) refined ; v = row j * rinv masked to its group and to c >= j ;
+//     a00 -= v (x) v ; a01 -= v (x) u          (rank-1 updates as MFMAs whose other three K-slots are zero)
+// with no per-element broadcasts at all (the register version spent 2 v_readlane + 1 FMA per (j, k) pair: ~6 us per block, this
+// is ~2.7).  The columns' lower halves u_j (rows 16..31) of four consecutive pivots fill the four K-slots of one operand register,
+// so a11 gets a rank-4 update per 4 pivots and L10 Y00 needs no data movement either.  The inverse runs in the MFMA shadow of
+// the factorisation: step j scales row j of Y by rinv and subtracts L[i][j] (i > j) times it from the rows below - the same
+// operand registers again.  Y10 = -Y11 (L10 Y00) closes the block (one LDS round trip for the transposed operand).
+__device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (*Y)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
 {
-    const int i16 = lane & 15, kk = lane >> 4;
-#pragma nounroll
-    for (int hb = 0; hb < 2; ++hb) {
-        const int base = CH_H * hb;
-        // ---- 16x16 factor + inverse in registers (the four 16-lane groups work redundantly; group 0 stores)
-        double a[CH_H], rd[CH_H], y[CH_H];
-#pragma unroll
-        for (int c = 0; c < CH_H; ++c) a[c] = Ld[base + i16][base + c];
-#pragma unroll
-        for (int j = 0; j < CH_H; ++j) {
-            double piv = readlane_f64(a[j], j);
-            if (!(piv > 0.)) { if (report && lane == 0 && base + j < nb && info[0] == 0) info[0] = j0 + base + j + 1; piv = 1.0; }
-            const double rinv = rsqrt_refined(piv);
-            rd[j] = rinv;
-            const double l = (i16 == j) ? piv * rinv : a[j] * rinv;     // L[i][j]; the diagonal is sqrt(piv)
-            a[j] = l;
-#pragma unroll
-            for (int k = j + 1; k < CH_H; ++k) { const double lk = readlane_f64(l, k); a[k] = __builtin_fma(-l, lk, a[k]); }
-        }
-        // column-oriented substitution for Y = L^-1 (lane = column): the updates of a step are independent
-#pragma unroll
-        for (int i = 0; i < CH_H; ++i) y[i] = (i16 == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < CH_H; ++k) {
-            y[k] *= rd[k];
-#pragma unroll
-            for (int i = k + 1; i < CH_H; ++i) y[i] = __builtin_fma(-readlane_f64(a[k], i), y[k], y[i]);
-        }
-        if (lane < CH_H) {
-#pragma unroll
-            for (int c = 0; c < CH_H; ++c) Ld[base + lane][base + c] = (c <= lane) ? a[c] : 0.0;
-#pragma unroll
-            for (int i = 0; i < CH_H; ++i) Yi[base + i][base + lane] = (i >= lane) ? y[i] : 0.0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (hb == 0) {
-            // L21 = A21 Y11^T  (A[i][k] = A21[i][k], B[k][j] = Y11[j][k])
-            d4 acc = {0., 0., 0., 0.};
-#pragma unroll
-            for (int k0 = 0; k0 < CH_H; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ld[CH_H + i16][k0 + kk], Yi[i16][k0 + kk], acc, 0, 0, 0);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ld[CH_H + kk + 4 * r][i16] = acc[r];
-            __builtin_amdgcn_wave_barrier();
-            // A22 -= L21 L21^T
-            d4 sy = {0., 0., 0., 0.};
-#pragma unroll
-            for (int k0 = 0; k0 < CH_H; k0 += 4) { const double v = Ld[CH_H + i16][k0 + kk]; sy = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, sy, 0, 0, 0); }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ld[CH_H + kk + 4 * r][CH_H + i16] -= sy[r];
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    // Y21 = -Y22 (L21 Y11); the upper-right blocks are zero
-    d4 tt = {0., 0., 0., 0.};
-#pragma unroll
-    for (int k0 = 0; k0 < CH_H; k0 += 4) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(Ld[CH_H + i16][k0 + kk], Yi[k0 + kk][i16], tt, 0, 0, 0);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Yi[CH_H + kk + 4 * r][i16] = tt[r];
-    __builtin_amdgcn_wave_barrier();
-    d4 yy = {0., 0., 0., 0.};
-#pragma unroll
-    for (int k0 = 0; k0 < CH_H; k0 += 4) yy = __builtin_amdgcn_mfma_f64_16x16x4f64(Yi[CH_H + i16][CH_H + k0 + kk], Yi[CH_H + k0 + kk][i16], yy, 0, 0, 0);
-    __builtin_amdgcn_wave_barrier();
+    const int c = lane & 15, g = lane >> 4;
+    d4 a00, a01, a11, y00, y11, lop;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        Yi[CH_H + kk + 4 * r][i16] = -yy[r];
-        Yi[kk + 4 * r][CH_H + i16] = 0.; Ld[kk + 4 * r][CH_H + i16] = 0.;
+        a00[r] = D[g + 4 * r][c];
+        a01[r] = D[16 + c][g + 4 * r];
+        a11[r] = D[16 + g + 4 * r][16 + c];
+        y00[r] = (g + 4 * r == c) ? 1.0 : 0.0; y11[r] = y00[r]; lop[r] = 0.;
     }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = j >> 2, gj = j & 3;
+            d4& aa = half ? a11 : a00; d4& yy = half ? y11 : y00;
+            double piv = readlane_f64(aa[q], 16 * gj + j);
+            if (!(piv > 0.)) { if (report && lane == 0 && 16 * half + j < nb && info[0] == 0) info[0] = j0 + 16 * half + j + 1; piv = 1.0; }
+            const double rinv = rsqrt_refined(piv);
+            const bool rs = g == gj;
+            const double v = (rs && c >= j) ? aa[q] * rinv : 0.0;                 // L[c][j] (the diagonal is piv * rinv = sqrt(piv))
+            aa = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, aa, 0, 0, 0);
+            if (!half) {
+                const double u = rs ? a01[q] * rinv : 0.0;                        // L[16 + c][j]
+                a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, u, a01, 0, 0, 0);
+                lop[q] = rs ? u : lop[q];
+            }
+            yy[q] = rs ? yy[q] * rinv : yy[q];
+            const double vm = (c > j) ? v : 0.0, yb = rs ? yy[q] : 0.0;
+            yy = __builtin_amdgcn_mfma_f64_16x16x4f64(-vm, yb, yy, 0, 0, 0);
+            if (!half && gj == 3) a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-lop[q], lop[q], a11, 0, 0, 0);
+        }
+    }
+    // T = L10 Y00 (operands are lop and y00 as they stand), then Y10 = -Y11 T with Y11 read back transposed from LDS
+    d4 tt = {0., 0., 0., 0.};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[q], y00[q], tt, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Y[g + 4 * r][c] = y00[r]; Y[16 + g + 4 * r][16 + c] = y11[r]; Y[g + 4 * r][16 + c] = 0.; }
+    __builtin_amdgcn_wave_barrier();
+    d4 yl = {0., 0., 0., 0.};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yl = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[16 + c][16 + 4 * q + g], tt[q], yl, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y[16 + g + 4 * r][c] = -yl[r];
+    __builtin_amdgcn_wave_barrier();
 }
 
 #define CL_KC 128
@@ -341,7 +382,6 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
     const int nb = min(CP_NB, m - j0);
     const bool s_role = (int)blockIdx.x < n_sblocks;
-    if (j0 == 0 && blockIdx.x == 0 && t == 0) info[0] = 0;          // the reporter below is this same thread
     CH_TICK(0);
     // ---- own piece, brought up to date with panels 0..p-1 (kept in the accumulators)
     d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
@@ -452,7 +492,7 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
     }
     __syncthreads();
     CH_TICK(2);
-    if (wave == 0) chol32_inv_wave(Ld, Yi, nb, lane, info, j0, blockIdx.x == 0);
+    if (wave == 0) chol32_inv_mfma(Ld, Yi, nb, lane, info, j0, blockIdx.x == 0);
     CH_TICK(5);
     __syncthreads();
     CH_TICK(6);
@@ -495,17 +535,21 @@ __global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int l
 }
 
 // ------------------------------------------------------------------------- fused Cholesky + solve, m <= 160: ONE launch
-// The per-panel launches above spend ~19 us per 32 columns, of which only ~8 us is the dependent pivot chain of the diagonal block;
+// The per-panel launches above spend ~19 us per 32 columns, of which only a few us are the dependent pivot chain of the diagonal block;
 // the rest is launch latency, first-touch trips to the memory side and the left-looking re-read of S.  Here workgroup 0 keeps the whole
-// lower triangle of S in LDS (32x32 blocks) and factors it right-looking: wavefront 0 factors + inverts diagonal block p+1 while the
-// other three wavefronts finish the trailing update of panel p.  After every panel it publishes L[:, p] and L_pp^-1 to global memory and
-// raises a flag (agent-scope release); workgroups 1.. own 16 columns of B = [HP | r] per wavefront, keep their W rows in LDS, and
-// trail the factorisation by one panel: B_p -= L[p, 0:p] W[0:p] while the diagonal block is still being factored, then
-// W_p = L_pp^-1 B_p as soon as the flag arrives.  Workgroup 0 is dispatched first (workgroups of a grid are dispatched in order) and
-// never waits for anybody, so the spinning solvers cannot starve it.
+// lower triangle of S in LDS (32x32 blocks) and factors it right-looking with the critical path first:
+//   C1  wavefront 0 factors + inverts diagonal block p (chol32_inv_mfma) while wavefronts 1..3 finish panel p-1 off the critical
+//       path: publish L[:, p-1] and L_pp^-1 to global memory and raise the flag (ONE wavefront pays the agent-scope release - the
+//       L2 write-back used to sit on every panel of the chain), and the trailing update of everything right of block column p;
+//   C2  all four: L[p+1.., p] = A Y^T ;   C3  all four: diagonal block p+1 -= L[p+1, p] L[p+1, p]^T ;  then C1 of panel p+1.
+// Workgroups 1.. own 16 columns of B = [HP | r] per wavefront, keep their W rows in LDS, and trail the factorisation by one
+// panel: B_p -= L[p, 0:p] W[0:p] while the diagonal block is still being factored, then W_p = L_pp^-1 B_p as soon as the flag
+// arrives.  Workgroup 0 never waits for anybody, so the spinning solvers cannot starve it; their spin is bounded all the same
+// (CF_SPIN_MAX polls: a factor workgroup that never shows up - a broken device - ends the launch with info[1] set instead of hanging it).
 #define CF_MAXB 5                                   // m <= 160
 #define CF_LD (CP_NB + 1)
 #define CF_WLD 17
+#define CF_SPIN_MAX (1 << 21)
 typedef double cf_blk[CP_NB][CF_LD];
 __device__ __forceinline__ int cf_idx(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
 // C[tile tr,tc of block Cb] -= A[rows of tile tr] . Bm[rows of tile tc]^T over K = 32
@@ -517,10 +561,56 @@ __device__ __forceinline__ void cf_tile_sub(cf_blk& Cb, const cf_blk& A, const c
 #pragma unroll
     for (int r = 0; r < 4; ++r) Cb[16 * tr + kk + 4 * r][16 * tc + i16] -= acc[r];
 }
-__device__ __forceinline__ void cf_wait(const int* flag, int target, int lane)
+__device__ __forceinline__ bool cf_wait(const int* flag, int target, int lane, int* __restrict__ info)
 {
-    if (lane == 0) while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    int ok = 1;
+    if (lane == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > CF_SPIN_MAX) { ok = 0; info[1] = target; break; }
+        }
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok != 0;
+}
+// what wavefronts 1..3 of the factor workgroup do for panel p while wavefront 0 factors diagonal block p+1 (or after the last panel)
+__device__ __forceinline__ void cf_deferred(cf_blk* Sb, cf_blk& Yp, int p, int nblk, int m, double* __restrict__ S, int lds_, double* __restrict__ Yg,
+                                            int* __restrict__ flag, int base, int wave, int lane)
+{
+    const int i16 = lane & 15, kk = lane >> 4;
+    if (wave == 3) {
+        // publish Y_pp = L_pp^-1 and the blocks of L below the diagonal (the diagonal blocks of L are not stored: nothing reads them)
+        double* yg = Yg + (size_t)p * CP_NB * CP_NB;
+        for (int e = lane; e < CP_NB * CP_NB / 4; e += 64) {
+            const int a = e >> 3, b4 = (e & 7) * 4;
+            d4 v; v[0] = Yp[a][b4]; v[1] = Yp[a][b4 + 1]; v[2] = Yp[a][b4 + 2]; v[3] = Yp[a][b4 + 3];
+            *(d4*)(yg + a * CP_NB + b4) = v;
+        }
+        for (int bi = p + 1; bi < nblk; ++bi) {
+            const cf_blk& A = Sb[cf_idx(bi, p)];
+            for (int e = lane; e < CP_NB * CP_NB / 4; e += 64) {
+                const int a = e >> 3, b4 = (e & 7) * 4, gr = 32 * bi + a;
+                d4 v; v[0] = A[a][b4]; v[1] = A[a][b4 + 1]; v[2] = A[a][b4 + 2]; v[3] = A[a][b4 + 3];
+                if (gr < m) *(d4*)(S + (size_t)gr * lds_ + 32 * p + b4) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(flag, base + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // trailing update with panel p of everything right of block column p+1 and below block row p+1 (block column p+1 itself included;
+    // diagonal block p+1 was done on the critical path).  Of a diagonal block only the tiles chol32_inv_mfma reads: (0,0) (1,0) (1,1).
+    // Wavefront 3 (busy publishing first) takes one tile in five.
+    int u = 0;
+    for (int bi = p + 2; bi < nblk; ++bi)
+        for (int bj = p + 1; bj <= bi; ++bj)
+            for (int tt = 0; tt < 4; ++tt) {
+                if (bi == bj && tt == 1) continue;
+                const int owner = (u % 5 == 4) ? 3 : 1 + ((u % 5) >> 1);
+                ++u;
+                if (owner == wave) cf_tile_sub(Sb[cf_idx(bi, bj)], Sb[cf_idx(bi, p)], Sb[cf_idx(bj, p)], tt >> 1, tt & 1, i16, kk);
+            }
 }
 
 // A second right-hand side (B2: m x nbcols2, own leading dimension) gets its own solver workgroups behind those of B: the caller
@@ -538,8 +628,7 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
     if (blockIdx.x == 0) {
         // ===================================================================== factor role
         cf_blk* Sb = (cf_blk*)cf_smem;                                   // lower blocks, cf_idx(bi, bj)
-        cf_blk& Yi = *(cf_blk*)(cf_smem + (size_t)(CF_MAXB * (CF_MAXB + 1) / 2) * CP_NB * CF_LD);
-        if (t == 0 && row0 == 0) info[0] = 0;
+        cf_blk* Yb = (cf_blk*)(cf_smem + (size_t)(CF_MAXB * (CF_MAXB + 1) / 2) * CP_NB * CF_LD);    // two: panel p's inverse is published while p+1's is being built
         {   // whole lower triangle: one 32-byte load per thread and block, all in flight
             const int row = t >> 3, c4 = (t & 7) * 4;
             d4 v[CF_MAXB * (CF_MAXB + 1) / 2];
@@ -565,26 +654,12 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
         }
         __syncthreads();
         for (int p = 0; p < nblk; ++p) {
-            cf_blk& D = Sb[cf_idx(p, p)];
-            const int nb = min(CP_NB, m - 32 * p);
-            if (wave == 0) chol32_inv_wave(D, Yi, nb, lane, info, row0 + 32 * p, true);
-            else if (p > 0) {
-                // the rest of panel p-1's trailing update (block columns p+1..), in the shadow of the factorisation
-                int u = 0;
-                for (int bi = p + 1; bi < nblk; ++bi)
-                    for (int bj = p + 1; bj <= bi; ++bj)
-                        for (int tt = 0; tt < 4; ++tt, ++u)
-                            if (u % 3 == wave - 1) cf_tile_sub(Sb[cf_idx(bi, bj)], Sb[cf_idx(bi, p - 1)], Sb[cf_idx(bj, p - 1)], tt >> 1, tt & 1, i16, kk);
-            }
+            cf_blk& Yi = Yb[p & 1];
+            // ---- C1
+            if (wave == 0) chol32_inv_mfma(Sb[cf_idx(p, p)], Yi, min(CP_NB, m - 32 * p), lane, info, row0 + 32 * p, true);
+            else if (p > 0) cf_deferred(Sb, Yb[(p - 1) & 1], p - 1, nblk, m, S, lds_, Yg, flag, base, wave, lane);
             __syncthreads();
-            {   // publish Y_pp = L_pp^-1 (the diagonal blocks of L themselves are not stored: nothing reads them)
-                double* yg = Yg + (size_t)p * CP_NB * CP_NB;
-                for (int e = t; e < CP_NB * CP_NB; e += 256) {
-                    const int a = e >> 5, b = e & 31;
-                    yg[e] = Yi[a][b];
-                }
-            }
-            // L21: X = A Y^T for the blocks below the diagonal, 16 rows x 32 columns per unit
+            // ---- C2: X = A Y^T for the blocks below the diagonal, 16 rows x 32 columns per unit (block p+1's two units first)
             for (int u = wave; u < 2 * (nblk - p - 1); u += 4) {
                 const int bi = p + 1 + (u >> 1), tr = u & 1;
                 cf_blk& A = Sb[cf_idx(bi, p)];
@@ -597,24 +672,16 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lr = 16 * tr + kk + 4 * r, gr = 32 * bi + lr;
-                    A[lr][i16] = o0[r]; A[lr][16 + i16] = o1[r];
-                    if (gr < m) { S[(size_t)gr * lds_ + 32 * p + i16] = o0[r]; S[(size_t)gr * lds_ + 32 * p + 16 + i16] = o1[r]; }
-                }
+                for (int r = 0; r < 4; ++r) { const int lr = 16 * tr + kk + 4 * r; A[lr][i16] = o0[r]; A[lr][16 + i16] = o1[r]; }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (t == 0) __hip_atomic_store(flag, base + p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            // block column p+1 brought up to date with panel p (the next diagonal block and everything below it)
             if (p + 1 < nblk) {
-                for (int u = wave; u < 4 * (nblk - p - 1); u += 4) {
-                    const int bi = p + 1 + (u >> 2), tt = u & 3;
-                    cf_tile_sub(Sb[cf_idx(bi, p + 1)], Sb[cf_idx(bi, p)], Sb[cf_idx(p + 1, p)], tt >> 1, tt & 1, i16, kk);
-                }
+                __syncthreads();
+                // ---- C3: the next diagonal block, one tile per wavefront ((0,1) is never read)
+                if (wave != 1) cf_tile_sub(Sb[cf_idx(p + 1, p + 1)], Sb[cf_idx(p + 1, p)], Sb[cf_idx(p + 1, p)], wave >> 1, wave & 1, i16, kk);
+                __syncthreads();
             }
-            __syncthreads();
         }
+        if (wave != 0) cf_deferred(Sb, Yb[(nblk - 1) & 1], nblk - 1, nblk, m, S, lds_, Yg, flag, base, wave, lane);
         return;
     }
     // ========================================================================= solver role: 16 columns of B per wavefront
@@ -662,7 +729,7 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { Cs[kk + 4 * r][i16] = own[p][0][r] - c0[r]; Cs[16 + kk + 4 * r][i16] = own[p][1][r] - c1[r]; }
-        cf_wait(flag, base + p + 1, lane);
+        if (!cf_wait(flag, base + p + 1, lane, info)) return;
         const double* yg = Yg + (size_t)p * CP_NB * CP_NB;
         d4 y0[2], y1[2];
 #pragma unroll
@@ -707,7 +774,7 @@ static lvk_status launch_chol_solve(lvk_context* ctx, double* S, int lds_, int m
         if (!ws) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
         int* flag = (int*)(ws + ybytes);
         if (fresh || ctx->chol_epoch > (1 << 27)) { LVK_HIP(ctx, hipMemsetAsync(flag, 0, 64, s)); ctx->chol_epoch = 0; }
-        const size_t lds_f = sizeof(double) * (size_t)(CF_MAXB * (CF_MAXB + 1) / 2 + 1) * CP_NB * CF_LD;
+        const size_t lds_f = sizeof(double) * (size_t)(CF_MAXB * (CF_MAXB + 1) / 2 + 2) * CP_NB * CF_LD;
         const size_t lds_s = sizeof(double) * (size_t)4 * (CF_MAXB * CP_NB + CP_NB) * CF_WLD;
         const size_t shm = lds_f > lds_s ? lds_f : lds_s;
         // Residency: 1 + ceil(nbcols / 64) (+ ceil(rest / 64)) workgroups (<= 12 at the largest state the filter accepts), one per CU
@@ -811,7 +878,17 @@ extern "C" lvk_status lvk_ekf_update(lvk_context* ctx, double* d_P, int ldp, int
     ws.S = (double*)lvk_ctx_scratch(ctx, 5, sizeof(double) * (size_t)(m > 0 ? m : 1) * (ws.lds > 0 ? ws.lds : 8));
     ws.info = (int*)lvk_ctx_scratch(ctx, 6, 64);
     if (!ws.B || !ws.S || !ws.info) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
-    return lvk_update_core(ctx, d_P, ldp, n, d_H, ldh, m, d_r, sigma2, d_dx, ws);
+    LVK_HIP(ctx, hipMemsetAsync(ws.info, 0, 64, ctx->stream));
+    lvk_status st = lvk_update_core(ctx, d_P, ldp, n, d_H, ldh, m, d_r, sigma2, d_dx, ws);
+    if (st != LVK_OK) return st;
+    // the stage-level call reports the factorisation's health itself (the frame-level filter reads the same words from mapped memory
+    // at the sync it needs anyway): this entry point waits for its update
+    int info[2] = {0, 0};
+    LVK_HIP(ctx, hipMemcpyAsync(info, ws.info, sizeof info, hipMemcpyDeviceToHost, ctx->stream));
+    LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (info[1]) return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_ekf_update: a solver workgroup waited for panel %d of the factorisation in vain", info[1]);
+    if (info[0]) return lvk_set_error(ctx, LVK_ERR_NUMERIC, "lvk_ekf_update: H P H^T + sigma2 I is not positive definite (pivot %d)", info[0] - 1);
+    return LVK_OK;
 }
 
 extern "C" lvk_status lvk_dgemm(lvk_context* ctx, int transa, int transb, int M, int N, int K, double alpha, const double* d_A, int lda,

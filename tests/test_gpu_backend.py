@@ -12,7 +12,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("shape", [(232, 262, 232), (17, 5, 33), (64, 64, 64), (300, 1, 7)])
+@pytest.mark.parametrize("shape", [(232, 262, 232), (17, 5, 33), (64, 64, 64), (300, 1, 7), (216, 217, 110), (160, 160, 216), (440, 434, 433), (33, 47, 192), (33, 47, 193), (20, 20, 257)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
 def test_dgemm_mfma_f64(gpu_ctx, shape, ta, tb):
     from larvio_amd import larvio as lv
@@ -47,6 +47,26 @@ def test_ekf_update_matches_oracle(gpu_ctx, N, m):
     assert _rel(P_g, P_o) < 1e-10
     assert np.array_equal(P_g, P_g.T)                              # P - W^T W is symmetric by construction
     assert np.linalg.eigvalsh(P_g).min() > -1e-12
+
+
+@pytest.mark.parametrize("N,m,bad", [(120, 40, 7), (232, 150, 149), (232, 200, 170), (232, 330, 5)])
+def test_ekf_update_reports_a_non_positive_definite_innovation(gpu_ctx, N, m, bad):
+    """k_chol_fused writes the first non-positive pivot into its report words; the stage-level call returns LVK_ERR_NUMERIC (5)
+    instead of factoring on with pivot := 1 (what nobody used to read), and the same context goes on working afterwards.
+    The indefinite S comes from an indefinite P: one direction with a large negative variance, seen by measurement row `bad`."""
+    from larvio_amd import larvio as lv
+    from larvio_amd._lib import LvkError
+    P, H, r = _update_problem(N + m, N, m)
+    H[:, 30] = 0.0; H[bad, :] = 0.0; H[bad, 30] = 1.0       # only row `bad` sees direction 30, and it sees nothing else
+    P[30, :] = 0.0; P[:, 30] = 0.0; P[30, 30] = -1.0
+    with pytest.raises(LvkError) as ei:
+        lv.ekf_update(gpu_ctx, P, H, r, 0.008 ** 2)
+    assert "not positive definite" in str(ei.value), str(ei.value)
+    # rows before `bad` do not see the negative direction: the reported pivot is exactly that row
+    assert f"pivot {bad})" in str(ei.value), str(ei.value)
+    P2, H2, r2 = _update_problem(1, N, m)
+    dx, Pn = lv.ekf_update(gpu_ctx, P2, H2, r2, 0.008 ** 2)
+    assert np.isfinite(dx).all() and np.isfinite(Pn).all()
 
 
 @pytest.mark.parametrize("rows,cols", [(300, 202), (700, 202), (2500, 82), (18000, 120), (150, 202), (3000, 442), (3536, 452), (9000, 300), (1500, 500),
