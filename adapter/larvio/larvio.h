@@ -54,6 +54,7 @@ class LarVio {
     lvk_ekf* ekf;
     std::FILE *f_state, *f_takeoff;
     bool takeoff_written;
+    bool failed; double good_state[30];                   // a (deferred) update failed: the filter is unusable, getters answer from the last good state
     bool blocking, pending;                               // LVK_ADAPTER_BLOCKING=1: processFeatures runs the update before it returns
     std::map<FeatureIDType, Eigen::Vector3d> active_slam_features;   // refreshed after every update (larvio.cpp:455-458), cleared on read
 };

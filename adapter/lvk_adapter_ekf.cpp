@@ -18,8 +18,10 @@ namespace larvio {
 // a driver that calls getTbw() right after processFeatures (app/larvioMain.cpp:139) simply waits there instead.
 // LVK_ADAPTER_BLOCKING=1 restores the blocking call.
 LarVio::LarVio(std::string& config_file_) : config_file(config_file_), cfg(), ctx(nullptr), ekf(nullptr), f_state(nullptr), f_takeoff(nullptr), takeoff_written(false),
-                                            blocking(false), pending(false)
+                                            failed(false), good_state(), blocking(false), pending(false)
 {
+    good_state[4] = 1.0;                                                              // identity quaternion (x y z w at [1..4]) until the first update
+    good_state[17] = good_state[21] = good_state[25] = 1.0;
     const char* b = std::getenv("LVK_ADAPTER_BLOCKING");
     blocking = b && std::atoi(b) != 0;
 }
@@ -49,13 +51,13 @@ void LarVio::reset()
 {
     finish();
     if (ekf) { lvk_ekf_destroy(ekf); ekf = nullptr; }
-    active_slam_features.clear(); takeoff_written = false;
+    active_slam_features.clear(); takeoff_written = false; failed = false;
     initialize();
 }
 
 bool LarVio::processFeatures(MonoCameraMeasurementPtr msg, std::vector<ImuData>& imu_msg_buffer)
 {
-    if (!ekf || !msg) return false;
+    if (!ekf || !msg || failed) return false;                                        // a failed filter stays failed (the library says so too): the driver sees `false` from now on
     std::vector<lvk_imu> conv;
     const lvk_imu* imu = nullptr;
     if (!imu_msg_buffer.empty()) {
@@ -92,7 +94,12 @@ void LarVio::finish()
     if (!pending || !ekf) return;
     pending = false;
     int upd = 0;
-    if (lvk_ekf_wait(ekf, &upd) != LVK_OK) { std::printf("LarVio::processFeatures (deferred): %s\n", lvk_last_error(ctx)); return; }
+    if (lvk_ekf_wait(ekf, &upd) != LVK_OK) {
+        // the frame's processFeatures already answered `true`; what can still be done: nothing of the failed update is published or
+        // logged, the getters keep answering from the last good state, and every later processFeatures returns false
+        std::printf("LarVio::processFeatures (deferred): %s\n", lvk_last_error(ctx)); failed = true; return;
+    }
+    lvk_ekf_get_state(ekf, good_state);
     writeLogs();                                                                      // :388, :446-453
     // active_slam_features (:455-458): the in-state features after this update
     std::vector<int64_t> ids(4096); std::vector<double> idp(4096), pos(3 * 4096);
@@ -114,7 +121,7 @@ static Eigen::Matrix3d quat_to_rot(const double* q /* x y z w */)
 Eigen::Isometry3d LarVio::getTbw()
 {
     finish();
-    double s[30]; lvk_ekf_get_state(ekf, s);
+    double s[30]; if (failed || lvk_ekf_get_state(ekf, s) != LVK_OK) std::memcpy(s, good_state, sizeof s);
     Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
     T.linear() = quat_to_rot(s + 1);
     T.translation() = Eigen::Vector3d(s[8], s[9], s[10]);
@@ -124,7 +131,7 @@ Eigen::Isometry3d LarVio::getTbw()
 Eigen::Vector3d LarVio::getVel()
 {
     finish();
-    double s[30]; lvk_ekf_get_state(ekf, s);
+    double s[30]; if (failed || lvk_ekf_get_state(ekf, s) != LVK_OK) std::memcpy(s, good_state, sizeof s);
     return Eigen::Vector3d(s[5], s[6], s[7]);
 }
 

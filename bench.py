@@ -234,6 +234,13 @@ def timed(run, frames, d_frames, W, K, dist, torch):
     # tens of milliseconds - the warm-up is there to undo exactly that) and keep the collector off until the timed region has ended.
     gc.collect()
     gc.disable()
+    try:
+        return _timed_body(run, feed, W, K, dist, torch)
+    finally:
+        gc.enable()
+
+
+def _timed_body(run, feed, W, K, dist, torch):
     for _ in range(W):
         feed()
     run.drain()
@@ -257,7 +264,6 @@ def timed(run, frames, d_frames, W, K, dist, torch):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t_begin
-    gc.enable()
     if dist is not None:
         elapsed = max_over_ranks(dist, torch, elapsed)
     prof = run.fe.profile_read()
@@ -270,6 +276,7 @@ def timed(run, frames, d_frames, W, K, dist, torch):
     if not run.sequential:
         out["pst"] = run.drv.stats()
         out["early"] = run.drv.early_counts()
+        out["n_msgs_total"] = run.drv.drain()[1]         # messages since the pipeline was created (the early counts are since then too)
         e2e = lat.copy() * 1e6                           # image-in -> state-out: front-end completion, or the end of the update it triggered
         pl = run.drv.latencies()
         idx = np.flatnonzero(msg_mask)
@@ -406,14 +413,16 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
         torch.cuda.synchronize()
         lat = np.empty(K)
         gc.collect(); gc.disable()
-        t_begin = time.perf_counter()
-        for k in range(K):
-            t0 = time.perf_counter(); one(i); i += 1; lat[k] = time.perf_counter() - t0
-        ctx.sync(); torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t_begin
-        gc.enable()
+        try:
+            t_begin = time.perf_counter()
+            for k in range(K):
+                t0 = time.perf_counter(); one(i); i += 1; lat[k] = time.perf_counter() - t0
+            ctx.sync(); torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            elapsed = time.perf_counter() - t_begin
+        finally:
+            gc.enable()
         if dist is not None:
             elapsed = max_over_ranks(dist, torch, elapsed)
         c1 = be.counters(); s1 = be.shard_stats()
@@ -574,6 +583,9 @@ def main():
     ap.add_argument("--no-device-pass", action="store_true", help="skip the second (device-resident) pass")
     ap.add_argument("--dump-latencies", action="store_true", help="per-step caller time of the timed region (us) and which steps published a message, on stderr")
     ap.add_argument("--no-adapter-pass", action="store_true", help="skip the passes through the adapter's schedule (deferred processFeatures under a blocking driver)")
+    ap.add_argument("--unaligned", action="store_true", help="camera stamps off the IMU grid (phase + jitter, jittered IMU stamps: larvio_amd.synthetic.unaligned_stamps): "
+                                                               "the pipelined driver's early erase count is then not always available")
+    ap.add_argument("--no-unaligned-pass", action="store_true", help="skip the extra pipelined pass on off-grid stamps appended to the default line")
     ap.add_argument("--sequential", action="store_true", help="one blocking lvk_vio_process per frame instead of the two-stream pipeline")
     ap.add_argument("--sharded", action="store_true", help="config 5 across ranks: per-rank feature rows, RCCL all-gather of the compressed R")
     ap.add_argument("--no-shard-probe", action="store_true", help="skip the configs[4]-depth (sharded) filter probe appended to the default line")
@@ -615,6 +627,9 @@ def main():
     seq = S.imu_only_sequence(S.MASTER_SEED + seed_off, cam=wl["cam"])
     k_lo = max(int(ts[0] * 200) - 4, 0)
     imu_all = seq.imu_array(k_lo, int(ts[-1] * 200) + 40)
+    ts_grid, imu_grid = ts, imu_all
+    if args.unaligned:
+        ts, imu_all = S.unaligned_stamps(ts, imu_all, seed=S.MASTER_SEED + seed_off)
 
     bind_one_socket(local_rank)
     # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
@@ -664,6 +679,22 @@ def main():
             ma = timed(run3, frames, None, W, K, dist, torch)
             run3.close()
             adapter[getters] = ma
+    # ---- the same pipelined schedule on a camera that is NOT on the IMU grid (every real one): the early erase count is only taken when
+    #      no IMU sample lies within 0.5 ms of its bound, otherwise the frame waits for the running update (larvio.cpp:464-512)
+    unal = None
+    if not args.unaligned and not args.no_unaligned_pass and not args.sequential and shard is None and world == 1:
+        ts_u, imu_u = S.unaligned_stamps(ts_grid, imu_grid, seed=S.MASTER_SEED + seed_off)
+        run4 = Run(wl, args, local_rank, imu_u, seq, ts_u, False, torch_stream=stream.cuda_stream)
+        while run4.i < n_pre:
+            run4.step(host_img=frames[run4.i])
+        mu = timed(run4, frames, None, W, K, dist, torch)
+        run4.close()
+        unal = {"value": round(K / mu["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(mu["elapsed"] / K * 1e3, 4), "messages": int(mu["msg_mask"].sum()),
+                "erase_counts_taken_early_since_start": mu["early"][0], "found_wrong": mu["early"][1], "messages_since_start": mu["n_msgs_total"],
+                "back_end_ms_per_message": round(mu["pst"]["filter_us"] / max(int(mu["msg_mask"].sum()), 1) * 1e-3, 4),
+                "caller_wait_ms_per_frame": round(mu["pst"]["caller_wait_us"] / K * 1e-3, 4),
+                "note": "same frames and IMU values, stamps off the grid: image stamps + 1.7 ms phase +- 0.3 ms jitter, IMU stamps +- 50 us "
+                        "(larvio_amd.synthetic.unaligned_stamps); frames whose erase count has an IMU sample within the margin wait for the running update"}
     # The sharded update at configs[4] depth, measured in the same invocation (filter only, simulated feature messages - seconds, no
     # rendering): at N > 1 the per-feature work is split over the N ranks with one RCCL all-gather per update, at N = 1 it is the
     # unsharded baseline of the same workload.  This is the strong-scaling curve north_star asks for "when the tracked-feature count
@@ -717,7 +748,7 @@ def main():
                "back_end_ms_per_message": None if pst is None else round(pst["filter_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
                "caller_wait_ms_per_frame": None if pst is None else round(pst["caller_wait_us"] / K * 1e-3, 4),
                "worker_idle_ms_per_message": None if pst is None else round(pst["worker_idle_us"] / max(int(mm.sum()), 1) * 1e-3, 4),
-               "erase_counts_taken_early": None if pst is None else {"since_start": m["early"][0], "found_wrong": m["early"][1],
+               "erase_counts_taken_early": None if pst is None else {"since_start": m["early"][0], "found_wrong": m["early"][1], "messages_since_start": m["n_msgs_total"],
                                                                      "note": "lvk_vio_pipe_early_counts: the caller's thread took the IMU erase count of a queued update from the last published td "
                                                                              "(no IMU sample within 0.5 ms of the bound) instead of waiting for the running update; checked by the filter's thread"},
                "device_resident": None if md is None else {"value": round(streams * K / md["elapsed"], 2), "unit": "frames/s", "ms_per_step": round(md["elapsed"] / K * 1e3, 4),
@@ -732,6 +763,7 @@ def main():
                            "lvk_frontend_process (waits for its message) + lvk_ekf_process_async per frame, pose read right after processFeatures "
                            "(value) or after the next frame's processImage (pose_read_one_frame_late); identical results "
                            "(tests/test_gpu_vio_driver.py::test_deferred_update_is_identical_to_blocking)"},
+               "unaligned_stamps": unal,
                "higher_is_better": True, "scaling": ("strong" if args.sharded else "weak"), "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
                "config": {"workload": wl["label"] + ", pyramid 3 levels, win %d, pub %g Hz" % (win, wl["fcfg"]["pub_frequency"]),
@@ -742,7 +774,8 @@ def main():
                           "stages": "processImage every frame + processFeatures on every feature message, as app/larvioMain.cpp:106-116",
                           "pre_roll_frames": n_pre, "timed_region_alignment": "starts on a publish frame: %d whole publish cycles of %d frames" % (K // period, period) if bool(m["msg_mask"][0]) else "starts %d frame(s) before a publish frame" % int(np.argmax(m["msg_mask"])), "sw_size": sw, "clones": n_clones, "state_dim": state_dim, "backend": counters,
                           "timed_region": {"messages": int(mm.sum()), "hybrid_updates": m["n_hybrid"], "msckf_pruning_updates": m["n_msckf"]},
-                          "live_tracks": live,
+                          "live_tracks": live, "tracker_budget_max_features_num": wl["fcfg"]["max_features_num"], "nominal_tracks": wl["nominal_tracks"],
+                          "stamps": "off the IMU grid (--unaligned)" if args.unaligned else "on the IMU grid (synthetic)",
                           "rehearsal_one_gpu_gloo": bool(os.environ.get("LVK_BENCH_ONE_GPU")), "parallelism": ("sharded x%d: contiguous feature ranges per rank, RCCL all-gather of the packed R factors" % world) if args.sharded
                                          else "replicas x%d" % world},
                "roofline": roofline,

@@ -286,8 +286,11 @@ lvk_status lvk_ekf_profile_qr(lvk_ekf* e, double* h_out4);
  * hip_stream.  fn = NULL (world 1) switches sharding off; with a transport the sharded path runs at any world size, world 1 included
  * (a loop-back through pack -> all-gather -> unpack -> second stage: validates a transport on one GPU).  The exchange buffers are
  * allocated by this call.  Every capacity test of the sharded update has the same outcome on all ranks (each rank plans every rank's
- * share), so a capacity error is raised everywhere before anybody enters the collective; a rank that fails locally afterwards still
- * enters it, with a poisoned block header, and its peers return LVK_ERR_DEVICE at their next sync instead of waiting. */
+ * share), so a capacity error is raised everywhere before anybody enters the collective; a rank that fails locally (a launch error
+ * while queueing its rows, or later) still enters it, with a poisoned block header, and its peers return LVK_ERR_DEVICE at their
+ * next sync instead of waiting.  One case cannot post a block - an update that admits new in-state features sizes its exchange from
+ * gate results the failing rank could not read - and calls fn(user, NULL, NULL, 0, stream) instead: bytes_per_rank == 0 means
+ * ABORT, the transport must make the peers' pending exchange fail (lvk_shard_allgather_rccl: ncclCommAbort). */
 typedef int /* lvk_status */ (*lvk_exchange_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
 lvk_status lvk_ekf_set_shard(lvk_ekf* e, int rank, int world, lvk_exchange_fn fn, void* user);
 /* [0] exchanges [1] bytes sent by this rank [2] sharded updates [3] rows this rank stacked; [4] updates the structure-aware

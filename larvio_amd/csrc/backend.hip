@@ -30,6 +30,11 @@
 #include <condition_variable>
 #include <deque>
 
+#if defined(__x86_64__) || defined(__i386__)
+#define LVK_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define LVK_CPU_RELAX() do { } while (0)
+#endif
 #define LEG (e->leg)           // LEG_DIM: 22, or 46 with online IMU-intrinsics calibration (larvio.cpp:158-161)
 #define LEG_MAX 46
 #define GRAV 9.81
@@ -38,6 +43,8 @@ struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t 
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
 lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq);
+lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n_out, int L,
+                                    const double* d_phiq, const int* d_ilist, int n_i, const int* d_clist, int n_c);
 lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const double* d_J, int fc);
 lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, int nn, const double* H1, int ldh, const double* H2, const double* r1,
                                    const double* dx, double sigma2, double* tmp, double* dx_new);
@@ -283,7 +290,7 @@ static void ekf_quiesce(const lvk_ekf* e)
 {
     lvk_ekf::Async* a = e->async;
     if (!a || a->state.load(std::memory_order_acquire) == 0) return;
-    for (int spin = 0; spin < 40000; ++spin) { if (a->state.load(std::memory_order_acquire) == 0) return; __builtin_ia32_pause(); }
+    for (int spin = 0; spin < 40000; ++spin) { if (a->state.load(std::memory_order_acquire) == 0) return; LVK_CPU_RELAX(); }
     std::unique_lock<std::mutex> lk(a->mu);
     a->cv.wait(lk, [&] { return a->state.load(std::memory_order_acquire) == 0; });
 }
@@ -689,6 +696,7 @@ static void process_model(lvk_ekf* e, double time, const double* m_gyro, const d
     e->s.t = time; e->s_fej_now.t = time;
 }
 
+#ifdef LVK_AB_SEPARATE_PROPAGATE
 static lvk_status apply_propagation(lvk_ekf* e)
 {
     if (!e->have_prop) return LVK_OK;
@@ -699,6 +707,7 @@ static lvk_status apply_propagation(lvk_ekf* e)
     double* P = e->dP[e->cur]; const int N = e->N, L = LEG; const double* d_h = dev(e, h);
     return run_or_defer(e, [=]() { return lvk_cov_propagate(e->ctx, P, e->ld, N, L, d_h); });
 }
+#endif
 
 static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
 {   // larvio.cpp:464-517
@@ -756,7 +765,23 @@ static lvk_status state_augmentation(lvk_ekf* e)
     for (int i = 0; i < pose_rows; ++i) idx.push_back(i);
     for (int i = 0; i < 6; ++i) idx.push_back(sel[i]);
     for (int i = pose_rows; i < e->N; ++i) idx.push_back(i);
-    return cov_gather(e, idx);
+    if (!e->have_prop) return cov_gather(e, idx);
+    // the frame's propagation (composed Phi, Q) rides in the same launch: k_cov_propagate_gather
+    const int n_out = (int)idx.size(), L = LEG;
+    int* h_idx = up_alloc<int>(e, (size_t)2 * n_out); double* h_pq = up_alloc<double>(e, (size_t)2 * L * L);
+    if (!h_idx || !h_pq) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
+    int* h_il = h_idx + n_out; int n_i = 0, n_c = 0;
+    for (int a = 0; a < n_out; ++a) { h_idx[a] = idx[a]; if (idx[a] < L) h_il[n_i++] = a; }
+    int* h_cl = h_il + n_i;                                  // ilist and clist share the second half (n_i + n_c = n_out)
+    for (int a = 0; a < n_out; ++a) if (idx[a] >= L) h_cl[n_c++] = a;
+    memcpy(h_pq, e->Phi_tot, sizeof(double) * L * L); memcpy(h_pq + L * L, e->Q_tot, sizeof(double) * L * L);
+    e->have_prop = false;
+    double* src = e->dP[e->cur]; double* dst = e->dP[e->cur ^ 1];
+    const int* d_idx = dev(e, h_idx); const int* d_il = dev(e, h_il); const int* d_cl = dev(e, h_cl); const double* d_pq = dev(e, h_pq);
+    lvk_status st = run_or_defer(e, [=]() { return lvk_cov_propagate_gather(e->ctx, src, e->ld, dst, e->ld, d_idx, n_out, L, d_pq, d_il, n_i, d_cl, n_c); });
+    if (st != LVK_OK) return st;
+    e->cur ^= 1; e->N = n_out;
+    return LVK_OK;
 }
 
 static void add_observations(lvk_ekf* e, const lvk_feature_obs* f, int n)
@@ -1096,6 +1121,14 @@ static lvk_status qr_level_launch(lvk_ekf* e, const QrPlanLevel& L, const double
     if (a) { hipEventRecord(b, e->ctx->stream); e->prof_pending.push_back({a, b, qr_level_flops(L), 1, (double)L.in_rows}); }
     return st;
 }
+// A rank that fails locally BEFORE the exchange's size is known to it (the layout of an update that admits new in-state features
+// depends on gate results it could not read) cannot post a poisoned block; it tells the transport to break the collective instead:
+// the exchange callback with bytes_per_rank == 0 means "abort" (lvk_shard_allgather_rccl: ncclCommAbort - the peers' pending
+// all-gather returns an error instead of waiting for this rank).
+static void shard_abort(lvk_ekf* e)
+{
+    if (e->shard.fn) (void)e->shard.fn(e->shard.user, nullptr, nullptr, 0, (void*)e->ctx->stream);
+}
 static lvk_status shard_peer_check(lvk_ekf* e)
 {   // call after a stream sync: did k_shard_unpack find a peer's block poisoned (that rank failed before the exchange)?
     if (!e->shard.fn) return LVK_OK;
@@ -1104,7 +1137,10 @@ static lvk_status shard_peer_check(lvk_ekf* e)
     const int mask = *f; *f = 0;
     return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "sharded update: the block of a peer rank (mask 0x%x) arrived invalid - that rank failed before the exchange", mask);
 }
-static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std::vector<RowGroup>& groups, int ncols, const std::vector<size_t>* job_b, int* m_out)
+// pre_fail: this rank already failed locally (a launch error while queueing its rows) - it still plans (host only), posts a poisoned
+// header and takes part in the collective, then returns that error: its peers are told by k_shard_unpack instead of waiting forever.
+static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std::vector<RowGroup>& groups, int ncols, const std::vector<size_t>* job_b, int* m_out,
+                               lvk_status pre_fail = LVK_OK)
 {
     auto& S = e->shard; const int W = S.world, me = S.rank;
     std::vector<std::vector<RowGroup>> gr((size_t)W), outg((size_t)W);
@@ -1165,7 +1201,7 @@ static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std
         if (st == LVK_OK) st = lvk_shard_pack(e->ctx, e->d_fout + hm[me].job_lo, hm[me].job_n, X, e->ld, rX, kk[(size_t)me], ncols, S.d_send, res_bytes, me);
         return st;
     };
-    const lvk_status st_local = local();
+    const lvk_status st_local = pre_fail != LVK_OK ? pre_fail : local();
     if (st_local != LVK_OK) { (void)hipGetLastError(); (void)hipMemsetAsync(S.d_send, 0xFF, LVK_SHARD_HDR, e->ctx->stream); }
     lvk_status st = S.fn(S.user, S.d_send, S.d_recv, bytes, (void*)e->ctx->stream);
     if (st_local != LVK_OK) return st_local;
@@ -1388,7 +1424,8 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
             begin_defer(e);                             // the jobs and the stacking map go up in one copy
             st = launch_feature_rows(e, jobs, sharded ? &own : nullptr);
-            if (st != LVK_OK) { end_defer(e); return st; }
+            if (st != LVK_OK && !sharded) { end_defer(e); return st; }
+            lvk_status st_rows = st;                    // sharded: a local failure still goes through the exchange (shard_stage1, pre_fail)
             std::vector<StackRow> map_o; std::vector<RowGroup> grp;
             int rows_m = 0, rows_e = 0;
             auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
@@ -1397,10 +1434,10 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + 1; rows_m += r; }
             for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + rows_e + 1; rows_e += 2; }
             int m = rows_m + rows_e;
-            if (m > e->hrows) { for (RowJob& j : jobs) j.hdev->dst_row1 = 0; end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
+            if (m > e->hrows) { for (RowJob& j : jobs) if (j.hdev) j.hdev->dst_row1 = 0; end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }   // (the same on every rank)
             if (!sharded && !direct) st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
-            if (sharded && st == LVK_OK) { st = shard_stage1(e, map_o, grp, N, &jb, &m); e->shard.stats[2]++; }
+            if (sharded) { st = shard_stage1(e, map_o, grp, N, &jb, &m, st_rows != LVK_OK ? st_rows : st); e->shard.stats[2]++; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, m, dx, 0, &grp);
             TR(TR_RLF_UPD);
@@ -1432,6 +1469,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             rgs.push_back({0, j_ekf}); rgs.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]});
             st = launch_feature_rows(e, jobs, &rgs);
             if (st == LVK_OK) st = fetch_feature_results(e, jobs);          // local sync: only jobs [0, j_ekf) are looked at before the exchange
+            if (st != LVK_OK) shard_abort(e);                               // the exchange's size depends on those results: cannot post a poisoned block
         } else st = run_feature_rows(e, jobs);
         if (st != LVK_OK) return st;
         auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
@@ -1673,7 +1711,8 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
         begin_defer(e);
         st = launch_feature_rows(e, jobs, sharded ? &own : nullptr);
-        if (st != LVK_OK) { end_defer(e); return st; }
+        if (st != LVK_OK && !sharded) { end_defer(e); return st; }
+        const lvk_status st_rows = st;                       // sharded: a local failure still goes through the exchange (shard_stage1, pre_fail)
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; std::vector<RowGroup> grp; int rows = 0;
         const bool direct = !sharded && e->rows_direct;      // as in remove_lost_features: the row kernel writes H_o itself
@@ -1682,7 +1721,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         {
             if (!sharded && !direct) st = stack_rows(e, map_o, e->d_H, e->N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
-            if (sharded && st == LVK_OK) { st = shard_stage1(e, map_o, grp, e->N, &jb, &rows); e->shard.stats[2]++; }
+            if (sharded) { st = shard_stage1(e, map_o, grp, e->N, &jb, &rows, st_rows != LVK_OK ? st_rows : st); e->shard.stats[2]++; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, rows, dx, 0, &grp);
             TR(TR_PR_UPD);
@@ -1977,7 +2016,7 @@ static void ekf_async_worker(lvk_ekf* e)
     hipSetDevice(e->ctx->device);
     lvk_ekf::Async* a = e->async;
     for (;;) {
-        for (int spin = 0; spin < 40000 && a->state.load(std::memory_order_acquire) != 1 && !a->stop.load(); ++spin) __builtin_ia32_pause();
+        for (int spin = 0; spin < 40000 && a->state.load(std::memory_order_acquire) != 1 && !a->stop.load(); ++spin) LVK_CPU_RELAX();
         {
             std::unique_lock<std::mutex> lk(a->mu);
             a->cv.wait(lk, [&] { return a->stop.load() || a->state.load(std::memory_order_acquire) == 1; });
@@ -2075,10 +2114,14 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
     if (off + used != *n_consumed) return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "internal: IMU consumption count mismatch");
     TR(TR_IMU);
-    begin_defer(e);                                     // propagation and augmentation share one upload
+#ifdef LVK_AB_SEPARATE_PROPAGATE                       // A/B builds only: k_cov_propagate (one workgroup), then the gather
+    begin_defer(e);
     lvk_status st = apply_propagation(e);
     if (st == LVK_OK) st = state_augmentation(e);
     { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
+#else
+    lvk_status st = state_augmentation(e);             // ONE launch: the frame's propagation + the augmentation gather
+#endif
     if (st != LVK_OK) return st;
     TR(TR_PROP);
     if (fetch) { lvk_status fs = fetch(fetch_user, &feats, &n_feats); if (fs != LVK_OK) return fs; }
@@ -2188,6 +2231,7 @@ lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* o)
 {
     if (!e || !o) return LVK_ERR_ARG;
     ekf_quiesce(e);
+    if (e->failed != LVK_OK) return e->failed;           // a half-applied update: state, clone list and covariance layout are out of step
     o[0] = e->s.t; memcpy(o + 1, e->s.q, 32); memcpy(o + 5, e->s.v, 24); memcpy(o + 8, e->s.p, 24); memcpy(o + 11, e->s.bg, 24); memcpy(o + 14, e->s.ba, 24);
     memcpy(o + 17, e->R_b2c, 72); memcpy(o + 26, e->t_c_b, 24); o[29] = e->td;
     return LVK_OK;
@@ -2196,6 +2240,7 @@ lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P)
 {
     if (!e || !h_P) return LVK_ERR_ARG;
     ekf_quiesce(e);
+    if (e->failed != LVK_OK) return e->failed;
     EKF_HIP(hipMemcpy2D(h_P, sizeof(double) * e->N, e->dP[e->cur], sizeof(double) * e->ld, sizeof(double) * e->N, e->N, hipMemcpyDeviceToHost));
     return LVK_OK;
 }
@@ -2275,12 +2320,20 @@ lvk_status lvk_vio_process_deferred(lvk_frontend* fe, lvk_ekf* ekf, const lvk_im
 // sample) submit() takes it at once from the last published td and the caller's thread runs on while up to two updates are in
 // flight; the filter's thread checks the count against the real td when the job starts (never different in any run here; counted in
 // lvk_vio_pipe_early_counts if it ever is, and the IMU window is put right for the frames that follow).  Otherwise - an IMU sample
-// within the margin of the bound - it waits as before.
+// sample within the margin of the bound - it waits as before.
+// Two guards keep a wrong early count from ever reaching the filter (round-3 advice): (1) the IMU view of an update is NOT a copy made at
+// submit time but is cut by the filter's thread, when the job starts, from the driver's buffer at the filter's own head (the sum of the TRUE
+// counts of the updates before it) - so the filter integrates exactly the samples the sequential loop would, whatever submit() guessed;
+// a wrong guess can only have shown a few front-end frames a gyro window that starts one sample off (counted in n_early_wrong, and the
+// caller's head is put right at once); (2) submit() only guesses while td is quiet: the largest |td step| of the last eight updates,
+// times the updates that can be in flight, must stay well inside the margin - while td is still converging from a bad initial value
+// every frame waits for its count.
 static double now_us_fwd();
 struct lvk_vio_pipe {
     lvk_frontend* fe; lvk_ekf* ekf;
-    std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..)
-    struct Job { double ts; int slot = -1; std::vector<lvk_imu> view; bool precounted = false; double t_submit = 0;      // slot: the front-end's message ring entry
+    std::vector<lvk_imu> imu; size_t head = 0;          // the driver's imu_msg_buffer = imu[head..) as the CALLER's thread sees it (early counts applied)
+    size_t base = 0, fhead = 0;                         // absolute index of imu[0]; absolute index the FILTER has consumed up to (true counts only)
+    struct Job { double ts; int slot = -1; std::vector<lvk_imu> view; size_t end_abs = 0; bool precounted = false; double t_submit = 0;      // slot: the front-end's message ring entry; view: cut by the worker from [fhead, end_abs)
                  bool early = false; int n_pre = 0; double t0_pre = 0; };                                                // early: counted by submit() from the published td (to be checked)
     std::vector<float> lat_us;                          // image-in -> state-out of every message-carrying frame (submit entry to update done)
     bool cur_precounted = false;                        // the running job's erase count was already applied by submit()
@@ -2291,6 +2344,7 @@ struct lvk_vio_pipe {
     // what submit() needs for an early count, all under mu: the filter is initialised, td after the last finished update, the state
     // time after the IMU batch of the last COUNTED job (the filter's own s.t belongs to its thread while a job runs)
     bool steady = false; double td_pub = 0, state_t = 0, td_margin = 5e-4; bool early_on = true;
+    double td_steps[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n_td = 0;       // |td change| of the last eight finished updates
     int depth = 2;                                      // updates the caller may have in flight when a frame starts (LVK_PIPE_DEPTH; 1: never more than one update ahead - lower latency, the filter's thread waits for messages)
     long n_early = 0, n_early_wrong = 0;
     int in_flight = 0;                                  // queued + running
@@ -2303,15 +2357,22 @@ struct lvk_vio_pipe {
     struct Ev { double t; int what; };                    // LVK_PIPE_LOG=<file>: event log (0 submit begin, 1 wait done, 2 front-end done,
     std::vector<Ev> log; bool logging = false;            //  3 job queued [4 precounted], 5 job start, 6 job end)
     void ev(int what) { if (logging) log.push_back({now_us_fwd(), what}); }   // LVK_EKF_TRACE: where the two threads spend their time (us)
+    bool td_quiet() const
+    {   // may submit() trust the published td for a count?  (depth + 1) updates can move td before the counted one starts
+        if (n_td < 3) return false;
+        double mx = 0; for (int i = 0; i < 8 && i < n_td; ++i) mx = std::max(mx, td_steps[i]);
+        return 2.0 * (depth + 1) * mx < td_margin;
+    }
 };
 static double now_us_fwd() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void pipe_on_consumed(void* user, int n)
-{
+{   // fired by the filter once per call, when the number of samples it erases is final (before any GPU work)
     lvk_vio_pipe* p = (lvk_vio_pipe*)user;
     {
         std::lock_guard<std::mutex> lk(p->mu);
+        p->fhead += (size_t)n;                          // the filter's own head: true counts only
         if (p->cur_precounted) return;
         p->head += (size_t)n; p->unknown_consume -= 1;
         p->gen.fetch_add(1, std::memory_order_release);
@@ -2327,7 +2388,7 @@ template <typename Pred> static void pipe_wait(lvk_vio_pipe* p, std::unique_lock
         if (pred()) return;
         const unsigned seen = p->gen.load(std::memory_order_acquire);
         lk.unlock();
-        for (int spin = 0; spin < 4000 && p->gen.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+        for (int spin = 0; spin < 4000 && p->gen.load(std::memory_order_acquire) == seen; ++spin) LVK_CPU_RELAX();
         lk.lock();
     }
     cv.wait(lk, pred);
@@ -2356,7 +2417,11 @@ static void pipe_worker(lvk_vio_pipe* p)
             p->cur_precounted = job.precounted;
         }
         const double t1 = now_us();
-        { std::lock_guard<std::mutex> lk(p->mu); p->ev(5); }
+        {   // this update's IMU view: from the filter's own head to what the driver had pushed when the frame was submitted
+            std::lock_guard<std::mutex> lk(p->mu); p->ev(5);
+            const size_t lo = std::min(p->fhead - p->base, p->imu.size()), hi = std::min(std::max(job.end_abs - p->base, lo), p->imu.size());
+            job.view.assign(p->imu.begin() + (long)lo, p->imu.begin() + (long)hi);
+        }
         // The erase count of this update depends on time stamps, the state time and td only - all final now that the previous update
         // is done - so it is published BEFORE this thread blocks on the message: the caller's next frame needs nothing else from here.
         if (!job.precounted && p->ekf->b_first_features && p->ekf->is_gravity_set) {
@@ -2369,14 +2434,17 @@ static void pipe_worker(lvk_vio_pipe* p)
             }
             p->cv_state.notify_all();
         } else if (job.early) {
-            // counted by submit() from an older td: the same count with the td this update starts from?
+            // counted by submit() from an older td: the same count with the td this update starts from?  (The filter is not affected
+            // either way - its view starts at its own head; a wrong guess only moved the window the front-end of the frames submitted
+            // since integrated its gyro prediction over.)
             double t_after = 0;
             const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size(), &t_after);
             if (n != job.n_pre || p->ekf->s.t != job.t0_pre) {
                 std::lock_guard<std::mutex> lk(p->mu);
-                const long nh = (long)p->head + (n - job.n_pre);      // (the vector may have been compacted since the count was taken: stay inside it)
-                p->head = nh < 0 ? 0 : std::min((size_t)nh, p->imu.size()); p->n_early_wrong += 1;
+                const long nh = (long)p->head + (n - job.n_pre);
+                p->head = (size_t)std::max(nh, (long)(p->fhead - p->base)); p->head = std::min(p->head, p->imu.size()); p->n_early_wrong += 1;
                 if (p->q.empty()) p->state_t = t_after;                 // later jobs were counted from the wrong state time: they are checked in turn
+                for (int i = 0; i < 8; ++i) p->td_steps[i] = p->td_margin;   // and nobody guesses again until eight quiet updates have gone by
                 p->gen.fetch_add(1, std::memory_order_release);
             }
         }
@@ -2400,7 +2468,10 @@ static void pipe_worker(lvk_vio_pipe* p)
             if (p->lat_us.size() < (size_t)1 << 20) p->lat_us.push_back((float)(t2 - job.t_submit));
             if (st != LVK_OK && p->st == LVK_OK) p->st = st;
             p->n_updates += upd; p->in_flight -= 1;
-            p->td_pub = p->ekf->td; p->steady = p->ekf->b_first_features && p->ekf->is_gravity_set;
+            const bool was_steady = p->steady;
+            p->steady = p->ekf->b_first_features && p->ekf->is_gravity_set;
+            if (was_steady && p->steady && upd) { p->td_steps[p->n_td % 8] = fabs(p->ekf->td - p->td_pub); p->n_td += 1; }
+            p->td_pub = p->ekf->td;
             p->gen.fetch_add(1, std::memory_order_release);
         }
         p->cv_state.notify_all();
@@ -2441,7 +2512,10 @@ lvk_status lvk_vio_pipe_push_imu(lvk_vio_pipe* p, const lvk_imu* h_imu, int n)
 {
     if (!p || (n > 0 && !h_imu)) return LVK_ERR_ARG;
     std::lock_guard<std::mutex> lk(p->mu);
-    if (p->head > 4096 && p->unknown_consume == 0) { p->imu.erase(p->imu.begin(), p->imu.begin() + (long)p->head); p->head = 0; }
+    // compaction: nothing in front of the filter's own head is needed by anybody (queued jobs cut their views from there on, the
+    // caller's head is never behind it)
+    const size_t done = p->fhead - p->base;
+    if (done > 4096 && p->unknown_consume == 0 && done <= p->head) { p->imu.erase(p->imu.begin(), p->imu.begin() + (long)done); p->head -= done; p->base = p->fhead; }
     p->imu.insert(p->imu.end(), h_imu, h_imu + n);
     return LVK_OK;
 }
@@ -2476,23 +2550,24 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
     lvk_vio_pipe::Job job;
     job.t_submit = tb;
     job.ts = ts; job.slot = slot;
-    job.view.assign(p->imu.begin() + (long)head, p->imu.begin() + (long)end);
     {
         std::lock_guard<std::mutex> lk(p->mu);
+        job.end_abs = p->base + end;
+        const lvk_imu* view = p->imu.data() + head; const int n_view = (int)(end - head);
         // With the worker idle the filter is quiescent: the erase count (timestamps, state time and td only) can be taken here
         // and the next frame need not wait for the worker to wake up.
         lvk_ekf* e = p->ekf;
         bool counted = false;
         if (p->in_flight == 0 && e->b_first_features && e->is_gravity_set) {
             double t_after = 0;
-            p->head += (size_t)batch_imu_count(e, ts + e->td, job.view.data(), (int)job.view.size(), &t_after);
+            p->head += (size_t)batch_imu_count(e, ts + e->td, view, n_view, &t_after);
             p->state_t = t_after; p->td_pub = e->td; p->steady = true;
             job.precounted = true; counted = true; p->ev(4);
-        } else if (p->in_flight > 0 && p->early_on && p->steady) {
+        } else if (p->in_flight > 0 && p->early_on && p->steady && p->td_quiet()) {
             // every queued job is counted (the wait above), so state_t is the state time this job will start from
             double ta = 0, tb2 = 0;
-            const int n_lo = imu_erase_count(p->state_t, ts + p->td_pub - p->td_margin, e->imu_img_time_th, job.view.data(), (int)job.view.size(), &ta);
-            const int n_hi = imu_erase_count(p->state_t, ts + p->td_pub + p->td_margin, e->imu_img_time_th, job.view.data(), (int)job.view.size(), &tb2);
+            const int n_lo = imu_erase_count(p->state_t, ts + p->td_pub - p->td_margin, e->imu_img_time_th, view, n_view, &ta);
+            const int n_hi = imu_erase_count(p->state_t, ts + p->td_pub + p->td_margin, e->imu_img_time_th, view, n_view, &tb2);
             if (n_lo == n_hi) {
                 job.precounted = true; job.early = true; job.n_pre = n_lo; job.t0_pre = p->state_t;
                 p->head += (size_t)n_lo; p->state_t = ta; p->n_early += 1; counted = true; p->ev(7);

@@ -185,6 +185,77 @@ __global__ void __launch_bounds__(CPR_THREADS) k_cov_propagate(double* __restric
     }
 }
 
+// Propagation AND clone augmentation in one launch (processModel's covariance part, larvio.cpp:553-571, then stateAugmentation's
+// J P J^T, :752-798, which is a pure gather):  Pout[a][b] = Pprop[idx[a]][idx[b]]  with Pprop = the propagated Pin, never stored.
+// 81 % of the outputs (clone x clone, feature blocks) are plain copies; what propagation changes is the L-wide strip of IMU rows and
+// columns, so the grid has three roles and only 1 + CPG_STRIPS workgroups read Phi and Q (they sit in the pinned upload arena):
+//   blockIdx <  n_out               row a of Pout, copies where both sources are outside the IMU block
+//   next CPG_STRIPS workgroups      a chunk of the outside columns: W = Phi Pin[0:L, chunk], written to every output row / column
+//                                   whose source is an IMU row (the six duplicated ones included), both orientations
+//   last workgroup                  the IMU block itself: sym(Phi P_II Phi^T + Q), scattered to all (a, b) with both sources inside
+// ilist / clist: the output indices whose source is < L / >= L (host-built, ascending).  Sums run over k ascending, exactly as
+// k_cov_propagate's, so the two routes give the same bits.  15 us (one workgroup) + a launch gap + 5 us (gather) -> one ~6 us launch.
+#define CPG_STRIPS 8
+__global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __restrict__ Pin, int ldin, double* __restrict__ Pout, int ldout,
+                                                             const int* __restrict__ idx, int n_out, int L, const double* __restrict__ phiq,
+                                                             const int* __restrict__ ilist, int n_i, const int* __restrict__ clist, int n_c)
+{
+    extern __shared__ double sh[];
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x < n_out) {
+        const int a = blockIdx.x, i = idx[a];
+        if (i < L) return;
+        for (int b = t; b < n_out; b += 256) { const int j = idx[b]; if (j >= L) Pout[(size_t)a * ldout + b] = Pin[(size_t)i * ldin + j]; }
+        return;
+    }
+    const int role = (int)blockIdx.x - n_out;
+    double* Phi = sh;                                   // L x L
+    if (role < CPG_STRIPS) {
+        const int cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS, c0 = role * cc, cw = min(cc, n_c - c0);
+        if (cw <= 0) return;
+        double* R = sh + L * L;                         // L x cc : Pin[0:L, source columns of the chunk]
+        double* W = R + L * cc;                         // L x cc : Phi R
+        for (int e = t; e < L * L; e += 256) Phi[e] = phiq[e];
+        for (int e = t; e < L * cw; e += 256) { const int k = e / cw, q = e - k * cw; R[k * cc + q] = Pin[(size_t)k * ldin + idx[clist[c0 + q]]]; }
+        __syncthreads();
+        for (int e = t; e < L * cw; e += 256) {
+            const int i = e / cw, q = e - i * cw; double s = 0.;
+            for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * cc + q];
+            W[i * cc + q] = s;
+        }
+        __syncthreads();
+        for (int e = t; e < n_i * cw; e += 256) {
+            const int ai = e / cw, q = e - ai * cw, a = ilist[ai], b = clist[c0 + q];
+            const double v = W[idx[a] * cc + q];
+            Pout[(size_t)a * ldout + b] = v; Pout[(size_t)b * ldout + a] = v;
+        }
+        return;
+    }
+    double* Q = sh + L * L; double* PII = Q + L * L; double* T = PII + L * L; double* Pn = T + L * L;
+    for (int e = t; e < 2 * L * L; e += 256) sh[e] = phiq[e];
+    for (int e = t; e < L * L; e += 256) { const int i = e / L, j = e - i * L; PII[e] = Pin[(size_t)i * ldin + j]; }
+    __syncthreads();
+    for (int e = t; e < L * L; e += 256) {
+        const int i = e / L, j = e - i * L; double s = 0.;
+        for (int k = 0; k < L; ++k) s += Phi[i * L + k] * PII[k * L + j];
+        T[e] = s;
+    }
+    __syncthreads();
+    for (int e = t; e < L * L; e += 256) {
+        const int i = e / L, j = e - i * L;
+        if (j > i) continue;
+        double s1 = 0., s2 = 0.;
+        for (int k = 0; k < L; ++k) { s1 += T[i * L + k] * Phi[j * L + k]; s2 += T[j * L + k] * Phi[i * L + k]; }
+        const double v = ((s1 + Q[i * L + j]) + (s2 + Q[j * L + i])) / 2.0;
+        Pn[i * L + j] = v; Pn[j * L + i] = v;
+    }
+    __syncthreads();
+    for (int e = t; e < n_i * n_i; e += 256) {
+        const int ai = e / n_i, bi = e - ai * n_i, a = ilist[ai], b = ilist[bi];
+        Pout[(size_t)a * ldout + b] = Pn[idx[a] * L + idx[b]];
+    }
+}
+
 // re-anchoring of a 1-D inverse-depth feature (updateFeatureCov_1didp, larvio.cpp:3125-3293): row/col fc <- J P, J P J^T
 __global__ void __launch_bounds__(256) k_cov_reanchor(double* __restrict__ P, int ld, int n, const double* __restrict__ J, int fc)
 {
@@ -848,6 +919,19 @@ lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, 
     if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n);
     if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 0, k_cov_propagate, shmem);      // beyond 64 KB the launch needs the attribute
     hipLaunchKernelGGL(k_cov_propagate, dim3(1), dim3(CPR_THREADS), shmem, ctx->stream, P, ld, n, L, d_phiq);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n_out, int L,
+                                    const double* d_phiq, const int* d_ilist, int n_i, const int* d_clist, int n_c)
+{
+    const int cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS;
+    const size_t strip = sizeof(double) * ((size_t)L * L + (size_t)2 * L * (cc > 0 ? cc : 1)), core = sizeof(double) * (size_t)5 * L * L;
+    const size_t shmem = strip > core ? strip : core;
+    if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n_out);
+    if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 9, k_cov_propagate_gather, shmem);
+    hipLaunchKernelGGL(k_cov_propagate_gather, dim3(n_out + CPG_STRIPS + 1), dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, d_idx, n_out, L, d_phiq,
+                       d_ilist, n_i, d_clist, n_c);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

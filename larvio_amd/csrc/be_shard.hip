@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_shard_unpack(const char* __restrict__ r
         for (int j = t; j < ncols; j += 256) dst[j] = src[j];
         if (t == 0) r[m.row_off + i] = src[ncols];
     } else {
-        if (!good) { if (t == 0 && peer_fail) atomicOr(peer_fail, 1 << (g & 30)); return; }
+        if (!good) { if (t == 0 && peer_fail) atomicOr(peer_fail, 1 << (g < 31 ? g : 31)); return; }
         const FeatResult* src = (const FeatResult*)base;
         for (int j = t; j < m.job_n; j += 256) { const FeatResult v = src[j]; fout[m.job_lo + j] = v; if (fout_host) fout_host[m.job_lo + j] = v; }
     }
@@ -93,6 +93,7 @@ struct RcclApi {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommAbort) comm_abort = nullptr;
     decltype(&ncclGetErrorString) err_string = nullptr;
     char why[160] = {0};
     char path[512] = {0};                               // the librccl that was bound
@@ -120,6 +121,7 @@ static const RcclApi* rccl_api()
         a.comm_init_rank = (decltype(a.comm_init_rank))dlsym(a.lib, "ncclCommInitRank");
         a.all_gather = (decltype(a.all_gather))dlsym(a.lib, "ncclAllGather");
         a.comm_destroy = (decltype(a.comm_destroy))dlsym(a.lib, "ncclCommDestroy");
+        a.comm_abort = (decltype(a.comm_abort))dlsym(a.lib, "ncclCommAbort");
         a.err_string = (decltype(a.err_string))dlsym(a.lib, "ncclGetErrorString");
         if (!a.get_unique_id || !a.comm_init_rank || !a.all_gather || !a.comm_destroy) snprintf(a.why, sizeof a.why, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
         return a;
@@ -172,8 +174,17 @@ const char* lvk_shard_rccl_path(void) { const RcclApi* a = rccl_api(); return a-
 lvk_status lvk_shard_allgather_rccl(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream)
 {
     lvk_shard_comm* c = (lvk_shard_comm*)user;
-    if (!c || !d_send || !d_recv) return LVK_ERR_ARG;
+    if (!c) return LVK_ERR_ARG;
     const RcclApi* a = rccl_api();
+    if (bytes_per_rank == 0) {
+        // abort (lvk_exchange_fn contract): this rank cannot take part in the update's collective - break the communicator so that
+        // the peers' all-gather ends with an error instead of waiting for it
+        if (c->comm && a->comm_abort) { a->comm_abort(c->comm); c->comm = nullptr; }
+        snprintf(c->err, sizeof c->err, "communicator aborted: this rank failed before the exchange");
+        return LVK_ERR_DEVICE;
+    }
+    if (!d_send || !d_recv) return LVK_ERR_ARG;
+    if (!c->comm) { snprintf(c->err, sizeof c->err, "communicator was aborted"); return LVK_ERR_DEVICE; }
     const ncclResult_t rc = a->all_gather(d_send, d_recv, bytes_per_rank, ncclInt8, c->comm, (hipStream_t)hip_stream);
     if (rc == ncclSuccess) return LVK_OK;
     snprintf(c->err, sizeof c->err, "ncclAllGather: %s", a->err_string ? a->err_string(rc) : "?");

@@ -89,6 +89,16 @@ class HostExchange:
         from ._lib import lib
         try:
             L = lib()
+            if nbytes == 0:
+                # abort (lvk_exchange_fn contract: this rank failed before it knew the exchange's size).  torch.distributed has no
+                # per-collective abort on gloo: announce it in the size handshake below, the peers' exchange then returns an error
+                self.dist.all_gather([torch.empty(1, dtype=torch.int64) for _ in range(self.world)], torch.tensor([-1], dtype=torch.int64))
+                return 2
+            sizes = [torch.empty(1, dtype=torch.int64) for _ in range(self.world)]
+            self.dist.all_gather(sizes, torch.tensor([nbytes], dtype=torch.int64))
+            if any(int(x) != nbytes for x in sizes):
+                print("HostExchange: a peer aborted or disagrees about the block size:", [int(x) for x in sizes])
+                return 2
             self.ctx.sync()                                                   # everything queued before the exchange has run
             mine = np.empty(nbytes, np.uint8)
             self.ctx.check(L.lvk_memcpy_d2h(self.ctx.h, mine.ctypes.data_as(C.c_void_p), C.c_void_p(d_send), nbytes))

@@ -271,6 +271,20 @@ def imu_only_sequence(seed=MASTER_SEED, cam=EUROC, imu_rate=200.0, noise_scale=1
     return seq
 
 
+
+def unaligned_stamps(ts, imu_all, seed=MASTER_SEED, phase=1.7e-3, cam_jitter=3e-4, imu_jitter=5e-5):
+    """A camera that is NOT on the IMU grid (every real one): image stamps shifted by a constant phase plus per-frame jitter, IMU stamps
+    jittered around their grid.  The synthetic sequence puts every image stamp exactly half-way between two IMU samples' bounds, where
+    the pipelined driver's early erase count (lvk_vio_pipe_submit) is always safe; with these stamps a sample falls within its 0.5 ms
+    margin of the bound in roughly a fifth of the message frames, which then wait for the running update (larvio.cpp:464-512 is the
+    rule both schedules implement).  The constant phase acts as a true camera-IMU time offset: with estimate_td the filter's td walks
+    towards it, so the bound moves while the test runs.  Returns (ts', imu_all') - same images, same IMU values, new stamps."""
+    rng = np.random.default_rng([seed, 77])
+    ts2 = np.asarray(ts, np.float64) + phase + rng.uniform(-cam_jitter, cam_jitter, len(ts))
+    imu2 = np.array(imu_all, copy=True)
+    imu2["t"] = imu2["t"] + rng.uniform(-imu_jitter, imu_jitter, len(imu2))
+    return ts2, imu2
+
 # ------------------------------------------------------------------ the configurations BASELINE.json names (SURVEY.md §8d)
 CAM_TUMVI_LIKE = dict(width=512, height=512, intrinsics=(190.978, 190.973, 254.932, 256.897), distortion_model=1,
                       distortion=(0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367), T_cam_imu=EUROC["T_cam_imu"])
@@ -296,11 +310,12 @@ def workload(name, max_features=None, sw_size=None):
         label = "configs[4]: synthetic 1920x1080 @60 Hz, 1d-hybrid, messages at 30 Hz"
     else:
         raise ValueError("workload must be one of A, 3, 4, 5")
+    nominal = {"A": 150, "3": 150, "4": 300, "5": 2000}[name]       # the track count BASELINE.json states for the configuration
     mf = max_features or mf; sw = sw_size or sw
     fcfg = frontend_config(cam=cam, max_features_num=mf, **fo)
     bcfg = backend_config(cam=cam, sw_size=sw, max_features=mf, **bo)
-    return dict(name=name, cam=cam, img_rate=rate, fcfg=fcfg, bcfg=bcfg, max_features=mf, sw_size=sw,
-                label="%s, max_features %d, sw_size %d" % (label, mf, sw))
+    return dict(name=name, cam=cam, img_rate=rate, fcfg=fcfg, bcfg=bcfg, max_features=mf, sw_size=sw, nominal_tracks=nominal,
+                label="%s, tracker budget max_features_num %d (sized to HOLD the stated ~%d tracks), sw_size %d" % (label, mf, nominal, sw))
 
 
 _RENDER_SEQ = None

@@ -136,5 +136,10 @@ def test_deferred_update_reports_its_failure_at_the_next_call(gpu_ctx):
         be.processFeaturesAsync((imu["t"][100], np.zeros(4, OBS)), imu[:110])
     with pytest.raises(larvio_amd.LvkError, match="failed state"):
         be.processFeatures((imu["t"][100], np.zeros(4, OBS)), imu[:110])
+    # the getters of a failed filter say so instead of handing out a half-updated state (lvk_ekf_get_state / lvk_ekf_get_cov)
+    with pytest.raises(larvio_amd.LvkError):
+        be.state()
+    with pytest.raises(larvio_amd.LvkError):
+        be.cov()
     be.close()
     be2 = larvio_amd.LarVio(S.backend_config(sw_size=8), gpu_ctx); assert be2.initialize(); be2.close()      # the context survives

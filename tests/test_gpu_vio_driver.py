@@ -63,8 +63,20 @@ def test_driver_loop_matches_oracle(gpu_ctx, device_frames):
         assert be.dim == obe.dim
         so, sg = obe.state(), be.state()
         for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
-            worst = max(worst, _rel(sg[k], so[k]))
-        worst = max(worst, _rel(be.cov(), obe.cov()))
+            e_k = _rel(sg[k], so[k])
+            if e_k > worst:
+                worst = e_k; _WORST_AT.update(update=n_upd, frame=i, what=k, detail="")
+        Pg, Po = be.cov(), obe.cov()
+        e_p = _rel(Pg, Po)
+        if e_p > worst:
+            # which entry of P carries it: the block names of its row and column, its own size against the largest entry of P
+            ij = np.unravel_index(np.argmax(np.abs(Pg - Po)), Po.shape); leg = 46 if bcfg.get("calib_imu_instrinsic") else 22
+            nc = len(obe.clones()["id"])
+            def blk(x):
+                if x < leg: return ("th", "v", "p", "bg", "ba", "th_ext", "t_ext", "td/imx")[min(x // 3, 7)]
+                return f"clone{(x - leg) // 6}.{'th' if (x - leg) % 6 < 3 else 'p'}" if x < leg + 6 * nc else f"feat{x - leg - 6 * nc}"
+            worst = e_p; _WORST_AT.update(update=n_upd, frame=i, what="P", detail=f"entry ({blk(ij[0])},{blk(ij[1])}) = {Po[ij]:.3e} differs by {abs(Pg[ij] - Po[ij]):.3e}; max|P| = {np.abs(Po).max():.3e} "
+                                          f"at {blk(np.unravel_index(np.argmax(np.abs(Po)), Po.shape)[0])}; rows of the last update {be.counters().get('last_rows')}")
         assert np.array_equal(be.clones()["id"], obe.clones()["id"])
         assert np.array_equal(be.features()[0], obe.features()[0])
         assert worst < REL, (i, worst)
@@ -210,6 +222,9 @@ TUMVI_LIKE = dict(
     T_cam_imu=None)
 
 
+_WORST_AT = {}      # where the worst relative error of the last _driver_pair run sat (printed by the whole-loop tests)
+
+
 def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt, min_updates, mutate=None, oracle_threads=1, workload=None):
     """oracle loop vs VioDriver on frames [first, first+count) of the synthetic sequence seen through `cam`
     (workload: a larvio_amd.synthetic.workload() dict - camera, frame rate and both configurations exactly as bench.py runs them)"""
@@ -261,8 +276,20 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
         assert be.dim == obe.dim
         so, sg = obe.state(), be.state()
         for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
-            worst = max(worst, _rel(sg[k], so[k]))
-        worst = max(worst, _rel(be.cov(), obe.cov()))
+            e_k = _rel(sg[k], so[k])
+            if e_k > worst:
+                worst = e_k; _WORST_AT.update(update=n_upd, frame=i, what=k, detail="")
+        Pg, Po = be.cov(), obe.cov()
+        e_p = _rel(Pg, Po)
+        if e_p > worst:
+            # which entry of P carries it: the block names of its row and column, its own size against the largest entry of P
+            ij = np.unravel_index(np.argmax(np.abs(Pg - Po)), Po.shape); leg = 46 if bcfg.get("calib_imu_instrinsic") else 22
+            nc = len(obe.clones()["id"])
+            def blk(x):
+                if x < leg: return ("th", "v", "p", "bg", "ba", "th_ext", "t_ext", "td/imx")[min(x // 3, 7)]
+                return f"clone{(x - leg) // 6}.{'th' if (x - leg) % 6 < 3 else 'p'}" if x < leg + 6 * nc else f"feat{x - leg - 6 * nc}"
+            worst = e_p; _WORST_AT.update(update=n_upd, frame=i, what="P", detail=f"entry ({blk(ij[0])},{blk(ij[1])}) = {Po[ij]:.3e} differs by {abs(Pg[ij] - Po[ij]):.3e}; max|P| = {np.abs(Po).max():.3e} "
+                                          f"at {blk(np.unravel_index(np.argmax(np.abs(Po)), Po.shape)[0])}; rows of the last update {be.counters().get('last_rows')}")
         assert np.array_equal(be.clones()["id"], obe.clones()["id"]) and np.array_equal(be.features()[0], obe.features()[0])
         assert worst < REL, (i, worst)
     assert n_upd >= min_updates
@@ -319,7 +346,7 @@ def test_whole_loop_configs1_as_benchmarked_150_live_tracks(gpu_ctx):
     wl = S.workload("A")
     n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, int(2.0 * wl["img_rate"]), 150, {}, {}, init_from_gt=True, min_updates=70, workload=wl)
     assert n_clones >= 28 and c["msckf"] >= 5 and 140 <= n_tracks <= wl["max_features"], (n_clones, c, n_tracks)
-    print("configs[1] as benchmarked: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+    print("configs[1] as benchmarked: updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim, "worst at", dict(_WORST_AT))
 
 
 def test_whole_loop_configs2_imu_intrinsics_sw30(gpu_ctx):
@@ -329,7 +356,7 @@ def test_whole_loop_configs2_imu_intrinsics_sw30(gpu_ctx):
     wl = S.workload("3")
     n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, int(2.0 * wl["img_rate"]), 140, {}, {}, init_from_gt=True, min_updates=65, workload=wl)
     assert wl["bcfg"]["calib_imu_instrinsic"] == 1 and n_clones >= 28 and c["msckf"] >= 5 and dim >= 46 + 6 * 28, (n_clones, c, dim)
-    print("configs[2] (IMU intrinsics, sw 30): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+    print("configs[2] (IMU intrinsics, sw 30): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim, "worst at", dict(_WORST_AT))
 
 
 def test_whole_loop_configs3_tumvi_300_tracks_sw30_zupt(gpu_ctx):
@@ -342,7 +369,7 @@ def test_whole_loop_configs3_tumvi_300_tracks_sw30_zupt(gpu_ctx):
     wl = S.workload("4")
     n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, 0, 170, {}, {}, init_from_gt=True, min_updates=60, workload=wl)
     assert n_clones >= 28 and c["zupt"] >= 1 and c["msckf"] >= 5 and n_tracks >= 200, (n_clones, c, n_tracks)
-    print("configs[3] (300 tracks, sw 30, ZUPT): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+    print("configs[3] (300 tracks, sw 30, ZUPT): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim, "worst at", dict(_WORST_AT))
 
 
 def test_whole_loop_configs4_1080p_2000_tracks_sw60(gpu_ctx):
@@ -354,7 +381,7 @@ def test_whole_loop_configs4_1080p_2000_tracks_sw60(gpu_ctx):
     n_upd, worst, c, n_tracks, n_clones, dim = _driver_pair(gpu_ctx, None, int(2.0 * wl["img_rate"]), 140, {}, {}, init_from_gt=True, min_updates=65,
                                                              workload=wl, oracle_threads=_oracle_threads())
     assert n_clones >= 58 and c["msckf"] >= 3 and n_tracks >= 1800 and dim >= 22 + 6 * 58, (n_clones, c, n_tracks, dim)
-    print("configs[4] (1080p, 2000 tracks, sw 60): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim)
+    print("configs[4] (1080p, 2000 tracks, sw 60): updates", n_upd, "worst rel", worst, c, "tracks", n_tracks, "clones", n_clones, "dim", dim, "worst at", dict(_WORST_AT))
 
 
 def test_driver_loop_config5_shape_1080p_many_tracks(gpu_ctx):
@@ -410,6 +437,83 @@ def test_pipelined_driver_is_identical_to_sequential_at_configs4_shape(gpu_ctx):
         for k in a[0]:
             assert np.array_equal(a[0][k], b[0][k]), k
         assert np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+
+
+def test_pipelined_driver_on_a_camera_off_the_imu_grid(gpu_ctx):
+    """Every other pipelined-driver test feeds stamps that sit exactly on the synthetic grid, where lvk_vio_pipe_submit may ALWAYS take the
+    IMU erase count early; a real camera is not aligned with the IMU.  Here the stamps carry a phase, per-frame jitter and jittered IMU
+    times (larvio_amd.synthetic.unaligned_stamps), and td is estimated, so the bound "image time + td + half an IMU period"
+    (larvio.cpp:464-512) wanders across IMU samples while the run goes on.  Asserted: some frames had to WAIT for their count
+    (n_early < messages: the fall-back path ran on the GPU), no early count was found wrong, the pipelined run equals the sequential
+    one bit for bit, and both agree with the oracle's loop on the same stamps (1e-5, discrete results identical)."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver, VioPipeline
+    from oracle import lvo, lvo_be
+    from tests.conftest import synth_frames
+    frames = synth_frames(40, 120)
+    seq = S.imu_only_sequence()
+    ts0 = np.array([f[0] for f in frames])
+    imu0 = seq.imu_array(max(int(ts0[0] * 200) - 4, 0), int(ts0[-1] * 200) + 40)
+    ts, imu_all = S.unaligned_stamps(ts0, imu0)
+    fcfg = S.frontend_config(max_features_num=150)
+    bcfg = S.backend_config(sw_size=20, if_zupt_valid=0)
+    k = int(np.searchsorted(imu_all["t"], ts[1], side="right")) - 1
+    t0 = imu_all["t"][k]; tr = seq.traj
+    init = (t0, _R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+    # ---- the oracle's loop
+    ofe = lvo.Frontend(fcfg); obe = lvo_be.Ekf(bcfg)
+    lo = 0; vis = lambda t: int(np.searchsorted(imu_all["t"], t + 0.05, side="left"))
+    for i, (_, img) in enumerate(frames):
+        if i == 1:
+            obe.set_state(*init)
+        buf = imu_all[lo:vis(ts[i])]
+        have, m = ofe.process(img, float(ts[i]), buf)
+        if have:
+            _, used = obe.process(float(ts[i]), m, buf); lo += used
+    ctx2 = larvio_amd.Context(0)
+    out = []
+    for mode in ("seq", "pipe"):
+        fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
+        be = larvio_amd.LarVio(bcfg, ctx2 if mode == "pipe" else gpu_ctx); assert be.initialize()
+        drv = (VioPipeline if mode == "pipe" else VioDriver)(fe, be, imu_all)
+        n_msg = 0
+        for i, (_, img) in enumerate(frames):
+            if i == 1:
+                if mode == "pipe":
+                    drv.drain()
+                be.set_state(*init)
+            r = drv.step(float(ts[i]), drv.visible_end(float(ts[i])), img=img)
+            n_msg += int(r if mode == "pipe" else r[0])
+        if mode == "pipe":
+            n_upd, n_m = drv.drain()
+            early, wrong = drv.early_counts()
+            assert n_m == n_msg and wrong == 0, (n_m, n_msg, early, wrong)
+            assert 0 < early < n_msg - 4, ("the waiting path did not run" if early else "no count was ever taken early", early, n_msg)
+            print("off-grid camera: %d messages, %d erase counts taken early (%d frames waited), %d wrong; td %.3e" % (n_m, early, n_m - early, wrong, be.state()["td"]))
+            drv.close()
+        st = be.state()
+        out.append((n_msg, {k_: np.array(v, copy=True) for k_, v in st.items()}, be.cov(), be.clones()["id"].copy(), be.features()[0].copy(), be.counters(), fe.tracks()))
+        be.close(); fe.close()
+    ctx2.close()
+    a, b = out
+    assert a[0] == b[0] and a[0] >= 50
+    for k_ in a[1]:
+        assert np.array_equal(a[1][k_], b[1][k_]), k_
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[5] == b[5]
+    for k_ in ("ids", "pts", "lifetime"):
+        assert np.array_equal(a[6][k_], b[6][k_])
+    so = obe.state()
+    for k_ in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
+        assert _rel(b[1][k_], so[k_]) < REL, k_
+    assert abs(b[1]["td"] - so["td"]) < 1e-9 and abs(so["td"]) > 1e-5                 # td moved (the bound wandered), identically
+    assert _rel(b[2], obe.cov()) < REL
+    assert np.array_equal(b[3], obe.clones()["id"]) and np.array_equal(b[4], obe.features()[0])
+    to = ofe.tracks()
+    assert np.array_equal(b[6]["ids"], to["ids"]) and np.array_equal(b[6]["pts"], to["pts"])
+    co = obe.counters()
+    for k_ in ("hybrid", "msckf", "gated_in", "gated_out", "map"):
+        assert b[5][k_] == co[k_], (k_, b[5], co)
 
 
 def test_cpp_driver_matches_python_driver_bit_for_bit(gpu_ctx, tmp_path):
