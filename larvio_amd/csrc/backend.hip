@@ -43,15 +43,15 @@ struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t 
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
 lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq);
-lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n_out, int L,
-                                    const double* d_phiq, const int* d_ilist, int n_i, const int* d_clist, int n_c);
+lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_ix, int n_out, int n_i, int L,
+                                    const double* d_phiq);
 lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const double* d_J, int fc);
 lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, int nn, const double* H1, int ldh, const double* H2, const double* r1,
                                    const double* dx, double sigma2, double* tmp, double* dx_new);
 lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out);
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out, FeatResult* d_out_host,
-                                   double* d_Hout, int ldh, int ncols_out, double* d_rout);
+                                   double* d_Hout, int ldh, int ncols_out, double* d_rout, int obs_stride, int n_clones);
 lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
 
@@ -237,7 +237,6 @@ struct lvk_ekf {
     double* d_staging = nullptr; size_t staging_cap = 0; int* d_ccols = nullptr; size_t ccols_cap = 0; StackRow* d_map = nullptr;
     double *d_H = nullptr, *d_r = nullptr, *d_H1 = nullptr, *d_H2 = nullptr, *d_r1 = nullptr;
     double *d_Hb = nullptr, *d_rb = nullptr;            // ping-pong partner of d_H / d_r for the levels of the structure-aware compression
-    int sparse_qr = 1;                                  // LVK_SPARSE_QR=0 disables the structure-aware compression (A/B runs)
     int sparse_qr_min_rows = 480;
     std::vector<int> tri_ranks; std::vector<double> tri_z;       // view pools of the triangulation requests of the current batch
     struct ColCache { int type = -1, ncols = 0, anchor = 0, fcol = 0; std::vector<long long> sids; ColList cols; };
@@ -262,7 +261,6 @@ struct lvk_ekf {
     // results come back WITHOUT copies: the kernels that produce them (triangulation, per-feature rows, the dx column of W^T[W|w])
     // also write them into this device-mapped pinned buffer; the host reads it after the stream sync it needs anyway
     char* h_down = nullptr; size_t down_cap = 0; char* dh_down = nullptr; size_t down_feat = 0, down_dx = 0;
-    bool rows_direct = true;                            // k_feature_rows writes the dense measurement rows itself where the slots are known before its launch (LVK_ROWS_DIRECT=0: always through k_stack_rows)
     // fired as soon as the number of IMU samples this call erases is final (before any GPU work): lets a pipelined driver
     // hand the next frame's front-end the right buffer view while this update is still running
     void (*on_consumed)(void*, int) = nullptr; void* on_consumed_user = nullptr;
@@ -777,8 +775,9 @@ static lvk_status state_augmentation(lvk_ekf* e)
     memcpy(h_pq, e->Phi_tot, sizeof(double) * L * L); memcpy(h_pq + L * L, e->Q_tot, sizeof(double) * L * L);
     e->have_prop = false;
     double* src = e->dP[e->cur]; double* dst = e->dP[e->cur ^ 1];
-    const int* d_idx = dev(e, h_idx); const int* d_il = dev(e, h_il); const int* d_cl = dev(e, h_cl); const double* d_pq = dev(e, h_pq);
-    lvk_status st = run_or_defer(e, [=]() { return lvk_cov_propagate_gather(e->ctx, src, e->ld, dst, e->ld, d_idx, n_out, L, d_pq, d_il, n_i, d_cl, n_c); });
+    const int* d_ix = dev(e, h_idx); const double* d_pq = dev(e, h_pq);      // [idx | ilist | clist] is one array
+    (void)h_cl;
+    lvk_status st = run_or_defer(e, [=]() { return lvk_cov_propagate_gather(e->ctx, src, e->ld, dst, e->ld, d_ix, n_out, n_i, L, d_pq); });
     if (st != LVK_OK) return st;
     e->cur ^= 1; e->N = n_out;
     return LVK_OK;
@@ -959,7 +958,11 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
     if (jobs.empty()) return LVK_OK;
     if ((int)jobs.size() > 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
     size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2;
-    for (auto& j : jobs) tot += j.sids.size();
+    size_t m_max = 1; for (auto& j : jobs) { tot += j.sids.size(); m_max = std::max(m_max, j.sids.size()); }
+    // short tracks only (always, with max_track_len 6) and one launch for the whole batch: the observations go to fixed-stride slots,
+    // so that the row kernel can ask for them without having read the job record first (k_feature_rows: one PCIe round trip less)
+    const int obs_stride = (!ranges && m_max <= 8) ? (int)m_max : 0;
+    if (obs_stride) tot = jobs.size() * (size_t)obs_stride;
     if ((int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "observation batch exceeds capacity");
     FeatJob* hj = up_alloc<FeatJob>(e, jobs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot); double* hv = up_alloc<double>(e, 2 * tot);
     if (!hj || !hr || !hz || !hv) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
@@ -969,6 +972,7 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
         const int M = (int)j.sids.size();
         const int c = (j.type == JOB_MSCKF) ? 7 + 6 * M : 7 + 6 + 6 * M + 1;
         FeatJob& d = j.dev; memset(&d, 0, sizeof d);
+        if (obs_stride) off = i * (size_t)obs_stride;
         d.type = j.type; d.n_obs = M; d.obs_off = (int)off; d.want_gate = j.want_gate ? 1 : 0;
         d.anchor_rank = (j.type == JOB_MSCKF) ? 0 : clone_rank(e, f->id_anchor);
         d.fcol = (j.type == JOB_MSCKF) ? 0 : LEG + 6 * (int)e->clones.size() + fs_rank(e, f->id);
@@ -981,6 +985,7 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
             hz[2 * (off + k)] = f->obs[oi].z[0]; hz[2 * (off + k) + 1] = f->obs[oi].z[1];
             hv[2 * (off + k)] = f->obs[oi].zv[0]; hv[2 * (off + k) + 1] = f->obs[oi].zv[1];
         }
+        if (obs_stride) for (int k = M; k < obs_stride; ++k) { hr[off + k] = 0; hz[2 * (off + k)] = hz[2 * (off + k) + 1] = hv[2 * (off + k)] = hv[2 * (off + k) + 1] = 0.; }
         off += M;
         stage += (size_t)2 * M * c * 2 + 2 * M; ccols += c;
         max_rows = std::max(max_rows, 2 * M);
@@ -992,11 +997,12 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
     const int nj = (int)jobs.size(); const CloneDev* d_cl = e->dv_clones; double* P = e->dP[e->cur];
     FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
     double* Ho = e->d_H; double* ro = e->d_r; const int ldh = e->ld, ncols_out = e->N;       // direct output of the jobs that carry a destination row (set_direct_rows)
-    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh, Ho, ldh, ncols_out, ro); });
+    const int n_cl = (int)e->clones.size();
+    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh, Ho, ldh, ncols_out, ro, obs_stride, n_cl); });
     for (const auto& rg : *ranges) {                    // jobs carry absolute offsets into the observation / staging / column arrays
         const size_t lo = rg.first; const int n = (int)(rg.second - rg.first);
         if (n <= 0) continue;
-        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo, nullptr, 0, 0, nullptr); });
+        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo, nullptr, 0, 0, nullptr, 0, n_cl); });
         if (st != LVK_OK) return st;
     }
     return LVK_OK;
@@ -1223,13 +1229,15 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
 {
     lvk_status st = LVK_OK;
     double* H = e->d_H; double* r = e->d_r;
-    // The nodes cost ~1 us per column of their union (one barrier-separated Householder step each, ~50..60 steps): measured on MI355X
-    // the compression pays once it saves more than a few 32-row Cholesky panels - not for the typical update of the north-star size
-    // (m ~ 110..260 rows of 9-row feature blocks over ~50 columns), decisively at configs[4] (thousands of rows).  From
-    // LVK_SPARSE_QR_MIN_ROWS (480) rows on it is always taken; between one fused Cholesky launch (160 rows) and that, it is taken
+    // The nodes cost 1-2 us per column of their union (one barrier-separated Householder step each, ~50..60 steps): measured on
+    // MI355X the compression pays once it saves more than a few 32-row Cholesky panels - not for the typical update of the
+    // north-star size (m ~ 110..260 rows of 9-row feature blocks over ~50 columns), decisively at configs[4] (thousands of rows).
+    // From sparse_qr_min_rows (480) rows on it is always taken; between one fused Cholesky launch (160 rows) and that, it is taken
     // when a cost model of both routes says so - the case that matters is a pruning update at configs[4] depth: ~400 one-row blocks
-    // that all live in the same 19 columns compress to 19 rows in one ~40 us level instead of a 400-row factorisation.
-    if (groups && e->sparse_qr && m > 160) {
+    // that all live in the same 19 columns compress to 19 rows in one ~60 us level instead of a 400-row factorisation.  Constants
+    // from profiles/r4_a_kernel_stats.csv: k_qr_sparse 124 us for a 55-column node over ~250 rows; k_chol_fused 31 us per 160-row
+    // super-panel (~5 us per 32-row panel + 8), two k_dgemm_sk launches (~12 us) per further super-panel.
+    if (groups && m > 160) {
         std::vector<QrPlanLevel> levels; int m2 = m;
         lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
         bool take = !levels.empty() && m2 + 32 <= m;
@@ -1237,10 +1245,10 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
             double t_qr = 0;                               // microseconds: launch + the longest node's reflector chain per level
             for (const QrPlanLevel& L : levels) {
                 double worst = 0;
-                for (const QrBlock& b : L.blocks) if (!b.copy) worst = std::max(worst, (double)std::min(b.ncols, b.in_rows) * (0.6 + 0.0025 * b.in_rows));
+                for (const QrBlock& b : L.blocks) if (!b.copy) worst = std::max(worst, (double)std::min(b.ncols, b.in_rows) * (1.0 + 0.004 * b.in_rows));
                 t_qr += 12.0 + worst;
             }
-            auto t_chol = [](int rows) { const int p = (rows + 31) / 32, sp = (rows + 159) / 160; return 8.0 * p + 22.0 * (sp - 1) + 1.5e-4 * rows * rows; };
+            auto t_chol = [](int rows) { const int p = (rows + 31) / 32, sp = (rows + 159) / 160; return 8.0 + 5.0 * p + 12.0 * (sp - 1) + 1.0e-4 * rows * rows; };
             take = t_qr + t_chol(m2) < t_chol(m);
         }
         if (take) {
@@ -1430,7 +1438,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             int rows_m = 0, rows_e = 0;
             auto own_of = [&](size_t k) { return sharded ? shard_owner(jb, k) : 0; };
             // unsharded: the row kernel (still held back by begin_defer) writes its rows straight into H_o - the slots are known now
-            const bool direct = !sharded && e->rows_direct;
+            const bool direct = !sharded;
             for (size_t k = j_msckf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + 1; rows_m += r; }
             for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + rows_e + 1; rows_e += 2; }
             int m = rows_m + rows_e;
@@ -1715,7 +1723,7 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
         const lvk_status st_rows = st;                       // sharded: a local failure still goes through the exchange (shard_stage1, pre_fail)
         TR(TR_PR_ROWS);
         std::vector<StackRow> map_o; std::vector<RowGroup> grp; int rows = 0;
-        const bool direct = !sharded && e->rows_direct;      // as in remove_lost_features: the row kernel writes H_o itself
+        const bool direct = !sharded;      // as in remove_lost_features: the row kernel writes H_o itself
         for (size_t k = 0; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows, (int)k, &grp, e, e->N, sharded ? shard_owner(jb, k) : 0); if (direct) jobs[k].hdev->dst_row1 = rows + 1; rows += r; }
         for (auto kv : e->map) for (int k = 0; k < nrm; ++k) kv.second.erase(rm[k]);
         {
@@ -1898,8 +1906,6 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     g_tr.on = getenv("LVK_EKF_TRACE") != nullptr;
     lvk_ekf* e = new (std::nothrow) lvk_ekf();
     if (!e) return LVK_ERR_DEVICE;
-    { const char* sq = getenv("LVK_SPARSE_QR"); if (sq) e->sparse_qr = atoi(sq) != 0; }
-    { const char* sq = getenv("LVK_SPARSE_QR_MIN_ROWS"); if (sq && atoi(sq) > 0) e->sparse_qr_min_rows = atoi(sq); }
     e->ctx = ctx; e->cfg = *cfg;
     const lvk_ekf_config& c = e->cfg;
     e->leg = c.calib_imu_instrinsic ? 46 : 22;
@@ -1950,7 +1956,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     e->down_feat = (sizeof(TriResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_dx = (e->down_feat + sizeof(FeatResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_flag = (e->down_dx + sizeof(double) * (size_t)(e->ld + 64) + 255) & ~(size_t)255;
-    e->down_info = e->down_flag + 256;                  // [0] first non-positive Cholesky pivot (+1), [1] a solver workgroup gave up waiting: written by k_chol_fused / k_chol_left
+    e->down_info = e->down_flag + 256;                  // [0] first non-positive Cholesky pivot (+1), [1] a solver workgroup gave up waiting: written by k_chol_fused
     e->down_cap = e->down_info + 256;
     ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
     if (ok) {
@@ -1962,7 +1968,6 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
         ok = ok && hipHostGetDevicePointer(&dd, e->h_down, 0) == hipSuccess && dd; e->dh_down = (char*)dd;
         e->d_triout = (TriResult*)e->dh_down;
         e->ws.info = (int*)(e->dh_down + e->down_info); memset(e->h_down + e->down_info, 0, 256);
-        if (const char* v = getenv("LVK_ROWS_DIRECT")) e->rows_direct = atoi(v) != 0;
     }
     if (!ok) { lvk_ekf_destroy(e); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_ekf_create: allocation failed"); }
     // initial covariance (larvio.cpp:163-186)
@@ -2343,7 +2348,7 @@ struct lvk_vio_pipe {
     int unknown_consume = 0;                            // queued or running updates whose erase count is not final yet
     // what submit() needs for an early count, all under mu: the filter is initialised, td after the last finished update, the state
     // time after the IMU batch of the last COUNTED job (the filter's own s.t belongs to its thread while a job runs)
-    bool steady = false; double td_pub = 0, state_t = 0, td_margin = 5e-4; bool early_on = true;
+    bool steady = false; double td_pub = 0, state_t = 0, td_margin = 5e-4;
     double td_steps[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n_td = 0;       // |td change| of the last eight finished updates
     int depth = 2;                                      // updates the caller may have in flight when a frame starts (LVK_PIPE_DEPTH; 1: never more than one update ahead - lower latency, the filter's thread waits for messages)
     long n_early = 0, n_early_wrong = 0;
@@ -2488,8 +2493,6 @@ lvk_status lvk_vio_pipe_create(lvk_frontend* fe, lvk_ekf* ekf, lvk_vio_pipe** ou
     lvk_vio_pipe* p = new lvk_vio_pipe();
     p->fe = fe; p->ekf = ekf; p->wmsg.resize(8192);
     p->logging = getenv("LVK_PIPE_LOG") != nullptr; if (p->logging) p->log.reserve(1 << 16);
-    if (const char* v = getenv("LVK_PIPE_EARLY_COUNT")) p->early_on = atoi(v) != 0;
-    if (const char* v = getenv("LVK_PIPE_TD_MARGIN")) { const double m = atof(v); if (m > 0) p->td_margin = m; }
     if (const char* v = getenv("LVK_PIPE_DEPTH")) { const int d = atoi(v); if (d >= 1 && d <= 3) p->depth = d; }      // 3 = the message ring minus the entry being written
     ekf->on_consumed = pipe_on_consumed; ekf->on_consumed_user = p;
     p->worker = std::thread(pipe_worker, p);
@@ -2563,7 +2566,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
             p->head += (size_t)batch_imu_count(e, ts + e->td, view, n_view, &t_after);
             p->state_t = t_after; p->td_pub = e->td; p->steady = true;
             job.precounted = true; counted = true; p->ev(4);
-        } else if (p->in_flight > 0 && p->early_on && p->steady && p->td_quiet()) {
+        } else if (p->in_flight > 0 && p->steady && p->td_quiet()) {
             // every queued job is counted (the wait above), so state_t is the state time this job will start from
             double ta = 0, tb2 = 0;
             const int n_lo = imu_erase_count(p->state_t, ts + p->td_pub - p->td_margin, e->imu_img_time_th, view, n_view, &ta);

@@ -14,6 +14,7 @@
 #include "lvk_internal.h"
 #include "be_dev.h"
 #include <vector>
+typedef double d4 __attribute__((ext_vector_type(4)));
 #include <algorithm>
 
 // ========================================================================= triangulation
@@ -140,13 +141,26 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
                                                             const double* __restrict__ P, int ldp, FilterFlags fl,
                                                             double* __restrict__ staging, int* __restrict__ ccols, FeatResult* __restrict__ out,
                                                             FeatResult* __restrict__ out_host /* optional mirror in device-mapped host memory */,
-                                                            double* __restrict__ H_out, int ldh, int ncols_out, double* __restrict__ r_out /* direct output, see the end */)
+                                                            double* __restrict__ H_out, int ldh, int ncols_out, double* __restrict__ r_out /* direct output, see the end */,
+                                                            int obs_stride /* > 0: job jb's observations sit at [jb * obs_stride, ..): their address does not wait for the job record */,
+                                                            int n_clones)
 {
     extern __shared__ double sh[];
     const int jb = blockIdx.x;
     if (jb >= n_jobs) return;
+    const int t = threadIdx.x;
+    // Everything the host staged for this job lives in the pinned upload arena, i.e. in HOST memory: job record -> observation
+    // ranks -> clone poses used to be three dependent PCIe round trips before the first flop.  SMALL batches lay the observations
+    // out at a fixed stride, so ranks / observations (and the whole clone table, a few KB, into LDS) are requested together with
+    // the job record: one trip.
+    int my_rank = 0; double my_z[2] = {0., 0.}, my_zv[2] = {0., 0.};
+    const bool pre = SMALL && obs_stride > 0;
+    if (pre && t < obs_stride) {
+        const int oi = jb * obs_stride + t;
+        my_rank = obs_rank[oi]; my_z[0] = obs_z[2 * oi]; my_z[1] = obs_z[2 * oi + 1]; my_zv[0] = obs_zv[2 * oi]; my_zv[1] = obs_zv[2 * oi + 1];
+    }
     const FeatJob job = jobs[jb];
-    const int t = threadIdx.x, M = job.n_obs;
+    const int M = job.n_obs;
     const int rows = 2 * M;
     const int nf = (job.type == JOB_MSCKF) ? 3 : 1;                  // columns of H_f
     const int c = (job.type == JOB_MSCKF) ? 7 + 6 * M : 7 + 6 + 6 * M + 1;
@@ -162,38 +176,46 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     double* T = SMALL ? Gl + FRS_ROWS * FRS_COLS : Gg + (size_t)rows * c;
     double* rr = SMALL ? Gl + 2 * FRS_ROWS * FRS_COLS : rrg;
     double* Pcc = Gl + 2 * FRS_ROWS * FRS_COLS + FRS_ROWS;           // SMALL only: [c][FRS_PLD]
+    double* cl_s = Pcc + FRS_COLS * FRS_PLD;                          // SMALL only: the clone table (n_clones x 22 doubles)
+    int* srank = (int*)(cl_s + (size_t)n_clones * (sizeof(CloneDev) / sizeof(double)));   // SMALL only: clone rank of every observation
+    if (SMALL) {
+        for (int e = t; e < n_clones * (int)(sizeof(CloneDev) / sizeof(double)); e += FR_THREADS) cl_s[e] = ((const double*)clones)[e];
+        if (!pre && t < M) {
+            const int oi = job.obs_off + t;
+            my_rank = obs_rank[oi]; my_z[0] = obs_z[2 * oi]; my_z[1] = obs_z[2 * oi + 1]; my_zv[0] = obs_zv[2 * oi]; my_zv[1] = obs_zv[2 * oi + 1];
+        }
+        if (t < M) srank[t] = my_rank;
+        __syncthreads();
+    }
     // ---- zero the block, write the compact column map
     for (int e = t; e < rows * c; e += FR_THREADS) G[e] = 0.;
     for (int e = t; e < c; e += FR_THREADS) {
         int col;
         if (e < 7) col = 15 + e;
-        else if (job.type == JOB_MSCKF) col = fl.leg_dim + 6 * obs_rank[job.obs_off + (e - 7) / 6] + (e - 7) % 6;
+        else if (job.type == JOB_MSCKF) col = fl.leg_dim + 6 * (SMALL ? srank[(e - 7) / 6] : obs_rank[job.obs_off + (e - 7) / 6]) + (e - 7) % 6;
         else if (e < 13) col = fl.leg_dim + 6 * job.anchor_rank + (e - 7);
-        else if (e < 13 + 6 * M) col = fl.leg_dim + 6 * obs_rank[job.obs_off + (e - 13) / 6] + (e - 13) % 6;
+        else if (e < 13 + 6 * M) col = fl.leg_dim + 6 * (SMALL ? srank[(e - 13) / 6] : obs_rank[job.obs_off + (e - 13) / 6]) + (e - 13) % 6;
         else col = job.fcol;
         cc[e] = col;
     }
     __syncthreads();
+    // P_cc = P[cc, cc]: up to 32 entries per thread, every load issued before the first store - and the stores wait until the
+    // Jacobians below are done (their threads would otherwise sit on the loads' return before starting)
+    constexpr int PER = SMALL ? (FRS_COLS * FRS_COLS + FR_THREADS - 1) / FR_THREADS : 1;
+    double pv[PER];
     if (SMALL && job.want_gate) {
-        // P_cc = P[cc, cc]: up to 32 entries per thread, every load issued before the first store
-        constexpr int PER = (FRS_COLS * FRS_COLS + FR_THREADS - 1) / FR_THREADS;
-        double pv[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int e = t + FR_THREADS * u;
             if (e < c * c) { const int i = e / c, j = e - i * c; pv[u] = P[(size_t)cc[i] * ldp + cc[j]]; }
         }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int e = t + FR_THREADS * u;
-            if (e < c * c) { const int i = e / c, j = e - i * c; Pcc[i * FRS_PLD + j] = pv[u]; }
-        }
     }
     // ---- per-observation Jacobians (one thread per observation)
     if (t < M) {
         const int oi = job.obs_off + t;
-        const CloneDev ck = clones[obs_rank[oi]];
-        const double z[2] = {obs_z[2 * oi], obs_z[2 * oi + 1]};
+        const CloneDev ck = SMALL ? *(const CloneDev*)(cl_s + (size_t)my_rank * (sizeof(CloneDev) / sizeof(double))) : clones[obs_rank[oi]];
+        const double z[2] = {SMALL ? my_z[0] : obs_z[2 * oi], SMALL ? my_z[1] : obs_z[2 * oi + 1]};
+        const double zvv[2] = {SMALL ? my_zv[0] : obs_zv[2 * oi], SMALL ? my_zv[1] : obs_zv[2 * oi + 1]};
         double Hx[12], He[12], r2[2];
         if (job.type == JOB_MSCKF) {
             double hf[6];
@@ -201,25 +223,32 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             for (int a = 0; a < 2; ++a) {
                 double* row = G + (size_t)(2 * t + a) * c;
                 for (int j = 0; j < 6; ++j) row[j] = He[a * 6 + j];
-                if (fl.estimate_td) row[6] = obs_zv[2 * oi + a];
+                if (fl.estimate_td) row[6] = zvv[a];
                 for (int j = 0; j < 6; ++j) row[7 + 6 * t + j] = Hx[a * 6 + j];
                 for (int j = 0; j < 3; ++j) Hf[(2 * t + a) * 3 + j] = hf[a * 3 + j];
                 rr[2 * t + a] = r2[a];
             }
         } else {
-            const CloneDev ca = clones[job.anchor_rank];
+            const CloneDev ca = SMALL ? *(const CloneDev*)(cl_s + (size_t)job.anchor_rank * (sizeof(CloneDev) / sizeof(double))) : clones[job.anchor_rank];
             double hf[2], Ha[12];
             d_ekf_obs_jacobian(ck, ca, job, z, fl.if_fej, hf, Ha, Hx, He, r2);
             for (int a = 0; a < 2; ++a) {
                 double* row = G + (size_t)(2 * t + a) * c;
                 for (int j = 0; j < 6; ++j) row[j] = He[a * 6 + j];
-                if (fl.estimate_td) row[6] = obs_zv[2 * oi + a];
+                if (fl.estimate_td) row[6] = zvv[a];
                 for (int j = 0; j < 6; ++j) row[7 + j] = Ha[a * 6 + j];
                 for (int j = 0; j < 6; ++j) row[13 + 6 * t + j] = Hx[a * 6 + j];
                 row[c - 1] = hf[a];
                 Hf[(2 * t + a) * 3] = hf[a];
                 rr[2 * t + a] = r2[a];
             }
+        }
+    }
+    if (SMALL && job.want_gate) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = t + FR_THREADS * u;
+            if (e < c * c) { const int i = e / c, j = e - i * c; Pcc[i * FRS_PLD + j] = pv[u]; }
         }
     }
     __syncthreads();
@@ -301,6 +330,45 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             S[a * k + b] = s + (a == b ? fl.sigma2 : 0.);
         }
         __syncthreads();
+        if (SMALL) {
+            // gamma = r'^T S^-1 r' on ONE wavefront: the bordered matrix [S r'; r'^T 0] (k + 1 <= 14 rows) sits in a 16x16 FP64-MFMA
+            // accumulator tile and is eliminated by k rank-1 updates (row j of the tile is already laid out as K-slot j & 3 of both
+            // operands, see chol32_inv_mfma in be_linalg.hip); what is left in the corner is -r'^T S^-1 r'.  Replaces a column-by-column
+            // Cholesky with two barriers per column and a one-thread forward substitution (~4.5 us of the kernel's chain).
+            double* y = S + k * k;
+            if (t < 64) {
+                const int cth = t & 15, gth = t >> 4;
+                d4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = gth + 4 * r, col = cth;
+                    double v;
+                    if (row < k && col < k) v = S[(row > col ? row : col) * k + (row > col ? col : row)];
+                    else if (row == k && col < k) v = rr[first_row + col];
+                    else if (col == k && row < k) v = rr[first_row + row];
+                    else v = (row == col && row > k) ? 1.0 : 0.0;
+                    acc[r] = v;
+                }
+                int bad = 0;
+#pragma unroll
+                for (int j = 0; j < 14; ++j) {
+                    if (j < k) {
+                        const int q = j >> 2, gj = j & 3;
+                        double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(acc[q]), 16 * gj + j), __builtin_amdgcn_readlane(__double2loint(acc[q]), 16 * gj + j));
+                        if (!(piv > 0.)) { bad = 1; piv = 1.0; }
+                        const double rinv = 1.0 / sqrt(piv);
+                        const double v = (gth == gj && cth >= j) ? acc[q] * rinv : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
+                    }
+                }
+                const int lk = 16 * (k & 3) + k;
+                const double corner = (k >> 2) == 0 ? acc[0] : (k >> 2) == 1 ? acc[1] : (k >> 2) == 2 ? acc[2] : acc[3];
+                const double g = -__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(corner), lk), __builtin_amdgcn_readlane(__double2loint(corner), lk));
+                if (t == 0) y[k] = bad ? 1e300 : g;
+            }
+            __syncthreads();
+            gamma = y[k];
+        } else {
         // Cholesky in LDS (column by column), then forward substitution on r'
         int fail = 0;
         for (int j = 0; j < k; ++j) {
@@ -331,6 +399,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             }
             __syncthreads();
             gamma = y[k];
+        }
         }
     }
     if (SMALL) {
@@ -394,21 +463,23 @@ lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_
 
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging,
-                                   int* d_ccols, FeatResult* d_out, FeatResult* d_out_host, double* d_Hout, int ldh, int ncols_out, double* d_rout)
+                                   int* d_ccols, FeatResult* d_out, FeatResult* d_out_host, double* d_Hout, int ldh, int ncols_out, double* d_rout,
+                                   int obs_stride, int n_clones)
 {
     if (n_jobs <= 0) return LVK_OK;
     const size_t base = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
     // max_rows = 2 M_max; compact columns <= 7 + 6 + 6 M_max + 1
     const bool small = max_rows <= FRS_ROWS && 14 + 3 * max_rows <= FRS_COLS;
-    const size_t shmem = base + (small ? sizeof(double) * ((size_t)2 * FRS_ROWS * FRS_COLS + FRS_ROWS + (size_t)FRS_COLS * FRS_PLD) : 0);
+    const size_t shmem = base + (small ? sizeof(double) * ((size_t)2 * FRS_ROWS * FRS_COLS + FRS_ROWS + (size_t)FRS_COLS * FRS_PLD + (size_t)n_clones * (sizeof(CloneDev) / sizeof(double)) + 16) : 0);
     if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
     if (small) {
+        if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 10, k_feature_rows<true>, shmem);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<true>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout, obs_stride, n_clones);
     } else {
         LVK_LDS_OPTIN(ctx, 1, k_feature_rows<false>, shmem);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<false>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout, 0, n_clones);
     }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -509,7 +580,7 @@ extern "C" lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* 
     double* d_staging = (double*)d_st; int* d_ccols = (int*)(d_st + ((sizeof(double) * stage + 63) & ~(size_t)63));
     FeatResult* d_fout = (FeatResult*)(d_out + o_fo);
     lvk_status st = lvk_launch_feature_rows(ctx, (const FeatJob*)(d_in + o_job), n_feats, max_rows, (const CloneDev*)(d_in + o_cl), (const int*)(d_in + o_rk),
-                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr, nullptr, 0, 0, nullptr);
+                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr, nullptr, 0, 0, nullptr, 0, n_clones);
     if (st != LVK_OK) return st;
     std::vector<FeatResult> res(n_feats);
     LVK_HIP(ctx, hipMemcpyAsync(res.data(), d_fout, sizeof(FeatResult) * n_feats, hipMemcpyDeviceToHost, ctx->stream));

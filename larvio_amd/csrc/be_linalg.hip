@@ -194,18 +194,24 @@ __global__ void __launch_bounds__(CPR_THREADS) k_cov_propagate(double* __restric
 //                                   whose source is an IMU row (the six duplicated ones included), both orientations
 //   last workgroup                  the IMU block itself: sym(Phi P_II Phi^T + Q), scattered to all (a, b) with both sources inside
 // ilist / clist: the output indices whose source is < L / >= L (host-built, ascending).  Sums run over k ascending, exactly as
-// k_cov_propagate's, so the two routes give the same bits.  15 us (one workgroup) + a launch gap + 5 us (gather) -> one ~6 us launch.
+// k_cov_propagate's, so the two routes give the same bits.
 #define CPG_STRIPS 8
+// ix = [idx (n_out) | ilist (n_i) | clist (n_c)], n_i + n_c = n_out: ONE array in the pinned upload arena.  Every workgroup copies what it
+// needs of it (and Phi, Q) into LDS with its first loads, all in flight together: the arena is host memory, and a chain of dependent
+// reads through it (clist -> idx -> Pin) costs a PCIe round trip per link - the first version of this kernel took 18.6 us that way.
 __global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __restrict__ Pin, int ldin, double* __restrict__ Pout, int ldout,
-                                                             const int* __restrict__ idx, int n_out, int L, const double* __restrict__ phiq,
-                                                             const int* __restrict__ ilist, int n_i, const int* __restrict__ clist, int n_c)
+                                                             const int* __restrict__ ix, int n_out, int n_i, int L, const double* __restrict__ phiq)
 {
     extern __shared__ double sh[];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, n_c = n_out - n_i;
     if ((int)blockIdx.x < n_out) {
-        const int a = blockIdx.x, i = idx[a];
+        int* sidx = (int*)sh;
+        const int a = blockIdx.x;
+        for (int e = t; e < n_out; e += 256) sidx[e] = ix[e];
+        __syncthreads();
+        const int i = sidx[a];
         if (i < L) return;
-        for (int b = t; b < n_out; b += 256) { const int j = idx[b]; if (j >= L) Pout[(size_t)a * ldout + b] = Pin[(size_t)i * ldin + j]; }
+        for (int b = t; b < n_out; b += 256) { const int j = sidx[b]; if (j >= L) Pout[(size_t)a * ldout + b] = Pin[(size_t)i * ldin + j]; }
         return;
     }
     const int role = (int)blockIdx.x - n_out;
@@ -215,8 +221,12 @@ __global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __re
         if (cw <= 0) return;
         double* R = sh + L * L;                         // L x cc : Pin[0:L, source columns of the chunk]
         double* W = R + L * cc;                         // L x cc : Phi R
+        int* sidx = (int*)(W + L * cc);                 // the whole index array
+        for (int e = t; e < 2 * n_out; e += 256) sidx[e] = ix[e];
         for (int e = t; e < L * L; e += 256) Phi[e] = phiq[e];
-        for (int e = t; e < L * cw; e += 256) { const int k = e / cw, q = e - k * cw; R[k * cc + q] = Pin[(size_t)k * ldin + idx[clist[c0 + q]]]; }
+        __syncthreads();
+        const int* il = sidx + n_out; const int* cl = il + n_i;
+        for (int e = t; e < L * cw; e += 256) { const int k = e / cw, q = e - k * cw; R[k * cc + q] = Pin[(size_t)k * ldin + sidx[cl[c0 + q]]]; }
         __syncthreads();
         for (int e = t; e < L * cw; e += 256) {
             const int i = e / cw, q = e - i * cw; double s = 0.;
@@ -225,13 +235,15 @@ __global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __re
         }
         __syncthreads();
         for (int e = t; e < n_i * cw; e += 256) {
-            const int ai = e / cw, q = e - ai * cw, a = ilist[ai], b = clist[c0 + q];
-            const double v = W[idx[a] * cc + q];
+            const int ai = e / cw, q = e - ai * cw, a = il[ai], b = cl[c0 + q];
+            const double v = W[sidx[a] * cc + q];
             Pout[(size_t)a * ldout + b] = v; Pout[(size_t)b * ldout + a] = v;
         }
         return;
     }
     double* Q = sh + L * L; double* PII = Q + L * L; double* T = PII + L * L; double* Pn = T + L * L;
+    int* sidx = (int*)(Pn + L * L);
+    for (int e = t; e < 2 * n_out; e += 256) sidx[e] = ix[e];
     for (int e = t; e < 2 * L * L; e += 256) sh[e] = phiq[e];
     for (int e = t; e < L * L; e += 256) { const int i = e / L, j = e - i * L; PII[e] = Pin[(size_t)i * ldin + j]; }
     __syncthreads();
@@ -250,9 +262,10 @@ __global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __re
         Pn[i * L + j] = v; Pn[j * L + i] = v;
     }
     __syncthreads();
+    const int* il = sidx + n_out;
     for (int e = t; e < n_i * n_i; e += 256) {
-        const int ai = e / n_i, bi = e - ai * n_i, a = ilist[ai], b = ilist[bi];
-        Pout[(size_t)a * ldout + b] = Pn[idx[a] * L + idx[b]];
+        const int ai = e / n_i, bi = e - ai * n_i, a = il[ai], b = il[bi];
+        Pout[(size_t)a * ldout + b] = Pn[sidx[a] * L + sidx[b]];
     }
 }
 
@@ -352,7 +365,7 @@ __global__ void __launch_bounds__(256) k_cov_append_corner(double* __restrict__ 
 }
 
 
-// ------------------------------------------------------------------------- blocked Cholesky + forward substitution, multi-workgroup
+// ------------------------------------------------------------------------- Cholesky + forward substitution, multi-workgroup
 #define CP_NB 32
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {   // lane is a compile-time constant after unrolling: two v_readlane_b32
@@ -367,20 +380,6 @@ __device__ __forceinline__ double rsqrt_refined(double x)
     return y;
 }
 
-// Left-looking, ONE launch per 32-column panel.
-// Every workgroup first brings its own piece up to date with all previous panels on the FP64 matrix cores
-// (S rows: A[R, p] -= L[R, 0:j0] L[p, 0:j0]^T ; B columns: B[p, C] -= L[p, 0:j0] W[0:j0, C]) and, redundantly, the 32x32 diagonal
-// block; one wavefront factors the block in registers AND inverts the factor (column c of L11^-1 in lane c, L broadcast with
-// v_readlane); the triangular solves then become two small MFMA products with L11^-1 (X = A L11^-T, W_p = L11^-1 B_p).
-// Compared with a right-looking pair (panel + trailing update) this halves the launches on the dependent chain and has no
-// per-thread forward substitutions (496 dependent FMAs each).
-#ifdef LVK_CHOL_TIMING
-static __device__ unsigned long long g_ch_tick[16];
-#define CH_TICK(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ch_tick[k] = wall_clock64(); } while (0)
-extern "C" void lvk_debug_chol_ticks(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_tick), sizeof(unsigned long long) * 16); }
-#else
-#define CH_TICK(k) do { } while (0)
-#endif
 // One wavefront: Y = L^-1 for the Cholesky factor L of the 32x32 block in D (full symmetric block; identity padding beyond nb).
 // Nothing downstream reads L_pp itself (the solves are products with L_pp^-1), so only Y is produced.
 // The block lives in three FP64-MFMA accumulator tiles (lane (g = lane >> 4, c = lane & 15), register r <-> T[g + 4 r][c]):
@@ -441,168 +440,6 @@ __device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (
 #pragma unroll
     for (int r = 0; r < 4; ++r) Y[16 + g + 4 * r][c] = -yl[r];
     __builtin_amdgcn_wave_barrier();
-}
-
-#define CL_KC 128
-__global__ void __launch_bounds__(256) k_chol_left(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
-                                                  int j0, int n_sblocks, int* __restrict__ info)
-{
-    __shared__ double Ld[CP_NB][CP_NB + 1], Yi[CP_NB][CP_NB + 1];
-    __shared__ double Cs[4][CP_NB][CP_NB + 1];
-    __shared__ __attribute__((aligned(32))) double Lp[CP_NB][CL_KC + 4];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
-    const int nb = min(CP_NB, m - j0);
-    const bool s_role = (int)blockIdx.x < n_sblocks;
-    CH_TICK(0);
-    // ---- own piece, brought up to date with panels 0..p-1 (kept in the accumulators)
-    d4 c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.};
-    const int rbase = j0 + nb + blockIdx.x * 64 + wave * 16;                     // S role: 16 rows per wavefront
-    const int bc = (blockIdx.x - n_sblocks) * 64 + wave * 16 + i16;             // B role: 16 columns per wavefront
-    // K (= all previous panels) is walked in chunks of CL_KC columns.  Per chunk the 32 rows L[p, chunk] - the operand every
-    // wavefront shares - are staged in LDS by all threads with four 32-byte loads each, and each wavefront's private operand is
-    // fetched with all its loads in flight at once: S and B were just written by other XCDs, so a dependent load costs a trip
-    // to the memory side (~1.5 us); what matters is the number of round trips, not the bytes.
-    // Lane (i, kk) takes the four CONSECUTIVE k = k0 + 4 kk + q and feeds element q to the q-th MFMA - a permutation of the
-    // summation index that both operands share.
-    const d4 zero4 = {0., 0., 0., 0.};
-    d4 dacc = {0., 0., 0., 0.};
-    const int ti = wave >> 1, tj = wave & 1;
-    // the current values of the own piece and of the diagonal tile are fetched up front, in the shadow of the first chunk
-    double own0[4], own1[4], dcur[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (s_role) {
-            const int row = rbase + kk + 4 * r;
-            own0[r] = (row < m && i16 < nb) ? S[(size_t)row * lds_ + j0 + i16] : 0.;
-            own1[r] = (row < m && 16 + i16 < nb) ? S[(size_t)row * lds_ + j0 + 16 + i16] : 0.;
-        } else {
-            const int r0 = kk + 4 * r, r1 = 16 + kk + 4 * r;
-            own0[r] = (r0 < nb && bc < nbcols) ? B[(size_t)(j0 + r0) * ldb + bc] : 0.;
-            own1[r] = (r1 < nb && bc < nbcols) ? B[(size_t)(j0 + r1) * ldb + bc] : 0.;
-        }
-        const int row = 16 * ti + kk + 4 * r, col = 16 * tj + i16;
-        dcur[r] = (row < nb && col < nb) ? S[(size_t)(j0 + row) * lds_ + j0 + col] : (row == col ? 1.0 : 0.0);
-    }
-    for (int kc = 0; kc < j0; kc += CL_KC) {
-        const int kw = min(CL_KC, j0 - kc);
-        {
-            const int row = t >> 3, seg = (t & 7) * 16;
-            const bool ok = j0 + row < m;
-            const double* src = S + (size_t)(ok ? j0 + row : 0) * lds_ + kc + seg;
-            d4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (ok && seg + 4 * q < kw) ? *(const d4*)(src + 4 * q) : zero4;
-            if (kc) __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *(d4*)&Lp[row][seg + 4 * q] = v[q];
-        }
-        if (s_role) {
-            const int ar = rbase + i16;
-            const double* pa = S + (size_t)(ar < m ? ar : 0) * lds_ + kc + 4 * kk;
-            d4 av[CL_KC / 16];
-#pragma unroll
-            for (int u = 0; u < CL_KC / 16; ++u) av[u] = (ar < m && 16 * u < kw) ? *(const d4*)(pa + 16 * u) : zero4;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < CL_KC / 16; ++u) {
-                if (16 * u >= kw) break;                                             // FP64 MFMA is 64 cycles: no padded K
-                const d4 v0 = *(const d4*)&Lp[i16][16 * u + 4 * kk], v1 = *(const d4*)&Lp[16 + i16][16 * u + 4 * kk];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][q], v0[q], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][q], v1[q], c1, 0, 0, 0);
-                }
-            }
-        } else {
-            const double* pb = B + (size_t)(kc + 4 * kk) * ldb + (bc < nbcols ? bc : 0);
-            double bv[CL_KC / 16][4];
-#pragma unroll
-            for (int u = 0; u < CL_KC / 16; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[u][q] = (bc < nbcols && 16 * u < kw) ? pb[(size_t)(16 * u + q) * ldb] : 0.;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < CL_KC / 16; ++u) {
-                if (16 * u >= kw) break;
-                const d4 v0 = *(const d4*)&Lp[i16][16 * u + 4 * kk], v1 = *(const d4*)&Lp[16 + i16][16 * u + 4 * kk];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0[q], bv[u][q], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[q], bv[u][q], c1, 0, 0, 0);
-                }
-            }
-        }
-        // the diagonal block's tile of this wavefront: both operands are in LDS
-#pragma unroll
-        for (int u = 0; u < CL_KC / 16; ++u) {
-            if (16 * u >= kw) break;
-            const d4 va = *(const d4*)&Lp[16 * ti + i16][16 * u + 4 * kk], vb = *(const d4*)&Lp[16 * tj + i16][16 * u + 4 * kk];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[q], vb[q], dacc, 0, 0, 0);
-        }
-    }
-    CH_TICK(1);
-    if (s_role) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Cs[wave][kk + 4 * r][i16] = own0[r] - c0[r];                           // Cs[row 0..15][col 0..31]
-            Cs[wave][kk + 4 * r][16 + i16] = own1[r] - c1[r];
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int r0 = kk + 4 * r, r1 = 16 + kk + 4 * r;
-            Cs[wave][r0][i16] = own0[r] - c0[r];                                   // Cs[row k 0..31][col 0..15]
-            Cs[wave][r1][i16] = own1[r] - c1[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + kk + 4 * r, col = 16 * tj + i16;
-        Ld[row][col] = (row < nb && col < nb) ? dcur[r] - dacc[r] : dcur[r];
-    }
-    __syncthreads();
-    CH_TICK(2);
-    if (wave == 0) chol32_inv_mfma(Ld, Yi, nb, lane, info, j0, blockIdx.x == 0);
-    CH_TICK(5);
-    __syncthreads();
-    CH_TICK(6);
-    // The diagonal block of the factor is NOT written back to S: every workgroup of this launch reads A_pp from there at its start, and
-    // a workgroup that is dispatched late (other streams keep CUs busy) would pick up L_pp instead - which is what happened, rarely, in
-    // the pipelined driver at configs[4] until round 2.  Nothing downstream reads the diagonal blocks (the solves use L_pp^-1 from LDS).
-    // ---- triangular solves as products with L11^-1
-    d4 o0 = {0., 0., 0., 0.}, o1 = {0., 0., 0., 0.};
-    if (s_role) {                                                                  // X = C Y^T : X[r][c] = sum_k C[r][k] Y[c][k]
-#pragma unroll
-        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
-            const double a = Cs[wave][i16][k0 + kk];
-            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yi[i16][k0 + kk], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yi[16 + i16][k0 + kk], o1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rbase + kk + 4 * r;
-            if (row < m && i16 < nb) S[(size_t)row * lds_ + j0 + i16] = o0[r];
-            if (row < m && 16 + i16 < nb) S[(size_t)row * lds_ + j0 + 16 + i16] = o1[r];
-        }
-    } else {                                                                       // W = Y C : W[a][j] = sum_k Y[a][k] C[k][j]
-#pragma unroll
-        for (int k0 = 0; k0 < CP_NB; k0 += 4) {
-            const double b = Cs[wave][k0 + kk][i16];
-            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yi[i16][k0 + kk], b, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Yi[16 + i16][k0 + kk], b, o1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int r0 = kk + 4 * r, r1 = 16 + kk + 4 * r;
-            if (r0 < nb && bc < nbcols) B[(size_t)(j0 + r0) * ldb + bc] = o0[r];
-            if (r1 < nb && bc < nbcols) B[(size_t)(j0 + r1) * ldb + bc] = o1[r];
-        }
-    }
-    CH_TICK(7);
-#ifdef LVK_CHOL_TIMING
-    if (threadIdx.x == 0 && blockIdx.x == 0) { g_ch_tick[8] = j0; g_ch_tick[9] = m; }
-#endif
 }
 
 // ------------------------------------------------------------------------- fused Cholesky + solve, m <= 160: ONE launch
@@ -832,57 +669,37 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
 //   [S11 . ; S21 S22]:  the fused launch factors S11 = L11 L11^T, solves W1 = L11^-1 B1 and - through the second right-hand side, the
 //   block S12 = S21^T that k_dgemm left to the right of S11 (S is computed in full) - L21^T = L11^-1 S21^T, in place;
 //   then S22 -= L21 L21^T and B2 -= L21 W1 on the FP64 matrix cores, and the recursion continues on (S22, B2).
-// Against one k_chol_left launch per 32 columns (~22 us each, 6..14 of them per update above 160 rows) this is ~(40 + 20) us per 160 rows.
 static lvk_status launch_chol_solve(lvk_context* ctx, double* S, int lds_, int m, double* B, int ldb, int nbcols, int* info)
 {
     hipStream_t s = ctx->stream;
-    if (ctx->chol_mode == 0) { const char* v = getenv("LVK_CHOL_FUSED"); ctx->chol_mode = (v && atoi(v) == 0) ? 2 : (v && atoi(v) == 2) ? 3 : 1; }   // 3: fused only up to 160 rows (A/B runs)
     const int MB = CF_MAXB * CP_NB;
-    if ((ctx->chol_mode == 1 || (ctx->chol_mode == 3 && m <= MB))) {
-        const size_t ybytes = sizeof(double) * CF_MAXB * CP_NB * CP_NB;
-        const bool fresh = ctx->scratch_bytes[12] < ybytes + 64;
-        char* ws = (char*)lvk_ctx_scratch(ctx, 12, ybytes + 64);
-        if (!ws) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
-        int* flag = (int*)(ws + ybytes);
-        if (fresh || ctx->chol_epoch > (1 << 27)) { LVK_HIP(ctx, hipMemsetAsync(flag, 0, 64, s)); ctx->chol_epoch = 0; }
-        const size_t lds_f = sizeof(double) * (size_t)(CF_MAXB * (CF_MAXB + 1) / 2 + 2) * CP_NB * CF_LD;
-        const size_t lds_s = sizeof(double) * (size_t)4 * (CF_MAXB * CP_NB + CP_NB) * CF_WLD;
-        const size_t shm = lds_f > lds_s ? lds_f : lds_s;
-        // Residency: 1 + ceil(nbcols / 64) (+ ceil(rest / 64)) workgroups (<= 12 at the largest state the filter accepts), one per CU
-        // because of their LDS; the factor workgroup never waits for anybody, so solvers that were dispatched ahead of it only spin
-        // until it gets a CU - no ordering assumption is needed for progress, only for speed.  (The LDS request is the larger of
-        // the two roles': a launch has one size.)  If the device refuses the LDS opt-in or a launch, this context falls back for
-        // good to one launch per panel (k_chol_left) instead of failing the update - and with it, stickily, the filter.
-        bool ok = true;
-        if (ctx->lds_optin[8] < shm) {
-            if (hipFuncSetAttribute((const void*)k_chol_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess) ctx->lds_optin[8] = shm;
-            else { (void)hipGetLastError(); ok = false; }
+    const size_t ybytes = sizeof(double) * CF_MAXB * CP_NB * CP_NB;
+    const bool fresh = ctx->scratch_bytes[12] < ybytes + 64;
+    char* ws = (char*)lvk_ctx_scratch(ctx, 12, ybytes + 64);
+    if (!ws) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
+    int* flag = (int*)(ws + ybytes);
+    if (fresh || ctx->chol_epoch > (1 << 27)) { LVK_HIP(ctx, hipMemsetAsync(flag, 0, 64, s)); ctx->chol_epoch = 0; }
+    const size_t lds_f = sizeof(double) * (size_t)(CF_MAXB * (CF_MAXB + 1) / 2 + 2) * CP_NB * CF_LD;
+    const size_t lds_s = sizeof(double) * (size_t)4 * (CF_MAXB * CP_NB + CP_NB) * CF_WLD;
+    const size_t shm = lds_f > lds_s ? lds_f : lds_s;
+    // Residency: 1 + ceil(nbcols / 64) (+ ceil(rest / 64)) workgroups (<= 12 at the largest state the filter accepts), one per CU
+    // because of their LDS (144 KB of the CU's 160: the launch has one size, the larger of the two roles'); the factor workgroup
+    // never waits for anybody, so solvers that were dispatched ahead of it only spin until it gets a CU - no ordering assumption
+    // is needed for progress, only for speed.
+    LVK_LDS_OPTIN(ctx, 8, k_chol_fused, shm);
+    for (int off = 0; off < m; off += MB) {
+        const int mb = (m - off) < MB ? (m - off) : MB, rest = m - off - mb;
+        double* S11 = S + (size_t)off * lds_ + off; double* B1 = B + (size_t)off * ldb;
+        double* S12 = S11 + mb;                       // rows off..off+mb-1, columns off+mb..m-1: A21^T
+        const int base = 8 * ctx->chol_epoch++;
+        hipLaunchKernelGGL(k_chol_fused, dim3(1 + (nbcols + 63) / 64 + (rest + 63) / 64), dim3(256), shm, s, S11, lds_, mb, B1, ldb, nbcols,
+                           S12, lds_, rest, off, (double*)ws, flag, base, info);
+        LVK_LAUNCH_CHECK(ctx);
+        if (rest > 0) {
+            double* S22 = S + (size_t)(off + mb) * lds_ + off + mb; double* B2 = B + (size_t)(off + mb) * ldb;
+            launch_dgemm<true, false>(s, rest, rest, mb, S12, lds_, S12, lds_, S22, lds_, -1.0, 1.0, 0.0);        // S22 -= L21 L21^T
+            launch_dgemm<true, false>(s, rest, nbcols, mb, S12, lds_, B1, ldb, B2, ldb, -1.0, 1.0, 0.0);          // B2 -= L21 W1
         }
-        int off = 0;
-        while (ok && off < m) {
-            const int mb = (m - off) < MB ? (m - off) : MB, rest = m - off - mb;
-            double* S11 = S + (size_t)off * lds_ + off; double* B1 = B + (size_t)off * ldb;
-            double* S12 = S11 + mb;                       // rows off..off+mb-1, columns off+mb..m-1: A21^T
-            const int base = 8 * ctx->chol_epoch++;
-            hipLaunchKernelGGL(k_chol_fused, dim3(1 + (nbcols + 63) / 64 + (rest + 63) / 64), dim3(256), shm, s, S11, lds_, mb, B1, ldb, nbcols,
-                               S12, lds_, rest, off, (double*)ws, flag, base, info);
-            if (hipGetLastError() != hipSuccess) { ok = false; break; }
-            if (rest > 0) {
-                double* S22 = S + (size_t)(off + mb) * lds_ + off + mb; double* B2 = B + (size_t)(off + mb) * ldb;
-                launch_dgemm<true, false>(s, rest, rest, mb, S12, lds_, S12, lds_, S22, lds_, -1.0, 1.0, 0.0);        // S22 -= L21 L21^T
-                launch_dgemm<true, false>(s, rest, nbcols, mb, S12, lds_, B1, ldb, B2, ldb, -1.0, 1.0, 0.0);          // B2 -= L21 W1
-            }
-            off += mb;
-        }
-        if (ok) return LVK_OK;
-        if (off > 0) return lvk_set_error(ctx, LVK_ERR_DEVICE, "fused Cholesky: a launch failed after the first super-panel");   // S is half factored: no clean fallback
-        ctx->chol_mode = 2;
-    }
-    for (int j0 = 0; j0 < m; j0 += CP_NB) {
-        const int nb = (m - j0) < CP_NB ? (m - j0) : CP_NB;
-        const int rest = m - j0 - nb;
-        const int n_sblocks = (rest + 63) / 64, n_bblocks = (nbcols + 63) / 64;
-        hipLaunchKernelGGL(k_chol_left, dim3(n_sblocks + n_bblocks), dim3(256), 0, s, S, lds_, m, B, ldb, nbcols, j0, n_sblocks, info);
     }
     return LVK_OK;
 }
@@ -922,16 +739,16 @@ lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, 
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
-lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n_out, int L,
-                                    const double* d_phiq, const int* d_ilist, int n_i, const int* d_clist, int n_c)
+lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_ix, int n_out, int n_i, int L,
+                                    const double* d_phiq)
 {
-    const int cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS;
-    const size_t strip = sizeof(double) * ((size_t)L * L + (size_t)2 * L * (cc > 0 ? cc : 1)), core = sizeof(double) * (size_t)5 * L * L;
+    const int n_c = n_out - n_i, cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS;
+    const size_t ints = sizeof(int) * (size_t)2 * n_out + 16;
+    const size_t strip = sizeof(double) * ((size_t)L * L + (size_t)2 * L * (cc > 0 ? cc : 1)) + ints, core = sizeof(double) * (size_t)5 * L * L + ints;
     const size_t shmem = strip > core ? strip : core;
     if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n_out);
     if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 9, k_cov_propagate_gather, shmem);
-    hipLaunchKernelGGL(k_cov_propagate_gather, dim3(n_out + CPG_STRIPS + 1), dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, d_idx, n_out, L, d_phiq,
-                       d_ilist, n_i, d_clist, n_c);
+    hipLaunchKernelGGL(k_cov_propagate_gather, dim3(n_out + CPG_STRIPS + 1), dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, d_ix, n_out, n_i, L, d_phiq);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

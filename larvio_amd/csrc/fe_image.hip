@@ -41,18 +41,17 @@ void* lvk_ctx_scratch(lvk_context* ctx, int slot, size_t bytes)
 // LVK_CLAHE_S overrides it for experiments.
 __global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int sstride,
                                                   int tw, int th, int tiles_x, int clip, float lut_scale,
-                                                  uint8_t* __restrict__ lut, int S, int* __restrict__ ghist, int* __restrict__ tickets, int vec4)
+                                                  uint8_t* __restrict__ lut, int vec4)
 {
     __shared__ int sh[4][256];
     __shared__ int hist[256];
     __shared__ int red[4];
-    __shared__ int s_last;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int tile = blockIdx.x / S, slice = blockIdx.x - tile * S;
+    const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     for (int k = 0; k < 4; ++k) sh[k][t] = 0;
     __syncthreads();
-    const int r0 = (int)((long)slice * th / S), r1 = (int)((long)(slice + 1) * th / S);
+    const int r0 = 0, r1 = th;
     // the frame was just written by another agent (camera DMA / another XCD): a dependent load is a trip to the memory side, so
     // the pixels of this thread are fetched in batches with all loads in flight before any of them is counted
     if (vec4) {                                                      // tiles divide the image, rows are word-aligned: four pixels per load
@@ -91,18 +90,6 @@ __global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t* __restrict__ s
     }
     __syncthreads();
     int v = sh[0][t] + sh[1][t] + sh[2][t] + sh[3][t];
-    if (S > 1) {
-        int* gh = ghist + (size_t)tile * 256;
-        if (v) atomicAdd(&gh[t], v);
-        __threadfence();
-        __syncthreads();
-        if (t == 0) s_last = (atomicAdd(&tickets[tile], 1) == S - 1);
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();
-        v = __hip_atomic_exchange(&gh[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // read the total and leave zero behind
-        if (t == 0) tickets[tile] = 0;
-    }
     if (clip > 0) {
         int over = v > clip ? v - clip : 0;
         if (v > clip) v = clip;
@@ -131,16 +118,9 @@ __global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t* __restrict__ s
     lut[(size_t)tile * 256 + t] = d_sat_u8(d_cv_round((float)hist[t] * lut_scale));
 }
 // how a tile is split and whether the word-load path applies
-static void clahe_launch_shape(const uint8_t* src, int w, int h, int sstride, int tw, int th, int tiles_x, int tiles_y, int* S, int* vec4)
+static void clahe_launch_shape(const uint8_t* src, int w, int h, int sstride, int tw, int th, int tiles_x, int tiles_y, int* vec4)
 {
-    static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();   // A/B switch
-    if (legacy) { *S = 1; *vec4 = 0; return; }
-    *S = 1;
     *vec4 = (tiles_x * tw == w && tiles_y * th == h && (tw & 3) == 0 && (sstride & 3) == 0 && ((size_t)src & 3) == 0) ? 1 : 0;
-    static const int force_s = [] { const char* v = getenv("LVK_CLAHE_S"); return v ? atoi(v) : 0; }();          // experiments
-    static const int force_v = [] { const char* v = getenv("LVK_CLAHE_VEC"); return v ? atoi(v) : -1; }();
-    if (force_s > 0) *S = force_s > th ? th : force_s;
-    if (force_v == 0) *vec4 = 0;
 }
 
 // CLAHE bilinear LUT blend at image coordinate (x,y)  [CLAHE_Interpolation_Body]
@@ -762,14 +742,11 @@ lvk_status lvk_clahe_u8(lvk_context* ctx, const uint8_t* d_src, int w, int h, in
     const float lut_scale = (float)(255) / total;
     int clip = 0;
     if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
-    const size_t nt = (size_t)tiles_x * tiles_y, need = nt * 256 + nt * 256 * sizeof(int) + nt * sizeof(int);
-    const bool fresh = ctx->scratch_bytes[0] < need;
-    uint8_t* lut = (uint8_t*)lvk_ctx_scratch(ctx, 0, need);
+    const size_t nt = (size_t)tiles_x * tiles_y;
+    uint8_t* lut = (uint8_t*)lvk_ctx_scratch(ctx, 0, nt * 256);
     if (!lut) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
-    if (fresh) LVK_HIP(ctx, hipMemsetAsync(lut, 0, ctx->scratch_bytes[0], ctx->stream));     // tile histograms and tickets start at zero and return to it
-    int S, vec4; clahe_launch_shape(d_src, w, h, sstride, tw, th, tiles_x, tiles_y, &S, &vec4);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y * S), dim3(256), 0, ctx->stream, d_src, w, h, sstride, tw, th, tiles_x, clip, lut_scale, lut,
-                       S, (int*)(lut + nt * 256), (int*)(lut + nt * 256 + nt * 256 * sizeof(int)), vec4);
+    int vec4; clahe_launch_shape(d_src, w, h, sstride, tw, th, tiles_x, tiles_y, &vec4);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, d_src, w, h, sstride, tw, th, tiles_x, clip, lut_scale, lut, vec4);
     hipLaunchKernelGGL(k_clahe_apply, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, d_src, w, h, sstride, lut, tiles_x, tiles_y,
                        1.0f / tw, 1.0f / th, d_dst, dstride);
     LVK_LAUNCH_CHECK(ctx);
@@ -800,12 +777,7 @@ lvk_status lvk_pyramid_create(lvk_context* ctx, int w, int h, int win, int max_l
         if (lw <= win || lh <= win) break;                     // buildOpticalFlowPyramid stop rule
     }
     p->clahe_lut_cap = 64 * 256;
-    {   // LUTs, then the tiles' global histograms (ints) and arrival tickets of the split CLAHE pass: zero now, left zero by every launch
-        const size_t bytes = (size_t)p->clahe_lut_cap * (1 + sizeof(int)) + (size_t)(p->clahe_lut_cap / 256) * sizeof(int);
-        if (hipMalloc((void**)&p->clahe_lut, bytes) != hipSuccess) { lvk_pyramid_destroy(p); return lvk_set_error(ctx, LVK_ERR_DEVICE, "hipMalloc lut"); }
-        // on the context's own stream and waited for: a null-stream hipMemset of device memory may still be pending when this returns
-        if (hipMemsetAsync(p->clahe_lut, 0, bytes, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { lvk_pyramid_destroy(p); return lvk_set_error(ctx, LVK_ERR_DEVICE, "hipMemset lut"); }
-    }
+    if (hipMalloc((void**)&p->clahe_lut, (size_t)p->clahe_lut_cap) != hipSuccess) { lvk_pyramid_destroy(p); return lvk_set_error(ctx, LVK_ERR_DEVICE, "hipMalloc lut"); }
     *out = p;
     return LVK_OK;
 }
@@ -855,10 +827,8 @@ lvk_status lvk_pyramid_build_clahe(lvk_context* ctx, lvk_pyramid* p, const uint8
     const float lut_scale = (float)(255) / total;
     int clip = 0;
     if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
-    int S, vec4; clahe_launch_shape(d_img, w, h, stride, tw, th, tiles_x, tiles_y, &S, &vec4);
-    int* ghist = (int*)(p->clahe_lut + p->clahe_lut_cap);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y * S), dim3(256), 0, ctx->stream, d_img, w, h, stride, tw, th, tiles_x, clip, lut_scale, p->clahe_lut,
-                       S, ghist, ghist + p->clahe_lut_cap, vec4);
+    int vec4; clahe_launch_shape(d_img, w, h, stride, tw, th, tiles_x, tiles_y, &vec4);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, d_img, w, h, stride, tw, th, tiles_x, clip, lut_scale, p->clahe_lut, vec4);
     hipLaunchKernelGGL(k_level0_pad<true>, dim3((w + 2 * p->pad + 255) / 256, h + 2 * p->pad), dim3(256), 0, ctx->stream,
                        d_img, w, h, stride, (const uint8_t*)p->clahe_lut, tiles_x, tiles_y, 1.0f / tw, 1.0f / th, p->img[0], p->pad, p->istride[0]);
     return build_levels(ctx, p);
@@ -875,9 +845,8 @@ lvk_status lvk_pyramid_build_with_orb(lvk_context* ctx, lvk_pyramid* p, const ui
 {
     if (!ctx || !p || !d_img || !d_ext || !mosaic_done) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_pyramid_build_with_orb: bad argument");
     const int w = p->w[0], h = p->h[0], B = LVK_ORB_BORDER, es = w + 2 * B, eh = h + 2 * B;
-    static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();
     *mosaic_done = 0;
-    if (p->pad > B || legacy)                                     // the caller follows up with lvk_orb_prepare
+    if (p->pad > B)                                     // the caller follows up with lvk_orb_prepare
         return clahe ? lvk_pyramid_build_clahe(ctx, p, d_img, stride, clip_limit, tiles_x, tiles_y) : lvk_pyramid_build(ctx, p, d_img, stride);
     *mosaic_done = 1;
     float inv_tw = 1.f, inv_th = 1.f;
@@ -890,10 +859,8 @@ lvk_status lvk_pyramid_build_with_orb(lvk_context* ctx, lvk_pyramid* p, const ui
         const float lut_scale = (float)(255) / total;
         int clip = 0;
         if (clip_limit > 0.0) { clip = (int)(clip_limit * total / 256); if (clip < 1) clip = 1; }
-        int S, vec4; clahe_launch_shape(d_img, w, h, stride, tw, th, tiles_x, tiles_y, &S, &vec4);
-        int* ghist = (int*)(p->clahe_lut + p->clahe_lut_cap);
-        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y * S), dim3(256), 0, ctx->stream, d_img, w, h, stride, tw, th, tiles_x, clip, lut_scale, p->clahe_lut,
-                           S, ghist, ghist + p->clahe_lut_cap, vec4);
+        int vec4; clahe_launch_shape(d_img, w, h, stride, tw, th, tiles_x, tiles_y, &vec4);
+        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, d_img, w, h, stride, tw, th, tiles_x, clip, lut_scale, p->clahe_lut, vec4);
         inv_tw = 1.0f / tw; inv_th = 1.0f / th;
         hipLaunchKernelGGL(k_level0_pad_ext<true>, dim3((es + 255) / 256, eh), dim3(256), 0, ctx->stream, d_img, w, h, stride, (const uint8_t*)p->clahe_lut,
                            tiles_x, tiles_y, inv_tw, inv_th, p->img[0], p->pad, p->istride[0], d_ext, es);
@@ -907,78 +874,11 @@ lvk_status lvk_pyramid_build_with_orb(lvk_context* ctx, lvk_pyramid* p, const ui
 lvk_status lvk_orb_blur_only(lvk_context* ctx, const lvk_pyramid* p, const uint8_t* d_ext, uint8_t* d_blur)
 {
     const int w = p->w[0], h = p->h[0], B = LVK_ORB_BORDER, es = w + 2 * B, eh = h + 2 * B;
-    static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();
-    if (!legacy && (es & 3) == 0 && (((size_t)d_ext | (size_t)d_blur) & 3) == 0 && es >= 8)
+    if ((es & 3) == 0 && (((size_t)d_ext | (size_t)d_blur) & 3) == 0 && es >= 8)
         hipLaunchKernelGGL(k_orb_blur_w, dim3((es + BW_TX - 1) / BW_TX, (eh + BW_TY - 1) / BW_TY), dim3(256), 0, ctx->stream, d_ext, w, h, es, d_blur);
     else
         hipLaunchKernelGGL(k_orb_blur, dim3((es + BL_TX - 1) / BL_TX, (eh + BL_TY - 1) / BL_TY), dim3(256), 0, ctx->stream, d_ext, w, h, es, d_blur);
     LVK_LAUNCH_CHECK(ctx);
-    return LVK_OK;
-}
-
-extern "C" {
-
-}  // extern "C"
-
-// ---- the pyramid build of one pyramid object as a captured graph: 5 fixed-shape launches become one graph launch; the two
-// kernels that read the caller's image get their (pointer, stride) arguments patched when the image moves.
-struct lvk_pyr_graph {
-    hipGraph_t g; hipGraphExec_t x;
-    hipGraphNode_t node[2]; hipKernelNodeParams prm[2]; void* args[2][16]; int n_img_nodes;
-    const uint8_t* img; int stride;
-};
-
-void lvk_pyramid_graph_destroy(lvk_pyr_graph* G)
-{
-    if (!G) return;
-    if (G->x) hipGraphExecDestroy(G->x);
-    if (G->g) hipGraphDestroy(G->g);
-    delete G;
-}
-
-lvk_status lvk_pyramid_graph_capture(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride, int clahe, double clip_limit,
-                                     int tiles_x, int tiles_y, lvk_pyr_graph** out)
-{
-    if (!ctx || !p || !d_img || !out) return LVK_ERR_ARG;
-    lvk_pyr_graph* G = new lvk_pyr_graph(); memset(G, 0, sizeof *G);
-    // thread-local mode: the filter's thread keeps making HIP calls on its own stream while this one records
-    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete G; return lvk_set_error(ctx, LVK_ERR_DEVICE, "stream capture refused"); }
-    lvk_status st = clahe ? lvk_pyramid_build_clahe(ctx, p, d_img, stride, clip_limit, tiles_x, tiles_y) : lvk_pyramid_build(ctx, p, d_img, stride);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &G->g);
-    if (st != LVK_OK || e != hipSuccess || !G->g) { lvk_pyramid_graph_destroy(G); return st != LVK_OK ? st : lvk_set_error(ctx, LVK_ERR_DEVICE, "stream capture failed: %s", hipGetErrorString(e)); }
-    if (hipGraphInstantiate(&G->x, G->g, nullptr, nullptr, 0) != hipSuccess) { lvk_pyramid_graph_destroy(G); return lvk_set_error(ctx, LVK_ERR_DEVICE, "graph instantiation failed"); }
-    size_t n = 0; hipGraphGetNodes(G->g, nullptr, &n);
-    std::vector<hipGraphNode_t> nodes(n);
-    if (n) hipGraphGetNodes(G->g, nodes.data(), &n);
-    for (size_t i = 0; i < n; ++i) {
-        hipGraphNodeType ty;
-        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
-        hipKernelNodeParams prm;
-        if (hipGraphKernelNodeGetParams(nodes[i], &prm) != hipSuccess) continue;
-        int n_args = 0;
-        if (prm.func == (void*)k_clahe_lut) n_args = 14;
-        else if (prm.func == (void*)k_level0_pad<true> || prm.func == (void*)k_level0_pad<false>) n_args = 12;
-        if (!n_args || G->n_img_nodes >= 2 || !prm.kernelParams) continue;
-        const int k = G->n_img_nodes++;
-        G->node[k] = nodes[i]; G->prm[k] = prm;
-        for (int a = 0; a < n_args; ++a) G->args[k][a] = prm.kernelParams[a];      // the node's own copies (alive as long as the graph)
-        G->args[k][0] = &G->img; G->args[k][3] = &G->stride;                        // src, sstride: ours
-        G->prm[k].kernelParams = G->args[k]; G->prm[k].extra = nullptr;
-    }
-    const int want = clahe ? 2 : 1;
-    if (G->n_img_nodes != want) { lvk_pyramid_graph_destroy(G); return lvk_set_error(ctx, LVK_ERR_DEVICE, "captured graph: image-reading nodes not found"); }
-    G->img = d_img; G->stride = stride;
-    *out = G;
-    return LVK_OK;
-}
-
-lvk_status lvk_pyramid_graph_launch(lvk_context* ctx, lvk_pyr_graph* G, const uint8_t* d_img, int stride)
-{
-    if (d_img != G->img || stride != G->stride) {
-        G->img = d_img; G->stride = stride;
-        for (int k = 0; k < G->n_img_nodes; ++k) LVK_HIP(ctx, hipGraphExecKernelNodeSetParams(G->x, G->node[k], &G->prm[k]));
-    }
-    LVK_HIP(ctx, hipGraphLaunch(G->x, ctx->stream));
     return LVK_OK;
 }
 
@@ -1001,8 +901,7 @@ lvk_status lvk_orb_prepare(lvk_context* ctx, const lvk_pyramid* p, uint8_t* d_ex
     const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
     const int grow = p->pad < B ? p->pad : B;
     hipLaunchKernelGGL(k_orb_ext, dim3((es + 255) / 256, eh), dim3(256), 0, ctx->stream, s0, w, h, p->istride[0], grow, d_ext, es);
-    static const int legacy = [] { const char* v = getenv("LVK_FE_LEGACY_IMAGE_KERNELS"); return v && atoi(v) ? 1 : 0; }();
-    if (!legacy && (es & 3) == 0 && (((size_t)d_ext | (size_t)d_blur) & 3) == 0 && es >= 8)
+    if ((es & 3) == 0 && (((size_t)d_ext | (size_t)d_blur) & 3) == 0 && es >= 8)
         hipLaunchKernelGGL(k_orb_blur_w, dim3((es + BW_TX - 1) / BW_TX, (eh + BW_TY - 1) / BW_TY), dim3(256), 0, ctx->stream, (const uint8_t*)d_ext, w, h, es, d_blur);
     else
         hipLaunchKernelGGL(k_orb_blur, dim3((es + BL_TX - 1) / BL_TX, (eh + BL_TY - 1) / BL_TY), dim3(256), 0, ctx->stream, (const uint8_t*)d_ext, w, h, es, d_blur);

@@ -480,9 +480,9 @@ struct lvk_frontend {
     // Host images (the reference's cv::Mat, pageable) are copied by the calling thread into a ring of pinned, device-mapped staging
     // slots; the GPU side is either one asynchronous H2D copy into d_img (default) or, with LVK_FE_ZEROCOPY=1, the first two image
     // kernels reading the slot in place over PCIe.  The caller's buffer is free as soon as the call returns (as in the reference).
-    uint8_t* h_stage[3] = {nullptr, nullptr, nullptr}; uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
+    uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};
 
-    int stage_next = 0; int zero_copy = 0;
+    int stage_next = 0;
     TrackSet set[2];
     lvk_pt2f *w_curr, *wn_curr, *new_pts;
     lvk_pt2f *w_und, *wn_und;  // undistorted (prev, curr) pair per point, written by the LK kernel next to w_curr / wn_curr
@@ -513,8 +513,6 @@ struct lvk_frontend {
     // the data flow allows: ev_pyr / ev_orb (image stream -> main and side: pyramid / ORB planes of this frame ready), ev_new (side
     // stream -> main), ev_commit (main -> side), ev_tail (bootstrap only), ev_main / ev_side (end of a frame on either stream)
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
-    lvk_pyr_graph* pyr_graph[3] = {nullptr, nullptr, nullptr}; lvk_pyramid* pyr_graph_of[3] = {nullptr, nullptr, nullptr};
-    int use_graph = 0;                // LVK_FE_GRAPH=1: steady-state pyramid build as one graph launch per frame
     // sticky: a frame that failed AFTER its image stage was queued (device error, ring overrun) leaves the buffer-set rotation and the
     // end-of-frame events out of step with the frame count; the handle then refuses further frames instead of racing on its buffers
     lvk_status failed = LVK_OK; char failed_msg[200] = {0};
@@ -634,7 +632,6 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->w_und, fe->wn_und, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < 3; ++i) lvk_pyramid_graph_destroy(fe->pyr_graph[i]);
     for (int i = 0; i < 3; ++i) if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]);
     for (int i = 0; i < LVK_MSG_SLOTS; ++i) if (fe->ev_msg[i]) hipEventDestroy(fe->ev_msg[i]);
     if (fe->h_msg) hipHostFree(fe->h_msg);
@@ -663,7 +660,6 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     lvk_frontend* fe = new (std::nothrow) lvk_frontend();     // value-initialised: all PODs zero
     if (!fe) return LVK_ERR_DEVICE;
     fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
-    { const char* g = getenv("LVK_FE_GRAPH"); fe->use_graph = g && atoi(g) != 0; }
     const int w = cfg->width, h = cfg->height, cap = fe->cap;
     const size_t esz = (size_t)(w + 64) * (h + 64);
     bool ok = true;
@@ -687,12 +683,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
         ok = hipHostGetDevicePointer(&dm, fe->h_msg, 0) == hipSuccess && hipHostGetDevicePointer(&dn, fe->h_nmsg, 0) == hipSuccess && dm && dn;
         fe->d_msg = (lvk_feature_obs*)dm; fe->d_nmsg = (int*)dn;
     }
-    { const char* z = getenv("LVK_FE_ZEROCOPY"); fe->zero_copy = z && atoi(z) != 0; }
-    for (int i = 0; i < 3 && ok; ++i) {
-        void* dp = nullptr;
-        ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess && hipHostGetDevicePointer(&dp, fe->h_stage[i], 0) == hipSuccess && dp;
-        fe->d_stage[i] = (uint8_t*)dp;
-    }
+    for (int i = 0; i < 3 && ok; ++i) ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
     hipEvent_t* evs[] = {&fe->ev_pyr, &fe->ev_orb, &fe->ev_new, &fe->ev_commit, &fe->ev_tail, &fe->ev_main[0], &fe->ev_main[1], &fe->ev_side[0], &fe->ev_side[1]};
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
@@ -817,8 +808,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         uint8_t* hs = fe->h_stage[slot];
         if (image->stride == c.width) memcpy(hs, image->data, (size_t)c.width * c.height);
         else for (int y = 0; y < c.height; ++y) memcpy(hs + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
-        if (fe->zero_copy) d_img = fe->d_stage[slot];
-        else { LVK_HIP(ctx, hipMemcpyAsync(fe->d_img, hs, (size_t)c.width * c.height, hipMemcpyHostToDevice, fe->side[1]->stream)); d_img = fe->d_img; }
+        LVK_HIP(ctx, hipMemcpyAsync(fe->d_img, hs, (size_t)c.width * c.height, hipMemcpyHostToDevice, fe->side[1]->stream)); d_img = fe->d_img;
         d_stride = c.width;
     }
     lvk_status st;
@@ -832,17 +822,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         hipStreamWaitEvent(S0, fe->ev_main[par], 0); hipStreamWaitEvent(S0, fe->ev_side[par], 0);
     }
     int mosaic_done = 0;
-    if (fe->use_graph && fe->image_state == 3 && !((fe->prof_mask >> 0) & 1u)) {
-        int gs = -1;
-        for (int k = 0; k < 3; ++k) if (fe->pyr_graph_of[k] == fe->pyr[1]) gs = k;
-        if (gs < 0) {
-            for (int k = 0; k < 3; ++k) if (!fe->pyr_graph_of[k]) { gs = k; break; }
-            st = lvk_pyramid_graph_capture(icx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, &fe->pyr_graph[gs]);
-            if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
-            fe->pyr_graph_of[gs] = fe->pyr[1];
-        }
-        st = lvk_pyramid_graph_launch(icx, fe->pyr_graph[gs], d_img, d_stride);
-    } else {
+    {
         ProfScope ps(fe, 0, S0);
         st = lvk_pyramid_build_with_orb(icx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, fe->ext[1], &mosaic_done);
     }

@@ -25,7 +25,7 @@ struct lvk_context {
     size_t lds_optin[12];
     // fused Cholesky + solve (be_linalg.hip, k_chol_fused): the factor workgroup hands panels to the solver workgroups through a flag
     // that only ever grows; chol_epoch numbers the launches, chol_ws (scratch slot 12) holds the diagonal-block inverses and the flag
-    int chol_epoch; int chol_mode;      // chol_mode: 0 = not decided yet, 1 = fused, 2 = one launch per panel (LVK_CHOL_FUSED=0)
+    int chol_epoch;
 };
 // opt in to `bytes` of dynamic LDS for `fn` if this context has not already asked for at least that much
 #define LVK_LDS_OPTIN(ctx, slot, fn, bytes)                                                                             \
@@ -46,13 +46,6 @@ extern "C" lvk_status lvk_frontend_begin(lvk_frontend* fe, const lvk_image* img,
 // the pipelined driver's non-blocking processImage: *slot = ring entry of the feature message (when *has_msg), collected later
 extern "C" lvk_status lvk_frontend_process_async(lvk_frontend* fe, const lvk_image* img, double ts, const lvk_imu* h_imu, int n_imu, int* has_msg, int* slot);
 extern "C" lvk_status lvk_frontend_fetch_msg(lvk_frontend* fe, int slot, lvk_feature_obs* h_out, int cap, int* n_out);
-
-struct lvk_pyr_graph;                                     // fe_image.hip: the pyramid build of one pyramid object as a captured hipGraph
-struct lvk_pyramid;
-lvk_status lvk_pyramid_graph_capture(lvk_context* ctx, lvk_pyramid* p, const uint8_t* d_img, int stride, int clahe, double clip_limit,
-                                     int tiles_x, int tiles_y, lvk_pyr_graph** out);
-lvk_status lvk_pyramid_graph_launch(lvk_context* ctx, lvk_pyr_graph* g, const uint8_t* d_img, int stride);
-void lvk_pyramid_graph_destroy(lvk_pyr_graph* g);
 
 struct lvk_pyramid {
     lvk_context* ctx;

@@ -92,17 +92,6 @@ def test_image_stage_at_large_sizes(gpu_ctx, size):
     assert ca.shape == cb.shape and np.array_equal(ca, cb)
 
 
-def test_clahe_split_variant():
-    """LVK_CLAHE_S=4: tiles covered by four workgroups, global merge, last arrival finishes and re-zeroes (kept for experiments)."""
-    import os, subprocess, sys
-    code = ("import numpy as np, larvio_amd; from larvio_amd import ops; from oracle import lvo; from tests.test_gpu_frontend_stages import _big_image\n"
-            "ctx = larvio_amd.Context(0); img = _big_image(1920, 1080); ref = lvo.clahe(img)\n"
-            "assert all(np.array_equal(ops.clahe(ctx, img), ref) for _ in range(3)); print('ok')")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LVK_CLAHE_S="4", PYTHONPATH=root), capture_output=True, text=True, timeout=300, cwd=root)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-800:]
-
-
 def test_min_eigen_map_bit_exact(gpu_ctx, two_frames):
     g, o = _pyr_pair(gpu_ctx, two_frames[0], clahe=True)
     a, b = g.min_eigen_map(), o.min_eigen_map()
