@@ -43,9 +43,10 @@ struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t 
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
 lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq);
-lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_ix, int n_out, int n_i, int L,
-                                    const double* d_phiq);
+lvk_status lvk_cov_propagate_augment(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, int n_out, int pose_rows, int L,
+                                     const double* h_phi, const double* h_q, const double* d_phiq);
 lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const double* d_J, int fc);
+lvk_status lvk_stage_copy2(lvk_context* ctx, void* d_dst0, const void* d_src0, size_t bytes0, void* d_dst1, const void* d_src1, size_t bytes1);
 lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, int nn, const double* H1, int ldh, const double* H2, const double* r1,
                                    const double* dx, double sigma2, double* tmp, double* dx_new);
 lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out);
@@ -764,20 +765,15 @@ static lvk_status state_augmentation(lvk_ekf* e)
     for (int i = 0; i < 6; ++i) idx.push_back(sel[i]);
     for (int i = pose_rows; i < e->N; ++i) idx.push_back(i);
     if (!e->have_prop) return cov_gather(e, idx);
-    // the frame's propagation (composed Phi, Q) rides in the same launch: k_cov_propagate_gather
+    // the frame's propagation (composed Phi, Q) rides in the same launch: k_cov_propagate_augment (the index map is analytic there)
     const int n_out = (int)idx.size(), L = LEG;
-    int* h_idx = up_alloc<int>(e, (size_t)2 * n_out); double* h_pq = up_alloc<double>(e, (size_t)2 * L * L);
-    if (!h_idx || !h_pq) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
-    int* h_il = h_idx + n_out; int n_i = 0, n_c = 0;
-    for (int a = 0; a < n_out; ++a) { h_idx[a] = idx[a]; if (idx[a] < L) h_il[n_i++] = a; }
-    int* h_cl = h_il + n_i;                                  // ilist and clist share the second half (n_i + n_c = n_out)
-    for (int a = 0; a < n_out; ++a) if (idx[a] >= L) h_cl[n_c++] = a;
+    double* h_pq = up_alloc<double>(e, (size_t)2 * L * L);            // the launch may be deferred: Phi_tot / Q_tot are copied now
+    if (!h_pq) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     memcpy(h_pq, e->Phi_tot, sizeof(double) * L * L); memcpy(h_pq + L * L, e->Q_tot, sizeof(double) * L * L);
     e->have_prop = false;
     double* src = e->dP[e->cur]; double* dst = e->dP[e->cur ^ 1];
-    const int* d_ix = dev(e, h_idx); const double* d_pq = dev(e, h_pq);      // [idx | ilist | clist] is one array
-    (void)h_cl;
-    lvk_status st = run_or_defer(e, [=]() { return lvk_cov_propagate_gather(e->ctx, src, e->ld, dst, e->ld, d_ix, n_out, n_i, L, d_pq); });
+    const double* d_pq = dev(e, h_pq);
+    lvk_status st = run_or_defer(e, [=]() { return lvk_cov_propagate_augment(e->ctx, src, e->ld, dst, e->ld, n_out, pose_rows, L, h_pq, h_pq + L * L, d_pq); });
     if (st != LVK_OK) return st;
     e->cur ^= 1; e->N = n_out;
     return LVK_OK;
@@ -878,7 +874,14 @@ static lvk_status upload_clones(lvk_ekf* e)
         quat_to_rot(c.q_cam, hc[i].R); memcpy(hc[i].t, c.p_cam, 24);
         memcpy(hd[i].q, c.q, 32); memcpy(hd[i].p, c.p, 24); memcpy(hd[i].p_fej, c.p_fej, 24); memcpy(hd[i].R_b2c, c.R_b2c, 72); memcpy(hd[i].t_c_b, c.t_c_b, 24);
     }
-    e->dv_cams = dev(e, hc); e->dv_clones = dev(e, hd);
+    // The two tables are read by EVERY workgroup of the triangulation and row kernels that follow (40..2000 of them), and the arena is host
+    // memory: each of those reads would cross PCIe (k_feature_rows spent 9 of its 29 us fetching 5 KB of clone poses per workgroup,
+    // profiles/r4_c_be_ticks.json).  One small kernel copies them to device memory once; it runs while this thread is still building
+    // the jobs that use them.
+    const size_t nb_c = sizeof(CamPose) * n, nb_d = sizeof(CloneDev) * n;
+    lvk_status st = lvk_stage_copy2(e->ctx, e->d_cams, dev(e, hc), nb_c, e->d_clones, dev(e, hd), nb_d);
+    if (st != LVK_OK) return st;
+    e->dv_cams = e->d_cams; e->dv_clones = e->d_clones;
     return LVK_OK;
 }
 

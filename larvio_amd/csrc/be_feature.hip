@@ -13,6 +13,7 @@
 // blocks that are ~85 % zeros and multiplies them against the full P for every gate.
 #include "lvk_internal.h"
 #include "be_dev.h"
+#include "lvk_wave.h"
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 #include <algorithm>
@@ -126,6 +127,9 @@ __global__ void __launch_bounds__(64) k_triangulate(const TriJob* __restrict__ j
 }
 
 // ========================================================================= per-feature rows + gate
+BE_TICK_DECL(g_fr_tick);
+BE_TICK_GETTER(lvk_debug_ticks_feature_rows, g_fr_tick)
+#define FR_TICK(k) BE_TICK(g_fr_tick, SMALL && blockIdx.x == 0, k)
 // Staging slot of a job (doubles): G [rows_raw x c] | T [rows_raw x c] | r [rows_raw]; ccol ints kept separately.
 #define FR_THREADS 128
 // SMALL = every job of the batch has <= FRS_ROWS raw rows and <= FRS_COLS compact columns (true in steady state: max_track_len 6
@@ -153,6 +157,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     // ranks -> clone poses used to be three dependent PCIe round trips before the first flop.  SMALL batches lay the observations
     // out at a fixed stride, so ranks / observations (and the whole clone table, a few KB, into LDS) are requested together with
     // the job record: one trip.
+    FR_TICK(0);
     int my_rank = 0; double my_z[2] = {0., 0.}, my_zv[2] = {0., 0.};
     const bool pre = SMALL && obs_stride > 0;
     if (pre && t < obs_stride) {
@@ -178,6 +183,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     double* Pcc = Gl + 2 * FRS_ROWS * FRS_COLS + FRS_ROWS;           // SMALL only: [c][FRS_PLD]
     double* cl_s = Pcc + FRS_COLS * FRS_PLD;                          // SMALL only: the clone table (n_clones x 22 doubles)
     int* srank = (int*)(cl_s + (size_t)n_clones * (sizeof(CloneDev) / sizeof(double)));   // SMALL only: clone rank of every observation
+    int* scc = srank + 16;                                            // SMALL only: the compact column map (also written to ccols for k_stack_rows)
     if (SMALL) {
         for (int e = t; e < n_clones * (int)(sizeof(CloneDev) / sizeof(double)); e += FR_THREADS) cl_s[e] = ((const double*)clones)[e];
         if (!pre && t < M) {
@@ -187,6 +193,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         if (t < M) srank[t] = my_rank;
         __syncthreads();
     }
+    FR_TICK(1);                                                      // job, observations and clone table have arrived
     // ---- zero the block, write the compact column map
     for (int e = t; e < rows * c; e += FR_THREADS) G[e] = 0.;
     for (int e = t; e < c; e += FR_THREADS) {
@@ -197,18 +204,21 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         else if (e < 13 + 6 * M) col = fl.leg_dim + 6 * (SMALL ? srank[(e - 13) / 6] : obs_rank[job.obs_off + (e - 13) / 6]) + (e - 13) % 6;
         else col = job.fcol;
         cc[e] = col;
+        if (SMALL) scc[e] = col;
     }
     __syncthreads();
+    FR_TICK(2);                                                      // G zeroed, column map written
     // P_cc = P[cc, cc]: up to 32 entries per thread, every load issued before the first store - and the stores wait until the
     // Jacobians below are done (their threads would otherwise sit on the loads' return before starting)
+    // (index space 64 x 64, thread t keeps column t & 63 and walks rows (t >> 6) + 2 u: no divisions - this kernel runs its code ONCE per
+    // launch, so it is paced by instruction fetch, and the 64 unrolled integer divisions of the first version were 2,500 instructions)
     constexpr int PER = SMALL ? (FRS_COLS * FRS_COLS + FR_THREADS - 1) / FR_THREADS : 1;
     double pv[PER];
-    if (SMALL && job.want_gate) {
+    const int pj = t & 63, pi0 = t >> 6;
+    if (SMALL && job.want_gate && pj < c) {
+        const double* Pj = P + scc[pj];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int e = t + FR_THREADS * u;
-            if (e < c * c) { const int i = e / c, j = e - i * c; pv[u] = P[(size_t)cc[i] * ldp + cc[j]]; }
-        }
+        for (int u = 0; u < PER; ++u) { const int i = pi0 + 2 * u; if (i < c) pv[u] = Pj[(size_t)scc[i] * ldp]; }
     }
     // ---- per-observation Jacobians (one thread per observation)
     if (t < M) {
@@ -244,14 +254,13 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             }
         }
     }
-    if (SMALL && job.want_gate) {
+    FR_TICK(3);                                                      // Jacobians done
+    if (SMALL && job.want_gate && pj < c) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int e = t + FR_THREADS * u;
-            if (e < c * c) { const int i = e / c, j = e - i * c; Pcc[i * FRS_PLD + j] = pv[u]; }
-        }
+        for (int u = 0; u < PER; ++u) { const int i = pi0 + 2 * u; if (i < c) Pcc[i * FRS_PLD + pj] = pv[u]; }
     }
     __syncthreads();
+    FR_TICK(4);                                                      // P_cc parked
     int first_row = 0, k_rows = rows;
     double h2 = 0.;
     if (job.type != JOB_EKF_TRACKED) {
@@ -299,37 +308,45 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
             __syncthreads();
         }
     }
+    FR_TICK(5);                                                      // null-space projection done
     // ---- gate: S = G' P_cc G'^T + sigma2 I on rows first_row.. ; gamma = r'^T S^-1 r'
     double gamma = 0.;
     if (job.want_gate && k_rows > 0) {
         const int k = k_rows;
         const double* Gp = G + (size_t)first_row * c;
-        for (int e = t; e < k * c; e += FR_THREADS) {
-            int a = e / c, j = e - a * c;
-            double s = 0.;
-            const int colj = cc[j];
-            if (SMALL) {
-                // branch-free (a zero entry of G' adds an exact zero): the LDS reads of several steps can be in flight together
-#pragma unroll 8
-                for (int i = 0; i < c; ++i) s += Gp[(size_t)a * c + i] * Pcc[i * FRS_PLD + j];
-            } else {
+        if (SMALL) {
+            // branch-free (a zero entry of G' adds an exact zero); thread t: column t & 63, rows (t >> 6), (t >> 6) + 2, ...
+            if (pj < c)
+                for (int a = pi0; a < k; a += 2) {
+                    double s = 0.;
+#pragma unroll 4
+                    for (int i = 0; i < c; ++i) s += Gp[(size_t)a * c + i] * Pcc[i * FRS_PLD + pj];
+                    T[(size_t)a * c + pj] = s;
+                }
+        } else {
+            for (int e = t; e < k * c; e += FR_THREADS) {
+                int a = e / c, j = e - a * c;
+                double s = 0.;
+                const int colj = cc[j];
                 for (int i = 0; i < c; ++i) {
                     const double g = Gp[(size_t)a * c + i];
                     if (g != 0.) s += g * P[(size_t)cc[i] * ldp + colj];
                 }
+                T[(size_t)a * c + j] = s;
             }
-            T[(size_t)a * c + j] = s;
         }
         __syncthreads();
-        for (int e = t; e < k * k; e += FR_THREADS) {
-            int a = e / k, b = e - a * k;
+        for (int e = t; e < (SMALL ? 256 : k * k); e += FR_THREADS) {
+            int a, b;
+            if (SMALL) { a = e >> 4; b = e & 15; if (a >= k || b >= k) continue; } else { a = e / k; b = e - a * k; }
             if (b > a) continue;
             double s = 0.;
-#pragma unroll 8
+#pragma unroll 4
             for (int i = 0; i < c; ++i) s += T[(size_t)a * c + i] * Gp[(size_t)b * c + i];
             S[a * k + b] = s + (a == b ? fl.sigma2 : 0.);
         }
         __syncthreads();
+        FR_TICK(6);                                                  // T = G' P_cc and S done
         if (SMALL) {
             // gamma = r'^T S^-1 r' on ONE wavefront: the bordered matrix [S r'; r'^T 0] (k + 1 <= 14 rows) sits in a 16x16 FP64-MFMA
             // accumulator tile and is eliminated by k rank-1 updates (row j of the tile is already laid out as K-slot j & 3 of both
@@ -350,16 +367,15 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
                     acc[r] = v;
                 }
                 int bad = 0;
-#pragma unroll
-                for (int j = 0; j < 14; ++j) {
-                    if (j < k) {
-                        const int q = j >> 2, gj = j & 3;
-                        double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(acc[q]), 16 * gj + j), __builtin_amdgcn_readlane(__double2loint(acc[q]), 16 * gj + j));
-                        if (!(piv > 0.)) { bad = 1; piv = 1.0; }
-                        const double rinv = 1.0 / sqrt(piv);
-                        const double v = (gth == gj && cth >= j) ? acc[q] * rinv : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
-                    }
+#pragma nounroll
+                for (int j = 0; j < k; ++j) {                                    // a real loop: the kernel is paced by instruction fetch
+                    const int q = j >> 2, gj = j & 3, ln = 16 * gj + j;
+                    const double rowv = q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3];
+                    double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rowv), ln), __builtin_amdgcn_readlane(__double2loint(rowv), ln));
+                    if (!(piv > 0.)) { bad = 1; piv = 1.0; }
+                    const double rinv = rsqrt_goldschmidt(piv);
+                    const double v = (gth == gj && cth >= j) ? rowv * rinv : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, acc, 0, 0, 0);
                 }
                 const int lk = 16 * (k & 3) + k;
                 const double corner = (k >> 2) == 0 ? acc[0] : (k >> 2) == 1 ? acc[1] : (k >> 2) == 2 ? acc[2] : acc[3];
@@ -402,11 +418,13 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         }
         }
     }
+    FR_TICK(7);                                                      // gate value known
     if (SMALL) {
         __syncthreads();
         for (int e = t; e < rows * c; e += FR_THREADS) Gg[e] = G[e];
         for (int e = t; e < rows; e += FR_THREADS) rrg[e] = rr[e];
     }
+    FR_TICK(8);                                                      // staging written
     const int accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;      // gamma is the same in every thread
     if (t == 0) {
         FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2;
@@ -431,6 +449,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
                 if (col >= 0 && col < ncols_out) H_out[(size_t)(d0 + a) * ldh + col] = G[(size_t)(src0 + a) * c + j];
             }
     }
+    FR_TICK(9);
 }
 
 // dense H row d <- compact row src (job staging) ; r[d] likewise.  One workgroup per destination row.
@@ -470,7 +489,7 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
     const size_t base = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
     // max_rows = 2 M_max; compact columns <= 7 + 6 + 6 M_max + 1
     const bool small = max_rows <= FRS_ROWS && 14 + 3 * max_rows <= FRS_COLS;
-    const size_t shmem = base + (small ? sizeof(double) * ((size_t)2 * FRS_ROWS * FRS_COLS + FRS_ROWS + (size_t)FRS_COLS * FRS_PLD + (size_t)n_clones * (sizeof(CloneDev) / sizeof(double)) + 16) : 0);
+    const size_t shmem = base + (small ? sizeof(double) * ((size_t)2 * FRS_ROWS * FRS_COLS + FRS_ROWS + (size_t)FRS_COLS * FRS_PLD + (size_t)n_clones * (sizeof(CloneDev) / sizeof(double)) + 8 + FRS_COLS / 2 + 8) : 0);     // + srank (16 ints) + scc (64 ints)
     if (shmem > 150 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature block with %d rows exceeds the LDS budget", max_rows);
     if (small) {
         if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 10, k_feature_rows<true>, shmem);

@@ -142,6 +142,27 @@ __global__ void k_cov_gather(const double* __restrict__ Pin, int ldin, double* _
     Pout[(size_t)a * ldout + b] = Pin[(size_t)idx[a] * ldin + idx[b]];
 }
 
+// a few KB from the pinned upload arena (host memory) to device memory: one workgroup per table, 8-byte loads all in flight
+__global__ void __launch_bounds__(256) k_stage_copy(double* __restrict__ dst0, const double* __restrict__ src0, int n0,
+                                                   double* __restrict__ dst1, const double* __restrict__ src1, int n1)
+{
+    double* dst = blockIdx.x ? dst1 : dst0; const double* src = blockIdx.x ? src1 : src0; const int n = blockIdx.x ? n1 : n0;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < n) v[u] = src[e]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < n) dst[e] = v[u]; }
+    }
+}
+lvk_status lvk_stage_copy2(lvk_context* ctx, void* d_dst0, const void* d_src0, size_t bytes0, void* d_dst1, const void* d_src1, size_t bytes1)
+{
+    hipLaunchKernelGGL(k_stage_copy, dim3(2), dim3(256), 0, ctx->stream, (double*)d_dst0, (const double*)d_src0, (int)(bytes0 / sizeof(double)),
+                       (double*)d_dst1, (const double*)d_src1, (int)(bytes1 / sizeof(double)));
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
 // IMU propagation of the covariance (processModel, larvio.cpp:553-571) with the per-frame composed Phi (L x L) and Q:
 //   P_II <- sym(Phi P_II Phi^T + Q) ; P_IC <- Phi P_IC ; P_CI <- P_IC^T.    phiq = [Phi | Q] (2*L*L doubles).
 #define CPR_THREADS 1024
@@ -186,69 +207,93 @@ __global__ void __launch_bounds__(CPR_THREADS) k_cov_propagate(double* __restric
 }
 
 // Propagation AND clone augmentation in one launch (processModel's covariance part, larvio.cpp:553-571, then stateAugmentation's
-// J P J^T, :752-798, which is a pure gather):  Pout[a][b] = Pprop[idx[a]][idx[b]]  with Pprop = the propagated Pin, never stored.
+// J P J^T, :752-798, which is a pure gather):  Pout[a][b] = Pprop[src(a)][src(b)]  with Pprop = the propagated Pin, never stored, and
+//     src(a) = a                      a < pose_rows            (IMU block, old clones)
+//            = {0,1,2,6,7,8}[a - pose_rows]                    (the new clone's six rows: copies of theta and p)
+//            = a - 6                  otherwise                (in-state features)
 // 81 % of the outputs (clone x clone, feature blocks) are plain copies; what propagation changes is the L-wide strip of IMU rows and
-// columns, so the grid has three roles and only 1 + CPG_STRIPS workgroups read Phi and Q (they sit in the pinned upload arena):
+// columns, so the grid has three roles and only 1 + CPG_STRIPS workgroups read Phi (and one of them Q) from the pinned upload arena:
 //   blockIdx <  n_out               row a of Pout, copies where both sources are outside the IMU block
 //   next CPG_STRIPS workgroups      a chunk of the outside columns: W = Phi Pin[0:L, chunk], written to every output row / column
 //                                   whose source is an IMU row (the six duplicated ones included), both orientations
 //   last workgroup                  the IMU block itself: sym(Phi P_II Phi^T + Q), scattered to all (a, b) with both sources inside
-// ilist / clist: the output indices whose source is < L / >= L (host-built, ascending).  Sums run over k ascending, exactly as
-// k_cov_propagate's, so the two routes give the same bits.
+// No index arrays: the arena is HOST memory and every byte a kernel reads from it crosses PCIe at ~23 GB/s - the first version of this
+// kernel had every one of its 330 workgroups fetch a 1.8 KB index list and took 17.6 us, 8 of them waiting for those bytes
+// (profiles/r4_c_be_ticks.json).  Sums run over k ascending.
 #define CPG_STRIPS 8
-// ix = [idx (n_out) | ilist (n_i) | clist (n_c)], n_i + n_c = n_out: ONE array in the pinned upload arena.  Every workgroup copies what it
-// needs of it (and Phi, Q) into LDS with its first loads, all in flight together: the arena is host memory, and a chain of dependent
-// reads through it (clist -> idx -> Pin) costs a PCIe round trip per link - the first version of this kernel took 18.6 us that way.
-__global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __restrict__ Pin, int ldin, double* __restrict__ Pout, int ldout,
-                                                             const int* __restrict__ ix, int n_out, int n_i, int L, const double* __restrict__ phiq)
+BE_TICK_DECL(g_la_tick);
+BE_TICK_GETTER(lvk_debug_ticks_linalg, g_la_tick)
+__device__ __forceinline__ int cpg_src(int a, int pose_rows) { return a < pose_rows ? a : a < pose_rows + 6 ? (a - pose_rows < 3 ? a - pose_rows : a - pose_rows + 3) : a - 6; }
+// The composed transition of a frame has structure (backend.hip, compose_transition): rows 9.. of Phi are identity rows and Q is zero
+// outside its leading 15 x 15 block.  For the 22-dimensional IMU block that is 9 x 22 + 15 x 15 doubles = 3.4 KB: it travels BY VALUE in
+// the kernel arguments (device memory with HIP_FORCE_DEV_KERNARG=1, which the runtime section of INTEGRATION.md prescribes) instead of
+// being fetched from the pinned arena by nine workgroups (6.8 us of the kernel's 16, profiles/r4_d_be_ticks.json).  With IMU-intrinsics
+// calibration (L = 46) the block is too big for the 4 KB argument segment and still comes from the arena.
+struct PhiQ22 { double phi[9 * 22]; double q[15 * 15]; };
+template <int L, bool BYVAL>
+__global__ void __launch_bounds__(256) k_cov_propagate_augment(const double* __restrict__ Pin, int ldin, double* __restrict__ Pout, int ldout,
+                                                              int n_out, int pose_rows, const double* __restrict__ phiq, PhiQ22 pq)
 {
     extern __shared__ double sh[];
-    const int t = threadIdx.x, n_c = n_out - n_i;
+    const int t = threadIdx.x, n_i = L + 6, n_c = n_out - n_i;
     if ((int)blockIdx.x < n_out) {
-        int* sidx = (int*)sh;
-        const int a = blockIdx.x;
-        for (int e = t; e < n_out; e += 256) sidx[e] = ix[e];
-        __syncthreads();
-        const int i = sidx[a];
+        const int a = blockIdx.x, i = cpg_src(a, pose_rows);
         if (i < L) return;
-        for (int b = t; b < n_out; b += 256) { const int j = sidx[b]; if (j >= L) Pout[(size_t)a * ldout + b] = Pin[(size_t)i * ldin + j]; }
+        BE_TICK(g_la_tick, blockIdx.x == 100, 0);
+        for (int b = t; b < n_out; b += 256) { const int j = cpg_src(b, pose_rows); if (j >= L) Pout[(size_t)a * ldout + b] = Pin[(size_t)i * ldin + j]; }
+        BE_TICK(g_la_tick, blockIdx.x == 100, 2);
         return;
     }
     const int role = (int)blockIdx.x - n_out;
     double* Phi = sh;                                   // L x L
+    // output index of the ai-th row whose source is an IMU row / of the ci-th one whose source is not
+    auto il = [&](int ai) { return ai < L ? ai : pose_rows + (ai - L); };
+    auto cl = [&](int ci) { return ci < pose_rows - L ? L + ci : ci + L + 6; };
+    auto load_phi = [&]() {
+        for (int e = t; e < L * L; e += 256) {
+            if (BYVAL) { const int i = e / L, k = e - i * L; Phi[e] = i < 9 ? pq.phi[e] : (i == k ? 1.0 : 0.0); }
+            else Phi[e] = phiq[e];
+        }
+    };
     if (role < CPG_STRIPS) {
         const int cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS, c0 = role * cc, cw = min(cc, n_c - c0);
         if (cw <= 0) return;
         double* R = sh + L * L;                         // L x cc : Pin[0:L, source columns of the chunk]
         double* W = R + L * cc;                         // L x cc : Phi R
-        int* sidx = (int*)(W + L * cc);                 // the whole index array
-        for (int e = t; e < 2 * n_out; e += 256) sidx[e] = ix[e];
-        for (int e = t; e < L * L; e += 256) Phi[e] = phiq[e];
+        BE_TICK(g_la_tick, role == 0, 8);
+        load_phi();
+        for (int e = t; e < L * cw; e += 256) { const int k = e / cw, q = e - k * cw; R[k * cc + q] = Pin[(size_t)k * ldin + cpg_src(cl(c0 + q), pose_rows)]; }
         __syncthreads();
-        const int* il = sidx + n_out; const int* cl = il + n_i;
-        for (int e = t; e < L * cw; e += 256) { const int k = e / cw, q = e - k * cw; R[k * cc + q] = Pin[(size_t)k * ldin + sidx[cl[c0 + q]]]; }
-        __syncthreads();
+        BE_TICK(g_la_tick, role == 0, 9);
         for (int e = t; e < L * cw; e += 256) {
             const int i = e / cw, q = e - i * cw; double s = 0.;
+#pragma unroll
             for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * cc + q];
             W[i * cc + q] = s;
         }
         __syncthreads();
+        BE_TICK(g_la_tick, role == 0, 10);
         for (int e = t; e < n_i * cw; e += 256) {
-            const int ai = e / cw, q = e - ai * cw, a = il[ai], b = cl[c0 + q];
-            const double v = W[sidx[a] * cc + q];
+            const int ai = e / cw, q = e - ai * cw, a = il(ai), b = cl(c0 + q);
+            const double v = W[cpg_src(a, pose_rows) * cc + q];
             Pout[(size_t)a * ldout + b] = v; Pout[(size_t)b * ldout + a] = v;
         }
+        BE_TICK(g_la_tick, role == 0, 11);
         return;
     }
+    BE_TICK(g_la_tick, true, 16);
     double* Q = sh + L * L; double* PII = Q + L * L; double* T = PII + L * L; double* Pn = T + L * L;
-    int* sidx = (int*)(Pn + L * L);
-    for (int e = t; e < 2 * n_out; e += 256) sidx[e] = ix[e];
-    for (int e = t; e < 2 * L * L; e += 256) sh[e] = phiq[e];
-    for (int e = t; e < L * L; e += 256) { const int i = e / L, j = e - i * L; PII[e] = Pin[(size_t)i * ldin + j]; }
+    load_phi();
+    for (int e = t; e < L * L; e += 256) {
+        const int i = e / L, j = e - i * L;
+        if (BYVAL) Q[e] = (i < 15 && j < 15) ? pq.q[i * 15 + j] : 0.0; else Q[e] = phiq[L * L + e];
+        PII[e] = Pin[(size_t)i * ldin + j];
+    }
     __syncthreads();
+    BE_TICK(g_la_tick, true, 17);
     for (int e = t; e < L * L; e += 256) {
         const int i = e / L, j = e - i * L; double s = 0.;
+#pragma unroll
         for (int k = 0; k < L; ++k) s += Phi[i * L + k] * PII[k * L + j];
         T[e] = s;
     }
@@ -257,16 +302,17 @@ __global__ void __launch_bounds__(256) k_cov_propagate_gather(const double* __re
         const int i = e / L, j = e - i * L;
         if (j > i) continue;
         double s1 = 0., s2 = 0.;
+#pragma unroll
         for (int k = 0; k < L; ++k) { s1 += T[i * L + k] * Phi[j * L + k]; s2 += T[j * L + k] * Phi[i * L + k]; }
         const double v = ((s1 + Q[i * L + j]) + (s2 + Q[j * L + i])) / 2.0;
         Pn[i * L + j] = v; Pn[j * L + i] = v;
     }
     __syncthreads();
-    const int* il = sidx + n_out;
     for (int e = t; e < n_i * n_i; e += 256) {
-        const int ai = e / n_i, bi = e - ai * n_i, a = il[ai], b = il[bi];
-        Pout[(size_t)a * ldout + b] = Pn[sidx[a] * L + sidx[b]];
+        const int ai = e / n_i, bi = e - ai * n_i, a = il(ai), b = il(bi);
+        Pout[(size_t)a * ldout + b] = Pn[cpg_src(a, pose_rows) * L + cpg_src(b, pose_rows)];
     }
+    BE_TICK(g_la_tick, true, 18);
 }
 
 // re-anchoring of a 1-D inverse-depth feature (updateFeatureCov_1didp, larvio.cpp:3125-3293): row/col fc <- J P, J P J^T
@@ -393,6 +439,11 @@ __device__ __forceinline__ double rsqrt_refined(double x)
 // so a11 gets a rank-4 update per 4 pivots and L10 Y00 needs no data movement either.  The inverse runs in the MFMA shadow of
 // the factorisation: step j scales row j of Y by rinv and subtracts L[i][j] (i > j) times it from the rows below - the same
 // operand registers again.  Y10 = -Y11 (L10 Y00) closes the block (one LDS round trip for the transposed operand).
+// What paces the block is instruction ISSUE on the one wavefront that owns the chain (~60 wave64 instructions per pivot at >= 4 cycles
+// each: 6.4 us per 32 pivots, profiles/r4_e_be_ticks.json), not the matrix core and not the dependent chain alone: two variants were
+// built and measured against this one and dropped - the inverse on a second wavefront fed through LDS (the hand-over's writes cost
+// the leader what the MFMAs it shed had cost: 6.7 + 1.3 us, r4_g_be_ticks.json) and an LDL^T chain with the square roots deferred to
+// the end (5.7 + 1.1 us, r4_h_be_ticks.json).
 __device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (*Y)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
 {
     const int c = lane & 15, g = lane >> 4;
@@ -404,17 +455,26 @@ __device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (
         a11[r] = D[16 + g + 4 * r][16 + c];
         y00[r] = (g + 4 * r == c) ? 1.0 : 0.0; y11[r] = y00[r]; lop[r] = 0.;
     }
+    int first_bad = -1;                                  // wave-uniform: the first non-positive pivot of this block (reported once, after the loop)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        double piv = readlane_f64(half ? a11[0] : a00[0], 0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int q = j >> 2, gj = j & 3;
             d4& aa = half ? a11 : a00; d4& yy = half ? y11 : y00;
-            double piv = readlane_f64(aa[q], 16 * gj + j);
-            if (!(piv > 0.)) { if (report && lane == 0 && 16 * half + j < nb && info[0] == 0) info[0] = j0 + 16 * half + j + 1; piv = 1.0; }
-            const double rinv = rsqrt_refined(piv);
+            const bool okp = piv > 0.;
+            first_bad = (!okp && first_bad < 0 && 16 * half + j < nb) ? 16 * half + j : first_bad;
+            const double pv = okp ? piv : 1.0;
+            const double rinv = rsqrt_goldschmidt(pv);
             const bool rs = g == gj;
             const double v = (rs && c >= j) ? aa[q] * rinv : 0.0;                 // L[c][j] (the diagonal is piv * rinv = sqrt(piv))
+            if (j < 15) {
+                // the NEXT pivot, D[j+1][j+1] - L[j+1][j]^2, taken from registers while the rank-1 update below is still in the matrix
+                // core (one product, one rounding: the same value the update leaves in the tile): its rsqrt chain overlaps the MFMA
+                const double l1 = readlane_f64(v, 16 * gj + j + 1);
+                piv = __builtin_fma(-l1, l1, readlane_f64(aa[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1));
+            }
             aa = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, aa, 0, 0, 0);
             if (!half) {
                 const double u = rs ? a01[q] * rinv : 0.0;                        // L[16 + c][j]
@@ -427,6 +487,7 @@ __device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (
             if (!half && gj == 3) a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-lop[q], lop[q], a11, 0, 0, 0);
         }
     }
+    if (first_bad >= 0 && report && lane == 0 && info[0] == 0) info[0] = j0 + first_bad + 1;
     // T = L10 Y00 (operands are lop and y00 as they stand), then Y10 = -Y11 T with Y11 read back transposed from LDS
     d4 tt = {0., 0., 0., 0.};
 #pragma unroll
@@ -534,6 +595,7 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
     const int nblk = (m + CP_NB - 1) / CP_NB;
     const d4 zero4 = {0., 0., 0., 0.};
     if (blockIdx.x == 0) {
+        BE_TICK(g_la_tick, true, 22);
         // ===================================================================== factor role
         cf_blk* Sb = (cf_blk*)cf_smem;                                   // lower blocks, cf_idx(bi, bj)
         cf_blk* Yb = (cf_blk*)(cf_smem + (size_t)(CF_MAXB * (CF_MAXB + 1) / 2) * CP_NB * CF_LD);    // two: panel p's inverse is published while p+1's is being built
@@ -561,12 +623,14 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
                 }
         }
         __syncthreads();
+        BE_TICK(g_la_tick, true, 23);
         for (int p = 0; p < nblk; ++p) {
             cf_blk& Yi = Yb[p & 1];
             // ---- C1
-            if (wave == 0) chol32_inv_mfma(Sb[cf_idx(p, p)], Yi, min(CP_NB, m - 32 * p), lane, info, row0 + 32 * p, true);
+            if (wave == 0) { chol32_inv_mfma(Sb[cf_idx(p, p)], Yi, min(CP_NB, m - 32 * p), lane, info, row0 + 32 * p, true); BE_TICK(g_la_tick, true, 24 + 3 * p); }
             else if (p > 0) cf_deferred(Sb, Yb[(p - 1) & 1], p - 1, nblk, m, S, lds_, Yg, flag, base, wave, lane);
             __syncthreads();
+            BE_TICK(g_la_tick, true, 25 + 3 * p);
             // ---- C2: X = A Y^T for the blocks below the diagonal, 16 rows x 32 columns per unit (block p+1's two units first)
             for (int u = wave; u < 2 * (nblk - p - 1); u += 4) {
                 const int bi = p + 1 + (u >> 1), tr = u & 1;
@@ -584,12 +648,18 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
             }
             if (p + 1 < nblk) {
                 __syncthreads();
+                BE_TICK(g_la_tick, true, 26 + 3 * p);
                 // ---- C3: the next diagonal block, one tile per wavefront ((0,1) is never read)
                 if (wave != 1) cf_tile_sub(Sb[cf_idx(p + 1, p + 1)], Sb[cf_idx(p + 1, p)], Sb[cf_idx(p + 1, p)], wave >> 1, wave & 1, i16, kk);
                 __syncthreads();
             }
         }
         if (wave != 0) cf_deferred(Sb, Yb[(nblk - 1) & 1], nblk - 1, nblk, m, S, lds_, Yg, flag, base, wave, lane);
+        BE_TICK(g_la_tick, true, 40);
+        if (t == 0) { BE_TICK(g_la_tick, true, 41); }
+#ifdef LVK_BE_TIMING
+        if (t == 0) g_la_tick[42] = (unsigned long long)m;
+#endif
         return;
     }
     // ========================================================================= solver role: 16 columns of B per wavefront
@@ -739,16 +809,25 @@ lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, 
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
-lvk_status lvk_cov_propagate_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_ix, int n_out, int n_i, int L,
-                                    const double* d_phiq)
+// h_phi, h_q: the composed L x L transition and noise matrices on the HOST (row-major); d_phiq: their copy in the upload arena ([Phi | Q]),
+// used only when L != 22
+lvk_status lvk_cov_propagate_augment(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, int n_out, int pose_rows, int L,
+                                     const double* h_phi, const double* h_q, const double* d_phiq)
 {
-    const int n_c = n_out - n_i, cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS;
-    const size_t ints = sizeof(int) * (size_t)2 * n_out + 16;
-    const size_t strip = sizeof(double) * ((size_t)L * L + (size_t)2 * L * (cc > 0 ? cc : 1)) + ints, core = sizeof(double) * (size_t)5 * L * L + ints;
+    const int n_c = n_out - L - 6, cc = (n_c + CPG_STRIPS - 1) / CPG_STRIPS;
+    const size_t strip = sizeof(double) * ((size_t)L * L + (size_t)2 * L * (cc > 0 ? cc : 1)), core = sizeof(double) * (size_t)5 * L * L;
     const size_t shmem = strip > core ? strip : core;
     if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n_out);
-    if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 9, k_cov_propagate_gather, shmem);
-    hipLaunchKernelGGL(k_cov_propagate_gather, dim3(n_out + CPG_STRIPS + 1), dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, d_ix, n_out, n_i, L, d_phiq);
+    const dim3 grid(n_out + CPG_STRIPS + 1);
+    if (L == 22) {
+        PhiQ22 pq;
+        memcpy(pq.phi, h_phi, sizeof pq.phi);
+        for (int i = 0; i < 15; ++i) memcpy(pq.q + 15 * i, h_q + (size_t)22 * i, sizeof(double) * 15);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_propagate_augment<22, true>), grid, dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, n_out, pose_rows, (const double*)nullptr, pq);
+    } else if (L == 46) {
+        if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 9, (k_cov_propagate_augment<46, false>), shmem);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_propagate_augment<46, false>), grid, dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, n_out, pose_rows, d_phiq, PhiQ22());
+    } else return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "IMU block of %d states", L);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

@@ -93,6 +93,18 @@ lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...
 
 #define LVK_LAUNCH_CHECK(ctx) LVK_HIP(ctx, hipGetLastError())
 
+// ---- compile-time instrumentation (make CXXFLAGS+=-DLVK_BE_TIMING; tools/gpu/be_ticks.py): thread 0 of ONE chosen workgroup of a kernel
+// stores the 100 MHz wall clock at its phase boundaries into a per-file device array; off, the macros vanish
+#ifdef LVK_BE_TIMING
+#define BE_TICK_DECL(name) static __device__ unsigned long long name[64]
+#define BE_TICK(arr, cond, k) do { if (threadIdx.x == 0 && (cond)) arr[k] = wall_clock64(); } while (0)
+#define BE_TICK_GETTER(fn, arr) extern "C" void fn(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(arr), sizeof(unsigned long long) * 64); }
+#else
+#define BE_TICK_DECL(name)
+#define BE_TICK(arr, cond, k) do { } while (0)
+#define BE_TICK_GETTER(fn, arr)
+#endif
+
 // ---- device helpers shared by the kernels --------------------------------------------------
 __device__ __forceinline__ int d_reflect101(int p, int len)
 {

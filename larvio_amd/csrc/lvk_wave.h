@@ -27,4 +27,17 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return s;
 }
 
+// 1/sqrt(x) to full double precision from the v_rsq_f64 seed by two coupled (Goldschmidt) steps, all FMAs: six dependent operations
+// behind the seed (a Newton form compiled without contraction is nine, 1.0 / sqrt(x) is ~90 instructions of IEEE expansion)
+__device__ __forceinline__ double rsqrt_goldschmidt(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    double r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-g, h, 0.5);
+    h = __builtin_fma(h, r, h);
+    return h + h;
+}
+
 #endif

@@ -65,7 +65,7 @@ def test_driver_loop_matches_oracle(gpu_ctx, device_frames):
         for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
             e_k = _rel(sg[k], so[k])
             if e_k > worst:
-                worst = e_k; _WORST_AT.update(update=n_upd, frame=i, what=k, detail="")
+                worst = e_k; _WORST_AT.update(update=n_upd, frame=i, what=k, detail="max|ref| %.3e, abs diff %.3e" % (np.abs(so[k]).max(), np.abs(np.asarray(sg[k]) - so[k]).max()))
         Pg, Po = be.cov(), obe.cov()
         e_p = _rel(Pg, Po)
         if e_p > worst:
@@ -278,7 +278,7 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
         for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
             e_k = _rel(sg[k], so[k])
             if e_k > worst:
-                worst = e_k; _WORST_AT.update(update=n_upd, frame=i, what=k, detail="")
+                worst = e_k; _WORST_AT.update(update=n_upd, frame=i, what=k, detail="max|ref| %.3e, abs diff %.3e" % (np.abs(so[k]).max(), np.abs(np.asarray(sg[k]) - so[k]).max()))
         Pg, Po = be.cov(), obe.cov()
         e_p = _rel(Pg, Po)
         if e_p > worst:
