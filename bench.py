@@ -368,7 +368,7 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
     all-gathered over RCCL (strong scaling of the update); otherwise rank r runs its own stream (replicas).
     At N = 1, --sharded runs the sharded branch through RCCL with a one-rank communicator (loop-back: pack -> ncclAllGather -> unpack
     -> second stage on one GPU); without it the line carries that run as `rccl_loopback` next to the unsharded value.
-    The last 40 messages of the pre-roll run with HIP events around every level of the structure-aware TSQR compression (k_qr_sparse)
+    The last 40 messages of the pre-roll run with HIP events around every level of the structure-aware TSQR compression (k_qr_sparse_reg)
     and around the H P GEMM: `roofline` (TSQR) and `roofline_mfma` of this workload."""
     import larvio_amd
     from larvio_amd import synthetic as S
@@ -456,7 +456,7 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
     roof_qr = None
     if qr and qr["launches"] > 0 and qr["ms"] > 0:
         ach = qr["flops"] / qr["ms"] / 1e9
-        roof_qr = {"kernel": "k_qr_sparse (one level of the structure-aware TSQR compression of the stacked measurement rows; FP64 Householder nodes in LDS)",
+        roof_qr = {"kernel": "k_qr_sparse_reg (one level of the structure-aware TSQR compression of the stacked measurement rows; FP64 Householder nodes, columns in registers, reflector through LDS)",
                    "bound": "fp64-valu", "achieved": round(ach, 4), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 6),
                    "traffic": None, "flops_per_launch": round(qr["flops"] / qr["launches"], 1), "avg_launch_us": round(qr["ms"] / qr["launches"] * 1e3, 3),
                    "launches": qr["launches"], "rows_in_per_launch": round(qr["rows"] / qr["launches"], 1),

@@ -42,7 +42,6 @@
 struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; double* dx_host = nullptr; };   // ev_*: optional bracket around the H P GEMM; dx_host: host-mapped mirror of dx
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
-lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq);
 lvk_status lvk_cov_propagate_augment(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, int n_out, int pose_rows, int L,
                                      const double* h_phi, const double* h_q, const double* d_phiq);
 lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const double* d_J, int fc);
@@ -695,19 +694,6 @@ static void process_model(lvk_ekf* e, double time, const double* m_gyro, const d
     e->s.t = time; e->s_fej_now.t = time;
 }
 
-#ifdef LVK_AB_SEPARATE_PROPAGATE
-static lvk_status apply_propagation(lvk_ekf* e)
-{
-    if (!e->have_prop) return LVK_OK;
-    double* h = up_alloc<double>(e, 2 * LEG * LEG);
-    if (!h) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
-    memcpy(h, e->Phi_tot, sizeof(double) * LEG * LEG); memcpy(h + LEG * LEG, e->Q_tot, sizeof(double) * LEG * LEG);
-    e->have_prop = false;
-    double* P = e->dP[e->cur]; const int N = e->N, L = LEG; const double* d_h = dev(e, h);
-    return run_or_defer(e, [=]() { return lvk_cov_propagate(e->ctx, P, e->ld, N, L, d_h); });
-}
-#endif
-
 static int batch_imu(lvk_ekf* e, double time_bound, const lvk_imu* imu, int n_imu)
 {   // larvio.cpp:464-517
     int used = 0; double dt = 0.0;
@@ -1126,7 +1112,7 @@ static lvk_status qr_level_launch(lvk_ekf* e, const QrPlanLevel& L, const double
         a = take(); b = take();
         hipEventRecord(a, e->ctx->stream);
     }
-    lvk_status st = lvk_qr_sparse_level(e->ctx, Hin, e->ld, rin, Hout, e->ld, rout, d_blocks, (int)L.blocks.size(), d_cols, ncols, L.lds);
+    lvk_status st = lvk_qr_sparse_level(e->ctx, Hin, e->ld, rin, Hout, e->ld, rout, d_blocks, (int)L.blocks.size(), d_cols, ncols, L.lds, L.max_rows, L.max_cols);
     if (a) { hipEventRecord(b, e->ctx->stream); e->prof_pending.push_back({a, b, qr_level_flops(L), 1, (double)L.in_rows}); }
     return st;
 }
@@ -2122,14 +2108,7 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     const int used = batch_imu(e, ts + e->td, imu + off, n_imu - off);
     if (off + used != *n_consumed) return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "internal: IMU consumption count mismatch");
     TR(TR_IMU);
-#ifdef LVK_AB_SEPARATE_PROPAGATE                       // A/B builds only: k_cov_propagate (one workgroup), then the gather
-    begin_defer(e);
-    lvk_status st = apply_propagation(e);
-    if (st == LVK_OK) st = state_augmentation(e);
-    { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
-#else
     lvk_status st = state_augmentation(e);             // ONE launch: the frame's propagation + the augmentation gather
-#endif
     if (st != LVK_OK) return st;
     TR(TR_PROP);
     if (fetch) { lvk_status fs = fetch(fetch_user, &feats, &n_feats); if (fs != LVK_OK) return fs; }

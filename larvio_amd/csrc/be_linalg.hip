@@ -163,49 +163,6 @@ lvk_status lvk_stage_copy2(lvk_context* ctx, void* d_dst0, const void* d_src0, s
     return LVK_OK;
 }
 
-// IMU propagation of the covariance (processModel, larvio.cpp:553-571) with the per-frame composed Phi (L x L) and Q:
-//   P_II <- sym(Phi P_II Phi^T + Q) ; P_IC <- Phi P_IC ; P_CI <- P_IC^T.    phiq = [Phi | Q] (2*L*L doubles).
-#define CPR_THREADS 1024
-__global__ void __launch_bounds__(CPR_THREADS) k_cov_propagate(double* __restrict__ P, int ld, int n, int L, const double* __restrict__ phiq)
-{
-    extern __shared__ double sh[];
-    double* Phi = sh;                 // L x L
-    double* Q = sh + L * L;           // L x L
-    double* T = Q + L * L;            // L x L  : Phi * P_II
-    double* R = T + L * L;            // L x n  : old rows 0..L-1 of P
-    const int t = threadIdx.x;
-    // one workgroup on the dependent chain: all global loads of a thread are issued before the first one is used
-    for (int e = t; e < 2 * L * L; e += CPR_THREADS) sh[e] = phiq[e];
-    for (int e0 = t; e0 < L * n; e0 += CPR_THREADS * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + CPR_THREADS * u; if (e < L * n) { int i = e / n, j = e - i * n; v[u] = P[(size_t)i * ld + j]; } }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + CPR_THREADS * u; if (e < L * n) R[e] = v[u]; }
-    }
-    __syncthreads();
-    for (int e = t; e < L * L; e += CPR_THREADS) {
-        int i = e / L, j = e - i * L; double s = 0.;
-        for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * n + j];
-        T[e] = s;
-    }
-    // P_IC = Phi * R[:, L:]
-    for (int e = t; e < L * (n - L); e += CPR_THREADS) {
-        int i = e / (n - L), j = L + e % (n - L); double s = 0.;
-        for (int k = 0; k < L; ++k) s += Phi[i * L + k] * R[k * n + j];
-        P[(size_t)i * ld + j] = s; P[(size_t)j * ld + i] = s;
-    }
-    __syncthreads();
-    for (int e = t; e < L * L; e += CPR_THREADS) {
-        int i = e / L, j = e - i * L;
-        if (j > i) continue;
-        double s1 = 0., s2 = 0.;
-        for (int k = 0; k < L; ++k) { s1 += T[i * L + k] * Phi[j * L + k]; s2 += T[j * L + k] * Phi[i * L + k]; }
-        double v = ((s1 + Q[i * L + j]) + (s2 + Q[j * L + i])) / 2.0;
-        P[(size_t)i * ld + j] = v; P[(size_t)j * ld + i] = v;
-    }
-}
-
 // Propagation AND clone augmentation in one launch (processModel's covariance part, larvio.cpp:553-571, then stateAugmentation's
 // J P J^T, :752-798, which is a pure gather):  Pout[a][b] = Pprop[src(a)][src(b)]  with Pprop = the propagated Pin, never stored, and
 //     src(a) = a                      a < pose_rows            (IMU block, old clones)
@@ -797,15 +754,6 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n)
 {
     hipLaunchKernelGGL(k_cov_gather, dim3((n + 127) / 128, n), dim3(128), 0, ctx->stream, Pin, ldin, Pout, ldout, d_idx, n);
-    LVK_LAUNCH_CHECK(ctx);
-    return LVK_OK;
-}
-lvk_status lvk_cov_propagate(lvk_context* ctx, double* P, int ld, int n, int L, const double* d_phiq)
-{
-    const size_t shmem = sizeof(double) * ((size_t)3 * L * L + (size_t)L * n);
-    if (shmem > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "covariance dimension %d too large for the propagate kernel", n);
-    if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 0, k_cov_propagate, shmem);      // beyond 64 KB the launch needs the attribute
-    hipLaunchKernelGGL(k_cov_propagate, dim3(1), dim3(CPR_THREADS), shmem, ctx->stream, P, ld, n, L, d_phiq);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

@@ -13,10 +13,10 @@ struct RowGroup { int start, rows; ColList cols; int owner = 0; };   // owner: t
 // one node of one level: rows [in_start, in_start + in_rows) of the level's input, restricted to ncols columns (col_lists + col_off),
 // reduced to out_rows = min(in_rows, ncols) rows written at out_start of the level's output; copy = pass the rows through unchanged
 struct QrBlock { int in_start, in_rows, out_start, out_rows, ncols, col_off, copy, pad; };
-struct QrPlanLevel { std::vector<QrBlock> blocks; std::vector<int> cols; int in_rows = 0, out_rows = 0; size_t lds = 0; };
+struct QrPlanLevel { std::vector<QrBlock> blocks; std::vector<int> cols; int in_rows = 0, out_rows = 0; size_t lds = 0; int max_rows = 0, max_cols = 0; };   // max_*: over the level's factoring nodes
 
 size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N);
 // final_groups (optional): the row groups of the result (consecutive, with their column unions) - the input of a further stage
 void lvk_qr_sparse_plan(std::vector<RowGroup> groups, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups = nullptr);
 lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
-                               const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds);
+                               const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds, int max_rows, int max_cols);

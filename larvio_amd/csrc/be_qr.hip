@@ -107,18 +107,157 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restri
     }
 }
 
+// The same node with its columns in REGISTERS.  What paced k_qr_sparse was not flops but its per-step chain: three LDS-latency-bound loops
+// over the column (dot product, update, next norm) and a 64-lane reduction per column (~1.3-2.2 us per reflector, ~55 reflectors per
+// node: 77-150 us per level).  Here a column is spread over SIXTEEN lanes (lane l holds rows l, l + 16, ...), four columns share one
+// wavefront instruction, and a workgroup of sixteen wavefronts covers 64 columns per "quad" (QUADS of them): a dot product is RPL FMAs
+// on registers and a four-step DPP rotation inside the 16-lane row - for four columns at once, the sum arriving in every lane that
+// needs it - and the update is RPL FMAs.  Only the reflector itself travels through LDS (double-buffered, one barrier per step: the
+// wavefront that owns column k+1 updates it first and publishes its reflector in the shadow of the other columns' updates).
+// The gather on the way in and the expansion on the way out go through the same column-major LDS image as k_qr_sparse.
+__device__ __forceinline__ double row16_sum_f64(double v)
+{   // every lane ends up with the sum over its 16-lane DPP row
+    v += dpp_ror_f64(v, 8); v += dpp_ror_f64(v, 4); v += dpp_ror_f64(v, 2); v += dpp_ror_f64(v, 1);
+    return v;
+}
+template <int RPL, int QUADS>
+__global__ void __launch_bounds__(QS_THREADS) k_qr_sparse_reg(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
+                                                             double* __restrict__ Hout, int ldout, double* __restrict__ rout,
+                                                             const QrBlock* __restrict__ blocks, const int* __restrict__ col_lists, int N)
+{
+    extern __shared__ double sm[];
+    const QrBlock b = blocks[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l16 = lane & 15, cq = lane >> 4;
+    if (b.copy) {
+        for (int i = wave; i < b.in_rows; i += QS_WAVES) {
+            const double* src = Hin + (size_t)(b.in_start + i) * ldin; double* dst = Hout + (size_t)(b.out_start + i) * ldout;
+            for (int j = lane; j < N; j += 64) dst[j] = src[j];
+            if (lane == 0) rout[b.out_start + i] = rin[b.in_start + i];
+        }
+        return;
+    }
+    const int nc = b.ncols, R = b.in_rows, Rp = R | 1;
+    double* A = sm;                                                    // (nc + 1) columns of Rp doubles; column nc is the residual
+    double* diag = A + (size_t)(nc + 1) * Rp;                          // nc
+    double* scal = diag + nc;                                          // 2 (beta of the current / the next step)
+    double* vbuf = scal + 2;                                           // 2 x Rp: the reflector of the current / the next step
+    int* inv = (int*)(vbuf + 2 * (size_t)Rp);                          // N: dense column -> position in the union (or -1)
+    const int* cols = col_lists + b.col_off;
+    for (int j = t; j < N; j += QS_THREADS) inv[j] = -1;
+    for (int i = wave; i < R; i += QS_WAVES) {
+        const double* src = Hin + (size_t)(b.in_start + i) * ldin;
+        for (int c = lane; c <= nc; c += 64) A[(size_t)c * Rp + i] = c < nc ? src[cols[c]] : rin[b.in_start + i];
+    }
+    __syncthreads();
+    for (int c = t; c < nc; c += QS_THREADS) inv[cols[c]] = c;
+    // ---- columns into registers: quad Q = wave + 16 qd holds columns 4Q .. 4Q + 3, this lane column 4Q + cq, rows l16 + 16 rr
+    double a[QUADS][RPL];
+#pragma unroll
+    for (int qd = 0; qd < QUADS; ++qd) {
+        const int j = 4 * (wave + QS_WAVES * qd) + cq;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; a[qd][rr] = (j <= nc && i < R) ? A[(size_t)j * Rp + i] : 0.; }
+    }
+    const int steps = nc < R - 1 ? nc : R - 1;
+    // reflector of column k (rows k..): by the 16 lanes that hold it; v -> vbuf[k & 1], beta -> scal[k & 1], R's diagonal -> diag[k]
+    auto prep = [&](int k) {
+        const int qd = (k >> 2) / QS_WAVES;                              // (the caller made sure this wavefront owns column k)
+        if (cq != (k & 3)) return;
+        double part = 0., akk = 0.;
+#pragma unroll
+        for (int q2 = 0; q2 < QUADS; ++q2) if (q2 == qd) {
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; const double x = a[q2][rr]; if (i >= k) part += x * x; if (i == k) akk = x; }
+        }
+        const double s = row16_sum_f64(part);
+        akk = row16_sum_f64(akk);
+        // (norm and 2 / |v|^2 from FMA-refined hardware seeds: the IEEE sqrt and divide expand to ~80 instructions on this step's chain)
+        const double nrm = s > 0. ? s * rsqrt_goldschmidt(s) : 0.;
+        const double alpha = akk >= 0. ? -nrm : nrm;
+        const double vn2 = 2. * (s - alpha * akk);                 // |x - alpha e_k|^2
+        double beta = 0.;
+        if (nrm != 0. && vn2 != 0.) { const double y = rsqrt_goldschmidt(vn2); beta = 2. * (y * y); }
+        double* vb = vbuf + (size_t)(k & 1) * Rp;
+#pragma unroll
+        for (int q2 = 0; q2 < QUADS; ++q2) if (q2 == qd) {
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; if (i < R) vb[i] = i < k ? 0. : (i == k && beta != 0.) ? a[q2][rr] - alpha : a[q2][rr]; }
+        }
+        if (l16 == 0) { diag[k] = beta != 0. ? alpha : akk; scal[k & 1] = beta; }
+    };
+    if (wave == 0 && steps > 0) prep(0);
+    __syncthreads();
+    for (int k = 0; k < steps; ++k) {
+        const double beta = scal[k & 1];
+        const double* vb = vbuf + (size_t)(k & 1) * Rp;
+        const int r0 = k >> 4;                                       // rows below 16 r0 are finished
+        double v[RPL];
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; v[rr] = (rr >= r0 && i < R) ? vb[i] : 0.; }
+        const int own_next = (((k + 1) >> 2) % QS_WAVES) == wave && k + 1 < steps;
+#pragma unroll
+        for (int qd = 0; qd < QUADS; ++qd) {
+            const int j = 4 * (wave + QS_WAVES * qd) + cq;
+            if (4 * (wave + QS_WAVES * qd) + 3 <= k || beta == 0.) continue;      // the whole quad is finished (wave-uniform)
+            double s = 0.;
+#pragma unroll
+            for (int rr = 0; rr < RPL; ++rr) s += v[rr] * a[qd][rr];
+            s = row16_sum_f64(s) * beta;
+            if (j > k && j <= nc) {
+#pragma unroll
+                for (int rr = 0; rr < RPL; ++rr) a[qd][rr] -= s * v[rr];
+            }
+        }
+        if (own_next) prep(k + 1);                                   // in the shadow of the other wavefronts' updates
+        __syncthreads();
+    }
+    // ---- back to the LDS image (rows above the diagonal are R; the diagonal comes from diag[]), then expanded to the dense layout
+#pragma unroll
+    for (int qd = 0; qd < QUADS; ++qd) {
+        const int j = 4 * (wave + QS_WAVES * qd) + cq;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; if (j <= nc && i < R) A[(size_t)j * Rp + i] = a[qd][rr]; }
+    }
+    __syncthreads();
+    for (int i = wave; i < b.out_rows; i += QS_WAVES) {
+        double* dst = Hout + (size_t)(b.out_start + i) * ldout;
+        for (int j = lane; j < N; j += 64) {
+            const int c = inv[j];
+            double val = 0.;
+            if (c >= i && i < R) val = (c == i) ? (i < steps ? diag[i] : A[(size_t)i * Rp + i]) : A[(size_t)c * Rp + i];
+            dst[j] = val;
+        }
+        if (lane == 0) rout[b.out_start + i] = i < R ? A[(size_t)nc * Rp + i] : 0.;
+    }
+}
+
 // LDS a node needs (bytes): the planner's fit test and the launch use the same formula
 size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N)
 {
     const size_t Rp = (size_t)(rows | 1);
-    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2) + sizeof(int) * (size_t)N + 16;
+    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2 + 2 * Rp) + sizeof(int) * (size_t)N + 16;
+}
+template <int RPL, int QUADS>
+static lvk_status launch_qr_reg(lvk_context* ctx, int slot, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
+                                const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds)
+{
+    if (max_lds > 64 * 1024) LVK_LDS_OPTIN(ctx, slot, (k_qr_sparse_reg<RPL, QUADS>), max_lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_qr_sparse_reg<RPL, QUADS>), dim3(n_blocks), dim3(QS_THREADS), max_lds, ctx->stream, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, d_cols, N);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
 }
 lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
-                               const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds)
+                               const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds, int max_rows, int max_cols)
 {
     if (n_blocks <= 0) return LVK_OK;
     if (max_lds > 160 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "QR node needs %zu bytes of LDS", max_lds);
-    if (max_lds > 64 * 1024) LVK_LDS_OPTIN(ctx, 3, k_qr_sparse, max_lds);
+    // register-resident nodes where every node of the level fits one of the compiled shapes (rows <= 16 RPL, columns + 1 <= 64 QUADS)
+    const int rpl = (max_rows + 15) / 16, quads = (max_cols + 1 + 63) / 64;
+#define QR_REG(R_, Q_, slot_) return launch_qr_reg<R_, Q_>(ctx, slot_, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, n_blocks, d_cols, N, max_lds)
+    if (max_rows > 0 && quads == 1) { if (rpl <= 8) QR_REG(8, 1, 12); if (rpl <= 16) QR_REG(16, 1, 13); if (rpl <= 24) QR_REG(24, 1, 14); }
+    if (max_rows > 0 && quads == 2) { if (rpl <= 8) QR_REG(8, 2, 15); if (rpl <= 16) QR_REG(16, 2, 16); }
+#undef QR_REG
+    if (max_lds > 64 * 1024) LVK_LDS_OPTIN(ctx, 11, k_qr_sparse, max_lds);
     hipLaunchKernelGGL(k_qr_sparse, dim3(n_blocks), dim3(QS_THREADS), max_lds, ctx->stream, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, d_cols, N);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -136,6 +275,7 @@ static void merge_cols(const std::vector<int>& a, const std::vector<int>& b, std
 void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups)
 {
     const size_t LDS_CAP = (size_t)152 * 1024;
+    const int ROWS_CAP = 256, COLS_CAP = 127;             // the shapes k_qr_sparse_reg holds in registers (16 rows per lane, two column quads per wavefront)
     levels.clear();
     int total = 0; for (auto& g : cur) { g.start = total; total += g.rows; }
     std::vector<int> uni, merged;
@@ -148,11 +288,11 @@ void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLeve
             while (j < cur.size()) {
                 const int r2 = rows + cur[j].rows;
                 if (cur[j].cols.get() == same) {
-                    if (lvk_qr_sparse_lds_bytes(r2, (int)uni.size(), N) > LDS_CAP) break;
+                    if (lvk_qr_sparse_lds_bytes(r2, (int)uni.size(), N) > LDS_CAP || r2 > ROWS_CAP) break;
                     rows = r2; ++j; continue;
                 }
                 merge_cols(uni, *cur[j].cols, merged);
-                if (lvk_qr_sparse_lds_bytes(r2, (int)merged.size(), N) > LDS_CAP) break;
+                if (lvk_qr_sparse_lds_bytes(r2, (int)merged.size(), N) > LDS_CAP || r2 > ROWS_CAP || (int)merged.size() > COLS_CAP) break;
                 if (rows > (int)uni.size() && (int)(merged.size() - uni.size()) > cur[j].rows) break;
                 if (merged.size() != uni.size()) same = nullptr;
                 uni.swap(merged); rows = r2; ++j;
@@ -163,6 +303,7 @@ void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLeve
                 b.copy = 0; b.ncols = (int)uni.size(); b.out_rows = b.ncols; b.col_off = (int)L.cols.size();
                 L.cols.insert(L.cols.end(), uni.begin(), uni.end());
                 L.lds = std::max(L.lds, lvk_qr_sparse_lds_bytes(rows, b.ncols, N));
+                L.max_rows = std::max(L.max_rows, rows); L.max_cols = std::max(L.max_cols, b.ncols);
                 next.emplace_back(); next.back().start = out_row; next.back().rows = b.out_rows; next.back().cols = std::make_shared<const std::vector<int>>(uni);
                 any = true;
             } else {
@@ -250,7 +391,7 @@ extern "C" lvk_status lvk_ekf_compress_qr_groups(lvk_context* ctx, double* d_H, 
     double* H = d_H; double* r = d_r; size_t ob = 0, oc = 0;
     for (auto& L : levels) {
         double* Ho = (H == d_H) ? Hb : d_H; double* ro = (r == d_r) ? rb : d_r;
-        lvk_status st = lvk_qr_sparse_level(ctx, H, ld, r, Ho, ld, ro, d_blocks + ob, (int)L.blocks.size(), d_cols + oc, cols, L.lds);
+        lvk_status st = lvk_qr_sparse_level(ctx, H, ld, r, Ho, ld, ro, d_blocks + ob, (int)L.blocks.size(), d_cols + oc, cols, L.lds, L.max_rows, L.max_cols);
         if (st != LVK_OK) return st;
         ob += L.blocks.size(); oc += L.cols.size() + 1;
         H = Ho; r = ro;

@@ -20,9 +20,8 @@ struct lvk_context {
     void* scratch[LVK_SCRATCH_SLOTS];
     size_t scratch_bytes[LVK_SCRATCH_SLOTS];
     // dynamic-LDS opt-ins (hipFuncAttributeMaxDynamicSharedMemorySize) already made through THIS context: function attributes are
-    // per device, so the cache lives here and not in a process-wide static (slots: 0 k_cov_propagate, 1 k_feature_rows<false>,
-    // 2 k_gftt_select, 3 k_qr_panel)
-    size_t lds_optin[12];
+    // per device, so the cache lives here and not in a process-wide static (one slot per kernel instantiation, numbered at the call sites)
+    size_t lds_optin[24];
     // fused Cholesky + solve (be_linalg.hip, k_chol_fused): the factor workgroup hands panels to the solver workgroups through a flag
     // that only ever grows; chol_epoch numbers the launches, chol_ws (scratch slot 12) holds the diagonal-block inverses and the flag
     int chol_epoch;
