@@ -14,6 +14,7 @@
 #include "be_dev.h"
 #include "be_host_math.h"
 #include "be_qr.h"
+#include "be_init.h"
 #include <vector>
 #include <map>
 #include <stdexcept>
@@ -223,6 +224,8 @@ struct lvk_ekf {
     std::vector<int> grid_count;
     std::vector<double> coarse_dis;
     int static_counter = 0, static_num = 0; double lower_time_bound = 0;
+    lvk_status dyn_status = LVK_OK;
+    lvk_init::DynInit* dyn = nullptr;                    // the moving-start initialiser (be_init.h); lives until the filter has a state
     std::map<long long, std::pair<double, double>> init_features;
     long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     lvk_status failed = LVK_OK; char failed_msg[256] = {0};   // sticky: set by the first lvk_ekf_process that returned an error
@@ -1852,6 +1855,46 @@ static bool static_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, int
     return true;
 }
 
+// ------------------------------------------------------------------------- dynamic initializer (DynamicInitializer.cpp, be_init.h)
+// cv::findFundamentalMat's RANSAC mask from the library's own kernel (fe_track.hip); a cold path: buffers come and go with the call
+static bool dyn_ransac(void* user, const std::vector<lvk_init::Pt2>& ll, const std::vector<lvk_init::Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask)
+{
+    lvk_ekf* e = (lvk_ekf*)user;
+    const int n = (int)ll.size();
+    std::vector<lvk_pt2f> h((size_t)2 * n);
+    for (int i = 0; i < n; ++i) { h[(size_t)i] = lvk_pt2f{(float)ll[(size_t)i].x, (float)ll[(size_t)i].y}; h[(size_t)n + i] = lvk_pt2f{(float)rr[(size_t)i].x, (float)rr[(size_t)i].y}; }
+    lvk_pt2f* d_p = nullptr; uint8_t* d_mask = nullptr; int* d_info = nullptr; int info[2] = {0, 0};
+    bool ok = hipMalloc((void**)&d_p, sizeof(lvk_pt2f) * 2 * n) == hipSuccess && hipMalloc((void**)&d_mask, (size_t)n) == hipSuccess && hipMalloc((void**)&d_info, 2 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_p, h.data(), sizeof(lvk_pt2f) * 2 * n, hipMemcpyHostToDevice, e->ctx->stream) == hipSuccess;
+    ok = ok && lvk_find_fundamental_mask(e->ctx, d_p, d_p + n, n, thresh, conf, d_mask, d_info) == LVK_OK;
+    mask.assign((size_t)n, 0);
+    ok = ok && hipMemcpyAsync(mask.data(), d_mask, (size_t)n, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(info, d_info, sizeof info, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(e->ctx->stream) == hipSuccess;
+    if (d_p) hipFree(d_p); if (d_mask) hipFree(d_mask); if (d_info) hipFree(d_info);
+    if (!ok) e->dyn_status = lvk_set_error(e->ctx, LVK_ERR_DEVICE, "dynamic initialiser: RANSAC stage failed on the device");
+    return ok && info[0] == 1;
+}
+static bool dynamic_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, int n, const lvk_imu* imu, int n_imu, int* n_erased)
+{
+    *n_erased = 0;
+    if (!e->dyn) {                                       // DynamicInitializer's constructor (DynamicInitializer.h:40-75, larvio.cpp:343-349)
+        e->dyn = new lvk_init::DynInit();
+        lvk_init::DynInit& d = *e->dyn;
+        d.reset();
+        d.td = e->td; d.imu_img_time_th = e->imu_img_time_th;
+        m3_t(e->R_b2c, d.RIC); memcpy(d.TIC, e->t_c_b, 24);
+        memcpy(d.Ma, e->Ma, 72); memcpy(d.Tg, e->Tg, 72); memcpy(d.As, e->As, 72);
+        d.ransac = dyn_ransac; d.ransac_user = e;
+    }
+    lvk_init::DynInit& d = *e->dyn;
+    if (!d.try_init(ts, f, n, imu, n_imu, n_erased)) return false;
+    e->s.t = d.out.state_time;
+    memcpy(e->s.q, d.out.q, 32); memcpy(e->s.p, d.out.p, 24); memcpy(e->s.v, d.out.v, 24); memcpy(e->s.bg, d.out.bg, 24); memcpy(e->s.ba, d.out.ba, 24);
+    memcpy(e->m_gyro_old, d.out.last_gyro, 24); memcpy(e->m_acc_old, d.out.last_acc, 24);
+    return true;
+}
+
 // ------------------------------------------------------------------------- C ABI
 template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess; }
 
@@ -1883,6 +1926,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
     if (e->h_down) hipHostFree(e->h_down);
     if (e->shard.d_send) hipFree(e->shard.d_send);
     if (e->shard.d_recv) hipFree(e->shard.d_recv);
+    delete e->dyn;
     delete e;
 }
 
@@ -2094,11 +2138,15 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     if (!e->is_gravity_set) {
         if (fetch) { lvk_status fs = fetch(fetch_user, &feats, &n_feats); if (fs != LVK_OK) return fs; fetch = nullptr; }
         int erased = 0;
-        if (static_try_init(e, ts, feats, n_feats, imu, n_imu, &erased)) {
+        // FlexibleInitializer::tryIncInit (FlexibleInitializer.cpp:11-25): the static initialiser first, the dynamic one when that says no
+        bool ok = static_try_init(e, ts, feats, n_feats, imu, n_imu, &erased);
+        if (!ok) { e->dyn_status = LVK_OK; ok = dynamic_try_init(e, ts, feats, n_feats, imu, n_imu, &erased); if (e->dyn_status != LVK_OK) return e->dyn_status; }
+        if (ok) {
             e->is_gravity_set = true;
             e->take_off_stamp = e->s.t; e->last_zupt_time = e->s.t; e->last_update_time = e->s.t;
             e->s_fej_now = e->s;
             off = erased;
+            delete e->dyn; e->dyn = nullptr;
         } else return LVK_OK;
     }
     g_tr.start();

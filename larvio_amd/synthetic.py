@@ -396,12 +396,13 @@ INIT_COV = dict(initial_covariance_orientation=1e-6, initial_covariance_velocity
                 initial_covariance_gyro_bias=1e-8, initial_covariance_acc_bias=1e-6)
 
 
-def simulate_features(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=150, perturb=True, n_per_batch=120, **cfg_over):
+def simulate_features(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=150, perturb=True, n_per_batch=120, traj=None, fresh_ids=False, **cfg_over):
     """-> dict(cfg, imu, init=(t, q, p, v, bg, ba, gyro_old, acc_old), msgs=[(ts, OBS array)], traj)
     sigma: observation noise in normalised image units (3e-4 ~ 0.14 px at f = 458: what sub-pixel LK delivers);
     imu_noise: scale on the simulator's IMU noise densities (1.0 = synthetic.IMU_NOISE_*).  The initial state is the truth plus a
-    draw from the (small) initial covariance the configuration states."""
-    tr = Trajectory(); seq = imu_only_sequence(seed=seed, noise_scale=imu_noise)
+    draw from the (small) initial covariance the configuration states.  traj: another Trajectory than the default one; fresh_ids: a
+    landmark that left the view never comes back under its id (what a tracker does: a lost track's id is not reused)."""
+    tr = traj if traj is not None else Trajectory(); seq = imu_only_sequence(seed=seed, noise_scale=imu_noise); seq.traj = tr
     rng = np.random.default_rng([seed, 5])
     cloud = LandmarkCloud(tr, t0, t1, seed, n_per_batch=n_per_batch)
     over = dict(sw_size=20, estimate_td=0, estimate_extrin=0, if_zupt_valid=0, **INIT_COV)
@@ -415,7 +416,7 @@ def simulate_features(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=
         q = qmul(np.concatenate([0.5 * dth, [1.0]]), q); q /= np.linalg.norm(q)
         p += rng.normal(0, np.sqrt(cfg["initial_covariance_position"]), 3); v += rng.normal(0, np.sqrt(cfg["initial_covariance_velocity"]), 3)
     init = (ti, q, p, v, np.zeros(3), np.zeros(3), imu["gyro"][ki].copy(), imu["acc"][ki].copy())
-    tracked, prev_uv, msgs = {}, None, []
+    tracked, prev_uv, msgs, retired = {}, None, [], set()
     for i in range(int(round((t1 - t0) * 20)) + 1):            # camera frames at 20 Hz, a message every other frame
         ts = t0 + i * 0.05
         uv, vis = cloud.project(ts)
@@ -423,12 +424,15 @@ def simulate_features(seed, t0=2.0, t1=8.0, sigma=3e-4, imu_noise=1.0, max_feat=
         for j in list(tracked):
             if not vis[j]:
                 del tracked[j]
+                if fresh_ids:
+                    retired.add(j)
         if len(tracked) < max_feat:
             cand = np.flatnonzero(vis); rng.shuffle(cand)
             for j in cand:
                 if len(tracked) >= max_feat:
                     break
-                tracked.setdefault(int(j), True)
+                if int(j) not in retired:
+                    tracked.setdefault(int(j), True)
         if i % 2 == 0 and prev_uv is not None:
             ids = sorted(tracked)
             m = np.zeros(len(ids), _OBS)

@@ -47,3 +47,14 @@ def test_early_erase_count_equals_the_sequential_count_whenever_it_is_taken(tmp_
     r = _run_host_check(tmp_path, "erase_count_check")
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
     print(r.stdout.strip())
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc (host compile only)")
+def test_moving_start_initialiser_blocks_and_whole_on_closed_form_cases(tmp_path):
+    """be_init.h (DynamicInitializer.cpp and what it takes from OpenCV / Ceres, restated on the host): 3x3 SVD, 8-point + recoverPose,
+    PnP, the window's bundle adjustment and the pre-integration's bias Jacobian on closed-form cases; then the whole initialiser on a
+    simulated moving start with exact measurements (gravity direction < 2e-3, body velocity < 2 cm/s, gyro bias < 2e-4 rad/s, state
+    time and IMU erase count)."""
+    r = _run_host_check(tmp_path, "init_check")
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
+    print(r.stdout.strip())
