@@ -467,7 +467,7 @@ def backend_only(args, rank, world, local_rank, dist, torch, K=None, W=None, sha
     roof_hp = None
     if hp and hp["launches"] > 0 and hp["ms"] > 0:
         ach = hp["flops"] / hp["ms"] / 1e9
-        roof_hp = {"kernel": "k_dgemm<false,false> (H P)", "bound": "mfma", "achieved": round(ach, 4), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roof_hp = {"kernel": "k_dgemm_sk<false,false> (H P: four wavefronts split K for each 16x16 tile, ordered LDS reduction)", "bound": "mfma", "achieved": round(ach, 4), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 6), "flops_per_launch": round(hp["flops"] / hp["launches"], 1),
                    "avg_launch_us": round(hp["ms"] / hp["launches"] * 1e3, 3), "launches": hp["launches"]}
     lat = m["lat"]
@@ -780,7 +780,7 @@ def main():
                                          else "replicas x%d" % world},
                "roofline": roofline,
                # the one GEMM-shaped contraction of the path (P H^T as H P, FP64 MFMA 16x16x4): utilisation against the dense FP64 matrix peak
-               "roofline_mfma": {"kernel": "k_dgemm<false,false> (H P)", "bound": "mfma", "achieved": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9, 4),
+               "roofline_mfma": {"kernel": "k_dgemm_sk<false,false> (H P: four wavefronts split K for each 16x16 tile, ordered LDS reduction)", "bound": "mfma", "achieved": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9, 4),
                                  "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(hp["flops"] / max(hp["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 6),
                                  "flops_per_launch": round(hp["flops"] / max(hp["launches"], 1), 1),
                                  "avg_launch_us": round(hp["ms"] / max(hp["launches"], 1) * 1e3, 3), "launches": hp["launches"],

@@ -298,17 +298,19 @@ static void ekf_quiesce(const lvk_ekf* e)
 
 // ------------------------------------------------------------------------- host-side phase tracer (LVK_EKF_TRACE=1)
 #include <chrono>
-enum { TR_IMU, TR_PROP, TR_ADDOBS, TR_AUG, TR_ZUPT, TR_RLF_PRE, TR_RLF_TRI, TR_RLF_TRIAGE, TR_RLF_ROWS, TR_RLF_UPD, TR_RLF_DX, TR_RLF_INJ,
+enum { TR_IMU, TR_PROP, TR_FETCH, TR_ADDOBS, TR_ZUPT, TR_RLF_PRE, TR_RLF_TRI, TR_RLF_TRIAGE, TR_RLF_ROWS, TR_RLF_UPD, TR_RLF_DX, TR_RLF_INJ,
        TR_PR_PRE, TR_PR_TRI, TR_PR_ROWS, TR_PR_UPD, TR_PR_DX, TR_PR_END, TR_FINAL, TR_N };
-static const char* const TR_NAMES[TR_N] = {"batch_imu", "propagate(launch)", "add_obs", "augment(launch)", "zupt_check", "lost:prepare", "lost:triangulate+sync",
+static const char* const TR_NAMES[TR_N] = {"batch_imu", "propagate+augment(launch)", "message fetch (front-end wait)", "add_obs", "zupt_check", "lost:prepare", "lost:triangulate+sync",
     "lost:triage+jobs", "lost:rows+sync", "lost:stack+update(launch)", "lost:dx sync", "lost:inject", "prune:prepare(+reanchor)", "prune:triangulate+sync",
     "prune:rows+sync", "prune:update(launch)", "prune:dx sync", "prune:inject+delete", "final sync"};
 struct EkfTrace {
     bool on = false; double acc[TR_N] = {0}; long n = 0;
+    double sub_acc[8] = {0}; std::chrono::steady_clock::time_point last_sub;      // finer marks inside one phase (TRS): time since the previous mark of either kind
     double cur[TR_N] = {0};                              // this update's phases: an update above LVK_EKF_TRACE_SLOW_US is printed on its own
     std::chrono::steady_clock::time_point last;
-    void start() { if (on) { last = std::chrono::steady_clock::now(); for (int i = 0; i < TR_N; ++i) cur[i] = 0; } }
-    void mark(int slot) { if (!on) return; auto t = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double, std::micro>(t - last).count(); acc[slot] += d; cur[slot] += d; last = t; }
+    void start() { if (on) { last = last_sub = std::chrono::steady_clock::now(); for (int i = 0; i < TR_N; ++i) cur[i] = 0; } }
+    void mark(int slot) { if (!on) return; auto t = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double, std::micro>(t - last).count(); acc[slot] += d; cur[slot] += d; last = t; last_sub = t; }
+    void sub(int k) { if (!on) return; auto t = std::chrono::steady_clock::now(); sub_acc[k] += std::chrono::duration<double, std::micro>(t - last_sub).count(); last_sub = t; }
     void end_update(const char* const* names)
     {
         static const double slow = [] { const char* v = getenv("LVK_EKF_TRACE_SLOW_US"); return v ? atof(v) : 0.0; }();
@@ -322,6 +324,9 @@ struct EkfTrace {
 };
 static EkfTrace g_tr;
 #define TR(slot) g_tr.mark(slot)
+#define TRS(k) g_tr.sub(k)
+static const char* const TRS_NAMES[8] = {"update w/o new feature: jobs staged (launch_feature_rows)", "  row slots + groups (push_rows)", "  uploads flushed, row kernel launched (end_defer)",
+    "  compression planned / launched", "  update core launched (4 kernels)", "batch_imu: (unused)", "(unused)", "(unused)"};
 
 // Deferred updates (lvk_ekf_process_async): every entry point that reads or changes the filter first waits for the queued update.
 static void ekf_quiesce(const lvk_ekf* e);
@@ -1265,6 +1270,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
         if (st != LVK_OK) return st;
         m = m2;
     }
+    TRS(3);
     UpdateWs ws = e->ws;
     ws.dx_host = (double*)(e->dh_down + e->down_dx);
     if (e->prof_on && m > 0) {
@@ -1274,6 +1280,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     }
     st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, H, e->ld, m, r, e->sigma2, e->d_dx, ws);
     if (st != LVK_OK) return st;
+    TRS(4);
     dx.assign((size_t)e->N + extra, 0.0);
     e->counters[2] = m;
     return LVK_OK;
@@ -1424,6 +1431,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             if (sharded) { shard_bounds(jobs, 0, jobs.size(), e->shard.world, jb); own.push_back({jb[(size_t)e->shard.rank], jb[(size_t)e->shard.rank + 1]}); }
             begin_defer(e);                             // the jobs and the stacking map go up in one copy
             st = launch_feature_rows(e, jobs, sharded ? &own : nullptr);
+            TRS(0);
             if (st != LVK_OK && !sharded) { end_defer(e); return st; }
             lvk_status st_rows = st;                    // sharded: a local failure still goes through the exchange (shard_stage1, pre_fail)
             std::vector<StackRow> map_o; std::vector<RowGroup> grp;
@@ -1435,8 +1443,10 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             for (size_t k = j_ekf; k < j_msckf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, own_of(k)); if (direct) jobs[k].hdev->dst_row1 = rows_m + rows_e + 1; rows_e += 2; }
             int m = rows_m + rows_e;
             if (m > e->hrows) { for (RowJob& j : jobs) if (j.hdev) j.hdev->dst_row1 = 0; end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }   // (the same on every rank)
+            TRS(1);
             if (!sharded && !direct) st = stack_rows(e, map_o, e->d_H, N, e->d_r);
             { lvk_status s2 = end_defer(e); if (st == LVK_OK) st = s2; }
+            TRS(2);
             if (sharded) { st = shard_stage1(e, map_o, grp, N, &jb, &m, st_rows != LVK_OK ? st_rows : st); e->shard.stats[2]++; }
             std::vector<double> dx;
             if (st == LVK_OK) st = dense_update(e, m, dx, 0, &grp);
@@ -1917,6 +1927,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
         double tot = 0; for (int i = 0; i < TR_N; ++i) tot += g_tr.acc[i];
         fprintf(stderr, "[lvk_ekf trace] %ld updates, %.1f us/update host wall\n", g_tr.n, tot / g_tr.n);
         for (int i = 0; i < TR_N; ++i) fprintf(stderr, "  %-28s %8.1f us\n", TR_NAMES[i], g_tr.acc[i] / g_tr.n);
+        for (int i = 0; i < 8; ++i) if (g_tr.sub_acc[i] > 0) fprintf(stderr, "    [%s] %.1f us\n", TRS_NAMES[i], g_tr.sub_acc[i] / g_tr.n);
         g_tr = EkfTrace();
     }
     void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
@@ -2160,9 +2171,9 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     if (st != LVK_OK) return st;
     TR(TR_PROP);
     if (fetch) { lvk_status fs = fetch(fetch_user, &feats, &n_feats); if (fs != LVK_OK) return fs; }
+    TR(TR_FETCH);
     add_observations(e, feats, n_feats);
     TR(TR_ADDOBS);
-    TR(TR_AUG);
     if (e->cfg.if_zupt_valid) { bool z = false; st = check_zupt(e, &z); if (st != LVK_OK) return st; e->if_zupt = z; }
     TR(TR_ZUPT);
     st = remove_lost_features(e);

@@ -924,14 +924,14 @@ lvk_status lvk_min_eigen_map(lvk_context* ctx, const lvk_pyramid* p, float* d_ei
 // internal: GFTT on a precomputed eig map with caller-provided scratch (used by the frame-level path too)
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
                         double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
-                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub)
-{
+                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared)
+{   // prepared: lvk_gftt_prepare already queued the two memsets (ahead of whatever this call has to wait for)
     if (min_distance < 1.0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "goodFeaturesToTrack with minDistance < 1 is not supported");
     const int cell = (int)rint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     if (gw * gh > GF_MAX_CELLS) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT grid %dx%d exceeds %d cells", gw, gh, GF_MAX_CELLS);
     if (max_corners > GF_MAX_OUT || max_corners <= 0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "maxCorners must be in 1..%d", GF_MAX_OUT);
-    LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
+    if (!prepared) LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
     { int mb = (w * h / 4 + 2047) / 2048; mb = mb < 128 ? 128 : mb > 1024 ? 1024 : mb;      // ~8 four-pixel loads per lane
       hipLaunchKernelGGL(k_masked_max, dim3(mb), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch); }
     hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, (h - 2 + GC_ROWS - 1) / GC_ROWS), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
@@ -943,9 +943,18 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
     return LVK_OK;
 }
 
-lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask)
+// the two clears of a detection (mask image, selection scratch): they depend on nothing but the previous detection on the same stream,
+// so the frame path queues them BEFORE it waits for the frame's commit - two dispatches less on the chain commit -> detection -> next
+// frame's new-point tracking, which is what bounds the front-end's frame rate (profiles/r4_y_frontend_caller_trace.txt)
+lvk_status lvk_gftt_prepare(lvk_context* ctx, uint8_t* d_mask, int w, int h, unsigned* d_scratch)
 {
-    LVK_HIP(ctx, hipMemsetAsync(d_mask, 255, (size_t)w * h, ctx->stream));
+    if (d_mask) LVK_HIP(ctx, hipMemsetAsync(d_mask, 255, (size_t)w * h, ctx->stream));
+    LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
+    return LVK_OK;
+}
+lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask, bool prepared)
+{
+    if (!prepared) LVK_HIP(ctx, hipMemsetAsync(d_mask, 255, (size_t)w * h, ctx->stream));
     if (max_pts > 0) hipLaunchKernelGGL(k_mask_boxes, dim3(max_pts), dim3(256), 0, ctx->stream, d_pts, d_n, w, h, md, d_mask);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -963,6 +972,6 @@ extern "C" lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, 
     unsigned long long* cands = (unsigned long long*)lvk_ctx_scratch(ctx, 3, sizeof(unsigned long long) * cand_alloc);
     if (!eig || !scratch || !cands) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
     lvk_status st = lvk_min_eigen_map(ctx, p, eig);
-    if (st == LVK_OK) st = lvk_gftt_run(ctx, eig, d_mask, w, h, max_corners, quality, min_distance, scratch, cands, cand_cap, d_out, cap, d_n_out, nullptr);
+    if (st == LVK_OK) st = lvk_gftt_run(ctx, eig, d_mask, w, h, max_corners, quality, min_distance, scratch, cands, cand_cap, d_out, cap, d_n_out, nullptr, false);
     return st;
 }

@@ -20,8 +20,9 @@
 
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
                         double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
-                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub);
-lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask);
+                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared);
+lvk_status lvk_gftt_prepare(lvk_context* ctx, uint8_t* d_mask, int w, int h, unsigned* d_scratch);
+lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask, bool prepared);
 
 // =========================================================================== context
 extern "C" {
@@ -552,6 +553,19 @@ static void prof_collect(lvk_frontend* fe)
 
 template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess; }
 
+// host-side phase tracer of the calling thread (LVK_FE_TRACE=1; printed by lvk_frontend_destroy): where the caller's time per frame goes
+#include <chrono>
+enum { FT_SLOT_WAIT, FT_STAGE_COPY, FT_UPLOAD, FT_IMAGE_LAUNCH, FT_PREDICT, FT_TRACK_LAUNCH, FT_COMMIT_LAUNCH, FT_PUBLISH, FT_DETECT, FT_END, FT_N };
+static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: events + 6 launches", "frame checks + predict_homography",
+    "track chains: 2 launches + events", "commits: 2 launches + events", "message: slot + launch + event", "detection: 7 launches", "end-of-frame events + rotation"};
+struct FeTrace {
+    bool on = false; double acc[FT_N] = {0}; long n = 0; std::chrono::steady_clock::time_point last;
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(int k) { if (!on) return; auto t = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(t - last).count(); last = t; }
+};
+static FeTrace g_ft;
+#define FT(k) g_ft.mark(k)
+
 static void set_free(TrackSet& s)
 {
     if (s.id) hipFree(s.id); if (s.pts) hipFree(s.pts); if (s.ppts) hipFree(s.ppts); if (s.init) hipFree(s.init);
@@ -618,6 +632,12 @@ extern "C" {
 void lvk_frontend_destroy(lvk_frontend* fe)
 {
     if (!fe) return;
+    if (g_ft.on && g_ft.n > 0) {
+        double tot = 0; for (int i = 0; i < FT_N; ++i) tot += g_ft.acc[i];
+        fprintf(stderr, "[lvk_frontend trace] %ld frames, %.1f us/frame of caller time inside the front-end\n", g_ft.n, tot / g_ft.n);
+        for (int i = 0; i < FT_N; ++i) fprintf(stderr, "  %-44s %8.1f us\n", FT_NAMES[i], g_ft.acc[i] / g_ft.n);
+        g_ft = FeTrace();
+    }
     prof_collect(fe);
     hipStreamSynchronize(fe->ctx->stream);
     for (int i = 0; i < 2; ++i) if (fe->side[i]) { hipStreamSynchronize(fe->side[i]->stream); lvk_context_destroy(fe->side[i]); }
@@ -643,6 +663,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
 lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_frontend** out)
 {
     if (!ctx || !cfg || !out) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_frontend_create: bad argument");
+    g_ft.on = getenv("LVK_FE_TRACE") != nullptr;
     if (cfg->width < 64 || cfg->height < 64) return lvk_set_error(ctx, LVK_ERR_ARG, "image too small");
     if (cfg->max_features_num <= 0 || cfg->max_features_num > FM_MAX_N) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "max_features_num must be in 1..%d", FM_MAX_N);
     if (cfg->distortion_model != 0 && cfg->distortion_model != 1) return lvk_set_error(ctx, LVK_ERR_ARG, "distortion_model must be 0 (radtan) or 1 (equidistant)");
@@ -717,13 +738,13 @@ static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
     lvk_context* cx = fe->side[0];
     const lvk_fe_config& c = fe->cfg;
     lvk_status st;
-    { ProfScope ps(fe, 6, cx->stream); st = lvk_min_eigen_map(cx, fe->pyr[1], fe->eig); }
+    { ProfScope ps(fe, 6, cx->stream); st = lvk_min_eigen_map(cx, fe->pyr[1], fe->eig); if (st == LVK_OK) st = lvk_gftt_prepare(cx, fe->mask, c.width, c.height, fe->gf_scratch); }
     if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
     hipStreamWaitEvent(cx->stream, fe->ev_commit, 0);
     ProfScope ps(fe, 7, cx->stream);
-    st = lvk_mask_boxes(cx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask);
+    st = lvk_mask_boxes(cx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask, true);
     if (st == LVK_OK) st = lvk_gftt_run(cx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
-                                        fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst]);
+                                        fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst], true);
     if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
     return LVK_OK;
 }
@@ -757,8 +778,10 @@ static lvk_status fe_publish_finish(lvk_frontend* fe, int dst, double ts, int sl
 {
     hipEventRecord(fe->ev_msg[slot], fe->ctx->stream);
     fe->msg_pending[slot].store(1, std::memory_order_release);
+    FT(FT_PUBLISH);
     lvk_status st = fe_detect_new(fe, dst);              // queued on side[0] before anybody blocks on the message
     if (st != LVK_OK) return st;
+    FT(FT_DETECT);
     fe->last_pub_time = ts; fe->pub_counter++;
     if (async_slot) { *async_slot = slot; *n_out = 0; return LVK_OK; }
     return lvk_frontend_fetch_msg(fe, slot, h_out, cap, n_out);
@@ -800,16 +823,20 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     if (stc != LVK_OK) return stc;
     const uint8_t* d_img = image->data; int d_stride = image->stride;
     int slot = -1;
+    g_ft.start();
     if (!image->is_device) {
         slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
         // The slot was last used three frames back.  Its upload precedes frame f-2's image stage on the image stream, which the
         // main stream waited for before it recorded the end of frame f-2: that event covers it (and has long fired) - no per-slot event.
         if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_main[fe->n_img & 1]));
+        FT(FT_SLOT_WAIT);
         uint8_t* hs = fe->h_stage[slot];
         if (image->stride == c.width) memcpy(hs, image->data, (size_t)c.width * c.height);
         else for (int y = 0; y < c.height; ++y) memcpy(hs + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
+        FT(FT_STAGE_COPY);
         LVK_HIP(ctx, hipMemcpyAsync(fe->d_img, hs, (size_t)c.width * c.height, hipMemcpyHostToDevice, fe->side[1]->stream)); d_img = fe->d_img;
         d_stride = c.width;
+        FT(FT_UPLOAD);
     }
     lvk_status st;
     lvk_context* icx = fe->side[1];
@@ -835,6 +862,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
     hipEventRecord(fe->ev_orb, S0);
     fe->n_img += 1;
+    FT(FT_IMAGE_LAUNCH);
     return LVK_OK;
 }
 
@@ -938,7 +966,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         // initializeFirstFrame (:337-352): goodFeaturesToTrack(max_features_num, 0.01, min_distance), no mask
         { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
         if (st == LVK_OK) st = lvk_gftt_run(ctx, fe->eig, nullptr, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
-                                            fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, nullptr);
+                                            fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, nullptr, false);
         if (st == LVK_OK) st = fe_read_dev(fe);
         if (st != LVK_OK) return st;
         fe->last_pub_time = ts;
@@ -947,6 +975,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         HMat H;
         st = lvk_predict_homography(h_imu, n_imu, fe->prev_img_time, ts, c.R_cam_imu, c.intrinsics, H.h);
         if (st != LVK_OK) return lvk_set_error(ctx, st, "predict_homography failed");
+        FT(FT_PREDICT);
         if (fe->image_state == 2) {
             // initializeFirstFeatures (:355-537)
             st = track_chain(fe, S1, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
@@ -973,6 +1002,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             hipEventRecord(fe->ev_new, S2);
             if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
             if (st != LVK_OK) return st;
+            FT(FT_TRACK_LAUNCH);
             // the old tracks' RANSAC + commit overlaps the wait for the new points' chain; their append and the message follow.
             // (Both commits - and all three stages - as ONE launch were measured in same-box A/B runs and were slower: the old tracks'
             //  commit then waits for the new points' chain; profiles/r3_jk_frontend_chain_ab.json)
@@ -983,6 +1013,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             if (st != LVK_OK) return st;
             curr_valid = true;
             hipEventRecord(fe->ev_commit, S1);
+            FT(FT_COMMIT_LAUNCH);
             if (ts - fe->last_pub_time >= pub_gate) {
                 st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                 if (st != LVK_OK) return st;
@@ -999,6 +1030,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
     fe->cur = dst;
     fe->prev_img_time = ts;
     if (fe->pending.size() > 4096) prof_collect(fe);
+    FT(FT_END); g_ft.n++;
     return LVK_OK;
 }
 
