@@ -20,53 +20,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // Two optional riders save launches on the update's dependent chain: (xin, xin_col) copies a vector into column xin_col of C
 // ([HP | r] in one launch); (xout, xout_col) diverts output column xout_col to a vector, unscaled (W^T [W | w] -> P update and dx).
 struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; double* xout_host = nullptr; };   // xout_host: mirror of xout in device-mapped host memory
-template <bool TA, bool TB, int KU>
-__global__ void __launch_bounds__(256) k_dgemm(int M, int N, int K, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                              double* __restrict__ C, int ldc, double alpha, double beta, double diag_add, GemmRider rd)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.y * 2 + (wave >> 1)) * 16, col0 = (blockIdx.x * 2 + (wave & 1)) * 16;
-    if (row0 >= M || col0 >= N) return;
-    if (rd.xin && col0 == 0 && lane < 16 && row0 + lane < M) C[(size_t)(row0 + lane) * ldc + rd.xin_col] = rd.xin[row0 + lane];
-    const int i = lane & 15, kk = lane >> 4;
-    const int ar = row0 + i, bc = col0 + i;
-    const bool a_ok = ar < M, b_ok = bc < N;
-    // The operands come from other XCDs' L2s / the memory side (they were written by the previous kernel), so a dependent load
-    // costs microseconds and the tile's time is (number of load round trips) x latency, not bytes or flops: K is walked in
-    // chunks of 4 KU (64, or 128 for K >= 256: configs[4], N ~ 430) with all 2 KU loads of a chunk in flight before its KU MFMAs.
-    // Lane (i, kk) takes k = k0 + 16 u + 4 kk + q
-    // (4 consecutive k per lane: contiguous for the row-major operand) - a permutation of the summation index shared by A and B.
-    d4 acc = {0., 0., 0., 0.};
-    for (int k0 = 0; k0 < K; k0 += 4 * KU) {
-        double a[KU], b[KU];
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int k = k0 + 16 * (u >> 2) + 4 * kk + (u & 3);
-            const bool k_ok = k < K;
-            a[u] = (a_ok && k_ok) ? (TA ? A[(size_t)k * lda + ar] : A[(size_t)ar * lda + k]) : 0.;
-            b[u] = (b_ok && k_ok) ? (TB ? B[(size_t)bc * ldb + k] : B[(size_t)k * ldb + bc]) : 0.;
-        }
-#pragma unroll
-        for (int u = 0; u < KU; ++u)
-            if (k0 + 16 * (u >> 2) < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);   // FP64 MFMA is 64 cycles: no padded K groups
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = row0 + kk + 4 * r, col = col0 + i;
-        if (row < M && col < N) {
-            if (rd.xout && col == rd.xout_col) { rd.xout[row] = acc[r]; if (rd.xout_host) rd.xout_host[row] = acc[r]; continue; }
-            double v = alpha * acc[r];
-            if (beta != 0.) v += beta * C[(size_t)row * ldc + col];
-            if (row == col) v += diag_add;
-            C[(size_t)row * ldc + col] = v;
-        }
-    }
-}
-
-// Split-K form: the four wavefronts of a workgroup share ONE 16x16 tile and take every fourth K-chunk (kc <= 64 consecutive k, a
-// multiple of 16) each, so a tile of the update's products (K = N ~ 216 or K = m ~ 110..260) costs ONE load round trip per
-// wavefront instead of four dependent ones; the partial tiles meet in LDS and wavefront 0 adds them in a fixed order (chunk 0, 1,
-// 2, 3: reproducible).  Same lane <-> k permutation inside a chunk as k_dgemm.
+// Split-K: the four wavefronts of a workgroup share ONE 16x16 tile and take every fourth K-chunk (kc <= 64 consecutive k, a
+// multiple of 16) each.  The operands come from other XCDs' L2s / the memory side (they were written by the previous kernel), so a
+// dependent load costs microseconds and a tile's time is (number of load round trips) x latency, not bytes or flops: a tile of the
+// update's products (K = N ~ 216 or K = m ~ 110..260) costs ONE round trip per wavefront (all its loads in flight before the first
+// MFMA) instead of the four dependent ones of the tile-per-wavefront kernel of rounds 1-3; the partial tiles meet in LDS and
+// wavefront 0 adds them in a fixed order (chunk 0, 1, 2, 3: reproducible).  Inside a chunk lane (i, kk) takes k = k0 + 16 u + 4 kk + q
+// (4 consecutive k per lane: contiguous for the row-major operand) - a permutation of the summation index shared by A and B.
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) k_dgemm_sk(int M, int N, int K, int kc, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
                                                  double* __restrict__ C, int ldc, double alpha, double beta, double diag_add, GemmRider rd)
@@ -123,13 +83,8 @@ static void launch_dgemm(hipStream_t s, int M, int N, int K, const double* A, in
                          double alpha, double beta, double diag_add, GemmRider rd = GemmRider{nullptr, 0, nullptr, 0, nullptr})
 {
     if (M <= 0 || N <= 0) return;
-#ifdef LVK_AB_DGEMM_TILE_PER_WAVE     // A/B builds only: one tile per wavefront, K walked in dependent 64-wide phases
-    dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm<TA, TB, 16>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
-#else
     const int kc = K >= 193 ? 64 : 16 * ((K + 63) / 64);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dgemm_sk<TA, TB>), dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, s, M, N, K, kc, A, lda, B, ldb, C, ldc, alpha, beta, diag_add, rd);
-#endif
 }
 
 
