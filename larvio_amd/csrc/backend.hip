@@ -1234,7 +1234,15 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     // that all live in the same 19 columns compress to 19 rows in one ~60 us level instead of a 400-row factorisation.  Constants
     // from profiles/r4_a_kernel_stats.csv: k_qr_sparse 124 us for a 55-column node over ~250 rows; k_chol_fused 31 us per 160-row
     // super-panel (~5 us per 32-row panel + 8), two k_dgemm_sk launches (~12 us) per further super-panel.
-    if (groups && m > 160) {
+    auto t_chol = [](int rows) { const int p = (rows + 31) / 32, sp = (rows + 159) / 160; return 8.0 + 5.0 * p + 12.0 * (sp - 1) + 1.0e-4 * rows * rows; };
+    bool worth_planning = groups && m > 160;
+    if (worth_planning && m < e->sparse_qr_min_rows && !e->shard.fn) {
+        // the plan itself costs the filter's thread ~20 us: not drawn up when even its best case cannot win - one level whose widest
+        // node has only the widest row group's columns (c), compressing to c rows
+        size_t c = 0; for (const RowGroup& g : *groups) if (g.cols) c = std::max(c, g.cols->size());
+        worth_planning = 12.0 + (double)c + t_chol((int)c) < t_chol(m);
+    }
+    if (worth_planning) {
         std::vector<QrPlanLevel> levels; int m2 = m;
         lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
         bool take = !levels.empty() && m2 + 32 <= m;
@@ -1245,7 +1253,6 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
                 for (const QrBlock& b : L.blocks) if (!b.copy) worst = std::max(worst, (double)std::min(b.ncols, b.in_rows) * (1.0 + 0.004 * b.in_rows));
                 t_qr += 12.0 + worst;
             }
-            auto t_chol = [](int rows) { const int p = (rows + 31) / 32, sp = (rows + 159) / 160; return 8.0 + 5.0 * p + 12.0 * (sp - 1) + 1.0e-4 * rows * rows; };
             take = t_qr + t_chol(m2) < t_chol(m);
         }
         if (take) {
