@@ -444,21 +444,37 @@ __global__ void __launch_bounds__(256) k_gftt_candidates(const float* __restrict
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const int x = blockIdx.x * 256 + threadIdx.x + 1;
+    const int y0 = blockIdx.y * GC_ROWS + 1;
+    // every value a thread will look at - its column and the two next to it over GC_ROWS + 2 rows, its mask bytes - is asked for
+    // before the first one is used: the map was written by the previous kernel on other XCDs, and a row loop that loads, tests and
+    // only then loads the neighbours was three dependent round trips per row (11.5 us for a 361 KB image)
+    float e[GC_ROWS + 2][3]; uint8_t mk[GC_ROWS];
+    const bool xin = x < w - 1;
+#pragma unroll
+    for (int r = 0; r < GC_ROWS + 2; ++r) {
+        const int yy = y0 - 1 + r;
+        const bool ok = xin && yy < h;
+        const float* row = eig + (size_t)yy * w + x;
+        e[r][0] = ok ? row[-1] : 0.f; e[r][1] = ok ? row[0] : 0.f; e[r][2] = ok ? row[1] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < GC_ROWS; ++r) { const int y = y0 + r; mk[r] = (mask && xin && y < h - 1) ? mask[(size_t)y * w + x] : (uint8_t)1; }
     const float max_val = ord2f(scratch[0]);
     const float thresh = (float)((double)max_val * (double)quality);
+#pragma unroll
     for (int ry = 0; ry < GC_ROWS; ++ry) {
-        const int y = blockIdx.y * GC_ROWS + ry + 1;
+        const int y = y0 + ry;
         if (x >= w - 1 || y >= h - 1) continue;
-        float v = eig[(size_t)y * w + x];
+        float v = e[ry + 1][1];
         v = v > thresh ? v : 0.f;
         if (v == 0.f) continue;
-        if (mask && !mask[(size_t)y * w + x]) continue;
+        if (mask && !mk[ry]) continue;
         float m = v;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = 0; dy <= 2; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                float u = eig[(size_t)(y + dy) * w + x + dx];
+            for (int dx = 0; dx <= 2; ++dx) {
+                float u = e[ry + dy][dx];
                 u = u > thresh ? u : 0.f;
                 m = fmaxf(m, u);
             }
@@ -552,7 +568,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
     GF_TICK(2);
     // first bucket: a few times the corners still wanted (the publish-frame case asks for 10-50), later buckets double
     int target = 1024;
-    if (max_corners > 0) { target = 256; while (target < 4 * max_corners && target < 1024) target <<= 1; }
+    if (max_corners > 0) { target = 64; while (target < 4 * max_corners && target < 1024) target <<= 1; }   // (any bucket boundaries give the same corners)
     for (int bucket = 0; bucket < 4096; ++bucket) {
         // next bucket = whole histogram groups [lo, hi) below the current top holding >= target candidates (or all that is left):
         // suffix sums of the 1024 group counts by a block scan, then ONE thread-parallel boundary test - a serial walk over
@@ -632,16 +648,20 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
             __syncthreads();
         }
         if (ns <= 512) {
-            // rank sort, two threads per key: rank = number of larger keys (keys are unique: the pixel index is in the low word)
+            // rank sort, 1024 / P threads per key (P = ns rounded up to a power of two): rank = number of larger keys (keys are unique:
+            // the pixel index is in the low word).  The usual first bucket of a publish frame holds 100-200 keys: 4-8 threads per key,
+            // 16-32 comparisons each (two threads per key and 256 comparisons each were 13 of the kernel's 28 us)
             unsigned* rank = reinterpret_cast<unsigned*>(surv + 1024);
             unsigned long long* sorted = surv + 2048;
             if (t < 512) rank[t] = 0u;
             __syncthreads();
-            const int e = t & 511, half = t >> 9;
+            int P = 64; while (P < ns) P <<= 1;
+            const int parts = 1024 / P, e = t & (P - 1), part = t / P, span = (ns + parts - 1) / parts;
             if (e < ns) {
                 const unsigned long long mine = surv[e];
-                const int j0 = half * 256, j1 = min(ns, j0 + 256);
+                const int j0 = part * span, j1 = min(ns, j0 + span);
                 unsigned c = 0;
+#pragma unroll 4
                 for (int j = j0; j < j1; ++j) c += surv[j] > mine;
                 if (c) atomicAdd(&rank[e], c);
             }
@@ -669,6 +689,10 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
         }
         if (bucket == 0) GF_TICK(5);
         if (t < 64) {
+            // wavefront 0 resolves the sorted survivors in order, 64 at a time.  Inside a batch the loop only DECIDES (one iteration per
+            // accepted corner: its coordinates are broadcast from registers, the lanes behind it that it rules out drop out); the
+            // batch's accepted corners are then written - output list, accepted list, grid cell - by their own lanes in parallel
+            // (a one-lane section with two integer divisions and a dependent LDS slot search per corner was 7.6 of the kernel's 28 us)
             int na = sh_na;
             bool done = false;
             for (int sb = 0; sb < ns && !done; sb += 64) {
@@ -680,18 +704,12 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                     sy = idx / w; sx = idx - sy * w;
                     if (sb > 0 && gf_grid_conflict(cells, acc, gw, gh, cell, md2, sx, sy)) g = false;   // corners accepted earlier in this bucket
                 }
-                unsigned long long mm = __ballot(g);
+                unsigned long long mm = __ballot(g), accm = 0ull;
+                const int na0 = na;
                 while (mm) {
-                    const int j = __ffsll((long long)mm) - 1;
-                    const int xj = __shfl(sx, j), yj = __shfl(sy, j);
-                    if (lane == 0) {
-                        if (na < out_cap) { out[na].x = (float)xj; out[na].y = (float)yj; }
-                        if (na < GF_MAX_OUT) {
-                            acc[na] = make_short2((short)xj, (short)yj);
-                            unsigned short* c = cells[(yj / cell) * gw + (xj / cell)];
-                            for (int sl = 0; sl < 4; ++sl) if (c[sl] == 0xFFFF) { c[sl] = (unsigned short)na; break; }
-                        }
-                    }
+                    const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+                    const int xj = __builtin_amdgcn_readlane(sx, j), yj = __builtin_amdgcn_readlane(sy, j);
+                    accm |= 1ull << j;
                     ++na;
                     if ((max_corners > 0 && na == max_corners) || na >= GF_MAX_OUT) { done = true; break; }
                     if (g && lane > j) {
@@ -700,6 +718,27 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                     }
                     mm = __ballot(g && lane > j);
                 }
+                if ((accm >> lane) & 1ull) {
+                    const int r = na0 + __popcll(accm & ((1ull << lane) - 1ull));
+                    if (r < out_cap) { out[r].x = (float)sx; out[r].y = (float)sy; }
+                    if (r < GF_MAX_OUT) {
+                        acc[r] = make_short2((short)sx, (short)sy);
+                        // first free slot of the corner's cell (four 16-bit slots = one 64-bit word; slot order is irrelevant to the
+                        // conflict test; a full cell drops the entry, as before)
+                        unsigned long long* c64 = reinterpret_cast<unsigned long long*>(cells) + ((sy / cell) * gw + (sx / cell));
+                        unsigned long long old = *c64;
+                        for (;;) {
+                            int sl = -1;
+                            for (int q = 0; q < 4; ++q) if (((old >> (16 * q)) & 0xFFFFull) == 0xFFFFull) { sl = q; break; }
+                            if (sl < 0) break;
+                            const unsigned long long nw = (old & ~(0xFFFFull << (16 * sl))) | ((unsigned long long)(unsigned)r << (16 * sl));
+                            const unsigned long long prev = atomicCAS(c64, old, nw);
+                            if (prev == old) break;
+                            old = prev;
+                        }
+                    }
+                }
+                __threadfence_block();                      // the next batch's grid test reads what this one inserted
             }
             if (lane == 0) { sh_na = na; if (done) sh_done = 1; sh_hi = lo; }
         }
