@@ -427,7 +427,7 @@ static inline bool bundle_adjust(int nf, int l, std::vector<std::array<double, 9
             fprintf(stderr, "[init] BA it %d try %d lambda %.2e cost %.6e -> %.6e\n", it, tries, lambda, c0, c1);
 #endif
             if (std::isfinite(c1) && c1 < c0) {
-                converged = (c0 - c1) <= 1e-6 * c0;       // Ceres' function_tolerance
+                converged = (c0 - c1) <= 1e-13 * c0;      // (Ceres stops at 1e-6 or after 0.2 s, initial_sfm.cpp:288-290; this runs to the minimum - a cold path, and a defined target)
                 Rc.swap(Rn); tc.swap(tn); Xp.swap(Xn); c0 = c1; lambda = std::max(lambda / 3., 1e-12); improved = true;
             } else lambda *= 4.;
         }
@@ -590,6 +590,8 @@ static inline bool visual_imu_alignment(std::vector<Frame*>& fr, double (*Bgs)[3
 
 // ------------------------------------------------------------------------------------------------ the initialiser object
 struct Result { double state_time, q[4], p[3], v[3], bg[3], ba[3], last_gyro[3], last_acc[3]; };
+// intermediate results of the successful attempt (read by the replay harness of the CPU suite, tests/host/init_replay.hip)
+struct Diag { int l = -1; double relR[9], relT[3]; std::vector<std::array<double, 9>> sfm_R; std::vector<std::array<double, 3>> sfm_T; double g[3] = {0, 0, 0}, scale = 0; int n_points = 0; };
 // callback for cv::findFundamentalMat(ll, rr, FM_RANSAC, thresh, conf, mask): float correspondences -> inlier mask (empty = none computed)
 typedef bool (*ransac_fn)(void* user, const std::vector<Pt2>& ll, const std::vector<Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask);
 
@@ -605,7 +607,7 @@ struct DynInit {
     std::map<double, Frame> frames;                      // all_image_frame
     std::vector<FeatTrack> tracks;                       // FeatureManager::feature (std::list there; erase order is what matters, not the container)
     double g[3] = {0, 0, 0};
-    Result out;
+    Result out; Diag diag;
 
     void reset()
     {
@@ -690,11 +692,13 @@ struct DynInit {
         double relR[9], relT[3]; int l = 0;
         if (!relative_pose(relR, relT, &l)) return false;
         std::vector<std::array<double, 9>> Q; std::vector<std::array<double, 3>> T;
-        if (!global_sfm(frame_count + 1, l, relR, relT, sfm, Q, T)) return false;
+        if (!global_sfm(frame_count + 1, l, relR, relT, sfm, Q, T)) return false;      // (marginalization_flag = MARGIN_OLD: it always is, see add_features)
+        diag.l = l; memcpy(diag.relR, relR, 72); memcpy(diag.relT, relT, 24); diag.sfm_R = Q; diag.sfm_T = T;
+        diag.n_points = 0; for (auto& sf : sfm) diag.n_points += sf.state ? 1 : 0;
 #ifdef LVK_INIT_DEBUG
         fprintf(stderr, "[init] l = %d relT = %.4f %.4f %.4f\n", l, relT[0], relT[1], relT[2]);
         for (int i = 0; i <= frame_count; ++i) fprintf(stderr, "[init] frame %d T = %.4f %.4f %.4f  R row0 = %.4f %.4f %.4f\n", i, T[(size_t)i][0], T[(size_t)i][1], T[(size_t)i][2], Q[(size_t)i][0], Q[(size_t)i][1], Q[(size_t)i][2]);
-#endif      // (marginalization_flag = MARGIN_OLD: it always is, see add_features)
+#endif
         // every frame of all_image_frame is a window frame here (the map is trimmed to the window in slide_window), so each takes the
         // structure-from-motion pose: R = Q[i] RIC^T, T = T[i]  (:203-209; the PnP branch for frames between key frames cannot occur)
         int i = 0;
@@ -710,6 +714,7 @@ struct DynInit {
         std::vector<Frame*> fr; for (auto& kv : frames) fr.push_back(&kv.second);
         std::vector<double> x;
         if (!visual_imu_alignment(fr, Bgs, TIC, g, x)) return false;
+        memcpy(diag.g, g, 24); diag.scale = x.back();
         for (int i = 0; i <= frame_count; ++i) { Frame& f = frames[Times[i] + td]; memcpy(Ps[i], f.T, 24); memcpy(Rs[i], f.R, 72); f.key = true; }
         int kv = -1;
         for (auto& f : frames) if (f.second.key) { ++kv; m3_v(f.second.R, &x[(size_t)kv * 3], Vs[kv]); }
