@@ -31,11 +31,6 @@
 #include <condition_variable>
 #include <deque>
 
-#if defined(__x86_64__) || defined(__i386__)
-#define LVK_CPU_RELAX() __builtin_ia32_pause()
-#else
-#define LVK_CPU_RELAX() do { } while (0)
-#endif
 #define LEG (e->leg)           // LEG_DIM: 22, or 46 with online IMU-intrinsics calibration (larvio.cpp:158-161)
 #define LEG_MAX 46
 #define GRAV 9.81

@@ -757,7 +757,7 @@ static lvk_status fe_publish_slot(lvk_frontend* fe, int* slot_out)
     const int slot = fe->msg_next; fe->msg_next = (slot + 1) % LVK_MSG_SLOTS;
     if (fe->msg_pending[slot].load(std::memory_order_acquire)) {       // four publishes ago and still not fetched: the consumer is far behind
         LVK_HIP(ctx, hipEventSynchronize(fe->ev_msg[slot]));
-        for (int spin = 0; fe->msg_pending[slot].load(std::memory_order_acquire); ++spin) { if (spin > 2000000) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature-message ring overrun"); __builtin_ia32_pause(); }
+        for (int spin = 0; fe->msg_pending[slot].load(std::memory_order_acquire); ++spin) { if (spin > 2000000) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "feature-message ring overrun"); LVK_CPU_RELAX(); }
     }
     *slot_out = slot;
     return LVK_OK;

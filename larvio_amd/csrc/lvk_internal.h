@@ -6,6 +6,13 @@
 #include <string.h>
 #include "../../include/lvk_c.h"
 
+// spin-wait hint of a host thread (x86 pause; nothing elsewhere)
+#if defined(__x86_64__) || defined(__i386__)
+#define LVK_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define LVK_CPU_RELAX() do { } while (0)
+#endif
+
 #define LVK_MAX_LEVELS 8
 #define LVK_ORB_BORDER 32
 
