@@ -300,7 +300,7 @@ static const char* const TR_NAMES[TR_N] = {"batch_imu", "propagate+augment(launc
     "prune:rows+sync", "prune:update(launch)", "prune:dx sync", "prune:inject+delete", "final sync"};
 struct EkfTrace {
     bool on = false; double acc[TR_N] = {0}; long n = 0;
-    double sub_acc[8] = {0}; std::chrono::steady_clock::time_point last_sub;      // finer marks inside one phase (TRS): time since the previous mark of either kind
+    double sub_acc[8] = {0}; std::chrono::steady_clock::time_point last_sub; long cnt[4] = {0, 0, 0, 0};      // cnt: updates above 160 rows / plans drawn up / compressions taken / rows of those updates      // finer marks inside one phase (TRS): time since the previous mark of either kind
     double cur[TR_N] = {0};                              // this update's phases: an update above LVK_EKF_TRACE_SLOW_US is printed on its own
     std::chrono::steady_clock::time_point last;
     void start() { if (on) { last = last_sub = std::chrono::steady_clock::now(); for (int i = 0; i < TR_N; ++i) cur[i] = 0; } }
@@ -1231,6 +1231,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     // super-panel (~5 us per 32-row panel + 8), two k_dgemm_sk launches (~12 us) per further super-panel.
     auto t_chol = [](int rows) { const int p = (rows + 31) / 32, sp = (rows + 159) / 160; return 8.0 + 5.0 * p + 12.0 * (sp - 1) + 1.0e-4 * rows * rows; };
     bool worth_planning = groups && m > 160;
+    if (g_tr.on && m > 160) { g_tr.cnt[0]++; g_tr.cnt[3] += m; }
     if (worth_planning && m < e->sparse_qr_min_rows && !e->shard.fn) {
         // the plan itself costs the filter's thread ~20 us: not drawn up when even its best case cannot win - one level whose widest
         // node has only the widest row group's columns (c), compressing to c rows
@@ -1241,6 +1242,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
         std::vector<QrPlanLevel> levels; int m2 = m;
         lvk_qr_sparse_plan(*groups, e->N, levels, &m2);
         bool take = !levels.empty() && m2 + 32 <= m;
+        if (g_tr.on) g_tr.cnt[1]++;
         if (take && m < e->sparse_qr_min_rows) {
             double t_qr = 0;                               // microseconds: launch + the longest node's reflector chain per level
             for (const QrPlanLevel& L : levels) {
@@ -1250,6 +1252,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
             }
             take = t_qr + t_chol(m2) < t_chol(m);
         }
+        if (take && g_tr.on) g_tr.cnt[2]++;
         if (take) {
             for (QrPlanLevel& L : levels) {
                 QrBlock* hb = up_alloc<QrBlock>(e, L.blocks.size()); int* hc = up_alloc<int>(e, L.cols.size() + 1);
@@ -1930,6 +1933,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
         fprintf(stderr, "[lvk_ekf trace] %ld updates, %.1f us/update host wall\n", g_tr.n, tot / g_tr.n);
         for (int i = 0; i < TR_N; ++i) fprintf(stderr, "  %-28s %8.1f us\n", TR_NAMES[i], g_tr.acc[i] / g_tr.n);
         for (int i = 0; i < 8; ++i) if (g_tr.sub_acc[i] > 0) fprintf(stderr, "    [%s] %.1f us\n", TRS_NAMES[i], g_tr.sub_acc[i] / g_tr.n);
+        fprintf(stderr, "    updates above 160 rows: %ld (mean %.0f rows), compression plans drawn up: %ld, taken: %ld\n", g_tr.cnt[0], g_tr.cnt[0] ? (double)g_tr.cnt[3] / g_tr.cnt[0] : 0.0, g_tr.cnt[1], g_tr.cnt[2]);
         g_tr = EkfTrace();
     }
     void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
