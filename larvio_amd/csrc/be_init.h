@@ -18,7 +18,9 @@
 //   ceres::Solve (DENSE_SCHUR, quaternion poses)        Levenberg-Marquardt with a Schur complement on the points; accepted like the
 //                                                       reference accepts Ceres' answer: converged, or final cost < 5e-3 (initial_sfm.cpp:292)
 // None of this is bit-comparable with the reference (different minimisers reach the same minimum to their tolerances); it is pinned by
-// closed-form cases (tests/host/init_check.hip) and by moving-start runs against ground truth (tests/test_gpu_dynamic_init.py).
+// an independent numpy / scipy restatement (oracle/dyn_init.py; every intermediate and final result to 1e-13 noise-free / 1e-8 noisy,
+// tests/test_oracle_dynamic_init.py through tests/host/init_replay.hip), by closed-form cases (tests/host/init_check.hip) and by
+// moving-start runs against ground truth through lvk_ekf_process (tests/test_gpu_dynamic_init.py).
 #pragma once
 #include <array>
 #include <map>
