@@ -15,6 +15,7 @@
 #include "be_host_math.h"
 #include "be_qr.h"
 #include "be_init.h"
+#include <immintrin.h>
 #include <vector>
 #include <map>
 #include <stdexcept>
@@ -254,6 +255,7 @@ struct lvk_ekf {
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
     char* d_up = nullptr;                               // device mirror of the upload arena: ONE H2D copy per sync point
     bool zero_copy = false;                             // d_up aliases the pinned arena (device-mapped host memory): no H2D copies at all
+    bool bar_push = false;                              // d_up is DEVICE memory that this thread writes through the PCIe BAR (flush_uploads): see lvk_ekf_create
     int defer = 0; std::vector<std::function<lvk_status()>> deferred;   // launches waiting for a shared flush (begin_defer/end_defer)
     CamPose* dv_cams = nullptr; CloneDev* dv_clones = nullptr;
     // results come back WITHOUT copies: the kernels that produce them (triangulation, per-feature rows, the dx column of W^T[W|w])
@@ -373,6 +375,10 @@ template <typename T> static T* up_alloc(lvk_ekf* e, size_t n)
 template <typename T> static T* dev(lvk_ekf* e, T* host) { return (T*)(e->d_up + ((char*)host - e->h_up)); }
 static lvk_status flush_uploads(lvk_ekf* e)
 {   // everything staged in the pinned arena since the last flush goes up in one stream-ordered copy
+    if (e->bar_push) {                                                   // the host pushes what it staged into the device-resident arena
+        if (e->up_off > e->up_flushed) { memcpy(e->d_up + e->up_flushed, e->h_up + e->up_flushed, e->up_off - e->up_flushed); _mm_sfence(); e->up_flushed = e->up_off; }
+        return LVK_OK;
+    }
     if (e->zero_copy) { e->up_flushed = e->up_off; return LVK_OK; }     // kernels read the pinned arena directly
     if (e->up_off > e->up_flushed) {
         EKF_HIP(hipMemcpyAsync(e->d_up + e->up_flushed, e->h_up + e->up_flushed, e->up_off - e->up_flushed, hipMemcpyHostToDevice, e->ctx->stream));
@@ -867,6 +873,12 @@ static lvk_status upload_clones(lvk_ekf* e)
     // memory: each of those reads would cross PCIe (k_feature_rows spent 9 of its 29 us fetching 5 KB of clone poses per workgroup,
     // profiles/r4_c_be_ticks.json).  One small kernel copies them to device memory once; it runs while this thread is still building
     // the jobs that use them.
+    if (e->bar_push) {                                  // the arena IS device memory: the tables are read where the host pushed them
+        lvk_status fs = flush_uploads(e);
+        if (fs != LVK_OK) return fs;
+        e->dv_cams = dev(e, hc); e->dv_clones = dev(e, hd);
+        return LVK_OK;
+    }
     const size_t nb_c = sizeof(CamPose) * n, nb_d = sizeof(CloneDev) * n;
     lvk_status st = lvk_stage_copy2(e->ctx, e->d_cams, dev(e, hc), nb_c, e->d_clones, dev(e, hd), nb_d);
     if (st != LVK_OK) return st;
@@ -1205,7 +1217,8 @@ static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std
     if (st_local != LVK_OK) return st_local;
     if (st != LVK_OK) return lvk_set_error(e->ctx, st, "sharded update: the exchange callback failed");
     FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
-    st = lvk_shard_unpack(e->ctx, S.d_recv, bytes, res_bytes, dev(e, hm), W, ncols, k_max, e->d_fout, d_fh, e->d_H, e->ld, e->d_r, (int*)(e->dh_down + e->down_flag));
+    st = flush_uploads(e);
+    if (st == LVK_OK) st = lvk_shard_unpack(e->ctx, S.d_recv, bytes, res_bytes, dev(e, hm), W, ncols, k_max, e->d_fout, d_fh, e->d_H, e->ld, e->d_r, (int*)(e->dh_down + e->down_flag));
     if (st != LVK_OK) return st;
     S.stats[0]++; S.stats[1] += (long)bytes; S.stats[3] += m_loc;
     groups.clear();
@@ -2010,10 +2023,20 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     e->down_cap = e->down_info + 256;
     ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
     if (ok) {
-        // both arenas are read / written by the kernels in place (device-mapped pinned memory): a few KB per update over PCIe
-        // instead of ~10 copy commands on the dependent chain (each ~8 us of API + copy + barrier): 385 -> 336 us per update
+        // No copy commands on the filter's chain (each ~8 us of API + copy + barrier; ten of them were 385 -> 336 us per update):
+        // what the kernels write for the host (results, dx) goes to device-mapped pinned memory, and what the host stages for the
+        // kernels goes the other way round - since round 4 into DEVICE memory that this thread writes through the PCIe BAR (every
+        // MI355X host maps the whole HBM: hipDeviceAttributeIsLargeBar).  The first read of staged data by a workgroup is then an HBM
+        // access (~1 us) instead of a PCIe round trip to host memory (2-3 us each, three dependent ones in k_feature_rows, and ~23 GB/s
+        // in total for tables every workgroup reads): tools/gpu/bar_probe.hip.  Staging is built in a host shadow (h_up, patched until
+        // the launch) and pushed with one sequential copy + sfence per launch group (flush_uploads).  Without a large BAR the kernels
+        // read the pinned shadow in place as before.
+        int large_bar = 0; void* da = nullptr;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar &&
+            hipExtMallocWithFlags(&da, e->up_cap, hipDeviceMallocFinegrained) == hipSuccess && da) { e->d_up = (char*)da; e->bar_push = true; }
+        else (void)hipGetLastError();
         void* dp = nullptr;
-        ok = hipHostGetDevicePointer(&dp, e->h_up, 0) == hipSuccess && dp; e->d_up = (char*)dp; e->zero_copy = ok;
+        if (!e->bar_push) { ok = hipHostGetDevicePointer(&dp, e->h_up, 0) == hipSuccess && dp; e->d_up = (char*)dp; e->zero_copy = ok; }
         void* dd = nullptr;
         ok = ok && hipHostGetDevicePointer(&dd, e->h_down, 0) == hipSuccess && dd; e->dh_down = (char*)dd;
         e->d_triout = (TriResult*)e->dh_down;
