@@ -482,6 +482,14 @@ struct lvk_frontend {
     // slots; the GPU side is either one asynchronous H2D copy into d_img (default) or, with LVK_FE_ZEROCOPY=1, the first two image
     // kernels reading the slot in place over PCIe.  The caller's buffer is free as soon as the call returns (as in the reference).
     uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};
+    // Blocking calls (lvk_frontend_process without lvk_frontend_begin: the adapter's and the sequential driver's schedule) on a host with
+    // a large BAR (every MI355X host; hipDeviceAttributeIsLargeBar): the calling thread copies the image straight into one of three
+    // DEVICE buffers instead - the same ~10 us of CPU copy as into a pinned slot (tools/gpu/bar_probe.hip) and no copy command, whose
+    // engine start-up + transfer (~20 us) stood in front of the frame's first kernel: sequential driver +5.6 %, adapter's schedule
+    // +2.6 % (profiles/r4_al_image_bar_push_ab.txt).  The pipelined driver queues its image stage a frame ahead, where that latency
+    // is hidden, and keeps the copy engine (the BAR copy measured -0.8 % there).  A buffer is reused three frames later, behind an
+    // event recorded after the two kernels that read it (ev_img).
+    uint8_t* d_ring[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_img[3] = {nullptr, nullptr, nullptr}; bool ev_img_set[3] = {false, false, false}; bool bar_push = false;
 
     int stage_next = 0;
     TrackSet set[2];
@@ -555,6 +563,7 @@ template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((vo
 
 // host-side phase tracer of the calling thread (LVK_FE_TRACE=1; printed by lvk_frontend_destroy): where the caller's time per frame goes
 #include <chrono>
+#include <immintrin.h>
 enum { FT_SLOT_WAIT, FT_STAGE_COPY, FT_UPLOAD, FT_IMAGE_LAUNCH, FT_PREDICT, FT_TRACK_LAUNCH, FT_COMMIT_LAUNCH, FT_PUBLISH, FT_DETECT, FT_END, FT_N };
 static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: events + 6 launches", "frame checks + predict_homography",
     "track chains: 2 launches + events", "commits: 2 launches + events", "message: slot + launch + event", "detection: 7 launches", "end-of-frame events + rotation"};
@@ -652,7 +661,7 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     void* ptrs[] = {fe->d_img, fe->w_curr, fe->wn_curr, fe->w_und, fe->wn_und, fe->new_pts, fe->w_status, fe->wn_status, fe->wn_desc, fe->eig, fe->mask,
                     fe->gf_scratch, fe->gf_cands, fe->dev};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < 3; ++i) if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]);
+    for (int i = 0; i < 3; ++i) { if (fe->h_stage[i]) hipHostFree(fe->h_stage[i]); if (fe->d_ring[i]) hipFree(fe->d_ring[i]); if (fe->ev_img[i]) hipEventDestroy(fe->ev_img[i]); }
     for (int i = 0; i < LVK_MSG_SLOTS; ++i) if (fe->ev_msg[i]) hipEventDestroy(fe->ev_msg[i]);
     if (fe->h_msg) hipHostFree(fe->h_msg);
     if (fe->h_nmsg) hipHostFree(fe->h_nmsg);
@@ -703,6 +712,15 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
         void *dm = nullptr, *dn = nullptr;
         ok = hipHostGetDevicePointer(&dm, fe->h_msg, 0) == hipSuccess && hipHostGetDevicePointer(&dn, fe->h_nmsg, 0) == hipSuccess && dm && dn;
         fe->d_msg = (lvk_feature_obs*)dm; fe->d_nmsg = (int*)dn;
+    }
+    {
+        int large_bar = 0;
+        fe->bar_push = hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar;
+        for (int i = 0; i < 3 && fe->bar_push; ++i) {
+            void* p = nullptr;
+            if (hipExtMallocWithFlags(&p, (size_t)w * h, hipDeviceMallocFinegrained) == hipSuccess && p && hipEventCreateWithFlags(&fe->ev_img[i], hipEventDisableTiming) == hipSuccess) fe->d_ring[i] = (uint8_t*)p;
+            else { (void)hipGetLastError(); fe->bar_push = false; }
+        }
     }
     for (int i = 0; i < 3 && ok; ++i) ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;
@@ -824,7 +842,19 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     const uint8_t* d_img = image->data; int d_stride = image->stride;
     int slot = -1;
     g_ft.start();
-    if (!image->is_device) {
+    if (!image->is_device && fe->bar_push && !early) {
+        slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
+        if (fe->ev_img_set[slot]) LVK_HIP(ctx, hipEventSynchronize(fe->ev_img[slot]));      // the kernels that read this buffer three frames ago
+        if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_main[fe->n_img & 1]));   // (the same bound on frames in flight as the pinned-slot path)
+        FT(FT_SLOT_WAIT);
+        uint8_t* dd = fe->d_ring[slot];
+        if (image->stride == c.width) memcpy(dd, image->data, (size_t)c.width * c.height);
+        else for (int y = 0; y < c.height; ++y) memcpy(dd + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
+        _mm_sfence();
+        FT(FT_STAGE_COPY);
+        d_img = dd; d_stride = c.width;
+        FT(FT_UPLOAD);
+    } else if (!image->is_device) {
         slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
         // The slot was last used three frames back.  Its upload precedes frame f-2's image stage on the image stream, which the
         // main stream waited for before it recorded the end of frame f-2: that event covers it (and has long fired) - no per-slot event.
@@ -854,6 +884,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         st = lvk_pyramid_build_with_orb(icx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, fe->ext[1], &mosaic_done);
     }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
+    if (slot >= 0 && fe->bar_push) { hipEventRecord(fe->ev_img[slot], S0); fe->ev_img_set[slot] = true; }
     // queued ahead of the frame's tracking (pipelined driver): the ORB planes are done long before anybody asks, one event (ev_orb)
     // stands for the whole stage; queued together with the tracking (blocking API): LK may start as soon as the pyramid exists
     if (!early) hipEventRecord(fe->ev_pyr, S0);
