@@ -2031,10 +2031,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
         // in total for tables every workgroup reads): tools/gpu/bar_probe.hip.  Staging is built in a host shadow (h_up, patched until
         // the launch) and pushed with one sequential copy + sfence per launch group (flush_uploads).  Without a large BAR the kernels
         // read the pinned shadow in place as before.
-        int large_bar = 0; void* da = nullptr;
-        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar &&
-            hipExtMallocWithFlags(&da, e->up_cap, hipDeviceMallocFinegrained) == hipSuccess && da) { e->d_up = (char*)da; e->bar_push = true; }
-        else (void)hipGetLastError();
+        if (void* da = lvk_bar_alloc(ctx->device, e->up_cap)) { e->d_up = (char*)da; e->bar_push = true; }
         void* dp = nullptr;
         if (!e->bar_push) { ok = hipHostGetDevicePointer(&dp, e->h_up, 0) == hipSuccess && dp; e->d_up = (char*)dp; e->zero_copy = ok; }
         void* dd = nullptr;

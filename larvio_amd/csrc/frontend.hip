@@ -713,14 +713,10 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
         ok = hipHostGetDevicePointer(&dm, fe->h_msg, 0) == hipSuccess && hipHostGetDevicePointer(&dn, fe->h_nmsg, 0) == hipSuccess && dm && dn;
         fe->d_msg = (lvk_feature_obs*)dm; fe->d_nmsg = (int*)dn;
     }
-    {
-        int large_bar = 0;
-        fe->bar_push = hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar;
-        for (int i = 0; i < 3 && fe->bar_push; ++i) {
-            void* p = nullptr;
-            if (hipExtMallocWithFlags(&p, (size_t)w * h, hipDeviceMallocFinegrained) == hipSuccess && p && hipEventCreateWithFlags(&fe->ev_img[i], hipEventDisableTiming) == hipSuccess) fe->d_ring[i] = (uint8_t*)p;
-            else { (void)hipGetLastError(); fe->bar_push = false; }
-        }
+    fe->bar_push = true;
+    for (int i = 0; i < 3 && fe->bar_push; ++i) {
+        fe->d_ring[i] = (uint8_t*)lvk_bar_alloc(ctx->device, (size_t)w * h);
+        if (!fe->d_ring[i] || hipEventCreateWithFlags(&fe->ev_img[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); fe->bar_push = false; }
     }
     for (int i = 0; i < 3 && ok; ++i) ok = hipHostMalloc((void**)&fe->h_stage[i], (size_t)w * h) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) ok = lvk_context_create(ctx->device, &fe->side[i]) == LVK_OK;

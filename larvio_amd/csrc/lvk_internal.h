@@ -13,6 +13,25 @@
 #define LVK_CPU_RELAX() do { } while (0)
 #endif
 
+// Device memory that the HOST writes through the PCIe BAR (the filter's upload arena, the blocking front-end's image buffers): a
+// fine-grained device allocation when the device reports a large BAR AND the process really has a writable mapping of it (checked in
+// /proc/self/maps: a container may hide what the attribute promises); nullptr otherwise - callers then keep their pinned-host path.
+static inline void* lvk_bar_alloc(int device, size_t bytes)
+{
+    int large_bar = 0; void* p = nullptr;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) { (void)hipGetLastError(); return nullptr; }
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    bool writable = false;
+    if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char line[512]; unsigned long lo = 0, hi = 0; char perm[8] = {0};
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perm) == 3 && (unsigned long)p >= lo && (unsigned long)p < hi) { writable = perm[0] == 'r' && perm[1] == 'w'; break; }
+        fclose(f);
+    }
+    if (!writable) { (void)hipFree(p); return nullptr; }
+    return p;
+}
+
 #define LVK_MAX_LEVELS 8
 #define LVK_ORB_BORDER 32
 
