@@ -869,7 +869,7 @@ static lvk_status upload_clones(lvk_ekf* e)
         quat_to_rot(c.q_cam, hc[i].R); memcpy(hc[i].t, c.p_cam, 24);
         memcpy(hd[i].q, c.q, 32); memcpy(hd[i].p, c.p, 24); memcpy(hd[i].p_fej, c.p_fej, 24); memcpy(hd[i].R_b2c, c.R_b2c, 72); memcpy(hd[i].t_c_b, c.t_c_b, 24);
     }
-    // The two tables are read by EVERY workgroup of the triangulation and row kernels that follow (40..2000 of them), and the arena is host
+    // (pinned-host arena only.)  The two tables are read by EVERY workgroup of the triangulation and row kernels that follow (40..2000 of them), and the arena is host
     // memory: each of those reads would cross PCIe (k_feature_rows spent 9 of its 29 us fetching 5 KB of clone poses per workgroup,
     // profiles/r4_c_be_ticks.json).  One small kernel copies them to device memory once; it runs while this thread is still building
     // the jobs that use them.

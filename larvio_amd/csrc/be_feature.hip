@@ -153,8 +153,10 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     const int jb = blockIdx.x;
     if (jb >= n_jobs) return;
     const int t = threadIdx.x;
-    // Everything the host staged for this job lives in the pinned upload arena, i.e. in HOST memory: job record -> observation
-    // ranks -> clone poses used to be three dependent PCIe round trips before the first flop.  SMALL batches lay the observations
+    // Everything the host staged for this job lives in the upload arena - device memory the host pushes through the BAR since round 4,
+    // pinned HOST memory before that (and still, without a large BAR): job record -> observation ranks -> clone poses were three
+    // dependent PCIe round trips before the first flop; in device memory they are three dependent HBM reads, which the layout below
+    // still folds into one.  SMALL batches lay the observations
     // out at a fixed stride, so ranks / observations (and the whole clone table, a few KB, into LDS) are requested together with
     // the job record: one trip.
     FR_TICK(0);

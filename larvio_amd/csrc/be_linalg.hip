@@ -97,6 +97,7 @@ __global__ void k_cov_gather(const double* __restrict__ Pin, int ldin, double* _
     Pout[(size_t)a * ldout + b] = Pin[(size_t)idx[a] * ldin + idx[b]];
 }
 
+// (only when the upload arena is pinned HOST memory, i.e. without a large BAR)
 // a few KB from the pinned upload arena (host memory) to device memory: one workgroup per table, 8-byte loads all in flight
 __global__ void __launch_bounds__(256) k_stage_copy(double* __restrict__ dst0, const double* __restrict__ src0, int n0,
                                                    double* __restrict__ dst1, const double* __restrict__ src1, int n1)
@@ -129,7 +130,7 @@ lvk_status lvk_stage_copy2(lvk_context* ctx, void* d_dst0, const void* d_src0, s
 //   next CPG_STRIPS workgroups      a chunk of the outside columns: W = Phi Pin[0:L, chunk], written to every output row / column
 //                                   whose source is an IMU row (the six duplicated ones included), both orientations
 //   last workgroup                  the IMU block itself: sym(Phi P_II Phi^T + Q), scattered to all (a, b) with both sources inside
-// No index arrays: the arena is HOST memory and every byte a kernel reads from it crosses PCIe at ~23 GB/s - the first version of this
+// No index arrays: when this was written the arena was HOST memory and every byte a kernel read from it crossed PCIe at ~23 GB/s - the first version of this
 // kernel had every one of its 330 workgroups fetch a 1.8 KB index list and took 17.6 us, 8 of them waiting for those bytes
 // (profiles/r4_c_be_ticks.json).  Sums run over k ascending.
 #define CPG_STRIPS 8
