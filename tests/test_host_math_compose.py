@@ -58,3 +58,34 @@ def test_moving_start_initialiser_blocks_and_whole_on_closed_form_cases(tmp_path
     r = _run_host_check(tmp_path, "init_check")
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
     print(r.stdout.strip())
+
+
+def test_product_host_math_against_scipy(tmp_path):
+    """be_host_math.h (quaternion / 3x3 helpers of the product's host side; Hamilton [x y z w] as math_utils.hpp:54-102, Eigen's
+    Quaternion <-> matrix formulas) against scipy / numpy on 200 random inputs incl. the trace <= 0 branches of the matrix -> quaternion
+    conversion.  These helpers share their text with oracle/be_math.h: this is their pin that does not pass through the oracle."""
+    import json
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+    cxx = shutil.which("g++") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "host_math_dump")
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-w", "-x", "c++"] if cxx.endswith("g++") else ["-O2", "-std=c++17", "-ffp-contract=off", "-w", "-x", "hip", "--offload-arch=gfx950"]
+    subprocess.check_call([cxx] + flags + [os.path.join(ROOT, "tests", "host", "host_math_dump.hip"), "-o", exe])
+    rows = [json.loads(l) for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()]
+    assert len(rows) == 200
+    saw_neg_trace = 0
+    for r in rows:
+        q, p, w = np.array(r["q"]), np.array(r["p"]), np.array(r["w"]); A, B = np.reshape(r["A"], (3, 3)), np.reshape(r["B"], (3, 3)); v = np.array(r["v"])
+        R = Rotation.from_quat(q).as_matrix()                                      # scipy: scalar-last, active rotation - Eigen's convention
+        assert np.abs(np.reshape(r["R"], (3, 3)) - R).max() < 1e-14
+        saw_neg_trace += np.trace(R) <= 0
+        q2 = np.array(r["q2"]); assert min(np.abs(q2 - q).max(), np.abs(q2 + q).max()) < 1e-13 and abs(np.linalg.norm(q2) - 1) < 1e-14
+        qp = (Rotation.from_quat(q) * Rotation.from_quat(p / np.linalg.norm(p))).as_quat() * np.linalg.norm(p)      # Hamilton product, q then scaled p
+        got = np.array(r["qp"]); assert min(np.abs(got - qp).max(), np.abs(got + qp).max()) < 1e-13
+        assert np.abs(np.reshape(r["AB"], (3, 3)) - A @ B).max() < 1e-14 and np.array_equal(np.reshape(r["At"], (3, 3)), A.T)
+        assert np.abs(np.array(r["Av"]) - A @ v).max() < 1e-14 and np.abs(np.array(r["Atv"]) - A.T @ v).max() < 1e-14
+        assert np.abs(np.reshape(r["S"], (3, 3)) @ v - np.cross(w, v)).max() < 1e-14 and abs(r["n"][0] - np.linalg.norm(v)) < 1e-15
+        d = w / 2; n2 = d @ d                                                       # smallAngleQuaternion (math_utils.hpp:85-102)
+        dq = np.concatenate([d, [np.sqrt(1 - n2)]]) if n2 <= 1 else np.concatenate([d, [1.0]]) / np.sqrt(1 + n2)
+        assert np.abs(np.array(r["dq"]) - dq).max() < 1e-15
+    assert saw_neg_trace >= 20
