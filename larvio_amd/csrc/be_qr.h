@@ -17,6 +17,6 @@ struct QrPlanLevel { std::vector<QrBlock> blocks; std::vector<int> cols; int in_
 
 size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N);
 // final_groups (optional): the row groups of the result (consecutive, with their column unions) - the input of a further stage
-void lvk_qr_sparse_plan(std::vector<RowGroup> groups, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups = nullptr);
+void lvk_qr_sparse_plan(const std::vector<RowGroup>& groups, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups = nullptr);
 lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,
                                const QrBlock* d_blocks, int n_blocks, const int* d_cols, int N, size_t max_lds, int max_rows, int max_cols);

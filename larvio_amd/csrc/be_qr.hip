@@ -7,6 +7,7 @@
 //     structure and for the stage-level entry point.
 #include "lvk_internal.h"
 #include "be_qr.h"
+#include <unordered_map>
 #include "lvk_wave.h"
 #include "chi2_table.inc"
 #include <algorithm>
@@ -263,48 +264,71 @@ lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, 
     return LVK_OK;
 }
 
-static void merge_cols(const std::vector<int>& a, const std::vector<int>& b, std::vector<int>& out)
-{
-    out.clear(); out.reserve(a.size() + b.size());
-    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
-}
 // Greedy, level by level: consecutive groups are merged into one node while the node still fits the workgroup's LDS; a node that
 // already shrinks (rows > columns) does not take in a group that brings more new columns than rows (the two rows of an in-state
 // feature with its own anchor block).  A node with rows <= columns is passed through.  A level is kept only if it removes at
 // least a fifth of the rows.  Everything here is known on the host before any kernel runs: no counts come back from the device.
-void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups)
+// Column sets are BIT SETS over the state's columns while the plan is drawn up (union = OR, size = popcount; a group's set is built
+// once per distinct column list - features that share their clone set share the list): the sorted-list merges of rounds 2-3 cost the
+// filter's thread 250-400 us per update at configs[4] depth (1900 groups), this ~40 (same nodes, same order).
+void lvk_qr_sparse_plan(const std::vector<RowGroup>& groups, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups)
 {
     const size_t LDS_CAP = (size_t)152 * 1024;
     const int ROWS_CAP = 256, COLS_CAP = 127;             // the shapes k_qr_sparse_reg holds in registers (16 rows per lane, two column quads per wavefront)
     levels.clear();
-    int total = 0; for (auto& g : cur) { g.start = total; total += g.rows; }
-    std::vector<int> uni, merged;
+    const size_t W = ((size_t)N + 63) / 64;               // words per set
+    struct G { int start, rows; const std::vector<int>* cols; size_t bits; int n; ColList keep; };     // bits: offset of the set in `pool`; keep: owner of a list made here
+    std::vector<uint64_t> pool; pool.reserve(W * 64);
+    const std::vector<int>* last_list = nullptr; size_t last_off = 0;                                // consecutive groups often carry the same list
+    std::unordered_map<const std::vector<int>*, size_t> seen; seen.reserve(64);                      // distinct lists of the input (a handful in the filter)
+    auto set_of = [&](const std::vector<int>* c) -> size_t {
+        if (c == last_list) return last_off;
+        auto it = seen.find(c);
+        if (it == seen.end()) {
+            const size_t off = pool.size(); pool.resize(off + W, 0);
+            for (int x : *c) pool[off + ((size_t)x >> 6)] |= 1ull << (x & 63);
+            it = seen.emplace(c, off).first;
+        }
+        last_list = c; last_off = it->second;
+        return last_off;
+    };
+    std::vector<G> cur; cur.reserve(groups.size());
+    int total = 0;
+    for (const RowGroup& g : groups) { G x; x.start = total; x.rows = g.rows; x.cols = g.cols.get(); x.bits = set_of(x.cols); x.n = (int)x.cols->size(); total += g.rows; cur.push_back(std::move(x)); }
+    std::vector<uint64_t> uni(W), merged(W);
+    std::vector<int> list;
     for (int lvl = 0; lvl < 8 && cur.size() > 0; ++lvl) {
-        QrPlanLevel L; std::vector<RowGroup> next;
+        QrPlanLevel L; std::vector<G> next; next.reserve(cur.size() / 4 + 4);
         size_t i = 0; int out_row = 0; bool any = false;
         while (i < cur.size()) {
-            uni = *cur[i].cols; int rows = cur[i].rows; size_t j = i + 1;
-            const std::vector<int>* same = cur[i].cols.get();        // while every merged group carries this very list the union is unchanged
+            for (size_t w = 0; w < W; ++w) uni[w] = pool[cur[i].bits + w];
+            int n_uni = cur[i].n, rows = cur[i].rows; size_t j = i + 1;
+            const std::vector<int>* same = cur[i].cols;        // while every merged group carries this very list the union is unchanged
             while (j < cur.size()) {
                 const int r2 = rows + cur[j].rows;
-                if (cur[j].cols.get() == same) {
-                    if (lvk_qr_sparse_lds_bytes(r2, (int)uni.size(), N) > LDS_CAP || r2 > ROWS_CAP) break;
+                if (cur[j].cols == same) {
+                    if (lvk_qr_sparse_lds_bytes(r2, n_uni, N) > LDS_CAP || r2 > ROWS_CAP) break;
                     rows = r2; ++j; continue;
                 }
-                merge_cols(uni, *cur[j].cols, merged);
-                if (lvk_qr_sparse_lds_bytes(r2, (int)merged.size(), N) > LDS_CAP || r2 > ROWS_CAP || (int)merged.size() > COLS_CAP) break;
-                if (rows > (int)uni.size() && (int)(merged.size() - uni.size()) > cur[j].rows) break;
-                if (merged.size() != uni.size()) same = nullptr;
-                uni.swap(merged); rows = r2; ++j;
+                int n_m = 0;
+                for (size_t w = 0; w < W; ++w) { merged[w] = uni[w] | pool[cur[j].bits + w]; n_m += __builtin_popcountll(merged[w]); }
+                if (lvk_qr_sparse_lds_bytes(r2, n_m, N) > LDS_CAP || r2 > ROWS_CAP || n_m > COLS_CAP) break;
+                if (rows > n_uni && n_m - n_uni > cur[j].rows) break;
+                if (n_m != n_uni) same = nullptr;
+                uni.swap(merged); n_uni = n_m; rows = r2; ++j;
             }
             QrBlock b; memset(&b, 0, sizeof b);
             b.in_start = cur[i].start; b.in_rows = rows; b.out_start = out_row;
-            if (rows > (int)uni.size() && !uni.empty() && lvk_qr_sparse_lds_bytes(rows, (int)uni.size(), N) <= LDS_CAP) {
-                b.copy = 0; b.ncols = (int)uni.size(); b.out_rows = b.ncols; b.col_off = (int)L.cols.size();
-                L.cols.insert(L.cols.end(), uni.begin(), uni.end());
+            if (rows > n_uni && n_uni > 0 && lvk_qr_sparse_lds_bytes(rows, n_uni, N) <= LDS_CAP) {
+                b.copy = 0; b.ncols = n_uni; b.out_rows = b.ncols; b.col_off = (int)L.cols.size();
+                list.clear();
+                for (size_t w = 0; w < W; ++w) for (uint64_t m = uni[w]; m; m &= m - 1) list.push_back((int)(64 * w) + __builtin_ctzll(m));
+                L.cols.insert(L.cols.end(), list.begin(), list.end());
                 L.lds = std::max(L.lds, lvk_qr_sparse_lds_bytes(rows, b.ncols, N));
                 L.max_rows = std::max(L.max_rows, rows); L.max_cols = std::max(L.max_cols, b.ncols);
-                next.emplace_back(); next.back().start = out_row; next.back().rows = b.out_rows; next.back().cols = std::make_shared<const std::vector<int>>(uni);
+                G x; x.start = out_row; x.rows = b.out_rows; x.keep = std::make_shared<const std::vector<int>>(list); x.cols = x.keep.get(); x.n = n_uni;
+                x.bits = pool.size(); pool.insert(pool.end(), uni.begin(), uni.end());
+                next.push_back(std::move(x));
                 any = true;
             } else {
                 b.copy = 1; b.ncols = 0; b.out_rows = rows; b.col_off = 0;
@@ -319,7 +343,17 @@ void lvk_qr_sparse_plan(std::vector<RowGroup> cur, int N, std::vector<QrPlanLeve
         cur.swap(next); total = out_row;
     }
     *final_rows = total;
-    if (final_groups) final_groups->swap(cur);
+    if (final_groups) {
+        // (lists that came in with the caller's groups are shared again by pointer identity: the caller's ColLists stay the owners)
+        final_groups->clear(); final_groups->reserve(cur.size());
+        size_t gi = 0;
+        for (const G& x : cur) {
+            RowGroup r; r.start = x.start; r.rows = x.rows;
+            if (x.keep) r.cols = x.keep;
+            else { while (gi < groups.size() && groups[gi].cols.get() != x.cols) ++gi; r.cols = gi < groups.size() ? groups[gi].cols : std::make_shared<const std::vector<int>>(*x.cols); }
+            final_groups->push_back(std::move(r));
+        }
+    }
 }
 
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);   // be_qr_dense.hip
