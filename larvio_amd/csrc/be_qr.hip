@@ -255,8 +255,7 @@ lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, 
     // register-resident nodes where every node of the level fits one of the compiled shapes (rows <= 16 RPL, columns + 1 <= 64 QUADS)
     const int rpl = (max_rows + 15) / 16, quads = (max_cols + 1 + 63) / 64;
 #define QR_REG(R_, Q_, slot_) return launch_qr_reg<R_, Q_>(ctx, slot_, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, n_blocks, d_cols, N, max_lds)
-    if (max_rows > 0 && quads == 1) { if (rpl <= 8) QR_REG(8, 1, 12); if (rpl <= 16) QR_REG(16, 1, 13); if (rpl <= 24) QR_REG(24, 1, 14); }
-    if (max_rows > 0 && quads == 2) { if (rpl <= 8) QR_REG(8, 2, 15); if (rpl <= 16) QR_REG(16, 2, 16); }
+    if (max_rows > 0 && quads == 1) { if (rpl <= 8) QR_REG(8, 1, 12); if (rpl <= 16) QR_REG(16, 1, 13); }        // (every node the planner makes; anything else: the LDS kernel below)
 #undef QR_REG
     if (max_lds > 64 * 1024) LVK_LDS_OPTIN(ctx, 11, k_qr_sparse, max_lds);
     hipLaunchKernelGGL(k_qr_sparse, dim3(n_blocks), dim3(QS_THREADS), max_lds, ctx->stream, d_Hin, ldin, d_rin, d_Hout, ldout, d_rout, d_blocks, d_cols, N);
@@ -274,7 +273,11 @@ lvk_status lvk_qr_sparse_level(lvk_context* ctx, const double* d_Hin, int ldin, 
 void lvk_qr_sparse_plan(const std::vector<RowGroup>& groups, int N, std::vector<QrPlanLevel>& levels, int* final_rows, std::vector<RowGroup>* final_groups)
 {
     const size_t LDS_CAP = (size_t)152 * 1024;
-    const int ROWS_CAP = 256, COLS_CAP = 127;             // the shapes k_qr_sparse_reg holds in registers (16 rows per lane, two column quads per wavefront)
+    // the shapes k_qr_sparse_reg holds in registers: 16 rows per lane x 16 lanes, one column "quad" (63 columns + the residual).  Nodes of
+    // up to 127 columns (two quads) were planned until the middle of round 4: their reflector chain is twice as long, and at configs[4]
+    // a level with such a node took 186 us against 68 - narrower nodes and, now and then, one more level are faster (3653-3670 ->
+    // 3744-3763 frames/s for caps of 48 / 64 / 80, profiles/r4_an_qr_cols_cap_ab.txt)
+    const int ROWS_CAP = 256, COLS_CAP = 63;
     levels.clear();
     const size_t W = ((size_t)N + 63) / 64;               // words per set
     struct G { int start, rows; const std::vector<int>* cols; size_t bits; int n; ColList keep; };     // bits: offset of the set in `pool`; keep: owner of a list made here
