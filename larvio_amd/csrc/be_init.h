@@ -161,19 +161,26 @@ struct PreInt {
         dt_buf.clear(); acc_buf.clear(); gyr_buf.clear(); zero();
     }
     void zero() { sum_dt = 0; for (int i = 0; i < 3; ++i) { dp[i] = 0; dv[i] = 0; dq[i] = 0; } dq[3] = 1; for (int i = 0; i < 9; ++i) J_R_bg[i] = 0; }
+    // Eigen's Quaternion * Vector3 (QuaternionBase::_transformVector): v + w uv + q x uv with uv = 2 q x v.  For a unit quaternion this is
+    // the rotation; result_delta_q below is NOT unit (|q|^2 = 1 + |w dt / 2|^2) when it rotates acc_1 (:77-78), and this formula - not
+    // toRotationMatrix() - is what the reference then evaluates
+    static void quat_times_vec(const double* q, const double* v, double* o)
+    {
+        double uv[3] = {2 * (q[1] * v[2] - q[2] * v[1]), 2 * (q[2] * v[0] - q[0] * v[2]), 2 * (q[0] * v[1] - q[1] * v[0])};
+        const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+        for (int i = 0; i < 3; ++i) o[i] = v[i] + q[3] * uv[i] + c[i];
+    }
     void propagate(double dt, const double* a1, const double* g1)
     {   // midPointIntegration (:62-142) + propagate (:144-167)
-        double R0[9], una0[3], t[3], w[3];
-        quat_to_rot(dq, R0);
+        double una0[3], t[3], w[3];
         for (int i = 0; i < 3; ++i) t[i] = acc0[i] - ba[i];
-        m3_v(R0, t, una0);
+        quat_times_vec(dq, t, una0);
         for (int i = 0; i < 3; ++i) w[i] = 0.5 * (gyr0[i] + g1[i]) - bg[i];
         const double dqs[4] = {w[0] * dt / 2, w[1] * dt / 2, w[2] * dt / 2, 1.0};
         double q1[4]; quat_mul(dq, dqs, q1);
-        double R1[9], una1[3];
-        quat_to_rot_general(q1, R1);
+        double una1[3];
         for (int i = 0; i < 3; ++i) t[i] = a1[i] - ba[i];
-        m3_v(R1, t, una1);
+        quat_times_vec(q1, t, una1);
         for (int i = 0; i < 3; ++i) { const double ua = 0.5 * (una0[i] + una1[i]); dp[i] = dp[i] + dv[i] * dt + 0.5 * ua * dt * dt; dv[i] = dv[i] + ua * dt; }
         double Wx[9], M[9], Jn[9]; skew3(w, Wx);
         for (int i = 0; i < 9; ++i) M[i] = (i % 4 == 0 ? 1. : 0.) - Wx[i] * dt;
@@ -183,9 +190,6 @@ struct PreInt {
         for (int i = 0; i < 4; ++i) dq[i] = q1[i] / n;
         sum_dt += dt; memcpy(acc0, a1, 24); memcpy(gyr0, g1, 24);
     }
-    // Eigen rotates a vector by a NON-unit quaternion through toRotationMatrix(), whose formula assumes unit norm: result_delta_q above
-    // is |q| = sqrt(1 + |w dt / 2|^2) long when it rotates acc_1 (:77-78); the same formula is applied here
-    static void quat_to_rot_general(const double* q, double* R) { quat_to_rot(q, R); }
     void push_back(double dt, const double* a, const double* g)
     {
         dt_buf.push_back(dt); acc_buf.push_back({a[0], a[1], a[2]}); gyr_buf.push_back({g[0], g[1], g[2]});
@@ -557,8 +561,6 @@ static inline void alignment_system(std::vector<Frame*>& fr, const double* TIC, 
             double s = 0.; for (int k = 0; k < 6; ++k) s += tA[k * w + a] * tb[k]; b[(size_t)col(a)] += s;
         }
     }
-    for (auto& v : A) v *= 1000.0;
-    for (auto& v : b) v *= 1000.0;
 }
 static inline bool visual_imu_alignment(std::vector<Frame*>& fr, double (*Bgs)[3], const double* TIC, double* g, std::vector<double>& x)
 {   // VisualIMUAlignment (:204-212): solveGyroscopeBias, LinearAlignment (:130-201), RefineGravity (:65-127)
@@ -567,6 +569,8 @@ static inline bool visual_imu_alignment(std::vector<Frame*>& fr, double (*Bgs)[3
     std::vector<double> A, b;
     alignment_system(fr, TIC, 3, nullptr, nullptr, A, b);
     int n = nfr * 3 + 4;
+    for (auto& v : A) v *= 1000.0;
+    for (auto& v : b) v *= 1000.0;
     sym_solve(n, A.data(), b.data());
     double s = b[(size_t)n - 1] / 100.0;
     for (int k = 0; k < 3; ++k) g[k] = b[(size_t)(n - 4 + k)];
@@ -576,10 +580,17 @@ static inline bool visual_imu_alignment(std::vector<Frame*>& fr, double (*Bgs)[3
     if (fabs(v3_norm(g) - GRAV_NORM) > 1.0 || s < 0) return false;
     double g0[3]; { const double ng = v3_norm(g); for (int k = 0; k < 3; ++k) g0[k] = g[k] / ng * GRAV_NORM; }
     n = nfr * 3 + 3;
+    // RefineGravity (:65-127) declares its normal equations OUTSIDE the four passes and never clears them: pass k solves
+    // 1000 (A_{k-1} + fresh_k), i.e. the first pass's system (in the first pass's tangent basis) outweighs every later one a
+    // thousandfold.  Kept as the reference has it (so is VINS-Mono's original).
+    std::vector<double> Aacc((size_t)n * n, 0.), bacc((size_t)n, 0.);
     for (int k = 0; k < 4; ++k) {
         double bb[3], cc[3]; tangent_basis(g0, bb, cc);
         const double lxly[6] = {bb[0], cc[0], bb[1], cc[1], bb[2], cc[2]};
         alignment_system(fr, TIC, 2, g0, lxly, A, b);
+        for (size_t q = 0; q < Aacc.size(); ++q) Aacc[q] = (Aacc[q] + A[q]) * 1000.0;
+        for (size_t q = 0; q < bacc.size(); ++q) bacc[q] = (bacc[q] + b[q]) * 1000.0;
+        A = Aacc; b = bacc;
         sym_solve(n, A.data(), b.data());
         double gn[3]; for (int r = 0; r < 3; ++r) gn[r] = g0[r] + lxly[r * 2] * b[(size_t)n - 3] + lxly[r * 2 + 1] * b[(size_t)n - 2];
         const double nn = v3_norm(gn); for (int r = 0; r < 3; ++r) g0[r] = gn[r] / nn * GRAV_NORM;

@@ -52,11 +52,16 @@ class PreInt:
         self.acc0, self.gyr0 = self.lin_acc.copy(), self.lin_gyr.copy()
         self.sum_dt = 0.0; self.dp = np.zeros(3); self.dv = np.zeros(3); self.dq = np.array([0, 0, 0, 1.0]); self.J = np.zeros((3, 3))
 
+    @staticmethod
+    def _qv(q, v):                                  # Eigen's Quaternion * Vector3 (_transformVector): exact rotation only for a unit q
+        uv = 2 * np.cross(q[:3], v)
+        return v + q[3] * uv + np.cross(q[:3], uv)
+
     def _propagate(self, dt, a1, g1):              # midPointIntegration (:62-142)
-        un0 = _q2R(self.dq) @ self.acc0
+        un0 = self._qv(self.dq, self.acc0)
         w = 0.5 * (self.gyr0 + g1) - self.bg
         q1 = _qmul(self.dq, np.array([w[0] * dt / 2, w[1] * dt / 2, w[2] * dt / 2, 1.0]))
-        un1 = _q2R(q1) @ a1                         # (:77-78: the rotation by the not yet normalised quaternion)
+        un1 = self._qv(q1, np.asarray(a1, float))   # (:77-78: the product with the not yet normalised quaternion)
         ua = 0.5 * (un0 + un1)
         self.dp = self.dp + self.dv * dt + 0.5 * ua * dt * dt
         self.dv = self.dv + ua * dt
@@ -98,16 +103,16 @@ def recover_pose(E, p1, p2):
     if np.linalg.det(U) < 0: U = -U
     if np.linalg.det(Vt) < 0: Vt = -Vt
     W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    R1, R2, t0 = U @ W @ Vt, U @ W.T @ Vt, U[:, 2]
     best = None
-    for R in (U @ W @ Vt, U @ W.T @ Vt):
-        for t in (U[:, 2], -U[:, 2]):
-            P1 = np.hstack([R, t[:, None]]); P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
-            good = 0
-            for a, b in zip(p1, p2):
-                X = _triangulate(P0, P1, a, b); z2 = (R @ X + t)[2]
-                good += (0 < X[2] < 50) and (0 < z2 < 50)
-            if best is None or good > best[0]:
-                best = (good, R, t)
+    for R, t in ((R1, t0), (R2, t0), (R1, -t0), (R2, -t0)):         # the order of preference of solve_5pts.cpp:150-180 (first of equals wins)
+        P1 = np.hstack([R, t[:, None]]); P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+        good = 0
+        for a, b in zip(p1, p2):
+            X = _triangulate(P0, P1, a, b); z2 = (R @ X + t)[2]
+            good += (0 < X[2] < 50) and (0 < z2 < 50)
+        if best is None or good > best[0]:
+            best = (good, R, t)
     return best
 
 
@@ -218,8 +223,7 @@ def _alignment(frames, TIC, g0=None):
         tb[3:6] = fj["pre"].dv - Rg * dt
         cols = list(range(3 * i, 3 * i + 6)) + list(range(n - ng - 1, n))
         A[np.ix_(cols, cols)] += tA.T @ tA; b[cols] += tA.T @ tb
-    x = np.linalg.solve(A * 1000.0, b * 1000.0)
-    return x, (None if g0 is None else lxly)
+    return A, b, (None if g0 is None else lxly)
 
 
 def visual_imu_alignment(frames, TIC):
@@ -235,13 +239,17 @@ def visual_imu_alignment(frames, TIC):
     dbg = np.linalg.solve(A, b)
     for f in frames[1:]:
         f["pre"].repropagate(dbg)
-    x, _ = _alignment(frames, TIC)
+    A, b, _ = _alignment(frames, TIC)
+    x = np.linalg.solve(A * 1000.0, b * 1000.0)
     n = len(x); g = x[n - 4:n - 1]; s = x[n - 1] / 100.0
     if abs(np.linalg.norm(g) - G_NORM) > 1.0 or s < 0:
         return None
     g0 = g / np.linalg.norm(g) * G_NORM
+    Aacc = bacc = 0.0                                # RefineGravity never clears its normal equations between the four passes (:74-77, 120-122)
     for _ in range(4):
-        x, lxly = _alignment(frames, TIC, g0)
+        A, b, lxly = _alignment(frames, TIC, g0)
+        Aacc = (Aacc + A) * 1000.0; bacc = (bacc + b) * 1000.0
+        x = np.linalg.solve(Aacc, bacc)
         dg = x[-3:-1]
         g0 = g0 + lxly @ dg; g0 = g0 / np.linalg.norm(g0) * G_NORM
     x = x.copy(); x[-1] = x[-1] / 100.0
