@@ -226,9 +226,10 @@ def _alignment(frames, TIC, g0=None):
     return A, b, (None if g0 is None else lxly)
 
 
-def visual_imu_alignment(frames, TIC):
-    """VisualIMUAlignment (:204-212).  frames: dicts R, T, pre (frames[1:] carry the pre-integration from their predecessor).
-    Returns (delta_bg, g, x) or None."""
+def visual_imu_alignment(frames, TIC, Bg):
+    """VisualIMUAlignment (:204-212).  frames: dicts R, T, pre (frames[1:] carry the pre-integration from their predecessor); Bg: the
+    window's gyro bias, updated IN PLACE even when the alignment then fails (solveGyroscopeBias adds delta_bg to every Bgs[i] - they are
+    one vector - and re-propagates with it before LinearAlignment has its say).  Returns (g, x) or None."""
     A = np.zeros((3, 3)); b = np.zeros(3)
     for fi, fj in zip(frames[:-1], frames[1:]):                                      # solveGyroscopeBias (:12-46)
         qij = Rotation.from_matrix(fi["R"].T @ fj["R"]).as_quat()
@@ -236,9 +237,9 @@ def visual_imu_alignment(frames, TIC):
         if qe[3] < 0: qe = -qe                                                      # (Eigen's Quaterniond(Matrix3d) returns w >= 0 for these small rotations)
         J = fj["pre"].J
         A += J.T @ J; b += J.T @ (2 * qe[:3])
-    dbg = np.linalg.solve(A, b)
+    Bg += np.linalg.solve(A, b)
     for f in frames[1:]:
-        f["pre"].repropagate(dbg)
+        f["pre"].repropagate(Bg)
     A, b, _ = _alignment(frames, TIC)
     x = np.linalg.solve(A * 1000.0, b * 1000.0)
     n = len(x); g = x[n - 4:n - 1]; s = x[n - 1] / 100.0
@@ -255,7 +256,7 @@ def visual_imu_alignment(frames, TIC):
     x = x.copy(); x[-1] = x[-1] / 100.0
     if x[-1] < 0:
         return None
-    return dbg, g0, x
+    return g0, x
 
 
 # ------------------------------------------------------------------------------------------------ the replay
@@ -267,6 +268,7 @@ def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
     acc0 = gyr0 = None; curr_time = -1.0
     Times = [0.0] * (WINDOW_SIZE + 1)
     tmp_pre = None
+    Bg = np.zeros(3)                                 # Bgs[0..WINDOW_SIZE]: one vector (see visual_imu_alignment)
     frames = {}                                      # all_image_frame: key ts + td
     tracks = []                                      # FeatureManager::feature: dict(id, start, pts list)
     last = None
@@ -282,7 +284,7 @@ def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
                 first_imu = True; acc0, gyr0, curr_time = a, g, s["t"]
             dt = s["t"] - curr_time
             if tmp_pre is None:
-                tmp_pre = PreInt(acc0, gyr0, np.zeros(3))
+                tmp_pre = PreInt(acc0, gyr0, Bg)
             if frame_count != 0:
                 tmp_pre.push_back(dt, a, g)
             acc0, gyr0, curr_time = a, g, s["t"]; last = (g, a)
@@ -296,13 +298,13 @@ def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
             else: tr["pts"].append(p)
         Times[frame_count] = ts
         frames[ts + td] = dict(pre=tmp_pre)
-        tmp_pre = PreInt(acc0, gyr0, np.zeros(3)) if acc0 is not None else None
+        tmp_pre = PreInt(acc0, gyr0, Bg) if acc0 is not None else None
         if frame_count < WINDOW_SIZE:
             frame_count += 1
             continue
         ok = None
         if ts - initial_ts > 0.1:
-            ok = _initial_structure(tracks, frames, Times, td, RIC, TIC)
+            ok = _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg)
             initial_ts = ts
         if ok is not None:
             state_time = Times[WINDOW_SIZE] + td + ddt
@@ -321,7 +323,7 @@ def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
     return None
 
 
-def _initial_structure(tracks, frames, Times, td, RIC, TIC):
+def _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg):
     nf = WINDOW_SIZE + 1
     tr_maps = [{t["start"] + k: p for k, p in enumerate(t["pts"])} for t in tracks]
     # relativePose (:330-359)
@@ -348,13 +350,13 @@ def _initial_structure(tracks, frames, Times, td, RIC, TIC):
     fl = []
     for i in range(nf):
         f = frames[Times[i] + td]; f["R"] = Q[i] @ RIC.T; f["T"] = T[i]; fl.append(f)
-    al = visual_imu_alignment(fl, TIC)
+    al = visual_imu_alignment(fl, TIC, Bg)
     if al is None:
         return None
-    dbg, g, x = al
+    g, x = al
     v_last = fl[-1]["R"] @ x[3 * (nf - 1):3 * nf]
     # visualInitialAlign (:278-327): Quaterniond::FromTwoVectors(g, (0, 0, |g|))
     a = g / np.linalg.norm(g); bz = np.array([0, 0, 1.0]); ax = np.cross(a, bz); c = a @ bz
     R_c0w = np.eye(3) + _skew(ax) + _skew(ax) @ _skew(ax) / (1 + c)
-    return dict(l=l, relR=relR, relT=relT, sfm_R=np.array(Q), sfm_T=np.array(T), n_points=n_pts, ba_cost=cost, g=g, scale=x[-1], bg=dbg,
+    return dict(l=l, relR=relR, relT=relT, sfm_R=np.array(Q), sfm_T=np.array(T), n_points=n_pts, ba_cost=cost, g=g, scale=x[-1], bg=Bg.copy(),
                 q=Rotation.from_matrix(R_c0w @ fl[-1]["R"]).as_quat(), v=R_c0w @ v_last, R=R_c0w @ fl[-1]["R"])
