@@ -114,6 +114,11 @@ lvk_status lvk_undistort_points(lvk_context* ctx, const lvk_pt2f* d_in, int n, c
  * d_mask n bytes; d_info[0] = 1 if a mask was written (n>=7) else 0, d_info[1] = hypotheses drawn. */
 lvk_status lvk_find_fundamental_mask(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n,
                                      double thresh, double conf, uint8_t* d_mask, int* d_info);
+/* the same call where the reference also uses the MATRIX it returns (solve_5pts.cpp:206, the moving-start initialiser's relative pose):
+ * d_F (9 doubles, row-major) = the registrator's best minimal-sample model - cv::findFundamentalMat does not refit on the inliers -,
+ * all zeros when it has none (OpenCV's empty Mat); n == 7: the first of the solver's up to three models. */
+lvk_status lvk_find_fundamental(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n,
+                                double thresh, double conf, uint8_t* d_mask, int* d_info, double* d_F);
 /* the RANSAC branch alone for any n >= 8 (stage parity) */
 lvk_status lvk_ransac_fundamental(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n,
                                   double thresh, double conf, int max_iters, uint8_t* d_mask, int* d_info);

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "lvk_malloc", "lvk_free", "lvk_memcpy_h2d", "lvk_memcpy_d2h", "lvk_memset",
     "lvk_clahe_u8", "lvk_pyramid_create", "lvk_pyramid_destroy", "lvk_pyramid_build", "lvk_pyramid_build_clahe",
     "lvk_pyramid_levels", "lvk_pyramid_level", "lvk_orb_prepare", "lvk_min_eigen_map", "lvk_good_features",
-    "lvk_lk_track", "lvk_orb_describe", "lvk_hamming256_rows", "lvk_undistort_points", "lvk_find_fundamental_mask",
+    "lvk_lk_track", "lvk_orb_describe", "lvk_hamming256_rows", "lvk_undistort_points", "lvk_find_fundamental_mask", "lvk_find_fundamental",
     "lvk_ransac_fundamental", "lvk_predict_homography",
     "lvk_frontend_create", "lvk_frontend_destroy", "lvk_frontend_process", "lvk_frontend_tracks", "lvk_frontend_new_pts",
     "lvk_frontend_state", "lvk_frontend_lk_stats", "lvk_frontend_msg_stats", "lvk_frontend_profile_enable", "lvk_frontend_profile_read",
@@ -91,6 +91,7 @@ def lib():
             "lvk_hamming256_rows": ([vp, vp, vp, i, vp], i),
             "lvk_undistort_points": ([vp, vp, i, vp, i, vp, vp, vp], i),
             "lvk_find_fundamental_mask": ([vp, vp, vp, i, d, d, vp, vp], i),
+            "lvk_find_fundamental": ([vp, vp, vp, i, d, d, vp, vp, vp], i),
             "lvk_ransac_fundamental": ([vp, vp, vp, i, d, d, i, vp, vp], i),
             "lvk_predict_homography": ([vp, i, d, d, vp, vp, vp], i),
             "lvk_frontend_create": ([vp, C.POINTER(FeConfig), C.POINTER(vp)], i), "lvk_frontend_destroy": ([vp], None),

@@ -1884,22 +1884,23 @@ static bool static_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, int
 }
 
 // ------------------------------------------------------------------------- dynamic initializer (DynamicInitializer.cpp, be_init.h)
-// cv::findFundamentalMat's RANSAC mask from the library's own kernel (fe_track.hip); a cold path: buffers come and go with the call
-static bool dyn_ransac(void* user, const std::vector<lvk_init::Pt2>& ll, const std::vector<lvk_init::Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask)
+// cv::findFundamentalMat (mask and matrix) from the library's own kernel (fe_track.hip); a cold path: buffers come and go with the call
+static bool dyn_ransac(void* user, const std::vector<lvk_init::Pt2>& ll, const std::vector<lvk_init::Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask, double* F)
 {
     lvk_ekf* e = (lvk_ekf*)user;
     const int n = (int)ll.size();
     std::vector<lvk_pt2f> h((size_t)2 * n);
     for (int i = 0; i < n; ++i) { h[(size_t)i] = lvk_pt2f{(float)ll[(size_t)i].x, (float)ll[(size_t)i].y}; h[(size_t)n + i] = lvk_pt2f{(float)rr[(size_t)i].x, (float)rr[(size_t)i].y}; }
-    lvk_pt2f* d_p = nullptr; uint8_t* d_mask = nullptr; int* d_info = nullptr; int info[2] = {0, 0};
-    bool ok = hipMalloc((void**)&d_p, sizeof(lvk_pt2f) * 2 * n) == hipSuccess && hipMalloc((void**)&d_mask, (size_t)n) == hipSuccess && hipMalloc((void**)&d_info, 2 * sizeof(int)) == hipSuccess;
+    lvk_pt2f* d_p = nullptr; uint8_t* d_mask = nullptr; int* d_info = nullptr; double* d_F = nullptr; int info[2] = {0, 0};
+    bool ok = hipMalloc((void**)&d_p, sizeof(lvk_pt2f) * 2 * n) == hipSuccess && hipMalloc((void**)&d_mask, (size_t)n) == hipSuccess && hipMalloc((void**)&d_info, 2 * sizeof(int)) == hipSuccess && hipMalloc((void**)&d_F, 9 * sizeof(double)) == hipSuccess;
     ok = ok && hipMemcpyAsync(d_p, h.data(), sizeof(lvk_pt2f) * 2 * n, hipMemcpyHostToDevice, e->ctx->stream) == hipSuccess;
-    ok = ok && lvk_find_fundamental_mask(e->ctx, d_p, d_p + n, n, thresh, conf, d_mask, d_info) == LVK_OK;
+    ok = ok && lvk_find_fundamental(e->ctx, d_p, d_p + n, n, thresh, conf, d_mask, d_info, d_F) == LVK_OK;
     mask.assign((size_t)n, 0);
     ok = ok && hipMemcpyAsync(mask.data(), d_mask, (size_t)n, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(info, d_info, sizeof info, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(F, d_F, 9 * sizeof(double), hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(e->ctx->stream) == hipSuccess;
-    if (d_p) hipFree(d_p); if (d_mask) hipFree(d_mask); if (d_info) hipFree(d_info);
+    if (d_p) hipFree(d_p); if (d_mask) hipFree(d_mask); if (d_info) hipFree(d_info); if (d_F) hipFree(d_F);
     if (!ok) e->dyn_status = lvk_set_error(e->ctx, LVK_ERR_DEVICE, "dynamic initialiser: RANSAC stage failed on the device");
     return ok && info[0] == 1;
 }

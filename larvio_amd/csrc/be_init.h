@@ -11,8 +11,8 @@
 // FlexibleInitializer.cpp:11-25 tries the static initialiser first and this one when that says no, with the same message.
 //
 // What comes from OpenCV / Ceres in the reference is restated from the published algorithms, on the host, in plain C++:
-//   cv::findFundamentalMat(FM_RANSAC, 0.3/460, 0.99)   the library's own RANSAC kernel (lvk_find_fundamental_mask: same draws, same mask as
-//                                                       OpenCV's, fe_track.hip) + the normalised 8-point refit on the inliers (run8Point)
+//   cv::findFundamentalMat(FM_RANSAC, 0.3/460, 0.99)   the library's own RANSAC kernel (lvk_find_fundamental, fe_track.hip: OpenCV's draws, OpenCV's
+//                                                       mask, and the matrix OpenCV returns: the best minimal-sample model, NOT refitted)
 //   cv::recoverPose                                     SVD of E, four (R, t) candidates, DLT triangulation, cheirality + 50-unit depth vote
 //   cv::solvePnP(..., useExtrinsicGuess = true)         Levenberg-Marquardt on the reprojection error from the given pose (CvLevMarq's job)
 //   ceres::Solve (DENSE_SCHUR, quaternion poses)        Levenberg-Marquardt with a Schur complement on the points; accepted like the
@@ -211,7 +211,8 @@ struct Frame {                                           // ImageFrame (initial_
 struct SfmFeature { bool state = false; long long id = 0; std::vector<std::pair<int, Pt2>> obs; double position[3] = {0, 0, 0}; };
 
 // ------------------------------------------------------------------------------------------------ two-view geometry
-// normalised 8-point algorithm on n >= 8 correspondences (OpenCV's run8Point): F with x2^T F x1 = 0, F[8] = 1 when it is not ~0
+// normalised 8-point algorithm on n >= 8 correspondences (OpenCV's run8Point): F with x2^T F x1 = 0, F[8] = 1 when it is not ~0.
+// NOT on the product's path (findFundamentalMat's RANSAC result is not refitted): the stand-in for the RANSAC stage in the host-only tests.
 static inline bool eight_point(const std::vector<Pt2>& p1, const std::vector<Pt2>& p2, double* F)
 {
     const int n = (int)p1.size();
@@ -605,8 +606,9 @@ static inline bool visual_imu_alignment(std::vector<Frame*>& fr, double (*Bgs)[3
 struct Result { double state_time, q[4], p[3], v[3], bg[3], ba[3], last_gyro[3], last_acc[3]; };
 // intermediate results of the successful attempt (read by the replay harness of the CPU suite, tests/host/init_replay.hip)
 struct Diag { int l = -1; double relR[9], relT[3]; std::vector<std::array<double, 9>> sfm_R; std::vector<std::array<double, 3>> sfm_T; double g[3] = {0, 0, 0}, scale = 0; int n_points = 0; };
-// callback for cv::findFundamentalMat(ll, rr, FM_RANSAC, thresh, conf, mask): float correspondences -> inlier mask (empty = none computed)
-typedef bool (*ransac_fn)(void* user, const std::vector<Pt2>& ll, const std::vector<Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask);
+// callback for E = cv::findFundamentalMat(ll, rr, FM_RANSAC, thresh, conf, mask): float correspondences -> inlier mask and the matrix (9 doubles;
+// false / all zeros = OpenCV's empty Mat)
+typedef bool (*ransac_fn)(void* user, const std::vector<Pt2>& ll, const std::vector<Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask, double* F);
 
 struct DynInit {
     // configuration (DynamicInitializer.h:40-75)
@@ -675,10 +677,10 @@ struct DynInit {
         for (auto& p : ll) { p.x = (double)(float)p.x; p.y = (double)(float)p.y; }      // cv::Point2f
         for (auto& p : rr) { p.x = (double)(float)p.x; p.y = (double)(float)p.y; }
         std::vector<unsigned char> mask;
-        if (!ransac || !ransac(ransac_user, ll, rr, 0.3 / 460, 0.99, mask) || mask.size() != ll.size()) return false;
-        std::vector<Pt2> i1, i2; for (size_t i = 0; i < ll.size(); ++i) if (mask[i]) { i1.push_back(ll[i]); i2.push_back(rr[i]); }
-        double E[9];
-        if (!eight_point(i1, i2, E)) return false;       // findFundamentalMat's final refit on the inliers (run8Point)
+        double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!ransac || !ransac(ransac_user, ll, rr, 0.3 / 460, 0.99, mask, E) || mask.size() != ll.size()) return false;
+        bool any = false; for (double v : E) any = any || v != 0.;
+        if (!any) return false;                          // (the reference would hand an empty Mat to recoverPose: an OpenCV assertion)
         double R[9], t[3];
         const int inl = recover_pose(E, ll, rr, mask, R, t);
         double Rt[9], v[3]; m3_t(R, Rt); m3_v(Rt, t, v);

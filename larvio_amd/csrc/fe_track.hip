@@ -59,14 +59,14 @@ __global__ void k_undistort(const lvk_pt2f* __restrict__ in, int n, CamParams ca
 template <int NT>
 __global__ void __launch_bounds__(NT) k_fundamental_mask(const lvk_pt2f* __restrict__ p1, const lvk_pt2f* __restrict__ p2, int n,
                                                        double thresh, double conf, int max_iters, int force_ransac,
-                                                       uint8_t* __restrict__ mask, int* __restrict__ info)
+                                                       uint8_t* __restrict__ mask, int* __restrict__ info, double* __restrict__ model)
 {
     __shared__ lvk_pt2f s1[FM_MAX_N], s2[FM_MAX_N];
     __shared__ uint8_t smask[FM_MAX_N];
     for (int i = threadIdx.x; i < n; i += NT) { s1[i] = p1[i]; s2[i] = p2[i]; }
     __syncthreads();
     int iters = 0;
-    int wrote = fm_mask_block<NT>(s1, s2, n, thresh, conf, max_iters, force_ransac, smask, &iters);
+    int wrote = fm_mask_block<NT>(s1, s2, n, thresh, conf, max_iters, force_ransac, smask, &iters, model);
     __syncthreads();
     if (wrote) for (int i = threadIdx.x; i < n; i += NT) mask[i] = smask[i];
     if (threadIdx.x == 0 && info) { info[0] = wrote; info[1] = iters; }
@@ -138,13 +138,13 @@ lvk_status lvk_undistort_points(lvk_context* ctx, const lvk_pt2f* d_in, int n, c
 }
 
 static lvk_status fm_launch(lvk_context* ctx, const lvk_pt2f* p1, const lvk_pt2f* p2, int n, double thresh, double conf, int max_iters,
-                            int force_ransac, uint8_t* mask, int* info)
+                            int force_ransac, uint8_t* mask, int* info, double* model = nullptr)
 {
     if (!ctx || n < 0 || (n > 0 && (!p1 || !p2 || !mask))) return lvk_set_error(ctx, LVK_ERR_ARG, "fundamental: bad argument");
     if (n > FM_MAX_N) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "fundamental: n=%d exceeds %d", n, FM_MAX_N);
     // same split as the frame path (frontend.hip: commit): the wide workgroup for point sets the per-point loops dominate
-    if (n > FM_WIDE_FROM) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fundamental_mask<FM_THREADS_WIDE>), dim3(1), dim3(FM_THREADS_WIDE), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fundamental_mask<FM_THREADS>), dim3(1), dim3(FM_THREADS), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info);
+    if (n > FM_WIDE_FROM) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fundamental_mask<FM_THREADS_WIDE>), dim3(1), dim3(FM_THREADS_WIDE), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info, model);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fundamental_mask<FM_THREADS>), dim3(1), dim3(FM_THREADS), 0, ctx->stream, p1, p2, n, thresh, conf, max_iters, force_ransac, mask, info, model);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
@@ -153,6 +153,14 @@ lvk_status lvk_find_fundamental_mask(lvk_context* ctx, const lvk_pt2f* d_p1, con
                                      uint8_t* d_mask, int* d_info)
 {
     return fm_launch(ctx, d_p1, d_p2, n, thresh, conf, 1000, 0, d_mask, d_info);
+}
+
+lvk_status lvk_find_fundamental(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n, double thresh, double conf,
+                                uint8_t* d_mask, int* d_info, double* d_F)
+{
+    if (!d_F) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_find_fundamental: d_F is null");
+    if (n < 7) { if (ctx) hipMemsetAsync(d_F, 0, 9 * sizeof(double), ctx->stream); }      // (the kernel returns before it touches anything)
+    return fm_launch(ctx, d_p1, d_p2, n, thresh, conf, 1000, 0, d_mask, d_info, d_F);
 }
 
 lvk_status lvk_ransac_fundamental(lvk_context* ctx, const lvk_pt2f* d_p1, const lvk_pt2f* d_p2, int n, double thresh, double conf,

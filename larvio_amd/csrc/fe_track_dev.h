@@ -906,8 +906,9 @@ __device__ __noinline__ int fm_lmeds_block(const lvk_pt2f* s1, const lvk_pt2f* s
 //   the sequential "better model -> shrink niters" rule over the round in order.
 template <int NT>
 __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int n, double thresh, double conf, int max_iters,
-                                    int force_ransac, uint8_t* smask, int* iters_out)
-{
+                                    int force_ransac, uint8_t* smask, int* iters_out, double* model_out = nullptr)
+{   // model_out (optional, global memory, 9 doubles): the matrix cv::findFundamentalMat RETURNS - the registrator's best minimal-sample
+    // model, zeros when it has none (the empty Mat); for n == 7 the first of the solver's models.  nullptr in the frame path.
     __shared__ lvk_pt2f sub1[FM_ROUND][7], sub2[FM_ROUND][7];
     __shared__ double models[FM_ROUND][27];
     __shared__ int nmodels[FM_ROUND], found[FM_ROUND], good[FM_ROUND][3];
@@ -923,7 +924,17 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
     const int t = threadIdx.x;
     *iters_out = 0;
     if (n < 7) return 0;
-    if (n == 7) { for (int i = t; i < n; i += NT) smask[i] = 1; __syncthreads(); return 1; }
+    if (model_out && t < 9) model_out[t] = 0.;
+    if (n == 7) {
+        for (int i = t; i < n; i += NT) smask[i] = 1;
+        if (model_out) {                                   // (stage-level call only)
+            __shared__ double m7[27]; __shared__ int nm7;
+            if (t == 0) { lvk_pt2f a[7], b[7]; for (int i = 0; i < 7; ++i) { a[i] = s1[i]; b[i] = s2[i]; } nm7 = d_fundamental_7pt(a, b, m7); }
+            __syncthreads();
+            if (nm7 > 0 && t < 9) model_out[t] = m7[t];
+        }
+        __syncthreads(); return 1;
+    }
     if (thresh <= 0) thresh = 3;
     if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
 
@@ -1064,6 +1075,7 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
         if (sh_ctl[1]) { for (int i = t; i < n; i += NT) smask[i] = d_fm_error(s1[i], s2[i], best_model) <= tthr; }
         else { for (int i = t; i < n; i += NT) smask[i] = 0; }
         *iters_out = sh_ctl[2];
+        if (model_out && sh_ctl[1] && t < 9) model_out[t] = best_model[t];
         __syncthreads();
         return 1;
     }
@@ -1071,5 +1083,7 @@ __device__ inline int fm_mask_block(const lvk_pt2f* s1, const lvk_pt2f* s2, int 
     // ---- LMedS (8 <= n < 15)
     __shared__ lvk_pt2f lsub1[FM_THREADS][7], lsub2[FM_THREADS][7];
     __shared__ int lfound[FM_THREADS];
-    return fm_lmeds_block<NT>(s1, s2, n, conf, smask, iters_out, lsub1, lsub2, lfound, lm_med, lm_seq, best_model, sh_ctl, &sh_rng);
+    const int wrote = fm_lmeds_block<NT>(s1, s2, n, conf, smask, iters_out, lsub1, lsub2, lfound, lm_med, lm_seq, best_model, sh_ctl, &sh_rng);
+    if (model_out) { __syncthreads(); if (wrote && sh_ctl[1] >= 0 && t < 9) model_out[t] = best_model[t]; }      // (sh_ctl[1] = the winning thread, -1: none)
+    return wrote;
 }

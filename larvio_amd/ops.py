@@ -142,6 +142,15 @@ def find_fundamental_mask(ctx, p1, p2, thresh=1.0, conf=0.99):
     return (ctx.to_host(dm, np.uint8, (n,)) if info[0] else None), int(info[1])
 
 
+def find_fundamental(ctx, p1, p2, thresh=1.0, conf=0.99):
+    """lvk_find_fundamental: -> (mask or None, F 3x3, hypotheses drawn); F = the matrix cv::findFundamentalMat returns (zeros: the empty Mat)"""
+    a = _pts(p1); b = _pts(p2); n = len(a)
+    da = ctx.to_device(a); db = ctx.to_device(b); dm = ctx.alloc(max(n, 1)); di = ctx.alloc(8); dF = ctx.alloc(72)
+    ctx.check(lib().lvk_find_fundamental(ctx.h, _p(da), _p(db), n, thresh, conf, _p(dm), _p(di), _p(dF)))
+    info = ctx.to_host(di, np.int32, (2,))
+    return (ctx.to_host(dm, np.uint8, (n,)) if info[0] else None), ctx.to_host(dF, np.float64, (3, 3)), int(info[1])
+
+
 def ransac_fundamental(ctx, p1, p2, thresh=1.0, conf=0.99, max_iters=1000):
     a = _pts(p1); b = _pts(p2); n = len(a)
     da = ctx.to_device(a); db = ctx.to_device(b); dm = ctx.alloc(max(n, 1)); di = ctx.alloc(8)

@@ -565,9 +565,9 @@ static int find_inliers(const lvo_pt2f* m1, const lvo_pt2f* m2, int n, const dou
     return nz;
 }
 
-int lvo_ransac_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count,
-                           double thresh, double conf, int max_iters, uint8_t* mask_out, int* iters_out)
-{   /* RANSACPointSetRegistrator::run, modelPoints 7 */
+static int ransac_fundamental_model(const lvo_pt2f* m1, const lvo_pt2f* m2, int count,
+                                    double thresh, double conf, int max_iters, uint8_t* mask_out, int* iters_out, double* best_out)
+{   /* RANSACPointSetRegistrator::run, modelPoints 7; best_out (optional): the model the registrator copies out (bestModel) */
     cv_rng rng; rng.state = (uint64_t)-1;
     int niters = max_iters > 1 ? max_iters : 1, max_good = 0, iter;
     float* err = (float*)malloc(sizeof(float) * (size_t)count);
@@ -582,6 +582,7 @@ int lvo_ransac_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count,
             int good = find_inliers(m1, m2, count, model + 9 * i, err, mask, thresh);
             if (good > (max_good > 6 ? max_good : 6)) {
                 memcpy(mask_out, mask, (size_t)count);
+                if (best_out) memcpy(best_out, model + 9 * i, 9 * sizeof(double));
                 max_good = good;
                 niters = ransac_update_num_iters(conf, (double)(count - good) / count, 7, niters);
             }
@@ -592,9 +593,15 @@ int lvo_ransac_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count,
     return max_good > 0;
 }
 
+int lvo_ransac_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count,
+                           double thresh, double conf, int max_iters, uint8_t* mask_out, int* iters_out)
+{
+    return ransac_fundamental_model(m1, m2, count, thresh, conf, max_iters, mask_out, iters_out, NULL);
+}
+
 static int cmp_int(const void* a, const void* b) { int x = *(const int*)a, y = *(const int*)b; return x < y ? -1 : x > y; }
 
-static int lmeds_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count, double conf, uint8_t* mask_out)
+static int lmeds_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count, double conf, uint8_t* mask_out, double* best_out)
 {   /* LMeDSPointSetRegistrator::run, modelPoints 7, maxIters 1000 */
     cv_rng rng; rng.state = (uint64_t)-1;
     int niters = ransac_update_num_iters(conf, 0.45, 7, 1000);
@@ -620,24 +627,32 @@ static int lmeds_fundamental(const lvo_pt2f* m1, const lvo_pt2f* m2, int count, 
         double sigma = 2.5 * 1.4826 * (1 + 5. / (count - 7)) * sqrt(min_median);
         sigma = sigma > 0.001 ? sigma : 0.001;
         find_inliers(m1, m2, count, best, err, mask_out, sigma);
+        if (best_out) memcpy(best_out, best, sizeof best);
         ok = 1;
     }
     free(err); free(srt);
     return ok;
 }
 
-int lvo_find_fundamental_mask(const lvo_pt2f* p1, const lvo_pt2f* p2, int n, double thresh, double conf, uint8_t* mask)
-{   /* cv::findFundamentalMat(.., FM_RANSAC, ..) dispatch [upstream fundam.cpp] */
+int lvo_find_fundamental(const lvo_pt2f* p1, const lvo_pt2f* p2, int n, double thresh, double conf, uint8_t* mask, double* F)
+{   /* cv::findFundamentalMat(.., FM_RANSAC, ..) dispatch [upstream fundam.cpp]: the matrix it RETURNS is the registrator's best
+     * minimal-sample model - there is no refit on the inliers.  F (optional, 9 doubles) = zeros when the registrator fails (OpenCV returns an
+     * empty Mat); for n == 7 the first of the up to three models (OpenCV returns them stacked). */
+    if (F) memset(F, 0, 9 * sizeof(double));
     if (n < 7) return 0;                       /* returns before touching the mask */
-    if (n == 7) { memset(mask, 1, 7); return 1; }
+    if (n == 7) { memset(mask, 1, 7); if (F) { double m[27]; if (lvo_fundamental_7pt(p1, p2, m) > 0) memcpy(F, m, 9 * sizeof(double)); } return 1; }
     if (thresh <= 0) thresh = 3;
     if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
     if (n >= 15) {
-        if (!lvo_ransac_fundamental(p1, p2, n, thresh, conf, 1000, mask, NULL)) memset(mask, 0, (size_t)n);
+        if (!ransac_fundamental_model(p1, p2, n, thresh, conf, 1000, mask, NULL, F)) memset(mask, 0, (size_t)n);
     } else {
-        if (!lmeds_fundamental(p1, p2, n, conf, mask)) memset(mask, 0, (size_t)n);
+        if (!lmeds_fundamental(p1, p2, n, conf, mask, F)) memset(mask, 0, (size_t)n);
     }
     return 1;
+}
+int lvo_find_fundamental_mask(const lvo_pt2f* p1, const lvo_pt2f* p2, int n, double thresh, double conf, uint8_t* mask)
+{
+    return lvo_find_fundamental(p1, p2, n, thresh, conf, mask, NULL);
 }
 
 /* ======================================================================== gyro prediction

@@ -127,6 +127,9 @@ void lvo_undistort_points(const lvo_pt2f* in, int n, const double intr[4], int m
  * OpenCV would leave the mask untouched (n < 7).  n==7: all ones; 8..14: LMedS; >=15: RANSAC. */
 int lvo_find_fundamental_mask(const lvo_pt2f* p1, const lvo_pt2f* p2, int n,
                               double thresh, double conf, uint8_t* mask);
+/* the same with the matrix findFundamentalMat returns (the best minimal-sample model; zeros = the empty Mat) */
+int lvo_find_fundamental(const lvo_pt2f* p1, const lvo_pt2f* p2, int n,
+                         double thresh, double conf, uint8_t* mask, double* F);
 /* the RANSAC branch alone, any n >= 8 (stage-level parity with the HIP kernel).
  * iters_out = number of hypotheses drawn. */
 int lvo_ransac_fundamental(const lvo_pt2f* p1, const lvo_pt2f* p2, int n,

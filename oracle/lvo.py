@@ -81,6 +81,8 @@ def lib():
         L.lvo_undistort_points.argtypes = [vp, i, vp, i, vp, vp, vp]
         L.lvo_find_fundamental_mask.argtypes = [vp, vp, i, d, d, vp]
         L.lvo_find_fundamental_mask.restype = i
+        L.lvo_find_fundamental.argtypes = [vp, vp, i, d, d, vp, vp]
+        L.lvo_find_fundamental.restype = i
         L.lvo_ransac_fundamental.argtypes = [vp, vp, i, d, d, i, vp, vp]
         L.lvo_ransac_fundamental.restype = i
         L.lvo_fundamental_7pt.argtypes = [vp, vp, vp]
@@ -232,6 +234,14 @@ def find_fundamental_mask(p1, p2, thresh=1.0, conf=0.99):
     mask = np.zeros(max(n, 1), np.uint8)
     wrote = lib().lvo_find_fundamental_mask(_p(a), _p(b), n, thresh, conf, _p(mask))
     return (mask[:n] if wrote else None)
+
+
+def find_fundamental(p1, p2, thresh=1.0, conf=0.99):
+    """-> (mask or None, F 3x3): what cv::findFundamentalMat(p1, p2, FM_RANSAC, thresh, conf, mask) returns (F = zeros: the empty Mat)"""
+    a = pts(p1); b = pts(p2); n = len(a)
+    mask = np.zeros(max(n, 1), np.uint8); F = np.zeros(9, np.float64)
+    wrote = lib().lvo_find_fundamental(_p(a), _p(b), n, thresh, conf, _p(mask), _p(F))
+    return (mask[:n] if wrote else None), F.reshape(3, 3)
 
 
 def ransac_fundamental(p1, p2, thresh=1.0, conf=0.99, max_iters=1000):

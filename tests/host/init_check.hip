@@ -44,7 +44,8 @@ struct Traj {
         m3_t(R0, R0t); m3_mul(R0t, dR, M); w[0] = 0.5 * (M[7] - M[5]); w[1] = 0.5 * (M[2] - M[6]); w[2] = 0.5 * (M[3] - M[1]);
     }
 };
-static bool keep_all(void*, const std::vector<Pt2>& ll, const std::vector<Pt2>&, double, double, std::vector<unsigned char>& mask) { mask.assign(ll.size(), 1); return true; }
+// stand-in for the RANSAC stage (host-only test): every correspondence is an inlier, the matrix is the normalised 8-point fit of all of them
+static bool keep_all(void*, const std::vector<Pt2>& ll, const std::vector<Pt2>& rr, double, double, std::vector<unsigned char>& mask, double* F) { mask.assign(ll.size(), 1); return eight_point(ll, rr, F); }
 
 int main()
 {

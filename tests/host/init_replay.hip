@@ -5,7 +5,8 @@
 #include "../../larvio_amd/csrc/be_init.h"
 #include <stdio.h>
 using namespace lvk_init;
-static bool keep_all(void*, const std::vector<Pt2>& ll, const std::vector<Pt2>&, double, double, std::vector<unsigned char>& mask) { mask.assign(ll.size(), 1); return true; }
+// stand-in for the RANSAC stage (host-only test): every correspondence is an inlier, the matrix is the normalised 8-point fit of all of them
+static bool keep_all(void*, const std::vector<Pt2>& ll, const std::vector<Pt2>& rr, double, double, std::vector<unsigned char>& mask, double* F) { mask.assign(ll.size(), 1); return eight_point(ll, rr, F); }
 static void arr(const char* k, const double* v, int n, bool last = false) { printf("\"%s\": [", k); for (int i = 0; i < n; ++i) printf("%s%.17g", i ? ", " : "", v[i]); printf("]%s", last ? "" : ", "); }
 int main(int argc, char** argv)
 {

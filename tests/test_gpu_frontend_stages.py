@@ -254,6 +254,28 @@ def test_find_fundamental_dispatch(gpu_ctx, n):
         assert np.array_equal(mg, mo)
 
 
+@pytest.mark.parametrize("n", [5, 7, 11, 14, 15, 60, 400])
+def test_find_fundamental_returns_the_registrators_model(gpu_ctx, n):
+    """lvk_find_fundamental: mask AND matrix of cv::findFundamentalMat(.., FM_RANSAC, ..) - the best minimal-sample model (7-point solver,
+    no refit on the inliers), what the moving-start initialiser decomposes (solve_5pts.cpp:206-209).  Same bits as the oracle's: the
+    7-point solve and the model selection follow the same order of operations on both sides."""
+    from oracle import lvo
+    from larvio_amd import ops
+    x1, x2 = _two_view(max(n, 1), 0.15, 300 + n)
+    x1, x2 = x1[:n], x2[:n]
+    mo, Fo = lvo.find_fundamental(x1, x2)
+    mg, Fg, _ = ops.find_fundamental(gpu_ctx, x1, x2)
+    if n < 7:
+        assert mo is None and mg is None and not Fg.any() and not Fo.any()
+        return
+    assert np.array_equal(mg, mo)
+    assert Fo.any() and np.array_equal(Fg, Fo), (Fg, Fo)
+    if n >= 15:                                            # the model explains its own inliers: epipolar distance below the threshold
+        h = lambda x: np.column_stack([x, np.ones(len(x))])
+        l2 = h(x1) @ Fo.T; d = np.abs(np.sum(h(x2) * l2, 1)) / np.hypot(l2[:, 0], l2[:, 1])
+        assert d[mo.astype(bool)].max() < 1.5
+
+
 def test_predict_homography_host_math():
     """host-side float32 math of the C ABI equals the oracle's (no GPU involved, but lives in the HIP library)."""
     from oracle import lvo
