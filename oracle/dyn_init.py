@@ -97,8 +97,9 @@ def _triangulate(P0, P1, a, b):
     return X[:3] / X[3]
 
 
-def recover_pose(E, p1, p2):
-    """cv::recoverPose with the identity camera: (R, t) with x2 ~ R x1 + t, the candidate with the most points in front of both cameras"""
+def recover_pose(E, p1, p2, mask=None):
+    """recoverPose (solve_5pts.cpp:29-181) with the identity camera: (R, t) with x2 ~ R x1 + t, the candidate with the most points (of
+    those the incoming mask keeps) in front of both cameras"""
     U, _, Vt = np.linalg.svd(E)
     if np.linalg.det(U) < 0: U = -U
     if np.linalg.det(Vt) < 0: Vt = -Vt
@@ -108,7 +109,9 @@ def recover_pose(E, p1, p2):
     for R, t in ((R1, t0), (R2, t0), (R1, -t0), (R2, -t0)):         # the order of preference of solve_5pts.cpp:150-180 (first of equals wins)
         P1 = np.hstack([R, t[:, None]]); P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
         good = 0
-        for a, b in zip(p1, p2):
+        for k, (a, b) in enumerate(zip(p1, p2)):
+            if mask is not None and not mask[k]:
+                continue
             X = _triangulate(P0, P1, a, b); z2 = (R @ X + t)[2]
             good += (0 < X[2] < 50) and (0 < z2 < 50)
         if best is None or good > best[0]:
@@ -260,9 +263,11 @@ def visual_imu_alignment(frames, TIC, Bg):
 
 
 # ------------------------------------------------------------------------------------------------ the replay
-def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
+def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400, fundamental=None):
     """Feed feature messages [(ts, structured array with id/u/v/u_vel/v_vel)] and the IMU stream as LarVio::processFeatures would
-    (DynamicInitializer.cpp:20-44) until the initialiser succeeds.  -> dict of the successful attempt's results, or None."""
+    (DynamicInitializer.cpp:20-44) until the initialiser succeeds.  -> dict of the successful attempt's results, or None.
+    fundamental(p1, p2, thresh, conf) -> (mask, F): the stand-in for cv::findFundamentalMat (oracle.lvo.find_fundamental is the real one);
+    None = "every correspondence is an inlier, F = their 8-point fit"."""
     RIC = np.asarray(R_b2c, float).T; TIC = np.asarray(t_c_b, float)
     lower = 0.0; ddt = 0.0; first_imu = False; frame_count = 0; initial_ts = 0.0
     acc0 = gyr0 = None; curr_time = -1.0
@@ -304,7 +309,7 @@ def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
             continue
         ok = None
         if ts - initial_ts > 0.1:
-            ok = _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg)
+            ok = _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg, fundamental)
             initial_ts = ts
         if ok is not None:
             state_time = Times[WINDOW_SIZE] + td + ddt
@@ -323,7 +328,7 @@ def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400):
     return None
 
 
-def _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg):
+def _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg, fundamental=None):
     nf = WINDOW_SIZE + 1
     tr_maps = [{t["start"] + k: p for k, p in enumerate(t["pts"])} for t in tracks]
     # relativePose (:330-359)
@@ -334,8 +339,13 @@ def _initial_structure(tracks, frames, Times, td, RIC, TIC, Bg):
         a = np.array([x[0] for x in c]); b = np.array([x[1] for x in c])
         if np.mean(np.linalg.norm(a - b, axis=1)) * 460 <= 30 or len(c) < 15: continue
         a32, b32 = a.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
-        E = eight_point(a32, b32)
-        good, R, t = recover_pose(E, a32, b32)
+        if fundamental is None:
+            E, keep = eight_point(a32, b32), None
+        else:
+            keep, E = fundamental(a32.astype(np.float32), b32.astype(np.float32), 0.3 / 460, 0.99)       # solve_5pts.cpp:206
+            if keep is None or not E.any():
+                continue
+        good, R, t = recover_pose(E, a32, b32, keep)
         if good > 12:
             l = i; relR = R.T; relT = -R.T @ t
             break
