@@ -1,0 +1,80 @@
+"""ctypes binding of oracle/_ref/liblvref_orb.so: the REFERENCE's own ORB descriptor code (/root/reference/src/ORBDescriptor.cpp,
+include/ORB/ORBDescriptor.h), compiled in place against the OpenCV stand-ins of oracle/ref_shim/ (oracle/Makefile, target `ref`).
+TEST INFRASTRUCTURE ONLY: it pins the restatement in oracle/fe_track.c / fe_image.c; the product never loads it.
+The library is built here (where /root/reference exists) by __graft_entry__.build(); on the GPU box only the prebuilt file exists."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "liblvref_orb.so")
+_lib = None
+
+
+def available(build=True):
+    if os.path.exists(_SO):
+        return True
+    if build and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/liblvref_orb.so is missing and /root/reference is not here to build it from")
+        L = C.CDLL(_SO)
+        vp, i = C.c_void_p, C.c_int
+        L.lvref_orb_create.restype = vp; L.lvref_orb_create.argtypes = [vp, i, i, i, i, i]
+        L.lvref_orb_destroy.argtypes = [vp]
+        L.lvref_orb_describe.restype = i; L.lvref_orb_describe.argtypes = [vp, vp, i, vp, vp]
+        L.lvref_orb_hamming.restype = i; L.lvref_orb_hamming.argtypes = [vp, vp]
+        L.lvref_orb_planes.restype = i; L.lvref_orb_planes.argtypes = [vp, vp, vp]
+        L.lvref_orb_umax.restype = i; L.lvref_orb_umax.argtypes = [vp, vp]
+        L.lvref_orb_pattern.restype = i; L.lvref_orb_pattern.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+class RefOrb:
+    """larvio::ORBdescriptor(image, 2, nlevels) where `image` is the view of level 0 inside its padded LK-pyramid buffer
+    (`padded`: (h + 2 pad) x (w + 2 pad) u8, as image_processor.cpp:150 hands it over); pad = 0 for a stand-alone image."""
+
+    def __init__(self, padded, pad, nlevels=2):
+        padded = np.ascontiguousarray(padded, np.uint8)
+        self.h, self.w = padded.shape[0] - 2 * pad, padded.shape[1] - 2 * pad
+        self._keep = padded
+        self.o = lib().lvref_orb_create(padded.ctypes.data, self.w, self.h, pad, padded.shape[1], nlevels)
+        if not self.o:
+            raise MemoryError
+
+    def __del__(self):
+        if getattr(self, "o", None):
+            lib().lvref_orb_destroy(self.o); self.o = None
+
+    def describe(self, points):
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 2); n = len(p)
+        desc = np.empty((n, 32), np.uint8); ang = np.empty(n, np.float32)
+        if lib().lvref_orb_describe(self.o, p.ctypes.data, n, desc.ctypes.data, ang.ctypes.data) != 0:
+            raise RuntimeError("computeDescriptors returned false")
+        return desc, ang
+
+    def planes(self):
+        ext = np.empty((self.h + 64, self.w + 64), np.uint8); blur = np.empty_like(ext)
+        b = lib().lvref_orb_planes(self.o, ext.ctypes.data, blur.ctypes.data)
+        if b != 32:
+            raise RuntimeError(f"unexpected mosaic border {b}")
+        return ext, blur
+
+    def umax(self):
+        u = np.zeros(16, np.int32); n = lib().lvref_orb_umax(self.o, u.ctypes.data); return u[:n]
+
+    def pattern(self):
+        p = np.zeros(1024, np.int32); n = lib().lvref_orb_pattern(self.o, p.ctypes.data); return p[:2 * n]
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().lvref_orb_hamming(a.ctypes.data, b.ctypes.data)

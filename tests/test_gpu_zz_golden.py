@@ -45,3 +45,20 @@ def test_filter_against_the_committed_golden_fixture(gpu_ctx):
     s = ora.state()
     assert np.allclose(np.concatenate([[s["t"]], s["q"], s["p"], s["v"]]), z["trace"][-1][:-1], rtol=1e-9, atol=1e-12)
     assert [c[k] for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map")] == list(z["counters"])
+
+
+def test_orb_block_against_the_references_own_outputs(gpu_ctx):
+    """HIP ORB path against tests/golden/ref_orb.npz - outputs of the REFERENCE's ORBDescriptor.cpp compiled in place
+    (tests/golden/make_ref_orb.py; oracle/_ref), not of the oracle: mosaic + blur planes, IC angles, descriptors (cvRound ties and
+    border-reaching patches included) and the Hamming distance, bit for bit, with neither the oracle nor the library in the loop."""
+    from larvio_amd import ops
+    z = np.load(os.path.join(GOLDEN, "ref_orb.npz"))
+    img = z["img"]; h, w = img.shape
+    p = ops.Pyramid(gpu_ctx, w, h, int(z["pad"]), 2).build(img, clahe=False)
+    e, b = p.orb_prepare()
+    assert int(e.astype(np.int64).sum()) == int(z["ext_sum"]) and int(b.astype(np.int64).sum()) == int(z["blur_sum"])
+    assert np.array_equal(e[[0, 17, 31, 32, 150, h + 32, h + 63]], z["ext_rows"]) and np.array_equal(b[[32, 33, 150, h + 31]], z["blur_rows"])
+    d, a = ops.orb_describe(gpu_ctx, p, z["pts"])
+    assert np.array_equal(d, z["desc"])
+    assert np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), z["angle"].view(np.uint32))
+    assert list(ops.hamming_rows(gpu_ctx, z["ham_a"], z["ham_b"])) == list(z["ham"])
