@@ -50,45 +50,15 @@ def _cpulist(text):
     return cpus
 
 
-def bind_one_socket(local_rank=0):
-    """Keep the whole process - Python, the HIP runtime's own threads and queues, our two driver threads - close together, before
-    anything initialises HIP.  Dual-socket hosts: ONE socket (a process whose threads straddle both ran the filter at 0.35 instead
-    of 0.30 ms per update; which socket made no difference).  Within the socket: the physical cores (no SMT siblings) of ONE L3
-    group - the caller's and the filter's thread hand messages and counters to each other every ~100 us; with the scheduler free to
-    put them anywhere in the socket the filter ran in two modes, 0.264 or 0.276 ms per message, from run to run.  Ranks of one node
-    take different L3 groups.  LVK_BENCH_BIND=socket: the socket only; =0: nothing.  Returns the affinity set before binding."""
-    before = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
-    mode = os.environ.get("LVK_BENCH_BIND", "l3")
-    if mode != "0" and hasattr(os, "sched_setaffinity"):
-        try:
-            cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else min(before)
-            import glob as _glob
-            keep = set()
-            for node in _glob.glob("/sys/devices/system/node/node*/cpulist"):
-                cpus = _cpulist(open(node).read())
-                if cpu in cpus:
-                    keep = cpus & before
-                    break
-            if keep and mode != "socket":
-                groups = {}
-                for c in sorted(keep):
-                    try:
-                        l3 = frozenset(_cpulist(open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c).read()))
-                        sib = _cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read())
-                    except OSError:
-                        groups = {}
-                        break
-                    if c == min(sib):                    # one logical CPU per physical core
-                        groups.setdefault(min(l3), set()).add(c)
-                order = [groups[k] & keep for k in sorted(groups)]
-                order = [g for g in order if len(g) >= 4]
-                if order:
-                    keep = order[local_rank % len(order)]
-            if keep:
-                os.sched_setaffinity(0, keep)
-        except (OSError, ValueError):
-            pass
-    return before
+def runtime_env(local_rank=0):
+    """The library's own runtime settings (include/lvk_c.h: lvk_runtime_env) instead of a copy of them here: one hardware queue per
+    stream, kernel arguments in device memory, and - LVK_BENCH_BIND=0 turns it off - the whole process (Python, the HIP runtime's own
+    threads, our two driver threads) on the physical cores of ONE L3 group of the socket it runs on (rank r takes the r-th group).  Called
+    after `import torch` (which loads, but does not initialise, the HIP runtime the library then shares) and before the first HIP call.
+    Returns the flags that took effect."""
+    from larvio_amd._lib import lib
+    flags = 3 | (0 if os.environ.get("LVK_BENCH_BIND", "l3") == "0" else 4)
+    return int(lib().lvk_runtime_env(flags, int(local_rank)))
 
 
 class Run:
@@ -510,6 +480,41 @@ def cpu_baseline_backend(sim, n_pre, n_sample):
                       "the CPU oracle's filter (dense Householder compression); a restatement, not the Eigen/SuiteSparse build" % (n, dt, n_pre)}
 
 
+def adapter_cpp(wl, frames0, ts0, seq, n_timed, period):
+    """frames/s of the C++ binary adapter/adapter_main - the loop of app/larvioMain.cpp:84-117 (processImage, processFeatures, every
+    getter of :117-170 except the viewer's picture) written against the adapter classes with the reference's signatures - on the same
+    synthetic camera written as an ASL directory from t = 0 (static initialiser, window fill), its LAST n_timed frames timed by the binary
+    itself with the images decoded beforehand (--bench).  A separate process: it initialises its own HIP runtime, through the
+    library's lvk_runtime_env defaults, and inherits this process's core binding."""
+    import subprocess, tempfile, shutil, re
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from make_euroc_dir import write_euroc_dir
+    exe = os.path.join(ROOT, "adapter", "adapter_main")
+    if not os.path.exists(exe):
+        return {"error": "adapter/adapter_main not built"}
+    d = tempfile.mkdtemp(prefix="lvk_asl_")
+    try:
+        imu = seq.imu_array(0, int(ts0[-1] * 200) + 40)
+        write_euroc_dir(d, list(zip(ts0, frames0)), imu, wl["fcfg"], wl["bcfg"], output_dir=d + "/")
+        cmd = [exe, d + "/mav0/imu0/data.csv", d + "/mav0/cam0/data.csv", d + "/mav0/cam0/data", d + "/config.yaml", "--bench", str(n_timed), "--no-vis"]
+        best = None; runs = []
+        for _ in range(2):
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            mt = re.search(r"bench frames (\d+) seconds ([0-9.]+) frames_per_s ([0-9.]+)", r.stdout)
+            if r.returncode != 0 or not mt:
+                return {"error": "adapter_main failed (rc %d): %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+            runs.append(float(mt.group(3)))
+            tail = r.stdout.strip().splitlines()[-1]
+        best = max(runs)
+        return {"value": round(best, 2), "unit": "frames/s", "runs": runs, "timed_frames": n_timed, "frames_total": len(ts0), "binary": "adapter/adapter_main --bench %d --no-vis" % n_timed,
+                "summary": tail,
+                "note": "the reference's driver loop as a C++ process (adapter classes over the C ABI; deferred processFeatures, pose + covariances + window poses + "
+                        "map points read right after it as app/larvioMain.cpp:117-170 does): static start at t = 0, window filled before the timed frames; "
+                        "PNG decode outside the timed part; runtime settings from the library (lvk_runtime_env via lvk_context_create), core binding inherited"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def shard_probe(rank, world, local_rank):
     """Run `bench.py --backend-only [--sharded]` as a CHILD process per rank (own rendezvous on MASTER_PORT + 1, own RCCL
     communicator) with a 240 s time limit: a failure or a hang of the sharded path cannot take the headline measurement down with it."""
@@ -582,6 +587,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-pass", action="store_true", help="skip the second (device-resident) pass")
     ap.add_argument("--dump-latencies", action="store_true", help="per-step caller time of the timed region (us) and which steps published a message, on stderr")
+    ap.add_argument("--no-adapter-cpp", action="store_true", help="skip the C++ adapter binary's own frames/s (adapter/adapter_main on an ASL directory written from the synthetic camera)")
     ap.add_argument("--no-adapter-pass", action="store_true", help="skip the passes through the adapter's schedule (deferred processFeatures under a blocking driver)")
     ap.add_argument("--unaligned", action="store_true", help="camera stamps off the IMU grid (phase + jitter, jittered IMU stamps: larvio_amd.synthetic.unaligned_stamps): "
                                                                "the pipelined driver's early erase count is then not always available")
@@ -598,9 +604,8 @@ def main():
     if args.sharded and args.config != "5" and not args.backend_only:
         raise SystemExit("--sharded is the configs[4] path (2000 tracks): use --config 5 (or --backend-only)")
     if args.backend_only:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 % on these chains of small kernels (same-box A/B)
-        bind_one_socket(local_rank)
         import torch
+        runtime_env(local_rank)                          # lvk_runtime_env: hardware queues, kernel arguments, L3-group binding - before the first HIP call
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
         dist, local_rank = dist_setup(torch, world, local_rank)
@@ -624,6 +629,10 @@ def main():
     seed_off = 0 if args.sharded else rank               # sharded: every rank sees the same camera
     procs = max(1, min(32, (len(all_cpus) or os.cpu_count() or 1) // max(world, 1)))
     ts, frames = S.render_frames(first, n_frames, cam=wl["cam"], seed=S.MASTER_SEED + seed_off, img_rate=wl["img_rate"], procs=procs)
+    cpp_leg = rank == 0 and world == 1 and args.config == "A" and not args.sequential and not args.no_adapter_cpp and not args.unaligned
+    n_cpp_timed = 200
+    if cpp_leg:                                           # the C++ adapter binary starts at rest: frames from t = 0 (static start 1.2 s, window fill, 200 timed frames)
+        ts0, frames0 = S.render_frames(0, 30 + n_pre_max + n_cpp_timed, cam=wl["cam"], seed=S.MASTER_SEED, img_rate=wl["img_rate"], procs=procs)
     seq = S.imu_only_sequence(S.MASTER_SEED + seed_off, cam=wl["cam"])
     k_lo = max(int(ts[0] * 200) - 4, 0)
     imu_all = seq.imu_array(k_lo, int(ts[-1] * 200) + 40)
@@ -631,10 +640,10 @@ def main():
     if args.unaligned:
         ts, imu_all = S.unaligned_stamps(ts, imu_all, seed=S.MASTER_SEED + seed_off)
 
-    bind_one_socket(local_rank)
-    # three streams of ours + torch's: keep every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory: ~1 % on these chains of small kernels (same-box A/B)
     import torch
+    # three streams of ours + torch's: every stream on its own hardware queue (HIP's default is 4 queues, shared beyond that), kernel
+    # arguments in device memory, one L3 group: the library's lvk_runtime_env, before the process's first HIP call
+    rt_flags = runtime_env(local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: liblvk_hip.so has no CPU fallback")
     dist, local_rank = dist_setup(torch, world, local_rank)
@@ -699,6 +708,7 @@ def main():
     # rendering): at N > 1 the per-feature work is split over the N ranks with one RCCL all-gather per update, at N = 1 it is the
     # unsharded baseline of the same workload.  This is the strong-scaling curve north_star asks for "when the tracked-feature count
     # justifies it"; the headline value above stays the metric's own configuration.
+    cpp = adapter_cpp(wl, frames0, ts0, seq, n_cpp_timed, period) if cpp_leg else None
     probe = None
     if not args.no_shard_probe and args.config == "A" and not args.sequential:
         probe = shard_probe(rank, world, local_rank)
@@ -763,7 +773,9 @@ def main():
                            "lvk_frontend_process (waits for its message) + lvk_ekf_process_async per frame, pose read right after processFeatures "
                            "(value) or after the next frame's processImage (pose_read_one_frame_late); identical results "
                            "(tests/test_gpu_vio_driver.py::test_deferred_update_is_identical_to_blocking)"},
+               "adapter_cpp": cpp,
                "unaligned_stamps": unal,
+               "runtime_env": {"applied_flags": rt_flags, "source": "lvk_runtime_env (liblvk_hip.so): 1 GPU_MAX_HW_QUEUES=8, 2 HIP_FORCE_DEV_KERNARG=1, 4 one L3 group"},
                "higher_is_better": True, "scaling": ("strong" if args.sharded else "weak"), "vs_baseline": None, "dtype": "u8/f32 front-end, f64 back-end",
                "data": "synthetic",
                "config": {"workload": wl["label"] + ", pyramid 3 levels, win %d, pub %g Hz" % (win, wl["fcfg"]["pub_frequency"]),

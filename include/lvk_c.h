@@ -51,6 +51,20 @@ typedef struct {
     double u, v, u_init, v_init, u_vel, v_vel, u_init_vel, v_init_vel;
 } lvk_feature_obs;
 
+/* ------------------------------------------------------------------ runtime environment
+ * What a deployment should set before the HIP runtime initialises in its process, shipped with the library instead of living in a
+ * launcher script: GPU_MAX_HW_QUEUES=8 (one hardware queue per stream of the library and of the application; HIP's default of 4 makes
+ * streams share queues: -17 % frames/s), HIP_FORCE_DEV_KERNARG=1 (kernel arguments in device memory), and - opt-in - the calling
+ * thread and every thread started after it bound to the physical cores of one L3 group of its socket (local_rank picks the group).
+ * Variables already set by the user are respected.  Call it FIRST in main(), before any HIP call of the process; returns the flags
+ * that took effect.  lvk_context_create applies LVK_RT_DEFAULT by itself (unless LVK_RUNTIME_ENV=0), which suffices when the library
+ * is what makes the process's first HIP call.  No reference counterpart: the reference has no device. */
+#define LVK_RT_HW_QUEUES   1u
+#define LVK_RT_DEV_KERNARG 2u
+#define LVK_RT_BIND_L3     4u
+#define LVK_RT_DEFAULT     (LVK_RT_HW_QUEUES | LVK_RT_DEV_KERNARG)
+unsigned    lvk_runtime_env(unsigned flags, int local_rank);
+
 /* ------------------------------------------------------------------ context / memory */
 lvk_status  lvk_context_create(int device, lvk_context** out);
 void        lvk_context_destroy(lvk_context* ctx);

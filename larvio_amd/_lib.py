@@ -16,7 +16,7 @@ OBS = np.dtype([("id", np.uint64), ("u", np.float64), ("v", np.float64), ("u_ini
 
 # every symbol include/lvk_c.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
-    "lvk_context_create", "lvk_context_destroy", "lvk_context_set_stream", "lvk_context_get_stream", "lvk_sync", "lvk_last_error", "lvk_version",
+    "lvk_runtime_env", "lvk_context_create", "lvk_context_destroy", "lvk_context_set_stream", "lvk_context_get_stream", "lvk_sync", "lvk_last_error", "lvk_version",
     "lvk_malloc", "lvk_free", "lvk_memcpy_h2d", "lvk_memcpy_d2h", "lvk_memset",
     "lvk_clahe_u8", "lvk_pyramid_create", "lvk_pyramid_destroy", "lvk_pyramid_build", "lvk_pyramid_build_clahe",
     "lvk_pyramid_levels", "lvk_pyramid_level", "lvk_orb_prepare", "lvk_min_eigen_map", "lvk_good_features",
@@ -74,6 +74,7 @@ def lib():
         vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
         pi = C.POINTER(C.c_int)
         sig = {
+            "lvk_runtime_env": ([C.c_uint, i], C.c_uint),
             "lvk_context_create": ([i, C.POINTER(vp)], i), "lvk_context_destroy": ([vp], None),
             "lvk_context_set_stream": ([vp, vp], i), "lvk_sync": ([vp], i),
             "lvk_last_error": ([vp], C.c_char_p), "lvk_version": ([], C.c_char_p),

@@ -15,7 +15,6 @@
 #include "be_host_math.h"
 #include "be_qr.h"
 #include "be_init.h"
-#include <immintrin.h>
 #include <vector>
 #include <map>
 #include <stdexcept>
@@ -222,6 +221,7 @@ struct lvk_ekf {
     int static_counter = 0, static_num = 0; double lower_time_bound = 0;
     lvk_status dyn_status = LVK_OK;
     lvk_init::DynInit* dyn = nullptr;                    // the moving-start initialiser (be_init.h); lives until the filter has a state
+    char* d_dyn = nullptr; size_t dyn_cap = 0;           // device scratch of its RANSAC stage (dyn_ransac): grow-only
     std::map<long long, std::pair<double, double>> init_features;
     long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     lvk_status failed = LVK_OK; char failed_msg[256] = {0};   // sticky: set by the first lvk_ekf_process that returned an error
@@ -376,7 +376,7 @@ template <typename T> static T* dev(lvk_ekf* e, T* host) { return (T*)(e->d_up +
 static lvk_status flush_uploads(lvk_ekf* e)
 {   // everything staged in the pinned arena since the last flush goes up in one stream-ordered copy
     if (e->bar_push) {                                                   // the host pushes what it staged into the device-resident arena
-        if (e->up_off > e->up_flushed) { memcpy(e->d_up + e->up_flushed, e->h_up + e->up_flushed, e->up_off - e->up_flushed); _mm_sfence(); e->up_flushed = e->up_off; }
+        if (e->up_off > e->up_flushed) { memcpy(e->d_up + e->up_flushed, e->h_up + e->up_flushed, e->up_off - e->up_flushed); LVK_STORE_FENCE(); e->up_flushed = e->up_off; }
         return LVK_OK;
     }
     if (e->zero_copy) { e->up_flushed = e->up_off; return LVK_OK; }     // kernels read the pinned arena directly
@@ -961,7 +961,7 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
     // (fetch_feature_results does that)
     if (jobs.empty()) return LVK_OK;
     if ((int)jobs.size() > 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
-    size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2;
+    size_t tot = 0, stage = 0, ccols = 0; int max_rows = 2, gate_max = 0;
     size_t m_max = 1; for (auto& j : jobs) { tot += j.sids.size(); m_max = std::max(m_max, j.sids.size()); }
     // short tracks only (always, with max_track_len 6) and one launch for the whole batch: the observations go to fixed-stride slots,
     // so that the row kernel can ask for them without having read the job record first (k_feature_rows: one PCIe round trip less)
@@ -993,8 +993,13 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
         off += M;
         stage += (size_t)2 * M * c * 2 + 2 * M; ccols += c;
         max_rows = std::max(max_rows, 2 * M);
+        if (j.want_gate) gate_max = std::max(gate_max, 2 * M - (j.type == JOB_MSCKF ? 3 : j.type == JOB_EKF_NEW ? 1 : 0));
         hj[i] = d; j.hdev = &hj[i];
     }
+    // the SMALL row kernel's gate holds [S r; r^T 0] in ONE 16x16 MFMA tile (be_feature.hip): at most 15 gated rows.  MSCKF jobs of up
+    // to 8 observations (2M - 3 <= 13) and the one-observation jobs of tracked in-state features are; a batch with anything else
+    // takes the general kernel
+    if (gate_max > 15) max_rows = std::max(max_rows, 18);
     if (stage > e->staging_cap || ccols > e->ccols_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "staging buffer too small (%zu doubles needed)", stage);
     FilterFlags fl; fl.leg_dim = LEG; fl.if_fej = e->if_fej ? 1 : 0; fl.estimate_td = e->cfg.estimate_td; fl.pad = 0; fl.sigma2 = e->sigma2;
     const FeatJob* d_j = dev(e, hj); const int* d_r = dev(e, hr); const double* d_z = dev(e, hz); const double* d_v = dev(e, hv);
@@ -1884,23 +1889,36 @@ static bool static_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, int
 }
 
 // ------------------------------------------------------------------------- dynamic initializer (DynamicInitializer.cpp, be_init.h)
-// cv::findFundamentalMat (mask and matrix) from the library's own kernel (fe_track.hip); a cold path: buffers come and go with the call
+// cv::findFundamentalMat (mask and matrix) from the library's own kernel (fe_track.hip).  Its device buffers live in the filter
+// (grow-only, freed with it): with a full window this runs on every message for up to ten candidate frames, and a hipFree per
+// attempt would synchronise the whole device under the front-end's streams.  A pair list beyond the kernel's capacity (no front-end
+// of this library produces one) is "no relative pose from this frame", not a failure of the handle.
 static bool dyn_ransac(void* user, const std::vector<lvk_init::Pt2>& ll, const std::vector<lvk_init::Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask, double* F)
 {
     lvk_ekf* e = (lvk_ekf*)user;
     const int n = (int)ll.size();
+    mask.assign((size_t)n, 0);
+    if (n > 4096) return false;                                          // FM_MAX_N (fe_track_dev.h)
     std::vector<lvk_pt2f> h((size_t)2 * n);
     for (int i = 0; i < n; ++i) { h[(size_t)i] = lvk_pt2f{(float)ll[(size_t)i].x, (float)ll[(size_t)i].y}; h[(size_t)n + i] = lvk_pt2f{(float)rr[(size_t)i].x, (float)rr[(size_t)i].y}; }
-    lvk_pt2f* d_p = nullptr; uint8_t* d_mask = nullptr; int* d_info = nullptr; double* d_F = nullptr; int info[2] = {0, 0};
-    bool ok = hipMalloc((void**)&d_p, sizeof(lvk_pt2f) * 2 * n) == hipSuccess && hipMalloc((void**)&d_mask, (size_t)n) == hipSuccess && hipMalloc((void**)&d_info, 2 * sizeof(int)) == hipSuccess && hipMalloc((void**)&d_F, 9 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMemcpyAsync(d_p, h.data(), sizeof(lvk_pt2f) * 2 * n, hipMemcpyHostToDevice, e->ctx->stream) == hipSuccess;
-    ok = ok && lvk_find_fundamental(e->ctx, d_p, d_p + n, n, thresh, conf, d_mask, d_info, d_F) == LVK_OK;
-    mask.assign((size_t)n, 0);
-    ok = ok && hipMemcpyAsync(mask.data(), d_mask, (size_t)n, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(info, d_info, sizeof info, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(F, d_F, 9 * sizeof(double), hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
-    ok = ok && hipStreamSynchronize(e->ctx->stream) == hipSuccess;
-    if (d_p) hipFree(d_p); if (d_mask) hipFree(d_mask); if (d_info) hipFree(d_info); if (d_F) hipFree(d_F);
+    const size_t off_mask = sizeof(lvk_pt2f) * 2 * (size_t)n, off_info = (off_mask + (size_t)n + 15) & ~(size_t)15, off_F = off_info + 16, need = off_F + 9 * sizeof(double);
+    bool ok = true;
+    if (need > e->dyn_cap) {
+        if (e->d_dyn) { hipStreamSynchronize(e->ctx->stream); hipFree(e->d_dyn); e->d_dyn = nullptr; e->dyn_cap = 0; }
+        const size_t cap = std::max(need, (size_t)64 * 1024);
+        ok = hipMalloc((void**)&e->d_dyn, cap) == hipSuccess;
+        if (ok) e->dyn_cap = cap; else (void)hipGetLastError();
+    }
+    int info[2] = {0, 0};
+    if (ok) {
+        lvk_pt2f* d_p = (lvk_pt2f*)e->d_dyn; uint8_t* d_mask = (uint8_t*)(e->d_dyn + off_mask); int* d_info = (int*)(e->d_dyn + off_info); double* d_F = (double*)(e->d_dyn + off_F);
+        ok = hipMemcpyAsync(d_p, h.data(), sizeof(lvk_pt2f) * 2 * n, hipMemcpyHostToDevice, e->ctx->stream) == hipSuccess;
+        ok = ok && lvk_find_fundamental(e->ctx, d_p, d_p + n, n, thresh, conf, d_mask, d_info, d_F) == LVK_OK;
+        ok = ok && hipMemcpyAsync(mask.data(), d_mask, (size_t)n, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(info, d_info, sizeof info, hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(F, d_F, 9 * sizeof(double), hipMemcpyDeviceToHost, e->ctx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(e->ctx->stream) == hipSuccess;
+    }
     if (!ok) e->dyn_status = lvk_set_error(e->ctx, LVK_ERR_DEVICE, "dynamic initialiser: RANSAC stage failed on the device");
     return ok && info[0] == 1;
 }
@@ -1957,6 +1975,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
     if (e->h_down) hipHostFree(e->h_down);
     if (e->shard.d_send) hipFree(e->shard.d_send);
     if (e->shard.d_recv) hipFree(e->shard.d_recv);
+    if (e->d_dyn) hipFree(e->d_dyn);
     delete e->dyn;
     delete e;
 }
@@ -2148,7 +2167,10 @@ static lvk_status ekf_process_guarded(lvk_ekf* e, double ts, const lvk_feature_o
     *n_consumed = 0; *updated = 0;
     // An update that failed half way (capacity, device error) leaves clone list, feature map and covariance layout out of step with
     // each other: the handle stays failed and says so, instead of computing on with wrong column offsets.
-    if (e->failed != LVK_OK) return lvk_set_error(e->ctx, e->failed, "lvk_ekf_process: the filter is in a failed state after an earlier error (%s); destroy and re-create it", e->failed_msg);
+    if (e->failed != LVK_OK) {
+        if (e->on_consumed) e->on_consumed(e->on_consumed_user, 0);      // a pipelined driver counts every job's consumption, also the refused ones
+        return lvk_set_error(e->ctx, e->failed, "lvk_ekf_process: the filter is in a failed state after an earlier error (%s); destroy and re-create it", e->failed_msg);
+    }
     const lvk_status st = ekf_process_impl(e, ts, feats, n_feats, imu, n_imu, n_consumed, updated, fetch, fetch_user);
     if (st != LVK_OK) {
         e->failed = st;
@@ -2605,7 +2627,7 @@ lvk_status lvk_vio_pipe_submit(lvk_vio_pipe* p, const lvk_image* img, double ts,
     {
         std::unique_lock<std::mutex> lk(p->mu);
         p->ev(0);
-        pipe_wait(p, lk, p->cv_state, [&] { return p->unknown_consume == 0 && p->in_flight <= p->depth; });
+        pipe_wait(p, lk, p->cv_state, [&] { return p->st != LVK_OK || (p->unknown_consume == 0 && p->in_flight <= p->depth); });     // a failed filter never keeps the caller waiting
         if (p->st != LVK_OK) return p->st;
         head = p->head; end = p->imu.size();
         p->ev(1);

@@ -727,6 +727,7 @@ lvk_status lvk_cov_propagate_augment(lvk_context* ctx, const double* Pin, int ld
         PhiQ22 pq;
         memcpy(pq.phi, h_phi, sizeof pq.phi);
         for (int i = 0; i < 15; ++i) memcpy(pq.q + 15 * i, h_q + (size_t)22 * i, sizeof(double) * 15);
+        if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 3, (k_cov_propagate_augment<22, true>), shmem);     // strips of > ~1400 clone / feature columns
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cov_propagate_augment<22, true>), grid, dim3(256), shmem, ctx->stream, Pin, ldin, Pout, ldout, n_out, pose_rows, (const double*)nullptr, pq);
     } else if (L == 46) {
         if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 9, (k_cov_propagate_augment<46, false>), shmem);

@@ -24,8 +24,142 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
 lvk_status lvk_gftt_prepare(lvk_context* ctx, uint8_t* d_mask, int w, int h, unsigned* d_scratch);
 lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask, bool prepared);
 
+// =========================================================================== runtime environment, BAR self-test
+// plain loads, as the product kernels do them
+__global__ void k_bar_probe(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n, int stride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[(size_t)i * stride];
+}
+static bool bar_selftest(int device)
+{
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) { (void)hipGetLastError(); return false; }
+    int prev = -1; (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const int n = 256, stride = 64;                          // 256 words, one per 256-byte line, over 64 KB
+    unsigned* d = nullptr; unsigned* h = nullptr; unsigned* dh = nullptr; hipStream_t st = nullptr;
+    bool ok = hipExtMallocWithFlags((void**)&d, sizeof(unsigned) * n * stride, hipDeviceMallocFinegrained) == hipSuccess && d;
+    ok = ok && hipHostMalloc((void**)&h, sizeof(unsigned) * n) == hipSuccess && hipHostGetDevicePointer((void**)&dh, h, 0) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    if (ok) {
+        bool writable = false;
+        if (FILE* f = fopen("/proc/self/maps", "r")) {
+            char line[512]; unsigned long lo = 0, hi = 0; char perm[8] = {0};
+            while (fgets(line, sizeof line, f))
+                if (sscanf(line, "%lx-%lx %7s", &lo, &hi, perm) == 3 && (unsigned long)d >= lo && (unsigned long)d < hi) { writable = perm[0] == 'r' && perm[1] == 'w'; break; }
+            fclose(f);
+        }
+        ok = writable;
+    }
+    for (int round = 0; round < 6 && ok; ++round) {           // the same addresses rewritten before every launch, as the filter's arena is every frame
+        volatile unsigned* w = (volatile unsigned*)d;
+        for (int i = 0; i < n; ++i) w[(size_t)i * stride] = 0x9e3779b9u * (unsigned)(round + 1) + (unsigned)i;
+        LVK_STORE_FENCE();
+        memset(h, 0, sizeof(unsigned) * n);
+        hipLaunchKernelGGL(k_bar_probe, dim3(n / 64), dim3(64), 0, st, (const unsigned*)d, dh, n, stride);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        for (int i = 0; i < n && ok; ++i) ok = h[i] == 0x9e3779b9u * (unsigned)(round + 1) + (unsigned)i;
+    }
+    if (st) hipStreamDestroy(st);
+    if (h) hipHostFree(h);
+    if (d) hipFree(d);
+    (void)hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    return ok;
+}
+bool lvk_bar_usable(int device)
+{
+    static std::atomic<int> verdict[64];                     // 0 unknown, 1 usable, 2 not
+    if (device < 0 || device >= 64) return false;
+    int v = verdict[device].load(std::memory_order_acquire);
+    if (v == 0) {
+        const char* sw = getenv("LVK_BAR_PUSH");
+        bool ok = !(sw && !strcmp(sw, "0"));
+        if (ok) ok = bar_selftest(device);
+        else if (getenv("LVK_VERBOSE")) fprintf(stderr, "[lvk] LVK_BAR_PUSH=0: staging through pinned host memory\n");
+        if (!ok && !(sw && !strcmp(sw, "0")) && getenv("LVK_VERBOSE")) fprintf(stderr, "[lvk] device %d: BAR push not usable (no large BAR, no writable mapping, or stale reads in the self-test): pinned host staging\n", device);
+        v = ok ? 1 : 2;
+        verdict[device].store(v, std::memory_order_release);
+    }
+    return v == 1;
+}
+
+// lvk_runtime_env (include/lvk_c.h): what a deployment should set before the HIP runtime initialises, done by the library.
+//  * GPU_MAX_HW_QUEUES=8: the front-end's three streams + the filter's (+ the application's own) each get a hardware queue; with HIP's
+//    default of 4, streams share queues and serialise (measured: 5800 -> 4800 frames/s).
+//  * HIP_FORCE_DEV_KERNARG=1: kernel arguments in device memory (~1 % on these chains of small kernels).
+//  * LVK_RT_BIND_L3 (opt-in: a library should not move its caller's threads unasked): the calling thread - and every thread it
+//    starts afterwards: the HIP runtime's, the filter's worker - onto the physical cores of ONE L3 group of the socket it runs on
+//    (rank r takes the r-th group): the caller's and the filter's thread hand each other messages every ~100 us.
+// Variables the user has set are left alone.  Effective only if called before the process's first HIP call; lvk_context_create
+// calls it with LVK_RT_DEFAULT itself (LVK_RUNTIME_ENV=0 turns that off), which is early enough when the library makes that first call.
+static bool cpulist_parse(const char* path, cpu_set_t* out)
+{
+    CPU_ZERO(out);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    for (char* p = list; *p && *p != '\n';) {
+        char* end = nullptr;
+        long a = strtol(p, &end, 10); if (end == p) break;
+        long b = a; p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, out);
+        if (*p == ',') ++p;
+    }
+    return true;
+}
+static bool bind_l3_group(int local_rank)
+{
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return false;
+    char path[160]; cpu_set_t node; bool have_node = false;
+    for (int nd = 0; nd < 64 && !have_node; ++nd) {
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", nd);
+        if (!cpulist_parse(path, &node)) break;
+        have_node = CPU_ISSET(cpu, &node);
+    }
+    if (!have_node) return false;
+    // one logical CPU per physical core, grouped by L3; groups in ascending order of their first CPU
+    std::vector<std::pair<int, cpu_set_t>> groups;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &node) || !CPU_ISSET(c, &allowed)) continue;
+        cpu_set_t l3, sib;
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+        if (!cpulist_parse(path, &l3)) return false;
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        if (!cpulist_parse(path, &sib)) return false;
+        int first_sib = -1, first_l3 = -1;
+        for (int k = 0; k < CPU_SETSIZE && (first_sib < 0 || first_l3 < 0); ++k) { if (first_sib < 0 && CPU_ISSET(k, &sib)) first_sib = k; if (first_l3 < 0 && CPU_ISSET(k, &l3)) first_l3 = k; }
+        if (c != first_sib) continue;
+        size_t g = 0; while (g < groups.size() && groups[g].first != first_l3) ++g;
+        if (g == groups.size()) { cpu_set_t z; CPU_ZERO(&z); groups.push_back(std::make_pair(first_l3, z)); }
+        CPU_SET(c, &groups[g].second);
+    }
+    std::vector<cpu_set_t> usable;
+    for (auto& g : groups) if (CPU_COUNT(&g.second) >= 4) usable.push_back(g.second);
+    if (usable.empty()) return false;
+    const cpu_set_t& pick = usable[(size_t)(local_rank < 0 ? 0 : local_rank) % usable.size()];
+    return sched_setaffinity(0, sizeof pick, &pick) == 0;
+}
+
 // =========================================================================== context
 extern "C" {
+
+unsigned lvk_runtime_env(unsigned flags, int local_rank)
+{
+    unsigned done = 0;
+    if (flags & LVK_RT_HW_QUEUES) { if (setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0) done |= LVK_RT_HW_QUEUES; }
+    if (flags & LVK_RT_DEV_KERNARG) { if (setenv("HIP_FORCE_DEV_KERNARG", "1", 0) == 0) done |= LVK_RT_DEV_KERNARG; }
+    if (flags & LVK_RT_BIND_L3) { if (bind_l3_group(local_rank)) done |= LVK_RT_BIND_L3; }
+    return done;
+}
 
 const char* lvk_version(void) { return "lvk-hip 0.1 (gfx950)"; }
 
@@ -73,6 +207,14 @@ static void bind_thread_to_device_node(int device)
 lvk_status lvk_context_create(int device, lvk_context** out)
 {
     if (!out) return LVK_ERR_ARG;
+    {   // the library's runtime settings, in case this is the process's first HIP call (see lvk_runtime_env)
+        static std::atomic<bool> once{false};
+        if (!once.exchange(true)) { const char* sw = getenv("LVK_RUNTIME_ENV"); if (!(sw && !strcmp(sw, "0"))) {
+            const char* bd = getenv("LVK_RUNTIME_BIND");               // "l3" or "l3:<local rank>": the opt-in core binding for a driver that cannot call lvk_runtime_env (the reference's own main())
+            const bool l3 = bd && !strncmp(bd, "l3", 2);
+            lvk_runtime_env(LVK_RT_DEFAULT | (l3 ? LVK_RT_BIND_L3 : 0u), l3 && bd[2] == ':' ? atoi(bd + 3) : 0);
+        } }
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LVK_ERR_DEVICE;   // no CPU fallback
     if (hipSetDevice(device) != hipSuccess) return LVK_ERR_DEVICE;
@@ -563,7 +705,6 @@ template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((vo
 
 // host-side phase tracer of the calling thread (LVK_FE_TRACE=1; printed by lvk_frontend_destroy): where the caller's time per frame goes
 #include <chrono>
-#include <immintrin.h>
 enum { FT_SLOT_WAIT, FT_STAGE_COPY, FT_UPLOAD, FT_IMAGE_LAUNCH, FT_PREDICT, FT_TRACK_LAUNCH, FT_COMMIT_LAUNCH, FT_PUBLISH, FT_DETECT, FT_END, FT_N };
 static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: events + 6 launches", "frame checks + predict_homography",
     "track chains: 2 launches + events", "commits: 2 launches + events", "message: slot + launch + event", "detection: 7 launches", "end-of-frame events + rotation"};
@@ -846,7 +987,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         uint8_t* dd = fe->d_ring[slot];
         if (image->stride == c.width) memcpy(dd, image->data, (size_t)c.width * c.height);
         else for (int y = 0; y < c.height; ++y) memcpy(dd + (size_t)y * c.width, image->data + (size_t)y * image->stride, (size_t)c.width);
-        _mm_sfence();
+        LVK_STORE_FENCE();
         FT(FT_STAGE_COPY);
         d_img = dd; d_stride = c.width;
         FT(FT_UPLOAD);

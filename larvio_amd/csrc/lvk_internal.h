@@ -13,13 +13,27 @@
 #define LVK_CPU_RELAX() do { } while (0)
 #endif
 
+// store fence after host writes that a kernel launched next must see (write-combined BAR mappings: sfence on x86)
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+#define LVK_STORE_FENCE() _mm_sfence()
+#else
+#define LVK_STORE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#endif
+
+// May this process push host writes into device memory through the PCIe BAR on `device`?  frontend.hip: LVK_BAR_PUSH=0 says no; a
+// device without a large BAR says no; otherwise a self-test decides, once per device and process - the host writes a pattern into a
+// fine-grained device buffer, a kernel reads it, the host REWRITES the same addresses, a second kernel reads again: a stale second
+// read (L2 lines of the first read surviving the kernel boundary under this driver's MTYPE / partition settings) says no.
+bool lvk_bar_usable(int device);
+
 // Device memory that the HOST writes through the PCIe BAR (the filter's upload arena, the blocking front-end's image buffers): a
 // fine-grained device allocation when the device reports a large BAR AND the process really has a writable mapping of it (checked in
 // /proc/self/maps: a container may hide what the attribute promises); nullptr otherwise - callers then keep their pinned-host path.
 static inline void* lvk_bar_alloc(int device, size_t bytes)
 {
-    int large_bar = 0; void* p = nullptr;
-    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar) { (void)hipGetLastError(); return nullptr; }
+    void* p = nullptr;
+    if (!lvk_bar_usable(device)) return nullptr;
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
     bool writable = false;
     if (FILE* f = fopen("/proc/self/maps", "r")) {
