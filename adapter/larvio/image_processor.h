@@ -33,19 +33,22 @@ public:
   bool processImage(const ImageDataPtr& msg, const std::vector<ImuData>& imu_msg_buffer, MonoCameraMeasurementPtr features);
 
   // Get publish image (image_processor.h:63-65): the last published frame as RGB with the tracked features marked
-  cv::Mat getVisualImg() { return visual_img; }
+  cv::Mat getVisualImg() { if (vis_pending) publishVisual(); return visual_img; }
 
   typedef boost::shared_ptr<ImageProcessor> Ptr;
   typedef boost::shared_ptr<const ImageProcessor> ConstPtr;
 
 private:
-  void publishVisual(const cv::Mat& gray);
+  void publishVisual();          // builds visual_img from the last published frame - when somebody asks for it (getVisualImg)
   std::string config_file;
   lvk_fe_config cfg;
   lvk_context* ctx;
   lvk_frontend* fe;
   std::vector<lvk_feature_obs> out;
   cv::Mat visual_img;
+  cv::Mat vis_src;               // the last published frame's image (shared with the caller's cv::Mat, as a cv::Mat copy is)
+  bool vis_pending = false;      // a frame was published since visual_img was built
+  long frames_seen = 0, vis_frame = 0;
 };
 
 typedef ImageProcessor::Ptr ImageProcessorPtr;

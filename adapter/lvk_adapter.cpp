@@ -51,6 +51,7 @@ bool ImageProcessor::processImage(const ImageDataPtr& msg, const std::vector<Imu
     if (im.empty() || im.channels() != 1) { std::printf("ImageProcessor::processImage: an 8-bit single-channel image is expected\n"); return false; }
     const lvk_image li = {im.data, im.cols, im.rows, (int)im.step, /*is_device=*/0};
     int n = 0, has = 0;
+    ++frames_seen;
     if (lvk_frontend_process(fe, &li, msg->timeStampToSec, imu, (int)imu_msg_buffer.size(), out.data(), (int)out.size(), &n, &has) != LVK_OK) {
         std::printf("ImageProcessor::processImage: %s\n", lvk_last_error(ctx));
         return false;
@@ -60,14 +61,19 @@ bool ImageProcessor::processImage(const ImageDataPtr& msg, const std::vector<Imu
     features->features.resize((size_t)n);
     static_assert(sizeof(MonoFeatureMeasurement) == sizeof(lvk_feature_obs), "MonoFeatureMeasurement is the 72-byte wire record");
     if (n) std::memcpy(static_cast<void*>(features->features.data()), out.data(), sizeof(lvk_feature_obs) * (size_t)n);
-    publishVisual(im);                                                // publish() (:1131-1175) runs on publish frames only
+    // publish() (:1131-1175) draws the frame on every publish; here the picture is built when somebody asks for it (getVisualImg):
+    // a whole-image colour conversion and a read-back of the track table do not belong on the path to the filter
+    vis_src = im; vis_frame = frames_seen; vis_pending = true;
     return true;
 }
 
 // publish() draws on a COLOR_GRAY2RGB copy of the current image (image_processor.cpp:1136-1168); without cv::circle in reach the
 // tracked features are marked as 5x5 squares shaded by lifetime (blue = young, red = old, as the reference's colour ramp :1160-1161)
-void ImageProcessor::publishVisual(const cv::Mat& gray)
+void ImageProcessor::publishVisual()
 {
+    vis_pending = false;
+    const cv::Mat& gray = vis_src;
+    if (gray.empty()) return;
     cv::Mat rgb(gray.rows, gray.cols, CV_8UC3);
     for (int y = 0; y < gray.rows; ++y) {
         const unsigned char* s = gray.ptr(y); unsigned char* d = rgb.ptr(y);
@@ -75,7 +81,9 @@ void ImageProcessor::publishVisual(const cv::Mat& gray)
     }
     const int cap = cfg.max_features_num;
     std::vector<lvk_pt2f> pts((size_t)cap); std::vector<int> life((size_t)cap); int n = 0;
-    if (lvk_frontend_tracks(fe, nullptr, pts.data(), life.data(), nullptr, nullptr, cap, &n) == LVK_OK) {
+    // the track table is the front-end's CURRENT one: the published frame's as long as no later frame has been processed (the drivers ask
+    // right after processImage / processFeatures: app/larvioMain.cpp:139-170, the nodelet's callback); otherwise the picture stays unmarked
+    if (frames_seen == vis_frame && lvk_frontend_tracks(fe, nullptr, pts.data(), life.data(), nullptr, nullptr, cap, &n) == LVK_OK) {
         for (int i = 0; i < n; ++i) {
             const double len = life[i] >= 50 ? 1.0 : life[i] / 50.0;
             const unsigned char r = (unsigned char)(255 * (1 - len)), b = (unsigned char)(255 * len);

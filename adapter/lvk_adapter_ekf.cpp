@@ -138,8 +138,8 @@ Eigen::Vector3d LarVio::getVel()
 Eigen::Matrix<double, 6, 6> LarVio::getPpose()
 {
     finish();   // P_imu_pose << P_pp, P_po, P_op, P_oo  (position block first), larvio.cpp:2673-2679
-    const int N = lvk_ekf_dim(ekf);
-    std::vector<double> P((size_t)N * N); lvk_ekf_get_cov(ekf, P.data());
+    const int N = 9;
+    double P[81]; if (lvk_ekf_get_cov_imu(ekf, N, P) != LVK_OK) std::memset(P, 0, sizeof P);
     static const int idx[6] = {6, 7, 8, 0, 1, 2};
     Eigen::Matrix<double, 6, 6> out;
     for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out(a, b) = P[(size_t)idx[a] * N + idx[b]];
@@ -149,8 +149,8 @@ Eigen::Matrix<double, 6, 6> LarVio::getPpose()
 Eigen::Matrix3d LarVio::getPvel()
 {
     finish();
-    const int N = lvk_ekf_dim(ekf);
-    std::vector<double> P((size_t)N * N); lvk_ekf_get_cov(ekf, P.data());
+    const int N = 9;
+    double P[81]; if (lvk_ekf_get_cov_imu(ekf, N, P) != LVK_OK) std::memset(P, 0, sizeof P);
     Eigen::Matrix3d out;
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) out(a, b) = P[(size_t)(3 + a) * N + 3 + b];
     return out;

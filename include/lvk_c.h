@@ -280,11 +280,29 @@ lvk_status lvk_ekf_get_state(const lvk_ekf* e, double* h_out30);
 lvk_status lvk_ekf_get_imu_intrinsics(const lvk_ekf* e, double* h_out24);
 lvk_status lvk_ekf_set_imu_intrinsics(lvk_ekf* e, const double* h_in24);
 lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P);           /* N*N row-major, synchronises (getPpose/getPvel read blocks of it) */
+/* the leading n x n block of the covariance (n <= 16: orientation 0..2, velocity 3..5, position 6..8, gyro bias 9..11, ...), row-major -
+ * all that getPpose / getPvel read (larvio.cpp:2673-2690); served from a host-side mirror the update keeps, no transfer of the matrix */
+lvk_status lvk_ekf_get_cov_imu(lvk_ekf* e, int n, double* h_out);
 int        lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* h_out, int cap);       /* getSwPoses */
 int        lvk_ekf_get_features(const lvk_ekf* e, int64_t* h_ids, double* h_inv_depth, double* h_pos_w, int cap);  /* getActiveeMapPointPositions */
 /* getStableMapPointPositions (larvio.cpp:2717-2722): in-state features that were lost since the last call, with their last world
  * position; the entries handed out are removed, as the reference clears lost_slam_features on read.  Returns the count (<= cap). */
 int        lvk_ekf_take_lost_features(lvk_ekf* e, int64_t* h_ids, double* h_pos_w, int cap);
+/* What the moving-start initialiser (FlexibleInitializer.cpp:11-25 -> DynamicInitializer.cpp) handed to the filter, with the intermediate
+ * results of the successful attempt - for parity tests against an independent restatement fed the same messages:
+ *   valid        1 once the dynamic initialiser has succeeded on this handle (0: never ran, or the static one fired)
+ *   message      0-based index of the lvk_ekf_process call (counted from the first one the initialisers saw) that succeeded
+ *   attempts     relative-pose attempts made up to and including the successful one (= calls of the RANSAC stage's window scan that found a frame)
+ *   ransac_calls launches of the RANSAC kernel (cv::findFundamentalMat, solve_5pts.cpp:206) over all attempts
+ *   l, rel_R/rel_T   relativePose's frame and pose (DynamicInitializer.cpp:331-360), n_points = landmarks the SfM triangulated (initial_sfm.cpp)
+ *   sfm_R/sfm_T  the window's 11 structure-from-motion poses (camera-to-c0 rotation row-major, position)
+ *   bg, g, scale solveGyroscopeBias / LinearAlignment + RefineGravity (initial_alignment.cpp:74-122 ...)
+ *   state_time, q (x y z w), v, erase     the state the filter starts from and the IMU samples erased */
+typedef struct lvk_init_report {
+    int valid, message, attempts, ransac_calls, l, n_points, erase, pad;
+    double state_time, scale, rel_R[9], rel_T[3], sfm_R[11 * 9], sfm_T[11 * 3], bg[3], g[3], q[4], v[3];
+} lvk_init_report;
+lvk_status lvk_ekf_init_report(const lvk_ekf* e, lvk_init_report* h_out);
 /* [0] hybrid updates [1] msckf updates [2] rows of the last update [3] zupt updates [4] gated in [5] gated out [6] map size [7] triangulations */
 void       lvk_ekf_counters(const lvk_ekf* e, long* h_out8);
 /* HIP-event bracket around the H P GEMM (the P H^T contraction, FP64 MFMA) of every update: enable/disable; h_out3 (optional) receives

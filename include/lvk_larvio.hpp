@@ -133,13 +133,13 @@ public:
     // getPpose / getPvel (:2663-2700): covariance blocks of (theta, p) and v
     void getPpose(double P66[36]) const
     {
-        const int N = lvk_ekf_dim(ekf_); std::vector<double> P((size_t)N * N); lvk_ekf_get_cov(ekf_, P.data());
+        const int N = 9; double P[81]; if (lvk_ekf_get_cov_imu(ekf_, N, P) != LVK_OK) std::memset(P, 0, sizeof P);
         static const int idx[6] = {0, 1, 2, 6, 7, 8};
         for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) P66[6 * a + b] = P[(size_t)idx[a] * N + idx[b]];
     }
     void getPvel(double P33[9]) const
     {
-        const int N = lvk_ekf_dim(ekf_); std::vector<double> P((size_t)N * N); lvk_ekf_get_cov(ekf_, P.data());
+        const int N = 9; double P[81]; if (lvk_ekf_get_cov_imu(ekf_, N, P) != LVK_OK) std::memset(P, 0, sizeof P);
         for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) P33[3 * a + b] = P[(size_t)(3 + a) * N + 3 + b];
     }
     void getSwPoses(std::vector<lvk_clone>& out) const { out.resize(64); out.resize((size_t)lvk_ekf_get_clones(ekf_, out.data(), 64)); }     // :2703-2717

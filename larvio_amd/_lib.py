@@ -26,8 +26,8 @@ ABI_SYMBOLS = [
     "lvk_frontend_state", "lvk_frontend_lk_stats", "lvk_frontend_msg_stats", "lvk_frontend_profile_enable", "lvk_frontend_profile_read",
     "lvk_frontend_stage_name",
     "lvk_ekf_compress_qr", "lvk_ekf_compress_qr_groups", "lvk_ekf_qr_plan", "lvk_ekf_update", "lvk_dgemm", "lvk_ekf_create", "lvk_ekf_destroy", "lvk_ekf_process", "lvk_ekf_process_async", "lvk_ekf_wait", "lvk_ekf_set_state",
-    "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_take_off_stamp", "lvk_ekf_get_state", "lvk_ekf_get_imu_intrinsics", "lvk_ekf_set_imu_intrinsics", "lvk_ekf_get_cov", "lvk_ekf_get_clones", "lvk_ekf_get_features", "lvk_ekf_take_lost_features",
-    "lvk_ekf_counters", "lvk_ekf_profile", "lvk_ekf_profile_qr", "lvk_ekf_set_shard", "lvk_ekf_shard_stats", "lvk_shard_unique_id", "lvk_shard_comm_create", "lvk_shard_comm_destroy", "lvk_shard_comm_error", "lvk_shard_rccl_path", "lvk_shard_allgather_rccl", "lvk_triangulate", "lvk_ekf_gate_and_stack", "lvk_vio_process", "lvk_vio_process_deferred", "lvk_vio_pipe_create", "lvk_vio_pipe_destroy", "lvk_vio_pipe_push_imu", "lvk_vio_pipe_submit", "lvk_vio_pipe_drain", "lvk_vio_pipe_on_update", "lvk_vio_pipe_stats", "lvk_vio_pipe_latency", "lvk_vio_pipe_early_counts",
+    "lvk_ekf_dim", "lvk_ekf_is_initialized", "lvk_ekf_take_off_stamp", "lvk_ekf_get_state", "lvk_ekf_get_imu_intrinsics", "lvk_ekf_set_imu_intrinsics", "lvk_ekf_get_cov", "lvk_ekf_get_cov_imu", "lvk_ekf_get_clones", "lvk_ekf_get_features", "lvk_ekf_take_lost_features",
+    "lvk_ekf_counters", "lvk_ekf_init_report", "lvk_ekf_profile", "lvk_ekf_profile_qr", "lvk_ekf_set_shard", "lvk_ekf_shard_stats", "lvk_shard_unique_id", "lvk_shard_comm_create", "lvk_shard_comm_destroy", "lvk_shard_comm_error", "lvk_shard_rccl_path", "lvk_shard_allgather_rccl", "lvk_triangulate", "lvk_ekf_gate_and_stack", "lvk_vio_process", "lvk_vio_process_deferred", "lvk_vio_pipe_create", "lvk_vio_pipe_destroy", "lvk_vio_pipe_push_imu", "lvk_vio_pipe_submit", "lvk_vio_pipe_drain", "lvk_vio_pipe_on_update", "lvk_vio_pipe_stats", "lvk_vio_pipe_latency", "lvk_vio_pipe_early_counts",
 ]
 FE_STAGES = 9
 

@@ -35,7 +35,7 @@
 #define LEG_MAX 46
 #define GRAV 9.81
 
-struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; double* dx_host = nullptr; };   // ev_*: optional bracket around the H P GEMM; dx_host: host-mapped mirror of dx
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; double* dx_host = nullptr; double* p00_host = nullptr; };   // ev_*: optional bracket around the H P GEMM; dx_host: host-mapped mirror of dx; p00_host: of the updated P's leading 16 x 16 block
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2, double* dx, UpdateWs ws);
 lvk_status lvk_cov_gather(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, const int* d_idx, int n);
 lvk_status lvk_cov_propagate_augment(lvk_context* ctx, const double* Pin, int ldin, double* Pout, int ldout, int n_out, int pose_rows, int L,
@@ -44,10 +44,10 @@ lvk_status lvk_cov_reanchor(lvk_context* ctx, double* P, int ld, int n, const do
 lvk_status lvk_stage_copy2(lvk_context* ctx, void* d_dst0, const void* d_src0, size_t bytes0, void* d_dst1, const void* d_src1, size_t bytes1);
 lvk_status lvk_cov_append_features(lvk_context* ctx, double* P, int ld, int n, int nn, const double* H1, int ldh, const double* H2, const double* r1,
                                    const double* dx, double sigma2, double* tmp, double* dx_new);
-lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out);
+lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z, TriResult* d_out, TriResult* d_out_dev);
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging, int* d_ccols, FeatResult* d_out, FeatResult* d_out_host,
-                                   double* d_Hout, int ldh, int ncols_out, double* d_rout, int obs_stride, int n_clones);
+                                   double* d_Hout, int ldh, int ncols_out, double* d_rout, int obs_stride, int n_clones, const TriResult* d_tri);
 lvk_status lvk_launch_stack_rows(lvk_context* ctx, const FeatResult* d_fout, const StackRow* d_map, int n_rows, const double* d_staging, const int* d_ccols, double* d_H, int ldh, int ncols, double* d_r);
 lvk_status lvk_qr_compress_dev(lvk_context* ctx, double* d_H, int ldh, int rows, int cols, double* d_r, int* rows_out);
 
@@ -222,6 +222,8 @@ struct lvk_ekf {
     lvk_status dyn_status = LVK_OK;
     lvk_init::DynInit* dyn = nullptr;                    // the moving-start initialiser (be_init.h); lives until the filter has a state
     char* d_dyn = nullptr; size_t dyn_cap = 0;           // device scratch of its RANSAC stage (dyn_ransac): grow-only
+    lvk_init_report init_report = {};                    // what it handed over (lvk_ekf_init_report); valid = 0 until it has
+    int init_calls = 0, init_ransac_calls = 0;
     std::map<long long, std::pair<double, double>> init_features;
     long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     lvk_status failed = LVK_OK; char failed_msg[256] = {0};   // sticky: set by the first lvk_ekf_process that returned an error
@@ -232,6 +234,7 @@ struct lvk_ekf {
     double* dP[2] = {nullptr, nullptr}; int cur = 0;
     int* d_idx = nullptr; double *d_phiq = nullptr, *d_J = nullptr, *d_dx = nullptr, *d_tmp = nullptr;
     TriJob* d_tri = nullptr; TriResult* d_triout = nullptr; FeatJob* d_fj = nullptr; FeatResult* d_fout = nullptr;
+    TriResult* d_tridev = nullptr;                      // device copy of the triangulation results, indexed by the row job that consumes them (FJ_TRI_PENDING)
     int* d_rank = nullptr; double *d_z = nullptr, *d_zv = nullptr; CamPose* d_cams = nullptr; CloneDev* d_clones = nullptr;
     double* d_staging = nullptr; size_t staging_cap = 0; int* d_ccols = nullptr; size_t ccols_cap = 0; StackRow* d_map = nullptr;
     double *d_H = nullptr, *d_r = nullptr, *d_H1 = nullptr, *d_H2 = nullptr, *d_r1 = nullptr;
@@ -250,9 +253,12 @@ struct lvk_ekf {
                    long stats[4] = {0, 0, 0, 0}; } shard;     // stats: [0] exchanges [1] bytes sent per rank (sum) [2] sharded updates [3] rows this rank stacked
     size_t down_flag = 0;                               // offset in h_down of the word k_shard_unpack raises when a peer's block arrives poisoned
     size_t down_info = 0;                               // offset in h_down of the factorisation's report words (update_health)
+    size_t down_p00 = 0; bool p00_valid = false;        // offset in h_down of the mirror of P[0:16, 0:16] (q v p bg ba[0]) the last update's final GEMM wrote; valid: nothing has touched that block since
     UpdateWs ws;
     // pinned host arenas
     char* h_up = nullptr; size_t up_cap = 0, up_off = 0, up_flushed = 0;
+    size_t up_lim = 0; int up_half = 0;                 // the arena is used in halves, alternating per call: kernels queued behind a call's last sync may still read its half while the next call stages into the other
+    int n_sync = 0;                                     // stream syncs of the current call (a call without any ends with one: see ekf_process_impl)
     char* d_up = nullptr;                               // device mirror of the upload arena: ONE H2D copy per sync point
     bool zero_copy = false;                             // d_up aliases the pinned arena (device-mapped host memory): no H2D copies at all
     bool bar_push = false;                              // d_up is DEVICE memory that this thread writes through the PCIe BAR (flush_uploads): see lvk_ekf_create
@@ -368,7 +374,7 @@ static void clone_refresh_cam(const lvk_ekf* e, Clone* c)
 template <typename T> static T* up_alloc(lvk_ekf* e, size_t n)
 {   // bump allocation in the pinned upload arena (reset once per frame; copies are stream-ordered)
     size_t bytes = (sizeof(T) * n + 63) & ~(size_t)63;
-    if (e->up_off + bytes > e->up_cap) return nullptr;
+    if (e->up_off + bytes > e->up_lim) return nullptr;
     T* p = (T*)(e->h_up + e->up_off); e->up_off += bytes; return p;
 }
 #define EKF_HIP(call) LVK_HIP(e->ctx, call)
@@ -418,7 +424,7 @@ static lvk_status update_health(lvk_ekf* e)
 static lvk_status d2h_sync(lvk_ekf* e, void* dst, const void* src, size_t bytes)
 {
     if (bytes) EKF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->ctx->stream));
-    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream)); e->n_sync++;
     if (e->shard.fn) { int* f = (int*)(e->h_down + e->down_flag); if (*f) { const int mask = *f; *f = 0; return lvk_set_error(e->ctx, LVK_ERR_DEVICE, "sharded update: the block of a peer rank (mask 0x%x) arrived invalid - that rank failed before the exchange", mask); } }
     return update_health(e);
 }
@@ -759,6 +765,7 @@ static lvk_status state_augmentation(lvk_ekf* e)
     for (int i = 0; i < pose_rows; ++i) idx.push_back(i);
     for (int i = 0; i < 6; ++i) idx.push_back(sel[i]);
     for (int i = pose_rows; i < e->N; ++i) idx.push_back(i);
+    e->p00_valid = false;                                // the IMU block is about to be propagated
     if (!e->have_prop) return cov_gather(e, idx);
     // the frame's propagation (composed Phi, Q) rides in the same launch: k_cov_propagate_augment (the index map is analytic there)
     const int n_out = (int)idx.size(), L = LEG;
@@ -856,7 +863,7 @@ static void inject(lvk_ekf* e, const double* dx)
 // ------------------------------------------------------------------------- device job batches
 // one triangulation request: its views live in the filter's request pools (tri_ranks / tri_z) at [off, off + n) - no per-request
 // vectors (at configs[4] an update issues hundreds of requests)
-struct TriReq { Feature* f; int mode; int off, n; long long last_id; bool use_pos; };
+struct TriReq { Feature* f; int mode; int off, n; long long last_id; bool use_pos; int slot = -1; };   // slot >= 0: the row job that takes the result on the device (launch_triangulation)
 struct TriAns { bool ok; double position[3], inv_depth, obs_anchor[3]; long long id_anchor; };
 
 static lvk_status upload_clones(lvk_ekf* e)
@@ -908,33 +915,42 @@ static void apply_tri(Feature* f, int mode, const TriAns& a)
     f->inv_depth = a.inv_depth; memcpy(f->obs_anchor, a.obs_anchor, 24);
     if (mode == 2) f->ekf_feature = true;
 }
-static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::vector<TriAns>& ans)
+// queues the batch; results go to the device-mapped host mirror (d_triout) and to d_tridev, at the request's slot when it names one
+static lvk_status launch_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs)
 {
-    ans.assign(reqs.size(), TriAns());
     if (reqs.empty()) return LVK_OK;
     size_t tot = 0; for (auto& r : reqs) tot += (size_t)r.n;
     if ((int)reqs.size() > e->feat_cap || (int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "triangulation batch exceeds capacity");
+    for (auto& r : reqs) if (r.slot >= 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
     TriJob* hj = up_alloc<TriJob>(e, reqs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot);
     if (!hj || !hr || !hz) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
     size_t off = 0;
     for (size_t i = 0; i < reqs.size(); ++i) {
         TriReq& r = reqs[i];
-        hj[i].n = r.n; hj[i].use_position = r.use_pos ? 1 : 0; hj[i].obs_off = (int)off; hj[i].pad = 0;
+        hj[i].n = r.n; hj[i].use_position = r.use_pos ? 1 : 0; hj[i].obs_off = (int)off; hj[i].out_slot1 = r.slot >= 0 ? r.slot + 1 : 0;
         memcpy(hj[i].position_in, r.f->position, 24);
         memcpy(hr + off, e->tri_ranks.data() + r.off, sizeof(int) * (size_t)r.n); memcpy(hz + 2 * off, e->tri_z.data() + 2 * (size_t)r.off, sizeof(double) * 2 * (size_t)r.n);
         off += (size_t)r.n;
     }
     lvk_status st = flush_uploads(e);
-    if (st == LVK_OK) st = lvk_launch_triangulate(e->ctx, dev(e, hj), (int)reqs.size(), e->dv_cams, dev(e, hr), dev(e, hz), e->d_triout);
+    if (st == LVK_OK) st = lvk_launch_triangulate(e->ctx, dev(e, hj), (int)reqs.size(), e->dv_cams, dev(e, hr), dev(e, hz), e->d_triout, e->d_tridev);
+    if (st == LVK_OK) e->counters[7] += (long)reqs.size();
+    return st;
+}
+static TriAns tri_answer(const lvk_ekf* e, const TriReq& rq, size_t slot)
+{   // after a stream sync that covers the batch: d_triout IS the mapped view of h_down
+    const TriResult& o = ((const TriResult*)e->h_down)[slot];
+    TriAns a; a.ok = o.ok != 0; memcpy(a.position, o.position, 24); a.inv_depth = o.inv_depth; memcpy(a.obs_anchor, o.obs_anchor, 24); a.id_anchor = rq.last_id;
+    return a;
+}
+static lvk_status run_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs, std::vector<TriAns>& ans)
+{
+    ans.assign(reqs.size(), TriAns());
+    if (reqs.empty()) return LVK_OK;
+    lvk_status st = launch_triangulation(e, reqs);
     if (st != LVK_OK) return st;
-    TriResult* ho = (TriResult*)e->h_down;                       // d_triout IS the mapped view of h_down
-    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
-    if (st != LVK_OK) return st;
-    for (size_t i = 0; i < reqs.size(); ++i) {
-        ans[i].ok = ho[i].ok != 0; memcpy(ans[i].position, ho[i].position, 24); ans[i].inv_depth = ho[i].inv_depth; memcpy(ans[i].obs_anchor, ho[i].obs_anchor, 24);
-        ans[i].id_anchor = reqs[i].last_id;
-    }
-    e->counters[7] += (long)reqs.size();
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream)); e->n_sync++;
+    for (size_t i = 0; i < reqs.size(); ++i) ans[i] = tri_answer(e, reqs[i], reqs[i].slot >= 0 ? (size_t)reqs[i].slot : i);
     return LVK_OK;
 }
 static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracked)
@@ -953,7 +969,7 @@ static bool feat_check_motion(const lvk_ekf* e, const Feature& f, bool if_tracke
 }
 
 // One feature-rows job (rows on the device) ------------------------------------------------------------
-struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; FeatJob* hdev = nullptr; };   // hdev: the job's record in the upload arena (patched until the launch is flushed)
+struct RowJob { Feature* f; int type; std::vector<long long> sids; bool want_gate; int dof; FeatJob dev; FeatResult res; FeatJob* hdev = nullptr; bool tri_pending = false; };   // hdev: the job's record in the upload arena (patched until the launch is flushed)
 
 typedef std::vector<std::pair<size_t, size_t>> JobRanges;
 static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, const JobRanges* ranges = nullptr)
@@ -970,14 +986,15 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
     if ((int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "observation batch exceeds capacity");
     FeatJob* hj = up_alloc<FeatJob>(e, jobs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot); double* hv = up_alloc<double>(e, 2 * tot);
     if (!hj || !hr || !hz || !hv) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
-    size_t off = 0;
+    size_t off = 0; bool any_pending = false;
     for (size_t i = 0; i < jobs.size(); ++i) {
         RowJob& j = jobs[i]; Feature* f = j.f;
         const int M = (int)j.sids.size();
         const int c = (j.type == JOB_MSCKF) ? 7 + 6 * M : 7 + 6 + 6 * M + 1;
         FeatJob& d = j.dev; memset(&d, 0, sizeof d);
         if (obs_stride) off = i * (size_t)obs_stride;
-        d.type = j.type; d.n_obs = M; d.obs_off = (int)off; d.want_gate = j.want_gate ? 1 : 0;
+        d.type = j.type; d.n_obs = M; d.obs_off = (int)off; d.want_gate = (j.want_gate ? FJ_GATE : 0) | (j.tri_pending ? FJ_TRI_PENDING : 0);
+        any_pending = any_pending || j.tri_pending;
         d.anchor_rank = (j.type == JOB_MSCKF) ? 0 : clone_rank(e, f->id_anchor);
         d.fcol = (j.type == JOB_MSCKF) ? 0 : LEG + 6 * (int)e->clones.size() + fs_rank(e, f->id);
         d.stage_off = (long long)stage; d.ccol_off = (int)ccols;
@@ -1007,11 +1024,13 @@ static lvk_status launch_feature_rows(lvk_ekf* e, std::vector<RowJob>& jobs, con
     FeatResult* d_fh = (FeatResult*)(e->dh_down + e->down_feat);
     double* Ho = e->d_H; double* ro = e->d_r; const int ldh = e->ld, ncols_out = e->N;       // direct output of the jobs that carry a destination row (set_direct_rows)
     const int n_cl = (int)e->clones.size();
-    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh, Ho, ldh, ncols_out, ro, obs_stride, n_cl); });
+    const TriResult* d_tri = any_pending ? e->d_tridev : nullptr;      // results of the triangulation queued ahead, by job index (whole-batch launches only)
+    if (any_pending && ranges) return lvk_set_error(e->ctx, LVK_ERR_ARG, "internal: device-consumed triangulation in a ranged launch");
+    if (!ranges) return run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j, nj, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout, d_fh, Ho, ldh, ncols_out, ro, obs_stride, n_cl, d_tri); });
     for (const auto& rg : *ranges) {                    // jobs carry absolute offsets into the observation / staging / column arrays
         const size_t lo = rg.first; const int n = (int)(rg.second - rg.first);
         if (n <= 0) continue;
-        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo, nullptr, 0, 0, nullptr, 0, n_cl); });
+        lvk_status st = run_or_defer(e, [=]() { return lvk_launch_feature_rows(e->ctx, d_j + lo, n, max_rows, d_cl, d_r, d_z, d_v, P, e->ld, fl, e->d_staging, e->d_ccols, e->d_fout + lo, d_fh + lo, nullptr, 0, 0, nullptr, 0, n_cl, nullptr); });
         if (st != LVK_OK) return st;
     }
     return LVK_OK;
@@ -1021,7 +1040,7 @@ static lvk_status shard_peer_check(lvk_ekf* e);
 static lvk_status fetch_feature_results(lvk_ekf* e, std::vector<RowJob>& jobs, double* dx = nullptr, size_t n_dx = 0)
 {
     const FeatResult* ho = (const FeatResult*)(e->h_down + e->down_feat);
-    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream)); e->n_sync++;
     { lvk_status ps = shard_peer_check(e); if (ps != LVK_OK) return ps; }
     { lvk_status hs = update_health(e); if (hs != LVK_OK) return hs; }
     for (size_t i = 0; i < jobs.size(); ++i) jobs[i].res = ho[i];
@@ -1180,7 +1199,7 @@ static lvk_status shard_stage1(lvk_ekf* e, const std::vector<StackRow>& map, std
     for (int g = 0; g < W; ++g) {
         if (m_of[(size_t)g] > e->hrows) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: rank %d would stack %d measurement rows (capacity %d)", g, m_of[(size_t)g], e->hrows);
         if (kk[(size_t)g] > S.xk_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: rank %d's compressed block has %d rows (exchange capacity %d)", g, kk[(size_t)g], S.xk_cap);
-        if (e->up_off + need[(size_t)g] + sizeof(ShardMeta) * (size_t)W + 256 > e->up_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: upload arena too small for rank %d's plan", g);
+        if (e->up_off + need[(size_t)g] + sizeof(ShardMeta) * (size_t)W + 256 > e->up_lim) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "sharded update: upload arena too small for rank %d's plan", g);
         k_max = std::max(k_max, kk[(size_t)g]); m_tot += kk[(size_t)g];
         if (job_b) j_max = std::max(j_max, (int)((*job_b)[(size_t)g + 1] - (*job_b)[(size_t)g]));
     }
@@ -1296,6 +1315,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     TRS(3);
     UpdateWs ws = e->ws;
     ws.dx_host = (double*)(e->dh_down + e->down_dx);
+    ws.p00_host = (double*)(e->dh_down + e->down_p00);
     if (e->prof_on && m > 0) {
         auto take = [&]() { hipEvent_t ev; if (!e->prof_free.empty()) { ev = e->prof_free.back(); e->prof_free.pop_back(); } else hipEventCreate(&ev); return ev; };
         ws.ev_a = take(); ws.ev_b = take();
@@ -1303,6 +1323,7 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
     }
     st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, H, e->ld, m, r, e->sigma2, e->d_dx, ws);
     if (st != LVK_OK) return st;
+    e->p00_valid = m > 0;
     TRS(4);
     dx.assign((size_t)e->N + extra, 0.0);
     e->counters[2] = m;
@@ -1315,15 +1336,99 @@ static int grid_code(const lvk_ekf* e, const double* xy)
     int row = (int)((xy[1] - e->y_min) / e->grid_h), col = (int)((xy[0] - e->x_min) / e->grid_w);
     return row * e->cfg.aug_grid_cols + col;
 }
+// removeLostFeatures when no feature can enter the state in this update (the usual message: the augmentation grid is full, or no
+// track has reached max_track_len in a free cell) and the update is not sharded: NOTHING on the host depends on a device result
+// before the update is launched.  The triangulations of the features that need one are queued and consumed ON THE DEVICE by the row
+// kernel (FJ_TRI_PENDING: a failed triangulation = a rejected job = zero rows, which leave the update unchanged), every candidate
+// row has its slot, and triangulation results, gate results and dx come back in ONE sync.  Same decisions, same rows, same update
+// as the general path below (larvio.cpp:1897-2005): only the order in which the host learns them differs.
+static lvk_status remove_lost_fast(lvk_ekf* e, const std::vector<long long>& ekf_ids)
+{
+    const lvk_ekf_config& c = e->cfg;
+    struct Pick { Feature* f; bool lost; int tri; };
+    std::vector<Pick> picks; std::vector<long long> invalid; std::vector<TriReq> reqs;
+    e->tri_ranks.clear(); e->tri_z.clear();
+    const int n_ekf = (int)ekf_ids.size();
+    for (auto kv : e->map) {
+        Feature& f = kv.second;
+        if (f.in_state) continue;
+        const bool tracked = f.find(e->imu_id) >= 0;
+        if (!tracked) { if ((int)f.obs.size() < c.least_observation_number) { invalid.push_back(f.id); continue; } }
+        else if (!((int)f.obs.size() >= c.max_track_len)) continue;
+        int tri = -1;
+        if (!f.is_initialized) {
+            if (!feat_check_motion(e, f, tracked)) { if (!tracked) invalid.push_back(f.id); continue; }
+            reqs.emplace_back(); make_tri_req(e, &f, 0, &reqs.back()); tri = (int)reqs.size() - 1;
+            reqs.back().slot = n_ekf + (int)picks.size();
+        }
+        picks.push_back({&f, !tracked, tri});
+    }
+    for (long long id : invalid) e->map.erase(id);
+    if (picks.empty() && ekf_ids.empty()) return LVK_OK;
+    const int N = e->N;
+    std::vector<RowJob> jobs; jobs.reserve(ekf_ids.size() + picks.size());
+    for (long long id : ekf_ids) { Feature& f = e->map[id]; RowJob r; r.f = &f; r.type = JOB_EKF_TRACKED; r.sids = {e->imu_id}; r.want_gate = true; r.dof = 2; jobs.push_back(r); }
+    for (const Pick& pk : picks) {
+        RowJob r; r.f = pk.f; r.type = JOB_MSCKF; r.want_gate = true; r.dof = 2 * (int)pk.f->obs.size() - 3; r.tri_pending = pk.tri >= 0;
+        r.sids.reserve(pk.f->obs.size()); for (auto& o : pk.f->obs) r.sids.push_back(o.sid);
+        jobs.push_back(r);
+    }
+    TR(TR_RLF_PRE);
+    lvk_status st = launch_triangulation(e, reqs);
+    if (st != LVK_OK) return st;
+    TR(TR_RLF_TRI);
+    TR(TR_RLF_TRIAGE);
+    begin_defer(e);                                     // the jobs go up in one copy; the row kernel writes its rows straight into H_o
+    st = launch_feature_rows(e, jobs);
+    TRS(0);
+    if (st != LVK_OK) { end_defer(e); return st; }
+    std::vector<StackRow> map_o; std::vector<RowGroup> grp;
+    int rows_m = 0, rows_e = 0;
+    for (size_t k = (size_t)n_ekf; k < jobs.size(); ++k) { const int r = job_rows(jobs[k]); push_rows(map_o, jobs[k], job_first_row(jobs[k]), r, rows_m, (int)k, &grp, e, N, 0); jobs[k].hdev->dst_row1 = rows_m + 1; rows_m += r; }
+    for (size_t k = 0; k < (size_t)n_ekf; ++k) { push_rows(map_o, jobs[k], 0, 2, rows_m + rows_e, (int)k, &grp, e, N, 0); jobs[k].hdev->dst_row1 = rows_m + rows_e + 1; rows_e += 2; }
+    const int m = rows_m + rows_e;
+    if (m > e->hrows) { for (RowJob& j : jobs) if (j.hdev) j.hdev->dst_row1 = 0; end_defer(e); return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "too many measurement rows (%d)", m); }
+    TRS(1);
+    st = end_defer(e);
+    TRS(2);
+    std::vector<double> dx;
+    if (st == LVK_OK) st = dense_update(e, m, dx, 0, &grp);
+    TR(TR_RLF_UPD);
+    if (st == LVK_OK) st = fetch_feature_results(e, jobs, dx.data(), (size_t)N);
+    if (st != LVK_OK) return st;
+    TR(TR_RLF_DX);
+    int accepted = 0;
+    for (size_t k = (size_t)n_ekf; k < jobs.size(); ++k) {
+        const Pick& pk = picks[k - (size_t)n_ekf];
+        if (pk.tri >= 0) {
+            const TriAns a = tri_answer(e, reqs[(size_t)pk.tri], k);
+            apply_tri(pk.f, 0, a);
+            if (!a.ok) { if (pk.lost) e->map.erase(pk.f->id); continue; }      // a lost feature that cannot be triangulated is invalid (:1921-1925); a tracked one waits for more views
+        }
+        if (gate_ok(e, jobs[k])) accepted += job_rows(jobs[k]);
+        e->map.erase(pk.f->id);                          // used (:2240-2246)
+    }
+    for (size_t k = 0; k < (size_t)n_ekf; ++k) if (gate_ok(e, jobs[k])) accepted += 2;
+    if (accepted > 0) {
+        inject(e, dx.data());
+        e->last_update_time = e->s.t;
+        e->counters[0]++;
+        e->counters[2] = accepted;
+    }
+    TR(TR_RLF_INJ);
+    return LVK_OK;
+}
 static lvk_status remove_lost_features(lvk_ekf* e)
 {
     const lvk_ekf_config& c = e->cfg;
     const int cells = c.aug_grid_rows * c.aug_grid_cols;
     std::vector<long long> ekf_ids, ekf_lost;
+    std::vector<const Feature*> long_tracked;                    // tracked, not in the state, max_track_len observations: what may ask for admission
     for (auto kv : e->map) {
         Feature& f = kv.second;
         const bool tracked = f.find(e->imu_id) >= 0;
         if (f.in_state) { if (tracked) ekf_ids.push_back(f.id); else ekf_lost.push_back(f.id); }
+        else if (tracked && (int)f.obs.size() >= c.max_track_len) long_tracked.push_back(&f);
     }
     lvk_status st;
     if (!ekf_lost.empty()) {                                     // rmLostFeaturesCov (:3296-3348): all lost columns in one gather
@@ -1352,6 +1457,17 @@ static lvk_status remove_lost_features(lvk_ekf* e)
     }
     st = upload_clones(e);
     if (st != LVK_OK) return st;
+    if (!e->if_zupt && !e->shard.fn) {
+        // can the triage below take its EKF branch for anybody (:1945-1960)?  The grid only fills up while it runs, so "nobody now" is final.
+        bool admission = false;
+        if (e->s.t - e->last_zupt_time > 5 && (int)e->feature_states.size() < c.max_features_in_one_grid * cells)
+            for (const Feature* f : long_tracked) {
+                const int code = grid_code(e, f->obs[(size_t)f->find(e->imu_id)].z);
+                const int gcount = (code >= 0 && code < cells) ? e->grid_count[code] : 0;
+                if (gcount < c.max_features_in_one_grid) { admission = true; break; }
+            }
+        if (!admission) return remove_lost_fast(e, ekf_ids);
+    }
     // ---- pass 1: every triangulation the triage may ask for, batched on the device, then replayed in map order.
     //      (a) lost, not initialised: initializePosition.  (b) tracked long, not in state: the EKF branch wants
     //      initializeInvParamPosition (always from the two-view guess), the MSCKF branch initializePosition.
@@ -1718,26 +1834,41 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
     }
     std::vector<Use*> used;
     TR(TR_PR_PRE);
+    // unsharded: the triangulations are consumed on the device by the row kernel (FJ_TRI_PENDING, see remove_lost_fast) - the host
+    // reads them together with the gate results and dx, after the update
+    const bool tri_on_device = !e->shard.fn;
     if (!e->if_zupt && !uses.empty()) {
-        if (!reqs.empty()) {
-            st = upload_clones(e); clones_uploaded = true;
-            if (st == LVK_OK) st = run_triangulation(e, reqs, ans);
-            if (st != LVK_OK) return st;
-        }
-        for (auto& u : uses) {
-            if (!u.f->is_initialized) {
-                if (!u.motion) continue;
-                apply_tri(u.f, 1, ans[u.tri]);
-                if (!ans[u.tri].ok) continue;
+        if (tri_on_device) {
+            for (auto& u : uses) {
+                if (!u.f->is_initialized) { if (!u.motion) continue; reqs[(size_t)u.tri].slot = (int)used.size(); }
+                used.push_back(&u);
             }
-            used.push_back(&u);
+            if (!reqs.empty()) {
+                st = upload_clones(e); clones_uploaded = true;
+                if (st == LVK_OK) st = launch_triangulation(e, reqs);
+                if (st != LVK_OK) return st;
+            }
+        } else {
+            if (!reqs.empty()) {
+                st = upload_clones(e); clones_uploaded = true;
+                if (st == LVK_OK) st = run_triangulation(e, reqs, ans);
+                if (st != LVK_OK) return st;
+            }
+            for (auto& u : uses) {
+                if (!u.f->is_initialized) {
+                    if (!u.motion) continue;
+                    apply_tri(u.f, 1, ans[u.tri]);
+                    if (!ans[u.tri].ok) continue;
+                }
+                used.push_back(&u);
+            }
         }
     }
     TR(TR_PR_TRI);
     if (!e->if_zupt && !used.empty()) {
         if (!clones_uploaded) { st = upload_clones(e); if (st != LVK_OK) return st; }
         std::vector<RowJob> jobs;
-        for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; jobs.push_back(r); }
+        for (Use* u : used) { RowJob r; r.f = u->f; r.type = JOB_MSCKF; r.sids = u->inv; r.want_gate = true; r.dof = 2 * (int)u->inv.size() - 3; r.tri_pending = tri_on_device && u->tri >= 0 && !u->f->is_initialized; jobs.push_back(r); }
         // measurementUpdate_msckf (:1420-1602), gate decided on the device (see remove_lost_features): one sync for gate + dx
         const bool sharded = e->shard.fn != nullptr;
         std::vector<size_t> jb; JobRanges own;
@@ -1762,7 +1893,14 @@ static lvk_status prune_imu_state_buffer(lvk_ekf* e)
             if (st != LVK_OK) return st;
             TR(TR_PR_DX);
             int accepted = 0;
-            for (auto& j : jobs) if (gate_ok(e, j)) accepted += job_rows(j);
+            for (size_t k = 0; k < jobs.size(); ++k) {
+                if (jobs[k].tri_pending) {               // initializePosition_AssignAnchor's result (:2420-2440), read now
+                    const TriAns a = tri_answer(e, reqs[(size_t)used[k]->tri], k);
+                    apply_tri(used[k]->f, 1, a);
+                    if (!a.ok) continue;                  // not used in this update (its rows were zeroed on the device)
+                }
+                if (gate_ok(e, jobs[k])) accepted += job_rows(jobs[k]);
+            }
             if (accepted > 0) {
                 inject(e, dx.data());
                 e->last_update_time = e->s.t;
@@ -1897,6 +2035,7 @@ static bool dyn_ransac(void* user, const std::vector<lvk_init::Pt2>& ll, const s
 {
     lvk_ekf* e = (lvk_ekf*)user;
     const int n = (int)ll.size();
+    e->init_ransac_calls += 1;
     mask.assign((size_t)n, 0);
     if (n > 4096) return false;                                          // FM_MAX_N (fe_track_dev.h)
     std::vector<lvk_pt2f> h((size_t)2 * n);
@@ -1935,7 +2074,16 @@ static bool dynamic_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, in
         d.ransac = dyn_ransac; d.ransac_user = e;
     }
     lvk_init::DynInit& d = *e->dyn;
+    const int call = e->init_calls++;
     if (!d.try_init(ts, f, n, imu, n_imu, n_erased)) return false;
+    {
+        lvk_init_report& r = e->init_report; memset(&r, 0, sizeof r);
+        r.valid = 1; r.message = call; r.attempts = d.diag.attempts; r.ransac_calls = e->init_ransac_calls; r.l = d.diag.l; r.n_points = d.diag.n_points; r.erase = *n_erased;
+        r.state_time = d.out.state_time; r.scale = d.diag.scale;
+        memcpy(r.rel_R, d.diag.relR, 72); memcpy(r.rel_T, d.diag.relT, 24);
+        for (size_t i = 0; i < d.diag.sfm_R.size() && i < 11; ++i) { memcpy(r.sfm_R + 9 * i, d.diag.sfm_R[i].data(), 72); memcpy(r.sfm_T + 3 * i, d.diag.sfm_T[i].data(), 24); }
+        memcpy(r.bg, d.out.bg, 24); memcpy(r.g, d.diag.g, 24); memcpy(r.q, d.out.q, 32); memcpy(r.v, d.out.v, 24);
+    }
     e->s.t = d.out.state_time;
     memcpy(e->s.q, d.out.q, 32); memcpy(e->s.p, d.out.p, 24); memcpy(e->s.v, d.out.v, 24); memcpy(e->s.bg, d.out.bg, 24); memcpy(e->s.ba, d.out.ba, 24);
     memcpy(e->m_gyro_old, d.out.last_gyro, 24); memcpy(e->m_acc_old, d.out.last_acc, 24);
@@ -1968,7 +2116,7 @@ void lvk_ekf_destroy(lvk_ekf* e)
         fprintf(stderr, "    updates above 160 rows: %ld (mean %.0f rows), compression plans drawn up: %ld, taken: %ld\n", g_tr.cnt[0], g_tr.cnt[0] ? (double)g_tr.cnt[3] / g_tr.cnt[0] : 0.0, g_tr.cnt[1], g_tr.cnt[2]);
         g_tr = EkfTrace();
     }
-    void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
+    void* ptrs[] = {e->dP[0], e->dP[1], e->d_idx, e->d_phiq, e->d_J, e->d_dx, e->d_tmp, e->d_tri, e->d_tridev, e->d_fj, e->d_fout, e->d_rank, e->d_z, e->d_zv,
                     e->d_cams, e->d_clones, e->d_staging, e->d_ccols, e->d_map, e->d_H, e->d_r, e->d_Hb, e->d_rb, e->d_H1, e->d_H2, e->d_r1, e->ws.B, e->ws.S, e->zero_copy ? nullptr : (void*)e->d_up};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->h_up) hipHostFree(e->h_up);
@@ -2029,18 +2177,19 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     const size_t hrows = (size_t)e->hrows;
     bool ok = dalloc(&e->dP[0], (size_t)e->ld * e->ld) && dalloc(&e->dP[1], (size_t)e->ld * e->ld) && dalloc(&e->d_idx, e->ld) && dalloc(&e->d_phiq, 2 * LEG_MAX * LEG_MAX) &&
               dalloc(&e->d_J, e->ld) && dalloc(&e->d_dx, e->ld + 64) && dalloc(&e->d_tmp, (size_t)64 * e->ld) &&
-              dalloc(&e->d_tri, (size_t)2 * e->feat_cap) && dalloc(&e->d_fj, (size_t)2 * e->feat_cap) && dalloc(&e->d_fout, (size_t)2 * e->feat_cap) &&
+              dalloc(&e->d_tri, (size_t)2 * e->feat_cap) && dalloc(&e->d_tridev, (size_t)2 * e->feat_cap) && dalloc(&e->d_fj, (size_t)2 * e->feat_cap) && dalloc(&e->d_fout, (size_t)2 * e->feat_cap) &&
               dalloc(&e->d_rank, e->obs_cap) && dalloc(&e->d_z, (size_t)2 * e->obs_cap) && dalloc(&e->d_zv, (size_t)2 * e->obs_cap) &&
               dalloc(&e->d_cams, c.sw_size + 4) && dalloc(&e->d_clones, c.sw_size + 4) && dalloc(&e->d_staging, e->staging_cap) && dalloc(&e->d_ccols, e->ccols_cap) &&
               dalloc(&e->d_map, hrows) && dalloc(&e->d_H, hrows * e->ld) && dalloc(&e->d_r, hrows) && dalloc(&e->d_Hb, hrows * e->ld) && dalloc(&e->d_rb, hrows) && dalloc(&e->d_H1, (size_t)64 * e->ld) && dalloc(&e->d_H2, 64) && dalloc(&e->d_r1, 64);
     e->ws.ldb = ((e->ld + 8 + 7) & ~7) | 8; e->ws.lds = e->rows_cap + 8;      // odd multiples of 64 B: power-of-two row strides pile onto one L2 channel
     ok = ok && dalloc(&e->ws.B, (size_t)e->rows_cap * e->ws.ldb) && dalloc(&e->ws.S, (size_t)e->rows_cap * e->ws.lds);
-    e->up_cap = (size_t)32 << 20;
+    e->up_cap = (size_t)64 << 20; e->up_lim = e->up_cap / 2;     // two halves, alternating per call (ekf_process_impl)
     e->down_feat = (sizeof(TriResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_dx = (e->down_feat + sizeof(FeatResult) * (size_t)2 * e->feat_cap + 255) & ~(size_t)255;
     e->down_flag = (e->down_dx + sizeof(double) * (size_t)(e->ld + 64) + 255) & ~(size_t)255;
     e->down_info = e->down_flag + 256;                  // [0] first non-positive Cholesky pivot (+1), [1] a solver workgroup gave up waiting: written by k_chol_fused
-    e->down_cap = e->down_info + 256;
+    e->down_p00 = e->down_info + 256;                   // 16 x 16 doubles
+    e->down_cap = e->down_p00 + 2048;
     ok = ok && hipHostMalloc((void**)&e->h_up, e->up_cap) == hipSuccess && hipHostMalloc((void**)&e->h_down, e->down_cap) == hipSuccess;
     if (ok) {
         // No copy commands on the filter's chain (each ~8 us of API + copy + barrier; ten of them were 385 -> 336 us per update):
@@ -2094,6 +2243,22 @@ lvk_status lvk_ekf_set_state(lvk_ekf* e, double t, const double q[4], const doub
 // samples have been integrated and the propagation / augmentation kernels are queued - so that a pipelined driver overlaps that
 // work with the front-end that is still producing the message (the static initializer needs the message first and asks at once).
 typedef lvk_status (*lvk_feats_fn)(void* user, const lvk_feature_obs** feats, int* n_feats);
+// event brackets of the profiled launches (lvk_ekf_profile): harvested when both events have fired (all = after a stream sync)
+static void prof_harvest(lvk_ekf* e, bool all)
+{
+    size_t w = 0;
+    for (size_t i = 0; i < e->prof_pending.size(); ++i) {
+        auto pe = e->prof_pending[i];
+        if (!all && hipEventQuery(pe.b) != hipSuccess) { e->prof_pending[w++] = pe; continue; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            if (pe.kind == 0) { e->prof_ms += ms; e->prof_flops += pe.flops; e->prof_n += 1; }
+            else { e->prof_qr_ms += ms; e->prof_qr_flops += pe.flops; e->prof_qr_rows += pe.rows; e->prof_qr_n += 1; }
+        }
+        e->prof_free.push_back(pe.a); e->prof_free.push_back(pe.b);
+    }
+    e->prof_pending.resize(w);
+}
 static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
                                    lvk_feats_fn fetch, void* fetch_user);
 static lvk_status ekf_process_guarded(lvk_ekf* e, double ts, const lvk_feature_obs* feats, int n_feats, const lvk_imu* imu, int n_imu, int* n_consumed, int* updated,
@@ -2188,7 +2353,8 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
         void fire() { if (!fired) { fired = true; if (e->on_consumed) e->on_consumed(e->on_consumed_user, *n); } }
         ~Notify() { fire(); }
     } notify{e, n_consumed};
-    e->up_off = 0; e->up_flushed = 0;
+    e->up_half ^= 1; e->n_sync = 0;
+    e->up_off = e->up_flushed = e->up_half ? e->up_cap / 2 : 0; e->up_lim = e->up_off + e->up_cap / 2;
     e->colcache.cols.reset();                           // column lists depend on the clones' ranks, which this call changes
     if (!e->b_first_features) {
         if (n_imu > 0 && imu[0].t - ts - e->td <= 0.0) e->b_first_features = true;
@@ -2232,16 +2398,11 @@ static lvk_status ekf_process_impl(lvk_ekf* e, double ts, const lvk_feature_obs*
     TR(TR_PR_END);
     if (e->cfg.if_fej && !e->if_fej && e->s.t - e->take_off_stamp >= 0) e->if_fej = true;
     e->counters[6] = (long)e->map.size();
-    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
-    for (auto& pe : e->prof_pending) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
-            if (pe.kind == 0) { e->prof_ms += ms; e->prof_flops += pe.flops; e->prof_n += 1; }
-            else { e->prof_qr_ms += ms; e->prof_qr_flops += pe.flops; e->prof_qr_rows += pe.rows; e->prof_qr_n += 1; }
-        }
-        e->prof_free.push_back(pe.a); e->prof_free.push_back(pe.b);
-    }
-    e->prof_pending.clear();
+    // What is still queued now (the pruning's covariance gather, at most) changes neither the state nor anything the host reads, and
+    // it reads the half of the upload arena the NEXT call leaves alone: the call returns without waiting for it.  The call after
+    // that reuses this half - behind at least one stream sync of the call in between, which is why a call that had none ends with one.
+    if (e->n_sync == 0) { EKF_HIP(hipStreamSynchronize(e->ctx->stream)); e->n_sync++; }
+    prof_harvest(e, false);
 #ifdef LVK_MSG_HASH_LOG   // debugging aid, compiled out of the product (make CXXFLAGS+=-DLVK_MSG_HASH_LOG); bounded: the first 65536 messages
     {   // LVK_MSG_HASH=<file>: one line per processed message (time stamp, size, FNV-1a of its bytes, IMU samples used + their hash, td
         // before, state after).  Debugging aid: the message is only COPIED here (a few us); hashing and the file are left to exit.
@@ -2301,10 +2462,18 @@ void lvk_ekf_shard_stats(const lvk_ekf* e, long* out8)
     memcpy(out8, e->shard.stats, sizeof e->shard.stats); memcpy(out8 + 4, e->qr_stats, sizeof e->qr_stats);
 }
 
+lvk_status lvk_ekf_init_report(const lvk_ekf* e, lvk_init_report* out)
+{
+    if (!e || !out) return LVK_ERR_ARG;
+    ekf_quiesce(e);
+    *out = e->init_report;
+    return LVK_OK;
+}
 lvk_status lvk_ekf_profile(lvk_ekf* e, int enable, double* out3)
 {   // out3 (optional): [ms inside the H P GEMM, its flops 2 m N^2, launches] since the last call, then reset
     if (!e) return LVK_ERR_ARG;
     ekf_quiesce(e);
+    hipStreamSynchronize(e->ctx->stream); prof_harvest(e, true);
     if (out3) { out3[0] = e->prof_ms; out3[1] = e->prof_flops; out3[2] = (double)e->prof_n; }
     e->prof_ms = e->prof_flops = 0; e->prof_n = 0; e->prof_on = enable != 0;
     return LVK_OK;
@@ -2313,6 +2482,7 @@ lvk_status lvk_ekf_profile_qr(lvk_ekf* e, double* out4)
 {   // [ms inside k_qr_sparse levels, their Householder flops on the structure factored, launches, rows entering the levels] since the last call, then reset
     if (!e || !out4) return LVK_ERR_ARG;
     ekf_quiesce(e);
+    hipStreamSynchronize(e->ctx->stream); prof_harvest(e, true);
     out4[0] = e->prof_qr_ms; out4[1] = e->prof_qr_flops; out4[2] = (double)e->prof_qr_n; out4[3] = e->prof_qr_rows;
     e->prof_qr_ms = e->prof_qr_flops = e->prof_qr_rows = 0; e->prof_qr_n = 0;
     return LVK_OK;
@@ -2336,7 +2506,24 @@ lvk_status lvk_ekf_get_cov(lvk_ekf* e, double* h_P)
     if (!e || !h_P) return LVK_ERR_ARG;
     ekf_quiesce(e);
     if (e->failed != LVK_OK) return e->failed;
-    EKF_HIP(hipMemcpy2D(h_P, sizeof(double) * e->N, e->dP[e->cur], sizeof(double) * e->ld, sizeof(double) * e->N, e->N, hipMemcpyDeviceToHost));
+    EKF_HIP(hipMemcpy2DAsync(h_P, sizeof(double) * e->N, e->dP[e->cur], sizeof(double) * e->ld, sizeof(double) * e->N, e->N, hipMemcpyDeviceToHost, e->ctx->stream));
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream));       // (an update returns with its last covariance gather still queued)
+    return LVK_OK;
+}
+// the leading n x n block (n <= 16: q v p bg ba[0]) - what getPpose / getPvel read (larvio.cpp:2673-2690) - without moving the
+// covariance: the update's last GEMM mirrors that tile into host-mapped memory, and the host waited for that launch when it read dx
+lvk_status lvk_ekf_get_cov_imu(lvk_ekf* e, int n, double* h_out)
+{
+    if (!e || !h_out || n < 1 || n > 16) return LVK_ERR_ARG;
+    ekf_quiesce(e);
+    if (e->failed != LVK_OK) return e->failed;
+    if (e->p00_valid) {
+        const double* m = (const double*)(e->h_down + e->down_p00);
+        for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) h_out[a * n + b] = m[a * 16 + b];
+        return LVK_OK;
+    }
+    EKF_HIP(hipMemcpy2DAsync(h_out, sizeof(double) * n, e->dP[e->cur], sizeof(double) * e->ld, sizeof(double) * n, n, hipMemcpyDeviceToHost, e->ctx->stream));
+    EKF_HIP(hipStreamSynchronize(e->ctx->stream));
     return LVK_OK;
 }
 int lvk_ekf_get_clones(const lvk_ekf* e, lvk_clone* out, int cap)

@@ -6,11 +6,12 @@
 
 struct CamPose { double R[9]; double t[3]; };                       // camera-to-world rotation (row-major) + position
 struct CloneDev { double q[4], p[3], p_fej[3], R_b2c[9], t_c_b[3]; };  // IMUState_Aug fields the Jacobians read (imu_state.h:72-117)
-struct TriJob { int n, use_position, obs_off, pad; double position_in[3]; };
+struct TriJob { int n, use_position, obs_off, out_slot1; double position_in[3]; };    // out_slot1 > 0: the result goes to slot out_slot1 - 1 (the row job that consumes it on the device), 0: to the job's own index
 struct TriResult { int ok, pad; double position[3], solution[3], inv_depth, obs_anchor[3]; };
 enum { JOB_MSCKF = 0, JOB_EKF_NEW = 1, JOB_EKF_TRACKED = 2 };
+enum { FJ_GATE = 1, FJ_TRI_PENDING = 2 };
 struct FeatJob {
-    int type, n_obs, obs_off, anchor_rank, fcol, want_gate;
+    int type, n_obs, obs_off, anchor_rank, fcol, want_gate;      // want_gate bit 0: gate the job; bit 1 (FJ_TRI_PENDING): its landmark is TriResult[job index] of the triangulation queued ahead of it
     int ccol_off, dst_row1;          // dst_row1 > 0: the job's output rows also go, expanded, to rows dst_row1-1.. of the dense measurement matrix (k_feature_rows' direct output)
     long long stage_off;
     double p_w[3], p_fej[3], inv_depth, obs_anchor[3];

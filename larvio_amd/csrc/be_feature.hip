@@ -20,7 +20,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ========================================================================= triangulation
 __global__ void __launch_bounds__(64) k_triangulate(const TriJob* __restrict__ jobs, int n_jobs, const CamPose* __restrict__ cams,
-                                                   const int* __restrict__ obs_rank, const double* __restrict__ obs_z, TriResult* __restrict__ out)
+                                                   const int* __restrict__ obs_rank, const double* __restrict__ obs_z, TriResult* __restrict__ out,
+                                                   TriResult* __restrict__ out_dev /* optional: a second copy in device memory, read by k_feature_rows (FJ_TRI_PENDING) */)
 {
     __shared__ double red[64][13];
     const int jb = blockIdx.x;
@@ -122,7 +123,9 @@ __global__ void __launch_bounds__(64) k_triangulate(const TriJob* __restrict__ j
         const double idp = 1 / fp[2];
         o.inv_depth = idp;
         o.obs_anchor[0] = fp[0] * idp; o.obs_anchor[1] = fp[1] * idp; o.obs_anchor[2] = 1;
-        out[jb] = o;
+        const int slot = job.out_slot1 > 0 ? job.out_slot1 - 1 : jb;
+        out[slot] = o;
+        if (out_dev) out_dev[slot] = o;
     }
 }
 
@@ -147,7 +150,8 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
                                                             FeatResult* __restrict__ out_host /* optional mirror in device-mapped host memory */,
                                                             double* __restrict__ H_out, int ldh, int ncols_out, double* __restrict__ r_out /* direct output, see the end */,
                                                             int obs_stride /* > 0: job jb's observations sit at [jb * obs_stride, ..): their address does not wait for the job record */,
-                                                            int n_clones)
+                                                            int n_clones,
+                                                            const TriResult* __restrict__ tri /* optional: results of the triangulation queued ahead of this launch, indexed like the jobs */)
 {
     extern __shared__ double sh[];
     const int jb = blockIdx.x;
@@ -166,7 +170,15 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         const int oi = jb * obs_stride + t;
         my_rank = obs_rank[oi]; my_z[0] = obs_z[2 * oi]; my_z[1] = obs_z[2 * oi + 1]; my_zv[0] = obs_zv[2 * oi]; my_zv[1] = obs_zv[2 * oi + 1];
     }
+    // A job whose landmark is still being triangulated when the host queues this launch (FJ_TRI_PENDING) takes it from the
+    // triangulation's result slot - requested together with the job record, not after it - and counts as rejected when the
+    // triangulation failed: the host then never waits for the triangulation before it lays the update out.
+    int tri_ok = 1; double tri_p[3] = {0., 0., 0.};
+    if (tri) { tri_ok = tri[jb].ok; tri_p[0] = tri[jb].position[0]; tri_p[1] = tri[jb].position[1]; tri_p[2] = tri[jb].position[2]; }
     const FeatJob job = jobs[jb];
+    const bool tri_pending = tri && (job.want_gate & FJ_TRI_PENDING);
+    if (!tri_pending) tri_ok = 1;
+    const double p_w[3] = {tri_pending ? tri_p[0] : job.p_w[0], tri_pending ? tri_p[1] : job.p_w[1], tri_pending ? tri_p[2] : job.p_w[2]};
     const int M = job.n_obs;
     const int rows = 2 * M;
     const int nf = (job.type == JOB_MSCKF) ? 3 : 1;                  // columns of H_f
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     constexpr int PER = SMALL ? (FRS_COLS * FRS_COLS + FR_THREADS - 1) / FR_THREADS : 1;
     double pv[PER];
     const int pj = t & 63, pi0 = t >> 6;
-    if (SMALL && job.want_gate && pj < c) {
+    if (SMALL && (job.want_gate & FJ_GATE) && pj < c) {
         const double* Pj = P + scc[pj];
 #pragma unroll
         for (int u = 0; u < PER; ++u) { const int i = pi0 + 2 * u; if (i < c) pv[u] = Pj[(size_t)scc[i] * ldp]; }
@@ -231,7 +243,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         double Hx[12], He[12], r2[2];
         if (job.type == JOB_MSCKF) {
             double hf[6];
-            d_msckf_obs_jacobian(ck, job.p_w, z, fl.if_fej, Hx, He, hf, r2);
+            d_msckf_obs_jacobian(ck, p_w, z, fl.if_fej, Hx, He, hf, r2);
             for (int a = 0; a < 2; ++a) {
                 double* row = G + (size_t)(2 * t + a) * c;
                 for (int j = 0; j < 6; ++j) row[j] = He[a * 6 + j];
@@ -257,7 +269,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         }
     }
     FR_TICK(3);                                                      // Jacobians done
-    if (SMALL && job.want_gate && pj < c) {
+    if (SMALL && (job.want_gate & FJ_GATE) && pj < c) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) { const int i = pi0 + 2 * u; if (i < c) Pcc[i * FRS_PLD + pj] = pv[u]; }
     }
@@ -313,7 +325,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
     FR_TICK(5);                                                      // null-space projection done
     // ---- gate: S = G' P_cc G'^T + sigma2 I on rows first_row.. ; gamma = r'^T S^-1 r'
     double gamma = 0.;
-    if (job.want_gate && k_rows > 0) {
+    if ((job.want_gate & FJ_GATE) && k_rows > 0) {
         const int k = k_rows;
         const double* Gp = G + (size_t)first_row * c;
         if (SMALL) {
@@ -427,7 +439,7 @@ __global__ void __launch_bounds__(FR_THREADS) k_feature_rows(const FeatJob* __re
         for (int e = t; e < rows; e += FR_THREADS) rrg[e] = rr[e];
     }
     FR_TICK(8);                                                      // staging written
-    const int accept = (!job.want_gate || gamma < job.gate_thr) ? 1 : 0;      // gamma is the same in every thread
+    const int accept = (tri_ok && (!(job.want_gate & FJ_GATE) || gamma < job.gate_thr)) ? 1 : 0;      // gamma is the same in every thread (a NaN from a failed triangulation's landmark compares false)
     if (t == 0) {
         FeatResult o; o.gamma = gamma; o.rows = k_rows; o.first_row = first_row; o.c = c; o.h2 = h2;
         o.accept = accept;
@@ -474,10 +486,10 @@ __global__ void __launch_bounds__(128) k_stack_rows(const StackRow* __restrict__
 
 // ========================================================================= host launchers (internal)
 lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_jobs, const CamPose* d_cams, const int* d_rank, const double* d_z,
-                                  TriResult* d_out)
+                                  TriResult* d_out, TriResult* d_out_dev)
 {
     if (n_jobs <= 0) return LVK_OK;
-    hipLaunchKernelGGL(k_triangulate, dim3(n_jobs), dim3(64), 0, ctx->stream, d_jobs, n_jobs, d_cams, d_rank, d_z, d_out);
+    hipLaunchKernelGGL(k_triangulate, dim3(n_jobs), dim3(64), 0, ctx->stream, d_jobs, n_jobs, d_cams, d_rank, d_z, d_out, d_out_dev);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
@@ -485,7 +497,7 @@ lvk_status lvk_launch_triangulate(lvk_context* ctx, const TriJob* d_jobs, int n_
 lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int n_jobs, int max_rows, const CloneDev* d_clones, const int* d_rank,
                                    const double* d_z, const double* d_zv, const double* d_P, int ldp, FilterFlags fl, double* d_staging,
                                    int* d_ccols, FeatResult* d_out, FeatResult* d_out_host, double* d_Hout, int ldh, int ncols_out, double* d_rout,
-                                   int obs_stride, int n_clones)
+                                   int obs_stride, int n_clones, const TriResult* d_tri)
 {
     if (n_jobs <= 0) return LVK_OK;
     const size_t base = sizeof(double) * ((size_t)max_rows * 4 + (size_t)max_rows * max_rows + max_rows + 8);
@@ -496,11 +508,11 @@ lvk_status lvk_launch_feature_rows(lvk_context* ctx, const FeatJob* d_jobs, int 
     if (small) {
         if (shmem > 64 * 1024) LVK_LDS_OPTIN(ctx, 10, k_feature_rows<true>, shmem);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<true>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout, obs_stride, n_clones);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout, obs_stride, n_clones, d_tri);
     } else {
         LVK_LDS_OPTIN(ctx, 1, k_feature_rows<false>, shmem);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feature_rows<false>), dim3(n_jobs), dim3(FR_THREADS), shmem, ctx->stream, d_jobs, n_jobs, d_clones, d_rank, d_z, d_zv,
-                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout, 0, n_clones);
+                           d_P, ldp, fl, d_staging, d_ccols, d_out, d_out_host, d_Hout, ldh, ncols_out, d_rout, 0, n_clones, d_tri);
     }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
@@ -533,10 +545,10 @@ extern "C" lvk_status lvk_triangulate(lvk_context* ctx, const lvk_cam_pose* h_po
     for (int i = 0; i < n; ++i) ((int*)(h.data() + o_rank))[i] = i;
     memcpy(h.data() + o_z, h_obs, sizeof(double) * 2 * n);
     TriJob* j = (TriJob*)(h.data() + o_job);
-    j->n = n; j->use_position = use_position ? 1 : 0; j->obs_off = 0; j->pad = 0;
+    j->n = n; j->use_position = use_position ? 1 : 0; j->obs_off = 0; j->out_slot1 = 0;
     if (h_position_in) memcpy(j->position_in, h_position_in, 24);
     LVK_HIP(ctx, hipMemcpyAsync(d, h.data(), o_out, hipMemcpyHostToDevice, ctx->stream));
-    lvk_status st = lvk_launch_triangulate(ctx, (const TriJob*)(d + o_job), 1, (const CamPose*)(d + o_cams), (const int*)(d + o_rank), (const double*)(d + o_z), (TriResult*)(d + o_out));
+    lvk_status st = lvk_launch_triangulate(ctx, (const TriJob*)(d + o_job), 1, (const CamPose*)(d + o_cams), (const int*)(d + o_rank), (const double*)(d + o_z), (TriResult*)(d + o_out), nullptr);
     if (st != LVK_OK) return st;
     TriResult r;
     LVK_HIP(ctx, hipMemcpyAsync(&r, d + o_out, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
@@ -601,7 +613,7 @@ extern "C" lvk_status lvk_ekf_gate_and_stack(lvk_context* ctx, const lvk_clone* 
     double* d_staging = (double*)d_st; int* d_ccols = (int*)(d_st + ((sizeof(double) * stage + 63) & ~(size_t)63));
     FeatResult* d_fout = (FeatResult*)(d_out + o_fo);
     lvk_status st = lvk_launch_feature_rows(ctx, (const FeatJob*)(d_in + o_job), n_feats, max_rows, (const CloneDev*)(d_in + o_cl), (const int*)(d_in + o_rk),
-                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr, nullptr, 0, 0, nullptr, 0, n_clones);
+                                            (const double*)(d_in + o_z), (const double*)(d_in + o_zv), (const double*)(d_in + o_P), ld, fl, d_staging, d_ccols, d_fout, nullptr, nullptr, 0, 0, nullptr, 0, n_clones, nullptr);
     if (st != LVK_OK) return st;
     std::vector<FeatResult> res(n_feats);
     LVK_HIP(ctx, hipMemcpyAsync(res.data(), d_fout, sizeof(FeatResult) * n_feats, hipMemcpyDeviceToHost, ctx->stream));

@@ -605,7 +605,7 @@ static inline bool visual_imu_alignment(std::vector<Frame*>& fr, double (*Bgs)[3
 // ------------------------------------------------------------------------------------------------ the initialiser object
 struct Result { double state_time, q[4], p[3], v[3], bg[3], ba[3], last_gyro[3], last_acc[3]; };
 // intermediate results of the successful attempt (read by the replay harness of the CPU suite, tests/host/init_replay.hip)
-struct Diag { int l = -1; double relR[9], relT[3]; std::vector<std::array<double, 9>> sfm_R; std::vector<std::array<double, 3>> sfm_T; double g[3] = {0, 0, 0}, scale = 0; int n_points = 0; };
+struct Diag { int l = -1; double relR[9], relT[3]; std::vector<std::array<double, 9>> sfm_R; std::vector<std::array<double, 3>> sfm_T; double g[3] = {0, 0, 0}, scale = 0; int n_points = 0; int attempts = 0; };   // attempts: initial_structure() calls so far (full windows tried)
 // callback for E = cv::findFundamentalMat(ll, rr, FM_RANSAC, thresh, conf, mask): float correspondences -> inlier mask and the matrix (9 doubles;
 // false / all zeros = OpenCV's empty Mat)
 typedef bool (*ransac_fn)(void* user, const std::vector<Pt2>& ll, const std::vector<Pt2>& rr, double thresh, double conf, std::vector<unsigned char>& mask, double* F);
@@ -705,6 +705,7 @@ struct DynInit {
         std::vector<SfmFeature> sfm;
         for (auto& tr : tracks) { SfmFeature sf; sf.id = tr.id; int j = tr.start_frame - 1; for (auto& p : tr.per_frame) sf.obs.push_back({++j, p}); sfm.push_back(sf); }
         double relR[9], relT[3]; int l = 0;
+        diag.attempts += 1;
         if (!relative_pose(relR, relT, &l)) return false;
         std::vector<std::array<double, 9>> Q; std::vector<std::array<double, 3>> T;
         if (!global_sfm(frame_count + 1, l, relR, relT, sfm, Q, T)) return false;      // (marginalization_flag = MARGIN_OLD: it always is, see add_features)

@@ -19,7 +19,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // D: col = l&15, row = (l>>4) + 4*reg  (f64 has its own C/D map, cdna_hip_programming.md §3).
 // Two optional riders save launches on the update's dependent chain: (xin, xin_col) copies a vector into column xin_col of C
 // ([HP | r] in one launch); (xout, xout_col) diverts output column xout_col to a vector, unscaled (W^T [W | w] -> P update and dx).
-struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; double* xout_host = nullptr; };   // xout_host: mirror of xout in device-mapped host memory
+struct GemmRider { const double* xin; int xin_col; double* xout; int xout_col; double* xout_host = nullptr; double* c00_host = nullptr; };   // xout_host: mirror of xout in device-mapped host memory; c00_host: mirror (16 x 16, row-major) of C's leading tile, likewise
 // Split-K: the four wavefronts of a workgroup share ONE 16x16 tile and take every fourth K-chunk (kc <= 64 consecutive k, a
 // multiple of 16) each.  The operands come from other XCDs' L2s / the memory side (they were written by the previous kernel), so a
 // dependent load costs microseconds and a tile's time is (number of load round trips) x latency, not bytes or flops: a tile of the
@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(256) k_dgemm_sk(int M, int N, int K, int kc, c
             if (beta != 0.) v += beta * cin[r];
             if (row == col) v += diag_add;
             C[(size_t)row * ldc + col] = v;
+            if (rd.c00_host && row0 == 0 && col0 == 0) rd.c00_host[row * 16 + col] = v;
         }
     }
 }
@@ -688,7 +689,7 @@ static lvk_status launch_chol_solve(lvk_context* ctx, double* S, int lds_, int m
 }
 
 // ------------------------------------------------------------------------- host drivers (internal + C ABI)
-struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; double* dx_host = nullptr; };   // ev_*: optional bracket around the H P GEMM; dx_host: host-mapped mirror of dx
+struct UpdateWs { double* B; int ldb; double* S; int lds; int* info; hipEvent_t ev_a = nullptr, ev_b = nullptr; double* dx_host = nullptr; double* p00_host = nullptr; };   // ev_*: optional bracket around the H P GEMM; dx_host: host-mapped mirror of dx; p00_host: of the updated P's leading 16 x 16 block
 
 // dx (device, n) and P updated in place.  B: m x (n+1) workspace, S: m x m workspace.
 lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const double* H, int ldh, int m, const double* r, double sigma2,
@@ -702,7 +703,7 @@ lvk_status lvk_update_core(lvk_context* ctx, double* P, int ldp, int n, const do
     launch_dgemm<false, true>(s, m, m, n, ws.B, ws.ldb, H, ldh, ws.S, ws.lds, 1.0, 0.0, sigma2);           // S = HP H^T + sigma2 I
     { lvk_status cs = launch_chol_solve(ctx, ws.S, ws.lds, m, ws.B, ws.ldb, n + 1, ws.info); if (cs != LVK_OK) return cs; }                                    // S = L L^T ; W = L^-1 [HP | r]
     // W^T [W | w]: columns 0..n-1 update P (P -= W^T W), column n is dx = W^T w
-    launch_dgemm<true, false>(s, n, n + 1, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0, GemmRider{nullptr, 0, dx, n, ws.dx_host});
+    launch_dgemm<true, false>(s, n, n + 1, m, ws.B, ws.ldb, ws.B, ws.ldb, P, ldp, -1.0, 1.0, 0.0, GemmRider{nullptr, 0, dx, n, ws.dx_host, ws.p00_host});
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

@@ -365,7 +365,7 @@ __device__ __forceinline__ void cov_at(const uint8_t* __restrict__ s0, int sstri
 }
 
 __global__ void __launch_bounds__(256) k_min_eigen(const uint8_t* __restrict__ s0, int w, int h, int sstride,
-                                                  float* __restrict__ eig)
+                                                  float* __restrict__ eig, uint8_t* __restrict__ mask_init /* optional: the detection mask (w x h) is set to 255 on the way - no fill launch */)
 {
     __shared__ float cv[3][EG_TY + 2][EG_TX + 2];
     __shared__ float hs[3][EG_TY + 2][EG_TX];
@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(256) k_min_eigen(const uint8_t* __restrict__ s
         for (int c = 0; c < 3; ++c) s[c] = (hs[c][ry][rx] + hs[c][ry + 1][rx]) + hs[c][ry + 2][rx];
         float a = s[0] * 0.5f, b = s[1], c2 = s[2] * 0.5f;
         eig[(size_t)gy * w + gx] = (a + c2) - sqrtf((a - c2) * (a - c2) + b * b);
+        if (mask_init) mask_init[(size_t)gy * w + gx] = 255;
     }
 }
 
@@ -429,6 +430,80 @@ __global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ ei
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) { best = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); if (best) atomicMax(&scratch[0], best); }
+}
+
+// The frame path's detection mask and the masked maximum of the response map in ONE pass (findNewFeaturesToBeTracked's mask, image_processor.cpp:1005-1030,
+// and goodFeaturesToTrack's minMaxLoc under it): a workgroup owns MM_ROWS image rows, builds their mask in LDS - all 255, then the row
+// segments of every (2 md + 1)^2 box around round(pt) that reaches into the strip, zeroed -, writes it out for k_gftt_candidates and takes the
+// maximum of the response values it leaves visible (one atomicMax per workgroup).  Same bytes as k_mask_boxes on a 255-filled image, same
+// key as k_masked_max; one launch and one kernel boundary instead of a fill and two launches on the chain commit -> detection -> the next
+// frame's new-point tracking.  The strip's response values are requested before the mask is built (they do not depend on it).
+#define MM_ROWS 4
+#define MM_PRE 8
+__global__ void __launch_bounds__(256) k_mask_max(const lvk_pt2f* __restrict__ pts, const int* __restrict__ n_pts, int w, int h, int md,
+                                                 const float* __restrict__ eig, uint8_t* __restrict__ mask, unsigned* __restrict__ scratch)
+{
+    extern __shared__ unsigned mm_sh[];                     // MM_ROWS x wp bytes, wp = w rounded up to 4
+    uint8_t* mb = (uint8_t*)mm_sh;
+    const int t = threadIdx.x, y0 = blockIdx.x * MM_ROWS, rows = min(MM_ROWS, h - y0);
+    const int wq = (w + 3) >> 2, wp = wq * 4;
+    const bool vec = (w & 3) == 0 && ((((size_t)eig) & 15) | (((size_t)mask) & 3)) == 0;
+    const int nq = rows * wq;                               // 4-pixel groups of the strip
+    float4 pre[MM_PRE];
+    const bool use_pre = vec && nq <= MM_PRE * 256;
+    if (use_pre) {
+#pragma unroll
+        for (int u = 0; u < MM_PRE; ++u) { const int i = t + 256 * u; if (i < nq) { const int r = i / wq, q = i - r * wq; pre[u] = ((const float4*)(eig + (size_t)(y0 + r) * w))[q]; } }
+    }
+    for (int i = t; i < MM_ROWS * wq; i += 256) mm_sh[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const int n = *n_pts;
+    for (int i = t; i < n; i += 256) {
+        // round(): half away from zero on the float coordinate
+        const int ry = (int)roundf(pts[i].y), rx = (int)roundf(pts[i].x);
+        const int r0 = max(max(ry - md, 0), y0), r1 = min(min(ry + md, h - 1), y0 + rows - 1), c0 = max(rx - md, 0), c1 = min(rx + md, w - 1);
+        for (int y = r0; y <= r1; ++y) for (int x = c0; x <= c1; ++x) mb[(y - y0) * wp + x] = 0;
+    }
+    __syncthreads();
+    unsigned best = 0;
+    if (vec) {
+#pragma unroll
+        for (int u = 0; u < MM_PRE; ++u) {
+            const int i = t + 256 * u;
+            if (!use_pre || i >= nq) break;
+            const int r = i / wq, q = i - r * wq;
+            const unsigned mk = mm_sh[r * wq + q];
+            ((unsigned*)(mask + (size_t)(y0 + r) * w))[q] = mk;
+            const float4 v = pre[u];
+            if (mk & 0x000000FFu) best = max(best, f2ord(v.x));
+            if (mk & 0x0000FF00u) best = max(best, f2ord(v.y));
+            if (mk & 0x00FF0000u) best = max(best, f2ord(v.z));
+            if (mk & 0xFF000000u) best = max(best, f2ord(v.w));
+        }
+        if (!use_pre)
+            for (int i = t; i < nq; i += 256) {
+                const int r = i / wq, q = i - r * wq;
+                const unsigned mk = mm_sh[r * wq + q];
+                ((unsigned*)(mask + (size_t)(y0 + r) * w))[q] = mk;
+                const float4 v = ((const float4*)(eig + (size_t)(y0 + r) * w))[q];
+                if (mk & 0x000000FFu) best = max(best, f2ord(v.x));
+                if (mk & 0x0000FF00u) best = max(best, f2ord(v.y));
+                if (mk & 0x00FF0000u) best = max(best, f2ord(v.z));
+                if (mk & 0xFF000000u) best = max(best, f2ord(v.w));
+            }
+    } else {
+        for (int i = t; i < rows * w; i += 256) {
+            const int r = i / w, x = i - r * w;
+            const uint8_t b = mb[r * wp + x];
+            mask[(size_t)(y0 + r) * w + x] = b;
+            if (b) best = max(best, f2ord(eig[(size_t)(y0 + r) * w + x]));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+    __shared__ unsigned wmax[4];
+    if ((t & 63) == 0) wmax[t >> 6] = best;
+    __syncthreads();
+    if (t == 0) { best = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); if (best) atomicMax(&scratch[0], best); }
 }
 
 // 3x3 non-maximum suppression above quality*max, inside the mask.  One workgroup scans 256 columns x GC_ROWS rows, collects its
@@ -524,7 +599,7 @@ extern "C" void lvk_debug_gf_ticks(unsigned long long* out) { hipDeviceSynchroni
 #endif
 __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* __restrict__ cands, int cap, int w, int h,
                                                      int max_corners, int cell, float md2,
-                                                     const unsigned* __restrict__ scratch, lvk_pt2f* __restrict__ out, int out_cap,
+                                                     unsigned* __restrict__ scratch /* read, then left zeroed for the next detection (no fill launch) */, lvk_pt2f* __restrict__ out, int out_cap,
                                                      int* __restrict__ n_out, const int* __restrict__ d_sub)
 {
     extern __shared__ unsigned long long gf_sh[];           // surv [GF_SURV] u64 | cells [gw*gh][4] u16 | acc [GF_MAX_OUT] short2
@@ -539,7 +614,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
     const int t = threadIdx.x, lane = t & 63;
     if (d_sub) {   // image_processor.cpp:1034-1036: maxCorners = max_features_num - curr_pts_.size(), skipped when 0
         max_corners -= *d_sub;
-        if (max_corners <= 0) { if (t == 0) *n_out = 0; return; }
+        if (max_corners <= 0) { if (t == 0) { *n_out = 0; for (int q = 0; q < GF_SCRATCH_UINTS; ++q) scratch[q] = 0u; } return; }
     }
     GF_TICK(0);
     const int n = (int)min(scratch[1], (unsigned)cap);
@@ -748,7 +823,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
         if (target < GF_SURV) target <<= 1;
     }
     GF_TICK(7);
-    if (t == 0) *n_out = sh_na < out_cap ? sh_na : out_cap;
+    if (t == 0) { *n_out = sh_na < out_cap ? sh_na : out_cap; for (int q = 0; q < GF_SCRATCH_UINTS; ++q) scratch[q] = 0u; }   // every thread read scratch[1] many barriers ago
 }
 
 // mask with zeroed (2*md+1)^2 boxes around round(pt)  (image_processor.cpp:1009-1030)
@@ -953,31 +1028,45 @@ lvk_status lvk_min_eigen_map(lvk_context* ctx, const lvk_pyramid* p, float* d_ei
     if (!ctx || !p || !d_eig) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_min_eigen_map: bad argument");
     const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
     hipLaunchKernelGGL(k_min_eigen, dim3((p->w[0] + EG_TX - 1) / EG_TX, (p->h[0] + EG_TY - 1) / EG_TY), dim3(256), 0, ctx->stream,
-                       s0, p->w[0], p->h[0], p->istride[0], d_eig);
+                       s0, p->w[0], p->h[0], p->istride[0], d_eig, (uint8_t*)nullptr);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
 
 }  // extern "C"
 
+// internal (frame path): the response map and, in the same pass, the detection mask set to 255 everywhere (findNewFeaturesToBeTracked'
+// cv::Mat mask(..., Scalar(255)), image_processor.cpp:1005-1008) - the boxes are cut out later by lvk_mask_boxes(prepared = true)
+lvk_status lvk_min_eigen_map_mask(lvk_context* ctx, const lvk_pyramid* p, float* d_eig, uint8_t* d_mask)
+{
+    if (!ctx || !p || !d_eig) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_min_eigen_map: bad argument");
+    const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
+    hipLaunchKernelGGL(k_min_eigen, dim3((p->w[0] + EG_TX - 1) / EG_TX, (p->h[0] + EG_TY - 1) / EG_TY), dim3(256), 0, ctx->stream,
+                       s0, p->w[0], p->h[0], p->istride[0], d_eig, d_mask);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
 // internal: GFTT on a precomputed eig map with caller-provided scratch (used by the frame-level path too)
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
                         double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
-                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared)
-{   // prepared: lvk_gftt_prepare already queued the two memsets (ahead of whatever this call has to wait for)
+                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared, bool max_done)
+{   // max_done: scratch[0] already holds the masked maximum (lvk_mask_and_max)
+   // prepared: the scratch words are zero (k_gftt_select leaves them so; a scratch of unknown content is cleared here) and the mask is final
     if (min_distance < 1.0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "goodFeaturesToTrack with minDistance < 1 is not supported");
     const int cell = (int)rint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     if (gw * gh > GF_MAX_CELLS) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT grid %dx%d exceeds %d cells", gw, gh, GF_MAX_CELLS);
     if (max_corners > GF_MAX_OUT || max_corners <= 0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "maxCorners must be in 1..%d", GF_MAX_OUT);
     if (!prepared) LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
+    if (!max_done)
     { int mb = (w * h / 4 + 2047) / 2048; mb = mb < 128 ? 128 : mb > 1024 ? 1024 : mb;      // ~8 four-pixel loads per lane
       hipLaunchKernelGGL(k_masked_max, dim3(mb), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch); }
     hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, (h - 2 + GC_ROWS - 1) / GC_ROWS), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
     const size_t shm = (size_t)GF_SURV * 8 + (size_t)gw * gh * 8 + (size_t)GF_MAX_OUT * 4;
     LVK_LDS_OPTIN(ctx, 2, k_gftt_select, shm);   // the opt-in must leave room for the kernel's static LDS: ask for what is launched
     hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), shm, ctx->stream, (const unsigned long long*)d_cands, cand_cap, w, h, max_corners, cell,
-                       (float)(min_distance * min_distance), (const unsigned*)d_scratch, d_out, cap, d_n_out, d_sub);
+                       (float)(min_distance * min_distance), d_scratch, d_out, cap, d_n_out, d_sub);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
@@ -999,6 +1088,16 @@ lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_
     return LVK_OK;
 }
 
+// frame path: mask + masked maximum in one launch (k_mask_max); the scratch words must be zero (k_gftt_select leaves them so)
+lvk_status lvk_mask_and_max(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int w, int h, int md, const float* d_eig, uint8_t* d_mask, unsigned* d_scratch)
+{
+    const size_t shm = (size_t)MM_ROWS * (((size_t)w + 3) & ~(size_t)3);
+    if (shm > 60 * 1024) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "image width %d too large for the mask kernel", w);
+    hipLaunchKernelGGL(k_mask_max, dim3((h + MM_ROWS - 1) / MM_ROWS), dim3(256), shm, ctx->stream, d_pts, d_n, w, h, md, d_eig, d_mask, d_scratch);
+    LVK_LAUNCH_CHECK(ctx);
+    return LVK_OK;
+}
+
 extern "C" lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, const uint8_t* d_mask, int max_corners,
                                         double quality, double min_distance, lvk_pt2f* d_out, int cap, int* d_n_out)
 {
@@ -1011,6 +1110,6 @@ extern "C" lvk_status lvk_good_features(lvk_context* ctx, const lvk_pyramid* p, 
     unsigned long long* cands = (unsigned long long*)lvk_ctx_scratch(ctx, 3, sizeof(unsigned long long) * cand_alloc);
     if (!eig || !scratch || !cands) return lvk_set_error(ctx, LVK_ERR_DEVICE, "scratch allocation failed");
     lvk_status st = lvk_min_eigen_map(ctx, p, eig);
-    if (st == LVK_OK) st = lvk_gftt_run(ctx, eig, d_mask, w, h, max_corners, quality, min_distance, scratch, cands, cand_cap, d_out, cap, d_n_out, nullptr, false);
+    if (st == LVK_OK) st = lvk_gftt_run(ctx, eig, d_mask, w, h, max_corners, quality, min_distance, scratch, cands, cand_cap, d_out, cap, d_n_out, nullptr, false, false);
     return st;
 }

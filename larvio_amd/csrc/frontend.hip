@@ -20,8 +20,10 @@
 
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
                         double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
-                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared);
+                        lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared, bool max_done);
 lvk_status lvk_gftt_prepare(lvk_context* ctx, uint8_t* d_mask, int w, int h, unsigned* d_scratch);
+lvk_status lvk_min_eigen_map_mask(lvk_context* ctx, const lvk_pyramid* p, float* d_eig, uint8_t* d_mask);
+lvk_status lvk_mask_and_max(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int w, int h, int md, const float* d_eig, uint8_t* d_mask, unsigned* d_scratch);
 lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask, bool prepared);
 
 // =========================================================================== runtime environment, BAR self-test
@@ -865,9 +867,11 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { lvk_frontend_destroy(fe); return lvk_set_error(ctx, LVK_ERR_DEVICE, "lvk_frontend_create: allocation failed"); }
     hipMemsetAsync(fe->dev, 0, sizeof(FeDev), ctx->stream);
+    hipMemsetAsync(fe->gf_scratch, 0, sizeof(unsigned) * (4 + 8192), ctx->stream);      // the selection kernel keeps its words zeroed from here on (fe_detect_new queues no fill)
     memset(&fe->cam, 0, sizeof fe->cam);
     for (int i = 0; i < 4; ++i) { fe->cam.intr[i] = cfg->intrinsics[i]; fe->cam.dist[i] = cfg->distortion[i]; }
     fe->cam.model = cfg->distortion_model; fe->cam.width = w; fe->cam.height = h;
+    hipStreamSynchronize(ctx->stream);                  // the clears above are done before any of the three streams is used
     *out = fe;
     return LVK_OK;
 }
@@ -893,13 +897,14 @@ static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
     lvk_context* cx = fe->side[0];
     const lvk_fe_config& c = fe->cfg;
     lvk_status st;
-    { ProfScope ps(fe, 6, cx->stream); st = lvk_min_eigen_map(cx, fe->pyr[1], fe->eig); if (st == LVK_OK) st = lvk_gftt_prepare(cx, fe->mask, c.width, c.height, fe->gf_scratch); }
+    // no fill launches: the mask is written whole by k_mask_max, the previous selection left the scratch words zeroed
+    { ProfScope ps(fe, 6, cx->stream); st = lvk_min_eigen_map(cx, fe->pyr[1], fe->eig); }
     if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
     hipStreamWaitEvent(cx->stream, fe->ev_commit, 0);
     ProfScope ps(fe, 7, cx->stream);
-    st = lvk_mask_boxes(cx, fe->set[dst].pts, &fe->dev->n_tracks[dst], fe->cap, c.width, c.height, c.min_distance, fe->mask, true);
+    st = lvk_mask_and_max(cx, fe->set[dst].pts, &fe->dev->n_tracks[dst], c.width, c.height, c.min_distance, fe->eig, fe->mask, fe->gf_scratch);
     if (st == LVK_OK) st = lvk_gftt_run(cx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
-                                        fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst], true);
+                                        fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, &fe->dev->n_tracks[dst], true, true);
     if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
     return LVK_OK;
 }
@@ -1134,7 +1139,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         // initializeFirstFrame (:337-352): goodFeaturesToTrack(max_features_num, 0.01, min_distance), no mask
         { ProfScope ps(fe, 6); st = lvk_min_eigen_map(ctx, fe->pyr[1], fe->eig); }
         if (st == LVK_OK) st = lvk_gftt_run(ctx, fe->eig, nullptr, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
-                                            fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, nullptr, false);
+                                            fe->gf_cands, fe->gf_cand_cap, fe->new_pts, fe->cap, &fe->dev->n_new, nullptr, false, false);
         if (st == LVK_OK) st = fe_read_dev(fe);
         if (st != LVK_OK) return st;
         fe->last_pub_time = ts;

@@ -32,6 +32,13 @@ class EkfConfig(C.Structure):
 _sig_done = False
 
 
+class InitReport(C.Structure):
+    """lvk_init_report (include/lvk_c.h)"""
+    _fields_ = [("valid", C.c_int), ("message", C.c_int), ("attempts", C.c_int), ("ransac_calls", C.c_int), ("l", C.c_int), ("n_points", C.c_int), ("erase", C.c_int), ("pad", C.c_int),
+                ("state_time", C.c_double), ("scale", C.c_double), ("rel_R", C.c_double * 9), ("rel_T", C.c_double * 3), ("sfm_R", C.c_double * 99), ("sfm_T", C.c_double * 33),
+                ("bg", C.c_double * 3), ("g", C.c_double * 3), ("q", C.c_double * 4), ("v", C.c_double * 3)]
+
+
 def _L():
     global _sig_done
     L = lib()
@@ -53,11 +60,13 @@ def _L():
         L.lvk_ekf_take_lost_features.argtypes = [vp, vp, vp, i]; L.lvk_ekf_take_lost_features.restype = i
         L.lvk_ekf_get_state.argtypes = [vp, vp]; L.lvk_ekf_get_state.restype = i
         L.lvk_ekf_get_cov.argtypes = [vp, vp]; L.lvk_ekf_get_cov.restype = i
+        L.lvk_ekf_get_cov_imu.argtypes = [vp, i, vp]; L.lvk_ekf_get_cov_imu.restype = i
         L.lvk_ekf_get_imu_intrinsics.argtypes = [vp, vp]; L.lvk_ekf_get_imu_intrinsics.restype = i
         L.lvk_ekf_set_imu_intrinsics.argtypes = [vp, vp]; L.lvk_ekf_set_imu_intrinsics.restype = i
         L.lvk_ekf_get_clones.argtypes = [vp, vp, i]; L.lvk_ekf_get_clones.restype = i
         L.lvk_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvk_ekf_get_features.restype = i
         L.lvk_ekf_counters.argtypes = [vp, vp]; L.lvk_ekf_counters.restype = None
+        L.lvk_ekf_init_report.argtypes = [vp, vp]; L.lvk_ekf_init_report.restype = C.c_int
         L.lvk_ekf_profile.argtypes = [vp, i, vp]; L.lvk_ekf_profile.restype = i
         L.lvk_ekf_set_shard.argtypes = [vp, i, i, vp, vp]; L.lvk_ekf_set_shard.restype = i
         L.lvk_ekf_shard_stats.argtypes = [vp, vp]; L.lvk_ekf_shard_stats.restype = None
@@ -289,6 +298,10 @@ class LarVio:
     def cov(self):
         N = self.dim; P = np.zeros((N, N)); self.ctx.check(_L().lvk_ekf_get_cov(self._h, _p(P))); return P
 
+    def cov_imu(self, n=9):
+        """the covariance's leading n x n block (n <= 16): what getPpose / getPvel read, served without moving the matrix"""
+        P = np.zeros((n, n)); self.ctx.check(_L().lvk_ekf_get_cov_imu(self._h, n, _p(P))); return P
+
     def clones(self):
         o = np.zeros(256, CLONE); n = _L().lvk_ekf_get_clones(self._h, _p(o), 256); return o[:n].copy()
 
@@ -301,6 +314,18 @@ class LarVio:
         o = np.zeros(8, np.int64); _L().lvk_ekf_counters(self._h, _p(o))
         return dict(hybrid=int(o[0]), msckf=int(o[1]), last_rows=int(o[2]), zupt=int(o[3]), gated_in=int(o[4]), gated_out=int(o[5]),
                     map=int(o[6]), triangulations=int(o[7]))
+
+    def init_report(self):
+        """lvk_ekf_init_report: what the moving-start initialiser handed to the filter + the successful attempt's intermediate results
+        (None until it has succeeded on this handle)"""
+        r = InitReport(); rc = _L().lvk_ekf_init_report(self._h, C.byref(r))
+        if rc != 0:
+            raise LvkError("lvk_ekf_init_report failed (%d)" % rc)
+        if not r.valid:
+            return None
+        a = lambda x, shape=None: np.array(x, np.float64).reshape(shape) if shape else np.array(x, np.float64)
+        return dict(message=r.message, attempts=r.attempts, ransac_calls=r.ransac_calls, l=r.l, n_points=r.n_points, erase=r.erase, state_time=r.state_time, scale=r.scale,
+                    relR=a(r.rel_R, (3, 3)), relT=a(r.rel_T), sfm_R=a(r.sfm_R, (11, 3, 3)), sfm_T=a(r.sfm_T, (11, 3)), bg=a(r.bg), g=a(r.g), q=a(r.q), v=a(r.v))
 
     # reference getters (larvio.cpp:2644-2735)
     def getTbw(self):

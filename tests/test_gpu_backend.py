@@ -174,7 +174,9 @@ def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True, init_args=Non
         for k in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
             worst_x = max(worst_x, _rel(np.asarray(sg[k]), np.asarray(so[k])))
         assert abs(sg["td"] - so["td"]) <= REL * max(abs(so["td"]), 1e-3)
+        Pi = gpu.cov_imu(9)                              # getPpose / getPvel's block, from the update's host-side mirror: read BEFORE anything moves the matrix
         Po, Pg = ora.cov(), gpu.cov()
+        assert np.array_equal(Pi, Pg[:9, :9])            # ... and bit for bit the covariance's own leading block
         worst_P = max(worst_P, _rel(Pg, Po))
         co, cg = ora.clones(), gpu.clones()
         assert np.array_equal(cg["id"], co["id"])

@@ -7,7 +7,9 @@ Levenberg-Marquardt PnP and Schur-complement bundle adjustment stand against num
 rotation-vector parametrisation.  They have to arrive at the same minimum: intermediate results (frame l, relative pose, the window's
 structure-from-motion poses, gyro bias, gravity, metric scale) and the state handed to the filter agree to 1e-13 on noise-free input and
 to 1e-8 with observation / IMU noise (what is left is where each minimiser stops).  findFundamentalMat's RANSAC is "keep everything" on
-both sides here; the GPU suite runs the real kernel (tests/test_gpu_dynamic_init.py)."""
+both sides in the "keep" cases; the "real" cases of every recorded start run cv::findFundamentalMat's restatement (oracle/liblvo.so, bit for
+bit the product kernel's mask and matrix) on both sides, and the GPU suite drives lvk_ekf_process with the kernel itself and compares
+its lvk_ekf_init_report with this restatement fed the kernel's own answers (tests/test_gpu_dynamic_init.py)."""
 import json
 import os
 import shutil
@@ -49,16 +51,29 @@ def _ang(A, B):
     return float(np.linalg.norm(Rotation.from_matrix(np.asarray(A).T @ np.asarray(B)).as_rotvec()))
 
 
+def _sides(replay, rec, sim, R_b2c, t_c_b, ransac):
+    """product (replay harness) and independent restatement on one recorded start; ransac = "keep" (every correspondence an inlier, 8-point
+    fit: the stand-in) or "real" (cv::findFundamentalMat's restatement oracle/liblvo.so on both sides - mask and matrix bit for bit the
+    product kernel's, tests/test_gpu_frontend_stages.py - so the 7-point model hand-off of solve_5pts.cpp:206 is exercised end to end)"""
+    from oracle import dyn_init as D, lvo
+    if ransac == "keep":
+        P = json.loads(subprocess.run([replay, rec], capture_output=True, text=True, check=True, timeout=120).stdout)
+        return P, D.dynamic_init(sim["msgs"], sim["imu"], R_b2c, t_c_b)
+    lvo.lib()                                                                       # builds oracle/liblvo.so if need be
+    so = os.path.join(ROOT, "oracle", "liblvo.so")
+    P = json.loads(subprocess.run([replay, rec, so], capture_output=True, text=True, check=True, timeout=120).stdout)
+    return P, D.dynamic_init(sim["msgs"], sim["imu"], R_b2c, t_c_b, fundamental=lambda a, b, th, cf: lvo.find_fundamental(a, b, th, cf))
+
+
+@pytest.mark.parametrize("ransac", ["keep", "real"])
 @pytest.mark.parametrize("seed,speed,sigma,imu_noise,tol", [(1, 2.0, 0.0, 0.0, 1e-9), (2, 4.0, 3e-4, 1.0, 1e-6), (3, 3.0, 6e-4, 2.0, 1e-6)])
-def test_product_initialiser_against_the_independent_restatement_and_the_truth(replay, tmp_path, seed, speed, sigma, imu_noise, tol):
+def test_product_initialiser_against_the_independent_restatement_and_the_truth(replay, tmp_path, seed, speed, sigma, imu_noise, tol, ransac):
     from larvio_amd import synthetic as S
-    from oracle import dyn_init as D
     tr = S.Trajectory(speed=speed)
     sim = F.simulate(seed, t0=3.5, t1=5.2, sigma=sigma, imu_noise=imu_noise, traj=tr, fresh_ids=True)
     T = np.asarray(S.EUROC["T_cam_imu"], float); R_b2c = T[:3, :3]; t_c_b = -R_b2c.T @ T[:3, 3]
     rec = str(tmp_path / "start.txt"); _record(rec, sim, R_b2c, t_c_b)
-    P = json.loads(subprocess.run([replay, rec], capture_output=True, text=True, check=True, timeout=120).stdout)
-    O = D.dynamic_init(sim["msgs"], sim["imu"], R_b2c, t_c_b)
+    P, O = _sides(replay, rec, sim, R_b2c, t_c_b, ransac)
     assert O is not None and P["message"] == O["message"] == 10                     # the 11th message, first attempt
     assert P["l"] == O["l"] and P["n_points"] == O["n_points"] and P["erase"] == O["erase"] and P["state_time"] == O["state_time"]
     # relative pose of (l, newest): same linear algebra, library SVD against Jacobi
@@ -80,19 +95,18 @@ def test_product_initialiser_against_the_independent_restatement_and_the_truth(r
     assert abs(P["scale"] * np.linalg.norm(PT[10] - PT[P["l"]]) / base_true - 1) < (1e-4 if sigma == 0 else 3e-2 * sigma / 3e-4)      # metric scale from one second of motion: measured 0.2 % at 0.14 px, 4.6 % at 0.28 px and twice the IMU noise
 
 
-def test_window_slides_until_the_platform_moves(replay, tmp_path):
+@pytest.mark.parametrize("ransac", ["keep", "real"])
+def test_window_slides_until_the_platform_moves(replay, tmp_path, ransac):
     """A start from rest seen by the DYNAMIC initialiser alone (in the product the static one would fire first): no parallax, so
     relativePose refuses and the window slides message after message (slideWindow / removeBack, DynamicInitializer.cpp:362-402,
     feature_manager.cpp:205-222); when the platform has moved enough the first attempt that gets through must be the same one on both
     sides, with the same results."""
     from larvio_amd import synthetic as S
-    from oracle import dyn_init as D
     tr = S.Trajectory(speed=3.0)                                                    # rests until 1.2 s, then ramps up
     sim = F.simulate(5, t0=0.3, t1=3.6, sigma=3e-4, imu_noise=1.0, traj=tr, fresh_ids=True)
     T = np.asarray(S.EUROC["T_cam_imu"], float); R_b2c = T[:3, :3]; t_c_b = -R_b2c.T @ T[:3, 3]
     rec = str(tmp_path / "start.txt"); _record(rec, sim, R_b2c, t_c_b)
-    P = json.loads(subprocess.run([replay, rec], capture_output=True, text=True, check=True, timeout=120).stdout)
-    O = D.dynamic_init(sim["msgs"], sim["imu"], R_b2c, t_c_b)
+    P, O = _sides(replay, rec, sim, R_b2c, t_c_b, ransac)
     assert O is not None and P["message"] == O["message"] and P["message"] > 12, (P["message"], None if O is None else O["message"])
     assert P["l"] == O["l"] and P["n_points"] == O["n_points"] and P["erase"] == O["erase"] and P["state_time"] == O["state_time"]
     PT = np.reshape(P["sfm_T"], (-1, 3))
