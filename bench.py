@@ -190,6 +190,9 @@ def preroll(run, frames, d_frames, n_max, sw_size, extra_updates, warmup=0, peri
     return run.i, hp
 
 
+LK_EVENT_STRIDE = int(os.environ.get("LVK_BENCH_LK_EVENT_STRIDE", "5"))
+
+
 def timed(run, frames, d_frames, W, K, dist, torch):
     """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns a dict of measurements."""
     fsz = frames.shape[1] * frames.shape[2]; stride = frames.shape[2]
@@ -219,7 +222,7 @@ def _timed_body(run, feed, W, K, dist, torch):
     pl0, it0 = run.fe.lk_stats()
     mg0 = run.fe.msg_stats()
     c0 = run.be.counters()
-    run.fe.profile_enable(1 << 2)                        # HIP events around the LK launches only (dominant kernel family)
+    run.fe.profile_enable((1 << 2) | (LK_EVENT_STRIDE << 16))   # HIP events around the LK launches (dominant kernel family) of every 5th frame: an event record is a barrier packet on the frame's dependent chain (odd stride: publish and non-publish frames alike)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -716,8 +719,9 @@ def main():
         win = wl["fcfg"]["patch_size"]
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
         lk_bytes = m["lk_pl"] * (win + 3) ** 2 + m["lk_it"] * (win + 1) ** 2
-        lk_ms, lk_launches = m["lk_prof"]
-        achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_launches, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        lk_ms, lk_timed = m["lk_prof"]                   # event-bracketed launches: those of every LK_EVENT_STRIDE-th frame
+        lk_launches = 2 * K                              # two launches per frame (old tracks, new points: fixed-capacity launches with device-side counts)
+        achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_timed, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         # HBM traffic per launch: not measurable inside this process (PMC needs rocprofv3) - taken from the committed counter pass
         # of this same command (profiles/*_pmc_fetch_size.csv; FETCH_SIZE corrected as profiles/README.md's calibration states)
         traffic, traffic_src = None, None
@@ -734,8 +738,10 @@ def main():
         roofline = {"kernel": "k_fe_lk_both<%d> (forward + reverse LK of every track; a second wavefront per track computes the ORB descriptors of the gate in their "
                               "shadow - its bytes are NOT counted in `achieved`)" % win, "bound": "hbm", "achieved": round(achieved, 3),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                    "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_launches, 1) * 1e3, 3),
-                    "launches": lk_launches}
+                    "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_timed, 1) * 1e3, 3),
+                    "launches": lk_launches, "launches_timed": lk_timed,
+                    "timing": "HIP events on the launch's own stream around the LK launches of every %d-th frame of the timed region (an event record is a barrier "
+                              "packet on the frame's dependent chain: bracketing every launch slowed the run it measured by ~10 %%)" % LK_EVENT_STRIDE}
         cpu = None
         if n_cpu:
             his = [int(np.searchsorted(imu_all["t"], float(t) + 0.05, side="left")) for t in ts]

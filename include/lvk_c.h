@@ -183,7 +183,9 @@ lvk_status lvk_frontend_msg_stats(lvk_frontend* fe, uint64_t* messages, uint64_t
 /* Per-stage GPU time measured with HIP events on the context's stream (the reference only times the
  * whole call, app/larvioMain.cpp:106-109).  stage_mask bit i enables stage i; reading synchronises.
  * Stages: 0 pyramid(+CLAHE) 1 orb_prepare 2 lk_fwd 3 lk_rev 4 orb_gate 5 ransac_commit 6 min_eigen
- * 7 gftt_select(mask,max,candidates,select) 8 feature_msg.  LK/ORB/RANSAC stages sum old+new launches. */
+ * 7 gftt_select(mask,max,candidates,select) 8 feature_msg.  LK/ORB/RANSAC stages sum old+new launches.
+ * Bits 16..23 of stage_mask: bracket every n-th frame only (0 or 1: every frame) - an event record is a barrier packet on the frame's
+ * dependent chain, so a measurement that must not slow what it measures samples (bench.py: every 5th frame). */
 #define LVK_FE_STAGES 9
 lvk_status lvk_frontend_profile_enable(lvk_frontend* fe, unsigned stage_mask);
 lvk_status lvk_frontend_profile_read(lvk_frontend* fe, double ms_sum[LVK_FE_STAGES], uint64_t launches[LVK_FE_STAGES], int reset);

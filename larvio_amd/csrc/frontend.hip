@@ -666,11 +666,12 @@ struct lvk_frontend {
     // the data flow allows: ev_pyr / ev_orb (image stream -> main and side: pyramid / ORB planes of this frame ready), ev_new (side
     // stream -> main), ev_commit (main -> side), ev_tail (bootstrap only), ev_main / ev_side (end of a frame on either stream)
     hipEvent_t ev_pyr, ev_orb, ev_new, ev_commit, ev_tail;
+    bool ev_trim = true;                                 // LVK_FE_EVENT_TRIM=0: queue every event record / stream wait as rounds 1-4 did (A/B switch)
     // sticky: a frame that failed AFTER its image stage was queued (device error, ring overrun) leaves the buffer-set rotation and the
     // end-of-frame events out of step with the frame count; the handle then refuses further frames instead of racing on its buffers
     lvk_status failed = LVK_OK; char failed_msg[200] = {0};
     // HIP-event profiling of stages
-    unsigned prof_mask;
+    unsigned prof_mask; unsigned prof_stride; bool prof_take;     // stride: bracket every n-th frame only (event records are barrier packets on the frame's critical chain)
     struct Pending { int stage; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_free;
@@ -686,7 +687,7 @@ static hipEvent_t prof_event(lvk_frontend* fe)
 struct ProfScope {
     lvk_frontend* fe; int stage; hipEvent_t a; bool on;
     hipStream_t st;
-    ProfScope(lvk_frontend* f, int s, hipStream_t stream = nullptr) : fe(f), stage(s), on((f->prof_mask >> s) & 1u), st(stream ? stream : f->ctx->stream)
+    ProfScope(lvk_frontend* f, int s, hipStream_t stream = nullptr) : fe(f), stage(s), on(((f->prof_mask >> s) & 1u) && f->prof_take), st(stream ? stream : f->ctx->stream)
     { if (on) { a = prof_event(fe); hipEventRecord(a, st); } }
     ~ProfScope() { if (on) { hipEvent_t b = prof_event(fe); hipEventRecord(b, st); fe->pending.push_back({stage, a, b}); } }
 };
@@ -833,6 +834,7 @@ lvk_status lvk_frontend_create(lvk_context* ctx, const lvk_fe_config* cfg, lvk_f
     lvk_frontend* fe = new (std::nothrow) lvk_frontend();     // value-initialised: all PODs zero
     if (!fe) return LVK_ERR_DEVICE;
     fe->ctx = ctx; fe->cfg = *cfg; fe->cap = cfg->max_features_num; fe->image_state = 1;
+    { const char* v = getenv("LVK_FE_EVENT_TRIM"); fe->ev_trim = !(v && !strcmp(v, "0")); }
     const int w = cfg->width, h = cfg->height, cap = fe->cap;
     const size_t esz = (size_t)(w + 64) * (h + 64);
     bool ok = true;
@@ -964,6 +966,15 @@ static lvk_status fe_publish(lvk_frontend* fe, int dst, double ts, lvk_feature_o
 // The IMU-independent part of a frame: image upload, createImagePyramids (:318-334) on the main stream, ORBdescriptor ctor (:150)
 // on the side stream as soon as level 0 exists (steady state) or in line (bootstrap frames).  Split out so that a pipelined
 // driver can queue it before it knows which IMU samples the previous update erased (lvk_frontend_begin).
+// A stream wait is a barrier packet on the waiting queue, ~6 us of queue time between two kernels even when the event fired long ago
+// (profiles/r5_d_a_queue_gaps.txt: scharr -> blur 8.3 us with one event record between them against 1.5 us without; the last kernel of
+// a frame -> the next frame's LK 26 us with three).  An event that HAS fired needs no packet: everything recorded before it is done.
+static inline void fe_wait_unless_done(const lvk_frontend* fe, hipStream_t s, hipEvent_t ev)
+{
+    if (fe->ev_trim && hipEventQuery(ev) == hipSuccess) return;
+    (void)hipGetLastError();                             // hipErrorNotReady is not an error
+    hipStreamWaitEvent(s, ev, 0);
+}
 static lvk_status fe_check_image(lvk_frontend* fe, const lvk_image* img)
 {   // a cv::Mat carries its own size; a caller that hands over anything but the configured resolution gets an error, not a read
     // past its buffer (e.g. TUM-VI 512x512 images under a 752x480 configuration)
@@ -1018,7 +1029,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     // ends of frame f-2's two chains is therefore enough, and frame f-1's tracking runs concurrently with this image stage.
     if (fe->n_img >= 2) {
         const int par = (int)(fe->n_img & 1);            // parity of f-2
-        hipStreamWaitEvent(S0, fe->ev_main[par], 0); hipStreamWaitEvent(S0, fe->ev_side[par], 0);
+        fe_wait_unless_done(fe, S0, fe->ev_main[par]); fe_wait_unless_done(fe, S0, fe->ev_side[par]);
     }
     int mosaic_done = 0;
     {
@@ -1026,7 +1037,9 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         st = lvk_pyramid_build_with_orb(icx, fe->pyr[1], d_img, d_stride, c.flag_equalize, 3.0, 8, 8, fe->ext[1], &mosaic_done);
     }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
-    if (slot >= 0 && fe->bar_push) { hipEventRecord(fe->ev_img[slot], S0); fe->ev_img_set[slot] = true; }
+    // (the slot's readers - the two kernels above - are covered by the end-of-frame event of frame f-2 the caller waits for anyway, as in
+    //  the pinned-slot path: no event of their own)
+    if (slot >= 0 && fe->bar_push && !fe->ev_trim) { hipEventRecord(fe->ev_img[slot], S0); fe->ev_img_set[slot] = true; }
     // queued ahead of the frame's tracking (pipelined driver): the ORB planes are done long before anybody asks, one event (ev_orb)
     // stands for the whole stage; queued together with the tracking (blocking API): LK may start as soon as the pyramid exists
     if (!early) hipEventRecord(fe->ev_pyr, S0);
@@ -1121,10 +1134,11 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
     hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
     {   // this frame's pyramid (and ORB planes) come from the image stream
         hipEvent_t ready = fe->pyr_event ? fe->ev_pyr : fe->ev_orb;
-        hipStreamWaitEvent(S1, ready, 0); hipStreamWaitEvent(S2, ready, 0);
+        if (!(fe->ev_trim && hipEventQuery(ready) == hipSuccess)) { (void)hipGetLastError(); hipStreamWaitEvent(S1, ready, 0); hipStreamWaitEvent(S2, ready, 0); }
     }
     // the side stream reads (new points, their count) and overwrites (wn_*) what the previous frame's commits on the main stream used
     if (fe->n_img >= 2) hipStreamWaitEvent(S2, fe->ev_main[fe->n_img & 1], 0);
+    fe->prof_take = fe->prof_stride <= 1 || fe->n_img % fe->prof_stride == 0;
     fe->curr_img_time = ts;
     const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
     const int src = fe->cur, dst = fe->cur ^ 1;
@@ -1158,7 +1172,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             if (!fe->h_dev->boot_ok) fe->image_state = 1;
             else {
                 curr_valid = true;
-                hipEventRecord(fe->ev_commit, S1);
+                if (!fe->ev_trim || ts - fe->last_pub_time >= pub_gate) hipEventRecord(fe->ev_commit, S1);      // only the detection of a publish frame waits for it
                 if (ts - fe->last_pub_time >= pub_gate) {
                     st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                     if (st != LVK_OK) return st;
@@ -1185,7 +1199,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st != LVK_OK) return st;
             curr_valid = true;
-            hipEventRecord(fe->ev_commit, S1);
+            if (!fe->ev_trim || ts - fe->last_pub_time >= pub_gate) hipEventRecord(fe->ev_commit, S1);          // only the detection of a publish frame waits for it
             FT(FT_COMMIT_LAUNCH);
             if (ts - fe->last_pub_time >= pub_gate) {
                 st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
@@ -1246,7 +1260,7 @@ lvk_status lvk_frontend_profile_enable(lvk_frontend* fe, unsigned stage_mask)
 {
     if (!fe) return LVK_ERR_ARG;
     prof_collect(fe);
-    fe->prof_mask = stage_mask;
+    fe->prof_mask = stage_mask & 0xFFFFu; fe->prof_stride = (stage_mask >> 16) & 0xFFu; fe->prof_take = true;
     return LVK_OK;
 }
 lvk_status lvk_frontend_profile_read(lvk_frontend* fe, double ms_sum[LVK_FE_STAGES], uint64_t launches[LVK_FE_STAGES], int reset)
