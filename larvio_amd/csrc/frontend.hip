@@ -659,6 +659,8 @@ struct lvk_frontend {
     // so with three buffer sets they run ahead of the tracking chain of the previous frame (~55 us per frame off the main chain).
     lvk_context* side[2];
     hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};   // end of frame f's work on the main / side stream, by parity of f
+    hipEvent_t ev_end[2] = {nullptr, nullptr};           // what stands for "frame f's main-stream work is done": ev_main[par], or the message's own event when the frame published (nothing follows it on that stream: one record, not two)
+    int last_msg_slot = -1;                              // ring entry of the message published by the current frame (-1: none)
     long n_img = 0;                                                                // image stages queued so far
     bool image_done; double image_done_ts;       // lvk_frontend_begin already queued this frame's image stage
     bool pyr_event = true;                       // this frame's image stage recorded ev_pyr (blocking API); false: ev_orb stands for the whole stage
@@ -939,6 +941,7 @@ static FeMsgArgs fe_msg_args(lvk_frontend* fe, int slot)
 static lvk_status fe_publish_finish(lvk_frontend* fe, int dst, double ts, int slot, lvk_feature_obs* h_out, int cap, int* n_out, int* async_slot)
 {
     hipEventRecord(fe->ev_msg[slot], fe->ctx->stream);
+    fe->last_msg_slot = slot;
     fe->msg_pending[slot].store(1, std::memory_order_release);
     FT(FT_PUBLISH);
     lvk_status st = fe_detect_new(fe, dst);              // queued on side[0] before anybody blocks on the message
@@ -998,7 +1001,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     if (!image->is_device && fe->bar_push && !early) {
         slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
         if (fe->ev_img_set[slot]) LVK_HIP(ctx, hipEventSynchronize(fe->ev_img[slot]));      // the kernels that read this buffer three frames ago
-        if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_main[fe->n_img & 1]));   // (the same bound on frames in flight as the pinned-slot path)
+        if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_end[fe->n_img & 1]));   // (the same bound on frames in flight as the pinned-slot path)
         FT(FT_SLOT_WAIT);
         uint8_t* dd = fe->d_ring[slot];
         if (image->stride == c.width) memcpy(dd, image->data, (size_t)c.width * c.height);
@@ -1011,7 +1014,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
         slot = fe->stage_next; fe->stage_next = (slot + 1) % 3;
         // The slot was last used three frames back.  Its upload precedes frame f-2's image stage on the image stream, which the
         // main stream waited for before it recorded the end of frame f-2: that event covers it (and has long fired) - no per-slot event.
-        if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_main[fe->n_img & 1]));
+        if (fe->n_img >= 3) LVK_HIP(ctx, hipEventSynchronize(fe->ev_end[fe->n_img & 1]));
         FT(FT_SLOT_WAIT);
         uint8_t* hs = fe->h_stage[slot];
         if (image->stride == c.width) memcpy(hs, image->data, (size_t)c.width * c.height);
@@ -1029,7 +1032,7 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     // ends of frame f-2's two chains is therefore enough, and frame f-1's tracking runs concurrently with this image stage.
     if (fe->n_img >= 2) {
         const int par = (int)(fe->n_img & 1);            // parity of f-2
-        fe_wait_unless_done(fe, S0, fe->ev_main[par]); fe_wait_unless_done(fe, S0, fe->ev_side[par]);
+        fe_wait_unless_done(fe, S0, fe->ev_end[par]); fe_wait_unless_done(fe, S0, fe->ev_side[par]);
     }
     int mosaic_done = 0;
     {
@@ -1137,8 +1140,9 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         if (!(fe->ev_trim && hipEventQuery(ready) == hipSuccess)) { (void)hipGetLastError(); hipStreamWaitEvent(S1, ready, 0); hipStreamWaitEvent(S2, ready, 0); }
     }
     // the side stream reads (new points, their count) and overwrites (wn_*) what the previous frame's commits on the main stream used
-    if (fe->n_img >= 2) hipStreamWaitEvent(S2, fe->ev_main[fe->n_img & 1], 0);
+    if (fe->n_img >= 2) hipStreamWaitEvent(S2, fe->ev_end[fe->n_img & 1], 0);
     fe->prof_take = fe->prof_stride <= 1 || fe->n_img % fe->prof_stride == 0;
+    fe->last_msg_slot = -1;
     fe->curr_img_time = ts;
     const double pub_gate = 0.9 * (1.0 / c.pub_frequency);
     const int src = fe->cur, dst = fe->cur ^ 1;
@@ -1209,7 +1213,10 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         }
     }
     if (!curr_valid) LVK_HIP(ctx, hipMemsetAsync(&fe->dev->n_tracks[dst], 0, sizeof(int), ctx->stream));
-    { const int par = (int)((fe->n_img - 1) & 1); hipEventRecord(fe->ev_main[par], S1); hipEventRecord(fe->ev_side[par], S2); }
+    {   const int par = (int)((fe->n_img - 1) & 1);
+        if (fe->ev_trim && fe->last_msg_slot >= 0 && curr_valid) fe->ev_end[par] = fe->ev_msg[fe->last_msg_slot];     // recorded right behind the message kernel, the frame's last launch on this stream
+        else { hipEventRecord(fe->ev_main[par], S1); fe->ev_end[par] = fe->ev_main[par]; }
+        hipEventRecord(fe->ev_side[par], S2); }
     // rotation (:207-216), three-way: curr becomes prev, the spare set becomes the next frame's curr
     { lvk_pyramid* p = fe->pyr[0]; fe->pyr[0] = fe->pyr[1]; fe->pyr[1] = fe->pyr[2]; fe->pyr[2] = p; }
     { uint8_t* p = fe->ext[0]; fe->ext[0] = fe->ext[1]; fe->ext[1] = fe->ext[2]; fe->ext[2] = p;
