@@ -365,7 +365,7 @@ __device__ __forceinline__ void cov_at(const uint8_t* __restrict__ s0, int sstri
 }
 
 __global__ void __launch_bounds__(256) k_min_eigen(const uint8_t* __restrict__ s0, int w, int h, int sstride,
-                                                  float* __restrict__ eig, uint8_t* __restrict__ mask_init /* optional: the detection mask (w x h) is set to 255 on the way - no fill launch */)
+                                                  float* __restrict__ eig)
 {
     __shared__ float cv[3][EG_TY + 2][EG_TX + 2];
     __shared__ float hs[3][EG_TY + 2][EG_TX];
@@ -396,7 +396,6 @@ __global__ void __launch_bounds__(256) k_min_eigen(const uint8_t* __restrict__ s
         for (int c = 0; c < 3; ++c) s[c] = (hs[c][ry][rx] + hs[c][ry + 1][rx]) + hs[c][ry + 2][rx];
         float a = s[0] * 0.5f, b = s[1], c2 = s[2] * 0.5f;
         eig[(size_t)gy * w + gx] = (a + c2) - sqrtf((a - c2) * (a - c2) + b * b);
-        if (mask_init) mask_init[(size_t)gy * w + gx] = 255;
     }
 }
 
@@ -435,7 +434,7 @@ __global__ void __launch_bounds__(256) k_masked_max(const float* __restrict__ ei
 // The frame path's detection mask and the masked maximum of the response map in ONE pass (findNewFeaturesToBeTracked's mask, image_processor.cpp:1005-1030,
 // and goodFeaturesToTrack's minMaxLoc under it): a workgroup owns MM_ROWS image rows, builds their mask in LDS - all 255, then the row
 // segments of every (2 md + 1)^2 box around round(pt) that reaches into the strip, zeroed -, writes it out for k_gftt_candidates and takes the
-// maximum of the response values it leaves visible (one atomicMax per workgroup).  Same bytes as k_mask_boxes on a 255-filled image, same
+// maximum of the response values it leaves visible (one atomicMax per workgroup).  Same bytes as a 255-filled image with the boxes cut out (rounds 1-4: a fill and a kernel of one workgroup per box), same
 // key as k_masked_max; one launch and one kernel boundary instead of a fill and two launches on the chain commit -> detection -> the next
 // frame's new-point tracking.  The strip's response values are requested before the mask is built (they do not depend on it).
 #define MM_ROWS 4
@@ -826,23 +825,6 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
     if (t == 0) { *n_out = sh_na < out_cap ? sh_na : out_cap; for (int q = 0; q < GF_SCRATCH_UINTS; ++q) scratch[q] = 0u; }   // every thread read scratch[1] many barriers ago
 }
 
-// mask with zeroed (2*md+1)^2 boxes around round(pt)  (image_processor.cpp:1009-1030)
-__global__ void k_mask_boxes(const lvk_pt2f* __restrict__ pts, const int* __restrict__ n_pts, int w, int h, int md,
-                             uint8_t* __restrict__ mask)
-{
-    int i = blockIdx.x;
-    if (i >= *n_pts) return;
-    // round(): half away from zero on the float coordinate
-    int ry = (int)roundf(pts[i].y), rx = (int)roundf(pts[i].x);
-    int r0 = max(ry - md, 0), r1 = min(ry + md, h - 1), c0 = max(rx - md, 0), c1 = min(rx + md, w - 1);
-    int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
-    if (bw <= 0 || bh <= 0) return;
-    for (int k = threadIdx.x; k < bw * bh; k += blockDim.x) {
-        int yy = k / bw, xx = k - yy * bw;
-        mask[(size_t)(r0 + yy) * w + c0 + xx] = 0;
-    }
-}
-
 // =========================================================================== host side of the ABI
 extern "C" {
 
@@ -1028,24 +1010,12 @@ lvk_status lvk_min_eigen_map(lvk_context* ctx, const lvk_pyramid* p, float* d_ei
     if (!ctx || !p || !d_eig) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_min_eigen_map: bad argument");
     const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
     hipLaunchKernelGGL(k_min_eigen, dim3((p->w[0] + EG_TX - 1) / EG_TX, (p->h[0] + EG_TY - 1) / EG_TY), dim3(256), 0, ctx->stream,
-                       s0, p->w[0], p->h[0], p->istride[0], d_eig, (uint8_t*)nullptr);
+                       s0, p->w[0], p->h[0], p->istride[0], d_eig);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }
 
 }  // extern "C"
-
-// internal (frame path): the response map and, in the same pass, the detection mask set to 255 everywhere (findNewFeaturesToBeTracked'
-// cv::Mat mask(..., Scalar(255)), image_processor.cpp:1005-1008) - the boxes are cut out later by lvk_mask_boxes(prepared = true)
-lvk_status lvk_min_eigen_map_mask(lvk_context* ctx, const lvk_pyramid* p, float* d_eig, uint8_t* d_mask)
-{
-    if (!ctx || !p || !d_eig) return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_min_eigen_map: bad argument");
-    const uint8_t* s0 = p->img[0] + (size_t)p->pad * p->istride[0] + p->pad;
-    hipLaunchKernelGGL(k_min_eigen, dim3((p->w[0] + EG_TX - 1) / EG_TX, (p->h[0] + EG_TY - 1) / EG_TY), dim3(256), 0, ctx->stream,
-                       s0, p->w[0], p->h[0], p->istride[0], d_eig, d_mask);
-    LVK_LAUNCH_CHECK(ctx);
-    return LVK_OK;
-}
 
 // internal: GFTT on a precomputed eig map with caller-provided scratch (used by the frame-level path too)
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
@@ -1067,23 +1037,6 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
     LVK_LDS_OPTIN(ctx, 2, k_gftt_select, shm);   // the opt-in must leave room for the kernel's static LDS: ask for what is launched
     hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), shm, ctx->stream, (const unsigned long long*)d_cands, cand_cap, w, h, max_corners, cell,
                        (float)(min_distance * min_distance), d_scratch, d_out, cap, d_n_out, d_sub);
-    LVK_LAUNCH_CHECK(ctx);
-    return LVK_OK;
-}
-
-// the two clears of a detection (mask image, selection scratch): they depend on nothing but the previous detection on the same stream,
-// so the frame path queues them BEFORE it waits for the frame's commit - two dispatches less on the chain commit -> detection -> next
-// frame's new-point tracking, which is what bounds the front-end's frame rate (profiles/r4_y_frontend_caller_trace.txt)
-lvk_status lvk_gftt_prepare(lvk_context* ctx, uint8_t* d_mask, int w, int h, unsigned* d_scratch)
-{
-    if (d_mask) LVK_HIP(ctx, hipMemsetAsync(d_mask, 255, (size_t)w * h, ctx->stream));
-    LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
-    return LVK_OK;
-}
-lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask, bool prepared)
-{
-    if (!prepared) LVK_HIP(ctx, hipMemsetAsync(d_mask, 255, (size_t)w * h, ctx->stream));
-    if (max_pts > 0) hipLaunchKernelGGL(k_mask_boxes, dim3(max_pts), dim3(256), 0, ctx->stream, d_pts, d_n, w, h, md, d_mask);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

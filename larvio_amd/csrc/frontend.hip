@@ -21,10 +21,7 @@
 lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_mask, int w, int h, int max_corners,
                         double quality, double min_distance, unsigned* d_scratch, unsigned long long* d_cands, int cand_cap,
                         lvk_pt2f* d_out, int cap, int* d_n_out, const int* d_sub, bool prepared, bool max_done);
-lvk_status lvk_gftt_prepare(lvk_context* ctx, uint8_t* d_mask, int w, int h, unsigned* d_scratch);
-lvk_status lvk_min_eigen_map_mask(lvk_context* ctx, const lvk_pyramid* p, float* d_eig, uint8_t* d_mask);
 lvk_status lvk_mask_and_max(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int w, int h, int md, const float* d_eig, uint8_t* d_mask, unsigned* d_scratch);
-lvk_status lvk_mask_boxes(lvk_context* ctx, const lvk_pt2f* d_pts, const int* d_n, int max_pts, int w, int h, int md, uint8_t* d_mask, bool prepared);
 
 // =========================================================================== runtime environment, BAR self-test
 // plain loads, as the product kernels do them
