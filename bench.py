@@ -295,16 +295,20 @@ def cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_sample, all_cpus):
     legs = {}
     i = n_pre
 
-    def leg(nt, n):
+    def leg(nt, n, budget_s=None):
+        # budget_s: a leg of the thread sweep ends early once it has used that much wall time (an oversubscribed thread count can be
+        # a thousand times slower than the best one: r5_a measured 0.08 frames/s with 256 threads - 460 s for one sweep leg)
         nonlocal i
         lvo.set_threads(nt)
-        c_fe = c_be = 0.0
+        c_fe = c_be = 0.0; done = 0
         t0 = time.perf_counter()
         for _ in range(n):
-            a, b = one(i); c_fe += a; c_be += b; i += 1
+            a, b = one(i); c_fe += a; c_be += b; i += 1; done += 1
+            if budget_s is not None and time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
-        return dict(value=round(n / dt, 2), cores=nt, seconds=round(dt, 2), front_end_ms_per_frame=round(c_fe / n * 1e3, 3),
-                    back_end_ms_per_frame=round(c_be / n * 1e3, 3))
+        return dict(value=round(done / dt, 2), cores=nt, seconds=round(dt, 2), frames=done, front_end_ms_per_frame=round(c_fe / done * 1e3, 3),
+                    back_end_ms_per_frame=round(c_be / done * 1e3, 3))
     legs["one_thread"] = leg(1, n_sample)
     # The multi-threaded leg: at these sizes (0.36 MB images, ~150 tracks) fork/join of hundreds of threads costs more than the loops
     # it spreads, so the thread count is swept on short samples and the best one is timed over the full sample; the all-core figure
@@ -312,10 +316,12 @@ def cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_sample, all_cpus):
     n_short = max(16, n_sample // 8)
     sweep = {}
     for nt in sorted(set(x for x in (4, 8, 16, 32, 64, ncores) if x <= ncores)):
-        sweep[nt] = leg(nt, n_short)
+        sweep[nt] = leg(nt, n_short, budget_s=2.0)
+        if nt >= 16 and sweep[nt]["value"] < 0.25 * max(v["value"] for v in sweep.values()):
+            break                                        # past the knee: more threads only oversubscribe (the all-core figure is then the last one measured)
     best_nt = max(sweep, key=lambda k: sweep[k]["value"])
     legs["best"] = leg(best_nt, n_sample)
-    legs["all_cores"] = sweep[ncores]
+    legs["all_cores"] = sweep[max(sweep)]
     lvo.set_threads(1)
     dim_cpu = orb.dim
     one_t = legs["one_thread"]
@@ -323,7 +329,7 @@ def cpu_baseline(wl, frames, ts, imu_all, his, seq, n_pre, n_sample, all_cpus):
             "front_end_ms_per_frame": one_t["front_end_ms_per_frame"], "back_end_ms_per_frame": one_t["back_end_ms_per_frame"],
             "all_cores": {"value": legs["best"]["value"], "cores": legs["best"]["cores"], "front_end_ms_per_frame": legs["best"]["front_end_ms_per_frame"],
                           "back_end_ms_per_frame": legs["best"]["back_end_ms_per_frame"], "host_cores": ncores,
-                          "every_core": {"value": legs["all_cores"]["value"], "cores": ncores},
+                          "every_core": {"value": legs["all_cores"]["value"], "cores": legs["all_cores"]["cores"]},
                           "sweep_frames_per_s": {str(k): v["value"] for k, v in sweep.items()},
                           "note": "OpenMP over image rows, CLAHE tiles, tracks, key points and the dense update's rows/columns (bit-identical results); "
                                   "thread count swept over 4..all host cores on short samples, the best one timed over the full sample"},
