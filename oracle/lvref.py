@@ -1,5 +1,6 @@
-"""ctypes binding of oracle/_ref/liblvref_orb.so: the REFERENCE's own ORB descriptor code (/root/reference/src/ORBDescriptor.cpp,
-include/ORB/ORBDescriptor.h), compiled in place against the OpenCV stand-ins of oracle/ref_shim/ (oracle/Makefile, target `ref`).
+"""ctypes binding of oracle/_ref/liblvref_orb.so and liblvref_feature.so: the REFERENCE's own ORB descriptor code
+(/root/reference/src/ORBDescriptor.cpp, include/ORB/ORBDescriptor.h) and Feature code (include/larvio/feature.hpp: checkMotion and the
+initializePosition family), compiled in place against the OpenCV / Eigen stand-ins of oracle/ref_shim/ (oracle/Makefile, target `ref`).
 TEST INFRASTRUCTURE ONLY: it pins the restatement in oracle/fe_track.c / fe_image.c; the product never loads it.
 The library is built here (where /root/reference exists) by __graft_entry__.build(); on the GPU box only the prebuilt file exists."""
 import ctypes as C
@@ -78,3 +79,54 @@ class RefOrb:
 def hamming(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().lvref_orb_hamming(a.ctypes.data, b.ctypes.data)
+
+
+# ---------------------------------------------------------------------------------------------- the reference's Feature code
+_SO_F = os.path.join(_HERE, "_ref", "liblvref_feature.so")
+_lib_f = None
+
+
+def feature_available(build=True):
+    if os.path.exists(_SO_F):
+        return True
+    if build and os.path.isdir("/root/reference/include/larvio"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_F)
+
+
+def _libf():
+    global _lib_f
+    if _lib_f is None:
+        if not feature_available():
+            raise RuntimeError("oracle/_ref/liblvref_feature.so is missing and /root/reference is not here to build it from")
+        L = C.CDLL(_SO_F)
+        vp, i, ll, d = C.c_void_p, C.c_int, C.c_longlong, C.c_double
+        L.lvref_feature_initialize.argtypes = [i, i, vp, vp, vp, i, vp, vp, ll, i, vp, vp]; L.lvref_feature_initialize.restype = i
+        L.lvref_feature_check_motion.argtypes = [i, vp, vp, vp, i, vp, vp, i, d]; L.lvref_feature_check_motion.restype = i
+        _lib_f = L
+    return _lib_f
+
+
+def _views(state_ids, q_cam, p_cam, obs_ids, obs_uv):
+    return (np.ascontiguousarray(state_ids, np.int64), np.ascontiguousarray(q_cam, np.float64).reshape(-1, 4), np.ascontiguousarray(p_cam, np.float64).reshape(-1, 3),
+            np.ascontiguousarray(obs_ids, np.int64), np.ascontiguousarray(obs_uv, np.float64).reshape(-1, 2))
+
+
+def feature_initialize(mode, state_ids, q_cam, p_cam, obs_ids, obs_uv, curr_id=-1, is_initialized=False, position_in=None):
+    """Feature::initializePosition (mode 0, feature.hpp:383-552), initializePosition_AssignAnchor (1, :554-721) or
+    initializeInvParamPosition (2, :723-890) of the compiled reference on a feature with the given observations (state id -> (u, v)) and
+    camera states (id -> orientation_cam [x y z w], position_cam).  -> (ok, dict of the feature's members after the call)"""
+    sid, q, p, oid, uv = _views(state_ids, q_cam, p_cam, obs_ids, obs_uv)
+    pin = np.ascontiguousarray(position_in if position_in is not None else np.zeros(3), np.float64)
+    out = np.zeros(15)
+    ok = _libf().lvref_feature_initialize(int(mode), len(sid), sid.ctypes.data, q.ctypes.data, p.ctypes.data, len(oid), oid.ctypes.data, uv.ctypes.data,
+                                          int(curr_id), int(bool(is_initialized)), pin.ctypes.data, out.ctypes.data)
+    return bool(ok), dict(position=out[0:3].copy(), position_fej=out[3:6].copy(), inv_depth=float(out[6]), obs_anchor=out[7:10].copy(), id_anchor=int(out[10]),
+                          inv_param=out[11:14].copy(), is_initialized=bool(out[14]))
+
+
+def feature_check_motion(state_ids, q_cam, p_cam, obs_ids, obs_uv, if_tracked, translation_threshold):
+    """Feature::checkMotion (feature.hpp:334-381) of the compiled reference"""
+    sid, q, p, oid, uv = _views(state_ids, q_cam, p_cam, obs_ids, obs_uv)
+    return bool(_libf().lvref_feature_check_motion(len(sid), sid.ctypes.data, q.ctypes.data, p.ctypes.data, len(oid), oid.ctypes.data, uv.ctypes.data,
+                                                   int(bool(if_tracked)), float(translation_threshold)))

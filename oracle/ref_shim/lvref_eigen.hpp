@@ -1,0 +1,213 @@
+// lvref_eigen.hpp — ORACLE / TEST INFRASTRUCTURE ONLY.  A stand-in for the slice of Eigen 3 that /root/reference/include/larvio/feature.hpp,
+// imu_state.h and math_utils.hpp use, so that those reference headers can be compiled WHERE THEY LIE (oracle/Makefile, target `ref`) on a
+// machine without Eigen.  Fixed-size dense matrices with eager evaluation, the Isometry3d / Quaterniond members the headers call, and a
+// pivoted LDL^T for the 3x3 solve.  Inner products run over the summation index in ascending order, as Eigen's coefficient-wise lazy
+// products of small fixed-size matrices do - but no claim is made about Eigen's rounding: what the compiled reference pins is its
+// ALGORITHM TEXT (initial guess, Levenberg-Marquardt schedule, Huber weights, validity tests, frame and quaternion conventions), and the
+// tests compare at 1e-9, not bit for bit.  Nothing in the product includes this file.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <memory>
+#include <vector>
+#include <map>
+#include <algorithm>
+
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+namespace Eigen {
+
+template <typename T> using aligned_allocator = std::allocator<T>;
+
+template <typename T, int R, int C> class Matrix;
+
+// assignable view of a block of a parent matrix (row(), leftCols<>(), rightCols<>(), head<>())
+template <typename T, int PR, int PC, int BR, int BC> class BlockRef {
+public:
+    BlockRef(T* base, int r0, int c0) : b_(base), r0_(r0), c0_(c0) {}
+    T& at(int i, int j) const { return b_[(size_t)(c0_ + j) * PR + (r0_ + i)]; }
+    Matrix<T, BR, BC> eval() const;
+    operator Matrix<T, BR, BC>() const { return eval(); }
+    BlockRef& operator=(const Matrix<T, BR, BC>& m);
+    BlockRef& operator=(const BlockRef& o) { return *this = o.eval(); }
+    template <int QR, int QC> BlockRef& operator=(const BlockRef<T, QR, QC, BR, BC>& o) { return *this = o.eval(); }
+    T& operator()(int i) const { return BR == 1 ? at(0, i) : at(i, 0); }
+    T& operator()(int i, int j) const { return at(i, j); }
+    friend Matrix<T, BR, BC> operator*(T s, const BlockRef& b) { return s * b.eval(); }
+    friend Matrix<T, BR, BC> operator*(const BlockRef& b, T s) { return b.eval() * s; }
+    friend Matrix<T, BR, BC> operator/(const BlockRef& b, T s) { return b.eval() / s; }
+    friend Matrix<T, BR, BC> operator+(const BlockRef& a, const BlockRef& b) { return a.eval() + b.eval(); }
+    friend Matrix<T, BR, BC> operator-(const BlockRef& a, const BlockRef& b) { return a.eval() - b.eval(); }
+    friend Matrix<T, BR, BC> operator+(const Matrix<T, BR, BC>& a, const BlockRef& b) { return a + b.eval(); }
+    friend Matrix<T, BR, BC> operator-(const Matrix<T, BR, BC>& a, const BlockRef& b) { return a - b.eval(); }
+    friend Matrix<T, BR, BC> operator+(const BlockRef& a, const Matrix<T, BR, BC>& b) { return a.eval() + b; }
+    friend Matrix<T, BR, BC> operator-(const BlockRef& a, const Matrix<T, BR, BC>& b) { return a.eval() - b; }
+private:
+    T* b_; int r0_, c0_;
+};
+
+template <typename T, int N> struct LDLT3 {
+    // symmetric pivoting as Eigen's LDLT (largest remaining |diagonal| first); N x N, N <= 4
+    T L[N][N]; T D[N]; int perm[N];
+    explicit LDLT3(const Matrix<T, N, N>& A);
+    Matrix<T, N, 1> solve(const Matrix<T, N, 1>& b) const;
+};
+
+template <typename T, int R, int C> class Matrix {
+public:
+    Matrix() { for (int i = 0; i < R * C; ++i) d_[i] = T(0); }
+    Matrix(T x, T y) { static_assert(R * C == 2, "2-vector"); d_[0] = x; d_[1] = y; }
+    Matrix(T x, T y, T z) { static_assert(R * C == 3, "3-vector"); d_[0] = x; d_[1] = y; d_[2] = z; }
+    Matrix(T x, T y, T z, T w) { static_assert(R * C == 4, "4-vector"); d_[0] = x; d_[1] = y; d_[2] = z; d_[3] = w; }
+    template <int PR, int PC> Matrix(const BlockRef<T, PR, PC, R, C>& b) { *this = b.eval(); }
+    static Matrix Zero() { return Matrix(); }
+    static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
+    T& operator()(int i, int j) { return d_[(size_t)j * R + i]; }
+    const T& operator()(int i, int j) const { return d_[(size_t)j * R + i]; }
+    T& operator()(int i) { return d_[i]; }
+    const T& operator()(int i) const { return d_[i]; }
+    T& operator[](int i) { return d_[i]; }
+    const T& operator[](int i) const { return d_[i]; }
+    T* data() { return d_; }
+    const T* data() const { return d_; }
+    int rows() const { return R; }
+    int cols() const { return C; }
+    int size() const { return R * C; }
+    // a 1x1 result is a scalar (double depth = (A^T A)^-1 A^T b)
+    template <int RR = R, int CC = C, typename = typename std::enable_if<RR == 1 && CC == 1>::type> operator T() const { return d_[0]; }
+    Matrix<T, C, R> transpose() const { Matrix<T, C, R> m; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) m(j, i) = (*this)(i, j); return m; }
+    T squaredNorm() const { T s = d_[0] * d_[0]; for (int i = 1; i < R * C; ++i) s += d_[i] * d_[i]; return s; }
+    T norm() const { return std::sqrt(squaredNorm()); }
+    void normalize() { const T n = norm(); for (int i = 0; i < R * C; ++i) d_[i] /= n; }
+    Matrix normalized() const { Matrix m = *this; m.normalize(); return m; }
+    T trace() const { T s = (*this)(0, 0); for (int i = 1; i < (R < C ? R : C); ++i) s += (*this)(i, i); return s; }
+    T dot(const Matrix& o) const { T s = d_[0] * o.d_[0]; for (int i = 1; i < R * C; ++i) s += d_[i] * o.d_[i]; return s; }
+    T maxCoeff(int* idx) const { int b = 0; for (int i = 1; i < R * C; ++i) if (d_[i] > d_[b]) b = i; *idx = b; return d_[b]; }
+    T maxCoeff() const { int i; return maxCoeff(&i); }
+    T maxCoeff(int* row, int* col) const { int br = 0, bc = 0; for (int j = 0; j < C; ++j) for (int i = 0; i < R; ++i) if ((*this)(i, j) > (*this)(br, bc)) { br = i; bc = j; } *row = br; *col = bc; return (*this)(br, bc); }
+    Matrix inverse() const { static_assert(R == 1 && C == 1, "only the 1x1 inverse is needed"); Matrix m; m.d_[0] = T(1) / d_[0]; return m; }
+    Matrix<T, 3, 1> cross(const Matrix<T, 3, 1>& o) const
+    { return Matrix<T, 3, 1>(d_[1] * o(2) - d_[2] * o(1), d_[2] * o(0) - d_[0] * o(2), d_[0] * o(1) - d_[1] * o(0)); }
+    void setZero() { for (int i = 0; i < R * C; ++i) d_[i] = T(0); }
+    void setIdentity() { *this = Identity(); }
+    LDLT3<T, R> ldlt() const { static_assert(R == C, "square"); return LDLT3<T, R>(*this); }
+    // blocks
+    BlockRef<T, R, C, 1, C> row(int i) { return BlockRef<T, R, C, 1, C>(d_, i, 0); }
+    Matrix<T, 1, C> row(int i) const { Matrix<T, 1, C> m; for (int j = 0; j < C; ++j) m(0, j) = (*this)(i, j); return m; }
+    BlockRef<T, R, C, R, 1> col(int j) { return BlockRef<T, R, C, R, 1>(d_, 0, j); }
+    Matrix<T, R, 1> col(int j) const { Matrix<T, R, 1> m; for (int i = 0; i < R; ++i) m(i) = (*this)(i, j); return m; }
+    template <int N> BlockRef<T, R, C, R, N> leftCols() { return BlockRef<T, R, C, R, N>(d_, 0, 0); }
+    template <int N> Matrix<T, R, N> leftCols() const { Matrix<T, R, N> m; for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) m(i, j) = (*this)(i, j); return m; }
+    template <int N> BlockRef<T, R, C, R, N> rightCols() { return BlockRef<T, R, C, R, N>(d_, 0, C - N); }
+    template <int N> Matrix<T, R, N> rightCols() const { Matrix<T, R, N> m; for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) m(i, j) = (*this)(i, C - N + j); return m; }
+    template <int N> BlockRef<T, R, C, N, 1> head() { static_assert(C == 1, "vector"); return BlockRef<T, R, C, N, 1>(d_, 0, 0); }
+    template <int N> Matrix<T, N, 1> head() const { Matrix<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = d_[i]; return m; }
+    template <int BR_, int BC_> BlockRef<T, R, C, BR_, BC_> block(int r0, int c0) { return BlockRef<T, R, C, BR_, BC_>(d_, r0, c0); }
+    template <int BR_, int BC_> Matrix<T, BR_, BC_> block(int r0, int c0) const { Matrix<T, BR_, BC_> m; for (int i = 0; i < BR_; ++i) for (int j = 0; j < BC_; ++j) m(i, j) = (*this)(r0 + i, c0 + j); return m; }
+    // arithmetic
+    Matrix operator-() const { Matrix m; for (int i = 0; i < R * C; ++i) m.d_[i] = -d_[i]; return m; }
+    Matrix& operator+=(const Matrix& o) { for (int i = 0; i < R * C; ++i) d_[i] += o.d_[i]; return *this; }
+    Matrix& operator-=(const Matrix& o) { for (int i = 0; i < R * C; ++i) d_[i] -= o.d_[i]; return *this; }
+    Matrix& operator*=(T s) { for (int i = 0; i < R * C; ++i) d_[i] *= s; return *this; }
+    Matrix& operator/=(T s) { for (int i = 0; i < R * C; ++i) d_[i] /= s; return *this; }
+    friend Matrix operator+(const Matrix& a, const Matrix& b) { Matrix m; for (int i = 0; i < R * C; ++i) m.d_[i] = a.d_[i] + b.d_[i]; return m; }
+    friend Matrix operator-(const Matrix& a, const Matrix& b) { Matrix m; for (int i = 0; i < R * C; ++i) m.d_[i] = a.d_[i] - b.d_[i]; return m; }
+    friend Matrix operator*(T s, const Matrix& a) { Matrix m; for (int i = 0; i < R * C; ++i) m.d_[i] = s * a.d_[i]; return m; }
+    friend Matrix operator*(const Matrix& a, T s) { Matrix m; for (int i = 0; i < R * C; ++i) m.d_[i] = a.d_[i] * s; return m; }
+    friend Matrix operator/(const Matrix& a, T s) { Matrix m; for (int i = 0; i < R * C; ++i) m.d_[i] = a.d_[i] / s; return m; }
+    template <int K> Matrix<T, R, K> operator*(const Matrix<T, C, K>& o) const
+    {
+        Matrix<T, R, K> m;
+        for (int i = 0; i < R; ++i) for (int k = 0; k < K; ++k) { T s = (*this)(i, 0) * o(0, k); for (int j = 1; j < C; ++j) s += (*this)(i, j) * o(j, k); m(i, k) = s; }
+        return m;
+    }
+    // comma initialiser (row-major fill, as Eigen's)
+    struct Comma {
+        Matrix& m; int n;
+        Comma& operator,(T v) { m((n / C), (n % C)) = v; ++n; return *this; }
+    };
+    Comma operator<<(T v) { (*this)(0, 0) = v; return Comma{*this, 1}; }
+private:
+    T d_[R * C];
+};
+
+template <typename T, int PR, int PC, int BR, int BC> Matrix<T, BR, BC> BlockRef<T, PR, PC, BR, BC>::eval() const
+{ Matrix<T, BR, BC> m; for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(i, j) = at(i, j); return m; }
+template <typename T, int PR, int PC, int BR, int BC> BlockRef<T, PR, PC, BR, BC>& BlockRef<T, PR, PC, BR, BC>::operator=(const Matrix<T, BR, BC>& m)
+{ for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) at(i, j) = m(i, j); return *this; }
+
+template <typename T, int N> LDLT3<T, N>::LDLT3(const Matrix<T, N, N>& A0)
+{
+    T A[N][N];
+    for (int i = 0; i < N; ++i) { perm[i] = i; for (int j = 0; j < N; ++j) { A[i][j] = A0(i, j); L[i][j] = T(0); } }
+    for (int k = 0; k < N; ++k) {
+        int p = k; for (int i = k + 1; i < N; ++i) if (std::fabs(A[i][i]) > std::fabs(A[p][p])) p = i;
+        if (p != k) {                                   // symmetric row/column swap of the trailing matrix and of the rows of L built so far
+            for (int j = 0; j < N; ++j) std::swap(A[k][j], A[p][j]);
+            for (int i = 0; i < N; ++i) std::swap(A[i][k], A[i][p]);
+            for (int j = 0; j < k; ++j) std::swap(L[k][j], L[p][j]);
+            std::swap(perm[k], perm[p]);
+        }
+        D[k] = A[k][k]; L[k][k] = T(1);
+        for (int i = k + 1; i < N; ++i) L[i][k] = A[i][k] / D[k];
+        for (int i = k + 1; i < N; ++i) for (int j = k + 1; j < N; ++j) A[i][j] -= L[i][k] * D[k] * L[j][k];
+    }
+}
+template <typename T, int N> Matrix<T, N, 1> LDLT3<T, N>::solve(const Matrix<T, N, 1>& b) const
+{
+    T y[N], x[N];
+    for (int i = 0; i < N; ++i) { T s = b(perm[i]); for (int j = 0; j < i; ++j) s -= L[i][j] * y[j]; y[i] = s; }
+    for (int i = 0; i < N; ++i) y[i] /= D[i];
+    for (int i = N - 1; i >= 0; --i) { T s = y[i]; for (int j = i + 1; j < N; ++j) s -= L[j][i] * x[j]; x[i] = s; }
+    Matrix<T, N, 1> out; for (int i = 0; i < N; ++i) out(perm[i]) = x[i];
+    return out;
+}
+
+typedef Matrix<double, 2, 1> Vector2d;
+typedef Matrix<double, 3, 1> Vector3d;
+typedef Matrix<double, 4, 1> Vector4d;
+typedef Matrix<double, 2, 2> Matrix2d;
+typedef Matrix<double, 3, 3> Matrix3d;
+typedef Matrix<double, 4, 4> Matrix4d;
+
+// Eigen::Quaterniond: Hamilton convention, constructor order (w, x, y, z); toRotationMatrix as Eigen's QuaternionBase::toRotationMatrix
+class Quaterniond {
+public:
+    Quaterniond() : w_(1), x_(0), y_(0), z_(0) {}
+    Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+    double& w() { return w_; } double& x() { return x_; } double& y() { return y_; } double& z() { return z_; }
+    double w() const { return w_; } double x() const { return x_; } double y() const { return y_; } double z() const { return z_; }
+    void normalize() { const double n = std::sqrt(w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_); w_ /= n; x_ /= n; y_ /= n; z_ /= n; }
+    Matrix3d toRotationMatrix() const
+    {
+        Matrix3d res;
+        const double tx = 2 * x_, ty = 2 * y_, tz = 2 * z_;
+        const double twx = tx * w_, twy = ty * w_, twz = tz * w_;
+        const double txx = tx * x_, txy = ty * x_, txz = tz * x_;
+        const double tyy = ty * y_, tyz = tz * y_, tzz = tz * z_;
+        res(0, 0) = 1 - (tyy + tzz); res(0, 1) = txy - twz; res(0, 2) = txz + twy;
+        res(1, 0) = txy + twz; res(1, 1) = 1 - (txx + tzz); res(1, 2) = tyz - twx;
+        res(2, 0) = txz - twy; res(2, 1) = tyz + twx; res(2, 2) = 1 - (txx + tyy);
+        return res;
+    }
+private:
+    double w_, x_, y_, z_;
+};
+
+// Eigen::Isometry3d: rotation + translation, p -> R p + t
+class Isometry3d {
+public:
+    Isometry3d() : R_(Matrix3d::Identity()), t_() {}
+    static Isometry3d Identity() { return Isometry3d(); }
+    Matrix3d& linear() { return R_; }
+    const Matrix3d& linear() const { return R_; }
+    Vector3d& translation() { return t_; }
+    const Vector3d& translation() const { return t_; }
+    Isometry3d inverse() const { Isometry3d o; o.R_ = R_.transpose(); o.t_ = -(o.R_ * t_); return o; }
+    Isometry3d operator*(const Isometry3d& o) const { Isometry3d r; r.R_ = R_ * o.R_; r.t_ = R_ * o.t_ + t_; return r; }
+    Vector3d operator*(const Vector3d& p) const { return R_ * p + t_; }
+private:
+    Matrix3d R_; Vector3d t_;
+};
+
+}  // namespace Eigen

@@ -62,3 +62,30 @@ def test_orb_block_against_the_references_own_outputs(gpu_ctx):
     assert np.array_equal(d, z["desc"])
     assert np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), z["angle"].view(np.uint32))
     assert list(ops.hamming_rows(gpu_ctx, z["ham_a"], z["ham_b"])) == list(z["ham"])
+
+
+def test_triangulation_kernel_against_the_references_own_outputs(gpu_ctx):
+    """k_triangulate (lvk_triangulate) against tests/golden/ref_feature.npz - outputs of the REFERENCE's Feature::initializePosition family
+    (include/larvio/feature.hpp:383-890) compiled in place (tests/golden/make_ref_feature.py; oracle/_ref), not of the oracle: validity flags
+    exactly, world position / inverse depth / corrected anchor observation / (alpha, beta, rho) to 1e-6 relative (measured 1e-7: where two
+    solvers of the damped 3x3 system stop), with neither the oracle nor the reference library in the loop."""
+    from scipy.spatial.transform import Rotation
+    from larvio_amd import larvio as lv
+    from tests.test_oracle_ref_feature import selected_views
+    g = np.load(os.path.join(GOLDEN, "ref_feature.npz"))
+    worst = 0.0; n_ok = 0
+    for k in range(len(g["n_views"])):
+        n = int(g["n_views"][k]); ids = g["ids"][k, :n]; q = g["q_cam"][k, :n]; pc = g["p_cam"][k, :n]; uv = g["uv"][k, :n]
+        mode = int(g["mode"][k]); sel = selected_views(ids, mode, int(g["curr_id"][k]))
+        poses = np.zeros(len(sel), lv.POSE)
+        for j, i in enumerate(sel):
+            poses[j]["R"] = Rotation.from_quat(q[i]).as_matrix().ravel(); poses[j]["t"] = pc[i]
+        ok, pos, sol, idp, oa = lv.triangulate(gpu_ctx, poses, uv[sel], use_position=bool(g["is_initialized"][k]) and mode != 2, position_in=g["position_in"][k])
+        assert ok == bool(g["ok"][k]), k
+        if not ok:
+            continue
+        o = g["out"][k]; n_ok += 1
+        worst = max(worst, np.abs(pos - o[0:3]).max() / max(np.abs(pos).max(), 1.0), abs(idp - o[6]) / abs(idp), np.abs(oa - o[7:10]).max(),
+                    np.abs(sol - o[11:14]).max() / max(np.abs(sol).max(), 1.0))
+    print("k_triangulate against the reference's committed outputs: %d of %d valid, worst relative difference %.1e" % (n_ok, len(g["n_views"]), worst))
+    assert n_ok == int(g["ok"].sum()) and worst < 1e-6
