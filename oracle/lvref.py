@@ -130,3 +130,36 @@ def feature_check_motion(state_ids, q_cam, p_cam, obs_ids, obs_uv, if_tracked, t
     sid, q, p, oid, uv = _views(state_ids, q_cam, p_cam, obs_ids, obs_uv)
     return bool(_libf().lvref_feature_check_motion(len(sid), sid.ctypes.data, q.ctypes.data, p.ctypes.data, len(oid), oid.ctypes.data, uv.ctypes.data,
                                                    int(bool(if_tracked)), float(translation_threshold)))
+
+
+# ---------------------------------------------------------------------------------------------- the reference's IMU pre-integration
+_SO_P = os.path.join(_HERE, "_ref", "liblvref_preint.so")
+_lib_p = None
+
+
+def preint_available(build=True):
+    if os.path.exists(_SO_P):
+        return True
+    if build and os.path.isdir("/root/reference/include/Initializer"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_P)
+
+
+def preintegrate(acc0, gyr0, ba, bg, dt, acc, gyr, rebias=None):
+    """IntegrationBase (ImuPreintegration.h:27-230) of the compiled reference: linearised at (acc0, gyr0, ba, bg), the samples pushed,
+    optionally re-propagated about rebias = (ba2, bg2).  -> dict(dp, dq [x y z w], dv, sum_dt, dq_dbg, dp_dbg, dv_dbg, dp_dba, dv_dba)"""
+    global _lib_p
+    if _lib_p is None:
+        if not preint_available():
+            raise RuntimeError("oracle/_ref/liblvref_preint.so is missing and /root/reference is not here to build it from")
+        _lib_p = C.CDLL(_SO_P)
+        vp, i = C.c_void_p, C.c_int
+        _lib_p.lvref_preintegrate.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp]; _lib_p.lvref_preintegrate.restype = i
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    a0, g0, ba, bg, dt, acc, gyr = f(acc0), f(gyr0), f(ba), f(bg), f(dt), f(acc).reshape(-1, 3), f(gyr).reshape(-1, 3)
+    ba2, bg2 = (f(rebias[0]), f(rebias[1])) if rebias is not None else (np.zeros(3), np.zeros(3))
+    out = np.zeros(56)
+    _lib_p.lvref_preintegrate(a0.ctypes.data, g0.ctypes.data, ba.ctypes.data, bg.ctypes.data, len(dt), dt.ctypes.data, acc.ctypes.data, gyr.ctypes.data,
+                              int(rebias is not None), ba2.ctypes.data, bg2.ctypes.data, out.ctypes.data)
+    m = lambda k: out[11 + 9 * k:20 + 9 * k].reshape(3, 3).copy()
+    return dict(dp=out[0:3].copy(), dq=out[3:7].copy(), dv=out[7:10].copy(), sum_dt=float(out[10]), dq_dbg=m(0), dp_dbg=m(1), dv_dbg=m(2), dp_dba=m(3), dv_dba=m(4))

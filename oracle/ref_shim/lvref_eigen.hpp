@@ -20,6 +20,7 @@ namespace Eigen {
 template <typename T> using aligned_allocator = std::allocator<T>;
 
 template <typename T, int R, int C> class Matrix;
+class MatrixXd;
 
 // assignable view of a block of a parent matrix (row(), leftCols<>(), rightCols<>(), head<>())
 template <typename T, int PR, int PC, int BR, int BC> class BlockRef {
@@ -30,6 +31,7 @@ public:
     operator Matrix<T, BR, BC>() const { return eval(); }
     BlockRef& operator=(const Matrix<T, BR, BC>& m);
     BlockRef& operator=(const BlockRef& o) { return *this = o.eval(); }
+    BlockRef& operator=(const MatrixXd& m);
     template <int QR, int QC> BlockRef& operator=(const BlockRef<T, QR, QC, BR, BC>& o) { return *this = o.eval(); }
     T& operator()(int i) const { return BR == 1 ? at(0, i) : at(i, 0); }
     T& operator()(int i, int j) const { return at(i, j); }
@@ -60,6 +62,8 @@ public:
     Matrix(T x, T y, T z) { static_assert(R * C == 3, "3-vector"); d_[0] = x; d_[1] = y; d_[2] = z; }
     Matrix(T x, T y, T z, T w) { static_assert(R * C == 4, "4-vector"); d_[0] = x; d_[1] = y; d_[2] = z; d_[3] = w; }
     template <int PR, int PC> Matrix(const BlockRef<T, PR, PC, R, C>& b) { *this = b.eval(); }
+    Matrix(const MatrixXd& m);                          // sizes must agree (checked)
+    operator MatrixXd() const;
     static Matrix Zero() { return Matrix(); }
     static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
     T& operator()(int i, int j) { return d_[(size_t)j * R + i]; }
@@ -178,6 +182,25 @@ public:
     double& w() { return w_; } double& x() { return x_; } double& y() { return y_; } double& z() { return z_; }
     double w() const { return w_; } double x() const { return x_; } double y() const { return y_; } double z() const { return z_; }
     void normalize() { const double n = std::sqrt(w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_); w_ /= n; x_ /= n; y_ /= n; z_ /= n; }
+    Quaterniond normalized() const { Quaterniond q = *this; q.normalize(); return q; }
+    static Quaterniond Identity() { return Quaterniond(1, 0, 0, 0); }
+    void setIdentity() { w_ = 1; x_ = y_ = z_ = 0; }
+    Vector3d vec() const { return Vector3d(x_, y_, z_); }
+    double squaredNorm() const { return w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_; }
+    Quaterniond conjugate() const { return Quaterniond(w_, -x_, -y_, -z_); }
+    Quaterniond inverse() const { const double n2 = squaredNorm(); return Quaterniond(w_ / n2, -x_ / n2, -y_ / n2, -z_ / n2); }
+    // Hamilton product, as Eigen's internal::quat_product
+    Quaterniond operator*(const Quaterniond& b) const
+    {
+        return Quaterniond(w_ * b.w_ - x_ * b.x_ - y_ * b.y_ - z_ * b.z_, w_ * b.x_ + x_ * b.w_ + y_ * b.z_ - z_ * b.y_,
+                           w_ * b.y_ + y_ * b.w_ + z_ * b.x_ - x_ * b.z_, w_ * b.z_ + z_ * b.w_ + x_ * b.y_ - y_ * b.x_);
+    }
+    // Eigen's QuaternionBase::_transformVector: v + w uv + vec x uv with uv = 2 vec x v (the rotation only for a unit quaternion)
+    Vector3d operator*(const Vector3d& v) const
+    {
+        Vector3d uv = vec().cross(v); uv += uv;
+        return v + w_ * uv + vec().cross(uv);
+    }
     Matrix3d toRotationMatrix() const
     {
         Matrix3d res;
@@ -209,5 +232,45 @@ public:
 private:
     Matrix3d R_; Vector3d t_;
 };
+
+// dynamic-size matrix (ImuPreintegration.h builds its 15x15 / 15x18 step matrices as MatrixXd); column-major, eager
+class MatrixXd {
+public:
+    MatrixXd() : r_(0), c_(0) {}
+    MatrixXd(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
+    static MatrixXd Zero(int r, int c) { return MatrixXd(r, c); }
+    static MatrixXd Identity(int r, int c) { MatrixXd m(r, c); for (int i = 0; i < (r < c ? r : c); ++i) m(i, i) = 1.0; return m; }
+    int rows() const { return r_; }
+    int cols() const { return c_; }
+    double& operator()(int i, int j) { return d_[(size_t)j * r_ + i]; }
+    const double& operator()(int i, int j) const { return d_[(size_t)j * r_ + i]; }
+    MatrixXd transpose() const { MatrixXd m(c_, r_); for (int i = 0; i < r_; ++i) for (int j = 0; j < c_; ++j) m(j, i) = (*this)(i, j); return m; }
+    // fixed-size block of a dynamic matrix, assignable
+    template <int BR, int BC> struct XBlock {
+        MatrixXd& m; int r0, c0;
+        Matrix<double, BR, BC> eval() const { Matrix<double, BR, BC> o; for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) o(i, j) = m(r0 + i, c0 + j); return o; }
+        operator Matrix<double, BR, BC>() const { return eval(); }
+        XBlock& operator=(const Matrix<double, BR, BC>& v) { for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(r0 + i, c0 + j) = v(i, j); return *this; }
+        XBlock& operator=(const MatrixXd& v) { for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(r0 + i, c0 + j) = v(i, j); return *this; }
+        XBlock& operator=(const XBlock& v) { return *this = v.eval(); }
+    };
+    template <int BR, int BC> XBlock<BR, BC> block(int r0, int c0) { return XBlock<BR, BC>{*this, r0, c0}; }
+    friend MatrixXd operator*(const MatrixXd& a, const MatrixXd& b)
+    {
+        MatrixXd m(a.r_, b.c_);
+        for (int i = 0; i < a.r_; ++i) for (int k = 0; k < b.c_; ++k) { double s = a(i, 0) * b(0, k); for (int j = 1; j < a.c_; ++j) s += a(i, j) * b(j, k); m(i, k) = s; }
+        return m;
+    }
+    friend MatrixXd operator+(const MatrixXd& a, const MatrixXd& b) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = a.d_[i] + b.d_[i]; return m; }
+    friend MatrixXd operator-(const MatrixXd& a, const MatrixXd& b) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = a.d_[i] - b.d_[i]; return m; }
+    friend MatrixXd operator*(double s, const MatrixXd& a) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = s * a.d_[i]; return m; }
+    friend MatrixXd operator*(const MatrixXd& a, double s) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = a.d_[i] * s; return m; }
+private:
+    int r_, c_; std::vector<double> d_;
+};
+template <typename T, int R, int C> Matrix<T, R, C>::Matrix(const MatrixXd& m) { for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) (*this)(i, j) = (m.rows() == R && m.cols() == C) ? m(i, j) : std::nan(""); }
+template <typename T, int R, int C> Matrix<T, R, C>::operator MatrixXd() const { MatrixXd m(R, C); for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) m(i, j) = (*this)(i, j); return m; }
+template <typename T, int PR, int PC, int BR, int BC> BlockRef<T, PR, PC, BR, BC>& BlockRef<T, PR, PC, BR, BC>::operator=(const MatrixXd& m)
+{ for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) at(i, j) = m(i, j); return *this; }
 
 }  // namespace Eigen
