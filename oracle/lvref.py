@@ -163,3 +163,40 @@ def preintegrate(acc0, gyr0, ba, bg, dt, acc, gyr, rebias=None):
                               int(rebias is not None), ba2.ctypes.data, bg2.ctypes.data, out.ctypes.data)
     m = lambda k: out[11 + 9 * k:20 + 9 * k].reshape(3, 3).copy()
     return dict(dp=out[0:3].copy(), dq=out[3:7].copy(), dv=out[7:10].copy(), sum_dt=float(out[10]), dq_dbg=m(0), dp_dbg=m(1), dv_dbg=m(2), dp_dba=m(3), dv_dba=m(4))
+
+
+# ---------------------------------------------------------------------------------------------- the reference's visual-inertial alignment
+_SO_A = os.path.join(_HERE, "_ref", "liblvref_align.so")
+_lib_a = None
+
+
+def align_available(build=True):
+    if os.path.exists(_SO_A):
+        return True
+    if build and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_A)
+
+
+def visual_imu_alignment(t, R, T, heads, streams, bg0, tic):
+    """VisualIMUAlignment (src/initial_alignment.cpp:204-212) of the compiled reference on a window: frame keys t, rotations R (n, 3, 3) and
+    positions T (n, 3) as all_image_frame holds them; heads[j] = (acc0, gyr0) and streams[j] = (m, 7) samples (dt, acc, gyr) of the
+    pre-integration frame j >= 1 carries (index 0 unused).  -> dict(ok, bg, g, x)"""
+    global _lib_a
+    if _lib_a is None:
+        if not align_available():
+            raise RuntimeError("oracle/_ref/liblvref_align.so is missing and /root/reference is not here to build it from")
+        _lib_a = C.CDLL(_SO_A)
+        vp, i = C.c_void_p, C.c_int
+        _lib_a.lvref_visual_imu_alignment.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp]; _lib_a.lvref_visual_imu_alignment.restype = i
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    n = len(t)
+    tt, RR, TT = f(t), f(R).reshape(n, 9), f(T).reshape(n, 3)
+    ns = np.array([0] + [len(streams[j]) for j in range(1, n)], np.int32)
+    hd = np.zeros((n, 6)); hd[1:] = [np.concatenate(heads[j]) for j in range(1, n)]
+    sm = f(np.concatenate([np.asarray(streams[j], float).reshape(-1, 7) for j in range(1, n)]))
+    out = np.zeros(8 + 3 * n + 8)
+    ok = _lib_a.lvref_visual_imu_alignment(n, tt.ctypes.data, RR.ctypes.data, TT.ctypes.data, ns.ctypes.data, hd.ctypes.data, sm.ctypes.data, f(bg0).ctypes.data, f(tic).ctypes.data,
+                                           out.ctypes.data)
+    nx = int(out[7])
+    return dict(ok=bool(ok), bg=out[1:4].copy(), g=out[4:7].copy(), x=out[8:8 + nx].copy())

@@ -62,8 +62,14 @@ public:
     Matrix(T x, T y, T z) { static_assert(R * C == 3, "3-vector"); d_[0] = x; d_[1] = y; d_[2] = z; }
     Matrix(T x, T y, T z, T w) { static_assert(R * C == 4, "4-vector"); d_[0] = x; d_[1] = y; d_[2] = z; d_[3] = w; }
     template <int PR, int PC> Matrix(const BlockRef<T, PR, PC, R, C>& b) { *this = b.eval(); }
-    Matrix(const MatrixXd& m);                          // sizes must agree (checked)
-    operator MatrixXd() const;
+    explicit Matrix(const MatrixXd& m);                 // sizes must agree (NaN otherwise)
+    Matrix& operator=(const MatrixXd& m) { *this = Matrix(m); return *this; }
+    template <class XB, typename = decltype(std::declval<const XB&>().eval())> Matrix& operator=(const XB& b) { *this = Matrix(b.eval()); return *this; }
+    Matrix& operator+=(const MatrixXd& m) { *this += Matrix(m); return *this; }
+    Matrix& operator-=(const MatrixXd& m) { *this -= Matrix(m); return *this; }
+    bool operator==(const Matrix& o) const { for (int i = 0; i < R * C; ++i) if (d_[i] != o.d_[i]) return false; return true; }
+    template <int N> Matrix<T, N, 1> tail() const { Matrix<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = d_[R * C - N + i]; return m; }
+    template <int N> Matrix<T, N, 1> segment(int i0) const { Matrix<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = d_[i0 + i]; return m; }
     static Matrix Zero() { return Matrix(); }
     static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
     T& operator()(int i, int j) { return d_[(size_t)j * R + i]; }
@@ -72,6 +78,8 @@ public:
     const T& operator()(int i) const { return d_[i]; }
     T& operator[](int i) { return d_[i]; }
     const T& operator[](int i) const { return d_[i]; }
+    T& x() { return d_[0]; } T& y() { return d_[1]; } T& z() { return d_[2]; }
+    const T& x() const { return d_[0]; } const T& y() const { return d_[1]; } const T& z() const { return d_[2]; }
     T* data() { return d_; }
     const T* data() const { return d_; }
     int rows() const { return R; }
@@ -179,6 +187,20 @@ class Quaterniond {
 public:
     Quaterniond() : w_(1), x_(0), y_(0), z_(0) {}
     Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+    explicit Quaterniond(const Matrix3d& m)
+    {   // Eigen's quaternionbase_assign_impl<Matrix3> (Shoemake): the branch on the trace, then on the largest diagonal entry
+        double q[4];                                        // x y z w
+        double t = m(0, 0) + m(1, 1) + m(2, 2);
+        if (t > 0) { t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m(2, 1) - m(1, 2)) * t; q[1] = (m(0, 2) - m(2, 0)) * t; q[2] = (m(1, 0) - m(0, 1)) * t; }
+        else {
+            int i = 0; if (m(1, 1) > m(0, 0)) i = 1; if (m(2, 2) > m(i, i)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
+            q[i] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m(k, j) - m(j, k)) * t; q[j] = (m(j, i) + m(i, j)) * t; q[k] = (m(k, i) + m(i, k)) * t;
+        }
+        x_ = q[0]; y_ = q[1]; z_ = q[2]; w_ = q[3];
+    }
     double& w() { return w_; } double& x() { return x_; } double& y() { return y_; } double& z() { return z_; }
     double w() const { return w_; } double x() const { return x_; } double y() const { return y_; } double z() const { return z_; }
     void normalize() { const double n = std::sqrt(w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_); w_ /= n; x_ /= n; y_ /= n; z_ /= n; }
@@ -233,18 +255,27 @@ private:
     Matrix3d R_; Vector3d t_;
 };
 
-// dynamic-size matrix (ImuPreintegration.h builds its 15x15 / 15x18 step matrices as MatrixXd); column-major, eager
+// dynamic-size matrix / vector (ImuPreintegration.h builds its 15x15 / 15x18 step matrices as MatrixXd, initial_alignment.cpp its normal
+// equations as MatrixXd / VectorXd); column-major, eager.  VectorXd is the same class with one column.
 class MatrixXd {
 public:
     MatrixXd() : r_(0), c_(0) {}
     MatrixXd(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
+    explicit MatrixXd(int n) : r_(n), c_(1), d_((size_t)n, 0.0) {}
+    template <int R, int C> MatrixXd(const Matrix<double, R, C>& m) : r_(R), c_(C), d_((size_t)R * C) { for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) (*this)(i, j) = m(i, j); }
+    template <int PR, int PC, int BR, int BC> MatrixXd(const BlockRef<double, PR, PC, BR, BC>& b) : MatrixXd(b.eval()) {}
     static MatrixXd Zero(int r, int c) { return MatrixXd(r, c); }
     static MatrixXd Identity(int r, int c) { MatrixXd m(r, c); for (int i = 0; i < (r < c ? r : c); ++i) m(i, i) = 1.0; return m; }
     int rows() const { return r_; }
     int cols() const { return c_; }
+    int size() const { return r_ * c_; }
+    void setZero() { std::fill(d_.begin(), d_.end(), 0.0); }
     double& operator()(int i, int j) { return d_[(size_t)j * r_ + i]; }
     const double& operator()(int i, int j) const { return d_[(size_t)j * r_ + i]; }
+    double& operator()(int i) { return d_[(size_t)i]; }
+    const double& operator()(int i) const { return d_[(size_t)i]; }
     MatrixXd transpose() const { MatrixXd m(c_, r_); for (int i = 0; i < r_; ++i) for (int j = 0; j < c_; ++j) m(j, i) = (*this)(i, j); return m; }
+    double norm() const { double s = 0; for (double v : d_) s += v * v; return std::sqrt(s); }
     // fixed-size block of a dynamic matrix, assignable
     template <int BR, int BC> struct XBlock {
         MatrixXd& m; int r0, c0;
@@ -253,8 +284,51 @@ public:
         XBlock& operator=(const Matrix<double, BR, BC>& v) { for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(r0 + i, c0 + j) = v(i, j); return *this; }
         XBlock& operator=(const MatrixXd& v) { for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(r0 + i, c0 + j) = v(i, j); return *this; }
         XBlock& operator=(const XBlock& v) { return *this = v.eval(); }
+        XBlock& operator+=(const Matrix<double, BR, BC>& v) { for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(r0 + i, c0 + j) += v(i, j); return *this; }
+        double& operator()(int i) const { return BR == 1 ? m(r0, c0 + i) : m(r0 + i, c0); }
+        double& operator()(int i, int j) const { return m(r0 + i, c0 + j); }
     };
     template <int BR, int BC> XBlock<BR, BC> block(int r0, int c0) { return XBlock<BR, BC>{*this, r0, c0}; }
+    template <int BR, int BC> XBlock<BR, BC> topLeftCorner() { return XBlock<BR, BC>{*this, 0, 0}; }
+    template <int BR, int BC> XBlock<BR, BC> topRightCorner() { return XBlock<BR, BC>{*this, 0, c_ - BC}; }
+    template <int BR, int BC> XBlock<BR, BC> bottomLeftCorner() { return XBlock<BR, BC>{*this, r_ - BR, 0}; }
+    template <int BR, int BC> XBlock<BR, BC> bottomRightCorner() { return XBlock<BR, BC>{*this, r_ - BR, c_ - BC}; }
+    template <int N> XBlock<N, 1> segment(int i0) { return XBlock<N, 1>{*this, i0, 0}; }
+    template <int N> XBlock<N, 1> head() { return XBlock<N, 1>{*this, 0, 0}; }
+    template <int N> XBlock<N, 1> tail() { return XBlock<N, 1>{*this, r_ - N, 0}; }
+    template <int BR, int BC> MatrixXd(const XBlock<BR, BC>& b) : MatrixXd(b.eval()) {}
+    // symmetric pivoting LDL^T, as Eigen's LDLT
+    struct XLDLT {
+        int n; std::vector<double> L, D; std::vector<int> perm;
+        MatrixXd solve(const MatrixXd& b) const
+        {
+            std::vector<double> y((size_t)n), x((size_t)n);
+            for (int i = 0; i < n; ++i) { double s = b(perm[(size_t)i]); for (int j = 0; j < i; ++j) s -= L[(size_t)i * n + j] * y[(size_t)j]; y[(size_t)i] = s; }
+            for (int i = 0; i < n; ++i) y[(size_t)i] /= D[(size_t)i];
+            for (int i = n - 1; i >= 0; --i) { double s = y[(size_t)i]; for (int j = i + 1; j < n; ++j) s -= L[(size_t)j * n + i] * x[(size_t)j]; x[(size_t)i] = s; }
+            MatrixXd out(n); for (int i = 0; i < n; ++i) out(perm[(size_t)i]) = x[(size_t)i];
+            return out;
+        }
+    };
+    XLDLT ldlt() const
+    {
+        const int n = r_; XLDLT f; f.n = n; f.L.assign((size_t)n * n, 0.0); f.D.assign((size_t)n, 0.0); f.perm.resize((size_t)n);
+        std::vector<double> A((size_t)n * n);
+        for (int i = 0; i < n; ++i) { f.perm[(size_t)i] = i; for (int j = 0; j < n; ++j) A[(size_t)i * n + j] = (*this)(i, j); }
+        for (int k = 0; k < n; ++k) {
+            int p = k; for (int i = k + 1; i < n; ++i) if (std::fabs(A[(size_t)i * n + i]) > std::fabs(A[(size_t)p * n + p])) p = i;
+            if (p != k) {
+                for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]);
+                for (int i = 0; i < n; ++i) std::swap(A[(size_t)i * n + k], A[(size_t)i * n + p]);
+                for (int j = 0; j < k; ++j) std::swap(f.L[(size_t)k * n + j], f.L[(size_t)p * n + j]);
+                std::swap(f.perm[(size_t)k], f.perm[(size_t)p]);
+            }
+            f.D[(size_t)k] = A[(size_t)k * n + k]; f.L[(size_t)k * n + k] = 1.0;
+            for (int i = k + 1; i < n; ++i) f.L[(size_t)i * n + k] = A[(size_t)i * n + k] / f.D[(size_t)k];
+            for (int i = k + 1; i < n; ++i) for (int j = k + 1; j < n; ++j) A[(size_t)i * n + j] -= f.L[(size_t)i * n + k] * f.D[(size_t)k] * f.L[(size_t)j * n + k];
+        }
+        return f;
+    }
     friend MatrixXd operator*(const MatrixXd& a, const MatrixXd& b)
     {
         MatrixXd m(a.r_, b.c_);
@@ -265,11 +339,17 @@ public:
     friend MatrixXd operator-(const MatrixXd& a, const MatrixXd& b) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = a.d_[i] - b.d_[i]; return m; }
     friend MatrixXd operator*(double s, const MatrixXd& a) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = s * a.d_[i]; return m; }
     friend MatrixXd operator*(const MatrixXd& a, double s) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = a.d_[i] * s; return m; }
+    friend MatrixXd operator/(const MatrixXd& a, double s) { MatrixXd m(a.r_, a.c_); for (size_t i = 0; i < m.d_.size(); ++i) m.d_[i] = a.d_[i] / s; return m; }
 private:
     int r_, c_; std::vector<double> d_;
 };
+typedef MatrixXd VectorXd;
+// mixed fixed / dynamic arithmetic (exact-match templates: no implicit conversions between the two kinds, so no ambiguities)
+template <int R, int C> MatrixXd operator*(const MatrixXd& a, const Matrix<double, R, C>& b) { return a * MatrixXd(b); }
+template <int R, int C> MatrixXd operator*(const Matrix<double, R, C>& a, const MatrixXd& b) { return MatrixXd(a) * b; }
+template <int R, int C> Matrix<double, R, C> operator+(const Matrix<double, R, C>& a, const MatrixXd& b) { return a + Matrix<double, R, C>(b); }
+template <int R, int C> Matrix<double, R, C> operator-(const Matrix<double, R, C>& a, const MatrixXd& b) { return a - Matrix<double, R, C>(b); }
 template <typename T, int R, int C> Matrix<T, R, C>::Matrix(const MatrixXd& m) { for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) (*this)(i, j) = (m.rows() == R && m.cols() == C) ? m(i, j) : std::nan(""); }
-template <typename T, int R, int C> Matrix<T, R, C>::operator MatrixXd() const { MatrixXd m(R, C); for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) m(i, j) = (*this)(i, j); return m; }
 template <typename T, int PR, int PC, int BR, int BC> BlockRef<T, PR, PC, BR, BC>& BlockRef<T, PR, PC, BR, BC>::operator=(const MatrixXd& m)
 { for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) at(i, j) = m(i, j); return *this; }
 
