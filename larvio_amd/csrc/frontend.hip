@@ -708,8 +708,8 @@ template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((vo
 // host-side phase tracer of the calling thread (LVK_FE_TRACE=1; printed by lvk_frontend_destroy): where the caller's time per frame goes
 #include <chrono>
 enum { FT_SLOT_WAIT, FT_STAGE_COPY, FT_UPLOAD, FT_IMAGE_LAUNCH, FT_PREDICT, FT_TRACK_LAUNCH, FT_COMMIT_LAUNCH, FT_PUBLISH, FT_DETECT, FT_END, FT_N };
-static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: events + 6 launches", "frame checks + predict_homography",
-    "track chains: 2 launches + events", "commits: 2 launches + events", "message: slot + launch + event", "detection: 7 launches", "end-of-frame events + rotation"};
+static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: event queries + 6 launches", "frame checks + predict_homography",
+    "track chains: 2 launches + events", "commits: 2 launches + events", "message: slot + launch + event", "detection: 4 launches", "end-of-frame events + rotation"};
 struct FeTrace {
     bool on = false; double acc[FT_N] = {0}; long n = 0; std::chrono::steady_clock::time_point last;
     void start() { if (on) last = std::chrono::steady_clock::now(); }
