@@ -2249,7 +2249,7 @@ static void prof_harvest(lvk_ekf* e, bool all)
     size_t w = 0;
     for (size_t i = 0; i < e->prof_pending.size(); ++i) {
         auto pe = e->prof_pending[i];
-        if (!all && hipEventQuery(pe.b) != hipSuccess) { e->prof_pending[w++] = pe; continue; }
+        if (!all && hipEventQuery(pe.b) != hipSuccess) { (void)hipGetLastError(); e->prof_pending[w++] = pe; continue; }      // (hipErrorNotReady is not an error: keep it out of the next launch check)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
             if (pe.kind == 0) { e->prof_ms += ms; e->prof_flops += pe.flops; e->prof_n += 1; }

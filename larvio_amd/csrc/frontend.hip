@@ -657,6 +657,7 @@ struct lvk_frontend {
     lvk_context* side[2];
     hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};   // end of frame f's work on the main / side stream, by parity of f
     hipEvent_t ev_end[2] = {nullptr, nullptr};           // what stands for "frame f's main-stream work is done": ev_main[par], or the message's own event when the frame published (nothing follows it on that stream: one record, not two)
+    bool frame_early = false;                            // the current frame's image stage was queued ahead of its tracking (lvk_frontend_begin: the pipelined driver)
     int last_msg_slot = -1;                              // ring entry of the message published by the current frame (-1: none)
     long n_img = 0;                                                                // image stages queued so far
     bool image_done; double image_done_ts;       // lvk_frontend_begin already queued this frame's image stage
@@ -901,7 +902,11 @@ static lvk_status fe_detect_new(lvk_frontend* fe, int dst)
     // no fill launches: the mask is written whole by k_mask_max, the previous selection left the scratch words zeroed
     { ProfScope ps(fe, 6, cx->stream); st = lvk_min_eigen_map(cx, fe->pyr[1], fe->eig); }
     if (st != LVK_OK) return lvk_set_error(fe->ctx, st, "%s", cx->err);
-    hipStreamWaitEvent(cx->stream, fe->ev_commit, 0);
+    // the frame's tracks are final behind its second commit; with the event trims the detection waits for the message's own event instead
+    // (recorded right behind the message kernel, one launch later): one record less between the commit and the message the caller waits for
+    // (blocking schedules only: there the caller waits for the message; in the pipelined driver the detection is on the frame rate's recurrence
+    //  and starts behind the commit, without the message kernel in front of it)
+    hipStreamWaitEvent(cx->stream, (fe->ev_trim && !fe->frame_early && fe->last_msg_slot >= 0) ? fe->ev_msg[fe->last_msg_slot] : fe->ev_commit, 0);
     ProfScope ps(fe, 7, cx->stream);
     st = lvk_mask_and_max(cx, fe->set[dst].pts, &fe->dev->n_tracks[dst], c.width, c.height, c.min_distance, fe->eig, fe->mask, fe->gf_scratch);
     if (st == LVK_OK) st = lvk_gftt_run(cx, fe->eig, fe->mask, c.width, c.height, c.max_features_num, 0.01, (double)c.min_distance, fe->gf_scratch,
@@ -1042,8 +1047,13 @@ static lvk_status fe_image_stage(lvk_frontend* fe, const lvk_image* image, bool 
     if (slot >= 0 && fe->bar_push && !fe->ev_trim) { hipEventRecord(fe->ev_img[slot], S0); fe->ev_img_set[slot] = true; }
     // queued ahead of the frame's tracking (pipelined driver): the ORB planes are done long before anybody asks, one event (ev_orb)
     // stands for the whole stage; queued together with the tracking (blocking API): LK may start as soon as the pyramid exists
-    if (!early) hipEventRecord(fe->ev_pyr, S0);
-    fe->pyr_event = !early;
+    // (rounds 1-4 recorded ev_pyr here in the blocking schedules so that the frame could start on the pyramid alone; but the first thing a
+    //  steady-state frame queues is LK, whose second wavefront reads the ORB planes and waits for ev_orb anyway: the split only put a
+    //  record between the last Scharr launch and the blur, and a second wait on both tracking streams)
+    fe->frame_early = early;
+    const bool split = !early && !fe->ev_trim;
+    if (split) hipEventRecord(fe->ev_pyr, S0);
+    fe->pyr_event = split;
     { ProfScope ps(fe, 1, S0); st = mosaic_done ? lvk_orb_blur_only(icx, fe->pyr[1], fe->ext[1], fe->blur[1]) : lvk_orb_prepare(icx, fe->pyr[1], fe->ext[1], fe->blur[1]); }
     if (st != LVK_OK) return lvk_set_error(ctx, st, "%s", icx->err);
     hipEventRecord(fe->ev_orb, S0);
@@ -1137,7 +1147,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
         if (!(fe->ev_trim && hipEventQuery(ready) == hipSuccess)) { (void)hipGetLastError(); hipStreamWaitEvent(S1, ready, 0); hipStreamWaitEvent(S2, ready, 0); }
     }
     // the side stream reads (new points, their count) and overwrites (wn_*) what the previous frame's commits on the main stream used
-    if (fe->n_img >= 2) hipStreamWaitEvent(S2, fe->ev_end[fe->n_img & 1], 0);
+    if (fe->n_img >= 2) fe_wait_unless_done(fe, S2, fe->ev_end[fe->n_img & 1]);
     fe->prof_take = fe->prof_stride <= 1 || fe->n_img % fe->prof_stride == 0;
     fe->last_msg_slot = -1;
     fe->curr_img_time = ts;
@@ -1173,7 +1183,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             if (!fe->h_dev->boot_ok) fe->image_state = 1;
             else {
                 curr_valid = true;
-                if (!fe->ev_trim || ts - fe->last_pub_time >= pub_gate) hipEventRecord(fe->ev_commit, S1);      // only the detection of a publish frame waits for it
+                if (!fe->ev_trim || (fe->frame_early && ts - fe->last_pub_time >= pub_gate)) hipEventRecord(fe->ev_commit, S1);      // only the detection of a publish frame waits for it - and in the blocking schedules for the message's event instead (fe_detect_new)
                 if (ts - fe->last_pub_time >= pub_gate) {
                     st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
                     if (st != LVK_OK) return st;
@@ -1200,7 +1210,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st != LVK_OK) return st;
             curr_valid = true;
-            if (!fe->ev_trim || ts - fe->last_pub_time >= pub_gate) hipEventRecord(fe->ev_commit, S1);          // only the detection of a publish frame waits for it
+            if (!fe->ev_trim || (fe->frame_early && ts - fe->last_pub_time >= pub_gate)) hipEventRecord(fe->ev_commit, S1);          // only the detection of a publish frame waits for it - and in the blocking schedules for the message's event instead (fe_detect_new)
             FT(FT_COMMIT_LAUNCH);
             if (ts - fe->last_pub_time >= pub_gate) {
                 st = fe_publish(fe, dst, ts, h_out, cap, n_out, async_slot);
