@@ -2003,7 +2003,13 @@ static bool static_try_init(lvk_ekf* e, double ts, const lvk_feature_obs* f, int
     for (int i = 0; i < n_imu; ++i) {
         if (imu[i].t < e->lower_time_bound) continue;
         if (imu[i].t > time_bound) break;
-        for (int k = 0; k < 3; ++k) { sw[k] += imu[i].gyro[k]; sa[k] += imu[i].acc[k]; }
+        {   // Tg (w - As Ma a) and Ma a (StaticInitializer.cpp:84-85): the identity / zero matrices of a filter that does not calibrate them change no bit
+            double la[3], t3[3], w[3], ga[3];
+            m3_v(e->Ma, imu[i].acc, la); m3_v(e->As, la, t3);
+            for (int k = 0; k < 3; ++k) w[k] = imu[i].gyro[k] - t3[k];
+            m3_v(e->Tg, w, ga);
+            for (int k = 0; k < 3; ++k) { sw[k] += ga[k]; sa[k] += la[k]; }
+        }
         cnt++; last_t = imu[i].t;
     }
     double gi[3];

@@ -1254,7 +1254,13 @@ static int static_try_init(lvo_ekf* e, double ts, const lvo_feature_obs* f, int 
     for (int i = 0; i < n_imu; ++i) {
         if (imu[i].t < e->lower_time_bound) continue;
         if (imu[i].t > time_bound) break;
-        for (int k = 0; k < 3; ++k) { sw[k] += imu[i].gyro[k]; sa[k] += imu[i].acc[k]; }
+        {   /* Tg (w - As Ma a) and Ma a (StaticInitializer.cpp:84-85): the identity / zero matrices of a filter that does not calibrate them change no bit */
+            double la[3], t3[3], w[3], ga[3];
+            m3_v(e->Ma, imu[i].acc, la); m3_v(e->As, la, t3);
+            for (int k = 0; k < 3; ++k) w[k] = imu[i].gyro[k] - t3[k];
+            m3_v(e->Tg, w, ga);
+            for (int k = 0; k < 3; ++k) { sw[k] += ga[k]; sa[k] += la[k]; }
+        }
         cnt++; last_t = imu[i].t;
     }
     double gi[3];
@@ -1387,3 +1393,11 @@ int lvo_ekf_get_features(const lvo_ekf* e, int64_t* ids, double* inv_depth, doub
     return n;
 }
 void lvo_ekf_counters(const lvo_ekf* e, long* out7) { memcpy(out7, e->counters, sizeof e->counters); }
+/* stage-level entry for the tests: ONE step of the static initialiser (StaticInitializer::tryIncInit + assignInitialState) on this handle's
+ * counters; on success out8 = state time, q[4], b_g[3] and *n_erased = the IMU samples assignInitialState erases */
+int lvo_ekf_static_try_init(lvo_ekf* e, double ts, const lvo_feature_obs* f, int n, const lvo_imu* imu, int n_imu, int* n_erased, double* out8)
+{
+    const int ok = static_try_init(e, ts, f, n, imu, n_imu, n_erased);
+    if (ok) { out8[0] = e->s.t; memcpy(out8 + 1, e->s.q, 32); memcpy(out8 + 5, e->s.bg, 24); }
+    return ok;
+}

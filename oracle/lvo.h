@@ -266,6 +266,8 @@ int lvo_ekf_get_clones(const lvo_ekf* e, lvo_clone* out, int cap);
 int lvo_ekf_get_features(const lvo_ekf* e, int64_t* ids, double* inv_depth, double* pos_w, int cap);
 /* counters: [0] hybrid updates, [1] msckf updates, [2] rows of last H_o, [3] zupt updates, [4] features gated in, [5] gated out, [6] map size */
 void lvo_ekf_counters(const lvo_ekf* e, long* out7);
+/* one step of the static initialiser alone (stage-level parity with the reference's StaticInitializer compiled in place) */
+int lvo_ekf_static_try_init(lvo_ekf* e, double ts, const lvo_feature_obs* f, int n, const lvo_imu* imu, int n_imu, int* n_erased, double* out8);
 
 #ifdef __cplusplus
 }

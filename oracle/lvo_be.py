@@ -61,6 +61,7 @@ def _lib():
         L.lvo_ekf_get_clones.argtypes = [vp, vp, i]; L.lvo_ekf_get_clones.restype = i
         L.lvo_ekf_get_features.argtypes = [vp, vp, vp, vp, i]; L.lvo_ekf_get_features.restype = i
         L.lvo_ekf_counters.argtypes = [vp, vp]
+        L.lvo_ekf_static_try_init.argtypes = [vp, d, vp, i, vp, i, vp, vp]; L.lvo_ekf_static_try_init.restype = i
         L.lvo_stage_ekf1d_obs_jacobian.argtypes = [vp, vp, vp, d, vp, vp, vp, vp, vp, vp, vp]; L.lvo_stage_ekf1d_obs_jacobian.restype = i
         L.lvo_stage_hybrid_update_with_new.argtypes = [vp, i, vp, i, vp, vp, vp, vp, i, d, vp, vp]; L.lvo_stage_hybrid_update_with_new.restype = i
         L.lvo_stage_reanchor_row.argtypes = [vp, vp, vp, vp, vp, d, vp]; L.lvo_stage_reanchor_row.restype = i
@@ -151,6 +152,14 @@ class Ekf:
             _lib().lvo_ekf_destroy(self.h)
         except Exception:
             pass
+
+    def static_try_init(self, ts, feats, imu):
+        """one step of the static initialiser alone (StaticInitializer::tryIncInit + assignInitialState): None, or dict(t, q, bg, erased)"""
+        feats = np.ascontiguousarray(feats, lvo.OBS); imu = np.ascontiguousarray(imu, lvo.IMU)
+        n = C.c_int(0); out = np.zeros(8)
+        if not _lib().lvo_ekf_static_try_init(self.h, ts, _p(feats), len(feats), _p(imu), len(imu), C.byref(n), _p(out)):
+            return None
+        return dict(t=float(out[0]), q=out[1:5].copy(), bg=out[5:8].copy(), erased=int(n.value))
 
     def process(self, ts, feats, imu):
         feats = np.ascontiguousarray(feats, lvo.OBS); imu = np.ascontiguousarray(imu, lvo.IMU)

@@ -200,3 +200,45 @@ def visual_imu_alignment(t, R, T, heads, streams, bg0, tic):
                                            out.ctypes.data)
     nx = int(out[7])
     return dict(ok=bool(ok), bg=out[1:4].copy(), g=out[4:7].copy(), x=out[8:8 + nx].copy())
+
+
+# ---------------------------------------------------------------------------------------------- the reference's static initialiser
+_SO_S = os.path.join(_HERE, "_ref", "liblvref_static.so")
+_lib_s = None
+
+
+def static_available(build=True):
+    if os.path.exists(_SO_S):
+        return True
+    if build and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_S)
+
+
+class RefStaticInitializer:
+    """larvio::StaticInitializer (src/StaticInitializer.cpp) of the compiled reference: try_init(ts, ids, uv, imu) per message ->
+    None, or dict(t, q [x y z w], bg, erased, gyro_old, acc_old) = what tryIncInit + assignInitialState hand to the filter"""
+
+    def __init__(self, max_feature_dis, static_num, td=0.0, Ma=np.eye(3), Tg=np.eye(3), As=np.zeros((3, 3))):
+        global _lib_s
+        if _lib_s is None:
+            if not static_available():
+                raise RuntimeError("oracle/_ref/liblvref_static.so is missing and /root/reference is not here to build it from")
+            _lib_s = C.CDLL(_SO_S)
+            vp, i, d = C.c_void_p, C.c_int, C.c_double
+            _lib_s.lvref_static_create.argtypes = [d, i, d, vp, vp, vp]; _lib_s.lvref_static_create.restype = vp
+            _lib_s.lvref_static_destroy.argtypes = [vp]
+            _lib_s.lvref_static_try.argtypes = [vp, d, i, vp, vp, i, vp, vp]; _lib_s.lvref_static_try.restype = i
+        f = lambda a: np.ascontiguousarray(a, np.float64)
+        self.h = _lib_s.lvref_static_create(float(max_feature_dis), int(static_num), float(td), f(Ma).ctypes.data, f(Tg).ctypes.data, f(As).ctypes.data)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib_s.lvref_static_destroy(self.h); self.h = None
+
+    def try_init(self, ts, ids, uv, imu7):
+        ids = np.ascontiguousarray(ids, np.int64); uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2); imu7 = np.ascontiguousarray(imu7, np.float64).reshape(-1, 7)
+        out = np.zeros(15)
+        if not _lib_s.lvref_static_try(self.h, float(ts), len(ids), ids.ctypes.data, uv.ctypes.data, len(imu7), imu7.ctypes.data, out.ctypes.data):
+            return None
+        return dict(t=float(out[0]), q=out[1:5].copy(), bg=out[5:8].copy(), erased=int(out[8]), gyro_old=out[9:12].copy(), acc_old=out[12:15].copy())

@@ -7,7 +7,10 @@
 // tests compare at 1e-9, not bit for bit.  Nothing in the product includes this file.
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstddef>
+#include <utility>
+#include <type_traits>
 #include <memory>
 #include <vector>
 #include <map>
@@ -206,6 +209,17 @@ public:
     void normalize() { const double n = std::sqrt(w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_); w_ /= n; x_ /= n; y_ /= n; z_ /= n; }
     Quaterniond normalized() const { Quaterniond q = *this; q.normalize(); return q; }
     static Quaterniond Identity() { return Quaterniond(1, 0, 0, 0); }
+    Vector4d coeffs() const { return Vector4d(x_, y_, z_, w_); }
+    // Eigen's QuaternionBase::setFromTwoVectors for vectors that are not opposite: axis = v0 x v1, s = sqrt(2 (1 + v0.v1)), (axis / s, s / 2)
+    static Quaterniond FromTwoVectors(const Vector3d& a, const Vector3d& b)
+    {
+        const Vector3d v0 = a.normalized(), v1 = b.normalized();
+        const double c = v1.dot(v0);
+        if (c < -1.0 + 1e-12) return Quaterniond(0, 1, 0, 0);           // (opposite vectors: Eigen takes an SVD branch; not reached by the callers compiled here)
+        const Vector3d axis = v0.cross(v1);
+        const double s = std::sqrt((1.0 + c) * 2.0), invs = 1.0 / s;
+        return Quaterniond(s * 0.5, axis(0) * invs, axis(1) * invs, axis(2) * invs);
+    }
     void setIdentity() { w_ = 1; x_ = y_ = z_ = 0; }
     Vector3d vec() const { return Vector3d(x_, y_, z_); }
     double squaredNorm() const { return w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_; }
