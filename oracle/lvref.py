@@ -125,6 +125,15 @@ def feature_initialize(mode, state_ids, q_cam, p_cam, obs_ids, obs_uv, curr_id=-
                           inv_param=out[11:14].copy(), is_initialized=bool(out[14]))
 
 
+def math_small_angle(w):
+    """math_utils.hpp of the compiled reference: (skewSymmetric(w) 3x3, smallAngleQuaternion(w) [x y z w], getSmallAngleQuaternion(w) [x y z w])"""
+    L = _libf()
+    L.lvref_math_small_angle.argtypes = [C.c_void_p] * 4
+    w = np.ascontiguousarray(w, np.float64); S = np.zeros(9); a = np.zeros(4); b = np.zeros(4)
+    L.lvref_math_small_angle(w.ctypes.data, S.ctypes.data, a.ctypes.data, b.ctypes.data)
+    return S.reshape(3, 3), a, b
+
+
 def feature_check_motion(state_ids, q_cam, p_cam, obs_ids, obs_uv, if_tracked, translation_threshold):
     """Feature::checkMotion (feature.hpp:334-381) of the compiled reference"""
     sid, q, p, oid, uv = _views(state_ids, q_cam, p_cam, obs_ids, obs_uv)

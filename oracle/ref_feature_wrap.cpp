@@ -63,4 +63,18 @@ int lvref_feature_initialize(int mode, int n_states, const long long* state_ids,
     return ok ? 1 : 0;
 }
 
+// the reference's own quaternion / skew helpers (include/larvio/math_utils.hpp:26-38, 85-102, 113-133), for the product's host math
+// (larvio_amd/csrc/be_host_math.h: skew3, small_angle_quat): out9 = skewSymmetric(w) row-major, out4a = smallAngleQuaternion(w) [x y z w],
+// out4b = getSmallAngleQuaternion(w) [x y z w]
+void lvref_math_small_angle(const double* w, double* out9, double* out4a, double* out4b)
+{
+    const Eigen::Vector3d v(w[0], w[1], w[2]);
+    const Eigen::Matrix3d S = skewSymmetric(v);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out9[3 * i + j] = S(i, j);
+    const Eigen::Vector4d q = smallAngleQuaternion(v);
+    for (int k = 0; k < 4; ++k) out4a[k] = q(k);
+    const Eigen::Quaterniond g = getSmallAngleQuaternion(v);
+    out4b[0] = g.x(); out4b[1] = g.y(); out4b[2] = g.z(); out4b[3] = g.w();
+}
+
 }  // extern "C"

@@ -73,6 +73,8 @@ def test_product_host_math_against_scipy(tmp_path):
     subprocess.check_call([cxx] + flags + [os.path.join(ROOT, "tests", "host", "host_math_dump.hip"), "-o", exe])
     rows = [json.loads(l) for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()]
     assert len(rows) == 200
+    from oracle import lvref
+    ref = lvref if lvref.feature_available() else None
     saw_neg_trace = 0
     for r in rows:
         q, p, w = np.array(r["q"]), np.array(r["p"]), np.array(r["w"]); A, B = np.reshape(r["A"], (3, 3)), np.reshape(r["B"], (3, 3)); v = np.array(r["v"])
@@ -88,4 +90,7 @@ def test_product_host_math_against_scipy(tmp_path):
         d = w / 2; n2 = d @ d                                                       # smallAngleQuaternion (math_utils.hpp:85-102)
         dq = np.concatenate([d, [np.sqrt(1 - n2)]]) if n2 <= 1 else np.concatenate([d, [1.0]]) / np.sqrt(1 + n2)
         assert np.abs(np.array(r["dq"]) - dq).max() < 1e-15
+        if ref is not None:                                                         # ... and against the reference's own math_utils.hpp compiled in place (oracle/_ref)
+            S_r, qa, qb = ref.math_small_angle(w)
+            assert np.array_equal(np.reshape(r["S"], (3, 3)), S_r) and np.abs(np.array(r["dq"]) - qa).max() < 1e-15 and np.abs(np.array(r["dq"]) - qb).max() < 1e-15
     assert saw_neg_trace >= 20
