@@ -251,3 +251,54 @@ class RefStaticInitializer:
         if not _lib_s.lvref_static_try(self.h, float(ts), len(ids), ids.ctypes.data, uv.ctypes.data, len(imu7), imu7.ctypes.data, out.ctypes.data):
             return None
         return dict(t=float(out[0]), q=out[1:5].copy(), bg=out[5:8].copy(), erased=int(out[8]), gyro_old=out[9:12].copy(), acc_old=out[12:15].copy())
+
+
+# ---------------------------------------------------------------------------------------------- the reference's FeatureManager (window bookkeeping)
+_SO_M = os.path.join(_HERE, "_ref", "liblvref_fm.so")
+_lib_m = None
+
+
+def fm_available(build=True):
+    if os.path.exists(_SO_M):
+        return True
+    if build and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_M)
+
+
+class RefFeatureManager:
+    """larvio::FeatureManager (src/feature_manager.cpp) of the compiled reference"""
+
+    def __init__(self):
+        global _lib_m
+        if _lib_m is None:
+            if not fm_available():
+                raise RuntimeError("oracle/_ref/liblvref_fm.so is missing and /root/reference is not here to build it from")
+            _lib_m = C.CDLL(_SO_M)
+            vp, i, d = C.c_void_p, C.c_int, C.c_double
+            _lib_m.lvref_fm_create.restype = vp
+            _lib_m.lvref_fm_destroy.argtypes = [vp]
+            _lib_m.lvref_fm_add.argtypes = [vp, i, i, vp, vp, d]; _lib_m.lvref_fm_add.restype = i
+            _lib_m.lvref_fm_corresponding.argtypes = [vp, i, i, vp, i]; _lib_m.lvref_fm_corresponding.restype = i
+            _lib_m.lvref_fm_remove_back.argtypes = [vp]
+            _lib_m.lvref_fm_feature_count.argtypes = [vp]; _lib_m.lvref_fm_feature_count.restype = i
+        self.h = _lib_m.lvref_fm_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib_m.lvref_fm_destroy(self.h); self.h = None
+
+    def add(self, frame_count, ids, uvv, td):
+        """addFeatureCheckParallax(frame_count, image, td): uvv = (n, 4) u, v, u_vel, v_vel -> True = marginalise the oldest frame"""
+        ids = np.ascontiguousarray(ids, np.int64); uvv = np.ascontiguousarray(uvv, np.float64).reshape(-1, 4)
+        return bool(_lib_m.lvref_fm_add(self.h, int(frame_count), len(ids), ids.ctypes.data, uvv.ctypes.data, float(td)))
+
+    def corresponding(self, l, r):
+        out = np.zeros((4096, 4)); n = _lib_m.lvref_fm_corresponding(self.h, int(l), int(r), out.ctypes.data, 4096)
+        return out[:n].copy()
+
+    def remove_back(self):
+        _lib_m.lvref_fm_remove_back(self.h)
+
+    def feature_count(self):
+        return _lib_m.lvref_fm_feature_count(self.h)
