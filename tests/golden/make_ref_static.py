@@ -3,7 +3,7 @@
 (oracle/Makefile target `ref`; Eigen served by oracle/ref_shim/lvref_eigen.hpp).  The outputs stored here are NOT the oracle's.
 Needs /root/reference; run from the repo root:
     python tests/golden/make_ref_static.py
-Cases (seeded): message streams at 10 Hz with 30-60 features, a platform at rest for 0.4-2.5 s (feature jitter 0.0002) that then moves
+Cases (seeded): message streams at 10 Hz with 30-60 features, a platform at rest for 0.4-1.9 s (feature jitter 0.0002) that then moves
 (displacements well above zupt_max_feature_dis), features that come and go (fewer than 20 common ones resets the counter), tilted IMUs
 (gravity direction random), a gyro bias, IMU noise; static_duration 1.0 s at 10 Hz (static_Num 10) and 0.5 s (5)."""
 import os
@@ -21,8 +21,8 @@ def cases(seed, n_cases):
     rng = np.random.default_rng(seed)
     for k in range(n_cases):
         static_num = 10 if k % 2 == 0 else 5
-        rest = rng.uniform(0.4, 2.5)
-        n_msgs = 32
+        rest = rng.uniform(0.4, 1.9)
+        n_msgs = 24
         ts = 10.0 + 0.1 * np.arange(n_msgs) + rng.uniform(0, 0.004)
         nf = int(rng.integers(30, 61))
         base = rng.uniform(-0.4, 0.4, (nf, 2))
@@ -55,15 +55,15 @@ def run_reference(c):
 
 
 def main():
-    N = 12
+    N = 8
     rec = dict(static_num=[], ts=[], ids=[], uv=[], nf=[], imu7=[], n_imu=[], msg=[], out=[])
     for c in cases(20260925, N):
         i, r = run_reference(c)
         nf = len(c["msgs"][0][1])
-        ids = np.zeros((32, 60), np.int64); uv = np.zeros((32, 60, 2))
+        ids = np.zeros((24, 60), np.int64); uv = np.zeros((24, 60, 2))
         for j, (t, a, b) in enumerate(c["msgs"]):
             ids[j, :nf] = a; uv[j, :nf] = b
-        imu = np.zeros((900, 7)); imu[:len(c["imu7"])] = c["imu7"]
+        imu = np.zeros((560, 7)); imu[:len(c["imu7"])] = c["imu7"]
         rec["static_num"].append(c["static_num"]); rec["ts"].append([m[0] for m in c["msgs"]]); rec["ids"].append(ids); rec["uv"].append(uv); rec["nf"].append(nf)
         rec["imu7"].append(imu); rec["n_imu"].append(len(c["imu7"])); rec["msg"].append(i)
         rec["out"].append(np.concatenate([[r["t"]], r["q"], r["bg"], [r["erased"]]]) if r is not None else np.zeros(9))

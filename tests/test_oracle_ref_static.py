@@ -69,7 +69,7 @@ def test_oracle_static_initialiser_against_the_references_committed_outputs():
     worst = 0.0; fired = 0
     for k in range(len(g["msg"])):
         nf = int(g["nf"][k])
-        msgs = [(float(g["ts"][k][j]), g["ids"][k][j, :nf], g["uv"][k][j, :nf]) for j in range(32)]
+        msgs = [(float(g["ts"][k][j]), g["ids"][k][j, :nf], g["uv"][k][j, :nf]) for j in range(24)]
         i_o, r_o = _oracle(int(g["static_num"][k]), msgs, g["imu7"][k][:int(g["n_imu"][k])], thresh)
         o = g["out"][k]
         r_r = dict(t=float(o[0]), q=o[1:5], bg=o[5:8], erased=int(o[8])) if g["msg"][k] >= 0 else None
