@@ -134,6 +134,16 @@ def math_small_angle(w):
     return S.reshape(3, 3), a, b
 
 
+def math_quat(q, p):
+    """math_utils.hpp of the compiled reference: (quaternionToRotation(q) 3x3, rotationToQuaternion(of that) [x y z w],
+    quaternionMultiplication(q, p) [x y z w] - normalised, as the reference's is)"""
+    L = _libf()
+    L.lvref_math_quat.argtypes = [C.c_void_p] * 5
+    q = np.ascontiguousarray(q, np.float64); p = np.ascontiguousarray(p, np.float64); R = np.zeros(9); q2 = np.zeros(4); qp = np.zeros(4)
+    L.lvref_math_quat(q.ctypes.data, p.ctypes.data, R.ctypes.data, q2.ctypes.data, qp.ctypes.data)
+    return R.reshape(3, 3), q2, qp
+
+
 def feature_check_motion(state_ids, q_cam, p_cam, obs_ids, obs_uv, if_tracked, translation_threshold):
     """Feature::checkMotion (feature.hpp:334-381) of the compiled reference"""
     sid, q, p, oid, uv = _views(state_ids, q_cam, p_cam, obs_ids, obs_uv)

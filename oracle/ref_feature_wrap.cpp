@@ -77,4 +77,16 @@ void lvref_math_small_angle(const double* w, double* out9, double* out4a, double
     out4b[0] = g.x(); out4b[1] = g.y(); out4b[2] = g.z(); out4b[3] = g.w();
 }
 
+// ... and the conversions (math_utils.hpp:54-83 quaternionMultiplication - normalises its result -, :145-160 quaternionToRotation, :169-232
+// rotationToQuaternion): R9 = quaternionToRotation(q) row-major, q2 = rotationToQuaternion(R9), qp = quaternionMultiplication(q, p)
+void lvref_math_quat(const double* q, const double* p, double* R9, double* q2, double* qp)
+{
+    const Eigen::Vector4d a(q[0], q[1], q[2], q[3]), b(p[0], p[1], p[2], p[3]);
+    const Eigen::Matrix3d R = quaternionToRotation(a);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[3 * i + j] = R(i, j);
+    const Eigen::Vector4d c = rotationToQuaternion(R);
+    const Eigen::Vector4d d = quaternionMultiplication(a, b);
+    for (int k = 0; k < 4; ++k) { q2[k] = c(k); qp[k] = d(k); }
+}
+
 }  // extern "C"

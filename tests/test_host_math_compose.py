@@ -63,7 +63,9 @@ def test_moving_start_initialiser_blocks_and_whole_on_closed_form_cases(tmp_path
 def test_product_host_math_against_scipy(tmp_path):
     """be_host_math.h (quaternion / 3x3 helpers of the product's host side; Hamilton [x y z w] as math_utils.hpp:54-102, Eigen's
     Quaternion <-> matrix formulas) against scipy / numpy on 200 random inputs incl. the trace <= 0 branches of the matrix -> quaternion
-    conversion.  These helpers share their text with oracle/be_math.h: this is their pin that does not pass through the oracle."""
+    conversion - and, where oracle/_ref is built, against the reference's own math_utils.hpp compiled in place (skewSymmetric, both small-angle
+    quaternions, quaternionToRotation, rotationToQuaternion, quaternionMultiplication).  These helpers share their text with
+    oracle/be_math.h: this is their pin that does not pass through the oracle."""
     import json
     import numpy as np
     from scipy.spatial.transform import Rotation
@@ -93,4 +95,8 @@ def test_product_host_math_against_scipy(tmp_path):
         if ref is not None:                                                         # ... and against the reference's own math_utils.hpp compiled in place (oracle/_ref)
             S_r, qa, qb = ref.math_small_angle(w)
             assert np.array_equal(np.reshape(r["S"], (3, 3)), S_r) and np.abs(np.array(r["dq"]) - qa).max() < 1e-15 and np.abs(np.array(r["dq"]) - qb).max() < 1e-15
+            R_r, q2_r, qp_r = ref.math_quat(q, p)                                   # quaternionToRotation / rotationToQuaternion / quaternionMultiplication
+            assert np.abs(np.reshape(r["R"], (3, 3)) - R_r).max() < 1e-15
+            assert min(np.abs(q2 - q2_r).max(), np.abs(q2 + q2_r).max()) < 1e-13     # two branch rules (Eigen's, the reference's own), one rotation
+            gn = got / np.linalg.norm(got); assert min(np.abs(gn - qp_r).max(), np.abs(gn + qp_r).max()) < 1e-14
     assert saw_neg_trace >= 20
