@@ -12,6 +12,8 @@
 #include "chi2_table.inc"
 #include <algorithm>
 #include <iterator>
+#include <utility>
+#include <type_traits>
 
 double lvk_chi2_005(int dof) { return (dof >= 1 && dof <= 99) ? k_chi2_005[dof] : 0.0; }
 
@@ -111,21 +113,47 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse(const double* __restri
 // The same node with its columns in REGISTERS.  What paced k_qr_sparse was not flops but its per-step chain: three LDS-latency-bound loops
 // over the column (dot product, update, next norm) and a 64-lane reduction per column (~1.3-2.2 us per reflector, ~55 reflectors per
 // node: 77-150 us per level).  Here a column is spread over SIXTEEN lanes (lane l holds rows l, l + 16, ...), four columns share one
-// wavefront instruction, and a workgroup of sixteen wavefronts covers 64 columns per "quad" (QUADS of them): a dot product is RPL FMAs
-// on registers and a four-step DPP rotation inside the 16-lane row - for four columns at once, the sum arriving in every lane that
-// needs it - and the update is RPL FMAs.  Only the reflector itself travels through LDS (double-buffered, one barrier per step: the
-// wavefront that owns column k+1 updates it first and publishes its reflector in the shadow of the other columns' updates).
-// The gather on the way in and the expansion on the way out go through the same column-major LDS image as k_qr_sparse.
+// wavefront instruction, and a workgroup of sixteen wavefronts covers the 64 columns of a node: a dot product is RPL FMAs on registers
+// and a four-step DPP rotation inside the 16-lane row - for four columns at once, the sum arriving in every lane that needs it - and
+// the update is RPL FMAs.  Only the reflector itself travels through LDS (double-buffered, one barrier per step: the wavefront that
+// owns column k+1 updates it first and publishes its reflector in the shadow of the other columns' updates).
+// Round 5 - the step is ONE dependent chain (LDS read of v, dot, row sum, update, next norm, row sum, 1/sqrt, 1/x, LDS write, barrier)
+// on the wavefront that owns the next column, and what it cost was instructions on that chain, not flops:
+//   * the file is built without FP contraction, so `s += v * a` was a multiply AND an add - 32 dependent operations per dot product
+//     and as many per norm; now explicit FMAs into four partial sums (6 dependent levels);
+//   * the finished row chunks (rows < 16 (k >> 4)) were skipped through sixteen exec-masked LDS reads with six scalar instructions
+//     each; the step loop is now unrolled over the chunk index, so every register index, the set of chunks still alive and the one
+//     chunk that needs a per-lane row mask are compile-time facts (the reflector buffer is padded to 16 RPL rows: no `i < R` tests);
+//   * the pivot element comes from one v_readlane pair instead of a masked row sum, 2 / |v|^2 = (1/|x|) / (|x| + |x_k|) from the
+//     1/sqrt already at hand and ONE refined reciprocal instead of a second 1/sqrt chain;
+//   * the rows come straight from global memory into the registers, sixteen loads in flight per lane (the gather through the LDS
+//     image issued a column-list load and a row load per row, one after the other: 2 x 16 dependent trips to L2 before the first
+//     reflector); the LDS image is only used on the way out, for the expansion to the dense column layout, and only its first
+//     `ncols` rows are written.
+template <int... I, class F> __device__ __forceinline__ void lvk_static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 __device__ __forceinline__ double row16_sum_f64(double v)
 {   // every lane ends up with the sum over its 16-lane DPP row
     v += dpp_ror_f64(v, 8); v += dpp_ror_f64(v, 4); v += dpp_ror_f64(v, 2); v += dpp_ror_f64(v, 1);
     return v;
+}
+__device__ __forceinline__ double readlane_dyn_f64(double v, int lane)
+{   // lane: wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rcp_refined(double x)
+{   // v_rcp_f64 seed + two Newton steps, all FMAs
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0); r = __builtin_fma(r, e, r);
+    return r;
 }
 template <int RPL, int QUADS>
 __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse_reg(const double* __restrict__ Hin, int ldin, const double* __restrict__ rin,
                                                              double* __restrict__ Hout, int ldout, double* __restrict__ rout,
                                                              const QrBlock* __restrict__ blocks, const int* __restrict__ col_lists, int N)
 {
+    static_assert(QUADS == 1, "one column quad per wavefront: nodes of at most 63 columns + the residual");
     extern __shared__ double sm[];
     const QrBlock b = blocks[blockIdx.x];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l16 = lane & 15, cq = lane >> 4;
@@ -137,96 +165,102 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse_reg(const double* __re
         }
         return;
     }
+    constexpr int VLD = 16 * RPL;                                      // rows of a reflector buffer (rows >= R hold zeros, as the registers do)
     const int nc = b.ncols, R = b.in_rows, Rp = R | 1;
-    double* A = sm;                                                    // (nc + 1) columns of Rp doubles; column nc is the residual
+    double* A = sm;                                                    // (nc + 1) columns of Rp doubles; column nc is the residual (used on the way out only)
     double* diag = A + (size_t)(nc + 1) * Rp;                          // nc
     double* scal = diag + nc;                                          // 2 (beta of the current / the next step)
-    double* vbuf = scal + 2;                                           // 2 x Rp: the reflector of the current / the next step
-    int* inv = (int*)(vbuf + 2 * (size_t)Rp);                          // N: dense column -> position in the union (or -1)
+    double* vbuf = scal + 2;                                           // 2 x VLD: the reflector of the current / the next step
+    int* inv = (int*)(vbuf + 2 * (size_t)VLD);                         // N: dense column -> position in the union (or -1)
     const int* cols = col_lists + b.col_off;
-    for (int j = t; j < N; j += QS_THREADS) inv[j] = -1;
-    for (int i = wave; i < R; i += QS_WAVES) {
-        const double* src = Hin + (size_t)(b.in_start + i) * ldin;
-        for (int c = lane; c <= nc; c += 64) A[(size_t)c * Rp + i] = c < nc ? src[cols[c]] : rin[b.in_start + i];
-    }
-    __syncthreads();
-    for (int c = t; c < nc; c += QS_THREADS) inv[cols[c]] = c;
-    // ---- columns into registers: quad Q = wave + 16 qd holds columns 4Q .. 4Q + 3, this lane column 4Q + cq, rows l16 + 16 rr
-    double a[QUADS][RPL];
+    // ---- columns into registers: this wavefront holds columns 4 wave .. 4 wave + 3, this lane column j = 4 wave + cq, rows l16 + 16 rr
+    const int j = 4 * wave + cq;
+    const int my_col = j < nc ? cols[j] : 0, inv_col = t < nc ? cols[t] : 0;
+    for (int q = t; q < N; q += QS_THREADS) inv[q] = -1;
+    double a[RPL];
+    {
+        const double* base = j < nc ? Hin + (size_t)b.in_start * ldin + my_col : rin + b.in_start;
+        const size_t stride = j < nc ? (size_t)ldin : 1;
+        double x[RPL];
 #pragma unroll
-    for (int qd = 0; qd < QUADS; ++qd) {
-        const int j = 4 * (wave + QS_WAVES * qd) + cq;
+        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; x[rr] = base[(size_t)(i < R ? i : R - 1) * stride]; }     // all in flight
 #pragma unroll
-        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; a[qd][rr] = (j <= nc && i < R) ? A[(size_t)j * Rp + i] : 0.; }
+        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; a[rr] = (j <= nc && i < R) ? x[rr] : 0.; }
     }
     const int steps = nc < R - 1 ? nc : R - 1;
-    // reflector of column k (rows k..): by the 16 lanes that hold it; v -> vbuf[k & 1], beta -> scal[k & 1], R's diagonal -> diag[k]
-    auto prep = [&](int k) {
-        const int qd = (k >> 2) / QS_WAVES;                              // (the caller made sure this wavefront owns column k)
-        if (cq != (k & 3)) return;
-        double part = 0., akk = 0.;
+    // reflector of column k (pivot row k in the row chunk PC = k >> 4), by the 16 lanes that hold the column (the caller made sure this
+    // wavefront owns it): v -> vbuf[k & 1] (chunks >= PC: all a later step reads), beta -> scal[k & 1], R's diagonal -> diag[k]
+    auto prep = [&](auto pc_, int k) __attribute__((always_inline)) {
+        constexpr int PC = decltype(pc_)::value;
+        if constexpr (PC < RPL) {
+            if (cq != (k & 3)) return;
+            const int k15 = k & 15;
+            double p[4] = {0., 0., 0., 0.};
+            { const double x = l16 >= k15 ? a[PC] : 0.; p[0] = x * x; }
 #pragma unroll
-        for (int q2 = 0; q2 < QUADS; ++q2) if (q2 == qd) {
+            for (int rr = PC + 1; rr < RPL; ++rr) p[(rr - PC) & 3] = __builtin_fma(a[rr], a[rr], p[(rr - PC) & 3]);
+            const double s = row16_sum_f64((p[0] + p[1]) + (p[2] + p[3]));
+            const double akk = readlane_dyn_f64(a[PC], 16 * (k & 3) + k15);
+            // (1/sqrt and 1/x from FMA-refined hardware seeds: the IEEE sqrt and divide expand to ~80 instructions on this step's chain)
+            const double y = s > 0. ? rsqrt_goldschmidt(s) : 0.;
+            const double nrm = s * y;
+            const double alpha = akk >= 0. ? -nrm : nrm;
+            // beta = 2 / |x - alpha e_k|^2 = 2 / (2 (s - alpha a_kk)) = 1 / (|x| (|x| + |a_kk|))
+            const double beta = nrm != 0. ? y * rcp_refined(nrm + fabs(akk)) : 0.;
+            double* vb = vbuf + (size_t)(k & 1) * VLD;
+            { const double x = a[PC]; vb[l16 + 16 * PC] = l16 < k15 ? 0. : (l16 == k15 && beta != 0.) ? x - alpha : x; }
 #pragma unroll
-            for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; const double x = a[q2][rr]; if (i >= k) part += x * x; if (i == k) akk = x; }
+            for (int rr = PC + 1; rr < RPL; ++rr) vb[l16 + 16 * rr] = a[rr];
+            if (l16 == 0) { diag[k] = beta != 0. ? alpha : akk; scal[k & 1] = beta; }
         }
-        const double s = row16_sum_f64(part);
-        akk = row16_sum_f64(akk);
-        // (norm and 2 / |v|^2 from FMA-refined hardware seeds: the IEEE sqrt and divide expand to ~80 instructions on this step's chain)
-        const double nrm = s > 0. ? s * rsqrt_goldschmidt(s) : 0.;
-        const double alpha = akk >= 0. ? -nrm : nrm;
-        const double vn2 = 2. * (s - alpha * akk);                 // |x - alpha e_k|^2
-        double beta = 0.;
-        if (nrm != 0. && vn2 != 0.) { const double y = rsqrt_goldschmidt(vn2); beta = 2. * (y * y); }
-        double* vb = vbuf + (size_t)(k & 1) * Rp;
-#pragma unroll
-        for (int q2 = 0; q2 < QUADS; ++q2) if (q2 == qd) {
-#pragma unroll
-            for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; if (i < R) vb[i] = i < k ? 0. : (i == k && beta != 0.) ? a[q2][rr] - alpha : a[q2][rr]; }
-        }
-        if (l16 == 0) { diag[k] = beta != 0. ? alpha : akk; scal[k & 1] = beta; }
     };
-    if (wave == 0 && steps > 0) prep(0);
-    __syncthreads();
-    for (int k = 0; k < steps; ++k) {
-        const double beta = scal[k & 1];
-        const double* vb = vbuf + (size_t)(k & 1) * Rp;
-        const int r0 = k >> 4;                                       // rows below 16 r0 are finished
-        double v[RPL];
+    // step k inside row chunk R0 = k >> 4 (rows below 16 R0 are finished); PC: the chunk of the NEXT pivot row
+    auto step = [&](auto r0_, auto pc_, int k) __attribute__((always_inline)) {
+        constexpr int R0 = decltype(r0_)::value;
+        if (4 * wave + 3 > k) {                                        // (wave-uniform, known without a memory access) a column right of k lives here
+            // beta == 0 (a column that was zero below its diagonal): s = 0, nothing moves.  Finished columns of the quad keep their values
+            // (a - 0 v); the column test is a FACTOR of beta, not a select around it: with a select the compiler turns it into a branch and
+            // sinks beta's LDS read into it, behind the row sum - one more LDS latency on the chain.
+            const double bm = scal[k & 1] * ((j > k && j <= nc) ? 1.0 : 0.0);
+            const double* vb = vbuf + (size_t)(k & 1) * VLD;
+            double v[RPL];
 #pragma unroll
-        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; v[rr] = (rr >= r0 && i < R) ? vb[i] : 0.; }
-        const int own_next = (((k + 1) >> 2) % QS_WAVES) == wave && k + 1 < steps;
+            for (int rr = R0; rr < RPL; ++rr) v[rr] = vb[l16 + 16 * rr];
+            double p[4] = {0., 0., 0., 0.};
 #pragma unroll
-        for (int qd = 0; qd < QUADS; ++qd) {
-            const int j = 4 * (wave + QS_WAVES * qd) + cq;
-            if (4 * (wave + QS_WAVES * qd) + 3 <= k || beta == 0.) continue;      // the whole quad is finished (wave-uniform)
-            double s = 0.;
+            for (int rr = R0; rr < RPL; ++rr) p[(rr - R0) & 3] = __builtin_fma(v[rr], a[rr], p[(rr - R0) & 3]);
+            const double sj = row16_sum_f64((p[0] + p[1]) + (p[2] + p[3])) * bm;
 #pragma unroll
-            for (int rr = 0; rr < RPL; ++rr) s += v[rr] * a[qd][rr];
-            s = row16_sum_f64(s) * beta;
-            if (j > k && j <= nc) {
-#pragma unroll
-                for (int rr = 0; rr < RPL; ++rr) a[qd][rr] -= s * v[rr];
-            }
+            for (int rr = R0; rr < RPL; ++rr) a[rr] = __builtin_fma(-sj, v[rr], a[rr]);
         }
-        if (own_next) prep(k + 1);                                   // in the shadow of the other wavefronts' updates
+        if (k + 1 < steps && ((k + 1) >> 2) == wave) prep(pc_, k + 1);  // in the shadow of the other wavefronts' updates
         __syncthreads();
-    }
-    // ---- back to the LDS image (rows above the diagonal are R; the diagonal comes from diag[]), then expanded to the dense layout
+    };
+    if (wave == 0 && steps > 0) prep(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+    if (t < nc) inv[inv_col] = t;
+    lvk_static_for(std::make_integer_sequence<int, (RPL < 4 ? RPL : 4)>{}, [&](auto r0_) __attribute__((always_inline)) {      // steps <= 63: four chunks at most
+        constexpr int R0 = decltype(r0_)::value;
+        if (16 * R0 >= steps) return;
+        const int kend = 16 * R0 + 15 < steps ? 16 * R0 + 15 : steps;
+        for (int k = 16 * R0; k < kend; ++k) step(r0_, r0_, k);
+        if (16 * R0 + 15 < steps) step(r0_, std::integral_constant<int, R0 + 1>{}, 16 * R0 + 15);
+    });
+    // ---- the first nc rows back to the LDS image (rows above the diagonal are R; the diagonal comes from diag[]), then expanded to
+    // the dense layout
 #pragma unroll
-    for (int qd = 0; qd < QUADS; ++qd) {
-        const int j = 4 * (wave + QS_WAVES * qd) + cq;
-#pragma unroll
-        for (int rr = 0; rr < RPL; ++rr) { const int i = l16 + 16 * rr; if (j <= nc && i < R) A[(size_t)j * Rp + i] = a[qd][rr]; }
+    for (int rr = 0; rr < RPL; ++rr) {
+        const int i = l16 + 16 * rr;
+        if (16 * rr < nc && j <= nc && i < R) A[(size_t)j * Rp + i] = a[rr];
     }
     __syncthreads();
     for (int i = wave; i < b.out_rows; i += QS_WAVES) {
         double* dst = Hout + (size_t)(b.out_start + i) * ldout;
-        for (int j = lane; j < N; j += 64) {
-            const int c = inv[j];
+        for (int jj = lane; jj < N; jj += 64) {
+            const int c = inv[jj];
             double val = 0.;
             if (c >= i && i < R) val = (c == i) ? (i < steps ? diag[i] : A[(size_t)i * Rp + i]) : A[(size_t)c * Rp + i];
-            dst[j] = val;
+            dst[jj] = val;
         }
         if (lane == 0) rout[b.out_start + i] = i < R ? A[(size_t)nc * Rp + i] : 0.;
     }
@@ -236,7 +270,7 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse_reg(const double* __re
 size_t lvk_qr_sparse_lds_bytes(int rows, int ncols, int N)
 {
     const size_t Rp = (size_t)(rows | 1);
-    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2 + 2 * Rp) + sizeof(int) * (size_t)N + 16;
+    return sizeof(double) * ((size_t)(ncols + 1) * Rp + (size_t)ncols + 2 + 2 * (Rp > 256 ? Rp : 256)) + sizeof(int) * (size_t)N + 16;    // (2 x 256: the register kernel's padded reflector buffers)
 }
 template <int RPL, int QUADS>
 static lvk_status launch_qr_reg(lvk_context* ctx, int slot, const double* d_Hin, int ldin, const double* d_rin, double* d_Hout, int ldout, double* d_rout,

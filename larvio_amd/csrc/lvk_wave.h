@@ -7,13 +7,14 @@
 // 64-bit value moves as two 32-bit DPP movs), then the four row sums are read with v_readlane and added.  (__shfl_xor on a double is
 // two ds_bpermute per stage, ~12 LDS round trips per reduction: it dominated the first version of the LDS-resident QR nodes.)
 __device__ __forceinline__ double dpp_ror_f64(double v, const int ctrl_sel)
-{
+{   // (bound_ctrl set: a row rotation has no invalid source lane, and with it the compiler need not initialise the destination - two
+    // v_mov per 64-bit move less on every reduction chain)
     int lo = __double2loint(v), hi = __double2hiint(v);
     switch (ctrl_sel) {
-        case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false); break;
-        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, false); break;
-        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xF, 0xF, false); break;
-        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false); break;
+        case 8: lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true); break;
+        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, true); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xF, 0xF, true); break;
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, true); break;
     }
     return __hiloint2double(hi, lo);
 }
