@@ -375,6 +375,10 @@ __device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (
         double piv = readlane_f64(half ? a11[0] : a00[0], 0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
+            // pivots in the identity padding (the last panel of a matrix whose size is not a multiple of 32: half a panel on average,
+            // ~3 us of the ~28 an update's factorisation takes) change nothing - D and Y keep their identity rows, L10's padding rows are
+            // zero - and are skipped (wave-uniform scalar branch)
+            if (16 * half + j >= nb) continue;
             const int q = j >> 2, gj = j & 3;
             d4& aa = half ? a11 : a00; d4& yy = half ? y11 : y00;
             const bool okp = piv > 0.;
