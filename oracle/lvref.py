@@ -312,3 +312,133 @@ class RefFeatureManager:
 
     def feature_count(self):
         return _lib_m.lvref_fm_feature_count(self.h)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's filter itself
+_SO_LARVIO = os.environ.get("LVREF_LARVIO_SO", os.path.join(_HERE, "_ref", "liblvref_larvio.so"))
+_libv = None
+
+
+def larvio_available(build=True):
+    if os.path.exists(_SO_LARVIO):
+        return True
+    if build and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_LARVIO)
+
+
+def _libl():
+    global _libv
+    if _libv is None:
+        if not larvio_available():
+            raise RuntimeError("oracle/_ref/liblvref_larvio.so is missing and /root/reference is not here to build it from")
+        L = C.CDLL(_SO_LARVIO)
+        vp, i, d = C.c_void_p, C.c_int, C.c_double
+        L.lvref_larvio_create.restype = vp; L.lvref_larvio_create.argtypes = [C.c_char_p]
+        L.lvref_larvio_destroy.argtypes = [vp]
+        L.lvref_larvio_set_state.argtypes = [vp, d] + [vp] * 7
+        L.lvref_larvio_process.restype = i; L.lvref_larvio_process.argtypes = [vp, d, i, vp, i, vp, C.POINTER(i)]
+        L.lvref_larvio_dim.restype = i; L.lvref_larvio_dim.argtypes = [vp]
+        L.lvref_larvio_initialized.restype = i; L.lvref_larvio_initialized.argtypes = [vp]
+        L.lvref_larvio_get_state.argtypes = [vp, vp]; L.lvref_larvio_get_cov.argtypes = [vp, vp]
+        L.lvref_larvio_get_clones.restype = i; L.lvref_larvio_get_clones.argtypes = [vp, vp, i]
+        L.lvref_larvio_get_features.restype = i; L.lvref_larvio_get_features.argtypes = [vp, vp, vp, vp, i]
+        L.lvref_larvio_map_size.restype = i; L.lvref_larvio_map_size.argtypes = [vp]
+        L.lvref_larvio_chi2.restype = d; L.lvref_larvio_chi2.argtypes = [vp, i]
+        _libv = L
+    return _libv
+
+
+def larvio_yaml(cfg, output_dir):
+    """the oracle's configuration dict (larvio_amd.synthetic.backend_config) written the way the reference ships its own
+    (config/euroc.yaml: `%YAML:1.0`, an `!!opencv-matrix` node for T_cam_imu) - every key LarVio::loadParameters reads
+    (larvio.cpp:58-311); feature_idp_dim 1 and use_schmidt 0 are the modes this repository implements"""
+    T = np.asarray(cfg["T_cam_imu"], np.float64).reshape(4, 4)
+    fx, fy, cx, cy = cfg["intrinsics"]
+    g = lambda k: repr(float(cfg[k]))
+    lines = ["%YAML:1.0", "", 'output_dir: "%s"' % (output_dir if output_dir.endswith("/") else output_dir + "/"),
+             "if_FEJ: %d" % cfg["if_fej"], "estimate_extrin: %d" % cfg["estimate_extrin"], "estimate_td: %d" % cfg["estimate_td"],
+             "calib_imu_instrinsic: %d" % int(cfg.get("calib_imu_instrinsic", 0)),
+             "resolution_width: %d" % cfg["width"], "resolution_height: %d" % cfg["height"],
+             "intrinsics:", "   fx: %r" % float(fx), "   fy: %r" % float(fy), "   cx: %r" % float(cx), "   cy: %r" % float(cy),
+             "T_cam_imu: !!opencv-matrix", "   rows: 4", "   cols: 4", "   dt: d", "   data:",
+             "    [" + ",\n     ".join(", ".join(repr(float(x)) for x in row) for row in T) + "]",
+             "td: " + g("td"), "pub_frequency: " + g("pub_frequency"), "sw_size: %d" % cfg["sw_size"],
+             "position_std_threshold: 8.0", "rotation_threshold: " + g("rotation_threshold"), "translation_threshold: " + g("translation_threshold"),
+             "tracking_rate_threshold: " + g("tracking_rate_threshold"), "feature_translation_threshold: " + g("feature_translation_threshold"),
+             "noise_gyro: " + g("noise_gyro"), "noise_acc: " + g("noise_acc"), "noise_gyro_bias: " + g("noise_gyro_bias"), "noise_acc_bias: " + g("noise_acc_bias"),
+             "noise_feature: " + g("noise_feature"), "zupt_noise_v: " + g("zupt_noise_v"), "zupt_noise_p: " + g("zupt_noise_p"), "zupt_noise_q: " + g("zupt_noise_q")]
+    for k in ("orientation", "velocity", "position", "gyro_bias", "acc_bias", "extrin_rot", "extrin_trans"):
+        lines.append("initial_covariance_%s: %s" % (k, g("initial_covariance_" + k)))
+    lines += ["reset_fej_threshold: 10.11", "if_ZUPT_valid: %d" % cfg["if_zupt_valid"], "zupt_max_feature_dis: " + g("zupt_max_feature_dis"),
+              "static_duration: " + g("static_duration"), "imu_rate: " + g("imu_rate"), "max_track_len: %d" % cfg["max_track_len"],
+              "feature_idp_dim: 1", "use_schmidt: 0", "least_observation_number: %d" % cfg["least_observation_number"],
+              "max_features_in_one_grid: %d" % cfg["max_features_in_one_grid"], "aug_grid_rows: %d" % cfg["aug_grid_rows"], "aug_grid_cols: %d" % cfg["aug_grid_cols"], ""]
+    return "\n".join(lines)
+
+
+class RefLarVio:
+    """larvio::LarVio (src/larvio.cpp) of the compiled reference, driven like the oracle's lvo_be.Ekf: process(ts, feats, imu) takes the
+    message (lvo.OBS records) and the driver's whole IMU view for it (the samples the previous call did not erase come first, as
+    tests/feature_sim.drive hands them over) and returns (processFeatures' answer, samples erased from that view)."""
+
+    def __init__(self, cfg, workdir):
+        os.makedirs(workdir, exist_ok=True)
+        self._yaml = os.path.join(workdir, "lvref_larvio.yaml")
+        with open(self._yaml, "w") as f:
+            f.write(larvio_yaml(cfg, workdir))
+        self.h = _libl().lvref_larvio_create(self._yaml.encode())
+        if not self.h:
+            raise RuntimeError("the reference's LarVio::initialize() failed on " + self._yaml)
+        self._held = 0                      # samples of the caller's view that already sit in the wrapper's buffer
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _libl().lvref_larvio_destroy(self.h); self.h = None
+
+    def set_state(self, t, q, p, v, bg, ba, gyro_old, acc_old):
+        a = [np.ascontiguousarray(x, np.float64) for x in (q, p, v, bg, ba, gyro_old, acc_old)]
+        _libl().lvref_larvio_set_state(self.h, float(t), *[x.ctypes.data for x in a])
+
+    def process(self, ts, feats, imu):
+        n = len(feats); f = np.zeros((n, 9))
+        for k, name in enumerate(("id", "u", "v", "u_init", "v_init", "u_vel", "v_vel", "u_init_vel", "v_init_vel")):
+            f[:, k] = feats[name]
+        new = imu[self._held:]                                       # the view's head is what the buffer still holds
+        m = np.zeros((len(new), 7)); m[:, 0] = new["t"]; m[:, 1:4] = new["gyro"]; m[:, 4:7] = new["acc"]
+        left = C.c_int(0)
+        ok = _libl().lvref_larvio_process(self.h, float(ts), n, f.ctypes.data, len(m), m.ctypes.data, C.byref(left))
+        used = len(imu) - left.value
+        self._held = left.value
+        return bool(ok), used
+
+    @property
+    def dim(self):
+        return _libl().lvref_larvio_dim(self.h)
+
+    @property
+    def initialized(self):
+        return bool(_libl().lvref_larvio_initialized(self.h))
+
+    def state(self):
+        o = np.zeros(30); _libl().lvref_larvio_get_state(self.h, o.ctypes.data)
+        return dict(t=o[0], q=o[1:5].copy(), v=o[5:8].copy(), p=o[8:11].copy(), bg=o[11:14].copy(), ba=o[14:17].copy(),
+                    R_b2c=o[17:26].reshape(3, 3).copy(), t_c_b=o[26:29].copy(), td=o[29])
+
+    def cov(self):
+        N = self.dim; P = np.zeros((N, N)); _libl().lvref_larvio_get_cov(self.h, P.ctypes.data); return P
+
+    def clones(self):
+        o = np.zeros((256, 12)); n = _libl().lvref_larvio_get_clones(self.h, o.ctypes.data, 256)
+        return dict(id=o[:n, 0].astype(np.int64), time=o[:n, 1].copy(), q=o[:n, 2:6].copy(), p=o[:n, 6:9].copy(), p_fej=o[:n, 9:12].copy())
+
+    def features(self):
+        ids = np.zeros(4096, np.int64); idp = np.zeros(4096); pos = np.zeros((4096, 3))
+        n = _libl().lvref_larvio_get_features(self.h, ids.ctypes.data, idp.ctypes.data, pos.ctypes.data, 4096)
+        return ids[:n].copy(), idp[:n].copy(), pos[:n].copy()
+
+    def map_size(self):
+        return _libl().lvref_larvio_map_size(self.h)
+
+    def chi2(self, dof):
+        return _libl().lvref_larvio_chi2(self.h, dof)

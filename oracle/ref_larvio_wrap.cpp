@@ -1,0 +1,135 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY (see oracle/lvo.h).  C entry points around the REFERENCE's own filter - /root/reference/src/larvio.cpp,
+// src/FlexibleInitializer.cpp, src/StaticInitializer.cpp and src/feature_manager.cpp are compiled where they lie (oracle/Makefile, target
+// `ref` -> oracle/_ref/liblvref_larvio.so; never copied) against the stand-in headers of oracle/ref_shim2/ (Eigen, OpenCV's FileStorage,
+// boost's chi-squared quantile and shared_ptr, the Ceres names initial_sfm.h mentions).  What is NOT the reference's: the moving-start
+// initialiser's body (DynamicInitializer.cpp needs OpenCV proper and Ceres through solve_5pts.cpp / initial_sfm.cpp) - its two entry
+// points are defined below as "never succeeds", so a stream must start at rest (the reference's StaticInitializer fires) or from a
+// state handed in through lvref_larvio_set_state.  Used by oracle/lvref.py (RefLarVio) to hold the oracle's filter, update by update,
+// to LarVio::processFeatures itself.
+#include <string>
+#include <vector>
+#include <map>
+#include <set>
+#include <list>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <cstring>
+#include "lvref_eigen2.hpp"
+#include <boost/shared_ptr.hpp>
+#define private public
+#define protected public
+#include <larvio/larvio.h>
+#undef private
+#undef protected
+
+namespace larvio {
+// the moving-start initialiser is not part of this build (see the header comment)
+bool DynamicInitializer::tryDynInit(const std::vector<ImuData>&, MonoCameraMeasurementPtr) { return false; }
+void DynamicInitializer::assignInitialState(std::vector<ImuData>&, Eigen::Vector3d&, Eigen::Vector3d&, IMUState&) {}
+GlobalSFM::GlobalSFM() {}
+}
+
+using namespace larvio;
+
+struct RefVio {
+    LarVio* vio = nullptr;
+    std::vector<ImuData> imu;
+    MonoCameraMeasurement msg;
+};
+
+extern "C" {
+
+void* lvref_larvio_create(const char* yaml_path)
+{
+    IMUState::next_id = 0; Feature::next_id = 0;
+    std::string p(yaml_path);
+    std::streambuf* keep = std::cout.rdbuf(); std::ostringstream sink; std::cout.rdbuf(sink.rdbuf());      // (the reference prints its set-up)
+    RefVio* r = new RefVio(); r->vio = new LarVio(p);
+    const bool ok = r->vio->initialize();
+    std::cout.rdbuf(keep);
+    if (!ok) { delete r->vio; delete r; return nullptr; }
+    return r;
+}
+void lvref_larvio_destroy(void* h) { RefVio* r = (RefVio*)h; if (r) { delete r->vio; delete r; } }
+
+// start from a given state instead of an initialiser: what LarVio::processFeatures does when tryIncInit succeeds (larvio.cpp:375-391),
+// with the state handed in (the oracle's lvo_ekf_set_state is the same bypass; both let in-state features in at once)
+void lvref_larvio_set_state(void* h, double t, const double* q, const double* p, const double* v, const double* bg, const double* ba,
+                            const double* gyro_old, const double* acc_old)
+{
+    LarVio& L = *((RefVio*)h)->vio;
+    IMUState& s = L.state_server.imu_state;
+    s.time = t; s.orientation = Eigen::Vector4d(q[0], q[1], q[2], q[3]);
+    s.position = Eigen::Vector3d(p[0], p[1], p[2]); s.velocity = Eigen::Vector3d(v[0], v[1], v[2]);
+    s.gyro_bias = Eigen::Vector3d(bg[0], bg[1], bg[2]); s.acc_bias = Eigen::Vector3d(ba[0], ba[1], ba[2]);
+    L.m_gyro_old = Eigen::Vector3d(gyro_old[0], gyro_old[1], gyro_old[2]); L.m_acc_old = Eigen::Vector3d(acc_old[0], acc_old[1], acc_old[2]);
+    L.is_gravity_set = true; L.bFirstFeatures = true;
+    L.take_off_stamp = t; L.last_ZUPT_time = t - 10.0; L.last_update_time = t;
+    L.state_server.imu_state_FEJ_now = s;
+}
+
+// one LarVio::processFeatures call.  feats: n x 9 doubles (id, u, v, u_init, v_init, u_vel, v_vel, u_init_vel, v_init_vel);
+// imu: m x 7 doubles (t, gyro, acc) APPENDED to the driver's buffer (the call erases what it consumes, as in app/larvioMain.cpp).
+// Returns processFeatures' own answer; *n_left = samples left in the buffer.
+int lvref_larvio_process(void* h, double stamp, int n, const double* feats, int m, const double* imu, int* n_left)
+{
+    RefVio* r = (RefVio*)h;
+    for (int i = 0; i < m; ++i) r->imu.push_back(ImuData(imu[7 * i], imu[7 * i + 1], imu[7 * i + 2], imu[7 * i + 3], imu[7 * i + 4], imu[7 * i + 5], imu[7 * i + 6]));
+    r->msg.timeStampToSec = stamp; r->msg.features.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        MonoFeatureMeasurement& f = r->msg.features[(size_t)i]; const double* s = feats + 9 * i;
+        f.id = (unsigned long long)s[0]; f.u = s[1]; f.v = s[2]; f.u_init = s[3]; f.v_init = s[4]; f.u_vel = s[5]; f.v_vel = s[6]; f.u_init_vel = s[7]; f.v_init_vel = s[8];
+    }
+    std::streambuf* keep = std::cout.rdbuf(); std::ostringstream sink; std::cout.rdbuf(sink.rdbuf());
+    const bool ok = r->vio->processFeatures(&r->msg, r->imu);
+    std::cout.rdbuf(keep);
+    if (n_left) *n_left = (int)r->imu.size();
+    return ok ? 1 : 0;
+}
+
+int lvref_larvio_dim(void* h) { return ((RefVio*)h)->vio->state_server.state_cov.rows(); }
+int lvref_larvio_initialized(void* h) { return ((RefVio*)h)->vio->is_gravity_set ? 1 : 0; }
+// out30: t, q[4], v, p, bg, ba, R_imu_cam0 (row-major 9), t_cam0_imu, td   (the oracle's lvo_ekf_get_state layout)
+void lvref_larvio_get_state(void* h, double* o)
+{
+    LarVio& L = *((RefVio*)h)->vio; const IMUState& s = L.state_server.imu_state;
+    o[0] = s.time; for (int k = 0; k < 4; ++k) o[1 + k] = s.orientation(k);
+    for (int k = 0; k < 3; ++k) { o[5 + k] = s.velocity(k); o[8 + k] = s.position(k); o[11 + k] = s.gyro_bias(k); o[14 + k] = s.acc_bias(k); o[26 + k] = s.t_cam0_imu(k); }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[17 + 3 * i + j] = s.R_imu_cam0(i, j);
+    o[29] = L.state_server.td;
+}
+void lvref_larvio_get_cov(void* h, double* P)
+{   // row-major N x N
+    const Eigen::MatrixXd& C = ((RefVio*)h)->vio->state_server.state_cov; const int N = C.rows();
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) P[(size_t)i * N + j] = C(i, j);
+}
+// clones in window order: per clone 16 doubles (id, time, q[4], p[3], p_fej[3], q_cam... not kept: 0)
+int lvref_larvio_get_clones(void* h, double* out, int cap)
+{
+    LarVio& L = *((RefVio*)h)->vio; int n = 0;
+    for (const auto& kv : L.state_server.imu_states_augment) {
+        if (n >= cap) break;
+        double* o = out + 12 * n; const IMUState_Aug& c = kv.second;
+        o[0] = (double)c.id; o[1] = c.time; for (int k = 0; k < 4; ++k) o[2 + k] = c.orientation(k);
+        for (int k = 0; k < 3; ++k) { o[6 + k] = c.position(k); o[9 + k] = c.position_FEJ(k); }
+        ++n;
+    }
+    return n;
+}
+// in-state features in state order: ids, inverse depth, world position
+int lvref_larvio_get_features(void* h, long long* ids, double* idp, double* pos, int cap)
+{
+    LarVio& L = *((RefVio*)h)->vio; int n = 0;
+    for (auto fid : L.state_server.feature_states) {
+        if (n >= cap) break;
+        const Feature& f = L.map_server[fid];
+        ids[n] = (long long)fid; idp[n] = f.invDepth; for (int k = 0; k < 3; ++k) pos[3 * n + k] = f.position(k);
+        ++n;
+    }
+    return n;
+}
+int lvref_larvio_map_size(void* h) { return (int)((RefVio*)h)->vio->map_server.size(); }
+double lvref_larvio_chi2(void* h, int dof) { return ((RefVio*)h)->vio->chi_squared_test_table[dof]; }
+
+}  // extern "C"
