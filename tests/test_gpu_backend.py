@@ -141,7 +141,7 @@ def _messages(first, count, max_features=150):
     return msgs, imu_all, seq
 
 
-def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True, init_args=None):
+def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True, init_args=None, on_update=None):
     from oracle import lvo_be
     import larvio_amd
     ora = lvo_be.Ekf(cfg)
@@ -186,6 +186,8 @@ def _run_pair(gpu_ctx, msgs, imu_all, seq, cfg, init_from_gt=True, init_args=Non
         if len(io):
             assert _rel(dg, do_) < REL and _rel(pg, po) < REL
         assert worst_x < REL and worst_P < REL, (n_upd, worst_x, worst_P)
+        if on_update is not None:
+            on_update(sg, Pg, ig)                         # (the HIP filter's state, covariance and in-state feature ids after this update)
     cg, co = gpu.counters(), ora.counters()
     for k in ("hybrid", "msckf", "zupt", "gated_in", "gated_out", "map"):
         assert cg[k] == co[k], (k, cg, co)

@@ -89,3 +89,33 @@ def test_triangulation_kernel_against_the_references_own_outputs(gpu_ctx):
                     np.abs(sol - o[11:14]).max() / max(np.abs(sol).max(), 1.0))
     print("k_triangulate against the reference's committed outputs: %d of %d valid, worst relative difference %.1e" % (n_ok, len(g["n_views"]), worst))
     assert n_ok == int(g["ok"].sum()) and worst < 1e-6
+
+
+def test_filter_against_the_references_own_outputs(gpu_ctx):
+    """the HIP filter against what the REFERENCE'S OWN LarVio::processFeatures made of the stored back-end inputs - /root/reference/src/
+    larvio.cpp compiled in place (oracle/Makefile target `ref`), outputs written by tests/golden/make_ref_larvio.py into ref_larvio.npz
+    (stream A: the inputs of backend_sim.npz - start from a state, td + extrinsics estimated, 8-clone window, 19 updates with hybrid,
+    MSCKF and pruning steps); nothing of the reference is needed here.  After EVERY update: state dimension, the 30 state numbers,
+    P's leading 15 x 15 block, trace(P), |P|_F and the number of in-state features against the reference's record (1e-6 relative; the
+    oracle, which the pair runner also holds the HIP filter to, agrees with the reference to 1e-10 on this stream).  The file's second
+    stream (a start at rest: static initialiser + zero-velocity updates) is held on the CPU side, oracle against reference
+    (tests/test_oracle_ref_larvio.py)."""
+    from tests.test_oracle_backend import _load_backend_golden
+    from tests.test_gpu_backend import _run_pair
+    from tests.test_oracle_ref_larvio import check_against_row
+    z = np.load(os.path.join(GOLDEN, "ref_larvio.npz"))
+
+    class _Seq:
+        traj = None
+    za, cfg, init, msgs = _load_backend_golden()
+    k = [0]
+
+    def on_update(sg, Pg, ids):
+        row = z["a_state"][k[0]]
+        check_against_row(sg, Pg, row, z["a_p15"][k[0]], z["a_pnorm"][k[0]], tol=1e-6, exact_time=False)
+        assert len(ids) == int(row[31])
+        k[0] += 1
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, msgs, za["imu"], _Seq, cfg, init_args=init, on_update=on_update)
+    assert n_upd == k[0] == len(z["a_state"])
+    assert np.array_equal(ora.features()[0], z["a_feat_ids"])
+    print("HIP filter vs the reference's record: updates", n_upd, "(HIP vs oracle: state", wx, "P", wP, ")")
