@@ -8,13 +8,21 @@
  * bench.py's cpu_baseline leg may load it.  The product (larvio_amd/, include/) never
  * includes, links or calls anything here.
  *
- * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures (SURVEY.md §4,
- * §8c) and cannot be compiled in this environment (OpenCV, Eigen, SuiteSparse, Boost are
- * absent).  The arithmetic of the front-end lives in OpenCV (un-vendored, unpinned:
- * README.md:58 names 3.4.6 / 4.1.2); the functions below restate the published algorithms
- * of those OpenCV calls ("[upstream]" in comments) and follow the reference's own call
- * sites for parameters.  Where OpenCV's own result depends on its SIMD dispatch (float
- * summation order in LK / boxFilter), the oracle fixes ONE order and says so.
+ * PINNING.  The reference has no tests, golden vectors or fixtures and
+ * cannot be built as a whole here (OpenCV, Eigen, SuiteSparse, Boost, Ceres are absent).
+ * BACK-END: PINNED to the reference's own code compiled in place - src/larvio.cpp
+ * (LarVio::processFeatures) with FlexibleInitializer / StaticInitializer / feature_manager
+ * against stand-in headers (oracle/ref_shim2/, oracle/Makefile target `ref`): the filter in
+ * be_filter.c / be_core.c agrees with it after every update (tests/test_oracle_ref_larvio.py,
+ * tests/golden/ref_larvio.npz written by the reference); likewise, in smaller pieces, the ORB
+ * descriptor, the triangulation, the static initialiser, the moving-start initialiser's window
+ * bookkeeping, pre-integration and alignment.
+ * FRONT-END: PARITY UNPINNED against reference outputs except the ORB block - its arithmetic
+ * lives in OpenCV (un-vendored, unpinned: README.md:58 names 3.4.6 / 4.1.2); the functions
+ * below restate the published algorithms of those OpenCV calls ("[upstream]" in comments) and
+ * follow the reference's own call sites for parameters.  Where OpenCV's own result depends on
+ * its SIMD dispatch (float summation order in LK / boxFilter), the oracle fixes ONE order and
+ * says so.
  *
  * All floating-point code here must be built with -ffp-contract=off (see Makefile): the
  * HIP kernels are built the same way so that float32 stages agree bit-for-bit.
