@@ -30,6 +30,12 @@ typedef unsigned char uchar;
 #define CV_PI 3.1415926535897932384626433832795
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_32F 5
+#define CV_32FC1 5
+#define CV_64F 6
+#define CV_64FC1 6
+inline size_t lvref_elem_size(int type) { return type == CV_8UC3 ? 3 : type == CV_32F ? 4 : type == CV_64F ? 8 : 1; }
 
 inline int cvRound(double v) { return (int)std::nearbyint(v); }            // default rounding mode: half to even
 inline int cvRound(float v) { return (int)std::nearbyintf(v); }
@@ -43,7 +49,13 @@ template <typename T> struct Point_ {
     T x, y;
     Point_() : x(0), y(0) {}
     Point_(T x_, T y_) : x(x_), y(y_) {}
+    T dot(const Point_& o) const { return (T)(x * o.x + y * o.y); }                       // saturate_cast<_Tp>(x*pt.x + y*pt.y)
+    Point_& operator*=(float s) { x = (T)(x * s); y = (T)(y * s); return *this; }
+    Point_& operator*=(double s) { x = (T)(x * s); y = (T)(y * s); return *this; }
 };
+template <typename T> inline Point_<T> operator-(const Point_<T>& a, const Point_<T>& b) { return Point_<T>((T)(a.x - b.x), (T)(a.y - b.y)); }
+template <typename T> inline Point_<T> operator+(const Point_<T>& a, const Point_<T>& b) { return Point_<T>((T)(a.x + b.x), (T)(a.y + b.y)); }
+template <typename T> inline double norm(const Point_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y); }
 typedef Point_<int> Point;
 typedef Point_<float> Point2f;
 inline Point2f operator*(const Point2f& p, float s) { return Point2f(p.x * s, p.y * s); }     // saturate_cast<float>(x * s) in OpenCV: the same product
@@ -71,37 +83,65 @@ class RNG {
     uint64_t state;
 };
 
-// 8-bit single-channel matrix with OpenCV's header/buffer split: copies share the buffer, operator()(Rect) is a view that remembers
-// where it sits in the buffer it was cut from (locateROI), which copyMakeBorder and the filters use for non-isolated borders.
+struct Scalar {
+    double val[4];
+    Scalar(double a = 0, double b = 0, double c = 0, double d = 0) : val{a, b, c, d} {}
+    double operator[](int i) const { return val[i]; }
+};
+// matrix with OpenCV's header/buffer split: copies share the buffer, operator()(Rect) is a view that remembers where it sits in the
+// buffer it was cut from (locateROI), which copyMakeBorder and the filters use for non-isolated borders.  8-bit single channel is what
+// the ORB code and the image stages use; CV_64F / CV_32F / CV_8UC3 exist for the calibration matrices and the viewer's picture.
+// `aux`: an owner the stand-in functions may hang on a header (the LK pyramid a level belongs to) - shared by copies and views.
 class Mat {
   public:
     int rows = 0, cols = 0;
     uchar* data = nullptr;
     size_t step = 0;
+    std::shared_ptr<void> aux;
     Mat() {}
-    Mat(int r, int c, int /*type*/, void* ext, size_t st) : rows(r), cols(c), data((uchar*)ext), step(st), base((uchar*)ext), brows(r), bcols(c) {}
-    void create(int r, int c, int /*type*/)
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, const Scalar& v) { create(r, c, type); setTo(v); }
+    Mat(int r, int c, int type, void* ext, size_t st) : rows(r), cols(c), data((uchar*)ext), step(st), type_(type), esz(lvref_elem_size(type)), base((uchar*)ext), brows(r), bcols(c) {}
+    Mat(const Mat& m, const Rect& r) { *this = m(r); }
+    void create(int r, int c, int type)
     {
-        buf = std::make_shared<std::vector<uchar>>((size_t)r * (size_t)c);
-        rows = r; cols = c; step = (size_t)c; data = buf->data(); base = data; brows = r; bcols = c;
+        type_ = type; esz = lvref_elem_size(type);
+        buf = std::make_shared<std::vector<uchar>>((size_t)r * (size_t)c * esz);
+        rows = r; cols = c; step = (size_t)c * esz; data = buf->data(); base = data; brows = r; bcols = c;
     }
     void create(Size s, int type) { create(s.height, s.width, type); }
     static Mat zeros(int r, int c, int type) { Mat m; m.create(r, c, type); return m; }       // the vector is value-initialised
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
-    void release() { buf.reset(); data = base = nullptr; rows = cols = brows = bcols = 0; step = 0; }
+    void release() { buf.reset(); aux.reset(); data = base = nullptr; rows = cols = brows = bcols = 0; step = 0; }
     size_t step1() const { return step; }
+    int type() const { return type_; }
+    size_t elemSize() const { return esz; }
+    int channels() const { return type_ == CV_8UC3 ? 3 : 1; }
+    Size size() const { return Size(cols, rows); }
+    bool isContinuous() const { return step == (size_t)cols * esz; }
     Mat clone() const
     {
-        Mat m; m.create(rows, cols, CV_8U);
-        for (int y = 0; y < rows; ++y) memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols);
+        Mat m; m.create(rows, cols, type_);
+        for (int y = 0; y < rows; ++y) memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * esz);
         return m;
     }
+    void copyTo(Mat& dst) const { dst = clone(); }
     Mat operator()(const Rect& r) const
     {
         assert(r.x >= 0 && r.y >= 0 && r.x + r.width <= cols && r.y + r.height <= rows);
         Mat m = *this;
-        m.data = data + (size_t)r.y * step + r.x; m.rows = r.height; m.cols = r.width;
+        m.data = data + (size_t)r.y * step + (size_t)r.x * esz; m.rows = r.height; m.cols = r.width;
         return m;
+    }
+    Mat row(int y) const { return (*this)(Rect(0, y, cols, 1)); }
+    Mat& setTo(const Scalar& v)
+    {
+        for (int y = 0; y < rows; ++y) for (int x = 0; x < cols; ++x) {
+            uchar* p = data + (size_t)y * step + (size_t)x * esz;
+            if (type_ == CV_64F) *(double*)p = v.val[0]; else if (type_ == CV_32F) *(float*)p = (float)v.val[0];
+            else for (size_t k = 0; k < esz; ++k) p[k] = (uchar)std::min(255.0, std::max(0.0, std::nearbyint(v.val[k])));
+        }
+        return *this;
     }
     template <typename T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
     template <typename T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
@@ -110,10 +150,16 @@ class Mat {
     void locateROI(Size& whole, Point& ofs) const
     {
         const size_t d = (size_t)(data - base);
-        ofs.y = (int)(d / step); ofs.x = (int)(d % step);
+        ofs.y = (int)(d / step); ofs.x = (int)((d % step) / esz);
         whole.width = bcols; whole.height = brows;
     }
+    // a header over memory somebody else owns, as a view at (ox, oy) of a (bw x bh) buffer that starts at `b` (the LK pyramid's levels)
+    static Mat view_in(uchar* b, int bw, int bh, size_t st, int ox, int oy, int w, int h, std::shared_ptr<void> owner)
+    {
+        Mat m; m.rows = h; m.cols = w; m.step = st; m.data = b + (size_t)oy * st + ox; m.base = b; m.brows = bh; m.bcols = bw; m.aux = owner; return m;
+    }
   private:
+    int type_ = CV_8U; size_t esz = 1;
     std::shared_ptr<std::vector<uchar>> buf;
     uchar* base = nullptr; int brows = 0, bcols = 0;      // the buffer this header (or the view it was cut from) lives in
 };

@@ -1,8 +1,8 @@
 // lvref_eigen2.hpp - TEST INFRASTRUCTURE ONLY (see oracle/lvo.h): a second, wider stand-in for the few Eigen TYPES the reference's
 // filter (src/larvio.cpp and the headers it includes) is written against, so that those sources can be compiled where they lie under
 // /root/reference (Eigen itself is not installed in this image; oracle/Makefile target `ref`).  Everything is one concrete, dynamically
-// sized, column-major, EAGER matrix of doubles (`Mat`); `Matrix<double, R, C>` are thin shape-checked derivations of it, blocks are
-// writable views (`Blk`) that convert to `Mat`.  No expression templates: every operator evaluates its operands and returns a new Mat,
+// sized, column-major, EAGER matrix of doubles (`XMat`); `Matrix<double, R, C>` are thin shape-checked derivations of it, blocks are
+// writable views (`Blk`) that convert to `XMat`.  No expression templates: every operator evaluates its operands and returns a new XMat,
 // which is also what Eigen's aliasing rules make the reference's statements mean.  What this does NOT reproduce is Eigen's rounding
 // (operation order inside products, the pivoting of LDLT / inverse, JacobiSVD's U, SPQR's Q): the pinned thing is the reference's
 // algorithm text, and the comparisons that use this header state tolerances, not bit-equality.
@@ -35,18 +35,18 @@ template <typename T> struct aligned_allocator : std::allocator<T> {
     template <typename U> struct rebind { typedef aligned_allocator<U> other; };
 };
 
-class Mat;
+class XMat;
 class Blk;
 struct LDLTx;
 
 // ------------------------------------------------------------------ the one matrix
-class Mat {
+class XMat {
 public:
     int r_ = 0, c_ = 0;
     std::vector<double> d_;
-    Mat() {}
-    Mat(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
-    Mat(const Blk& b);
+    XMat() {}
+    XMat(int r, int c) : r_(r), c_(c), d_((size_t)r * c, 0.0) {}
+    XMat(const Blk& b);
     typedef double Scalar;
     int rows() const { return r_; }
     int cols() const { return c_; }
@@ -69,50 +69,50 @@ public:
 
     // ---- views (non-const: writable; const: a copy)
     inline Blk block(int i, int j, int r, int c);
-    Mat block(int i, int j, int r, int c) const { LVREF_CHECK(i >= 0 && j >= 0 && r >= 0 && c >= 0 && i + r <= r_ && j + c <= c_, "block out of range"); Mat o(r, c); for (int b = 0; b < c; ++b) for (int a = 0; a < r; ++a) o.d_[(size_t)b * r + a] = d_[(size_t)(j + b) * r_ + i + a]; return o; }
+    XMat block(int i, int j, int r, int c) const { LVREF_CHECK(i >= 0 && j >= 0 && r >= 0 && c >= 0 && i + r <= r_ && j + c <= c_, "block out of range"); XMat o(r, c); for (int b = 0; b < c; ++b) for (int a = 0; a < r; ++a) o.d_[(size_t)b * r + a] = d_[(size_t)(j + b) * r_ + i + a]; return o; }
     template <int BR, int BC> inline Blk block(int i, int j);
-    template <int BR, int BC> Mat block(int i, int j) const { return block(i, j, BR, BC); }
+    template <int BR, int BC> XMat block(int i, int j) const { return block(i, j, BR, BC); }
     inline Blk segment(int i, int n);
-    Mat segment(int i, int n) const { return c_ == 1 ? block(i, 0, n, 1) : block(0, i, 1, n); }
+    XMat segment(int i, int n) const { return c_ == 1 ? block(i, 0, n, 1) : block(0, i, 1, n); }
     template <int N> inline Blk segment(int i);
-    template <int N> Mat segment(int i) const { return segment(i, N); }
-    inline Blk head(int n); Mat head(int n) const { return segment(0, n); }
-    template <int N> inline Blk head(); template <int N> Mat head() const { return segment(0, N); }
-    inline Blk tail(int n); Mat tail(int n) const { return segment(size() - n, n); }
-    template <int N> inline Blk tail(); template <int N> Mat tail() const { return segment(size() - N, N); }
-    inline Blk leftCols(int n); Mat leftCols(int n) const { return block(0, 0, r_, n); }
-    template <int N> inline Blk leftCols(); template <int N> Mat leftCols() const { return block(0, 0, r_, N); }
-    inline Blk rightCols(int n); Mat rightCols(int n) const { return block(0, c_ - n, r_, n); }
-    template <int N> inline Blk rightCols(); template <int N> Mat rightCols() const { return block(0, c_ - N, r_, N); }
-    inline Blk topRows(int n); Mat topRows(int n) const { return block(0, 0, n, c_); }
-    template <int N> inline Blk topRows(); template <int N> Mat topRows() const { return block(0, 0, N, c_); }
-    inline Blk bottomRows(int n); Mat bottomRows(int n) const { return block(r_ - n, 0, n, c_); }
-    template <int N> inline Blk bottomRows(); template <int N> Mat bottomRows() const { return block(r_ - N, 0, N, c_); }
-    inline Blk middleRows(int i, int n); Mat middleRows(int i, int n) const { return block(i, 0, n, c_); }
-    inline Blk middleCols(int j, int n); Mat middleCols(int j, int n) const { return block(0, j, r_, n); }
-    inline Blk col(int j); Mat col(int j) const { return block(0, j, r_, 1); }
-    inline Blk row(int i); Mat row(int i) const { return block(i, 0, 1, c_); }
-    inline Blk topLeftCorner(int r, int c); Mat topLeftCorner(int r, int c) const { return block(0, 0, r, c); }
-    inline Blk topRightCorner(int r, int c); Mat topRightCorner(int r, int c) const { return block(0, c_ - c, r, c); }
-    inline Blk bottomLeftCorner(int r, int c); Mat bottomLeftCorner(int r, int c) const { return block(r_ - r, 0, r, c); }
-    inline Blk bottomRightCorner(int r, int c); Mat bottomRightCorner(int r, int c) const { return block(r_ - r, c_ - c, r, c); }
-    template <int R, int C> inline Blk topLeftCorner(); template <int R, int C> Mat topLeftCorner() const { return block(0, 0, R, C); }
-    template <int R, int C> inline Blk topRightCorner(); template <int R, int C> Mat topRightCorner() const { return block(0, c_ - C, R, C); }
-    template <int R, int C> inline Blk bottomLeftCorner(); template <int R, int C> Mat bottomLeftCorner() const { return block(r_ - R, 0, R, C); }
-    template <int R, int C> inline Blk bottomRightCorner(); template <int R, int C> Mat bottomRightCorner() const { return block(r_ - R, c_ - C, R, C); }
-    Mat diagonal() const { const int n = std::min(r_, c_); Mat o(n, 1); for (int i = 0; i < n; ++i) o.d_[i] = (*this)(i, i); return o; }
+    template <int N> XMat segment(int i) const { return segment(i, N); }
+    inline Blk head(int n); XMat head(int n) const { return segment(0, n); }
+    template <int N> inline Blk head(); template <int N> XMat head() const { return segment(0, N); }
+    inline Blk tail(int n); XMat tail(int n) const { return segment(size() - n, n); }
+    template <int N> inline Blk tail(); template <int N> XMat tail() const { return segment(size() - N, N); }
+    inline Blk leftCols(int n); XMat leftCols(int n) const { return block(0, 0, r_, n); }
+    template <int N> inline Blk leftCols(); template <int N> XMat leftCols() const { return block(0, 0, r_, N); }
+    inline Blk rightCols(int n); XMat rightCols(int n) const { return block(0, c_ - n, r_, n); }
+    template <int N> inline Blk rightCols(); template <int N> XMat rightCols() const { return block(0, c_ - N, r_, N); }
+    inline Blk topRows(int n); XMat topRows(int n) const { return block(0, 0, n, c_); }
+    template <int N> inline Blk topRows(); template <int N> XMat topRows() const { return block(0, 0, N, c_); }
+    inline Blk bottomRows(int n); XMat bottomRows(int n) const { return block(r_ - n, 0, n, c_); }
+    template <int N> inline Blk bottomRows(); template <int N> XMat bottomRows() const { return block(r_ - N, 0, N, c_); }
+    inline Blk middleRows(int i, int n); XMat middleRows(int i, int n) const { return block(i, 0, n, c_); }
+    inline Blk middleCols(int j, int n); XMat middleCols(int j, int n) const { return block(0, j, r_, n); }
+    inline Blk col(int j); XMat col(int j) const { return block(0, j, r_, 1); }
+    inline Blk row(int i); XMat row(int i) const { return block(i, 0, 1, c_); }
+    inline Blk topLeftCorner(int r, int c); XMat topLeftCorner(int r, int c) const { return block(0, 0, r, c); }
+    inline Blk topRightCorner(int r, int c); XMat topRightCorner(int r, int c) const { return block(0, c_ - c, r, c); }
+    inline Blk bottomLeftCorner(int r, int c); XMat bottomLeftCorner(int r, int c) const { return block(r_ - r, 0, r, c); }
+    inline Blk bottomRightCorner(int r, int c); XMat bottomRightCorner(int r, int c) const { return block(r_ - r, c_ - c, r, c); }
+    template <int R, int C> inline Blk topLeftCorner(); template <int R, int C> XMat topLeftCorner() const { return block(0, 0, R, C); }
+    template <int R, int C> inline Blk topRightCorner(); template <int R, int C> XMat topRightCorner() const { return block(0, c_ - C, R, C); }
+    template <int R, int C> inline Blk bottomLeftCorner(); template <int R, int C> XMat bottomLeftCorner() const { return block(r_ - R, 0, R, C); }
+    template <int R, int C> inline Blk bottomRightCorner(); template <int R, int C> XMat bottomRightCorner() const { return block(r_ - R, c_ - C, R, C); }
+    XMat diagonal() const { const int n = std::min(r_, c_); XMat o(n, 1); for (int i = 0; i < n; ++i) o.d_[i] = (*this)(i, i); return o; }
 
     // ---- whole-matrix operations
-    Mat transpose() const { Mat o(c_, r_); for (int j = 0; j < c_; ++j) for (int i = 0; i < r_; ++i) o.d_[(size_t)i * c_ + j] = d_[(size_t)j * r_ + i]; return o; }
-    Mat adjoint() const { return transpose(); }
-    Mat eval() const { return *this; }
-    Mat& noalias() { return *this; }
-    const Mat& matrix() const { return *this; }
-    Mat array() const { return *this; }
-    Mat cwiseAbs() const { Mat o = *this; for (double& v : o.d_) v = std::fabs(v); return o; }
-    Mat cwiseSqrt() const { Mat o = *this; for (double& v : o.d_) v = std::sqrt(v); return o; }
-    Mat cwiseProduct(const Mat& b) const { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "cwiseProduct: shape"); Mat o = *this; for (size_t k = 0; k < d_.size(); ++k) o.d_[k] *= b.d_[k]; return o; }
-    Mat cwiseQuotient(const Mat& b) const { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "cwiseQuotient: shape"); Mat o = *this; for (size_t k = 0; k < d_.size(); ++k) o.d_[k] /= b.d_[k]; return o; }
+    XMat transpose() const { XMat o(c_, r_); for (int j = 0; j < c_; ++j) for (int i = 0; i < r_; ++i) o.d_[(size_t)i * c_ + j] = d_[(size_t)j * r_ + i]; return o; }
+    XMat adjoint() const { return transpose(); }
+    XMat eval() const { return *this; }
+    XMat& noalias() { return *this; }
+    const XMat& matrix() const { return *this; }
+    XMat array() const { return *this; }
+    XMat cwiseAbs() const { XMat o = *this; for (double& v : o.d_) v = std::fabs(v); return o; }
+    XMat cwiseSqrt() const { XMat o = *this; for (double& v : o.d_) v = std::sqrt(v); return o; }
+    XMat cwiseProduct(const XMat& b) const { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "cwiseProduct: shape"); XMat o = *this; for (size_t k = 0; k < d_.size(); ++k) o.d_[k] *= b.d_[k]; return o; }
+    XMat cwiseQuotient(const XMat& b) const { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "cwiseQuotient: shape"); XMat o = *this; for (size_t k = 0; k < d_.size(); ++k) o.d_[k] /= b.d_[k]; return o; }
     double squaredNorm() const { double s = 0; for (double v : d_) s += v * v; return s; }
     double norm() const { return std::sqrt(squaredNorm()); }
     double stableNorm() const { return norm(); }
@@ -127,69 +127,69 @@ public:
     bool hasNaN() const { for (double v : d_) if (v != v) return true; return false; }
     bool allFinite() const { for (double v : d_) if (!std::isfinite(v)) return false; return true; }
     bool isZero(double prec = 1e-12) const { for (double v : d_) if (std::fabs(v) > prec) return false; return true; }
-    Mat normalized() const { const double n = norm(); Mat o = *this; if (n > 0) for (double& v : o.d_) v /= n; return o; }
+    XMat normalized() const { const double n = norm(); XMat o = *this; if (n > 0) for (double& v : o.d_) v /= n; return o; }
     void normalize() { const double n = norm(); if (n > 0) for (double& v : d_) v /= n; }
-    double dot(const Mat& b) const { LVREF_CHECK(size() == b.size(), "dot: size"); double s = 0; for (size_t k = 0; k < d_.size(); ++k) s += d_[k] * b.d_[k]; return s; }
-    Mat cross(const Mat& b) const { LVREF_CHECK(size() == 3 && b.size() == 3, "cross: 3-vectors"); Mat o(3, 1); o.d_[0] = d_[1] * b.d_[2] - d_[2] * b.d_[1]; o.d_[1] = d_[2] * b.d_[0] - d_[0] * b.d_[2]; o.d_[2] = d_[0] * b.d_[1] - d_[1] * b.d_[0]; return o; }
-    Mat asDiagonal() const { const int n = size(); Mat o(n, n); for (int i = 0; i < n; ++i) o(i, i) = d_[i]; return o; }
-    template <typename T> Mat cast() const { return *this; }
-    Mat sparseView() const { return *this; }
-    inline Mat inverse() const;
+    double dot(const XMat& b) const { LVREF_CHECK(size() == b.size(), "dot: size"); double s = 0; for (size_t k = 0; k < d_.size(); ++k) s += d_[k] * b.d_[k]; return s; }
+    XMat cross(const XMat& b) const { LVREF_CHECK(size() == 3 && b.size() == 3, "cross: 3-vectors"); XMat o(3, 1); o.d_[0] = d_[1] * b.d_[2] - d_[2] * b.d_[1]; o.d_[1] = d_[2] * b.d_[0] - d_[0] * b.d_[2]; o.d_[2] = d_[0] * b.d_[1] - d_[1] * b.d_[0]; return o; }
+    XMat asDiagonal() const { const int n = size(); XMat o(n, n); for (int i = 0; i < n; ++i) o(i, i) = d_[i]; return o; }
+    template <typename T> XMat cast() const { return *this; }
+    XMat sparseView() const { return *this; }
+    inline XMat inverse() const;
     inline double determinant() const;
     inline LDLTx ldlt() const;
     inline LDLTx llt() const;
-    Mat& setZero() { std::fill(d_.begin(), d_.end(), 0.0); return *this; }
-    Mat& setOnes() { std::fill(d_.begin(), d_.end(), 1.0); return *this; }
-    Mat& setConstant(double v) { std::fill(d_.begin(), d_.end(), v); return *this; }
-    Mat& fill(double v) { return setConstant(v); }
-    Mat& setIdentity() { setZero(); for (int i = 0; i < std::min(r_, c_); ++i) (*this)(i, i) = 1.0; return *this; }
-    Mat& setZero(int r, int c) { r_ = r; c_ = c; d_.assign((size_t)r * c, 0.0); return *this; }
-    Mat& setZero(int n) { return setZero(n, 1); }
-    Mat& setIdentity(int r, int c) { setZero(r, c); return setIdentity(); }
+    XMat& setZero() { std::fill(d_.begin(), d_.end(), 0.0); return *this; }
+    XMat& setOnes() { std::fill(d_.begin(), d_.end(), 1.0); return *this; }
+    XMat& setConstant(double v) { std::fill(d_.begin(), d_.end(), v); return *this; }
+    XMat& fill(double v) { return setConstant(v); }
+    XMat& setIdentity() { setZero(); for (int i = 0; i < std::min(r_, c_); ++i) (*this)(i, i) = 1.0; return *this; }
+    XMat& setZero(int r, int c) { r_ = r; c_ = c; d_.assign((size_t)r * c, 0.0); return *this; }
+    XMat& setZero(int n) { return setZero(n, 1); }
+    XMat& setIdentity(int r, int c) { setZero(r, c); return setIdentity(); }
     void resize(int r, int c) { if (r != r_ || c != c_) { r_ = r; c_ = c; d_.assign((size_t)r * c, 0.0); } }
     void resize(int n) { if (c_ == 1 || (r_ == 0 && c_ == 0)) resize(n, 1); else if (r_ == 1) resize(1, n); else LVREF_CHECK(false, "resize(n) of a matrix"); }
     void conservativeResize(int r, int c)
     {   // (new entries are uninitialised in Eigen; zero here)
-        Mat o(r, c);
+        XMat o(r, c);
         for (int j = 0; j < std::min(c, c_); ++j) for (int i = 0; i < std::min(r, r_); ++i) o.d_[(size_t)j * r + i] = d_[(size_t)j * r_ + i];
         *this = o;
     }
     void conservativeResize(int n) { if (r_ == 1 && c_ != 1) conservativeResize(1, n); else conservativeResize(n, 1); }
-    Mat& operator+=(const Mat& b) { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "+=: shape"); for (size_t k = 0; k < d_.size(); ++k) d_[k] += b.d_[k]; return *this; }
-    Mat& operator-=(const Mat& b) { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "-=: shape"); for (size_t k = 0; k < d_.size(); ++k) d_[k] -= b.d_[k]; return *this; }
-    Mat& operator*=(double s) { for (double& v : d_) v *= s; return *this; }
-    Mat& operator/=(double s) { for (double& v : d_) v /= s; return *this; }
-    inline Mat& operator*=(const Mat& b);
+    XMat& operator+=(const XMat& b) { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "+=: shape"); for (size_t k = 0; k < d_.size(); ++k) d_[k] += b.d_[k]; return *this; }
+    XMat& operator-=(const XMat& b) { LVREF_CHECK(r_ == b.r_ && c_ == b.c_, "-=: shape"); for (size_t k = 0; k < d_.size(); ++k) d_[k] -= b.d_[k]; return *this; }
+    XMat& operator*=(double s) { for (double& v : d_) v *= s; return *this; }
+    XMat& operator/=(double s) { for (double& v : d_) v /= s; return *this; }
+    inline XMat& operator*=(const XMat& b);
 
     // ---- comma initialiser (scalars and blocks, row by row, as Eigen's CommaInitializer)
     struct Comma {
-        Mat& m; int row, col, cur_rows;
-        Comma(Mat& m_, double v) : m(m_), row(0), col(1), cur_rows(1) { LVREF_CHECK(m.r_ > 0 && m.c_ > 0, "<< into an empty matrix"); m(0, 0) = v; }
-        Comma(Mat& m_, const Mat& b) : m(m_), row(0), col(b.c_), cur_rows(b.r_) { put(0, 0, b); }
-        void put(int i, int j, const Mat& b) { LVREF_CHECK(i + b.r_ <= m.r_ && j + b.c_ <= m.c_, "<<: too many coefficients"); for (int q = 0; q < b.c_; ++q) for (int p = 0; p < b.r_; ++p) m(i + p, j + q) = b(p, q); }
+        XMat& m; int row, col, cur_rows;
+        Comma(XMat& m_, double v) : m(m_), row(0), col(1), cur_rows(1) { LVREF_CHECK(m.r_ > 0 && m.c_ > 0, "<< into an empty matrix"); m(0, 0) = v; }
+        Comma(XMat& m_, const XMat& b) : m(m_), row(0), col(b.c_), cur_rows(b.r_) { put(0, 0, b); }
+        void put(int i, int j, const XMat& b) { LVREF_CHECK(i + b.r_ <= m.r_ && j + b.c_ <= m.c_, "<<: too many coefficients"); for (int q = 0; q < b.c_; ++q) for (int p = 0; p < b.r_; ++p) m(i + p, j + q) = b(p, q); }
         Comma& operator,(double v) { if (col == m.c_) { row += cur_rows; col = 0; cur_rows = 1; } LVREF_CHECK(row < m.r_ && col < m.c_, "<<: too many coefficients"); m(row, col++) = v; return *this; }
-        Comma& operator,(const Mat& b) { if (col == m.c_) { row += cur_rows; col = 0; cur_rows = b.r_; } put(row, col, b); col += b.c_; return *this; }
-        Mat& finished() { return m; }
+        Comma& operator,(const XMat& b) { if (col == m.c_) { row += cur_rows; col = 0; cur_rows = b.r_; } put(row, col, b); col += b.c_; return *this; }
+        XMat& finished() { return m; }
     };
     Comma operator<<(double v) { return Comma(*this, v); }
-    Comma operator<<(const Mat& b) { return Comma(*this, b); }
+    Comma operator<<(const XMat& b) { return Comma(*this, b); }
 };
 
-inline std::ostream& operator<<(std::ostream& os, const Mat& m)
+inline std::ostream& operator<<(std::ostream& os, const XMat& m)
 {
     for (int i = 0; i < m.rows(); ++i) { for (int j = 0; j < m.cols(); ++j) os << (j ? " " : "") << m(i, j); if (i + 1 < m.rows()) os << "\n"; }
     return os;
 }
-inline Mat operator+(const Mat& a, const Mat& b) { Mat o = a; o += b; return o; }
-inline Mat operator-(const Mat& a, const Mat& b) { Mat o = a; o -= b; return o; }
-inline Mat operator-(const Mat& a) { Mat o = a; for (double& v : o.d_) v = -v; return o; }
-inline Mat operator*(const Mat& a, double s) { Mat o = a; o *= s; return o; }
-inline Mat operator*(double s, const Mat& a) { Mat o = a; o *= s; return o; }
-inline Mat operator/(const Mat& a, double s) { Mat o = a; o /= s; return o; }
-inline Mat operator*(const Mat& a, const Mat& b)
+inline XMat operator+(const XMat& a, const XMat& b) { XMat o = a; o += b; return o; }
+inline XMat operator-(const XMat& a, const XMat& b) { XMat o = a; o -= b; return o; }
+inline XMat operator-(const XMat& a) { XMat o = a; for (double& v : o.d_) v = -v; return o; }
+inline XMat operator*(const XMat& a, double s) { XMat o = a; o *= s; return o; }
+inline XMat operator*(double s, const XMat& a) { XMat o = a; o *= s; return o; }
+inline XMat operator/(const XMat& a, double s) { XMat o = a; o /= s; return o; }
+inline XMat operator*(const XMat& a, const XMat& b)
 {
     LVREF_CHECK(a.c_ == b.r_, "product: inner dimensions");
-    Mat o(a.r_, b.c_);
+    XMat o(a.r_, b.c_);
     for (int j = 0; j < b.c_; ++j)
         for (int k = 0; k < a.c_; ++k) {
             const double bkj = b.d_[(size_t)j * b.r_ + k];
@@ -199,31 +199,31 @@ inline Mat operator*(const Mat& a, const Mat& b)
         }
     return o;
 }
-inline Mat& Mat::operator*=(const Mat& b) { *this = *this * b; return *this; }
+inline XMat& XMat::operator*=(const XMat& b) { *this = *this * b; return *this; }
 
 // ------------------------------------------------------------------ writable view
 class Blk {
 public:
-    Mat& m; int i0, j0, r_, c_;
-    Blk(Mat& m_, int i, int j, int r, int c) : m(m_), i0(i), j0(j), r_(r), c_(c) { LVREF_CHECK(i >= 0 && j >= 0 && r >= 0 && c >= 0 && i + r <= m.r_ && j + c <= m.c_, "block out of range"); }
+    XMat& m; int i0, j0, r_, c_;
+    Blk(XMat& m_, int i, int j, int r, int c) : m(m_), i0(i), j0(j), r_(r), c_(c) { LVREF_CHECK(i >= 0 && j >= 0 && r >= 0 && c >= 0 && i + r <= m.r_ && j + c <= m.c_, "block out of range"); }
     int rows() const { return r_; } int cols() const { return c_; } int size() const { return r_ * c_; }
     double& operator()(int i, int j) { LVREF_CHECK(i >= 0 && i < r_ && j >= 0 && j < c_, "block index out of range"); return m(i0 + i, j0 + j); }
-    double operator()(int i, int j) const { LVREF_CHECK(i >= 0 && i < r_ && j >= 0 && j < c_, "block index out of range"); return ((const Mat&)m)(i0 + i, j0 + j); }
+    double operator()(int i, int j) const { LVREF_CHECK(i >= 0 && i < r_ && j >= 0 && j < c_, "block index out of range"); return ((const XMat&)m)(i0 + i, j0 + j); }
     double& operator()(int i) { return c_ == 1 ? (*this)(i, 0) : (*this)(0, i); }
     double operator()(int i) const { return c_ == 1 ? (*this)(i, 0) : (*this)(0, i); }
     double& operator[](int i) { return (*this)(i); } double operator[](int i) const { return (*this)(i); }
     double& x() { return (*this)(0); } double& y() { return (*this)(1); } double& z() { return (*this)(2); } double& w() { return (*this)(3); }
     double x() const { return (*this)(0); } double y() const { return (*this)(1); } double z() const { return (*this)(2); } double w() const { return (*this)(3); }
-    Mat eval() const { Mat o(r_, c_); for (int j = 0; j < c_; ++j) for (int i = 0; i < r_; ++i) o.d_[(size_t)j * r_ + i] = ((const Mat&)m)(i0 + i, j0 + j); return o; }
-    Blk& assign(const Mat& b)
+    XMat eval() const { XMat o(r_, c_); for (int j = 0; j < c_; ++j) for (int i = 0; i < r_; ++i) o.d_[(size_t)j * r_ + i] = ((const XMat&)m)(i0 + i, j0 + j); return o; }
+    Blk& assign(const XMat& b)
     {
         if ((r_ == 1 || c_ == 1) && b.r_ == c_ && b.c_ == r_ && r_ != c_) { for (int k = 0; k < r_ * c_; ++k) (*this)(k) = b.d_[k]; return *this; }     // vector <-> row vector, as Eigen allows
         LVREF_CHECK(b.r_ == r_ && b.c_ == c_, "block assignment: shape"); for (int j = 0; j < c_; ++j) for (int i = 0; i < r_; ++i) m(i0 + i, j0 + j) = b.d_[(size_t)j * r_ + i]; return *this;
     }
-    Blk& operator=(const Mat& b) { return assign(b); }
+    Blk& operator=(const XMat& b) { return assign(b); }
     Blk& operator=(const Blk& b) { return assign(b.eval()); }                     // (evaluated first: overlapping source and destination)
-    Blk& operator+=(const Mat& b) { return assign(eval() + b); }
-    Blk& operator-=(const Mat& b) { return assign(eval() - b); }
+    Blk& operator+=(const XMat& b) { return assign(eval() + b); }
+    Blk& operator-=(const XMat& b) { return assign(eval() - b); }
     Blk& operator*=(double s) { return assign(eval() * s); }
     Blk& operator/=(double s) { return assign(eval() / s); }
     Blk& setZero() { for (int j = 0; j < c_; ++j) for (int i = 0; i < r_; ++i) m(i0 + i, j0 + j) = 0.0; return *this; }
@@ -240,42 +240,42 @@ public:
     Blk col(int j) { return block(0, j, r_, 1); } Blk row(int i) { return block(i, 0, 1, c_); }
     Blk leftCols(int n) { return block(0, 0, r_, n); } Blk rightCols(int n) { return block(0, c_ - n, r_, n); }
     Blk topRows(int n) { return block(0, 0, n, c_); } Blk bottomRows(int n) { return block(r_ - n, 0, n, c_); }
-    Mat transpose() const { return eval().transpose(); }
-    Mat inverse() const { return eval().inverse(); }
-    Mat cwiseAbs() const { return eval().cwiseAbs(); }
-    Mat normalized() const { return eval().normalized(); }
-    Mat diagonal() const { return eval().diagonal(); }
-    Mat asDiagonal() const { return eval().asDiagonal(); }
-    Mat array() const { return eval(); }
+    XMat transpose() const { return eval().transpose(); }
+    XMat inverse() const { return eval().inverse(); }
+    XMat cwiseAbs() const { return eval().cwiseAbs(); }
+    XMat normalized() const { return eval().normalized(); }
+    XMat diagonal() const { return eval().diagonal(); }
+    XMat asDiagonal() const { return eval().asDiagonal(); }
+    XMat array() const { return eval(); }
     double norm() const { return eval().norm(); } double squaredNorm() const { return eval().squaredNorm(); }
     double sum() const { return eval().sum(); } double trace() const { return eval().trace(); }
     double maxCoeff() const { return eval().maxCoeff(); } double minCoeff() const { return eval().minCoeff(); }
-    double dot(const Mat& b) const { return eval().dot(b); } Mat cross(const Mat& b) const { return eval().cross(b); }
+    double dot(const XMat& b) const { return eval().dot(b); } XMat cross(const XMat& b) const { return eval().cross(b); }
     inline LDLTx ldlt() const;
-    Mat::Comma operator<<(double v);
-    Mat::Comma operator<<(const Mat& b);
+    XMat::Comma operator<<(double v);
+    XMat::Comma operator<<(const XMat& b);
 };
-inline Mat::Mat(const Blk& b) { *this = b.eval(); }
-inline Blk Mat::block(int i, int j, int r, int c) { return Blk(*this, i, j, r, c); }
-template <int BR, int BC> inline Blk Mat::block(int i, int j) { return Blk(*this, i, j, BR, BC); }
-inline Blk Mat::segment(int i, int n) { return c_ == 1 ? Blk(*this, i, 0, n, 1) : Blk(*this, 0, i, 1, n); }
-template <int N> inline Blk Mat::segment(int i) { return segment(i, N); }
-inline Blk Mat::head(int n) { return segment(0, n); } template <int N> inline Blk Mat::head() { return segment(0, N); }
-inline Blk Mat::tail(int n) { return segment(size() - n, n); } template <int N> inline Blk Mat::tail() { return segment(size() - N, N); }
-inline Blk Mat::leftCols(int n) { return Blk(*this, 0, 0, r_, n); } template <int N> inline Blk Mat::leftCols() { return leftCols(N); }
-inline Blk Mat::rightCols(int n) { return Blk(*this, 0, c_ - n, r_, n); } template <int N> inline Blk Mat::rightCols() { return rightCols(N); }
-inline Blk Mat::topRows(int n) { return Blk(*this, 0, 0, n, c_); } template <int N> inline Blk Mat::topRows() { return topRows(N); }
-inline Blk Mat::bottomRows(int n) { return Blk(*this, r_ - n, 0, n, c_); } template <int N> inline Blk Mat::bottomRows() { return bottomRows(N); }
-inline Blk Mat::middleRows(int i, int n) { return Blk(*this, i, 0, n, c_); } inline Blk Mat::middleCols(int j, int n) { return Blk(*this, 0, j, r_, n); }
-inline Blk Mat::col(int j) { return Blk(*this, 0, j, r_, 1); } inline Blk Mat::row(int i) { return Blk(*this, i, 0, 1, c_); }
-inline Blk Mat::topLeftCorner(int r, int c) { return Blk(*this, 0, 0, r, c); } inline Blk Mat::topRightCorner(int r, int c) { return Blk(*this, 0, c_ - c, r, c); }
-inline Blk Mat::bottomLeftCorner(int r, int c) { return Blk(*this, r_ - r, 0, r, c); } inline Blk Mat::bottomRightCorner(int r, int c) { return Blk(*this, r_ - r, c_ - c, r, c); }
-template <int R, int C> inline Blk Mat::topLeftCorner() { return topLeftCorner(R, C); } template <int R, int C> inline Blk Mat::topRightCorner() { return topRightCorner(R, C); }
-template <int R, int C> inline Blk Mat::bottomLeftCorner() { return bottomLeftCorner(R, C); } template <int R, int C> inline Blk Mat::bottomRightCorner() { return bottomRightCorner(R, C); }
+inline XMat::XMat(const Blk& b) { *this = b.eval(); }
+inline Blk XMat::block(int i, int j, int r, int c) { return Blk(*this, i, j, r, c); }
+template <int BR, int BC> inline Blk XMat::block(int i, int j) { return Blk(*this, i, j, BR, BC); }
+inline Blk XMat::segment(int i, int n) { return c_ == 1 ? Blk(*this, i, 0, n, 1) : Blk(*this, 0, i, 1, n); }
+template <int N> inline Blk XMat::segment(int i) { return segment(i, N); }
+inline Blk XMat::head(int n) { return segment(0, n); } template <int N> inline Blk XMat::head() { return segment(0, N); }
+inline Blk XMat::tail(int n) { return segment(size() - n, n); } template <int N> inline Blk XMat::tail() { return segment(size() - N, N); }
+inline Blk XMat::leftCols(int n) { return Blk(*this, 0, 0, r_, n); } template <int N> inline Blk XMat::leftCols() { return leftCols(N); }
+inline Blk XMat::rightCols(int n) { return Blk(*this, 0, c_ - n, r_, n); } template <int N> inline Blk XMat::rightCols() { return rightCols(N); }
+inline Blk XMat::topRows(int n) { return Blk(*this, 0, 0, n, c_); } template <int N> inline Blk XMat::topRows() { return topRows(N); }
+inline Blk XMat::bottomRows(int n) { return Blk(*this, r_ - n, 0, n, c_); } template <int N> inline Blk XMat::bottomRows() { return bottomRows(N); }
+inline Blk XMat::middleRows(int i, int n) { return Blk(*this, i, 0, n, c_); } inline Blk XMat::middleCols(int j, int n) { return Blk(*this, 0, j, r_, n); }
+inline Blk XMat::col(int j) { return Blk(*this, 0, j, r_, 1); } inline Blk XMat::row(int i) { return Blk(*this, i, 0, 1, c_); }
+inline Blk XMat::topLeftCorner(int r, int c) { return Blk(*this, 0, 0, r, c); } inline Blk XMat::topRightCorner(int r, int c) { return Blk(*this, 0, c_ - c, r, c); }
+inline Blk XMat::bottomLeftCorner(int r, int c) { return Blk(*this, r_ - r, 0, r, c); } inline Blk XMat::bottomRightCorner(int r, int c) { return Blk(*this, r_ - r, c_ - c, r, c); }
+template <int R, int C> inline Blk XMat::topLeftCorner() { return topLeftCorner(R, C); } template <int R, int C> inline Blk XMat::topRightCorner() { return topRightCorner(R, C); }
+template <int R, int C> inline Blk XMat::bottomLeftCorner() { return bottomLeftCorner(R, C); } template <int R, int C> inline Blk XMat::bottomRightCorner() { return bottomRightCorner(R, C); }
 
 // ------------------------------------------------------------------ dense kernels the filter calls
 // LU with partial pivoting: inverse and determinant
-inline bool lvref_lu(Mat& a, std::vector<int>& piv, int& sign)
+inline bool lvref_lu(XMat& a, std::vector<int>& piv, int& sign)
 {
     const int n = a.r_; piv.resize(n); sign = 1;
     for (int k = 0; k < n; ++k) {
@@ -288,12 +288,12 @@ inline bool lvref_lu(Mat& a, std::vector<int>& piv, int& sign)
     }
     return true;
 }
-inline Mat Mat::inverse() const
+inline XMat XMat::inverse() const
 {
     LVREF_CHECK(r_ == c_, "inverse of a non-square matrix");
-    const int n = r_; Mat a = *this; std::vector<int> piv; int sign;
-    if (!lvref_lu(a, piv, sign)) { Mat o(n, n); o.setConstant(std::numeric_limits<double>::infinity()); return o; }
-    Mat x(n, n); x.setIdentity();
+    const int n = r_; XMat a = *this; std::vector<int> piv; int sign;
+    if (!lvref_lu(a, piv, sign)) { XMat o(n, n); o.setConstant(std::numeric_limits<double>::infinity()); return o; }
+    XMat x(n, n); x.setIdentity();
     for (int k = 0; k < n; ++k) if (piv[k] != k) for (int j = 0; j < n; ++j) std::swap(x(k, j), x(piv[k], j));
     for (int j = 0; j < n; ++j) {
         for (int i = 0; i < n; ++i) { double s = x(i, j); for (int k = 0; k < i; ++k) s -= a(i, k) * x(k, j); x(i, j) = s; }
@@ -301,17 +301,17 @@ inline Mat Mat::inverse() const
     }
     return x;
 }
-inline double Mat::determinant() const
+inline double XMat::determinant() const
 {
     LVREF_CHECK(r_ == c_, "determinant of a non-square matrix");
-    Mat a = *this; std::vector<int> piv; int sign;
+    XMat a = *this; std::vector<int> piv; int sign;
     if (!lvref_lu(a, piv, sign)) return 0.0;
     double d = sign; for (int i = 0; i < r_; ++i) d *= a(i, i); return d;
 }
 // LDL^T with diagonal pivoting (Eigen's LDLT pivots the same way: largest remaining diagonal entry first)
 struct LDLTx {
-    Mat L; std::vector<double> D; std::vector<int> perm; bool ok = true;
-    explicit LDLTx(const Mat& A)
+    XMat L; std::vector<double> D; std::vector<int> perm; bool ok = true;
+    explicit LDLTx(const XMat& A)
     {
         LVREF_CHECK(A.r_ == A.c_, "ldlt of a non-square matrix");
         const int n = A.r_; L = A; D.assign(n, 0.0); perm.resize(n); for (int i = 0; i < n; ++i) perm[i] = i;
@@ -326,10 +326,10 @@ struct LDLTx {
             for (int j = k + 1; j < n; ++j) for (int i = k + 1; i < j; ++i) L(i, j) = L(j, i);       // keep the trailing block symmetric for the pivot swaps
         }
     }
-    Mat solve(const Mat& B) const
+    XMat solve(const XMat& B) const
     {
         const int n = L.r_; LVREF_CHECK(B.r_ == n, "ldlt.solve: rows");
-        Mat X(n, B.c_);
+        XMat X(n, B.c_);
         for (int j = 0; j < B.c_; ++j) {
             std::vector<double> y(n);
             for (int i = 0; i < n; ++i) y[i] = B(perm[i], j);
@@ -343,16 +343,16 @@ struct LDLTx {
     int info() const { return ok ? 0 : 1; }
     bool isPositive() const { for (double d : D) if (d <= 0) return false; return true; }
 };
-inline LDLTx Mat::ldlt() const { return LDLTx(*this); }
-inline LDLTx Mat::llt() const { return LDLTx(*this); }
+inline LDLTx XMat::ldlt() const { return LDLTx(*this); }
+inline LDLTx XMat::llt() const { return LDLTx(*this); }
 inline LDLTx Blk::ldlt() const { return LDLTx(eval()); }
 enum { Success = 0, NumericalIssue = 1 };
 
 // Householder QR with the full Q (rows x rows): Q^T A = R.  The stand-in behind JacobiSVD::matrixU (range basis first, null space last)
 // and SPQR (natural ordering, no column permutation).
-inline void lvref_householder_qr(const Mat& A, Mat& Q, Mat& R)
+inline void lvref_householder_qr(const XMat& A, XMat& Q, XMat& R)
 {
-    const int m = A.r_, n = A.c_; R = A; Q = Mat(m, m); Q.setIdentity();
+    const int m = A.r_, n = A.c_; R = A; Q = XMat(m, m); Q.setIdentity();
     std::vector<double> v(m);
     for (int k = 0; k < std::min(m - 1, n); ++k) {
         double s = 0; for (int i = k; i < m; ++i) s += R(i, k) * R(i, k);
@@ -371,16 +371,16 @@ inline void lvref_householder_qr(const Mat& A, Mat& Q, Mat& R)
 }
 
 // ------------------------------------------------------------------ the shaped derivations
-template <typename T, int R, int C, int Opt = 0, int MR = R, int MC = C> class Matrix : public Mat {
+template <typename T, int R, int C, int Opt = 0, int MR = R, int MC = C> class Matrix : public XMat {
     static_assert(std::is_same<T, double>::value, "lvref_eigen2: double matrices only");
     void shape_check() const { LVREF_CHECK((R == Dynamic || r_ == R) && (C == Dynamic || c_ == C), "assignment to a fixed-size matrix: shape"); }
 public:
     enum { RowsAtCompileTime = R, ColsAtCompileTime = C };
-    Matrix() : Mat(R == Dynamic ? 0 : R, C == Dynamic ? (R == Dynamic ? 0 : 0) : C) { if (R == Dynamic && C != Dynamic) { r_ = 0; c_ = C; } if (C == Dynamic && R != Dynamic) { r_ = R; c_ = 0; } }
-    Matrix(const Mat& m) : Mat(m) { fix_vector_shape(); shape_check(); }
-    Matrix(const Blk& b) : Mat(b) { fix_vector_shape(); shape_check(); }
+    Matrix() : XMat(R == Dynamic ? 0 : R, C == Dynamic ? (R == Dynamic ? 0 : 0) : C) { if (R == Dynamic && C != Dynamic) { r_ = 0; c_ = C; } if (C == Dynamic && R != Dynamic) { r_ = R; c_ = 0; } }
+    Matrix(const XMat& m) : XMat(m) { fix_vector_shape(); shape_check(); }
+    Matrix(const Blk& b) : XMat(b) { fix_vector_shape(); shape_check(); }
     // (rows, cols) of a dynamic matrix, or the two coefficients of a fixed 2-vector
-    Matrix(double a, double b) : Mat()
+    Matrix(double a, double b) : XMat()
     {
         if (R == Dynamic && C == Dynamic) { r_ = (int)a; c_ = (int)b; d_.assign((size_t)r_ * c_, 0.0); }
         else if (R != Dynamic && C != Dynamic && R * C == 2) { r_ = R; c_ = C; d_ = {a, b}; }
@@ -388,7 +388,7 @@ public:
         else if (C == Dynamic && R != Dynamic) { r_ = R; c_ = (int)b; LVREF_CHECK((int)a == R, "rows"); d_.assign((size_t)r_ * c_, 0.0); }
         else LVREF_CHECK(false, "two-argument constructor of this shape");
     }
-    explicit Matrix(double a) : Mat()
+    explicit Matrix(double a) : XMat()
     {   // size of a dynamic vector, or the coefficient of a 1x1
         if (R == Dynamic && C == 1) { r_ = (int)a; c_ = 1; d_.assign((size_t)r_, 0.0); }
         else if (R == 1 && C == Dynamic) { r_ = 1; c_ = (int)a; d_.assign((size_t)c_, 0.0); }
@@ -396,34 +396,34 @@ public:
         else if (R == Dynamic && C == Dynamic) { r_ = (int)a; c_ = 1; d_.assign((size_t)r_, 0.0); }
         else LVREF_CHECK(false, "one-argument constructor of this shape");
     }
-    Matrix(double a, double b, double c) : Mat(R, C) { LVREF_CHECK(R * C == 3, "three coefficients"); d_ = {a, b, c}; }
-    Matrix(double a, double b, double c, double d) : Mat(R, C) { LVREF_CHECK(R * C == 4, "four coefficients"); d_ = {a, b, c, d}; }
-    Matrix& operator=(const Mat& m) { Mat::operator=(m); fix_vector_shape(); shape_check(); return *this; }
-    Matrix& operator=(const Blk& b) { Mat::operator=(b.eval()); fix_vector_shape(); shape_check(); return *this; }
+    Matrix(double a, double b, double c) : XMat(R, C) { LVREF_CHECK(R * C == 3, "three coefficients"); d_ = {a, b, c}; }
+    Matrix(double a, double b, double c, double d) : XMat(R, C) { LVREF_CHECK(R * C == 4, "four coefficients"); d_ = {a, b, c, d}; }
+    Matrix& operator=(const XMat& m) { XMat::operator=(m); fix_vector_shape(); shape_check(); return *this; }
+    Matrix& operator=(const Blk& b) { XMat::operator=(b.eval()); fix_vector_shape(); shape_check(); return *this; }
     void fix_vector_shape()
     {   // a row assigned to a column type of the same length (and the reverse) is accepted where Eigen would transpose implicitly: vectors only
         if (C == 1 && R != 1 && c_ != 1 && r_ == 1) std::swap(r_, c_);
         else if (R == 1 && C != 1 && r_ != 1 && c_ == 1) std::swap(r_, c_);
     }
     static Matrix Zero() { Matrix m; m.setZero(); return m; }
-    static Matrix Zero(int r, int c) { Matrix m; m.Mat::setZero(r, c); return m; }
-    static Matrix Zero(int n) { Matrix m; if (R == 1 && C != 1) m.Mat::setZero(1, n); else m.Mat::setZero(n, 1); return m; }
+    static Matrix Zero(int r, int c) { Matrix m; m.XMat::setZero(r, c); return m; }
+    static Matrix Zero(int n) { Matrix m; if (R == 1 && C != 1) m.XMat::setZero(1, n); else m.XMat::setZero(n, 1); return m; }
     static Matrix Ones() { Matrix m; m.setOnes(); return m; }
-    static Matrix Ones(int r, int c) { Matrix m; m.Mat::setZero(r, c); m.setOnes(); return m; }
+    static Matrix Ones(int r, int c) { Matrix m; m.XMat::setZero(r, c); m.setOnes(); return m; }
     static Matrix Ones(int n) { Matrix m = Zero(n); m.setOnes(); return m; }
     static Matrix Constant(double v) { Matrix m; m.setConstant(v); return m; }
-    static Matrix Constant(int r, int c, double v) { Matrix m; m.Mat::setZero(r, c); m.setConstant(v); return m; }
+    static Matrix Constant(int r, int c, double v) { Matrix m; m.XMat::setZero(r, c); m.setConstant(v); return m; }
     static Matrix Constant(int n, double v) { Matrix m = Zero(n); m.setConstant(v); return m; }
     static Matrix Identity() { Matrix m; m.setIdentity(); return m; }
-    static Matrix Identity(int r, int c) { Matrix m; m.Mat::setZero(r, c); m.setIdentity(); return m; }
+    static Matrix Identity(int r, int c) { Matrix m; m.XMat::setZero(r, c); m.setIdentity(); return m; }
     static Matrix Random() { Matrix m; for (double& v : m.d_) v = 2.0 * std::rand() / RAND_MAX - 1.0; return m; }
-    static Matrix Random(int r, int c) { Matrix m; m.Mat::setZero(r, c); for (double& v : m.d_) v = 2.0 * std::rand() / RAND_MAX - 1.0; return m; }
+    static Matrix Random(int r, int c) { Matrix m; m.XMat::setZero(r, c); for (double& v : m.d_) v = 2.0 * std::rand() / RAND_MAX - 1.0; return m; }
     static Matrix UnitX() { Matrix m; m.setZero(); m(0) = 1; return m; }
     static Matrix UnitY() { Matrix m; m.setZero(); m(1) = 1; return m; }
     static Matrix UnitZ() { Matrix m; m.setZero(); m(2) = 1; return m; }
 };
-inline Mat::Comma Blk::operator<<(double v) { LVREF_CHECK(false, "<< into a block is not provided"); static Mat dummy(1, 1); (void)v; return Mat::Comma(dummy, 0.0); }
-inline Mat::Comma Blk::operator<<(const Mat& b) { LVREF_CHECK(false, "<< into a block is not provided"); static Mat dummy(1, 1); (void)b; return Mat::Comma(dummy, 0.0); }
+inline XMat::Comma Blk::operator<<(double v) { LVREF_CHECK(false, "<< into a block is not provided"); static XMat dummy(1, 1); (void)v; return XMat::Comma(dummy, 0.0); }
+inline XMat::Comma Blk::operator<<(const XMat& b) { LVREF_CHECK(false, "<< into a block is not provided"); static XMat dummy(1, 1); (void)b; return XMat::Comma(dummy, 0.0); }
 
 typedef Matrix<double, 2, 2> Matrix2d; typedef Matrix<double, 3, 3> Matrix3d; typedef Matrix<double, 4, 4> Matrix4d;
 typedef Matrix<double, 2, 1> Vector2d; typedef Matrix<double, 3, 1> Vector3d; typedef Matrix<double, 4, 1> Vector4d;
@@ -438,7 +438,7 @@ class Quaterniond {
 public:
     Quaterniond() { q_ = Vector4d(0, 0, 0, 1); }
     Quaterniond(double w, double x, double y, double z) { q_ = Vector4d(x, y, z, w); }
-    explicit Quaterniond(const Mat& m)
+    explicit Quaterniond(const XMat& m)
     {
         if (m.rows() == 3 && m.cols() == 3) from_rotation(m);
         else if (m.size() == 4) q_ = Vector4d(m(0), m(1), m(2), m(3));
@@ -447,7 +447,7 @@ public:
     explicit Quaterniond(const Blk& b) : Quaterniond(b.eval()) {}
     inline Quaterniond(const AngleAxisd& aa);
     explicit Quaterniond(const double* p) { q_ = Vector4d(p[0], p[1], p[2], p[3]); }
-    void from_rotation(const Mat& mat)
+    void from_rotation(const XMat& mat)
     {   // Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Other,3,3>
         double t = mat.trace();
         if (t > 0) {
@@ -464,7 +464,7 @@ public:
             q_(3) = (mat(k, j) - mat(j, k)) * t; q_(j) = (mat(j, i) + mat(i, j)) * t; q_(k) = (mat(k, i) + mat(i, k)) * t;
         }
     }
-    Quaterniond& operator=(const Mat& m) { *this = Quaterniond(m); return *this; }
+    Quaterniond& operator=(const XMat& m) { *this = Quaterniond(m); return *this; }
     double w() const { return q_(3); } double x() const { return q_(0); } double y() const { return q_(1); } double z() const { return q_(2); }
     double& w() { return q_(3); } double& x() { return q_(0); } double& y() { return q_(1); } double& z() { return q_(2); }
     const Vector4d& coeffs() const { return q_; } Vector4d& coeffs() { return q_; }
@@ -498,9 +498,9 @@ public:
         return res;
     }
     Matrix3d matrix() const { return toRotationMatrix(); }
-    Vector3d operator*(const Mat& v) const { LVREF_CHECK(v.size() == 3, "quaternion * 3-vector"); Vector3d p(v(0), v(1), v(2)); Vector3d u = vec(); Vector3d uv = u.cross(p); uv = uv + uv; return Vector3d(p + w() * uv + u.cross(uv)); }
-    Vector3d _transformVector(const Mat& v) const { return (*this) * v; }
-    static Quaterniond FromTwoVectors(const Mat& a, const Mat& b)
+    Vector3d operator*(const XMat& v) const { LVREF_CHECK(v.size() == 3, "quaternion * 3-vector"); Vector3d p(v(0), v(1), v(2)); Vector3d u = vec(); Vector3d uv = u.cross(p); uv = uv + uv; return Vector3d(p + w() * uv + u.cross(uv)); }
+    Vector3d _transformVector(const XMat& v) const { return (*this) * v; }
+    static Quaterniond FromTwoVectors(const XMat& a, const XMat& b)
     {   // Eigen's QuaternionBase::setFromTwoVectors (the branch for vectors that are not nearly opposite)
         Vector3d v0 = a.normalized(), v1 = b.normalized();
         double c = v1.dot(v0);
@@ -509,7 +509,7 @@ public:
         const double s = std::sqrt((1.0 + c) * 2.0), invs = 1.0 / s;
         return Quaterniond(s * 0.5, axis(0) * invs, axis(1) * invs, axis(2) * invs);
     }
-    Quaterniond& setFromTwoVectors(const Mat& a, const Mat& b) { *this = FromTwoVectors(a, b); return *this; }
+    Quaterniond& setFromTwoVectors(const XMat& a, const XMat& b) { *this = FromTwoVectors(a, b); return *this; }
     double angularDistance(const Quaterniond& o) const { Quaterniond d = (*this) * o.conjugate(); return 2.0 * std::atan2(d.vec().norm(), std::fabs(d.w())); }
 };
 typedef Quaterniond Quaternion_d;
@@ -518,9 +518,9 @@ class AngleAxisd {
     double angle_ = 0; Vector3d axis_;
 public:
     AngleAxisd() { axis_ = Vector3d(1, 0, 0); }
-    AngleAxisd(double a, const Mat& ax) : angle_(a) { axis_ = ax; }
+    AngleAxisd(double a, const XMat& ax) : angle_(a) { axis_ = ax; }
     explicit AngleAxisd(const Quaterniond& q) { from_q(q); }
-    explicit AngleAxisd(const Mat& R) { from_q(Quaterniond(R)); }
+    explicit AngleAxisd(const XMat& R) { from_q(Quaterniond(R)); }
     void from_q(const Quaterniond& q)
     {   // Eigen's AngleAxis::operator=(QuaternionBase)
         double n = q.vec().norm();
@@ -551,54 +551,54 @@ public:
     Isometry3d() { m_.setIdentity(); }
     static Isometry3d Identity() { return Isometry3d(); }
     Isometry3d& setIdentity() { m_.setIdentity(); return *this; }
-    Blk linear() { return m_.block(0, 0, 3, 3); } Mat linear() const { return m_.block(0, 0, 3, 3); }
-    Blk rotation_ref() { return linear(); } Mat rotation() const { return linear(); }
-    Blk translation() { return m_.block(0, 3, 3, 1); } Mat translation() const { return m_.block(0, 3, 3, 1); }
+    Blk linear() { return m_.block(0, 0, 3, 3); } XMat linear() const { return m_.block(0, 0, 3, 3); }
+    Blk rotation_ref() { return linear(); } XMat rotation() const { return linear(); }
+    Blk translation() { return m_.block(0, 3, 3, 1); } XMat translation() const { return m_.block(0, 3, 3, 1); }
     Matrix4d& matrix() { return m_; } const Matrix4d& matrix() const { return m_; }
     double& operator()(int i, int j) { return m_(i, j); } double operator()(int i, int j) const { return m_(i, j); }
     Isometry3d inverse() const
     {   // (Isometry: R^T, -R^T t)
-        Isometry3d o; Mat Rt = linear().transpose(); o.linear() = Rt; o.translation() = -(Rt * translation()); return o;
+        Isometry3d o; XMat Rt = linear().transpose(); o.linear() = Rt; o.translation() = -(Rt * translation()); return o;
     }
     Isometry3d operator*(const Isometry3d& b) const { Isometry3d o; o.linear() = linear() * b.linear(); o.translation() = linear() * b.translation() + translation(); return o; }
-    Vector3d operator*(const Mat& p) const { LVREF_CHECK(p.size() == 3, "Isometry3d * 3-vector"); return Vector3d(linear() * p + translation()); }
-    Isometry3d& operator=(const Mat& m) { LVREF_CHECK(m.rows() == 4 && m.cols() == 4, "Isometry3d from a 4x4"); m_ = m; return *this; }
+    Vector3d operator*(const XMat& p) const { LVREF_CHECK(p.size() == 3, "Isometry3d * 3-vector"); return Vector3d(linear() * p + translation()); }
+    Isometry3d& operator=(const XMat& m) { LVREF_CHECK(m.rows() == 4 && m.cols() == 4, "Isometry3d from a 4x4"); m_ = m; return *this; }
 };
 typedef Isometry3d Affine3d;
 
 // ------------------------------------------------------------------ decompositions as the filter names them
 template <typename M> class JacobiSVD {
-    Mat U_, R_;
+    XMat U_, R_;
 public:
     JacobiSVD() {}
-    JacobiSVD(const Mat& A, unsigned = 0) { compute(A); }
-    JacobiSVD& compute(const Mat& A, unsigned = 0) { lvref_householder_qr(A, U_, R_); return *this; }
+    JacobiSVD(const XMat& A, unsigned = 0) { compute(A); }
+    JacobiSVD& compute(const XMat& A, unsigned = 0) { lvref_householder_qr(A, U_, R_); return *this; }
     // an orthogonal U whose first rank(A) columns span range(A) and whose last rows - rank columns span its left null space: all the
     // filter takes from it (`matrixU().rightCols(rows - rank)`); NOT the singular vectors themselves
-    const Mat& matrixU() const { return U_; }
+    const XMat& matrixU() const { return U_; }
 };
 template <typename M> class HouseholderQR {
-    Mat Q_, R_;
+    XMat Q_, R_;
 public:
     HouseholderQR() {}
-    explicit HouseholderQR(const Mat& A) { compute(A); }
-    HouseholderQR& compute(const Mat& A) { lvref_householder_qr(A, Q_, R_); return *this; }
-    const Mat& householderQ() const { return Q_; } const Mat& matrixQR() const { return R_; }
+    explicit HouseholderQR(const XMat& A) { compute(A); }
+    HouseholderQR& compute(const XMat& A) { lvref_householder_qr(A, Q_, R_); return *this; }
+    const XMat& householderQ() const { return Q_; } const XMat& matrixQR() const { return R_; }
 };
-template <typename T> using SparseMatrix = Mat;
+template <typename T> using SparseMatrix = XMat;
 enum { SPQR_ORDERING_NATURAL = 1 };
-struct SPQRProduct { Mat v; void evalTo(Mat& out) const { out = v; } operator Mat() const { return v; } };
-struct SPQRQt { const Mat* Q; };
-struct SPQRQ { const Mat* Q; SPQRQt transpose() const { return SPQRQt{Q}; } };
-inline SPQRProduct operator*(const SPQRQt& q, const Mat& b) { return SPQRProduct{q.Q->transpose() * b}; }
-inline SPQRProduct operator*(const SPQRQ& q, const Mat& b) { return SPQRProduct{(*q.Q) * b}; }
+struct SPQRProduct { XMat v; void evalTo(XMat& out) const { out = v; } operator XMat() const { return v; } };
+struct SPQRQt { const XMat* Q; };
+struct SPQRQ { const XMat* Q; SPQRQt transpose() const { return SPQRQt{Q}; } };
+inline SPQRProduct operator*(const SPQRQt& q, const XMat& b) { return SPQRProduct{q.Q->transpose() * b}; }
+inline SPQRProduct operator*(const SPQRQ& q, const XMat& b) { return SPQRProduct{(*q.Q) * b}; }
 template <typename M> class SPQR {
-    Mat Q_, R_;
+    XMat Q_, R_;
 public:
     void setSPQROrdering(int) {}
-    void compute(const Mat& A) { lvref_householder_qr(A, Q_, R_); }
+    void compute(const XMat& A) { lvref_householder_qr(A, Q_, R_); }
     SPQRQ matrixQ() const { return SPQRQ{&Q_}; }
-    const Mat& matrixR() const { return R_; }
+    const XMat& matrixR() const { return R_; }
     int rank() const { int rk = 0; for (int i = 0; i < std::min(R_.rows(), R_.cols()); ++i) if (R_(i, i) != 0.0) ++rk; return rk; }
     int info() const { return 0; }
 };

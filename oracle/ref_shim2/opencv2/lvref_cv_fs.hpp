@@ -24,8 +24,8 @@ public:
 };
 struct Matx33d { double val[9]; Matx33d() : val{} {} Matx33d(const Mat& m) { LVREF_CHECK(m.rows == 3 && m.cols == 3, "Matx33d from a Mat of another shape"); for (int k = 0; k < 9; ++k) val[k] = m.d[k]; } double operator()(int i, int j) const { return val[3 * i + j]; } };
 struct Vec3d { double val[3]; Vec3d() : val{} {} Vec3d(const Mat& m) { LVREF_CHECK(m.rows * m.cols == 3, "Vec3d from a Mat of another shape"); for (int k = 0; k < 3; ++k) val[k] = m.d[k]; } double operator()(int i) const { return val[i]; } double operator[](int i) const { return val[i]; } };
-inline void cv2eigen(const Matx33d& s, Eigen::Mat& d) { LVREF_CHECK(d.rows() == 3 && d.cols() == 3, "cv2eigen: 3x3"); for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d(i, j) = s(i, j); }
-inline void cv2eigen(const Vec3d& s, Eigen::Mat& d) { LVREF_CHECK(d.size() == 3, "cv2eigen: 3-vector"); for (int i = 0; i < 3; ++i) d(i) = s(i); }
+inline void cv2eigen(const Matx33d& s, Eigen::XMat& d) { LVREF_CHECK(d.rows() == 3 && d.cols() == 3, "cv2eigen: 3x3"); for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d(i, j) = s(i, j); }
+inline void cv2eigen(const Vec3d& s, Eigen::XMat& d) { LVREF_CHECK(d.size() == 3, "cv2eigen: 3-vector"); for (int i = 0; i < 3; ++i) d(i) = s(i); }
 class FileNode {
 public:
     bool present = false; std::string text; std::map<std::string, FileNode> kids; Mat mat;
