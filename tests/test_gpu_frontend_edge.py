@@ -39,7 +39,7 @@ def _cfg(w, h, **over):
     return S.frontend_config(cam=cam, **over)
 
 
-def _run(gpu_ctx, frames, cfg, device_stride=None):
+def _run(gpu_ctx, frames, cfg, device_stride=None, on_frame=None):
     from oracle import lvo
     import larvio_amd
     ora = lvo.Frontend(cfg)
@@ -70,6 +70,8 @@ def _run(gpu_ctx, frames, cfg, device_stride=None):
         if ho:
             n_msgs += 1
             assert mg.features.tobytes() == mo.tobytes(), f"frame {i}: feature message"
+        if on_frame is not None:
+            on_frame(i, hg, mg.features.tobytes() if hg else b"", gpu.state, tg, gpu.new_pts())       # (the HIP front-end's outputs of this frame)
         states.append(ora.state); n_tracks.append(len(to["ids"]))
     assert gpu.lk_stats() == ora.lk_stats()
     gpu.close()

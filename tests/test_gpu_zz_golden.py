@@ -119,3 +119,23 @@ def test_filter_against_the_references_own_outputs(gpu_ctx):
     assert n_upd == k[0] == len(z["a_state"])
     assert np.array_equal(ora.features()[0], z["a_feat_ids"])
     print("HIP filter vs the reference's record: updates", n_upd, "(HIP vs oracle: state", wx, "P", wP, ")")
+
+
+def test_frontend_against_the_references_own_outputs(gpu_ctx):
+    """the HIP front-end against what the REFERENCE'S OWN ImageProcessor::processImage made of 26 stored frames - /root/reference/src/
+    image_processor.cpp compiled in place (oracle/Makefile target `ref`; behind OpenCV's image-algorithm names the oracle's restatements,
+    around them the reference's own text), outputs written by tests/golden/make_ref_imgproc.py into ref_imgproc.npz; nothing of the
+    reference is needed here.  Featureless frames at the start (the bootstrap waits) and in the middle (every track lost, ids continue).
+    After EVERY frame, byte for byte: processImage's answer, image_state, track ids / lifetimes / points / descriptors, the new corners
+    and the feature message (the frame runner holds the HIP front-end to the live oracle as well)."""
+    from tests.test_gpu_frontend_edge import _run
+    from tests.test_oracle_ref_imgproc import fixture_stream, check_frame_against_record
+    z = np.load(os.path.join(GOLDEN, "ref_imgproc.npz"))
+    frames, ts_all, imu_all, cfg = fixture_stream(z)
+    seen = [0]
+
+    def on_frame(i, have, msg_bytes, state, tracks, new_pts):
+        check_frame_against_record(z, i, have, msg_bytes, state, tracks, new_pts)
+        seen[0] += 1
+    states, n_tracks, n_msgs = _run(gpu_ctx, frames, cfg, on_frame=on_frame)
+    assert seen[0] == len(frames) and n_msgs == int(z["have"].sum())

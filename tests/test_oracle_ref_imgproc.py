@@ -1,0 +1,193 @@
+"""The oracle's FRONT-END OBJECT against the REFERENCE'S OWN: /root/reference/src/image_processor.cpp (ImageProcessor::processImage and
+everything under it - the FIRST / SECOND / OTHER image state machine, createImagePyramids, integrateImuData + predictFeatureTracking,
+initializeFirstFrame / initializeFirstFeatures, trackFeatures and trackNewFeatures with their forward / reverse / descriptor / RANSAC
+gates and every removeUnmarkedElements in their order, findNewFeaturesToBeTracked's mask, undistortPoints, getFeatureMsg, the publish
+cadence) compiled where it lies, with src/ORBDescriptor.cpp, into oracle/_ref/liblvref_imgproc.so (oracle/Makefile target `ref`).
+OpenCV is not installed: behind cv::'s IMAGE ALGORITHMS (CLAHE, buildOpticalFlowPyramid, calcOpticalFlowPyrLK, goodFeaturesToTrack,
+findFundamentalMat, undistortPoints) stand the oracle's own restatements of them (oracle/ref_shim3/lvref_cv3.hpp), so this does NOT
+pin those algorithms - it pins everything the reference does AROUND them, which is what oracle/fe_pipeline.c restates: the two must agree
+BYTE FOR BYTE after every frame (state, track ids / lifetimes / points / init points / descriptors, new corners, the feature message).
+The fixed-size algebra of the gyro prediction (Matx33f products and inverse, Vec3f arithmetic with OpenCV's saturate_cast rules,
+Rodrigues) is written in that header from OpenCV's documented semantics, independently of the oracle's - the predicted points feed LK,
+so a difference there would show in the tracked points' bits.
+
+First half: the compiled reference live.  Second half: the oracle against tests/golden/ref_imgproc.npz, WRITTEN BY THE REFERENCE
+(tests/golden/make_ref_imgproc.py); tests/test_gpu_zz_golden.py holds the HIP front-end to the same file."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lvo
+from tests.test_gpu_frontend_edge import _texture, _crops, _imu, _cfg, _walk
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_imgproc.npz")
+
+
+def _ref():
+    from oracle import lvref
+    if not lvref.imgproc_available():
+        pytest.skip("oracle/_ref/liblvref_imgproc.so not built and /root/reference absent")
+    return lvref
+
+
+def run_both(frames, ts_all, imu_all, cfg, workdir, lvref):
+    ora = lvo.Frontend(cfg); ref = lvref.RefImageProcessor(cfg, str(workdir))
+    states, n_tracks, n_msgs = [], [], 0
+    for i, (ts, img) in enumerate(zip(ts_all, frames)):
+        imu = imu_all[(imu_all["t"] < ts + 0.05)][-60:]
+        ho, mo = ora.process(img, ts, imu); hr, mr = ref.process(img, ts, imu)
+        assert ho == hr, f"frame {i}: haveFeatures"
+        assert ora.state == ref.state, f"frame {i}: image_state {ora.state} {ref.state}"
+        to, tr = ora.tracks(), ref.tracks()
+        assert np.array_equal(to["ids"], tr["ids"]), f"frame {i}: ids"
+        assert np.array_equal(to["lifetime"], tr["lifetime"]), f"frame {i}: lifetime"
+        assert np.array_equal(to["pts"].view(np.uint32), tr["pts"].view(np.uint32)), f"frame {i}: pts"
+        assert np.array_equal(to["init"].view(np.uint32), tr["init"].view(np.uint32)), f"frame {i}: init"
+        assert np.array_equal(to["desc"], tr["desc"]), f"frame {i}: desc"
+        assert np.array_equal(ora.new_pts(), ref.new_pts()), f"frame {i}: new_pts"
+        if ho:
+            n_msgs += 1
+            assert mo.tobytes() == mr.tobytes(), f"frame {i}: feature message"
+        states.append(ora.state); n_tracks.append(len(to["ids"]))
+    return states, n_tracks, n_msgs
+
+
+def _edge(frames, cfg, tmp_path):
+    ts_all = [1.0 + 0.05 * i for i in range(len(frames))]
+    return run_both(frames, ts_all, _imu(ts_all[-1]), cfg, tmp_path, _ref())
+
+
+@pytest.mark.parametrize("first,count", [(0, 160), (40, 60)])
+def test_headline_configuration_frames(first, count, tmp_path):
+    """the synthetic EuRoC-shaped sequence (752 x 480, CLAHE, 3 levels, 150 tracks): from rest through take-off, and a start in motion;
+    tracks die and are replaced, lifetimes grow, every second frame publishes"""
+    lvref = _ref()
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    frames = synth_frames(first, count)
+    seq = S.imu_only_sequence()
+    k_first = max(int(frames[0][0] * 200) - 2, 0)
+    imu_all = seq.imu_array(k_first, k_first + 200 * (count // 20 + 2))
+    states, n_tracks, n_msgs = run_both([f[1] for f in frames], [f[0] for f in frames], imu_all, S.frontend_config(max_features_num=150), tmp_path, lvref)
+    assert states[-1] == 3 and n_msgs >= count // 2 - 2 and min(n_tracks[3:]) > 100
+    if count > 100:
+        assert len(set(n_tracks[3:])) > 3                        # the track set did change
+
+
+@pytest.mark.parametrize("w,h,levels", [(321, 243, 3), (250, 187, 2), (336, 200, 4)])
+def test_odd_image_sizes(w, h, levels, tmp_path):
+    frames = _crops(_texture(1, h + 120, w + 160), w, h, _walk(14))
+    states, n_tracks, n_msgs = _edge(frames, _cfg(w, h, max_features_num=120, min_distance=12, pyramid_levels=levels), tmp_path)
+    assert states[-1] == 3 and n_tracks[-1] > 40 and n_msgs >= 5
+
+
+def test_featureless_frames_at_the_start_and_in_the_middle(tmp_path):
+    w, h = 320, 240
+    crops = _crops(_texture(2, h + 120, w + 160), w, h, _walk(16))
+    flat = np.full((h, w), 128, np.uint8)
+    frames = [flat, flat, flat] + crops[:6] + [flat, flat] + crops[6:13] + [np.zeros((h, w), np.uint8)] + crops[13:]
+    states, n_tracks, n_msgs = _edge(frames, _cfg(w, h, max_features_num=100, min_distance=15), tmp_path)
+    assert states[:3] == [1, 1, 1] and states[5] == 3 and n_tracks[5] > 30
+
+
+def test_feature_budget_at_the_bootstrap_threshold(tmp_path):
+    w, h = 320, 240
+    frames = _crops(_texture(3, h + 120, w + 160), w, h, _walk(12))
+    for budget, dist in ((22, 30), (20, 30), (8, 60)):
+        states, n_tracks, n_msgs = _edge(frames, _cfg(w, h, max_features_num=budget, min_distance=dist), tmp_path)
+        if budget <= 20:
+            assert set(states) == {1}
+
+
+def test_jumps_beyond_the_capture_range_and_unrelated_frames(tmp_path):
+    w, h = 320, 240
+    tex = _texture(4, h + 200, w + 300)
+    offs = _walk(6) + [(40 + 2 * 6 + 45, 30 + 6 + 30)] + [(40 + 57 + 2 * i, 66 + i) for i in range(1, 6)]
+    frames = _crops(tex, w, h, offs)
+    rng = np.random.default_rng(5)
+    noise = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(2)]
+    frames = frames[:9] + noise + frames[9:] + [_texture(6, h, w)] + _crops(tex, w, h, _walk(4, start=(100, 80)))
+    states, n_tracks, n_msgs = _edge(frames, _cfg(w, h, max_features_num=150, min_distance=10), tmp_path)
+    assert n_msgs >= 4
+
+
+def test_equidistant_model_without_clahe(tmp_path):
+    w, h = 328, 248
+    frames = _crops(_texture(7, h + 120, w + 160), w, h, _walk(12, step=(1, 2)))
+    cfg = _cfg(w, h, max_features_num=90, min_distance=14, distortion_model=1, distortion=(0.003, 0.0007, -0.002, 0.0002), flag_equalize=0)
+    states, n_tracks, n_msgs = _edge(frames, cfg, tmp_path)
+    assert states[-1] == 3 and n_tracks[-1] > 30
+
+
+# ---------------------------------------------------------------------------------------------- the reference-written fixture
+def fixture_stream(z):
+    """frames (crops of the stored texture), time stamps, IMU and configuration of tests/golden/ref_imgproc.npz"""
+    tex = z["texture"]; w, h = int(z["w"]), int(z["h"])
+    frames = []
+    for k, (ox, oy) in enumerate(z["offsets"]):
+        frames.append(np.full((h, w), 128, np.uint8) if ox < 0 else np.ascontiguousarray(tex[oy:oy + h, ox:ox + w]))
+    ts_all = [1.0 + 0.05 * i for i in range(len(frames))]
+    cfg = _cfg(w, h, max_features_num=int(z["max_features_num"]), min_distance=int(z["min_distance"]))
+    return frames, ts_all, _imu(ts_all[-1]), cfg
+
+
+def check_frame_against_record(z, i, have, msg_bytes, state, tracks, new_pts):
+    """one frame's outputs of a front-end (the oracle's, or the HIP one) against what the reference's ImageProcessor produced"""
+    assert bool(have) == bool(z["have"][i]) and state == int(z["state"][i]), f"frame {i}: have / state"
+    a, b = int(z["trk_off"][i]), int(z["trk_off"][i + 1])
+    assert np.array_equal(tracks["ids"], z["trk_ids"][a:b]) and np.array_equal(tracks["lifetime"], z["trk_life"][a:b]), f"frame {i}: ids / lifetimes"
+    assert np.array_equal(np.ascontiguousarray(tracks["pts"], np.float32).view(np.uint32), z["trk_pts"][a:b].view(np.uint32)), f"frame {i}: pts"
+    assert np.array_equal(tracks["desc"], z["trk_desc"][a:b]), f"frame {i}: desc"
+    c, d = int(z["new_off"][i]), int(z["new_off"][i + 1])
+    assert np.array_equal(np.ascontiguousarray(new_pts, np.float32).view(np.uint32), z["new_pts"][c:d].view(np.uint32)), f"frame {i}: new corners"
+    if have:
+        e, f = int(z["msg_off"][i]), int(z["msg_off"][i + 1])
+        assert msg_bytes == z["msg"][e:f].tobytes(), f"frame {i}: feature message"
+
+
+def test_oracle_against_the_references_committed_outputs():
+    """no library needed: 26 frames (featureless ones at the start - the bootstrap waits - and in the middle - every track is lost, ids
+    continue with new corners) as the compiled reference processed them, frame by frame and byte for byte"""
+    z = np.load(GOLDEN)
+    frames, ts_all, imu_all, cfg = fixture_stream(z)
+    ora = lvo.Frontend(cfg)
+    for i, (ts, img) in enumerate(zip(ts_all, frames)):
+        imu = imu_all[(imu_all["t"] < ts + 0.05)][-60:]
+        have, msg = ora.process(img, ts, imu)
+        check_frame_against_record(z, i, have, msg.tobytes(), ora.state, ora.tracks(), ora.new_pts())
+    n_trk = np.diff(z["trk_off"])
+    assert int(z["have"].sum()) >= 8 and z["state"][-1] == 3 and n_trk[4] > 30 and (n_trk[12:16] == 0).all() and n_trk[16] > 30      # every track lost in the middle, new ones picked up
+
+
+def test_the_gpu_tests_own_code_runs_with_the_oracle_standing_in(monkeypatch):
+    """tests/test_gpu_zz_golden.py::test_frontend_against_the_references_own_outputs cannot run without a GPU; its OWN code (the frame
+    runner's on_frame hook, the record indexing) is executed here with the oracle behind the product's Python surface.  Says nothing
+    about the HIP front-end."""
+    import larvio_amd
+
+    class _Msg:
+        def __init__(self, m):
+            self.features = m
+
+    class _OracleBehindTheProductsSurface:
+        def __init__(self, cfg, ctx):
+            self.o = lvo.Frontend(cfg)
+
+        def initialize(self):
+            return True
+
+        def processImage(self, img, imu, ts=None, device_ptr=None, stride=None):
+            have, m = self.o.process(img, ts, imu)
+            return have, _Msg(m)
+
+        state = property(lambda self: self.o.state)
+
+        def close(self):
+            pass
+
+        def __getattr__(self, name):                         # tracks, new_pts, lk_stats
+            return getattr(self.o, name)
+    monkeypatch.setattr(larvio_amd, "ImageProcessor", _OracleBehindTheProductsSurface)
+    from tests import test_gpu_zz_golden as T
+    T.test_frontend_against_the_references_own_outputs(None)
