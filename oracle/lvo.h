@@ -17,8 +17,12 @@
  * tests/golden/ref_larvio.npz written by the reference); likewise, in smaller pieces, the ORB
  * descriptor, the triangulation, the static initialiser, the moving-start initialiser's window
  * bookkeeping, pre-integration and alignment.
- * FRONT-END: PARITY UNPINNED against reference outputs except the ORB block - its arithmetic
- * lives in OpenCV (un-vendored, unpinned: README.md:58 names 3.4.6 / 4.1.2); the functions
+ * FRONT-END: the ORCHESTRATION in fe_pipeline.c is PINNED to src/image_processor.cpp compiled in
+ * place (ImageProcessor::processImage, byte for byte after every frame: tests/
+ * test_oracle_ref_imgproc.py), and the ORB block to src/ORBDescriptor.cpp; the IMAGE ALGORITHMS
+ * stay PARITY UNPINNED against reference outputs - that arithmetic lives in OpenCV
+ * (un-vendored, unpinned: README.md:58 names 3.4.6 / 4.1.2), and in that comparison the
+ * reference's cv:: calls are served by these very restatements; the functions
  * below restate the published algorithms of those OpenCV calls ("[upstream]" in comments) and
  * follow the reference's own call sites for parameters.  Where OpenCV's own result depends on
  * its SIMD dispatch (float summation order in LK / boxFilter), the oracle fixes ONE order and
