@@ -587,19 +587,53 @@ public:
 };
 template <typename T> using SparseMatrix = XMat;
 enum { SPQR_ORDERING_NATURAL = 1 };
+// SPQR with natural ordering = a Householder QR without column permutation.  Q is kept as its reflectors (a tall measurement stack has
+// tens of thousands of rows: an explicit rows x rows Q would not fit) and applied to whatever it multiplies.
+struct SPQRFactors {
+    int m = 0, n = 0; XMat R; std::vector<std::vector<double>> v; std::vector<double> beta; std::vector<int> k0;
+    void compute(const XMat& A)
+    {
+        m = A.r_; n = A.c_; R = A; v.clear(); beta.clear(); k0.clear();
+        for (int k = 0; k < std::min(m - 1, n); ++k) {
+            double s = 0; for (int i = k; i < m; ++i) s += R(i, k) * R(i, k);
+            const double nrm = std::sqrt(s);
+            if (nrm == 0.0) continue;
+            const double alpha = R(k, k) >= 0 ? -nrm : nrm;
+            std::vector<double> w((size_t)(m - k));
+            for (int i = k; i < m; ++i) w[(size_t)(i - k)] = R(i, k);
+            w[0] -= alpha;
+            double vn2 = 0; for (double x : w) vn2 += x * x;
+            if (vn2 == 0.0) continue;
+            const double b = 2.0 / vn2;
+            for (int j = k; j < n; ++j) { double d = 0; for (int i = k; i < m; ++i) d += w[(size_t)(i - k)] * R(i, j); d *= b; if (d != 0.0) for (int i = k; i < m; ++i) R(i, j) -= d * w[(size_t)(i - k)]; }
+            for (int i = k + 1; i < m; ++i) R(i, k) = 0.0;
+            v.push_back(std::move(w)); beta.push_back(b); k0.push_back(k);
+        }
+    }
+    XMat apply(const XMat& B, bool transpose) const
+    {   // Q = H_1 H_2 ... H_p:  Q^T B applies H_1 first, Q B applies H_p first
+        LVREF_CHECK(B.r_ == m, "SPQR Q times a matrix of another height");
+        XMat X = B; const int p = (int)v.size();
+        for (int t = 0; t < p; ++t) {
+            const int q = transpose ? t : p - 1 - t; const int k = k0[(size_t)q]; const std::vector<double>& w = v[(size_t)q];
+            for (int j = 0; j < X.c_; ++j) { double d = 0; for (int i = k; i < m; ++i) d += w[(size_t)(i - k)] * X(i, j); d *= beta[(size_t)q]; if (d != 0.0) for (int i = k; i < m; ++i) X(i, j) -= d * w[(size_t)(i - k)]; }
+        }
+        return X;
+    }
+};
 struct SPQRProduct { XMat v; void evalTo(XMat& out) const { out = v; } operator XMat() const { return v; } };
-struct SPQRQt { const XMat* Q; };
-struct SPQRQ { const XMat* Q; SPQRQt transpose() const { return SPQRQt{Q}; } };
-inline SPQRProduct operator*(const SPQRQt& q, const XMat& b) { return SPQRProduct{q.Q->transpose() * b}; }
-inline SPQRProduct operator*(const SPQRQ& q, const XMat& b) { return SPQRProduct{(*q.Q) * b}; }
+struct SPQRQt { const SPQRFactors* f; };
+struct SPQRQ { const SPQRFactors* f; SPQRQt transpose() const { return SPQRQt{f}; } };
+inline SPQRProduct operator*(const SPQRQt& q, const XMat& b) { return SPQRProduct{q.f->apply(b, true)}; }
+inline SPQRProduct operator*(const SPQRQ& q, const XMat& b) { return SPQRProduct{q.f->apply(b, false)}; }
 template <typename M> class SPQR {
-    XMat Q_, R_;
+    SPQRFactors f_;
 public:
     void setSPQROrdering(int) {}
-    void compute(const XMat& A) { lvref_householder_qr(A, Q_, R_); }
-    SPQRQ matrixQ() const { return SPQRQ{&Q_}; }
-    const XMat& matrixR() const { return R_; }
-    int rank() const { int rk = 0; for (int i = 0; i < std::min(R_.rows(), R_.cols()); ++i) if (R_(i, i) != 0.0) ++rk; return rk; }
+    void compute(const XMat& A) { f_.compute(A); }
+    SPQRQ matrixQ() const { return SPQRQ{&f_}; }
+    const XMat& matrixR() const { return f_.R; }
+    int rank() const { int rk = 0; for (int i = 0; i < std::min(f_.R.rows(), f_.R.cols()); ++i) if (f_.R(i, i) != 0.0) ++rk; return rk; }
     int info() const { return 0; }
 };
 }  // namespace Eigen

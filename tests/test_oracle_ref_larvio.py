@@ -9,7 +9,8 @@ Eigen's names (JacobiSVD::matrixU as the orthogonal factor of a Householder QR -
 filter takes from it -, SPQR as a dense Householder QR with natural ordering, LDLT with diagonal pivoting, inverse by LU), cv::FileStorage
 over the YAML dialect the reference ships, boost::math::quantile of the chi-squared distribution by bisection on the incomplete gamma
 function.  What the stand-ins do not give is Eigen's / SPQR's rounding (and a different but equally valid null-space basis and row sign
-of R): the comparison is therefore held to 1e-7 relative (measured: state <= 8e-10, covariance <= 3e-9 over 19-70 updates), with
+of R): the comparison is therefore held to 1e-7 relative (measured: state <= 8e-10, covariance <= 3e-9 over 19-72 updates, incl. the
+configs[4]-depth stream with 2000 features per message), with
 everything discrete - state dimension, in-state feature ids and their order, clone times, the IMU samples each call erases, the map
 size, processFeatures' own return value - identical.  The moving-start initialiser's body is not in the library (solve_5pts.cpp and
 initial_sfm.cpp need OpenCV proper and Ceres; oracle/ref_larvio_wrap.cpp defines its entry points as "never succeeds"): streams
@@ -106,6 +107,13 @@ CASES = {
     "imu_intrinsics_46": (dict(seed=6, calib_imu_instrinsic=1, estimate_td=1, estimate_extrin=1), True),
     "no_fej": (dict(seed=7, if_fej=0), True),
     "window30_everything_on": (dict(seed=8, sw_size=30, estimate_td=1, estimate_extrin=1, if_zupt_valid=1, t1=9.0), True),
+    # BASELINE.json configs[4] at real depth (the stream of test_backend_parity_config5_depth): 2000 features per message, a 60-clone
+    # window, ~18,000 stacked rows every sixth message - the SPQR compression at its largest shape, then pruning at 60 clones
+    "configs4_depth_2000_features_60_clones": (dict(seed=8, t0=2.0, t1=9.2, max_feat=2000, n_per_batch=500, sw_size=60, max_features_in_one_grid=2,
+                                                    estimate_td=1, estimate_extrin=1), True),
+    # tracks of up to 58 observations in a 60-clone window: gatingTest reads chi_squared_test_table[dof] for dof >= 100, which the table
+    # (filled for 1..99, larvio.cpp:353-357) answers with 0.0 through std::map::operator[] - such a feature can never pass, on either side
+    "gate_quirk_dof_100_and_more": (dict(seed=9, t0=2.0, t1=9.4, max_feat=40, sw_size=60, max_track_len=58, max_features_in_one_grid=0), True),
 }
 
 
@@ -119,9 +127,11 @@ def test_oracle_filter_equals_the_compiled_reference_after_every_update(name, tm
     assert n >= 19 and max(worst.values()) < TOL, (n, worst)
     if name == "static_start_zupt_td_extrinsics":
         assert c["zupt"] >= 1                                                    # the zero-velocity update ran on both sides
-    if name != "pure_msckf":
+    if name == "gate_quirk_dof_100_and_more":
+        assert c["gated_out"] >= 20                                              # the long tracks were rejected (dof >= 100)
+    elif name != "pure_msckf":
         assert c["hybrid"] >= 10 and c["msckf"] >= 5
-    assert c["gated_in"] > 300
+    assert c["gated_in"] > (150 if name == "gate_quirk_dof_100_and_more" else 300)
 
 
 def test_chi_squared_table_of_the_compiled_reference():
