@@ -222,3 +222,29 @@ def test_the_gpu_tests_own_code_runs_with_the_oracle_standing_in(monkeypatch):
     monkeypatch.setattr(larvio_amd, "LarVio", _OracleBehindTheProductsSurface)
     from tests import test_gpu_zz_golden as T
     T.test_filter_against_the_references_own_outputs(None)
+
+
+def test_whole_loop_on_tracker_messages_from_rest(tmp_path):
+    """the messages a front-end really publishes (the oracle's ImageProcessor on the rendered synthetic sequence - byte-identical to the
+    compiled reference's, tests/test_oracle_ref_imgproc.py): initial-frame observations of new tracks (u_init != -1), tracks that end
+    when the tracker loses them, a varying feature count.  120 frames from rest: the reference's StaticInitializer, zero-velocity
+    updates, take-off, hybrid and MSCKF updates with config/euroc.yaml's parameters (td, extrinsics, ZUPT on; 20-clone window)."""
+    lvref = _ref()
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    frames = synth_frames(0, 120)
+    seq = S.imu_only_sequence()
+    imu_all = seq.imu_array(0, 200 * 8)
+    fe = lvo.Frontend(S.frontend_config(max_features_num=150))
+    msgs = []
+    for ts, img in frames:
+        buf = imu_all[:int(np.searchsorted(imu_all["t"], ts + 0.05))]
+        have, msg = fe.process(img, ts, buf[-60:])
+        if have:
+            msgs.append((ts, msg))
+    assert any((m["u_init"] != -1).any() for _, m in msgs[2:])
+    sim = dict(cfg=S.backend_config(sw_size=20), imu=imu_all, msgs=msgs, init=None)
+    n, worst, c = run_both(sim, False, lvref, tmp_path)
+    print("tracker messages from rest: updates", n, worst, c)
+    assert n >= 40 and max(worst.values()) < TOL and c["zupt"] >= 1 and c["hybrid"] >= 10
