@@ -372,7 +372,7 @@ def larvio_yaml(cfg, output_dir):
         lines.append("initial_covariance_%s: %s" % (k, g("initial_covariance_" + k)))
     lines += ["reset_fej_threshold: 10.11", "if_ZUPT_valid: %d" % cfg["if_zupt_valid"], "zupt_max_feature_dis: " + g("zupt_max_feature_dis"),
               "static_duration: " + g("static_duration"), "imu_rate: " + g("imu_rate"), "max_track_len: %d" % cfg["max_track_len"],
-              "feature_idp_dim: 1", "use_schmidt: 0", "least_observation_number: %d" % cfg["least_observation_number"],
+              "feature_idp_dim: %d" % int(cfg.get("feature_idp_dim", 1)), "use_schmidt: %d" % int(cfg.get("use_schmidt", 0)), "least_observation_number: %d" % cfg["least_observation_number"],
               "max_features_in_one_grid: %d" % cfg["max_features_in_one_grid"], "aug_grid_rows: %d" % cfg["aug_grid_rows"], "aug_grid_cols: %d" % cfg["aug_grid_cols"], ""]
     return "\n".join(lines)
 

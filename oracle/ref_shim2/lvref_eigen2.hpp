@@ -315,6 +315,7 @@ struct LDLTx {
     {
         LVREF_CHECK(A.r_ == A.c_, "ldlt of a non-square matrix");
         const int n = A.r_; L = A; D.assign(n, 0.0); perm.resize(n); for (int i = 0; i < n; ++i) perm[i] = i;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) L(i, j) = L(j, i);      // Eigen's LDLT<_, Lower> reads the lower triangle only (larvio.cpp:1665 hands it a triangular block in the 3-D mode)
         for (int k = 0; k < n; ++k) {
             int p = k; double best = std::fabs(L(k, k));
             for (int i = k + 1; i < n; ++i) if (std::fabs(L(i, i)) > best) { best = std::fabs(L(i, i)); p = i; }
