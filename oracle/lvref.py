@@ -542,3 +542,58 @@ class RefImageProcessor:
         p = np.zeros((self.cap, 2), np.float32)
         n = _libip().lvref_imgproc_new_pts(self.h, p.ctypes.data, self.cap)
         return p[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------------ the reference's moving-start initialiser
+_SO_DYN = os.environ.get("LVREF_DYNINIT_SO", os.path.join(_HERE, "_ref", "liblvref_dyninit.so"))
+_libd = None
+
+
+def dyninit_available(build=True):
+    if os.path.exists(_SO_DYN):
+        return True
+    if build and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return os.path.exists(_SO_DYN)
+
+
+def _libdy():
+    global _libd
+    if _libd is None:
+        if not dyninit_available():
+            raise RuntimeError("oracle/_ref/liblvref_dyninit.so is missing and /root/reference is not here to build it from")
+        from . import lvo
+        lvo.lib()                                                      # liblvo.so first: the library links against it
+        L = C.CDLL(_SO_DYN)
+        vp, i, d = C.c_void_p, C.c_int, C.c_double
+        L.lvref_dyninit_create.restype = vp; L.lvref_dyninit_create.argtypes = [d, vp, vp, d, d, d, d, d]
+        L.lvref_dyninit_destroy.argtypes = [vp]
+        L.lvref_dyninit_try.restype = i; L.lvref_dyninit_try.argtypes = [vp, d, i, vp, i, vp, vp]
+        L.lvref_dyninit_frame_count.restype = i; L.lvref_dyninit_frame_count.argtypes = [vp]
+        _libd = L
+    return _libd
+
+
+def dynamic_init(msgs, imu, R_b2c, t_c_b, td=0.0, imu_img_time_th=1.0 / 400, noise=(0.08, 4e-5, 0.004, 2e-6)):
+    """larvio::DynamicInitializer of the compiled reference fed like oracle/dyn_init.dynamic_init: feature messages [(ts, OBS records)]
+    and the IMU stream, as LarVio::processFeatures -> FlexibleInitializer::tryIncInit hands them over (the buffer only grows until the
+    initialiser succeeds).  -> dict(message, state_time, q [x y z w], v, bg, g, erase, last_gyro, last_acc) of the first success, or None."""
+    L = _libdy()
+    R_c2b = np.ascontiguousarray(np.asarray(R_b2c, np.float64).T); t = np.ascontiguousarray(t_c_b, np.float64)
+    h = L.lvref_dyninit_create(float(td), R_c2b.ctypes.data, t.ctypes.data, *[float(x) for x in noise], float(imu_img_time_th))
+    try:
+        sent = 0
+        for mi, (ts, m) in enumerate(msgs):
+            hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
+            new = imu[sent:hi]; sent = hi
+            a = np.zeros((len(new), 7)); a[:, 0] = new["t"]; a[:, 1:4] = new["gyro"]; a[:, 4:7] = new["acc"]
+            f = np.zeros((len(m), 9))
+            for k, name in enumerate(("id", "u", "v", "u_init", "v_init", "u_vel", "v_vel", "u_init_vel", "v_init_vel")):
+                f[:, k] = m[name]
+            out = np.zeros(21)
+            if L.lvref_dyninit_try(h, float(ts), len(f), f.ctypes.data, len(a), a.ctypes.data, out.ctypes.data):
+                return dict(message=mi, state_time=out[0], q=out[1:5].copy(), v=out[5:8].copy(), bg=out[8:11].copy(), last_gyro=out[11:14].copy(),
+                            last_acc=out[14:17].copy(), g=out[17:20].copy(), erase=int(out[20]))
+        return None
+    finally:
+        L.lvref_dyninit_destroy(h)

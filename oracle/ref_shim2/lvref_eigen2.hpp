@@ -138,6 +138,8 @@ public:
     inline double determinant() const;
     inline LDLTx ldlt() const;
     inline LDLTx llt() const;
+    inline struct JacobiSVDx jacobiSvd(unsigned opts = 0) const;
+    void swap(XMat& o) { std::swap(r_, o.r_); std::swap(c_, o.c_); d_.swap(o.d_); }
     XMat& setZero() { std::fill(d_.begin(), d_.end(), 0.0); return *this; }
     XMat& setOnes() { std::fill(d_.begin(), d_.end(), 1.0); return *this; }
     XMat& setConstant(double v) { std::fill(d_.begin(), d_.end(), v); return *this; }
@@ -180,6 +182,8 @@ inline std::ostream& operator<<(std::ostream& os, const XMat& m)
     for (int i = 0; i < m.rows(); ++i) { for (int j = 0; j < m.cols(); ++j) os << (j ? " " : "") << m(i, j); if (i + 1 < m.rows()) os << "\n"; }
     return os;
 }
+inline bool operator==(const XMat& a, const XMat& b) { return a.r_ == b.r_ && a.c_ == b.c_ && a.d_ == b.d_; }
+inline bool operator!=(const XMat& a, const XMat& b) { return !(a == b); }
 inline XMat operator+(const XMat& a, const XMat& b) { XMat o = a; o += b; return o; }
 inline XMat operator-(const XMat& a, const XMat& b) { XMat o = a; o -= b; return o; }
 inline XMat operator-(const XMat& a) { XMat o = a; for (double& v : o.d_) v = -v; return o; }
@@ -370,6 +374,41 @@ inline void lvref_householder_qr(const XMat& A, XMat& Q, XMat& R)
         for (int j = 0; j < m; ++j) { double d = 0; for (int i = k; i < m; ++i) d += Q(j, i) * v[i]; d *= beta; if (d != 0.0) for (int i = k; i < m; ++i) Q(j, i) -= d * v[i]; }     // Q <- Q H_k
     }
 }
+
+// A real singular value decomposition for the SMALL matrices that ask for singular vectors (initial_sfm.cpp's 4x4 triangulation takes
+// matrixV().rightCols<1>()): one-sided Jacobi (Hestenes) on the columns, singular values sorted descending as Eigen's are.
+struct JacobiSVDx {
+    XMat U_, V_, S_;
+    explicit JacobiSVDx(const XMat& A)
+    {
+        const int m = A.r_, n = A.c_; XMat B = A; V_ = XMat(n, n); V_.setIdentity();
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0;
+            for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int i = 0; i < m; ++i) { a += B(i, p) * B(i, p); b += B(i, q) * B(i, q); c += B(i, p) * B(i, q); }
+                if (c == 0.0) continue;
+                off = std::max(off, std::fabs(c) / std::sqrt(std::max(a * b, 1e-300)));
+                const double zeta = (b - a) / (2.0 * c), t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta)), cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < m; ++i) { const double x = B(i, p), y = B(i, q); B(i, p) = cs * x - sn * y; B(i, q) = sn * x + cs * y; }
+                for (int i = 0; i < n; ++i) { const double x = V_(i, p), y = V_(i, q); V_(i, p) = cs * x - sn * y; V_(i, q) = sn * x + cs * y; }
+            }
+            if (off < 1e-15) break;
+        }
+        std::vector<double> sv(n); std::vector<int> order(n);
+        for (int j = 0; j < n; ++j) { double s = 0; for (int i = 0; i < m; ++i) s += B(i, j) * B(i, j); sv[j] = std::sqrt(s); order[j] = j; }
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return sv[a] > sv[b]; });
+        XMat Vs(n, n), Us(m, n); S_ = XMat(n, 1);
+        for (int k = 0; k < n; ++k) {
+            const int j = order[k]; S_(k) = sv[j];
+            for (int i = 0; i < n; ++i) Vs(i, k) = V_(i, j);
+            for (int i = 0; i < m; ++i) Us(i, k) = sv[j] > 0 ? B(i, j) / sv[j] : 0.0;
+        }
+        V_ = Vs; U_ = Us;
+    }
+    const XMat& matrixV() const { return V_; } const XMat& matrixU() const { return U_; } const XMat& singularValues() const { return S_; }
+};
+inline JacobiSVDx XMat::jacobiSvd(unsigned) const { return JacobiSVDx(*this); }
 
 // ------------------------------------------------------------------ the shaped derivations
 template <typename T, int R, int C, int Opt = 0, int MR = R, int MC = C> class Matrix : public XMat {
