@@ -62,20 +62,26 @@ def test_recorded_starts_reference_oracle_and_product(replay, tmp_path, seed, sp
 
 def test_window_slides_until_the_platform_moves(replay, tmp_path):
     """a start from rest seen by the moving-start initialiser alone: relativePose refuses and the window slides (slideWindow / removeBack)
-    until the first attempt that gets through - the same message on all three sides"""
+    until the first attempt that gets through - the same message for the compiled reference and the product's host code (the oracle's
+    agreement with the product on this start is tests/test_oracle_dynamic_init.py::test_window_slides_until_the_platform_moves)"""
+    import json
+    import subprocess
     lvref = _ref()
+    from oracle import lvo
     from larvio_amd import synthetic as S
     sim = F.simulate(5, t0=0.3, t1=3.6, sigma=3e-4, imu_noise=1.0, traj=S.Trajectory(speed=3.0), fresh_ids=True)
     R_b2c, t_c_b = _extr()
     rec = str(tmp_path / "start.txt"); _record(rec, sim, R_b2c, t_c_b)
-    P, O = _sides(replay, rec, sim, R_b2c, t_c_b, "real")
+    lvo.lib()
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liblvo.so")
+    P = json.loads(subprocess.run([replay, rec, so], capture_output=True, text=True, check=True, timeout=120).stdout)
     Rf = lvref.dynamic_init(sim["msgs"], sim["imu"], R_b2c, t_c_b)
-    assert Rf is not None and Rf["message"] == O["message"] == P["message"] and Rf["message"] > 12
-    assert Rf["state_time"] == O["state_time"] == P["state_time"] and Rf["erase"] == O["erase"] == P["erase"]
-    d_o = _diff(Rf, Rotation.from_matrix(O["R"]).as_quat(), O["v"], O["bg"], O["g"]); d_p = _diff(Rf, P["q"], P["v"], P["bg"], P["g"])
-    print("first success at message", Rf["message"], "reference vs oracle", {k: "%.1e" % x for k, x in d_o.items()}, "| vs product host code", {k: "%.1e" % x for k, x in d_p.items()})
-    for d in (d_o, d_p):             # frames from the rest sit in a flat valley of the bundle adjustment: the minimisers stop a few 1e-5 apart (tests/test_oracle_dynamic_init.py)
-        assert d["attitude"] < 1e-4 and d["v"] < 2e-3 and d["bg"] < 1e-5 and d["g"] < 2e-2, d
+    assert Rf is not None and Rf["message"] == P["message"] and Rf["message"] > 12
+    assert Rf["state_time"] == P["state_time"] and Rf["erase"] == P["erase"]
+    d = _diff(Rf, P["q"], P["v"], P["bg"], P["g"])
+    print("first success at message", Rf["message"], "reference vs product host code", {k: "%.1e" % x for k, x in d.items()})
+    # frames from the rest sit in a flat valley of the bundle adjustment: the minimisers stop a few 1e-5 apart (tests/test_oracle_dynamic_init.py)
+    assert d["attitude"] < 1e-4 and d["v"] < 2e-3 and d["bg"] < 1e-5 and d["g"] < 2e-2, d
 
 
 def load_fixture_stream(z):
