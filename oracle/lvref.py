@@ -345,6 +345,7 @@ def _libl():
         L.lvref_larvio_get_features.restype = i; L.lvref_larvio_get_features.argtypes = [vp, vp, vp, vp, i]
         L.lvref_larvio_map_size.restype = i; L.lvref_larvio_map_size.argtypes = [vp]
         L.lvref_larvio_chi2.restype = d; L.lvref_larvio_chi2.argtypes = [vp, i]
+        L.lvref_larvio_getters.argtypes = [vp, vp, vp, vp, vp]
         _libv = L
     return _libv
 
@@ -436,6 +437,12 @@ class RefLarVio:
         ids = np.zeros(4096, np.int64); idp = np.zeros(4096); pos = np.zeros((4096, 3))
         n = _libl().lvref_larvio_get_features(self.h, ids.ctypes.data, idp.ctypes.data, pos.ctypes.data, 4096)
         return ids[:n].copy(), idp[:n].copy(), pos[:n].copy()
+
+    def getters(self):
+        """LarVio::getTbw / getVel / getPpose / getPvel (larvio.cpp:2645-2700) -> (T 4x4, v, P_pose 6x6, P_vel 3x3)"""
+        T = np.zeros(16); v = np.zeros(3); Pp = np.zeros(36); Pv = np.zeros(9)
+        _libl().lvref_larvio_getters(self.h, T.ctypes.data, v.ctypes.data, Pp.ctypes.data, Pv.ctypes.data)
+        return T.reshape(4, 4), v, Pp.reshape(6, 6), Pv.reshape(3, 3)
 
     def map_size(self):
         return _libl().lvref_larvio_map_size(self.h)

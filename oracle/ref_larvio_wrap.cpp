@@ -129,6 +129,16 @@ int lvref_larvio_get_features(void* h, long long* ids, double* idp, double* pos,
     }
     return n;
 }
+// the public getters (larvio.cpp:2645-2700): T_b_w (row-major 4 x 4), velocity, P_pose (row-major 6 x 6), P_vel (row-major 3 x 3)
+void lvref_larvio_getters(void* h, double* T16, double* v3, double* Ppose36, double* Pvel9)
+{
+    LarVio& L = *((RefVio*)h)->vio;
+    const Eigen::Isometry3d T = L.getTbw(); const Eigen::Vector3d v = L.getVel(); const Eigen::Matrix<double, 6, 6> Pp = L.getPpose(); const Eigen::Matrix3d Pv = L.getPvel();
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T16[4 * i + j] = T.matrix()(i, j);
+    for (int i = 0; i < 3; ++i) v3[i] = v(i);
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ppose36[6 * i + j] = Pp(i, j);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Pvel9[3 * i + j] = Pv(i, j);
+}
 int lvref_larvio_map_size(void* h) { return (int)((RefVio*)h)->vio->map_server.size(); }
 double lvref_larvio_chi2(void* h, int dof) { return ((RefVio*)h)->vio->chi_squared_test_table[dof]; }
 

@@ -274,3 +274,25 @@ def test_the_references_own_3d_inverse_depth_mode_is_overconfident(tmp_path):
         nees[dim] = float(np.mean(acc))
     print("position NEES of the reference's own filter: 1-D", nees[1], "3-D", nees[3])
     assert nees[1] < 1.0 and nees[3] > 3.0 * nees[1] and nees[3] > 2.0
+
+
+def test_the_references_getters(tmp_path):
+    """what a driver reads after processFeatures (app/larvioMain.cpp:139-170), from the compiled reference itself: getTbw = (R(q), p),
+    getVel = v, getPpose = the covariance's position / orientation blocks with POSITION FIRST (`P_imu_pose << P_pp, P_po, P_op, P_oo`,
+    larvio.cpp:2673-2679), getPvel = its velocity block - the index lists of adapter/lvk_adapter_ekf.cpp (idx {6, 7, 8, 0, 1, 2}; 3..5),
+    which reads them from lvk_ekf_get_cov_imu's 9 x 9 block."""
+    lvref = _ref()
+    sim = F.simulate(1, t1=3.5)
+    ref = lvref.RefLarVio(sim["cfg"], str(tmp_path)); ref.set_state(*sim["init"])
+    imu = sim["imu"]; lo = 0
+    for ts, m in sim["msgs"]:
+        hi = int(np.searchsorted(imu["t"], ts + 0.05, side="left"))
+        ok, used = ref.process(ts, m, imu[lo:hi]); lo += used
+    s, P = ref.state(), ref.cov()
+    T, v, Pp, Pv = ref.getters()
+    x, y, z, w = s["q"]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    assert np.abs(T[:3, :3] - R).max() < 1e-15 and np.array_equal(T[:3, 3], s["p"]) and np.array_equal(T[3], [0, 0, 0, 1]) and np.array_equal(v, s["v"])
+    idx = [6, 7, 8, 0, 1, 2]
+    assert np.array_equal(Pp, P[np.ix_(idx, idx)]) and np.array_equal(Pv, P[3:6, 3:6])
