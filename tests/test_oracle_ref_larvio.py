@@ -248,6 +248,18 @@ def test_whole_loop_on_tracker_messages_from_rest(tmp_path):
     n, worst, c = run_both(sim, False, lvref, tmp_path)
     print("tracker messages from rest: updates", n, worst, c)
     assert n >= 40 and max(worst.values()) < TOL and c["zupt"] >= 1 and c["hybrid"] >= 10
+    # north_star's acceptance is phrased on trajectories ("RMSE within 1 mm of the reference"): the two trajectories themselves
+    ekf = lvo_be.Ekf(sim["cfg"]); ref = lvref.RefLarVio(sim["cfg"], str(tmp_path / "traj"))
+    lo_a = lo_b = 0; d = []
+    for ts, m in msgs:
+        hi = int(np.searchsorted(imu_all["t"], ts + 0.05, side="left"))
+        ua, na = ekf.process(ts, m, imu_all[lo_a:hi]); lo_a += na
+        ub, nb = ref.process(ts, m, imu_all[lo_b:hi]); lo_b += nb
+        if ua:
+            d.append(np.linalg.norm(ekf.state()["p"] - ref.state()["p"]))
+    path = float(np.linalg.norm(ekf.state()["p"]))
+    print("position of the oracle's trajectory against the reference's own: rms %.2e m, max %.2e m over %d poses (%.2f m from the start)" % (np.sqrt(np.mean(np.square(d))), max(d), len(d), path))
+    assert max(d) < 1e-6 and path > 0.3
 
 
 def test_the_references_own_3d_inverse_depth_mode_is_overconfident(tmp_path):
