@@ -1,8 +1,13 @@
-"""ctypes binding of oracle/_ref/liblvref_orb.so and liblvref_feature.so: the REFERENCE's own ORB descriptor code
-(/root/reference/src/ORBDescriptor.cpp, include/ORB/ORBDescriptor.h) and Feature code (include/larvio/feature.hpp: checkMotion and the
-initializePosition family), compiled in place against the OpenCV / Eigen stand-ins of oracle/ref_shim/ (oracle/Makefile, target `ref`).
-TEST INFRASTRUCTURE ONLY: it pins the restatement in oracle/fe_track.c / fe_image.c; the product never loads it.
-The library is built here (where /root/reference exists) by __graft_entry__.build(); on the GPU box only the prebuilt file exists."""
+"""ctypes bindings of oracle/_ref/*.so: the REFERENCE's own sources compiled where they lie under /root/reference (never copied) against
+stand-in headers for the libraries this image does not have (oracle/Makefile, target `ref`; oracle/ref_shim .. ref_shim4):
+    liblvref_larvio.so    src/larvio.cpp + FlexibleInitializer / StaticInitializer / feature_manager   -> RefLarVio (the whole filter)
+    liblvref_imgproc.so   src/image_processor.cpp + ORBDescriptor.cpp over the oracle's OpenCV restatements -> RefImageProcessor
+    liblvref_dyninit.so   src/DynamicInitializer.cpp + initial_sfm / initial_alignment / feature_manager over stand-in minimisers -> dynamic_init
+    liblvref_orb.so       src/ORBDescriptor.cpp                                                         -> RefOrb
+    liblvref_feature.so   include/larvio/feature.hpp, math_utils.hpp                                    -> feature_initialize, feature_check_motion, math_*
+    liblvref_preint.so / _align.so / _static.so / _fm.so   ImuPreintegration.h, initial_alignment.cpp, StaticInitializer.cpp, feature_manager.cpp
+TEST INFRASTRUCTURE ONLY: these pin the restatements in oracle/ (and, through fixtures they wrote, the product); the product never loads them.
+The libraries are built here (where /root/reference exists) by __graft_entry__.build(); on the GPU box only the prebuilt files exist."""
 import ctypes as C
 import os
 import subprocess
