@@ -2,7 +2,7 @@
 stand-in headers for the libraries this image does not have (oracle/Makefile, target `ref`; oracle/ref_shim .. ref_shim4):
     liblvref_larvio.so    src/larvio.cpp + FlexibleInitializer / StaticInitializer / feature_manager   -> RefLarVio (the whole filter)
     liblvref_imgproc.so   src/image_processor.cpp + ORBDescriptor.cpp over the oracle's OpenCV restatements -> RefImageProcessor
-    liblvref_dyninit.so   src/DynamicInitializer.cpp + initial_sfm / initial_alignment / feature_manager over stand-in minimisers -> dynamic_init
+    liblvref_dyninit.so   src/DynamicInitializer.cpp + initial_sfm / solve_5pts / initial_alignment / feature_manager over stand-in minimisers -> dynamic_init
     liblvref_orb.so       src/ORBDescriptor.cpp                                                         -> RefOrb
     liblvref_feature.so   include/larvio/feature.hpp, math_utils.hpp                                    -> feature_initialize, feature_check_motion, math_*
     liblvref_preint.so / _align.so / _static.so / _fm.so   ImuPreintegration.h, initial_alignment.cpp, StaticInitializer.cpp, feature_manager.cpp

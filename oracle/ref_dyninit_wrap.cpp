@@ -1,12 +1,12 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY (see oracle/lvo.h).  C entry points around the REFERENCE's own moving-start initialiser -
 // /root/reference/src/DynamicInitializer.cpp (tryDynInit / processIMU / processImage / initialStructure / relativePose /
 // visualInitialAlign / slideWindow / assignInitialState), src/initial_sfm.cpp (GlobalSFM::construct: the PnP / triangulation chain and the
-// bundle adjustment's problem set-up), src/initial_alignment.cpp, src/feature_manager.cpp and include/Initializer/ImuPreintegration.h,
-// compiled where they lie (oracle/Makefile, target `ref` -> oracle/_ref/liblvref_dyninit.so; never copied) against the stand-ins of
-// oracle/ref_shim4/ (Eigen as in ref_shim2; cv::solvePnP / Rodrigues / eigen2cv and the Ceres names served by small minimisers written
-// there).  NOT the reference's text in this library: src/solve_5pts.cpp, which is an excerpt of OpenCV's own recoverPose written
-// against OpenCV's Mat expressions - MotionEstimator::solveRelativeRT is defined below from what that file does (findFundamentalMat
-// through the oracle's RANSAC restatement, the four-candidate cheirality vote with the 50-unit distance bound).
+// bundle adjustment's problem set-up), src/solve_5pts.cpp (MotionEstimator::solveRelativeRT and the excerpt of OpenCV's own
+// decomposeEssentialMat / recoverPose it carries), src/initial_alignment.cpp, src/feature_manager.cpp and include/Initializer/
+// ImuPreintegration.h, compiled where they lie (oracle/Makefile, target `ref` -> oracle/_ref/liblvref_dyninit.so; never copied) against
+// the stand-ins of oracle/ref_shim4/ (Eigen as in ref_shim2; the slice of OpenCV's Mat algebra solve_5pts.cpp is written in; cv::solvePnP
+// / Rodrigues / SVD::compute / triangulatePoints and the Ceres names served by small routines written there; cv::findFundamentalMat by
+// the oracle's RANSAC restatement).
 #include <string>
 #include <vector>
 #include <map>
@@ -25,49 +25,6 @@ extern "C" {
 #include "Initializer/DynamicInitializer.h"
 #undef private
 #undef protected
-
-namespace larvio {
-static Eigen::Vector3d tri_two(const double P0[12], const double P1[12], const double a[2], const double b[2])
-{
-    Eigen::Matrix4d M;
-    for (int c = 0; c < 4; ++c) { M(0, c) = a[0] * P0[8 + c] - P0[c]; M(1, c) = a[1] * P0[8 + c] - P0[4 + c]; M(2, c) = b[0] * P1[8 + c] - P1[c]; M(3, c) = b[1] * P1[8 + c] - P1[4 + c]; }
-    Eigen::XMat X = M.jacobiSvd().matrixV().rightCols(1);
-    return Eigen::Vector3d(X(0) / X(3), X(1) / X(3), X(2) / X(3));
-}
-// what solve_5pts.cpp:185-231 does (see the header comment)
-bool MotionEstimator::solveRelativeRT(const std::vector<std::pair<Eigen::Vector3d, Eigen::Vector3d>>& corres, Eigen::Matrix3d& Rotation, Eigen::Vector3d& Translation)
-{
-    if (corres.size() < 15) return false;
-    const int n = (int)corres.size();
-    std::vector<lvo_pt2f> ll((size_t)n), rr((size_t)n);
-    for (int i = 0; i < n; ++i) { ll[(size_t)i].x = (float)corres[(size_t)i].first(0); ll[(size_t)i].y = (float)corres[(size_t)i].first(1); rr[(size_t)i].x = (float)corres[(size_t)i].second(0); rr[(size_t)i].y = (float)corres[(size_t)i].second(1); }
-    std::vector<uint8_t> mask((size_t)n, 1); double F[9];
-    if (!lvo_find_fundamental(ll.data(), rr.data(), n, 0.3 / 460, 0.99, mask.data(), F)) return false;
-    Eigen::Matrix3d E; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E(i, j) = F[3 * i + j];
-    Eigen::JacobiSVDx svd(E);
-    Eigen::Matrix3d U = svd.matrixU(), Vt = svd.matrixV().transpose();
-    if (U.determinant() < 0) U = -U;
-    if (Vt.determinant() < 0) Vt = -Vt;
-    Eigen::Matrix3d W; W << 0, 1, 0, -1, 0, 0, 0, 0, 1;
-    const Eigen::Matrix3d R1 = U * W * Vt, R2 = U * W.transpose() * Vt; const Eigen::Vector3d t0 = U.col(2);
-    int best = -1; Eigen::Matrix3d Rb; Eigen::Vector3d tb;
-    for (int c = 0; c < 4; ++c) {                               // (R1, t) (R2, t) (R1, -t) (R2, -t): the first of equals wins
-        const Eigen::Matrix3d R = (c & 1) ? R2 : R1; const Eigen::Vector3d t = (c & 2) ? Eigen::Vector3d(-t0) : t0;
-        double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, P1[12];
-        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P1[4 * i + j] = R(i, j); P1[4 * i + 3] = t(i); }
-        int good = 0;
-        for (int k = 0; k < n; ++k) {
-            if (!mask[(size_t)k]) continue;
-            const double a[2] = {ll[(size_t)k].x, ll[(size_t)k].y}, b[2] = {rr[(size_t)k].x, rr[(size_t)k].y};
-            const Eigen::Vector3d X = tri_two(P0, P1, a, b); const double z2 = (R * X + t)(2);
-            good += (X(2) > 0 && X(2) < 50 && z2 > 0 && z2 < 50);
-        }
-        if (good > best) { best = good; Rb = R; tb = t; }
-    }
-    Rotation = Rb.transpose(); Translation = -(Rb.transpose() * tb);
-    return best > 12;
-}
-}  // namespace larvio
 
 using namespace larvio;
 struct RefDyn { DynamicInitializer* d = nullptr; std::vector<ImuData> imu; MonoCameraMeasurement msg; };

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cfloat>
+#include <climits>
 #include <cassert>
 #include <memory>
 #include <vector>
@@ -83,6 +84,10 @@ class RNG {
     uint64_t state;
 };
 
+struct MatExpr;
+class _OutputArray;
+struct Range { int start, end; Range() : start(0), end(0) {} Range(int s, int e) : start(s), end(e) {} static Range all() { return Range(INT32_MIN, INT32_MAX); } };
+inline bool operator==(const Size& a, const Size& b) { return a.width == b.width && a.height == b.height; }
 struct Scalar {
     double val[4];
     Scalar(double a = 0, double b = 0, double c = 0, double d = 0) : val{a, b, c, d} {}
@@ -134,6 +139,26 @@ class Mat {
         return m;
     }
     Mat row(int y) const { return (*this)(Rect(0, y, cols, 1)); }
+    Mat col(int x) const { return (*this)(Rect(x, 0, 1, rows)); }
+    Mat operator()(const Range& r, const Range& c) const
+    {
+        const int r0 = r.start == INT32_MIN ? 0 : r.start, r1 = r.end == INT32_MAX ? rows : r.end, c0 = c.start == INT32_MIN ? 0 : c.start, c1 = c.end == INT32_MAX ? cols : c.end;
+        return (*this)(Rect(c0, r0, c1 - c0, r1 - r0));
+    }
+    // ---- the little dense algebra OpenCV's own recoverPose excerpt (the reference's src/solve_5pts.cpp) is written in: see ref_shim4/lvref_cvalg.hpp
+    inline Mat(const MatExpr& e);
+    inline Mat& operator=(const MatExpr& e);            // evaluates INTO this header's data when shape and type agree (a view keeps pointing into its parent), else re-allocates
+    inline MatExpr t() const;
+    inline MatExpr mul(const Mat& o) const;
+    inline Mat& operator*=(double a);
+    inline Mat& operator/=(const Mat& o);
+    inline void convertTo(Mat& dst, int type) const;
+    inline void copyTo(const _OutputArray& o) const;
+    static Mat eye(int r, int c, int type) { Mat m(r, c, type); for (int i = 0; i < std::min(r, c); ++i) { if (type == CV_64F) m.at<double>(i, i) = 1.0; else if (type == CV_32F) m.at<float>(i, i) = 1.f; else m.at<uchar>(i, i) = 1; } return m; }
+    int checkVector(int elemChannels) const { return (channels() == 1 && cols == elemChannels) ? rows : ((rows == 1 || cols == 1) && channels() == elemChannels ? rows * cols : -1); }
+    Mat reshape(int cn, int new_rows) const { assert(cn == 1 && channels() == 1 && new_rows == rows); return *this; }
+    double get(int y, int x) const { return type_ == CV_64F ? at<double>(y, x) : type_ == CV_32F ? (double)at<float>(y, x) : (double)at<uchar>(y, x); }
+    void set(int y, int x, double v) { if (type_ == CV_64F) at<double>(y, x) = v; else if (type_ == CV_32F) at<float>(y, x) = (float)v; else at<uchar>(y, x) = (uchar)std::min(255.0, std::max(0.0, std::nearbyint(v))); }
     Mat& setTo(const Scalar& v)
     {
         for (int y = 0; y < rows; ++y) for (int x = 0; x < cols; ++x) {

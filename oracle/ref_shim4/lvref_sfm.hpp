@@ -7,9 +7,11 @@
 #pragma once
 #include "../ref_shim/lvref_cv.hpp"
 #include "../ref_shim2/lvref_eigen2.hpp"
+#include "lvref_cvalg.hpp"
 #include <vector>
 #include <cmath>
 namespace cv {
+enum { FM_7POINT = 1, FM_8POINT = 2, FM_LMEDS = 4, FM_RANSAC = 8, RANSAC = 8, LMEDS = 4 };
 template <typename T> struct Point3_ { T x, y, z; Point3_() : x(0), y(0), z(0) {} Point3_(T a, T b, T c) : x(a), y(b), z(c) {} };
 typedef Point3_<float> Point3f; typedef Point3_<double> Point3d;
 template <typename T> class Mat_ : public Mat {

@@ -1,5 +1,5 @@
 """Generates tests/golden/ref_dyninit.npz from the REFERENCE'S OWN moving-start initialiser - /root/reference/src/DynamicInitializer.cpp,
-initial_sfm.cpp, initial_alignment.cpp, feature_manager.cpp compiled in place into oracle/_ref/liblvref_dyninit.so (oracle/Makefile target
+initial_sfm.cpp, solve_5pts.cpp, initial_alignment.cpp, feature_manager.cpp compiled in place into oracle/_ref/liblvref_dyninit.so (oracle/Makefile target
 `ref`; the minimisers behind cv::solvePnP and Ceres are stand-ins, see oracle/ref_shim4/).  The outputs stored here are NOT the oracle's.
 Needs /root/reference; run from the repo root:
     python tests/golden/make_ref_dyninit.py

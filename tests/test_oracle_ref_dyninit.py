@@ -1,12 +1,13 @@
 """Row N4's moving-start initialiser against the REFERENCE'S OWN: /root/reference/src/DynamicInitializer.cpp (tryDynInit, processIMU,
 processImage, initialStructure, relativePose, visualInitialAlign, slideWindow, assignInitialState), src/initial_sfm.cpp (GlobalSFM::
-construct: the PnP / triangulation chain in its order and the bundle adjustment's problem set-up), src/initial_alignment.cpp,
+construct: the PnP / triangulation chain in its order and the bundle adjustment's problem set-up), src/solve_5pts.cpp (solveRelativeRT
+and the excerpt of OpenCV's own decomposeEssentialMat / recoverPose it carries), src/initial_alignment.cpp,
 src/feature_manager.cpp and include/Initializer/ImuPreintegration.h compiled where they lie into oracle/_ref/liblvref_dyninit.so
 (oracle/Makefile target `ref`) against the stand-ins of oracle/ref_shim4/.  OpenCV and Ceres are not installed: cv::solvePnP, cv::Rodrigues
 and the Ceres problem are served by small minimisers written in those headers (Levenberg-Marquardt with central differences, run to
 convergence - real OpenCV / Ceres stop at their own tolerances, so digits beyond ~1e-6 are not theirs either), cv::findFundamentalMat by
-the oracle's RANSAC restatement; src/solve_5pts.cpp, an excerpt of OpenCV's recoverPose written against OpenCV's Mat expressions, is
-not compiled - MotionEstimator::solveRelativeRT is defined in oracle/ref_dyninit_wrap.cpp from what it does.  So what is pinned here is
+the oracle's RANSAC restatement, cv::SVD::compute / triangulatePoints by a Jacobi SVD, and the Mat expressions solve_5pts.cpp is written
+in by a small eager algebra (oracle/ref_shim4/lvref_cvalg.hpp).  So what is pinned here is
 the reference's ORCHESTRATION of the initialiser - which samples and frames, the window, frame l, the structure-from-motion order, the
 gauge, the alignment, the gravity-aligned state, the erase count - with every minimiser replaced by one that finds the same minimum.
 Held to it: the independent restatement oracle/dyn_init.py AND the product's own host code (larvio_amd/csrc/be_init.h through the
