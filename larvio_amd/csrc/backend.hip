@@ -217,6 +217,13 @@ struct lvk_ekf {
     double sigma2, zupt_v2, zupt_p2, zupt_q2, imu_img_time_th, Qc[12];
     double x_min, y_min, grid_w, grid_h;
     std::vector<int> grid_count;
+    // The reference's grid_map is a std::map<int, vector> (larvio.h:383): a feature whose code falls outside the rows x cols cells (undistorted
+    // coordinates beyond the image bounds) gets a cell of its own, which updateGridMap never clears (larvio.cpp:3356-3366) - it only fills up.
+    // Found by running the reference's own filter against the oracle (tests/test_oracle_ref_larvio.py) after the round's GPU budget was spent:
+    // LVK_GRID_REFERENCE=1 selects the reference's bookkeeping; the default (0: such codes are not counted at all, what this library has
+    // always done and what every GPU measurement and parity run of the round used) stays until the switch has been run on a GPU.
+    std::map<int, int> grid_phantom;
+    bool reference_grid = false;
     std::vector<double> coarse_dis;
     int static_counter = 0, static_num = 0; double lower_time_bound = 0;
     lvk_status dyn_status = LVK_OK;
@@ -1336,6 +1343,16 @@ static int grid_code(const lvk_ekf* e, const double* xy)
     int row = (int)((xy[1] - e->y_min) / e->grid_h), col = (int)((xy[0] - e->x_min) / e->grid_w);
     return row * e->cfg.aug_grid_cols + col;
 }
+static inline int grid_occupancy(lvk_ekf* e, int code, int cells)
+{   // grid_map[code].size() (larvio.cpp:1974)
+    if (code >= 0 && code < cells) return e->grid_count[(size_t)code];
+    return e->reference_grid ? e->grid_phantom[code] : 0;
+}
+static inline void grid_add(lvk_ekf* e, int code, int cells)
+{   // grid_map[code].push_back(id) (:1990, :3366)
+    if (code >= 0 && code < cells) e->grid_count[(size_t)code]++;
+    else if (e->reference_grid) e->grid_phantom[code]++;
+}
 // removeLostFeatures when no feature can enter the state in this update (the usual message: the augmentation grid is full, or no
 // track has reached max_track_len in a free cell) and the update is not sharded: NOTHING on the host depends on a device result
 // before the update is launched.  The triangulations of the features that need one are queued and consumed ON THE DEVICE by the row
@@ -1452,7 +1469,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             const int oi = f.find(e->imu_id);
             double xy[2] = {0, 0}; if (oi >= 0) { xy[0] = f.obs[oi].z[0]; xy[1] = f.obs[oi].z[1]; }
             const int code = grid_code(e, xy);
-            if (code >= 0 && code < cells) e->grid_count[code]++;
+            grid_add(e, code, cells);
         }
     }
     st = upload_clones(e);
@@ -1463,7 +1480,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
         if (e->s.t - e->last_zupt_time > 5 && (int)e->feature_states.size() < c.max_features_in_one_grid * cells)
             for (const Feature* f : long_tracked) {
                 const int code = grid_code(e, f->obs[(size_t)f->find(e->imu_id)].z);
-                const int gcount = (code >= 0 && code < cells) ? e->grid_count[code] : 0;
+                const int gcount = grid_occupancy(e, code, cells);
                 if (gcount < c.max_features_in_one_grid) { admission = true; break; }
             }
         if (!admission) return remove_lost_fast(e, ekf_ids);
@@ -1521,7 +1538,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
             Cand& cd = cands[ci++];
             const int oi = f.find(e->imu_id);
             const int code = grid_code(e, f.obs[oi].z);
-            const int gcount = (code >= 0 && code < cells) ? e->grid_count[code] : 0;
+            const int gcount = grid_occupancy(e, code, cells);
             if (gcount < c.max_features_in_one_grid && e->s.t - e->last_zupt_time > 5 &&
                 (int)(e->feature_states.size() + ekf_new.size()) < c.max_features_in_one_grid * cells) {
                 if (!f.ekf_feature) {
@@ -1530,7 +1547,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
                 }
                 if (!f.is_initialized) continue;
                 ekf_new.push_back(f.id);
-                if (code >= 0 && code < cells) e->grid_count[code]++;
+                grid_add(e, code, cells);
             } else {
                 if (!f.is_initialized) { if (cd.motion && cd.idx_pos >= 0) apply_tri(&f, 0, ans[cd.idx_pos]); }
                 if (!f.is_initialized) continue;
@@ -2167,6 +2184,8 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     if (cells != 0) { e->grid_w = (x_max - e->x_min) / c.aug_grid_cols; e->grid_h = (y_max - e->y_min) / c.aug_grid_rows; }
     else { e->grid_w = x_max - e->x_min; e->grid_h = y_max - e->y_min; }
     e->grid_count.assign((size_t)cells + 1, 0);
+    e->grid_phantom.clear();
+    if (const char* g = getenv("LVK_GRID_REFERENCE")) e->reference_grid = atoi(g) != 0;
     e->static_num = (int)((float)c.static_duration * (double)c.pub_frequency);
     // capacities
     const int max_feat_state = std::max(0, c.max_features_in_one_grid) * cells;

@@ -55,6 +55,7 @@ struct lvo_ekf {
     double sigma2, zupt_v2, zupt_p2, zupt_q2, imu_img_time_th;
     double x_min, y_min, grid_w, grid_h;
     int* grid_count;                       /* grid_map sizes */
+    int n_phantom, phantom_code[512], phantom_count[512];   /* reference_grid: the cells std::map makes for out-of-range codes (never cleared) */
     double* coarse_dis; int n_coarse, cap_coarse;
     /* static initializer */
     int static_counter, static_num; double lower_time_bound;
@@ -750,6 +751,22 @@ static int grid_code(const lvo_ekf* e, const double* xy)
     int row = (int)((xy[1] - e->y_min) / e->grid_h), col = (int)((xy[0] - e->x_min) / e->grid_w);
     return row * e->cfg.aug_grid_cols + col;
 }
+static int* phantom_cell(lvo_ekf* e, int code)
+{
+    for (int i = 0; i < e->n_phantom; ++i) if (e->phantom_code[i] == code) return &e->phantom_count[i];
+    if (e->n_phantom < 512) { e->phantom_code[e->n_phantom] = code; e->phantom_count[e->n_phantom] = 0; return &e->phantom_count[e->n_phantom++]; }
+    static int full; full = 1 << 30; return &full;
+}
+static int grid_occupancy(lvo_ekf* e, int code, int cells)
+{   /* grid_map[code].size() (larvio.cpp:1974) */
+    if (code >= 0 && code < cells) return e->grid_count[code];
+    return e->cfg.reference_grid ? *phantom_cell(e, code) : 0;
+}
+static void grid_add(lvo_ekf* e, int code, int cells)
+{   /* grid_map[code].push_back(id) (:1990, :3366) */
+    if (code >= 0 && code < cells) e->grid_count[code]++;
+    else if (e->cfg.reference_grid) (*phantom_cell(e, code))++;
+}
 static void update_grid_map(lvo_ekf* e)
 {   /* larvio.cpp:3351-3370 */
     const int cells = e->cfg.aug_grid_rows * e->cfg.aug_grid_cols;
@@ -761,7 +778,7 @@ static void update_grid_map(lvo_ekf* e)
         double xy[2] = {0, 0};
         if (oi >= 0) { xy[0] = f->z[oi][0]; xy[1] = f->z[oi][1]; }
         int code = grid_code(e, xy);
-        if (code >= 0 && code < cells) e->grid_count[code]++;
+        grid_add(e, code, cells);
         TR(e, "GRIDF %lld %.17g %.17g\n", (long long)f->id, xy[0], xy[1]);
     }
     if (e->trace) { TR(e, "GRID %d %d %.17g %.17g %.17g %.17g", e->cfg.aug_grid_rows, e->cfg.aug_grid_cols, e->x_min, e->y_min, e->grid_w, e->grid_h);
@@ -840,7 +857,7 @@ static void remove_lost_features(lvo_ekf* e)
             int oi = feat_obs_find(f, e->imu_id);
             int code = grid_code(e, f->z[oi]);
             tx = f->z[oi][0]; ty = f->z[oi][1];
-            int gcount = (code >= 0 && code < cells) ? e->grid_count[code] : 0;
+            int gcount = grid_occupancy(e, code, cells);
             if (gcount < c->max_features_in_one_grid && e->s.t - e->last_zupt_time > 5 &&
                 (e->n_fs + n_new) < c->max_features_in_one_grid * cells) {
                 if (!f->ekf_feature) {
@@ -851,7 +868,7 @@ static void remove_lost_features(lvo_ekf* e)
                 if (!f->is_initialized) { cat = 4; goto rec; }
                 rows_new += 2 * (f->n_obs - 1);
                 ekf_new[n_new++] = f->id; cat = 3;
-                if (code >= 0 && code < cells) e->grid_count[code]++;
+                grid_add(e, code, cells);
             } else {
                 if (!f->is_initialized) { mot = feat_check_motion(e, f, tracked); if (mot) tri = feat_initialize(e, f, 0); }
                 if (!f->is_initialized) { cat = 4; goto rec; }

@@ -19,7 +19,7 @@ _CFG_DBL = ["td", "pub_frequency", "imu_rate", "noise_gyro", "noise_acc", "noise
 
 class EkfConfig(C.Structure):
     _fields_ = ([(k, C.c_int) for k in _CFG_INT[:14]] + [("intrinsics", C.c_double * 4), ("T_cam_imu", C.c_double * 16)] +
-                [(k, C.c_double) for k in _CFG_DBL] + [("calib_imu_instrinsic", C.c_int)])
+                [(k, C.c_double) for k in _CFG_DBL] + [("calib_imu_instrinsic", C.c_int), ("reference_grid", C.c_int)])
 
 
 def make_ekf_config(cfg, cls=EkfConfig):
@@ -28,6 +28,8 @@ def make_ekf_config(cfg, cls=EkfConfig):
         setattr(c, k, cfg[k])
     if hasattr(c, "calib_imu_instrinsic"):
         c.calib_imu_instrinsic = int(cfg.get("calib_imu_instrinsic", 0))
+    if hasattr(c, "reference_grid"):
+        c.reference_grid = int(cfg.get("reference_grid", 0))      # see lvo.h: 1 = the reference's cells for out-of-range grid codes (the product's LVK_GRID_REFERENCE=1); 0 = not counted (both defaults)
     c.intrinsics = (C.c_double * 4)(*cfg["intrinsics"])
     c.T_cam_imu = (C.c_double * 16)(*np.asarray(cfg["T_cam_imu"], np.float64).reshape(16))
     return c

@@ -66,7 +66,7 @@ def check_against_row(s, P, row, p15, pnorm, tol=TOL, exact_time=True):
 def run_both(sim, set_state, ref_mod, workdir):
     """drive the oracle and the compiled reference with the same stream (tests/feature_sim.drive's protocol); every discrete thing must
     be identical after every call, everything continuous is returned as the worst relative difference"""
-    ekf = lvo_be.Ekf(sim["cfg"]); ref = ref_mod.RefLarVio(sim["cfg"], str(workdir))
+    ekf = lvo_be.Ekf(dict(sim["cfg"], reference_grid=sim.get("reference_grid", 1))); ref = ref_mod.RefLarVio(sim["cfg"], str(workdir))      # reference_grid: see lvo.h
     if set_state:
         ekf.set_state(*sim["init"]); ref.set_state(*sim["init"])
     imu = sim["imu"]; lo_a = lo_b = 0; worst = dict(state=0., cov=0., feat=0., clone=0.); n = 0
@@ -155,7 +155,7 @@ def load_stream_b(z):
 
 
 def _oracle_against_records(cfg, msgs, imu, init, z, pre):
-    ekf = lvo_be.Ekf(cfg)
+    ekf = lvo_be.Ekf(dict(cfg, reference_grid=1))
     if init is not None:
         ekf.set_state(*init)
     lo = 0; k = 0
@@ -249,7 +249,7 @@ def test_whole_loop_on_tracker_messages_from_rest(tmp_path):
     print("tracker messages from rest: updates", n, worst, c)
     assert n >= 40 and max(worst.values()) < TOL and c["zupt"] >= 1 and c["hybrid"] >= 10
     # north_star's acceptance is phrased on trajectories ("RMSE within 1 mm of the reference"): the two trajectories themselves
-    ekf = lvo_be.Ekf(sim["cfg"]); ref = lvref.RefLarVio(sim["cfg"], str(tmp_path / "traj"))
+    ekf = lvo_be.Ekf(dict(sim["cfg"], reference_grid=1)); ref = lvref.RefLarVio(sim["cfg"], str(tmp_path / "traj"))
     lo_a = lo_b = 0; d = []
     for ts, m in msgs:
         hi = int(np.searchsorted(imu_all["t"], ts + 0.05, side="left"))
@@ -364,3 +364,40 @@ def test_the_references_window_of_five_names_one_clone_twice(tmp_path):
             broken = (k, ref.dim, len(ref.clones()["id"])); break
         assert ekf.dim == ref.dim
     assert broken is not None and broken[1] == 46 + 6 * (broken[2] - 1), broken
+
+
+def _tracker_stream(first, count, max_features_num, min_distance, **bcfg):
+    """the oracle front-end's messages (byte-identical to the compiled reference's) on a stretch of the rendered sequence, with the
+    ground-truth state at the first message for a start from a handed-in state"""
+    from oracle import lvo
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    frames = synth_frames(first, count)
+    seq = S.imu_only_sequence(); imu_all = seq.imu_array(max(int(frames[0][0] * 200) - 2, 0), int(frames[-1][0] * 200) + 60)
+    fe = lvo.Frontend(S.frontend_config(max_features_num=max_features_num, min_distance=min_distance)); msgs = []
+    for ts, img in frames:
+        buf = imu_all[:int(np.searchsorted(imu_all["t"], ts + 0.05))]
+        have, msg = fe.process(img, ts, buf[-60:])
+        if have:
+            msgs.append((ts, msg))
+    tr = seq.traj; k = int(np.searchsorted(imu_all["t"], msgs[0][0], side="right")) - 1; t0 = imu_all["t"][k]
+    init = (t0, F.R2q(tr.R_wb(t0)), tr.p_wb(t0), tr.vel(t0), np.zeros(3), np.zeros(3), imu_all["gyro"][k], imu_all["acc"][k])
+    return dict(cfg=S.backend_config(**bcfg), imu=imu_all, msgs=msgs, init=init)
+
+
+def test_features_beyond_the_image_bounds_get_cells_of_their_own(tmp_path):
+    """FOUND with the compiled reference, after the round's last GPU run.  `grid_map` is a std::map<int, vector> (larvio.h:383): a feature
+    whose undistorted coordinates lie beyond the image bounds (radtan distortion: a band of 30-40 px along the borders) has a grid code
+    outside the rows x cols cells, and `grid_map[code]` makes a cell for it that updateGridMap never clears (larvio.cpp:3356-3366) - it
+    only fills up, so each such code admits `max_features_in_one_grid` features once and then never again.  The oracle and the product
+    did not count such codes at all (any number of border features could enter the state).  With `reference_grid = 1` the oracle follows
+    the reference (this test, the tracker-message cases of the fuzzing, everything else in this file); the product's switch is
+    LVK_GRID_REFERENCE=1, and its DEFAULT is still the old behaviour - every GPU measurement and parity run of the round used it, and the
+    switch has not run on a GPU.  On this moving start (100 rendered frames, 200 tracks) the old behaviour admits other features than
+    the reference from the first admission on, and the position estimates part by millimetres."""
+    lvref = _ref()
+    sim = _tracker_stream(30, 100, 200, 15, sw_size=30, max_features_in_one_grid=1)
+    n, worst, c = run_both(sim, True, lvref, tmp_path / "ref_grid")
+    assert n >= 45 and max(worst.values()) < TOL and c["hybrid"] >= 40, (n, worst, c)
+    with pytest.raises(AssertionError):                                           # the old bookkeeping: in-state feature ids differ
+        run_both(dict(sim, reference_grid=0), True, lvref, tmp_path / "old_grid")
