@@ -191,3 +191,45 @@ def test_the_gpu_tests_own_code_runs_with_the_oracle_standing_in(monkeypatch):
     monkeypatch.setattr(larvio_amd, "ImageProcessor", _OracleBehindTheProductsSurface)
     from tests import test_gpu_zz_golden as T
     T.test_frontend_against_the_references_own_outputs(None)
+
+
+def _random_frames(k):
+    """a random front-end case (seeded): image 160..420 x 120..320, 1..3 pyramid levels, patch 15 / 21 / 31, 21..260 tracks, min_distance
+    5..40, CLAHE on or off, radtan or equidistant, 10 / 30 LK iterations, publish rate 5 / 10 / 20 Hz; a random walk of the crop window with
+    jumps and stand-stills, flat, noise and exposure-shifted frames, a random constant gyro rate"""
+    rng = np.random.default_rng([k, 313])
+    w = int(rng.integers(160, 420)); h = int(rng.integers(120, 320))
+    levels = int(rng.integers(1, 4)); patch = int(rng.choice([15, 21, 21, 31])); nfr = int(rng.integers(10, 28))
+    tex = _texture(int(k) + 100, h + 260, w + 360)
+    x, y = 60, 60; offs = []
+    for i in range(nfr):
+        r = rng.random()
+        if r < 0.1: dx, dy = int(rng.integers(-40, 41)), int(rng.integers(-30, 31))
+        elif r < 0.2: dx, dy = 0, 0
+        else: dx, dy = int(rng.integers(-4, 5)), int(rng.integers(-3, 4))
+        x = int(np.clip(x + dx, 0, tex.shape[1] - w)); y = int(np.clip(y + dy, 0, tex.shape[0] - h)); offs.append((x, y))
+    frames = _crops(tex, w, h, offs)
+    for i in range(nfr):
+        r = rng.random()
+        if r < 0.05: frames[i] = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+        elif r < 0.08: frames[i] = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        elif r < 0.15: frames[i] = np.clip(frames[i].astype(int) + int(rng.integers(-60, 61)), 0, 255).astype(np.uint8)
+    model = int(rng.integers(0, 2))
+    dist = (0.003, 0.0007, -0.002, 0.0002) if model else (float(rng.uniform(-0.3, 0.05)), float(rng.uniform(-0.02, 0.08)), float(rng.uniform(-1e-3, 1e-3)), float(rng.uniform(-1e-3, 1e-3)))
+    cfg = _cfg(w, h, max_features_num=int(rng.integers(21, 260)), min_distance=int(rng.integers(5, 40)), pyramid_levels=levels, patch_size=patch,
+               flag_equalize=int(rng.integers(0, 2)), distortion_model=model, distortion=dist, max_iteration=int(rng.choice([10, 30])), track_precision=float(rng.choice([0.01, 0.03])),
+               pub_frequency=int(rng.choice([10, 10, 20, 5])))
+    ts_all = [1.0 + 0.05 * i for i in range(nfr)]
+    return frames, ts_all, _imu(ts_all[-1], gyro=tuple(rng.normal(0, 0.15, 3))), cfg
+
+
+def test_random_configurations(tmp_path):
+    """twelve of the random cases the oracle's front-end object was fuzzed with against the compiled reference (200 of them, every frame of
+    every one byte-identical)"""
+    lvref = _ref()
+    msgs = 0
+    for k in range(0, 12):
+        frames, ts_all, imu_all, cfg = _random_frames(k)
+        states, n_tracks, n_msgs = run_both(frames, ts_all, imu_all, cfg, tmp_path / str(k), lvref)
+        msgs += n_msgs
+    assert msgs > 60

@@ -401,3 +401,31 @@ def test_features_beyond_the_image_bounds_get_cells_of_their_own(tmp_path):
     assert n >= 45 and max(worst.values()) < TOL and c["hybrid"] >= 40, (n, worst, c)
     with pytest.raises(AssertionError):                                           # the old bookkeeping: in-state feature ids differ
         run_both(dict(sim, reference_grid=0), True, lvref, tmp_path / "old_grid")
+
+
+def test_zero_velocity_updates_in_the_middle_of_a_run(tmp_path):
+    """a platform that takes off from rest, stops for 1.4 s in mid-flight and goes on (the synthetic trajectory under a time warp): the
+    static initialiser, then zero-velocity updates at the start AND during the pause - checkZUPT, measurementUpdate_ZUPT_vpq, the removal of
+    the previous clone, last_ZUPT_time holding in-state features back for 5 s afterwards - 80 updates, 15 of them ZUPT"""
+    lvref = _ref()
+    from larvio_amd import synthetic as S
+
+    def s_int(x):                                            # integral of smoothstep
+        x = max(x, 0.0)
+        return x ** 6 - 3 * x ** 5 + 2.5 * x ** 4 if x < 1 else 0.5 + (x - 1)
+
+    class Pausing(S.Trajectory):
+        a, b, r = 4.0, 5.4, 0.4
+
+        def _s(self, t):
+            return t - self.r * (s_int((t - self.a) / self.r) - s_int((t - self.b) / self.r))
+
+        def p_wb(self, t):
+            return S.Trajectory.p_wb(self, self._s(t))
+
+        def R_wb(self, t):
+            return S.Trajectory.R_wb(self, self._s(t))
+    sim = F.simulate(1, t0=0.1, t1=9.0, traj=Pausing(speed=2.0), if_zupt_valid=1, estimate_td=1, estimate_extrin=1, sigma=3e-4, imu_noise=1.0, sw_size=20, **EUROC_COV)
+    n, worst, c = run_both(sim, False, lvref, tmp_path)
+    print("pause in mid-flight: updates", n, worst, c)
+    assert n >= 75 and c["zupt"] >= 10 and c["hybrid"] >= 30 and max(worst.values()) < TOL
