@@ -349,6 +349,7 @@ def _libl():
         L.lvref_larvio_get_clones.restype = i; L.lvref_larvio_get_clones.argtypes = [vp, vp, i]
         L.lvref_larvio_get_features.restype = i; L.lvref_larvio_get_features.argtypes = [vp, vp, vp, vp, i]
         L.lvref_larvio_map_size.restype = i; L.lvref_larvio_map_size.argtypes = [vp]
+        L.lvref_larvio_get_clone_cams.restype = i; L.lvref_larvio_get_clone_cams.argtypes = [vp, vp, i]
         L.lvref_larvio_chi2.restype = d; L.lvref_larvio_chi2.argtypes = [vp, i]
         L.lvref_larvio_getters.argtypes = [vp, vp, vp, vp, vp]
         _libv = L
@@ -438,6 +439,11 @@ class RefLarVio:
         o = np.zeros((256, 12)); n = _libl().lvref_larvio_get_clones(self.h, o.ctypes.data, 256)
         return dict(id=o[:n, 0].astype(np.int64), time=o[:n, 1].copy(), q=o[:n, 2:6].copy(), p=o[:n, 6:9].copy(), p_fej=o[:n, 9:12].copy())
 
+    def clone_cams(self):
+        """the clones' camera poses as feature.hpp reads them: ids, orientation_cam (n x 4), position_cam (n x 3)"""
+        o = np.zeros((256, 8)); n = _libl().lvref_larvio_get_clone_cams(self.h, o.ctypes.data, 256)
+        return o[:n, 0].astype(np.int64), o[:n, 1:5].copy(), o[:n, 5:8].copy()
+
     def features(self):
         ids = np.zeros(4096, np.int64); idp = np.zeros(4096); pos = np.zeros((4096, 3))
         n = _libl().lvref_larvio_get_features(self.h, ids.ctypes.data, idp.ctypes.data, pos.ctypes.data, 4096)
@@ -448,6 +454,13 @@ class RefLarVio:
         T = np.zeros(16); v = np.zeros(3); Pp = np.zeros(36); Pv = np.zeros(9)
         _libl().lvref_larvio_getters(self.h, T.ctypes.data, v.ctypes.data, Pp.ctypes.data, Pv.ctypes.data)
         return T.reshape(4, 4), v, Pp.reshape(6, 6), Pv.reshape(3, 3)
+
+    def map(self):
+        """map_server: (ids, observation counts, flags: 1 is_initialized, 2 in_state, 4 ekf_feature)"""
+        L = _libl(); L.lvref_larvio_map.restype = C.c_int; L.lvref_larvio_map.argtypes = [C.c_void_p] * 4 + [C.c_int]
+        ids = np.zeros(8192, np.int64); n_obs = np.zeros(8192, np.int32); fl = np.zeros(8192, np.int32)
+        n = L.lvref_larvio_map(self.h, ids.ctypes.data, n_obs.ctypes.data, fl.ctypes.data, 8192)
+        return ids[:n].copy(), n_obs[:n].copy(), fl[:n].copy()
 
     def map_size(self):
         return _libl().lvref_larvio_map_size(self.h)

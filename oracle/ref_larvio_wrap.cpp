@@ -117,6 +117,19 @@ int lvref_larvio_get_clones(void* h, double* out, int cap)
     }
     return n;
 }
+// the clones' camera poses as the triangulation reads them: per clone 8 doubles (id, orientation_cam[4], position_cam[3])
+int lvref_larvio_get_clone_cams(void* h, double* out, int cap)
+{
+    LarVio& L = *((RefVio*)h)->vio; int n = 0;
+    for (const auto& kv : L.state_server.imu_states_augment) {
+        if (n >= cap) break;
+        double* o = out + 8 * n; const IMUState_Aug& c = kv.second;
+        o[0] = (double)c.id; for (int k = 0; k < 4; ++k) o[1 + k] = c.orientation_cam(k);
+        for (int k = 0; k < 3; ++k) o[5 + k] = c.position_cam(k);
+        ++n;
+    }
+    return n;
+}
 // in-state features in state order: ids, inverse depth, world position
 int lvref_larvio_get_features(void* h, long long* ids, double* idp, double* pos, int cap)
 {
@@ -138,6 +151,13 @@ void lvref_larvio_getters(void* h, double* T16, double* v3, double* Ppose36, dou
     for (int i = 0; i < 3; ++i) v3[i] = v(i);
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ppose36[6 * i + j] = Pp(i, j);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Pvel9[3 * i + j] = Pv(i, j);
+}
+// the map server's features: id, observations, is_initialized, in_state (for looking into a disagreement)
+int lvref_larvio_map(void* h, long long* ids, int* n_obs, int* flags, int cap)
+{
+    LarVio& L = *((RefVio*)h)->vio; int n = 0;
+    for (const auto& kv : L.map_server) { if (n >= cap) break; ids[n] = (long long)kv.first; n_obs[n] = (int)kv.second.observations.size(); flags[n] = (kv.second.is_initialized ? 1 : 0) | (kv.second.in_state ? 2 : 0) | (kv.second.ekf_feature ? 4 : 0); ++n; }
+    return n;
 }
 int lvref_larvio_map_size(void* h) { return (int)((RefVio*)h)->vio->map_server.size(); }
 double lvref_larvio_chi2(void* h, int dof) { return ((RefVio*)h)->vio->chi_squared_test_table[dof]; }
