@@ -170,6 +170,8 @@ class Mat {
     }
     template <typename T> T& at(int y, int x) { return *(T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
     template <typename T> const T& at(int y, int x) const { return *(const T*)(data + (size_t)y * step + (size_t)x * sizeof(T)); }
+    uchar* ptr(int y = 0) { return data + (size_t)y * step; }
+    const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
     template <typename T> const T* ptr(int y = 0) const { return (const T*)(data + (size_t)y * step); }
     void locateROI(Size& whole, Point& ofs) const

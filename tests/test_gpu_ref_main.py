@@ -1,0 +1,89 @@
+"""The REFERENCE's own driver on the MI355X library: /root/reference/app/larvioMain.cpp, compiled where it lies and unmodified
+(oracle/Makefile, target `ref` -> oracle/_ref/larvio_ref_main), against the drop-in classes of adapter/ - its main() constructs
+larvio::ImageProcessor / larvio::LarVio from the configuration file, reads the ASL directory with the reference's own readers
+(include/utils/DataReader.hpp), decodes every image (cv::imread = the PNG reader of examples/), runs processImage / processFeatures
+and, after every odometry update, getTbw / getSwPoses / both map-point getters / getVisualImg, exactly as the reference ships it.
+What stands in on the driver's side is listed in oracle/ref_shim5/: a headless pangolin that writes the pose handed to Follow()
+(larvioMain.cpp:122-133) to a file, and the stand-in cv::Mat / Eigen headers the reference's src/*.cpp compile against here.
+The test: the binary runs to the end on the synthetic ASL sequence and the poses it drew are, double for double, the ones
+adapter/adapter_main (the same loop written against the adapter's minimal stubs, run on the GPU since round 3) logs.
+The binary cannot be built on the GPU box (no /root/reference there): it travels prebuilt, and the test skips without it.
+FIRST GPU EXECUTION of this test is the driver's round-end run (written after the round's GPU minutes were spent); on this
+container the binary was run up to the point where the library refuses to start without a gfx950 device."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_main")
+
+
+def write_sequence(d, n_frames):
+    """the synthetic sequence of tests/test_gpu_vio_driver.py's driver test as an ASL directory (PNG files, CRLF csv, OpenCV-style YAML)"""
+    sys.path.insert(0, os.path.join(ROOT, "examples")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_euroc_dir import write_euroc_dir
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    from tests.test_gpu_vio_driver import TUMVI_LIKE
+    cam = dict(TUMVI_LIKE); cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
+    frames = synth_frames(0, n_frames, cam=cam)
+    seq = S.imu_only_sequence(cam=cam)
+    ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    fcfg = S.frontend_config(cam=cam, max_features_num=300, min_distance=15)
+    bcfg = S.backend_config(cam=cam, sw_size=12, if_zupt_valid=1)
+    os.makedirs(os.path.join(d, "logs"))
+    write_euroc_dir(d, frames, imu_all, fcfg, bcfg, output_dir=os.path.join(d, "logs") + "/")
+    return [d + "/mav0/imu0/data.csv", d + "/mav0/cam0/data.csv", d + "/mav0/cam0/data", d + "/config.yaml"]
+
+
+def test_the_binary_is_the_references_main_on_the_adapter():
+    """CPU side (also runs here): the prebuilt driver needs nothing but liblvk_hip.so, zlib and the C++ runtime - no oracle library - and
+    without a gfx950 device it stops where the reference's main() stops when initialize() fails (larvioMain.cpp:44-47), not in a fallback"""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/larvio_ref_main not built (needs /root/reference: make -C oracle ref)")
+    needed = subprocess.run(["readelf", "-d", BIN], capture_output=True, text=True).stdout
+    assert "liblvk_hip.so" in needed and "liblvo" not in needed and "lvref" not in needed
+    import torch
+    if torch.cuda.is_available():
+        return
+    d = tempfile.mkdtemp(prefix="lv", dir="/tmp")
+    try:
+        args = write_sequence(d, 4)
+        r = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=120)
+        out = r.stdout + r.stderr
+        assert r.returncode == 1 and "Image Processer initialization failed!" in out and "no CPU fallback" in out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_the_references_main_runs_on_the_library():
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/larvio_ref_main not built (needs /root/reference: make -C oracle ref)")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "adapter"), "-s"])
+    d = tempfile.mkdtemp(prefix="lv", dir="/tmp")            # larvioMain.cpp:90-93 builds the image path in a 100-byte buffer: keep it short
+    try:
+        args = write_sequence(d, 64)
+        assert len(args[2]) + 1 + len("1403636579763555584.png") < 99
+        tum = os.path.join(d, "adapter.txt"); poses = os.path.join(d, "poses.txt")
+        ra = subprocess.run([os.path.join(ROOT, "adapter", "adapter_main")] + args + ["--tum", tum], capture_output=True, text=True, timeout=300)
+        assert ra.returncode == 0, ra.stdout + ra.stderr
+        rm = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, LVREF_MAIN_POSES=poses))
+        assert rm.returncode == 0, rm.stdout + rm.stderr
+        assert "Totally" in rm.stdout and "SLAM points" in rm.stdout            # the driver's own last line (larvioMain.cpp:176)
+        ad = np.loadtxt(tum, ndmin=2); M = np.loadtxt(poses, ndmin=2)
+        assert len(ad) >= 15 and M.shape == (len(ad), 16)
+        assert np.array_equal(M[:, 12:15], ad[:, 1:4])                          # OpenGlMatrix is column-major: m[12..14] = translation
+        R = M[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3, 3)                # columns of R_w_b
+        assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < 1e-12 and np.all(M[:, 15] == 1.0) and np.all(M[:, [3, 7, 11]] == 0.0)
+        # the same number of stable map points handed out over the run
+        n_stable = int(rm.stdout.split("Totally")[1].split()[0])
+        assert f"stable map points handed out {n_stable} " in ra.stdout
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
