@@ -3,7 +3,8 @@
  * a plain-C restatement of /root/reference/src/larvio.cpp:859-981 (MSCKF Jacobians + nullspace),
  * :1117-1244 (1-D inverse-depth Jacobian), :1430-1460,1578-1594 (compression + update),
  * :1865-1880 (gate) and include/larvio/feature.hpp:252-552 (LM triangulation).
- * PARITY UNPINNED against the reference (see lvo.h).
+ * PINNED to the reference compiled in place (lvo.h, "PINNING"): src/larvio.cpp's filter after every update
+ * (tests/test_oracle_ref_larvio.py) and include/larvio/feature.hpp's triangulation (tests/test_oracle_ref_feature.py).
  */
 #include "lvo.h"
 #include "be_math.h"

@@ -7,7 +7,11 @@
  * checkZUPT / measurementUpdate_ZUPT_vpq :2751-2962, updateFeatureCov_1didp :3125-3293, rmLostFeaturesCov
  * :3296-3348, updateGridMap :3351-3370, getNewAnchorId :3412-3472, calPhi :3475-3530 (calib_imu = 0 part) and
  * src/StaticInitializer.cpp:12-163.  feature_idp_dim = 1, use_schmidt = 0, calib_imu = 0 (LEG_DIM 22).
- * PARITY UNPINNED against the reference (see lvo.h).
+ * PINNED to the reference compiled in place (lvo.h, "PINNING"): LarVio::processFeatures itself, state / covariance /
+ * clones / map after every call on simulated and tracker-made streams, 330 random configurations, a fixture written
+ * by the reference (tests/test_oracle_ref_larvio.py), and the reference's whole program on files
+ * (tests/test_oracle_ref_main.py).  Two deviations are the reference's own: sw_size 5, and the
+ * grid cells of features beyond the image bounds (reference_grid = 0 keeps the older bookkeeping, 1 follows the reference).
  */
 #include "lvo.h"
 #include "be_math.h"

@@ -8,7 +8,9 @@ initialiser in numpy / scipy, the checker for larvio_amd/csrc/be_init.h (row N4 
     initial_sfm.cpp                  GlobalSFM::construct: PnP / triangulation chain + bundle adjustment
     initial_alignment.cpp            solveGyroscopeBias, LinearAlignment, RefineGravity
 
-PARITY UNPINNED against the reference (it cannot be built here, and it takes its minimisers from OpenCV and Ceres).  This file is
+PINNED, as far as the reference's own text goes, to the reference compiled in place (oracle/_ref/liblvref_dyninit.so: DynamicInitializer.cpp,
+initial_sfm.cpp, solve_5pts.cpp, initial_alignment.cpp, feature_manager.cpp; tests/test_oracle_ref_dyninit.py) - its orchestration, with
+OpenCV's and Ceres' minimisers replaced by stand-ins that find the same minima; beyond the minimisers' tolerances nothing is pinned.  This file is
 independent of be_init.h where independence is possible: library SVD / least squares (numpy.linalg, scipy.optimize.least_squares with a
 rotation-vector parametrisation) instead of the product's hand-written Jacobi SVD, Levenberg-Marquardt PnP and Schur-complement bundle
 adjustment; the bookkeeping (which samples, which frames, which gauge) is restated from the same reference lines.  Both minimise the same

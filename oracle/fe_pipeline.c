@@ -3,7 +3,8 @@
  * a plain-C restatement of /root/reference/src/image_processor.cpp:130-219 and the functions it
  * calls (initializeFirstFrame :337, initializeFirstFeatures :355, trackFeatures :540,
  * trackNewFeatures :813, findNewFeaturesToBeTracked :1005, getFeatureMsg :1076, publish :1131).
- * PARITY UNPINNED against the reference (see lvo.h).
+ * The ORCHESTRATION is PINNED to src/image_processor.cpp compiled in place (byte for byte after every frame,
+ * tests/test_oracle_ref_imgproc.py; 200 fuzzed streams); the image algorithms it calls are not (lvo.h, "PINNING").
  */
 #include "lvo.h"
 #include <math.h>

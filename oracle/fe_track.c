@@ -1,7 +1,9 @@
 /*
  * fe_track.c — ORACLE (test infrastructure, see lvo.h): per-point stages of the front-end:
  * pyramidal LK, ORB angle/descriptor/Hamming, undistortion, fundamental-matrix RANSAC/LMedS,
- * gyro-predicted homography.  PARITY UNPINNED against the reference (see lvo.h).
+ * gyro-predicted homography.  The ORB block is PINNED to src/ORBDescriptor.cpp compiled in place
+ * (tests/test_oracle_ref_orb.py); LK / findFundamentalMat restate OpenCV's published algorithms and stay
+ * PARITY UNPINNED against reference outputs (OpenCV is not vendored; see lvo.h, "PINNING").
  */
 #include "lvo.h"
 #include <math.h>

@@ -1,5 +1,5 @@
-"""Generates tests/golden/*.npz from the CPU oracle (the reference itself cannot run in this environment and has no
-fixtures of its own: SURVEY.md §8c "parity unpinned").  The fixtures freeze the oracle's arithmetic so that any later
+"""Generates tests/golden/*.npz from the CPU oracle (the reference has no fixtures of its own; the fixtures written by
+the reference compiled in place are the ref_*.npz files, made by make_ref_*.py).  The fixtures freeze the oracle's arithmetic so that any later
 edit that changes a byte is caught by tests/test_oracle_frontend.py::test_golden_fixtures and by the GPU parity tests.
 Run from the repo root:  python tests/golden/make_golden.py"""
 import os

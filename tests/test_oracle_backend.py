@@ -1,6 +1,7 @@
 """Pins the back-end oracle (oracle/be_*.c) against an INDEPENDENT numpy/scipy float64 implementation of the same
 algebra (SVD null space, dense QR, literal K = P H^T S^-1, (I-KH)P) and against closed-form properties.  The reference's
-own implementation (Eigen + SPQR) cannot be built here and ships no vectors: parity unpinned."""
+own implementation ships no vectors; since round 5 it is compiled in place against stand-in headers and the oracle is
+held to it directly (tests/test_oracle_ref_larvio.py) - these tests remain the independent-algebra pins."""
 import numpy as np
 import pytest
 import scipy.linalg as sla

@@ -1,0 +1,75 @@
+"""The oracle's whole loop against the REFERENCE'S WHOLE PROGRAM: /root/reference/app/larvioMain.cpp with every src/*.cpp of the
+reference, compiled where they lie (oracle/Makefile, target `ref` -> oracle/_ref/larvio_ref_full) - main(), the dataset readers, the
+ImageProcessor, the LarVio filter with its static AND moving-start initialisers, linked into one executable that reads an ASL
+directory and a configuration file like the shipped binary does.  Not the reference's: OpenCV's image algorithms (served by the
+oracle's restatements, oracle/ref_shim3/ - for those this run says nothing new), cv::imread (the PNG reader of examples/), Eigen /
+Ceres / boost (the stand-ins of oracle/ref_shim2/, ref_shim4/), and a headless pangolin that logs the pose main() hands to the viewer
+after every odometry update (oracle/ref_shim5/pangolin/pangolin.h).  What this adds to the per-class pins: the two classes as main()
+wires them - one IMU buffer shared by both (the filter erases, the front-end only reads), the 0.05 s look-ahead on the reader's
+stamps, features handed over by pointer - on files, from image bytes to poses."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import lvo, lvo_be
+from tests.test_gpu_ref_main import write_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_full")
+
+
+def run_binary(binary, args, d, name):
+    poses = os.path.join(d, name)
+    r = subprocess.run([binary] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, LVREF_MAIN_POSES=poses))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Totally" in r.stdout
+    return np.loadtxt(poses, ndmin=2), r.stdout
+
+
+def oracle_loop(args, fcfg, bcfg, frames):
+    """larvioMain.cpp:84-117 with the oracle's two classes, on the stamps the reference's readers deliver (1e-9 * integer ns)"""
+    t_img = [1e-9 * int(l.split(",")[0]) for l in open(args[1]).read().splitlines()[1:] if l.strip()]
+    raw = np.loadtxt(args[0], delimiter=",", skiprows=1)
+    imu = np.zeros(len(raw), lvo.IMU)
+    imu["t"] = 1e-9 * raw[:, 0]; imu["gyro"] = raw[:, 1:4]; imu["acc"] = raw[:, 4:7]
+    fe = lvo.Frontend(fcfg); be = lvo_be.Ekf(dict(bcfg, reference_grid=1))
+    lo = 0; rows = []
+    for t, (_, img) in zip(t_img, frames):
+        hi = int(np.count_nonzero(imu["t"] - float(t) < 0.05))
+        have, m = fe.process(img, float(t), imu[lo:hi])
+        if have:
+            upd, used = be.process(float(t), m, imu[lo:hi]); lo += used
+            if upd:
+                s = be.state(); rows.append(np.concatenate([s["p"], s["q"]]))
+    return np.array(rows)
+
+
+def test_the_references_whole_program_against_the_oracles_loop():
+    if not os.path.exists(FULL):
+        pytest.skip("oracle/_ref/larvio_ref_full not built (needs /root/reference: make -C oracle ref)")
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    from tests.test_gpu_vio_driver import TUMVI_LIKE
+    from scipy.spatial.transform import Rotation
+    d = tempfile.mkdtemp(prefix="lv", dir="/tmp")
+    try:
+        args = write_sequence(d, 64)
+        M, out = run_binary(FULL, args, d, "poses_full.txt")
+        cam = dict(TUMVI_LIKE); cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
+        fcfg = S.frontend_config(cam=cam, max_features_num=300, min_distance=15)
+        bcfg = S.backend_config(cam=cam, sw_size=12, if_zupt_valid=1)
+        orc = oracle_loop(args, fcfg, bcfg, synth_frames(0, 64, cam=cam))
+        assert len(orc) >= 15 and len(M) == len(orc), (len(M), len(orc))
+        dp = np.abs(M[:, 12:15] - orc[:, :3]).max()
+        # getTbw (larvio.cpp:2644-2658): linear() = R_b_w^T ... compared as rotations: the viewer's columns against the oracle's quaternion
+        R_view = M[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3, 3).transpose(0, 2, 1)       # column-major 4 x 4 -> R
+        R_orc = Rotation.from_quat(orc[:, 3:7]).as_matrix()
+        dR = min(np.abs(R_view - R_orc).max(), np.abs(R_view - R_orc.transpose(0, 2, 1)).max())
+        print("the reference's whole program against the oracle's loop: %d poses, position %.2e m, rotation %.2e (%.2f m from the start)" % (len(M), dp, dR, np.linalg.norm(orc[-1, :3])))
+        assert dp < 1e-6 and dR < 1e-6 and np.linalg.norm(orc[-1, :3]) > 0.3
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
