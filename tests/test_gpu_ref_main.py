@@ -24,15 +24,16 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_main")
 FULL = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_full")
 
 
-def write_sequence(d, n_frames):
-    """the synthetic sequence of tests/test_gpu_vio_driver.py's driver test as an ASL directory (PNG files, CRLF csv, OpenCV-style YAML)"""
+def write_sequence(d, n_frames, first=0):
+    """the synthetic sequence of tests/test_gpu_vio_driver.py's driver test as an ASL directory (PNG files, CRLF csv, OpenCV-style YAML);
+    first = 0 starts at rest (static initialiser), first = 70 in the moving part (the moving-start initialiser has to fire)"""
     sys.path.insert(0, os.path.join(ROOT, "examples")); sys.path.insert(0, os.path.join(ROOT, "tools"))
     from make_euroc_dir import write_euroc_dir
     from larvio_amd import synthetic as S
     from tests.conftest import synth_frames
     from tests.test_gpu_vio_driver import TUMVI_LIKE
     cam = dict(TUMVI_LIKE); cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
-    frames = synth_frames(0, n_frames, cam=cam)
+    frames = synth_frames(first, n_frames, cam=cam)
     seq = S.imu_only_sequence(cam=cam)
     ts = [f[0] for f in frames]
     imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
@@ -98,5 +99,35 @@ def test_the_references_main_runs_on_the_library():
         # the driver's own closing line (larvioMain.cpp:176)
         n_stable = int(rm.stdout.split("Totally")[1].split()[0])
         print("the driver's count of stable map points:", n_stable, "| adapter_main:", ra.stdout.strip().splitlines()[-1])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_moving_start_through_the_references_main_against_the_references_whole_program():
+    """BASELINE.json's trajectory clause ("RMSE within 1 mm of the reference") on what can be run here: the same files through the
+    reference's main() twice - on the product, and with the reference's own classes (oracle/_ref/larvio_ref_full, CPU) - from a start in
+    motion: neither side is handed a state, both have to pass through the moving-start initialiser (DynamicInitializer.cpp: window,
+    RANSAC'd relative pose, structure from motion, visual-inertial alignment; the product's is larvio_amd/csrc/be_init.h behind
+    lvk_ekf_process, the reference's runs on stand-in minimisers, oracle/ref_shim4/) and then run 1.5 s of hybrid updates.  Asked: the
+    same number of odometry updates (= the same first successful message) and every position within 1 mm.  Printed: the differences.
+    FIRST GPU EXECUTION is the driver's round-end run; here the reference side was run (34 poses, "Dynamic initialization success !")."""
+    if not (os.path.exists(BIN) and os.path.exists(FULL)):
+        pytest.skip("oracle/_ref/larvio_ref_main / larvio_ref_full not built (need /root/reference: make -C oracle ref)")
+    d = tempfile.mkdtemp(prefix="lv", dir="/tmp")
+    try:
+        args = write_sequence(d, 90, first=70)
+        poses = os.path.join(d, "poses.txt")
+        rm = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, LVREF_MAIN_POSES=poses))
+        assert rm.returncode == 0, rm.stdout[-2000:] + rm.stderr[-2000:]
+        rf = subprocess.run([FULL] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, LVREF_MAIN_POSES=poses + ".full"))
+        assert rf.returncode == 0 and "Dynamic initialization success" in rf.stdout, rf.stdout[-2000:] + rf.stderr[-2000:]
+        M = np.loadtxt(poses, ndmin=2); Mf = np.loadtxt(poses + ".full", ndmin=2)
+        print("moving start: poses product %d, reference %d" % (len(M), len(Mf)))
+        assert len(Mf) >= 20 and M.shape == Mf.shape
+        dp = np.linalg.norm(M[:, 12:15] - Mf[:, 12:15], axis=1)
+        print("moving start, the reference's main() on the product against the reference's whole program: position rms %.2e m, max %.2e m, rotation %.2e over %d poses (%.2f m travelled)"
+              % (np.sqrt(np.mean(dp * dp)), dp.max(), np.abs(M[:, :12] - Mf[:, :12]).max(), len(M), np.linalg.norm(Mf[-1, 12:15] - Mf[0, 12:15])))
+        assert dp.max() < 1e-3
     finally:
         shutil.rmtree(d, ignore_errors=True)

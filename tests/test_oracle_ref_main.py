@@ -17,6 +17,7 @@ import pytest
 
 from oracle import lvo, lvo_be
 from tests.test_gpu_ref_main import write_sequence
+from tests.test_oracle_dynamic_init import replay  # noqa: F401  (the harness fixture)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FULL = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_full")
@@ -73,3 +74,42 @@ def test_the_references_whole_program_against_the_oracles_loop():
         assert dp < 1e-6 and dR < 1e-6 and np.linalg.norm(orc[-1, :3]) > 0.3
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_moving_start_on_tracker_messages_product_host_code_against_the_references_initialiser(replay, tmp_path):
+    """the start tests/test_gpu_ref_main.py's moving-start case goes through, rehearsed on the CPU: the messages the front-end publishes on
+    frames 70.. of the synthetic sequence (the oracle's ImageProcessor = the reference's, byte for byte) handed to the reference's own
+    DynamicInitializer (compiled in place) and to the PRODUCT's initialiser code (larvio_amd/csrc/be_init.h through the replay harness,
+    cv::findFundamentalMat = the RANSAC restatement on both sides).  Asked: success on the same message with the same erase count, and
+    the state the filter is started from to the minimisers' tolerance."""
+    from oracle import lvref
+    if not lvref.dyninit_available():
+        pytest.skip("oracle/_ref/liblvref_dyninit.so not built")
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    from tests.test_gpu_vio_driver import TUMVI_LIKE
+    from tests.test_oracle_dynamic_init import _record, _ang
+    from scipy.spatial.transform import Rotation
+    import json
+    cam = dict(TUMVI_LIKE); cam["T_cam_imu"] = S.EUROC["T_cam_imu"]
+    frames = synth_frames(70, 40, cam=cam)
+    seq = S.imu_only_sequence(cam=cam)
+    ts = [f[0] for f in frames]
+    imu = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    fe = lvo.Frontend(S.frontend_config(cam=cam, max_features_num=300, min_distance=15))
+    msgs = []
+    for t, img in frames:
+        have, m = fe.process(img, t, imu[:int(np.count_nonzero(imu["t"] - t < 0.05))][-60:])
+        if have:
+            msgs.append((t, m))
+    T = np.asarray(cam["T_cam_imu"], float); R_b2c = T[:3, :3]; t_c_b = -R_b2c.T @ T[:3, 3]
+    Rf = lvref.dynamic_init(msgs, imu, R_b2c, t_c_b)
+    assert Rf is not None
+    rec = str(tmp_path / "start.txt"); _record(rec, dict(imu=imu, msgs=msgs), R_b2c, t_c_b)
+    lvo.lib()
+    P = json.loads(subprocess.run([replay, rec, os.path.join(ROOT, "oracle", "liblvo.so")], capture_output=True, text=True, check=True, timeout=300).stdout)
+    d = dict(attitude=_ang(Rotation.from_quat(Rf["q"]).as_matrix(), Rotation.from_quat(P["q"]).as_matrix()),
+             v=float(np.abs(Rf["v"] - np.array(P["v"])).max()), bg=float(np.abs(Rf["bg"] - np.array(P["bg"])).max()))
+    print("tracker-made moving start: first success at message", Rf["message"], "| reference vs product host code", {k: "%.1e" % x for k, x in d.items()})
+    assert Rf["message"] == P["message"] and Rf["state_time"] == P["state_time"] and Rf["erase"] == P["erase"]
+    assert d["attitude"] < 1e-4 and d["v"] < 2e-3 and d["bg"] < 1e-5, d
