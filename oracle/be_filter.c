@@ -234,6 +234,9 @@ void lvo_ekf_set_state(lvo_ekf* e, double t, const double q[4], const double p[3
     e->s_fej_now = e->s;
 }
 
+/* the start as an initialiser leaves it (larvio.cpp:379-386): the last ZUPT is "now", so in-state features wait 5 s (:1974) */
+void lvo_ekf_set_last_zupt_time(lvo_ekf* e, double t) { e->last_zupt_time = t; }
+
 /* ------------------------------------------------------------------------ propagation */
 static void predict_new_state(lvo_ekf* e, double dt, const double* gyro, const double* acc)
 {   /* larvio.cpp:581-649 */

@@ -267,6 +267,8 @@ int lvo_ekf_process(lvo_ekf* e, double ts, const lvo_feature_obs* feats, int n_f
 /* bypass the initializer (tests): IMU state at time t; gyro/acc = last IMU sample (m_gyro_old/m_acc_old) */
 void lvo_ekf_set_state(lvo_ekf* e, double t, const double q[4], const double p[3], const double v[3], const double bg[3], const double ba[3],
                        const double gyro_old[3], const double acc_old[3]);
+/* ... and the last ZUPT time as an initialiser leaves it (= the state time, larvio.cpp:384: in-state features wait 5 s) */
+void lvo_ekf_set_last_zupt_time(lvo_ekf* e, double t);
 /* stage-level views of two first-party formulas for the pins (tests only) */
 int lvo_stage_ekf1d_obs_jacobian(const lvo_clone* k, const lvo_clone* a, const double* p_w, double inv_depth, const double* obs_anchor,
                                  const double* z, double* Hf2, double* Ha12, double* Hx12, double* He12, double* r2);

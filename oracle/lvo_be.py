@@ -173,6 +173,10 @@ class Ekf:
         a = [np.ascontiguousarray(x, np.float64) for x in (q, p, v, bg, ba, gyro_old, acc_old)]
         _lib().lvo_ekf_set_state(self.h, t, *[_p(x) for x in a])
 
+    def set_last_zupt_time(self, t):
+        """the start as an initialiser leaves it (larvio.cpp:384): in-state features wait 5 s from t"""
+        L = _lib(); L.lvo_ekf_set_last_zupt_time.argtypes = [C.c_void_p, C.c_double]; L.lvo_ekf_set_last_zupt_time(self.h, float(t))
+
     @property
     def dim(self):
         return _lib().lvo_ekf_dim(self.h)

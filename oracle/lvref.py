@@ -435,6 +435,9 @@ class RefLarVio:
     def cov(self):
         N = self.dim; P = np.zeros((N, N)); _libl().lvref_larvio_get_cov(self.h, P.ctypes.data); return P
 
+    def set_last_zupt_time(self, t):
+        L = _libl(); L.lvref_larvio_set_last_zupt_time.argtypes = [C.c_void_p, C.c_double]; L.lvref_larvio_set_last_zupt_time(self.h, float(t))
+
     def clones(self):
         o = np.zeros((256, 12)); n = _libl().lvref_larvio_get_clones(self.h, o.ctypes.data, 256)
         return dict(id=o[:n, 0].astype(np.int64), time=o[:n, 1].copy(), q=o[:n, 2:6].copy(), p=o[:n, 6:9].copy(), p_fej=o[:n, 9:12].copy())

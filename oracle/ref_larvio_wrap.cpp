@@ -69,6 +69,9 @@ void lvref_larvio_set_state(void* h, double t, const double* q, const double* p,
     L.state_server.imu_state_FEJ_now = s;
 }
 
+// the start as an initialiser leaves it (larvio.cpp:384: last_ZUPT_time = the state time, so in-state features wait 5 s)
+void lvref_larvio_set_last_zupt_time(void* h, double t) { ((RefVio*)h)->vio->last_ZUPT_time = t; }
+
 // one LarVio::processFeatures call.  feats: n x 9 doubles (id, u, v, u_init, v_init, u_vel, v_vel, u_init_vel, v_init_vel);
 // imu: m x 7 doubles (t, gyro, acc) APPENDED to the driver's buffer (the call erases what it consumes, as in app/larvioMain.cpp).
 // Returns processFeatures' own answer; *n_left = samples left in the buffer.

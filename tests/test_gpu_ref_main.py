@@ -24,7 +24,7 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_main")
 FULL = os.path.join(ROOT, "oracle", "_ref", "larvio_ref_full")
 
 
-def write_sequence(d, n_frames, first=0):
+def write_sequence(d, n_frames, first=0, max_features_num=300):
     """the synthetic sequence of tests/test_gpu_vio_driver.py's driver test as an ASL directory (PNG files, CRLF csv, OpenCV-style YAML);
     first = 0 starts at rest (static initialiser), first = 70 in the moving part (the moving-start initialiser has to fire)"""
     sys.path.insert(0, os.path.join(ROOT, "examples")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -37,7 +37,7 @@ def write_sequence(d, n_frames, first=0):
     seq = S.imu_only_sequence(cam=cam)
     ts = [f[0] for f in frames]
     imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
-    fcfg = S.frontend_config(cam=cam, max_features_num=300, min_distance=15)
+    fcfg = S.frontend_config(cam=cam, max_features_num=max_features_num, min_distance=15)
     bcfg = S.backend_config(cam=cam, sw_size=12, if_zupt_valid=1)
     os.makedirs(os.path.join(d, "logs"))
     write_euroc_dir(d, frames, imu_all, fcfg, bcfg, output_dir=os.path.join(d, "logs") + "/")
