@@ -10,7 +10,7 @@
  * PINNED to the reference compiled in place (lvo.h, "PINNING"): LarVio::processFeatures itself, state / covariance /
  * clones / map after every call on simulated and tracker-made streams, 330 random configurations, a fixture written
  * by the reference (tests/test_oracle_ref_larvio.py), and the reference's whole program on files
- * (tests/test_oracle_ref_main.py).  Two deviations are the reference's own: sw_size 5, and the
+ * (tests/test_oracle_ref_main.py).  Two deviations are the reference's own (PARITY.md section 2): sw_size 5, and the
  * grid cells of features beyond the image bounds (reference_grid = 0 keeps the older bookkeeping, 1 follows the reference).
  */
 #include "lvo.h"

@@ -16,7 +16,7 @@
  * be_filter.c / be_core.c agrees with it after every update (tests/test_oracle_ref_larvio.py,
  * tests/golden/ref_larvio.npz written by the reference); likewise, in smaller pieces, the ORB
  * descriptor, the triangulation, the static initialiser, the moving-start initialiser's window
- * bookkeeping, pre-integration and alignment.
+ * bookkeeping, pre-integration and alignment (PARITY.md).
  * FRONT-END: the ORCHESTRATION in fe_pipeline.c is PINNED to src/image_processor.cpp compiled in
  * place (ImageProcessor::processImage, byte for byte after every frame: tests/
  * test_oracle_ref_imgproc.py), and the ORB block to src/ORBDescriptor.cpp; the IMAGE ALGORITHMS

@@ -87,7 +87,7 @@ def test_the_references_main_runs_on_the_library():
         # ... and against the REFERENCE'S WHOLE PROGRAM on the same files: the same main() with the reference's own classes (every src/*.cpp
         # compiled in place, oracle/_ref/larvio_ref_full; CPU; tests/test_oracle_ref_main.py holds the oracle's loop to it at 6e-11 m).
         # From image bytes to the poses the viewer gets: the product within 1e-6 m / 1e-6 of the reference (measured between the oracle
-        # and either side on this sequence: 6e-11 / 7e-11 m).  Both grid bookkeepings give this trajectory.
+        # and either side on this sequence: 6e-11 / 7e-11 m).  Both grid bookkeepings (PARITY.md section 2) give this trajectory.
         if os.path.exists(FULL):
             rf = subprocess.run([FULL] + args, capture_output=True, text=True, timeout=600, env=dict(os.environ, LVREF_MAIN_POSES=poses + ".full"))
             assert rf.returncode == 0, rf.stdout[-2000:] + rf.stderr[-2000:]

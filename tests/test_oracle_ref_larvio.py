@@ -263,7 +263,7 @@ def test_whole_loop_on_tracker_messages_from_rest(tmp_path):
 
 
 def test_the_references_own_3d_inverse_depth_mode_is_overconfident(tmp_path):
-    """why `feature_idp_dim 3` is not a parity target: the reference's own 3-D path, run here, on the streams its
+    """why `feature_idp_dim 3` is not a parity target (PARITY.md section 2): the reference's own 3-D path, run here, on the streams its
     1-D path handles conservatively.  Position NEES (3 = consistent) over 4 Monte-Carlo runs of 60 updates, 10-clone window (re-anchoring
     every few updates): 1-D 0.3, 3-D above 3 - `updateFeatureCov_3didp` builds its re-anchoring Jacobian from the OLD anchor on both
     sides (larvio.cpp:2998, 3058) and the delayed initialisation hands a triangular 3x3 block to LDLT (:1665-1666).  No shipped
