@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from oracle import lvo, lvo_be
-from tests.test_gpu_ref_main import write_sequence
+from tests.test_gpu_zzz_ref_main import write_sequence
 from tests.test_oracle_dynamic_init import replay  # noqa: F401  (the harness fixture)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -77,7 +77,7 @@ def test_the_references_whole_program_against_the_oracles_loop():
 
 
 def test_moving_start_on_tracker_messages_product_host_code_against_the_references_initialiser(replay, tmp_path):
-    """the start tests/test_gpu_ref_main.py's moving-start case goes through, rehearsed on the CPU: the messages the front-end publishes on
+    """the start tests/test_gpu_zzz_ref_main.py's moving-start case goes through, rehearsed on the CPU: the messages the front-end publishes on
     frames 70.. of the synthetic sequence (the oracle's ImageProcessor = the reference's, byte for byte) handed to the reference's own
     DynamicInitializer (compiled in place) and to the PRODUCT's initialiser code (larvio_amd/csrc/be_init.h through the replay harness,
     cv::findFundamentalMat = the RANSAC restatement on both sides).  Asked: success on the same message with the same erase count, and
@@ -170,7 +170,7 @@ def test_moving_start_the_references_whole_program_against_the_oracles_loop():
     """the same, from a start in motion: nothing handed in, the reference's program has to come through its DynamicInitializer ("Dynamic
     initialization success !") and then runs 3.4 s of updates.  Against it: the oracle's front-end and filter with (a) the reference's own
     initialiser compiled in place - which leaves the filter's flow after a moving start as the only thing compared (2e-10 m measured; 3e-10 at the
-    300-track budget of tests/test_gpu_ref_main.py's case) - and (b) the oracle's initialiser oracle/dyn_init.py, scipy's minimisers against the
+    300-track budget of tests/test_gpu_zzz_ref_main.py's case) - and (b) the oracle's initialiser oracle/dyn_init.py, scipy's minimisers against the
     stand-in Ceres / solvePnP (measured 2e-6 m at 300 tracks)."""
     from oracle import lvref, dyn_init as D
     if not (os.path.exists(FULL) and lvref.dyninit_available()):
