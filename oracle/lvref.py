@@ -399,6 +399,29 @@ class RefLarVio:
             raise RuntimeError("the reference's LarVio::initialize() failed on " + self._yaml)
         self._held = 0                      # samples of the caller's view that already sit in the wrapper's buffer
 
+    @classmethod
+    def from_yaml(cls, path):
+        """LarVio(config_file) + initialize() on a configuration file as it is (e.g. the reference's own config/euroc.yaml; its output_dir
+        must exist: the reference opens two log files there)"""
+        self = cls.__new__(cls); self._yaml = path; self._held = 0
+        self.h = _libl().lvref_larvio_create(path.encode())
+        if not self.h:
+            raise RuntimeError("the reference's LarVio::initialize() failed on " + path)
+        return self
+
+    PARAMS = ("if_fej estimate_extrin estimate_td if_zupt_valid sw_size max_track_len least_observation_number max_features_in_one_grid aug_grid_rows aug_grid_cols "
+              "pub_frequency imu_rate width height fx fy cx cy td noise_gyro noise_acc noise_gyro_bias noise_acc_bias noise_feature initial_covariance_orientation "
+              "initial_covariance_velocity initial_covariance_position initial_covariance_gyro_bias initial_covariance_acc_bias initial_covariance_extrin_rot "
+              "initial_covariance_extrin_trans rotation_threshold translation_threshold tracking_rate_threshold feature_translation_threshold zupt_max_feature_dis "
+              "zupt_noise_v zupt_noise_p zupt_noise_q static_duration feature_idp_dim use_schmidt calib_imu_instrinsic").split()
+
+    def params(self):
+        """what LarVio::loadParameters (larvio.cpp:58-311) made of the file, by lvk_ekf_config's field names (+ R_imu_cam0 3x3, t_cam0_imu)"""
+        L = _libl(); L.lvref_larvio_params.argtypes = [C.c_void_p, C.c_void_p]
+        o = np.zeros(55); L.lvref_larvio_params(self.h, o.ctypes.data)
+        d = dict(zip(self.PARAMS, o[:43].tolist())); d["R_imu_cam0"] = o[43:52].reshape(3, 3).copy(); d["t_cam0_imu"] = o[52:55].copy()
+        return d
+
     def __del__(self):
         if getattr(self, "h", None):
             _libl().lvref_larvio_destroy(self.h); self.h = None
@@ -526,6 +549,26 @@ class RefImageProcessor:
     """larvio::ImageProcessor (src/image_processor.cpp) of the compiled reference, driven like the oracle's lvo.Frontend:
     process(img, ts, imu) -> (have, message as lvo.OBS records).  Behind cv::'s image algorithms stand the oracle's restatements (see
     oracle/ref_shim3/lvref_cv3.hpp): this object pins the ORCHESTRATION to the reference's text."""
+
+    @classmethod
+    def from_yaml(cls, path, cap=4096):
+        """ImageProcessor(config_file) + initialize() on a configuration file as it is (e.g. the reference's own config/euroc.yaml)"""
+        from . import lvo
+        self = cls.__new__(cls); self._lvo = lvo; lvo.lib(); self._yaml = path; self.cap = cap
+        self.h = _libip().lvref_imgproc_create(path.encode())
+        if not self.h:
+            raise RuntimeError("the reference's ImageProcessor::initialize() failed on " + path)
+        return self
+
+    FE_PARAMS = "width height pyramid_levels patch_size max_iteration track_precision max_features_num min_distance flag_equalize pub_frequency distortion_model".split()
+
+    def params(self):
+        """what ImageProcessor::loadParameters (image_processor.cpp:44-113) made of the file, by lvk_fe_config's field names"""
+        L = _libip(); L.lvref_imgproc_params.argtypes = [C.c_void_p, C.c_void_p]
+        o = np.zeros(30); L.lvref_imgproc_params(self.h, o.ctypes.data)
+        d = dict(zip(self.FE_PARAMS, o[:11].tolist()))
+        d.update(intrinsics=o[11:15].copy(), distortion=o[15:19].copy(), R_cam_imu=o[19:28].reshape(3, 3).copy(), ransac_threshold=float(o[28]), img_rate=float(o[29]))
+        return d
 
     def __init__(self, cfg, workdir):
         from . import lvo

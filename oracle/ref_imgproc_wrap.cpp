@@ -33,6 +33,21 @@ void* lvref_imgproc_create(const char* yaml_path)
     if (!r->ip->initialize()) { delete r->ip; delete r; return nullptr; }
     return r;
 }
+// what ImageProcessor::loadParameters (image_processor.cpp:44-113) made of the configuration file, in lvk_fe_config's terms:
+// 0 width 1 height 2 pyramid_levels 3 patch_size 4 max_iteration 5 track_precision 6 max_features_num 7 min_distance 8 flag_equalize
+// 9 pub_frequency 10 distortion_model (0 radtan, 1 equidistant, -1 other) 11-14 intrinsics 15-18 distortion 19-27 R_cam_imu (row-major)
+// 28 ransac_threshold 29 img_rate
+void lvref_imgproc_params(void* h, double* o)
+{
+    ImageProcessor& I = *((RefFe*)h)->ip;
+    o[0] = I.cam_resolution[0]; o[1] = I.cam_resolution[1]; o[2] = I.processor_config.pyramid_levels; o[3] = I.processor_config.patch_size;
+    o[4] = I.processor_config.max_iteration; o[5] = I.processor_config.track_precision; o[6] = I.processor_config.max_features_num;
+    o[7] = I.processor_config.min_distance; o[8] = I.processor_config.flag_equalize ? 1 : 0; o[9] = I.processor_config.pub_frequency;
+    o[10] = I.cam_distortion_model == "radtan" ? 0 : I.cam_distortion_model == "equidistant" ? 1 : -1;
+    for (int k = 0; k < 4; ++k) { o[11 + k] = I.cam_intrinsics[k]; o[15 + k] = I.cam_distortion_coeffs[k]; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[19 + 3 * i + j] = I.R_cam_imu(i, j);
+    o[28] = I.processor_config.ransac_threshold; o[29] = I.processor_config.img_rate;
+}
 void lvref_imgproc_destroy(void* h) { RefFe* r = (RefFe*)h; if (r) { delete r->ip; delete r; } }
 
 // one ImageProcessor::processImage call.  img: h x w bytes (stride bytes per row); imu: m x 7 doubles (t, gyro, acc) = the driver's

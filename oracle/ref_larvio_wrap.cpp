@@ -15,6 +15,7 @@
 #include <iostream>
 #include <sstream>
 #include <cstring>
+#include <cmath>
 #include "lvref_eigen2.hpp"
 #include <boost/shared_ptr.hpp>
 #define private public
@@ -161,6 +162,28 @@ int lvref_larvio_map(void* h, long long* ids, int* n_obs, int* flags, int cap)
     LarVio& L = *((RefVio*)h)->vio; int n = 0;
     for (const auto& kv : L.map_server) { if (n >= cap) break; ids[n] = (long long)kv.first; n_obs[n] = (int)kv.second.observations.size(); flags[n] = (kv.second.is_initialized ? 1 : 0) | (kv.second.in_state ? 2 : 0) | (kv.second.ekf_feature ? 4 : 0); ++n; }
     return n;
+}
+// what LarVio::loadParameters (larvio.cpp:58-311) made of the configuration file, in lvk_ekf_config's terms (noises as standard
+// deviations: the reference squares them on loading; initial covariances read back from the diagonal it fills):
+// 0 if_FEJ 1 estimate_extrin 2 estimate_td 3 if_ZUPT_valid 4 sw_size 5 max_track_len 6 least_observation_number 7 max_features_in_one_grid
+// 8 aug_grid_rows 9 aug_grid_cols 10 pub_frequency 11 imu_rate 12 width 13 height 14-17 intrinsics 18 td 19-23 noise gyro / acc / gyro bias /
+// acc bias / feature 24-30 initial covariance orientation / velocity / position / gyro bias / acc bias / extrinsic rotation / translation
+// 31-33 rotation / translation / tracking-rate threshold 34 feature_translation_threshold 35 zupt_max_feature_dis 36-38 zupt noise v / p / q
+// 39 static_duration 40 feature_idp_dim 41 use_schmidt 42 calib_imu 43-51 R_imu_cam0 (row-major) 52-54 t_cam0_imu
+void lvref_larvio_params(void* h, double* o)
+{
+    LarVio& L = *((RefVio*)h)->vio; const Eigen::MatrixXd& P = L.state_server.state_cov;
+    o[0] = L.if_FEJ_config; o[1] = L.estimate_extrin; o[2] = L.estimate_td; o[3] = L.if_ZUPT_valid; o[4] = L.sw_size; o[5] = L.max_track_len;
+    o[6] = L.least_Obs_Num; o[7] = L.max_features; o[8] = L.grid_rows; o[9] = L.grid_cols; o[10] = L.features_rate; o[11] = L.imu_rate;
+    o[12] = L.cam_resolution[0]; o[13] = L.cam_resolution[1]; for (int k = 0; k < 4; ++k) o[14 + k] = L.cam_intrinsics[k];
+    o[18] = L.td_input;
+    o[19] = std::sqrt(L.imu_gyro_noise); o[20] = std::sqrt(L.imu_acc_noise); o[21] = std::sqrt(L.imu_gyro_bias_noise); o[22] = std::sqrt(L.imu_acc_bias_noise);
+    o[23] = std::sqrt(L.feature_observation_noise);
+    o[24] = P(0, 0); o[25] = P(3, 3); o[26] = P(6, 6); o[27] = P(9, 9); o[28] = P(12, 12); o[29] = P(15, 15); o[30] = P(18, 18);
+    o[31] = L.rotation_threshold; o[32] = L.translation_threshold; o[33] = L.tracking_rate_threshold; o[34] = Feature::optimization_config.translation_threshold;
+    o[35] = L.zupt_max_feature_dis; o[36] = std::sqrt(L.zupt_noise_v); o[37] = std::sqrt(L.zupt_noise_p); o[38] = std::sqrt(L.zupt_noise_q);
+    o[39] = L.Static_Duration; o[40] = L.feature_idp_dim; o[41] = L.use_schmidt; o[42] = L.calib_imu;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[43 + 3 * i + j] = L.state_server.imu_state.R_imu_cam0(i, j); o[52 + i] = L.state_server.imu_state.t_cam0_imu(i); }
 }
 int lvref_larvio_map_size(void* h) { return (int)((RefVio*)h)->vio->map_server.size(); }
 double lvref_larvio_chi2(void* h, int dof) { return ((RefVio*)h)->vio->chi_squared_test_table[dof]; }

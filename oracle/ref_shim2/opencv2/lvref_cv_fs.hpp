@@ -55,7 +55,10 @@ public:
     {
         std::ifstream f(path); if (!f) return false;
         std::vector<std::string> lines; std::string l;
-        while (std::getline(f, l)) { const size_t h = l.find('#'); if (h != std::string::npos && l.find('"') == std::string::npos) l = l.substr(0, h); lines.push_back(l); }
+        while (std::getline(f, l)) {      // a '#' outside quotes starts a comment
+            char q = 0; for (size_t k = 0; k < l.size(); ++k) { if (q) { if (l[k] == q) q = 0; } else if (l[k] == '"' || l[k] == '\'') q = l[k]; else if (l[k] == '#') { l = l.substr(0, k); break; } }
+            lines.push_back(l);
+        }
         std::string parent;                                                   // the open nested map / matrix node, "" at top level
         for (size_t i = 0; i < lines.size(); ++i) {
             const std::string& raw = lines[i];
