@@ -225,3 +225,27 @@ def test_headline_shape_with_in_state_features_the_references_whole_program_agai
         assert 1e-4 < res[0][0] < 5e-2          # the known deviation of the older bookkeeping, of this size
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_the_shipped_configuration_file_end_to_end():
+    """config/euroc.yaml as the reference ships it (read where it lies: this test needs /root/reference; only output_dir is pointed at a
+    directory that exists): the reference's whole program reads it with its own loadParameters, the oracle's loop is configured by the
+    product's loader (larvio_amd/config.py, the twin of include/lvk_config.hpp - held equal field by field in tests/test_oracle_ref_config.py)."""
+    import re
+    cfg_src = "/root/reference/config/euroc.yaml"
+    if not (os.path.exists(FULL) and os.path.exists(cfg_src)):
+        pytest.skip("needs /root/reference and oracle/_ref/larvio_ref_full")
+    from larvio_amd.config import load_config
+    d = tempfile.mkdtemp(prefix="lv", dir="/tmp")
+    try:
+        args, _, _, frames = write_headline_sequence(d, 140)
+        open(args[3], "w").write(re.sub(r'output_dir:\s*"[^"]*"', 'output_dir: "%s/logs/"' % d, open(cfg_src).read()))
+        fcfg, bcfg = load_config(args[3])[:2]
+        M, out = run_binary(FULL, args, d, "poses_full.txt")
+        orc = oracle_loop(args, fcfg, bcfg, frames)
+        assert len(M) == len(orc) >= 40
+        dp = np.abs(M[:, 12:15] - orc[:, :3]).max()
+        print("config/euroc.yaml end to end: %d poses, position %.2e m" % (len(M), dp))
+        assert dp < 1e-8
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
