@@ -1,10 +1,11 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY (see oracle/lvo.h).  C entry points around the REFERENCE's own filter - /root/reference/src/larvio.cpp,
 // src/FlexibleInitializer.cpp, src/StaticInitializer.cpp and src/feature_manager.cpp are compiled where they lie (oracle/Makefile, target
 // `ref` -> oracle/_ref/liblvref_larvio.so; never copied) against the stand-in headers of oracle/ref_shim2/ (Eigen, OpenCV's FileStorage,
-// boost's chi-squared quantile and shared_ptr, the Ceres names initial_sfm.h mentions).  What is NOT the reference's: the moving-start
-// initialiser's body (DynamicInitializer.cpp needs OpenCV proper and Ceres through solve_5pts.cpp / initial_sfm.cpp) - its two entry
-// points are defined below as "never succeeds", so a stream must start at rest (the reference's StaticInitializer fires) or from a
-// state handed in through lvref_larvio_set_state.  Used by oracle/lvref.py (RefLarVio) to hold the oracle's filter, update by update,
+// boost's chi-squared quantile and shared_ptr, the Ceres names initial_sfm.h mentions).  What is NOT in THIS library: the moving-start
+// initialiser's body (DynamicInitializer.cpp with solve_5pts.cpp / initial_sfm.cpp is compiled against the other stand-ins of
+// oracle/ref_shim4/ - into liblvref_dyninit.so, and together with these sources into the whole program _ref/larvio_ref_full) - its two
+// entry points are defined below as "never succeeds", so a stream must start at rest (the reference's StaticInitializer fires) or from
+// a state handed in through lvref_larvio_set_state (+ lvref_larvio_set_last_zupt_time for the start as an initialiser leaves it).  Used by oracle/lvref.py (RefLarVio) to hold the oracle's filter, update by update,
 // to LarVio::processFeatures itself.
 #include <string>
 #include <vector>
