@@ -1,5 +1,5 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY.  A headless pangolin + OpenGL for the reference's driver (app/larvioMain.cpp:57-78,119-199 and
-// include/visualization/visualize.hpp): every drawing call is a no-op, ShouldQuit() is true (the driver's closing loop runs once), and the
+// include/visualization/visualize.hpp): every drawing call is a no-op, ShouldQuit() is true (the driver's closing loop, larvioMain.cpp:179-199, is skipped), and the
 // one thing a test can look at - the body pose the driver hands to OpenGlRenderState::Follow after every odometry update
 // (larvioMain.cpp:122-133: GetCurrentOpenGLPoseMatrix(Tbw_pgl, Estimator->getTbw()), column-major 4 x 4) - is appended to the file
 // LVREF_MAIN_POSES names: one line per call, 16 numbers with 17 significant digits.
