@@ -373,7 +373,7 @@ def test_zero_baseline_start_is_ill_conditioned_in_the_reference_itself(tmp_path
 
 
 def test_random_configurations(tmp_path):
-    """fourteen of the random configurations the oracle was fuzzed with against the compiled reference (700 of them; four explained exceptions of two kinds - sw_size 5 and zero-baseline starts, below - the rest in agreement,
+    """fourteen of the random configurations the oracle was fuzzed with against the compiled reference (900 of them; four explained exceptions of two kinds - sw_size 5 and zero-baseline starts, below - the rest in agreement,
     worst 7e-8 on a 46-state case with 4000 gated-out features): everything discrete identical after every call, the rest to 1e-6"""
     lvref = _ref()
     total = 0
