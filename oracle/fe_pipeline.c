@@ -4,7 +4,7 @@
  * calls (initializeFirstFrame :337, initializeFirstFeatures :355, trackFeatures :540,
  * trackNewFeatures :813, findNewFeaturesToBeTracked :1005, getFeatureMsg :1076, publish :1131).
  * The ORCHESTRATION is PINNED to src/image_processor.cpp compiled in place (byte for byte after every frame,
- * tests/test_oracle_ref_imgproc.py; 200 fuzzed streams); the image algorithms it calls are not (lvo.h, "PINNING").
+ * tests/test_oracle_ref_imgproc.py; 400 fuzzed streams, one open case: PARITY.md section 2); the image algorithms it calls are not (lvo.h, "PINNING").
  */
 #include "lvo.h"
 #include <math.h>

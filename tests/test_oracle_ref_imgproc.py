@@ -224,8 +224,8 @@ def _random_frames(k):
 
 
 def test_random_configurations(tmp_path):
-    """twelve of the random cases the oracle's front-end object was fuzzed with against the compiled reference (200 of them, every frame of
-    every one byte-identical)"""
+    """twelve of the random cases the oracle's front-end object was fuzzed with against the compiled reference (400 of them: every frame of
+    399 byte-identical; one open case with a 21-px-wide ORB layer, PARITY.md section 2)"""
     lvref = _ref()
     msgs = 0
     for k in range(0, 12):
