@@ -34,7 +34,7 @@ int main(int argc, char** argv)
         BE(initial_covariance_acc_bias); BE(initial_covariance_extrin_rot); BE(initial_covariance_extrin_trans);
         BE(rotation_threshold); BE(translation_threshold); BE(tracking_rate_threshold); BE(feature_translation_threshold);
         BE(zupt_max_feature_dis); BE(zupt_noise_v); BE(zupt_noise_p); BE(zupt_noise_q); BE(static_duration);
-        BE(feature_idp_dim); BE(use_schmidt); BE(calib_imu_instrinsic); BE(max_features);
+        BE(feature_idp_dim); BE(use_schmidt); BE(calib_imu_instrinsic); BE(max_features); BE(legacy_grid); BE(reserved0);
         return 0;
     }
     if (argc >= 4 && !std::strcmp(argv[1], "png")) {

@@ -239,6 +239,12 @@ typedef struct {
     double static_duration;
     int feature_idp_dim, use_schmidt, calib_imu_instrinsic;   /* must be 1, 0, 0|1 (1: LEG_DIM 46, IMU intrinsics in the state) */
     int max_features;                                          /* capacity hint: features per message (0 = 1024) */
+    int legacy_grid;                                           /* 0 (default): grid_map as the reference keeps it - a std::map (larvio.h:383), so a grid code
+                                                                  beyond the rows x cols cells (undistorted coordinates outside the image bounds) gets a cell
+                                                                  of its own that updateGridMap never clears (larvio.cpp:1969-1975, 3351-3370).
+                                                                  1: such codes are not counted (what this library did before round 6; opt-out only,
+                                                                  also LVK_GRID_REFERENCE=0 in the environment) */
+    int reserved0;                                             /* must be 0 */
 } lvk_ekf_config;
 
 /* one sliding-window clone (IMUState_Aug, include/larvio/imu_state.h:72-117) */

@@ -218,12 +218,12 @@ struct lvk_ekf {
     double x_min, y_min, grid_w, grid_h;
     std::vector<int> grid_count;
     // The reference's grid_map is a std::map<int, vector> (larvio.h:383): a feature whose code falls outside the rows x cols cells (undistorted
-    // coordinates beyond the image bounds) gets a cell of its own, which updateGridMap never clears (larvio.cpp:3356-3366) - it only fills up.
-    // Found by running the reference's own filter against the oracle (tests/test_oracle_ref_larvio.py) after the round's GPU budget was spent:
-    // LVK_GRID_REFERENCE=1 selects the reference's bookkeeping; the default (0: such codes are not counted at all, what this library has
-    // always done and what every GPU measurement and parity run of the round used) stays until the switch has been run on a GPU.
+    // coordinates beyond the image bounds) gets a cell of its own, which updateGridMap never clears (larvio.cpp:3356-3366) - it only fills up
+    // and, once it holds max_features_in_one_grid ids, diverts every later feature with that code to the MSCKF branch (:1969-1975).
+    // reference_grid (the default) keeps that bookkeeping; lvk_ekf_config.legacy_grid = 1 or LVK_GRID_REFERENCE=0 selects what this
+    // library did before round 6 (such codes not counted at all) - an opt-out for comparing old records, not the reference's filter.
     std::map<int, int> grid_phantom;
-    bool reference_grid = false;
+    bool reference_grid = true;
     std::vector<double> coarse_dis;
     int static_counter = 0, static_num = 0; double lower_time_bound = 0;
     lvk_status dyn_status = LVK_OK;
@@ -2185,6 +2185,7 @@ lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf**
     else { e->grid_w = x_max - e->x_min; e->grid_h = y_max - e->y_min; }
     e->grid_count.assign((size_t)cells + 1, 0);
     e->grid_phantom.clear();
+    e->reference_grid = c.legacy_grid == 0;
     if (const char* g = getenv("LVK_GRID_REFERENCE")) e->reference_grid = atoi(g) != 0;
     e->static_num = (int)((float)c.static_duration * (double)c.pub_frequency);
     // capacities

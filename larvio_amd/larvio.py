@@ -26,7 +26,8 @@ _CFG_DBL = ["td", "pub_frequency", "imu_rate", "noise_gyro", "noise_acc", "noise
 class EkfConfig(C.Structure):
     _fields_ = ([(k, C.c_int) for k in _CFG_INT] + [("intrinsics", C.c_double * 4), ("T_cam_imu", C.c_double * 16)] +
                 [(k, C.c_double) for k in _CFG_DBL] +
-                [("feature_idp_dim", C.c_int), ("use_schmidt", C.c_int), ("calib_imu_instrinsic", C.c_int), ("max_features", C.c_int)])
+                [("feature_idp_dim", C.c_int), ("use_schmidt", C.c_int), ("calib_imu_instrinsic", C.c_int), ("max_features", C.c_int),
+                 ("legacy_grid", C.c_int), ("reserved0", C.c_int)])
 
 
 _sig_done = False
@@ -181,6 +182,7 @@ def make_ekf_config(config):
     c.T_cam_imu = (C.c_double * 16)(*np.asarray(config["T_cam_imu"], np.float64).reshape(16))
     c.feature_idp_dim = config.get("feature_idp_dim", 1); c.use_schmidt = config.get("use_schmidt", 0)
     c.calib_imu_instrinsic = config.get("calib_imu_instrinsic", 0); c.max_features = config.get("max_features", 0)
+    c.legacy_grid = config.get("legacy_grid", 0)          # 0 = the reference's grid_map bookkeeping (lvk_c.h)
     return c
 
 

@@ -248,12 +248,12 @@ typedef struct {
     double zupt_max_feature_dis, zupt_noise_v, zupt_noise_p, zupt_noise_q;
     double static_duration;
     int calib_imu_instrinsic;           /* 1: online IMU intrinsics (larvio.cpp:127-186), LEG_DIM 46 instead of 22 */
-    int reference_grid;                 /* 1: the reference's own bookkeeping for features whose grid code falls outside the rows x cols cells
-                                           (undistorted coordinates beyond the image bounds): grid_map is a std::map<int, vector>, so such a code
-                                           gets a cell of its own that updateGridMap never clears (larvio.cpp:3356-3366) - it only fills up.
-                                           0 (the default of lvo_be.py): such codes are not counted at all - what this oracle and the product
-                                           did until the reference's filter could be run here, and still the product's default (its switch is
-                                           LVK_GRID_REFERENCE=1) because the finding came after the round's last GPU run */
+    int reference_grid;                 /* 1 (the default of lvo_be.py, and the product's): the reference's own bookkeeping for features whose
+                                           grid code falls outside the rows x cols cells (undistorted coordinates beyond the image bounds):
+                                           grid_map is a std::map<int, vector> (larvio.h:383), so such a code gets a cell of its own that
+                                           updateGridMap never clears (larvio.cpp:3356-3366) - it only fills up (:1969-1975).
+                                           0: such codes are not counted at all - what this oracle and the product did before the reference's
+                                           filter could be run here (the product's opt-out: lvk_ekf_config.legacy_grid / LVK_GRID_REFERENCE=0) */
 } lvo_ekf_config;
 
 typedef struct lvo_ekf lvo_ekf;

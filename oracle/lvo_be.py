@@ -29,7 +29,7 @@ def make_ekf_config(cfg, cls=EkfConfig):
     if hasattr(c, "calib_imu_instrinsic"):
         c.calib_imu_instrinsic = int(cfg.get("calib_imu_instrinsic", 0))
     if hasattr(c, "reference_grid"):
-        c.reference_grid = int(cfg.get("reference_grid", 0))      # see lvo.h: 1 = the reference's cells for out-of-range grid codes (the product's LVK_GRID_REFERENCE=1); 0 = not counted (both defaults)
+        c.reference_grid = int(cfg.get("reference_grid", 1))      # see lvo.h: 1 = the reference's cells for out-of-range grid codes (the default here and in the product); 0 = the pre-round-6 bookkeeping
     c.intrinsics = (C.c_double * 4)(*cfg["intrinsics"])
     c.T_cam_imu = (C.c_double * 16)(*np.asarray(cfg["T_cam_imu"], np.float64).reshape(16))
     return c

@@ -453,18 +453,26 @@ def test_backend_accepts_empty_feature_messages(gpu_ctx):
     assert n_upd >= 25
 
 
-@pytest.mark.xfail(reason="LVK_GRID_REFERENCE=1 (the reference's cells for grid codes beyond the image bounds) was written after the round's last "
-                          "GPU run: this is its first execution on a GPU - XPASS means the switch works and can become the default", strict=False)
-def test_reference_grid_switch_against_the_oracle(gpu_ctx, monkeypatch):
-    """the HIP filter with LVK_GRID_REFERENCE=1 against the oracle with reference_grid = 1 (which agrees with the reference's own filter on
-    this stream: tests/test_oracle_ref_larvio.py::test_features_beyond_the_image_bounds_get_cells_of_their_own) on a moving start whose
-    border features make the two bookkeepings part (100 rendered frames, 200 tracks)"""
+def test_border_features_follow_the_references_grid_map(gpu_ctx, monkeypatch):
+    """grid codes beyond the image bounds (ref larvio.cpp:1969-1975, 3351-3370; larvio.h:383: grid_map is a std::map, such a code gets a
+    cell of its own that never clears).  The HIP filter's DEFAULT against the oracle's default (which agrees with the reference's own
+    filter on this stream: tests/test_oracle_ref_larvio.py::test_features_beyond_the_image_bounds_get_cells_of_their_own) on a moving
+    start whose border features make the old and the reference's bookkeeping part (100 rendered frames, 200 tracks); then the opt-out
+    (LVK_GRID_REFERENCE=0 / reference_grid = 0) on both sides, and the two modes must NOT agree with each other on this stream."""
     from tests.test_oracle_ref_larvio import _tracker_stream
-    monkeypatch.setenv("LVK_GRID_REFERENCE", "1")
+    monkeypatch.delenv("LVK_GRID_REFERENCE", raising=False)
     sim = _tracker_stream(30, 100, 200, 15, sw_size=30, max_features_in_one_grid=1)
 
     class _Seq:
         traj = None
-    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, sim["msgs"], sim["imu"], _Seq, dict(sim["cfg"], reference_grid=1), init_args=sim["init"])
+    hist = {"ref": [], "old": []}
+    n_upd, wx, wP, c, ora = _run_pair(gpu_ctx, sim["msgs"], sim["imu"], _Seq, sim["cfg"], init_args=sim["init"],
+                                      on_update=lambda s_, P_, ids: hist["ref"].append(tuple(int(i) for i in ids)))
     assert n_upd >= 45 and c["hybrid"] >= 40
-    print("reference grid switch: updates", n_upd, "worst rel state", wx, "cov", wP, c)
+    print("reference grid (default): updates", n_upd, "worst rel state", wx, "cov", wP, c)
+    monkeypatch.setenv("LVK_GRID_REFERENCE", "0")
+    n2, wx2, wP2, c2, ora2 = _run_pair(gpu_ctx, sim["msgs"], sim["imu"], _Seq, dict(sim["cfg"], reference_grid=0), init_args=sim["init"],
+                                       on_update=lambda s_, P_, ids: hist["old"].append(tuple(int(i) for i in ids)))
+    print("legacy grid (opt-out): updates", n2, "worst rel state", wx2, "cov", wP2, c2)
+    assert n2 >= 45
+    assert hist["ref"] != hist["old"]                     # the stream does tell the two bookkeepings apart (in-state feature ids differ)

@@ -428,15 +428,13 @@ def _tracker_stream(first, count, max_features_num, min_distance, **bcfg):
 
 
 def test_features_beyond_the_image_bounds_get_cells_of_their_own(tmp_path):
-    """FOUND with the compiled reference, after the round's last GPU run.  `grid_map` is a std::map<int, vector> (larvio.h:383): a feature
-    whose undistorted coordinates lie beyond the image bounds (radtan distortion: a band of 30-40 px along the borders) has a grid code
-    outside the rows x cols cells, and `grid_map[code]` makes a cell for it that updateGridMap never clears (larvio.cpp:3356-3366) - it
-    only fills up, so each such code admits `max_features_in_one_grid` features once and then never again.  The oracle and the product
-    did not count such codes at all (any number of border features could enter the state).  With `reference_grid = 1` the oracle follows
-    the reference (this test, the tracker-message cases of the fuzzing, everything else in this file); the product's switch is
-    LVK_GRID_REFERENCE=1, and its DEFAULT is still the old behaviour - every GPU measurement and parity run of the round used it, and the
-    switch has not run on a GPU.  On this moving start (100 rendered frames, 200 tracks) the old behaviour admits other features than
-    the reference from the first admission on, and the position estimates part by millimetres."""
+    """`grid_map` is a std::map<int, vector> (larvio.h:383): a feature whose undistorted coordinates lie beyond the image bounds (radtan
+    distortion: a band of 30-40 px along the borders) has a grid code outside the rows x cols cells, and `grid_map[code]` makes a cell
+    for it that updateGridMap never clears (larvio.cpp:3356-3366) - it only fills up, so each such code admits
+    `max_features_in_one_grid` features once and then never again.  Found in round 5 with the compiled reference; since round 6 it is
+    the default of the oracle (`reference_grid = 1`) and of the product (`lvk_ekf_config.legacy_grid = 0`).  The bookkeeping of rounds
+    1-5 (such codes not counted: any number of border features could enter the state) remains as an opt-out on both sides; on this
+    moving start (100 rendered frames, 200 tracks) it admits other features than the reference from the first admission on."""
     lvref = _ref()
     sim = _tracker_stream(30, 100, 200, 15, sw_size=30, max_features_in_one_grid=1)
     n, worst, c = run_both(sim, True, lvref, tmp_path / "ref_grid")
