@@ -11,7 +11,7 @@
 #include "fe_track_dev.h"
 
 // =========================================================================== stage-level kernels
-template <int WIN>
+template <int WIN, int VAR>
 __global__ void __launch_bounds__(64) k_lk_track(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ prev_pts,
                                                 lvk_pt2f* __restrict__ next_pts, uint8_t* __restrict__ status, int n,
                                                 int max_count, double epsilon, int* __restrict__ iters)
@@ -21,7 +21,9 @@ __global__ void __launch_bounds__(64) k_lk_track(PyrView prev, PyrView next, con
     const int n_levels = prev.n_levels < next.n_levels ? prev.n_levels : next.n_levels;
     lvk_pt2f np = next_pts[p];
     int st = 1;
-    lk_point<WIN>(prev, next, n_levels, prev_pts[p], np, st, max_count, epsilon, iters ? iters + (size_t)p * n_levels : nullptr);
+    __shared__ __attribute__((aligned(16))) unsigned long long s_acc[4];
+    LkLdsAcc acc = lk_acc_init(s_acc);
+    lk_point<WIN, VAR>(prev, next, n_levels, prev_pts[p], np, st, max_count, epsilon, iters ? iters + (size_t)p * n_levels : nullptr, acc);
     if ((threadIdx.x & 63) == 0) { next_pts[p] = np; status[p] = (uint8_t)st; }
 }
 
@@ -77,7 +79,8 @@ template <int WIN>
 static void launch_lk(lvk_context* ctx, const PyrView& a, const PyrView& b, const lvk_pt2f* pp, lvk_pt2f* np, uint8_t* st, int n,
                       int max_count, double epsilon, int* iters)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lk_track<WIN>), dim3(n), dim3(64), 0, ctx->stream, a, b, pp, np, st, n, max_count, epsilon, iters);
+    if (WIN == 21 && lvk_lk_variant() == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lk_track<WIN, 0>), dim3(n), dim3(64), 0, ctx->stream, a, b, pp, np, st, n, max_count, epsilon, iters);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lk_track<WIN, 1>), dim3(n), dim3(64), 0, ctx->stream, a, b, pp, np, st, n, max_count, epsilon, iters);
 }
 
 extern "C" {

@@ -3,6 +3,8 @@
 #pragma once
 #include "lvk_internal.h"
 #include <float.h>
+#include <limits.h>
+#include "lvk_sincosf.h"
 
 // ------------------------------------------------------------------------- wave reductions
 // integer all-reduce over the wavefront: four DPP row rotations (every lane gets its 16-lane row sum), then the four row
@@ -106,7 +108,7 @@ __device__ __forceinline__ int lk_point_generic(const PyrView& prev, const PyrVi
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if ((double)min_eig < 1e-4 || D < FLT_EPSILON) {
+        if (min_eig < (float)1e-4 || D < FLT_EPSILON) {      // float against float: LKTrackerInvoker keeps minEigThreshold as a float member
             if (level == 0) status = 0;
             if (iters_out && lane == 0) iters_out[level] = 0;
             continue;
@@ -248,7 +250,7 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if ((double)min_eig < 1e-4 || D < FLT_EPSILON) {
+        if (min_eig < (float)1e-4 || D < FLT_EPSILON) {      // float against float: LKTrackerInvoker keeps minEigThreshold as a float member
             if (level == 0) status = 0;
             if (iters_out && lane == 0) iters_out[level] = 0;
             continue;
@@ -301,16 +303,238 @@ __device__ __forceinline__ int lk_point_rs21(const PyrView& prev, const PyrView&
     return total_it;
 }
 
-// LVK_LK_GENERIC (compile-time, A/B builds): the one-pixel-per-lane-slot path for every window size
-template <int WIN>
+// ---- the same row-segment layout with the reductions through LDS (round 6).
+// What an iteration of lk_point_rs21 costs is instruction issue of ONE wavefront (~280 instructions, ~5.8 cycles each), and a third
+// of them are the two exact 64-bit wave sums: 16 DPP adds + 16 v_readlane + the scalar carry chain + two int64 -> float conversions
+// with find-first-bit.  Here: three DPP rotations leave the sum of each aligned group of 8 lanes in the group's last lane (7 pixels x
+// 8 lanes x |diff * Ix| <= 8 * 7 * 8160 * 4080 = 1.86e9 < 2^31: still an exact int32), the eight group leaders add theirs,
+// sign-extended, to a 64-bit LDS accumulator (ds_add_u64) that is NEVER reset - a running total modulo 2^64 whose difference to the
+// previous reading is this reduction's sum, exactly - and every lane reads the accumulators back.  LDS instructions of one wavefront
+// execute in issue order, so the read follows the adds without a barrier.  The int64 -> float conversion goes through double
+// (hi * 2^32 + lo is exact below 2^53, and (float)(double) rounds to nearest-even like (float)(int64)): three instructions.
+// Integer sums in a different order: the same bits.  Second change: the 16 bytes of the next image a lane holds are reloaded only
+// when the window's integer origin moved - after the first step of a level it usually has not (the update is sub-pixel), and the
+// L2 round trip leaves the iteration's dependent chain.
+struct LkLdsAcc {
+    unsigned off;                   // LDS byte address of 4 x u64 owned by this wavefront (3 running totals + pad, 16-byte aligned; zeroed once at kernel start)
+    unsigned long long prev[3];
+};
+__device__ __forceinline__ int lk_group8_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);   // row_ror:1  -> lane l: sum over lanes l-7..l of its row (cyclic)
+    return v;
+}
+// LDS instructions as written.  ds_add_u64: through atomicAdd the compiler's atomic optimiser turns a same-address LDS atomic into a
+// per-active-lane v_readlane loop (8 trips x 21 instructions here) - the very chain this variant removes.  The reads: through a
+// generic pointer they become flat loads with system-scope cache bits.
+__device__ __forceinline__ void lds_add_u64(unsigned off, unsigned long long v)
+{
+    asm volatile("ds_add_u64 %0, %1" :: "v"(off), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read_2xu64(unsigned off, unsigned long long& a, unsigned long long& b)
+{
+    uint4 r;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(off) : "memory");
+    a = ((unsigned long long)r.y << 32) | r.x; b = ((unsigned long long)r.w << 32) | r.z;
+}
+__device__ __forceinline__ float lk_i64_to_f32_scaled(long long s, float scale)
+{   // exact for |s| < 2^53: hi * 2^32 + lo in double, then one rounding to float - the same value as (float)s
+    const double d = __builtin_fma((double)(int)(s >> 32), 4294967296.0, (double)(unsigned)(s & 0xFFFFFFFFll));
+    return (float)d * scale;
+}
+template <int NV>
+__device__ __forceinline__ void lk_lds_sums(LkLdsAcc& A, const int (&part)[NV], float (&out)[NV], float scale)
+{
+    static_assert(NV == 2 || NV == 3, "two or three sums");
+    const int lane = threadIdx.x & 63;
+    int g[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) g[k] = lk_group8_sum(part[k]);
+    if ((lane & 7) == 7) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds_add_u64(A.off + 8 * k, (unsigned long long)(long long)g[k]);
+    }
+    unsigned long long now[4];
+    lds_read_2xu64(A.off, now[0], now[1]);
+    if (NV == 3) lds_read_2xu64(A.off + 16, now[2], now[3]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const long long s = (long long)(now[k] - A.prev[k]);
+        A.prev[k] = now[k];
+        // every lane read the same totals: say so, the loop control around this stays scalar
+        out[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lk_i64_to_f32_scaled(s, scale))));
+    }
+}
+__device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
+                                                 int& status, int max_count, double epsilon, int* __restrict__ iters_out, LkLdsAcc& acc)
+{
+    // every lane holds the same points: say so (v_readfirstlane), the level / iteration control flow below then compiles to scalar branches
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    prev_pt.x = uni(prev_pt.x); prev_pt.y = uni(prev_pt.y); next_pt.x = uni(next_pt.x); next_pt.y = uni(next_pt.y);
+    constexpr int WIN = 21;
+    int total_it = 0;
+    const int lane = threadIdx.x & 63;
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int max_level = n_levels - 1;
+    const int wrow = lane / 3, x0 = (lane - 3 * wrow) * LK_RS_SEG;
+    const bool act = lane < 3 * WIN;
+    struct Raw { unsigned long long i0, i1; uint4 d00, d01, d10, d11; int ipx, ipy; bool ok; };
+    auto fetch = [&](int level) {
+        Raw r; r.i0 = 0; r.i1 = 0; r.d00 = r.d01 = r.d10 = r.d11 = uint4{0, 0, 0, 0};
+        const float lscale = (float)(1. / (1 << level));
+        const float prx = prev_pt.x * lscale - half, pry = prev_pt.y * lscale - half;
+        r.ipx = d_cv_floor(prx); r.ipy = d_cv_floor(pry);
+        const int cols = prev.w[level], rows = prev.h[level];
+        r.ok = !(r.ipx < -WIN || r.ipx >= cols || r.ipy < -WIN || r.ipy >= rows);
+        if (r.ok && act) {
+            const int stepI = prev.istride[level], dstep = prev.dstride[level];
+            const uint8_t* src = prev.img[level] + (ptrdiff_t)(wrow + r.ipy) * stepI + (x0 + r.ipx);
+            const int16_t* ds = prev.der[level] + (ptrdiff_t)(wrow + r.ipy) * dstep + 2 * (x0 + r.ipx);
+            __builtin_memcpy(&r.i0, src, 8); __builtin_memcpy(&r.i1, src + stepI, 8);
+            __builtin_memcpy(&r.d00, ds, 16); __builtin_memcpy(&r.d01, ds + 8, 16);
+            __builtin_memcpy(&r.d10, ds + dstep, 16); __builtin_memcpy(&r.d11, ds + dstep + 8, 16);
+        }
+        return r;
+    };
+    Raw cur = fetch(max_level);
+
+    for (int level = max_level; level >= 0; --level) {
+        const Raw raw = cur;
+        if (level > 0) cur = fetch(level - 1);
+        const int cols = prev.w[level], rows = prev.h[level];
+        const int stepJ = next.istride[level];
+        const uint8_t* __restrict__ Jbase = next.img[level];
+        const float lscale = (float)(1. / (1 << level));
+        float prx = prev_pt.x * lscale, pry = prev_pt.y * lscale;
+        float nx, ny;
+        if (level == max_level) { nx = next_pt.x * lscale; ny = next_pt.y * lscale; }
+        else { nx = next_pt.x * 2.f; ny = next_pt.y * 2.f; }
+        next_pt.x = nx; next_pt.y = ny;
+        int n_it = 0;
+
+        prx -= half; pry -= half;
+        const int ipx = raw.ipx, ipy = raw.ipy;
+        if (!raw.ok) {
+            if (level == 0) status = 0;
+            if (iters_out && lane == 0) iters_out[level] = 0;
+            continue;
+        }
+        float a = prx - ipx, b = pry - ipy;
+        int iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+        int iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+        int iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+        int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+
+        short Iv[LK_RS_SEG], Ixv[LK_RS_SEG], Iyv[LK_RS_SEG];
+        int pA[3] = {0, 0, 0};
+        {
+            const unsigned long long i0 = raw.i0, i1 = raw.i1;
+            const uint4 d00 = raw.d00, d01 = raw.d01, d10 = raw.d10, d11 = raw.d11;
+            const unsigned dr0[8] = {d00.x, d00.y, d00.z, d00.w, d01.x, d01.y, d01.z, d01.w};
+            const unsigned dr1[8] = {d10.x, d10.y, d10.z, d10.w, d11.x, d11.y, d11.z, d11.w};
+#pragma unroll
+            for (int j = 0; j < LK_RS_SEG; ++j) {
+                const int s00 = (int)((i0 >> (8 * j)) & 0xFF), s01 = (int)((i0 >> (8 * j + 8)) & 0xFF);
+                const int s10 = (int)((i1 >> (8 * j)) & 0xFF), s11 = (int)((i1 >> (8 * j + 8)) & 0xFF);
+                const int x00 = (short)(dr0[j] & 0xFFFF), y00 = (short)(dr0[j] >> 16), x01 = (short)(dr0[j + 1] & 0xFFFF), y01 = (short)(dr0[j + 1] >> 16);
+                const int x10 = (short)(dr1[j] & 0xFFFF), y10 = (short)(dr1[j] >> 16), x11 = (short)(dr1[j + 1] & 0xFFFF), y11 = (short)(dr1[j + 1] >> 16);
+                int ival = (lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+                int ixval = (lk_blend_i16(x00, x01, x10, x11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                int iyval = (lk_blend_i16(y00, y01, y10, y11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+                if (!act) { ival = 0; ixval = 0; iyval = 0; }
+                Iv[j] = (short)ival; Ixv[j] = (short)ixval; Iyv[j] = (short)iyval;
+                pA[0] += ixval * ixval; pA[1] += ixval * iyval; pA[2] += iyval * iyval;
+            }
+        }
+        float fA[3];
+        lk_lds_sums<3>(acc, pA, fA, FLT_SCALE);
+        const float A11 = fA[0], A12 = fA[1], A22 = fA[2];
+        float D = A11 * A22 - A12 * A12;
+        const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if (min_eig < (float)1e-4 || D < FLT_EPSILON) {      // float against float: LKTrackerInvoker keeps minEigThreshold as a float member
+            if (level == 0) status = 0;
+            if (iters_out && lane == 0) iters_out[level] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        unsigned long long j0 = 0, j1 = 0;
+        int held_x = INT_MIN, held_y = INT_MIN;            // window origin the bytes in j0 / j1 were loaded for
+        for (int j = 0; j < max_count; ++j) {
+            const int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
+            if (inx < -WIN || inx >= cols || iny < -WIN || iny >= rows) {
+                if (level == 0) status = 0;
+                break;
+            }
+            ++n_it;
+            if (inx != held_x || iny != held_y) {
+                held_x = inx; held_y = iny;
+                if (act) {
+                    const uint8_t* Jp = Jbase + (ptrdiff_t)(wrow + iny) * stepJ + (x0 + inx);
+                    __builtin_memcpy(&j0, Jp, 8); __builtin_memcpy(&j1, Jp + stepJ, 8);
+                }
+            }
+            a = nx - inx; b = ny - iny;
+            iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+            iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+            iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+            iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            int pb[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < LK_RS_SEG; ++k) {
+                const int s00 = (int)((j0 >> (8 * k)) & 0xFF), s01 = (int)((j0 >> (8 * k + 8)) & 0xFF);
+                const int s10 = (int)((j1 >> (8 * k)) & 0xFF), s11 = (int)((j1 >> (8 * k + 8)) & 0xFF);
+                const int diff = ((lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
+                pb[0] += diff * Ixv[k]; pb[1] += diff * Iyv[k];          // lane 63 (no pixels): Ixv = Iyv = 0, j0 = j1 = 0
+            }
+            float fb[2];
+            lk_lds_sums<2>(acc, pb, fb, FLT_SCALE);
+            const float b1 = fb[0], b2 = fb[1];
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx; ny += dy;
+            next_pt.x = nx + half; next_pt.y = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                next_pt.x -= dx * 0.5f; next_pt.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (iters_out && lane == 0) iters_out[level] = n_it;
+        total_it += n_it;
+    }
+    return total_it;
+}
+
+// LK variants (run-time: LVK_LK_VARIANT, read once per process; A/B records in profiles/):
+//   0  lk_point_rs21      wave-wide sums by DPP + v_readlane + scalar carry chain (rounds 3-5)
+//   1  lk_point_rs21_lds  sums through LDS accumulators, next-image bytes kept while the window origin stands (the default)
+// LVK_LK_GENERIC (compile-time): the one-pixel-per-lane-slot path for every window size
+#define LVK_LK_VARIANTS 2
+template <int WIN, int VAR>
 __device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
-                                        int& status, int max_count, double epsilon, int* __restrict__ iters_out)
+                                        int& status, int max_count, double epsilon, int* __restrict__ iters_out, LkLdsAcc& acc)
 {
 #ifndef LVK_LK_GENERIC
-    if constexpr (WIN == 21) return lk_point_rs21(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out);
+    if constexpr (WIN == 21 && VAR == 1) return lk_point_rs21_lds(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out, acc);
+    else if constexpr (WIN == 21) return lk_point_rs21(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out);
     else
 #endif
     return lk_point_generic<WIN>(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out);
+}
+// zero the wavefront's LDS accumulators (4 x u64, 16-byte aligned; call once, by the wavefront that will use them)
+__device__ __forceinline__ LkLdsAcc lk_acc_init(unsigned long long* lds4)
+{
+    LkLdsAcc a; a.prev[0] = a.prev[1] = a.prev[2] = 0;
+    a.off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)lds4;
+    if ((threadIdx.x & 63) < 4) lds4[threadIdx.x & 63] = 0;
+    __builtin_amdgcn_wave_barrier();
+    return a;
 }
 
 // ------------------------------------------------------------------------- ORB
@@ -339,29 +563,6 @@ __device__ __forceinline__ float d_fast_atan2(float y, float x)
     return a;
 }
 
-// fixed-sequence double cos/sin (identical to oracle det_cos_sin)
-__device__ __forceinline__ void d_det_cos_sin(double x, double& c_out, double& s_out)
-{
-    const double two_over_pi = 6.36619772367581382433e-01;
-    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
-    double fn = rint(x * two_over_pi);
-    double r = (x - fn * pio2_1) - fn * pio2_1t;
-    int q = ((int)fn) & 3;
-    double z = r * r;
-    double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
-              + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
-    double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
-              + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-    double c = 1.0 - (0.5 * z - z * pc);
-    switch (q) {
-        case 0: c_out = c;  s_out = s;  break;
-        case 1: c_out = -s; s_out = c;  break;
-        case 2: c_out = -c; s_out = -s; break;
-        default: c_out = s; s_out = -c; break;
-    }
-}
-
 // one wavefront: IC angle on ext, 256 rotated tests on blur -> 4 x u64 descriptor (all lanes get it).
 __device__ __forceinline__ float orb_point(const uint8_t* __restrict__ ext, const uint8_t* __restrict__ blur, int step, lvk_pt2f pt,
                                            unsigned long long d[4])
@@ -382,9 +583,8 @@ __device__ __forceinline__ float orb_point(const uint8_t* __restrict__ ext, cons
     const float angle = d_fast_atan2((float)m01, (float)m10);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = angle * factorPI;
-    double cd, sd;
-    d_det_cos_sin((double)ang, cd, sd);
-    const float a = (float)cd, b = (float)sd;
+    float a, b;
+    lvk_sincosf(ang, &a, &b);                             // cosf / sinf as the reference's libm computes them (lvk_sincosf.h; ORBDescriptor.cpp:343)
     const uint8_t* bc = blur + (ptrdiff_t)(cy + B) * step + cx + B;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {

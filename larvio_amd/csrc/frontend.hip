@@ -386,7 +386,7 @@ __device__ __forceinline__ lvk_pt2f apply_h(const HMat& H, lvk_pt2f p)
 // wavefront also undistorts the point pair (K -> K, what findFundamentalMat is fed, :701-712 / :932-943) into w_und[2p], [2p+1]:
 // two sequential double-precision fixed-point loops per point that the one-workgroup commit kernel would otherwise run for
 // every point of its set (24 us of its 120 at 2000 tracks).
-template <int WIN>
+template <int WIN, int VAR>
 __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
                                                    HMat H, int width, int height, int max_count, double epsilon,
                                                    lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev,
@@ -397,6 +397,7 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
 {
     __shared__ lvk_pt2f s_np;
     __shared__ int s_st, s_dist;
+    __shared__ __attribute__((aligned(16))) unsigned long long s_acc[4];
     const int p = blockIdx.x;
     if (p >= *n_ptr) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -406,9 +407,11 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
     lvk_pt2f np = pp;
     int st = 1, its = 0;
     unsigned long long dp[4] = {0, 0, 0, 0};
+    LkLdsAcc acc; acc.off = 0; acc.prev[0] = acc.prev[1] = acc.prev[2] = 0;
     if (wave == 0) {
+        acc = lk_acc_init(s_acc);
         np = apply_h(H, pp);
-        its = lk_point<WIN>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr);
+        its = lk_point<WIN, VAR>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr, acc);
         if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
         if (lane == 0) { s_np = np; s_st = st; }
     } else {
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
         if (st) {
             lvk_pt2f back = pp;
             int sr = 1;
-            its += lk_point<WIN>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr);
+            its += lk_point<WIN, VAR>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr, acc);
             passes = 2;
             if (sr) {
                 if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
@@ -734,9 +737,14 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
     const int W = fe->cfg.width, Hh = fe->cfg.height;
     if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes (read by the kernel's second wavefront) follow it on the image stream
     ProfScope ps(fe, 2, s);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
-                       (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
-                       fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
+    if (WIN == 21 && lvk_lk_variant() == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN, 0>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
+                           (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
+                           fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN, 1>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
+                           (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
+                           fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
 }
 
 static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,

@@ -144,6 +144,13 @@ lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...
 #define BE_TICK_GETTER(fn, arr)
 #endif
 
+// LK kernel variant (fe_track_dev.h): LVK_LK_VARIANT in the environment, read once per process; default 1
+inline int lvk_lk_variant()
+{
+    static const int v = [] { const char* e = getenv("LVK_LK_VARIANT"); const int x = e ? atoi(e) : 1; return x < 0 || x > 1 ? 1 : x; }();
+    return v;
+}
+
 // ---- device helpers shared by the kernels --------------------------------------------------
 __device__ __forceinline__ int d_reflect101(int p, int len)
 {

@@ -41,7 +41,7 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
     double epsilon = eps < 0. ? 0. : eps > 10. ? 10. : eps;
     epsilon *= epsilon;
     const float FLT_SCALE = 1.f / (1 << 20);
-    const double min_eig_threshold = 1e-4;
+    const float min_eig_threshold = (float)1e-4;     /* calcOpticalFlowPyrLK takes a double, LKTrackerInvoker stores and compares it as a float */
     extern int lvo_threads_;
     short* Iwin_all = (short*)malloc(sizeof(short) * (size_t)win * win * 3 * (size_t)lvo_threads_);
     for (int i = 0; i < n; ++i) status[i] = 1;
@@ -101,7 +101,7 @@ void lvo_lk_track(const lvo_pyramid* prev, const lvo_pyramid* next,
             if (lvo_lk_float_accum_) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
             float D = A11 * A22 - A12 * A12;
             float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
-            if ((double)min_eig < min_eig_threshold || D < FLT_EPSILON) {
+            if (min_eig < min_eig_threshold || D < FLT_EPSILON) {
                 if (level == 0) status[p] = 0;
                 continue;
             }
@@ -176,30 +176,59 @@ float lvo_fast_atan2(float y, float x)
     return a;
 }
 
-/* cos/sin in double for |x| <= ~7 with a FIXED operation sequence (Cody-Waite reduction by
- * pi/2 + fdlibm kernel polynomials), so the HIP kernel can reproduce the bits.  The reference
- * calls libm cos/sin on (double)angle and casts to float (ORBDescriptor.cpp:343-344); this
- * differs from libm by <= ~1 ulp(double) before the cast. */
-static void det_cos_sin(double x, double* c_out, double* s_out)
+/* cosf / sinf as the reference calls them: ORBDescriptor.cpp:343 is `(float)cos(angle), (float)sin(angle)` on a float under
+ * `using namespace std;` (:16) - overload resolution picks std::cos(float) / std::sin(float), i.e. libm's cosf / sinf, NOT the double
+ * functions (rounds 1-5 restated cos((double)angle) rounded to float here: another float for 0.04 % / 0.09 % of the floats in
+ * [0, 2 pi], and - fuzz case 379 of the front-end streams - once in a while a sampling point of the rotated pattern one pixel off).
+ * Restated: glibc >= 2.28's algorithm for both (ARM Optimized Routines' sincosf; sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c,
+ * s_cosf.c, s_sincosf_data.c), plain C with a fixed operation sequence so that the HIP kernel computes the same bits
+ * (larvio_amd/csrc/lvk_sincosf.h is the twin).  PINNED against this host's libm over EVERY float in [0, 6.2832]
+ * (tests/test_oracle_frontend.py::test_sincosf_restatement_is_libms_on_every_angle: 1,086,918,650 values, zero mismatches). */
+static uint32_t sc_abstop12(float x) { uint32_t u; memcpy(&u, &x, 4); return (u >> 20) & 0x7ff; }
+static float sc_poly(double x, double x2, int n, int neg)
 {
-    const double two_over_pi = 6.36619772367581382433e-01;
-    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
-    double fn = rint(x * two_over_pi);
-    double r = (x - fn * pio2_1) - fn * pio2_1t;
-    int q = ((int)fn) & 3;
-    double z = r * r;
-    double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
-              + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
-    double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
-              + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-    double c = 1.0 - (0.5 * z - z * pc);
-    switch (q) {
-        case 0: *c_out = c;  *s_out = s;  break;
-        case 1: *c_out = -s; *s_out = c;  break;
-        case 2: *c_out = -c; *s_out = -s; break;
-        default: *c_out = s; *s_out = -c; break;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    if (neg) { C0 = -C0; C1 = -C1; C2 = -C2; C3 = -C3; C4 = -C4; }
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, s1 = S2 + x2 * S3, x7 = x3 * x2, s = x + x3 * S1;
+        return (float)(s + x7 * s1);
     }
+    const double x4 = x2 * x2, c2 = C3 + x2 * C4, c1 = C0 + x2 * C1, x6 = x4 * x2, c = c1 + x4 * C2;
+    return (float)(c + x6 * c2);
+}
+static void glibc_sincosf(float y, float* c_out, float* s_out)
+{
+    const double HPI_INV = 0x1.45F306DC9C883p+23, HPI = 0x1.921FB54442D18p0;    /* 2/pi * 2^24, pi/2 */
+    const double x = y;
+    if (sc_abstop12(y) < sc_abstop12(0x1.921FB6p-1f)) {
+        const double x2 = x * x;
+        const int tiny = sc_abstop12(y) < sc_abstop12(0x1p-12f);
+        *s_out = tiny ? y : sc_poly(x, x2, 0, 0);
+        *c_out = tiny ? 1.0f : sc_poly(x, x2, 1, 0);
+        return;
+    }
+    const double r = x * HPI_INV;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    const double xr = x - n * HPI;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    *s_out = sc_poly(xr * sgn, xr * xr, n, (n & 2) != 0);
+    *c_out = sc_poly(xr * sgn, xr * xr, n ^ 1, ((n + 1) & 2) != 0);
+}
+/* test hook: the restatement against THIS host's libm on the floats with bit patterns [lo_bits, hi_bits]; returns the number of
+ * inputs where either result differs (and the first such bit pattern) */
+long lvo_sincosf_sweep(uint32_t lo_bits, uint32_t hi_bits, uint32_t* first_bad)
+{
+    long bad = 0; uint32_t first = 0xFFFFFFFFu;
+#pragma omp parallel for reduction(+ : bad) reduction(min : first) schedule(static)
+    for (int64_t b = lo_bits; b <= (int64_t)hi_bits; ++b) {
+        const uint32_t u = (uint32_t)b; float x, c, s; memcpy(&x, &u, 4);
+        glibc_sincosf(x, &c, &s);
+        const float cl = cosf(x), sl = sinf(x);
+        if (memcmp(&c, &cl, 4) || memcmp(&s, &sl, 4)) { ++bad; if (u < first) first = u; }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
 }
 
 static void orb_umax(int* umax /*[16]*/)
@@ -245,9 +274,8 @@ void lvo_orb_describe(const uint8_t* ext, const uint8_t* blur, int w, int h,
         if (angle_out) angle_out[i] = angle;
         /* computeOrbDescriptor (ORBDescriptor.cpp:335-383); scale = 1/mvLayerScale[0] = 1 */
         float ang = angle * factorPI;
-        double cd, sd;
-        det_cos_sin((double)ang, &cd, &sd);
-        float a = (float)cd, b = (float)sd;
+        float a, b;
+        glibc_sincosf(ang, &a, &b);
         const uint8_t* bc = blur + (ptrdiff_t)(cv_round_f(pts[i].y * 1.f) + B) * step + cv_round_f(pts[i].x * 1.f) + B;
         const int8_t* pat = lvo_orb_pattern;
         for (int k = 0; k < 32; ++k, pat += 32) {

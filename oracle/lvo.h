@@ -125,6 +125,9 @@ void lvo_orb_describe(const uint8_t* ext, const uint8_t* blur, int w, int h,
                       const lvo_pt2f* pts, int n, uint8_t* desc, float* angle_out);
 /* ORBdescriptor::computeDescriptorDistance (ORBDescriptor.h:43-59) */
 int lvo_hamming256(const uint8_t* a, const uint8_t* b);
+/* test hook: the restated cosf / sinf (fe_track.c, ORBDescriptor.cpp:343) against this host's libm on the floats with bit patterns
+ * lo_bits..hi_bits: number of inputs where either differs, *first_bad = the smallest such pattern */
+long lvo_sincosf_sweep(uint32_t lo_bits, uint32_t hi_bits, uint32_t* first_bad);
 /* cv::fastAtan2 [upstream mathfuncs_core] (degrees) */
 float lvo_fast_atan2(float y, float x);
 

@@ -506,7 +506,7 @@ def test_pipelined_driver_on_a_camera_off_the_imu_grid(gpu_ctx):
     so = obe.state()
     for k_ in ("q", "v", "p", "bg", "ba", "R_b2c", "t_c_b"):
         assert _rel(b[1][k_], so[k_]) < REL, k_
-    assert abs(b[1]["td"] - so["td"]) < 1e-9 and abs(so["td"]) > 1e-5                 # td moved (the bound wandered), identically
+    assert abs(b[1]["td"] - so["td"]) < 1e-9 and abs(so["td"]) > 1e-6                 # td moved (the bound wandered), identically (where it stands at the end depends on which features are in the state: 4.8e-6 s with the reference's grid_map bookkeeping, 1.7e-5 before round 6)
     assert _rel(b[2], obe.cov()) < REL
     assert np.array_equal(b[3], obe.clones()["id"]) and np.array_equal(b[4], obe.features()[0])
     to = ofe.tracks()

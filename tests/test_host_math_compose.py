@@ -100,3 +100,17 @@ def test_product_host_math_against_scipy(tmp_path):
             assert min(np.abs(q2 - q2_r).max(), np.abs(q2 + q2_r).max()) < 1e-13     # two branch rules (Eigen's, the reference's own), one rotation
             gn = got / np.linalg.norm(got); assert min(np.abs(gn - qp_r).max(), np.abs(gn + qp_r).max()) < 1e-14
     assert saw_neg_trace >= 20
+
+
+def test_descriptor_rotation_cosf_sinf_restatement_is_libms_on_every_angle(tmp_path):
+    """larvio_amd/csrc/lvk_sincosf.h - what the HIP descriptor kernel computes for ORBDescriptor.cpp:343's `(float)cos(angle),
+    (float)sin(angle)` (std::cos(float) / std::sin(float) = libm's cosf / sinf under `using namespace std`) - compiled as host code and
+    compared with this host's libm on every float in [0, 6.2832]: 1,086,918,650 angles, bit for bit."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path / "sincosf_check")
+    subprocess.check_call([gxx, "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-I", os.path.join(ROOT, "larvio_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", "sincosf_check.cpp"), "-o", exe, "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok 1086918650"), r.stdout + r.stderr

@@ -193,13 +193,18 @@ def test_the_gpu_tests_own_code_runs_with_the_oracle_standing_in(monkeypatch):
     T.test_frontend_against_the_references_own_outputs(None)
 
 
-def _random_frames(k):
+def _random_frames(k, small=False):
     """a random front-end case (seeded): image 160..420 x 120..320, 1..3 pyramid levels, patch 15 / 21 / 31, 21..260 tracks, min_distance
     5..40, CLAHE on or off, radtan or equidistant, 10 / 30 LK iterations, publish rate 5 / 10 / 20 Hz; a random walk of the crop window with
-    jumps and stand-stills, flat, noise and exposure-shifted frames, a random constant gyro rate"""
-    rng = np.random.default_rng([k, 313])
+    jumps and stand-stills, flat, noise and exposure-shifted frames, a random constant gyro rate.
+    small: images of 96..160 x 80..128 with 3 pyramid levels - the coarsest layer of the ORB mosaic (24..40 px wide, 20..32 px high) is
+    then narrower than the 32 px border initializeLayerAndPyramid puts around it (ORBDescriptor.cpp:420-421, 460-466): the reflection
+    has to repeat"""
+    rng = np.random.default_rng([k, 313] if not small else [k, 313, 7])
     w = int(rng.integers(160, 420)); h = int(rng.integers(120, 320))
     levels = int(rng.integers(1, 4)); patch = int(rng.choice([15, 21, 21, 31])); nfr = int(rng.integers(10, 28))
+    if small:
+        w = int(rng.integers(96, 160)); h = int(rng.integers(80, 128)); levels = 3; patch = int(rng.choice([15, 21]))
     tex = _texture(int(k) + 100, h + 260, w + 360)
     x, y = 60, 60; offs = []
     for i in range(nfr):
@@ -216,7 +221,10 @@ def _random_frames(k):
         elif r < 0.15: frames[i] = np.clip(frames[i].astype(int) + int(rng.integers(-60, 61)), 0, 255).astype(np.uint8)
     model = int(rng.integers(0, 2))
     dist = (0.003, 0.0007, -0.002, 0.0002) if model else (float(rng.uniform(-0.3, 0.05)), float(rng.uniform(-0.02, 0.08)), float(rng.uniform(-1e-3, 1e-3)), float(rng.uniform(-1e-3, 1e-3)))
-    cfg = _cfg(w, h, max_features_num=int(rng.integers(21, 260)), min_distance=int(rng.integers(5, 40)), pyramid_levels=levels, patch_size=patch,
+    mf, md = int(rng.integers(21, 260)), int(rng.integers(5, 40))
+    if small:
+        mf, md = int(rng.integers(40, 200)), int(rng.integers(4, 10))
+    cfg = _cfg(w, h, max_features_num=mf, min_distance=md, pyramid_levels=levels, patch_size=patch,
                flag_equalize=int(rng.integers(0, 2)), distortion_model=model, distortion=dist, max_iteration=int(rng.choice([10, 30])), track_precision=float(rng.choice([0.01, 0.03])),
                pub_frequency=int(rng.choice([10, 10, 20, 5])))
     ts_all = [1.0 + 0.05 * i for i in range(nfr)]
@@ -224,12 +232,14 @@ def _random_frames(k):
 
 
 def test_random_configurations(tmp_path):
-    """twelve of the random cases the oracle's front-end object was fuzzed with against the compiled reference (400 of them: every frame of
-    399 byte-identical; one open case with a 21-px-wide ORB layer, PARITY.md section 2)"""
+    """fourteen of the random cases the oracle's front-end object was fuzzed with against the compiled reference (tools/fuzz_frontend.py:
+    400 + 400 with ORB layers narrower than the mosaic border, every frame of all of them byte-identical since round 6; PARITY.md
+    section 2) - among them case 379, the one stream of the first 400 that differed while the oracle restated cos(double) where the
+    reference calls cosf (ORBDescriptor.cpp:343), and two of the small-image cases"""
     lvref = _ref()
     msgs = 0
-    for k in range(0, 12):
-        frames, ts_all, imu_all, cfg = _random_frames(k)
-        states, n_tracks, n_msgs = run_both(frames, ts_all, imu_all, cfg, tmp_path / str(k), lvref)
+    for k, small in [(k, False) for k in range(0, 11)] + [(379, False), (3, True), (8, True)]:
+        frames, ts_all, imu_all, cfg = _random_frames(k, small)
+        states, n_tracks, n_msgs = run_both(frames, ts_all, imu_all, cfg, tmp_path / (str(k) + "sl"[small]), lvref)
         msgs += n_msgs
     assert msgs > 60
