@@ -741,8 +741,13 @@ def main():
             lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_lk_")]
             if lk:
                 traffic = round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1); traffic_src = os.path.basename(pm[-1])
-        roofline = {"kernel": "k_fe_lk_both<%d> (forward + reverse LK of every track; a second wavefront per track computes the ORB descriptors of the gate in their "
-                              "shadow - its bytes are NOT counted in `achieved`)" % win, "bound": "hbm", "achieved": round(achieved, 3),
+        lk_var = os.environ.get("LVK_LK_VARIANT")
+        lk_pipe = win == 21 and (lk_var == "2" or (lk_var not in ("0", "1") and wl["max_features"] <= 600))     # frontend.hip: launch_track_chain, LVK_LK_PIPE_MAX_TRACKS
+        lk_name = ("k_fe_lk_pipe<%d> (forward + reverse LK of every track, five wavefronts per track: one iterates, three build the levels' templates of a pass, "
+                   "one computes the ORB descriptors of the gate and the undistorted pair - the descriptor bytes are NOT counted in `achieved`)" % win) if lk_pipe else \
+                  ("k_fe_lk_both<%d> (forward + reverse LK of every track; a second wavefront per track computes the ORB descriptors of the gate in their "
+                   "shadow - its bytes are NOT counted in `achieved`)" % win)
+        roofline = {"kernel": lk_name, "bound": "hbm", "achieved": round(achieved, 3),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "bytes_per_launch": round(lk_bytes / max(lk_launches, 1), 1), "avg_launch_us": round(lk_ms / max(lk_timed, 1) * 1e3, 3),
                     "launches": lk_launches, "launches_timed": lk_timed,

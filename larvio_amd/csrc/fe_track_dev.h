@@ -367,6 +367,24 @@ __device__ __forceinline__ void lk_lds_sums(LkLdsAcc& A, const int (&part)[NV], 
         out[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lk_i64_to_f32_scaled(s, scale))));
     }
 }
+#ifdef LVK_LK_TIMING
+static __device__ unsigned long long g_lk_tick[4096][12];    // -DLVK_LK_TIMING=1: the kernel's spans only (g_lk_span, frontend.hip); =2: this phase account too
+#endif
+#if defined(LVK_LK_TIMING) && LVK_LK_TIMING >= 2
+// per-block phase account of the LK wavefront (variants/lkt.so, tools/gpu/lk_ticks.py): shader-clock cycles by category
+// 0 level set-up (template blends incl. the wait for the fetched bytes)  1 A sums  2 eigen test / inverse  3 iteration: origin, weights,
+// load (when the origin moved), blends  4 iteration: b sums  5 iteration: solve + stop tests  6 iterations  7 levels entered  8 loads issued
+#define LKT_DECL unsigned long long lkt_prev = clock64(); unsigned long long lkt_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define LKT(k) do { const unsigned long long lkt_now = clock64(); lkt_acc[k] += lkt_now - lkt_prev; lkt_prev = lkt_now; } while (0)
+#define LKT_COUNT(k) do { lkt_acc[k] += 1; } while (0)
+#define LKT_FLUSH(pass) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) { for (int q = 0; q < 9; ++q) { if (pass == 0) g_lk_tick[blockIdx.x][q] = lkt_acc[q]; else g_lk_tick[blockIdx.x][q] += lkt_acc[q]; } } } while (0)
+#else
+#define LKT_DECL do { } while (0)
+#define LKT(k) do { } while (0)
+#define LKT_COUNT(k) do { } while (0)
+#define LKT_FLUSH(pass) do { } while (0)
+#endif
+template <int LKT_PASS = 0>
 __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
                                                  int& status, int max_count, double epsilon, int* __restrict__ iters_out, LkLdsAcc& acc)
 {
@@ -400,6 +418,7 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
         return r;
     };
     Raw cur = fetch(max_level);
+    LKT_DECL;
 
     for (int level = max_level; level >= 0; --level) {
         const Raw raw = cur;
@@ -449,8 +468,10 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
                 pA[0] += ixval * ixval; pA[1] += ixval * iyval; pA[2] += iyval * iyval;
             }
         }
+        LKT(0); LKT_COUNT(7);
         float fA[3];
         lk_lds_sums<3>(acc, pA, fA, FLT_SCALE);
+        LKT(1);
         const float A11 = fA[0], A12 = fA[1], A22 = fA[2];
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
@@ -461,6 +482,7 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
         }
         D = 1.f / D;
         nx -= half; ny -= half;
+        LKT(2);
         float pdx = 0.f, pdy = 0.f;
         unsigned long long j0 = 0, j1 = 0;
         int held_x = INT_MIN, held_y = INT_MIN;            // window origin the bytes in j0 / j1 were loaded for
@@ -472,7 +494,7 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
             }
             ++n_it;
             if (inx != held_x || iny != held_y) {
-                held_x = inx; held_y = iny;
+                held_x = inx; held_y = iny; LKT_COUNT(8);
                 if (act) {
                     const uint8_t* Jp = Jbase + (ptrdiff_t)(wrow + iny) * stepJ + (x0 + inx);
                     __builtin_memcpy(&j0, Jp, 8); __builtin_memcpy(&j1, Jp + stepJ, 8);
@@ -491,6 +513,183 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
                 const int diff = ((lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
                 pb[0] += diff * Ixv[k]; pb[1] += diff * Iyv[k];          // lane 63 (no pixels): Ixv = Iyv = 0, j0 = j1 = 0
             }
+            LKT(3); LKT_COUNT(6);
+            float fb[2];
+            lk_lds_sums<2>(acc, pb, fb, FLT_SCALE);
+            LKT(4);
+            const float b1 = fb[0], b2 = fb[1];
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx; ny += dy;
+            next_pt.x = nx + half; next_pt.y = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                next_pt.x -= dx * 0.5f; next_pt.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+            LKT(5);
+        }
+        LKT(5);
+        if (iters_out && lane == 0) iters_out[level] = n_it;
+        total_it += n_it;
+    }
+    LKT_FLUSH(LKT_PASS);
+    return total_it;
+}
+
+// ---- variant 2: the same arithmetic, the levels' templates built by OTHER wavefronts of the block (k_fe_lk_pipe, frontend.hip).
+// What a track costs is one wavefront's dependent instruction stream (profiles/r6_e_*: fewer instructions in one phase did not make it
+// shorter), and a third of that stream - per level: six loads, 21 bilinear blends, three exact sums, a square root and two divisions,
+// ~1.7 us - does not depend on what the iterations find: the template of a level is a function of the point in the FIRST image alone.
+// So the wavefront that iterates no longer builds it: three builder wavefronts (levels l, l + 3, ...) do, at once, before the pass
+// starts, and leave per lane the 21 shorts (I, Ix, Iy of its seven pixels) and per level A11, A12, A22, 1 / D and the verdict of the
+// eigenvalue test in LDS.  Same loads, same integer blends, same exact sums, same float expressions: the same bits.
+#define LK_PIPE_MAX_LEVELS 4
+struct LkTplLevel {
+    unsigned long long px[64][6];       // per lane: Iv[7], Ixv[7], Iyv[7] (21 shorts, 48 bytes)
+    float A11, A12, A22, Dinv;
+    int state;                          // 0 the window's origin lies outside the image, 1 the eigenvalue / determinant test failed (either: no iterations, status 0 at level 0), 2 iterate
+    int pad_[3];
+};
+__device__ __forceinline__ void lk_tpl_build21(const PyrView& I, int level, lvk_pt2f prev_pt, LkTplLevel& T, LkLdsAcc& acc)
+{
+    constexpr int WIN = 21;
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    prev_pt.x = uni(prev_pt.x); prev_pt.y = uni(prev_pt.y);
+    const int lane = threadIdx.x & 63;
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int wrow = lane / 3, x0 = (lane - 3 * wrow) * LK_RS_SEG;
+    const bool act = lane < 3 * WIN;
+    const float lscale = (float)(1. / (1 << level));
+    const float prx = prev_pt.x * lscale - half, pry = prev_pt.y * lscale - half;
+    const int ipx = d_cv_floor(prx), ipy = d_cv_floor(pry);
+    const int cols = I.w[level], rows = I.h[level];
+    if (ipx < -WIN || ipx >= cols || ipy < -WIN || ipy >= rows) {
+        if (lane == 0) T.state = 0;
+        return;
+    }
+    unsigned long long i0 = 0, i1 = 0; uint4 d00 = {0, 0, 0, 0}, d01 = d00, d10 = d00, d11 = d00;
+    if (act) {
+        const int stepI = I.istride[level], dstep = I.dstride[level];
+        const uint8_t* src = I.img[level] + (ptrdiff_t)(wrow + ipy) * stepI + (x0 + ipx);
+        const int16_t* ds = I.der[level] + (ptrdiff_t)(wrow + ipy) * dstep + 2 * (x0 + ipx);
+        __builtin_memcpy(&i0, src, 8); __builtin_memcpy(&i1, src + stepI, 8);
+        __builtin_memcpy(&d00, ds, 16); __builtin_memcpy(&d01, ds + 8, 16);
+        __builtin_memcpy(&d10, ds + dstep, 16); __builtin_memcpy(&d11, ds + dstep + 8, 16);
+    }
+    const float a = prx - ipx, b = pry - ipy;
+    const int iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+    const int iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+    const int iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+    const int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+    unsigned short q[24];
+#pragma unroll
+    for (int j = 21; j < 24; ++j) q[j] = 0;
+    int pA[3] = {0, 0, 0};
+    {
+        const unsigned dr0[8] = {d00.x, d00.y, d00.z, d00.w, d01.x, d01.y, d01.z, d01.w};
+        const unsigned dr1[8] = {d10.x, d10.y, d10.z, d10.w, d11.x, d11.y, d11.z, d11.w};
+#pragma unroll
+        for (int j = 0; j < LK_RS_SEG; ++j) {
+            const int s00 = (int)((i0 >> (8 * j)) & 0xFF), s01 = (int)((i0 >> (8 * j + 8)) & 0xFF);
+            const int s10 = (int)((i1 >> (8 * j)) & 0xFF), s11 = (int)((i1 >> (8 * j + 8)) & 0xFF);
+            const int x00 = (short)(dr0[j] & 0xFFFF), y00 = (short)(dr0[j] >> 16), x01 = (short)(dr0[j + 1] & 0xFFFF), y01 = (short)(dr0[j + 1] >> 16);
+            const int x10 = (short)(dr1[j] & 0xFFFF), y10 = (short)(dr1[j] >> 16), x11 = (short)(dr1[j + 1] & 0xFFFF), y11 = (short)(dr1[j + 1] >> 16);
+            int ival = (lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5);
+            int ixval = (lk_blend_i16(x00, x01, x10, x11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+            int iyval = (lk_blend_i16(y00, y01, y10, y11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 1))) >> LK_W_BITS;
+            if (!act) { ival = 0; ixval = 0; iyval = 0; }
+            q[j] = (unsigned short)(short)ival; q[7 + j] = (unsigned short)(short)ixval; q[14 + j] = (unsigned short)(short)iyval;
+            pA[0] += ixval * ixval; pA[1] += ixval * iyval; pA[2] += iyval * iyval;
+        }
+    }
+    float fA[3];
+    lk_lds_sums<3>(acc, pA, fA, FLT_SCALE);
+    const float A11 = fA[0], A12 = fA[1], A22 = fA[2];
+    const float D = A11 * A22 - A12 * A12;
+    const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+    const bool bad = min_eig < (float)1e-4 || D < FLT_EPSILON;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        T.px[lane][j] = (unsigned long long)q[4 * j] | ((unsigned long long)q[4 * j + 1] << 16) | ((unsigned long long)q[4 * j + 2] << 32) | ((unsigned long long)q[4 * j + 3] << 48);
+    if (lane == 0) { T.A11 = A11; T.A12 = A12; T.A22 = A22; T.Dinv = bad ? 0.f : 1.f / D; T.state = bad ? 1 : 2; }
+}
+// the iterations of one pass over all levels, by the wavefront that owns the track; T[level] was filled by lk_tpl_build21 (and a barrier)
+__device__ __forceinline__ int lk_pass_iterate21(const PyrView& next, int n_levels, const LkTplLevel* T, lvk_pt2f& next_pt, int& status,
+                                                 int max_count, double epsilon, LkLdsAcc& acc)
+{
+    constexpr int WIN = 21;
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    next_pt.x = uni(next_pt.x); next_pt.y = uni(next_pt.y);
+    int total_it = 0;
+    const int lane = threadIdx.x & 63;
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int max_level = n_levels - 1;
+    const int wrow = lane / 3, x0 = (lane - 3 * wrow) * LK_RS_SEG;
+    const bool act = lane < 3 * WIN;
+    for (int level = max_level; level >= 0; --level) {
+        const int cols = next.w[level], rows = next.h[level];
+        const int stepJ = next.istride[level];
+        const uint8_t* __restrict__ Jbase = next.img[level];
+        const float lscale = (float)(1. / (1 << level));
+        float nx, ny;
+        if (level == max_level) { nx = next_pt.x * lscale; ny = next_pt.y * lscale; }
+        else { nx = next_pt.x * 2.f; ny = next_pt.y * 2.f; }
+        next_pt.x = nx; next_pt.y = ny;
+        int n_it = 0;
+        const LkTplLevel& L = T[level];
+        const int state = __builtin_amdgcn_readfirstlane(L.state);
+        if (state != 2) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        short Iv[LK_RS_SEG], Ixv[LK_RS_SEG], Iyv[LK_RS_SEG];
+        {
+            unsigned long long w[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) w[j] = L.px[lane][j];
+#pragma unroll
+            for (int j = 0; j < LK_RS_SEG; ++j) {
+                Iv[j] = (short)(w[j >> 2] >> (16 * (j & 3)));
+                Ixv[j] = (short)(w[(7 + j) >> 2] >> (16 * ((7 + j) & 3)));
+                Iyv[j] = (short)(w[(14 + j) >> 2] >> (16 * ((14 + j) & 3)));
+            }
+        }
+        const float A11 = uni(L.A11), A12 = uni(L.A12), A22 = uni(L.A22), D = uni(L.Dinv);
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        unsigned long long j0 = 0, j1 = 0;
+        int held_x = INT_MIN, held_y = INT_MIN;
+        for (int j = 0; j < max_count; ++j) {
+            const int inx = d_cv_floor(nx), iny = d_cv_floor(ny);
+            if (inx < -WIN || inx >= cols || iny < -WIN || iny >= rows) {
+                if (level == 0) status = 0;
+                break;
+            }
+            ++n_it;
+            if (inx != held_x || iny != held_y) {
+                held_x = inx; held_y = iny;
+                if (act) {
+                    const uint8_t* Jp = Jbase + (ptrdiff_t)(wrow + iny) * stepJ + (x0 + inx);
+                    __builtin_memcpy(&j0, Jp, 8); __builtin_memcpy(&j1, Jp + stepJ, 8);
+                }
+            }
+            const float a = nx - inx, b = ny - iny;
+            const int iw00 = d_cv_round((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+            const int iw01 = d_cv_round(a * (1.f - b) * (1 << LK_W_BITS));
+            const int iw10 = d_cv_round((1.f - a) * b * (1 << LK_W_BITS));
+            const int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            int pb[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < LK_RS_SEG; ++k) {
+                const int s00 = (int)((j0 >> (8 * k)) & 0xFF), s01 = (int)((j0 >> (8 * k + 8)) & 0xFF);
+                const int s10 = (int)((j1 >> (8 * k)) & 0xFF), s11 = (int)((j1 >> (8 * k + 8)) & 0xFF);
+                const int diff = ((lk_blend_u8(s00, s01, s10, s11, iw00, iw01, iw10, iw11) + (1 << (LK_W_BITS - 5 - 1))) >> (LK_W_BITS - 5)) - Iv[k];
+                pb[0] += diff * Ixv[k]; pb[1] += diff * Iyv[k];
+            }
             float fb[2];
             lk_lds_sums<2>(acc, pb, fb, FLT_SCALE);
             const float b1 = fb[0], b2 = fb[1];
@@ -505,7 +704,6 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
             }
             pdx = dx; pdy = dy;
         }
-        if (iters_out && lane == 0) iters_out[level] = n_it;
         total_it += n_it;
     }
     return total_it;
@@ -513,15 +711,17 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
 
 // LK variants (run-time: LVK_LK_VARIANT, read once per process; A/B records in profiles/):
 //   0  lk_point_rs21      wave-wide sums by DPP + v_readlane + scalar carry chain (rounds 3-5)
-//   1  lk_point_rs21_lds  sums through LDS accumulators, next-image bytes kept while the window origin stands (the default)
+//   1  lk_point_rs21_lds  sums through LDS accumulators, next-image bytes kept while the window origin stands
+//   2  k_fe_lk_pipe (frontend.hip): variant 1's arithmetic with the levels' templates built by three more wavefronts of the block
+// (tried and dropped, profiles/r6_e_*: sums by DPP + one FP64 MFMA; touching the next image's lines of all levels at the start of a pass)
 // LVK_LK_GENERIC (compile-time): the one-pixel-per-lane-slot path for every window size
-#define LVK_LK_VARIANTS 2
-template <int WIN, int VAR>
+#define LVK_LK_VARIANTS 3
+template <int WIN, int VAR, int PASS = 0>
 __device__ __forceinline__ int lk_point(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
                                         int& status, int max_count, double epsilon, int* __restrict__ iters_out, LkLdsAcc& acc)
 {
 #ifndef LVK_LK_GENERIC
-    if constexpr (WIN == 21 && VAR == 1) return lk_point_rs21_lds(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out, acc);
+    if constexpr (WIN == 21 && VAR >= 1) return lk_point_rs21_lds<PASS>(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out, acc);
     else if constexpr (WIN == 21) return lk_point_rs21(prev, next, n_levels, prev_pt, next_pt, status, max_count, epsilon, iters_out);
     else
 #endif
@@ -571,14 +771,24 @@ __device__ __forceinline__ float orb_point(const uint8_t* __restrict__ ext, cons
     const int cx = d_cv_round(pt.x * 1.0f), cy = d_cv_round(pt.y * 1.0f);
     const uint8_t* center = ext + (ptrdiff_t)(cy + B) * step + cx + B;
     int m10 = 0, m01 = 0;
-    for (int p = lane; p < 31 * 31; p += 64) {
-        int v = p / 31 - 15, u = p - (v + 15) * 31 - 15;
-        int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= k_orb_umax[av]) {
-            int val = center[v * step + u];
-            m10 += u * val; m01 += v * val;
-        }
+    // The 31 x 31 square around the point, 16 pixels per lane, ALL loads issued before the first is used: as a loop with the disc test
+    // (a table read) in front of each pixel read it was two dependent memory round trips per trip, fifteen trips - 6-9 us, the longest
+    // chain of the whole LK launch (the descriptor wavefront, not the reverse pass, was what the block waited for; round 6 spans).
+    // The half-widths of the disc's rows (k_orb_umax) come from a packed constant; pixels outside the disc are read and not counted.
+    const unsigned long long umax_nibbles = 0x3689ABCDDEEEFFFFull;            // nibble |v| = umax[|v|] = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
+    int val[16], uu[16], vv[16]; bool in[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int pidx = lane + 64 * k;
+        const int pc = pidx < 31 * 31 ? pidx : 31 * 31 - 1;
+        const int vrow = pc / 31;
+        vv[k] = vrow - 15; uu[k] = pc - vrow * 31 - 15;
+        const int av = vv[k] < 0 ? -vv[k] : vv[k], au = uu[k] < 0 ? -uu[k] : uu[k];
+        in[k] = pidx < 31 * 31 && au <= (int)((umax_nibbles >> (4 * av)) & 0xF);
+        val[k] = center[vv[k] * step + uu[k]];
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { m10 += in[k] ? uu[k] * val[k] : 0; m01 += in[k] ? vv[k] * val[k] : 0; }
     m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
     const float angle = d_fast_atan2((float)m01, (float)m10);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);

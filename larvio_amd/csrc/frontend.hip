@@ -386,6 +386,9 @@ __device__ __forceinline__ lvk_pt2f apply_h(const HMat& H, lvk_pt2f p)
 // wavefront also undistorts the point pair (K -> K, what findFundamentalMat is fed, :701-712 / :932-943) into w_und[2p], [2p+1]:
 // two sequential double-precision fixed-point loops per point that the one-workgroup commit kernel would otherwise run for
 // every point of its set (24 us of its 120 at 2000 tracks).
+#ifdef LVK_LK_TIMING
+static __device__ unsigned long long g_lk_span[4096][4];     // per block: cycles entry -> forward done, -> reverse done, -> end; 100 MHz ticks entry -> end
+#endif
 template <int WIN, int VAR>
 __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
                                                    HMat H, int width, int height, int max_count, double epsilon,
@@ -399,6 +402,10 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
     __shared__ int s_st, s_dist;
     __shared__ __attribute__((aligned(16))) unsigned long long s_acc[4];
     const int p = blockIdx.x;
+#ifdef LVK_LK_TIMING
+    const unsigned long long lkt_c0 = clock64(), lkt_w0 = wall_clock64();
+    unsigned long long lkt_c1 = 0, lkt_c2 = 0;
+#endif
     if (p >= *n_ptr) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_levels = prev.n_levels < next.n_levels ? prev.n_levels : next.n_levels;
@@ -414,6 +421,9 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
         its = lk_point<WIN, VAR>(prev, next, n_levels, pp, np, st, max_count, epsilon, nullptr, acc);
         if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
         if (lane == 0) { s_np = np; s_st = st; }
+#ifdef LVK_LK_TIMING
+        lkt_c1 = clock64();
+#endif
     } else {
         if (is_new) {
             orb_point(prv_ext, prv_blur, step, pp, dp);
@@ -428,7 +438,7 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
         if (st) {
             lvk_pt2f back = pp;
             int sr = 1;
-            its += lk_point<WIN, VAR>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr, acc);
+            its += lk_point<WIN, VAR, 1>(next, prev, n_levels, np, back, sr, max_count, epsilon, nullptr, acc);
             passes = 2;
             if (sr) {
                 if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
@@ -440,6 +450,9 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
             }
             if (!sr) code = ST_REV;
         }
+#ifdef LVK_LK_TIMING
+        lkt_c2 = clock64();
+#endif
     } else if (s_st) {
         unsigned long long dc[4];
         orb_point(cur_ext, cur_blur, step, s_np, dc);
@@ -452,6 +465,106 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
         w_curr[p] = np; w_status[p] = (uint8_t)code;
         atomicAdd(&dev->lk_point_levels, (unsigned long long)(passes * n_levels));
         atomicAdd(&dev->lk_iterations, (unsigned long long)its);
+#ifdef LVK_LK_TIMING
+        if (p < 4096) { g_lk_span[p][0] = lkt_c1 - lkt_c0; g_lk_span[p][1] = lkt_c2 - lkt_c0; g_lk_span[p][2] = clock64() - lkt_c0; g_lk_span[p][3] = wall_clock64() - lkt_w0; }
+#endif
+    }
+}
+
+// The same stages with the track's work spread over FIVE wavefronts (LK variant 2, fe_track_dev.h): wavefront 0 owns the track and
+// only iterates; wavefronts 1-3 build the levels' templates of a pass at once (level w - 1, w + 2, ...) before it starts - forward: from
+// the point in the previous image, known at launch; reverse: from the forward result - and wavefront 4 is the descriptor / undistortion
+// wavefront of k_fe_lk_both.  Four block barriers, every wavefront passes each of them.
+template <int WIN>
+__global__ void __launch_bounds__(320) k_fe_lk_pipe(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
+                                                   HMat H, int width, int height, int max_count, double epsilon,
+                                                   lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev,
+                                                   const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
+                                                   const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur,
+                                                   const unsigned long long* __restrict__ stored_desc /*old*/, unsigned long long* __restrict__ w_desc /*new: out*/, int is_new,
+                                                   CamParams cam, lvk_pt2f* __restrict__ w_und)
+{
+    static_assert(WIN == 21, "row-segment layout");
+    __shared__ lvk_pt2f s_np;
+    __shared__ int s_st, s_dist;
+    __shared__ __attribute__((aligned(16))) unsigned long long s_acc[4][4];
+    __shared__ __attribute__((aligned(16))) LkTplLevel s_tpl[LK_PIPE_MAX_LEVELS];
+    const int p = blockIdx.x;
+#ifdef LVK_LK_TIMING
+    const unsigned long long lkt_c0 = clock64(), lkt_w0 = wall_clock64();
+    unsigned long long lkt_c1 = 0, lkt_c2 = 0;
+#endif
+    if (p >= *n_ptr) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_levels = prev.n_levels < next.n_levels ? prev.n_levels : next.n_levels;
+    const int step = width + 2 * LVK_ORB_BORDER;
+    const lvk_pt2f pp = src_pts[p];
+    lvk_pt2f np = pp;
+    int st = 1, its = 0;
+    unsigned long long dp[4] = {0, 0, 0, 0};
+    LkLdsAcc acc; acc.off = 0; acc.prev[0] = acc.prev[1] = acc.prev[2] = 0;
+    if (wave < 4) acc = lk_acc_init(s_acc[wave]);
+    // ---- before the forward pass: its templates, the gyro-predicted start, the previous-image descriptor of a new point
+    if (wave == 0) np = apply_h(H, pp);
+    else if (wave < 4) { for (int level = wave - 1; level < n_levels; level += 3) lk_tpl_build21(prev, level, pp, s_tpl[level], acc); }
+    else {
+        if (is_new) {
+            orb_point(prv_ext, prv_blur, step, pp, dp);
+            if (lane == 0) { unsigned long long* o = w_desc + (size_t)p * 4; o[0] = dp[0]; o[1] = dp[1]; o[2] = dp[2]; o[3] = dp[3]; }
+        }
+        if (lane == 0) w_und[2 * (size_t)p] = undistort_point(pp, cam, cam.intr);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        its = lk_pass_iterate21(next, n_levels, s_tpl, np, st, max_count, epsilon, acc);
+        if (st && (np.y < 0 || np.y > height - 1 || np.x < 0 || np.x > width - 1)) st = 0;
+        if (lane == 0) { s_np = np; s_st = st; }
+#ifdef LVK_LK_TIMING
+        lkt_c1 = clock64();
+#endif
+    }
+    __syncthreads();
+    const int fwd_ok = s_st;
+    const lvk_pt2f fnp = s_np;
+    // ---- before the reverse pass: its templates, from the point the forward pass found in the current image
+    if (fwd_ok && wave >= 1 && wave < 4) { for (int level = wave - 1; level < n_levels; level += 3) lk_tpl_build21(next, level, fnp, s_tpl[level], acc); }
+    __syncthreads();
+    int code = ST_FWD, passes = 1;
+    if (wave == 0) {
+        code = st ? ST_ALIVE : ST_FWD;
+        if (st) {
+            lvk_pt2f back = pp;
+            int sr = 1;
+            its += lk_pass_iterate21(prev, n_levels, s_tpl, back, sr, max_count, epsilon, acc);
+            passes = 2;
+            if (sr) {
+                if (back.y < 0 || back.y > height - 1 || back.x < 0 || back.x > width - 1) sr = 0;
+                else {
+                    float dx = back.x - pp.x, dy = back.y - pp.y;
+                    float dis = (float)sqrt((double)dx * dx + (double)dy * dy);      // cv::norm(Point2f) is double
+                    if (dis > 1) sr = 0;
+                }
+            }
+            if (!sr) code = ST_REV;
+        }
+#ifdef LVK_LK_TIMING
+        lkt_c2 = clock64();
+#endif
+    } else if (wave == 4 && fwd_ok) {
+        unsigned long long dc[4];
+        orb_point(cur_ext, cur_blur, step, fnp, dc);
+        const int dist = is_new ? hamming256_u64(dc, dp) : hamming256_u64(dc, stored_desc + (size_t)p * 4);
+        if (lane == 0) { s_dist = dist; w_und[2 * (size_t)p + 1] = undistort_point(fnp, cam, cam.intr); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (code == ST_ALIVE && s_dist > 58) code = ST_ORB;
+        w_curr[p] = np; w_status[p] = (uint8_t)code;
+        atomicAdd(&dev->lk_point_levels, (unsigned long long)(passes * n_levels));
+        atomicAdd(&dev->lk_iterations, (unsigned long long)its);
+#ifdef LVK_LK_TIMING
+        if (p < 4096) { g_lk_span[p][0] = lkt_c1 - lkt_c0; g_lk_span[p][1] = lkt_c2 - lkt_c0; g_lk_span[p][2] = clock64() - lkt_c0; g_lk_span[p][3] = wall_clock64() - lkt_w0; }
+#endif
     }
 }
 
@@ -737,14 +850,22 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
     const int W = fe->cfg.width, Hh = fe->cfg.height;
     if (fe->pyr_event) hipStreamWaitEvent(s, fe->ev_orb, 0);      // the frame start waited for the pyramid only: the ORB planes (read by the kernel's second wavefront) follow it on the image stream
     ProfScope ps(fe, 2, s);
-    if (WIN == 21 && lvk_lk_variant() == 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN, 0>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
-                           (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
-                           fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN, 1>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
-                           (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
-                           fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
+#define LVK_LK_LAUNCH(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_both<WIN, V>), dim3(grid), dim3(128), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev, \
+                           (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new, \
+                           fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und)
+    int var = WIN == 21 ? lvk_lk_variant() : 1;
+    if (var < 0) var = grid <= LVK_LK_PIPE_MAX_TRACKS ? 2 : 1;
+    if constexpr (WIN == 21) {
+        if (var == 2 && pv.n_levels <= LK_PIPE_MAX_LEVELS && cv.n_levels <= LK_PIPE_MAX_LEVELS) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_pipe<21>), dim3(grid), dim3(320), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
+                               (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
+                               fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
+            return;
+        }
+    }
+    if (var == 0) LVK_LK_LAUNCH(0);
+    else LVK_LK_LAUNCH(1);
+#undef LVK_LK_LAUNCH
 }
 
 static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt2f* src_pts, const int* n_ptr, const HMat& H, lvk_pt2f* w_curr, uint8_t* w_status,
@@ -784,6 +905,9 @@ static lvk_status commit(lvk_frontend* fe, int mode, const lvk_pt2f* src_pts, co
 
 lvk_context* lvk_frontend_context(lvk_frontend* fe) { return fe ? fe->ctx : nullptr; }
 
+#ifdef LVK_LK_TIMING
+extern "C" void lvk_debug_lk_ticks(unsigned long long* out, unsigned long long* span) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lk_tick), sizeof(unsigned long long) * 4096 * 12); hipMemcpyFromSymbol(span, HIP_SYMBOL(g_lk_span), sizeof(unsigned long long) * 4096 * 4); }
+#endif
 #ifdef LVK_FM_TIMING
 extern "C" void lvk_debug_fm_ticks(unsigned long long* out) { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fm_tick), sizeof(unsigned long long) * 32); }
 #endif

@@ -144,10 +144,13 @@ lvk_status lvk_set_error(lvk_context* ctx, lvk_status code, const char* fmt, ...
 #define BE_TICK_GETTER(fn, arr)
 #endif
 
-// LK kernel variant (fe_track_dev.h): LVK_LK_VARIANT in the environment, read once per process; default 1
+// LK kernel variant (fe_track_dev.h): LVK_LK_VARIANT in the environment (0, 1, 2), read once per process; unset = -1 = the library chooses
+// (frame path: the five-wavefront kernel up to LVK_LK_PIPE_MAX_TRACKS track slots, the two-wavefront one above - at 2000 tracks five
+// wavefronts and 12 KB of LDS per track no longer fit the chip in one round: 100 us against 61, profiles/r6_h_lk_pipe_ab.json)
+#define LVK_LK_PIPE_MAX_TRACKS 600
 inline int lvk_lk_variant()
 {
-    static const int v = [] { const char* e = getenv("LVK_LK_VARIANT"); const int x = e ? atoi(e) : 1; return x < 0 || x > 1 ? 1 : x; }();
+    static const int v = [] { const char* e = getenv("LVK_LK_VARIANT"); const int x = e ? atoi(e) : -1; return x < -1 || x > 2 ? -1 : x; }();
     return v;
 }
 
