@@ -766,6 +766,9 @@ def main():
         metric = "VIO frames/sec (%dx%d, %d live tracks, %d-clone window)" % (wl["cam"]["width"], wl["cam"]["height"], live, n_clones)
         out = {"metric": metric, "value": round(value, 2), "unit": "frames/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(m["elapsed"] / K * 1e3, 4),
+               "timed_region_ms": round(m["elapsed"] * 1e3, 3),
+               "timed_region_note": "K frames fed + every queued filter update drained, between two barrier + synchronize pairs; with few steps the region is mostly pipeline "
+                                    "fill and drain (one update is ~0.2 ms: at --steps 20 the region is ~2 ms and the value ~10 %% below the 500-step one)",
                "p50_ms_per_frame": pct(e2e, 50), "p95_ms_per_frame": pct(e2e, 95),
                "p50_ms_frame_without_message": pct(e2e[~mm], 50), "p50_ms_frame_with_message": pct(e2e[mm], 50), "p95_ms_frame_with_message": pct(e2e[mm], 95),
                "latency_definition": "image-in -> state-out per frame: front-end completion for frames without a feature message, the end of the "
