@@ -421,6 +421,115 @@ __device__ __forceinline__ void chol32_inv_mfma(double (*D)[CP_NB + 1], double (
     __builtin_amdgcn_wave_barrier();
 }
 
+// Variant 2 of the block above (round 6; built, measured, NOT the default - LVK_CHOL_VARIANT=2 selects it): TWO pivots per step.  What a pivot costs is
+// a dependent chain - read the pivot, 1/sqrt of it (a seed and two coupled refinements), scale its row, rank-1 update in the matrix core -
+// and the next pivot cannot start its 1/sqrt before that update's entry is known: 178 ns per pivot, 5.7 us per 32-pivot block
+// (profiles/r4_h_be_ticks.json).  For the leading 2 x 2 block [a b; b c] of what is left, both reciprocal roots come from numbers that are
+// known NOW: 1/L11 = rsqrt(a) and 1/L22 = rsqrt(a c - b^2) * (a * rsqrt(a)) - two chains side by side instead of one after the other.
+// Rows j and j + 1 of a tile live in lane groups j & 3 and (j & 3) + 1 of the SAME register (j even), which is where the matrix core
+// wants K-slots j & 3 and (j & 3) + 1: v = [L[:, j] in group gj | L[:, j+1] in group gj + 1] makes the two rank-1 updates ONE MFMA per
+// tile.  Column j + 1 needs column j in the neighbouring lane group, L[c][j+1] = (A[c][j+1] - L[j+1][j] L[c][j]) / L22: one
+// v_permlane16_swap_b32 per 32-bit half (gfx950: swaps the odd 16-lane rows of one operand with the even rows of the other; with the same
+// value in both, row 2k is copied into row 2k + 1 - tools/gpu/permlane_probe.hip).  The inverse's rows follow the same pattern.
+// Rounding differs from the single-pivot chain in the last bits (a c - b^2 instead of c - (b / sqrt a)^2, and the look-ahead entries
+// are formed in registers); parity with the oracle's update is asked at 1e-5 and measured at 1e-9 either way (78 back-end tests + smoke).
+// MEASURED (profiles/r6_k_chol_two_pivot_ab.json, r6_l_be_ticks_chol_variant*.json): no gain - 5.2 us per 32-pivot block either way,
+// k_chol_fused 27.0 against 26.3 us.  The 40 matrix-core instructions it sheds per block are paid back by ~400 vector instructions (the
+// second 1/sqrt chain, the look-ahead's seven 64-bit v_readlane pairs, the lane-group moves): the block is paced by instruction ISSUE
+// on its one wavefront (~1450 instructions per block in both forms), not by the depth of the pivot chain.
+__device__ __forceinline__ double row_even_to_odd_f64(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+__device__ __forceinline__ void chol32_inv_mfma2(double (*D)[CP_NB + 1], double (*Y)[CP_NB + 1], int nb, int lane, int* __restrict__ info, int j0, bool report)
+{
+    const int c = lane & 15, g = lane >> 4;
+    d4 a00, a01, a11, y00, y11, lop;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a00[r] = D[g + 4 * r][c];
+        a01[r] = D[16 + c][g + 4 * r];
+        a11[r] = D[16 + g + 4 * r][16 + c];
+        y00[r] = (g + 4 * r == c) ? 1.0 : 0.0; y11[r] = y00[r]; lop[r] = 0.;
+    }
+    int first_bad = -1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        d4& aa = half ? a11 : a00; d4& yy = half ? y11 : y00;
+        // the leading 2 x 2 block of the half: [pa pb; pb pc]
+        double pa = readlane_f64(aa[0], 0), pb = readlane_f64(aa[0], 16 + 0), pc = readlane_f64(aa[0], 16 + 1);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            // nb is the number of real rows of the 32-row block; beyond it D is the identity and nothing changes (see the single-pivot variant)
+            if (16 * half + j >= nb) continue;
+            const int q = j >> 2, gj = j & 3;                             // gj is 0 or 2
+            const bool ok1 = pa > 0.;
+            first_bad = (!ok1 && first_bad < 0) ? 16 * half + j : first_bad;
+            const double a_ = ok1 ? pa : 1.0;                             // a pivot that is not positive is replaced by 1 (as in the single-pivot chain)
+            const double b_ = pb;
+            const double det = __builtin_fma(a_, pc, -(b_ * b_));
+            const bool real2 = 16 * half + j + 1 < nb;                     // an odd nb: the second pivot of the last pair is identity padding (b = 0, c = 1: left exactly alone)
+            const bool ok2 = det > 0.;
+            first_bad = (!ok2 && real2 && first_bad < 0) ? 16 * half + j + 1 : first_bad;
+            const double det_ = ok2 ? det : a_;                           // L22 = 1 for a pivot that is not positive
+            const double rinv1 = rsqrt_goldschmidt(a_);
+            const double rdet = rsqrt_goldschmidt(det_);
+            const double l21 = real2 ? b_ * rinv1 : 0.0;                  // L[j+1][j]
+            const double inv22 = real2 ? rdet * (a_ * rinv1) : 1.0;       // 1 / L[j+1][j+1] = sqrt(a) / sqrt(a c - b^2)
+            const bool r1 = g == gj, r2 = g == gj + 1;
+            // column j in group gj, column j + 1 in group gj + 1 (both from register q: rows j and j + 1 of the tile, by symmetry its columns)
+            const double v1 = (r1 && c >= j) ? aa[q] * rinv1 : 0.0;
+            const double v1n = row_even_to_odd_f64(v1);                   // column j, seen from group gj + 1
+            const double v2 = (r2 && real2 && c >= j + 1) ? __builtin_fma(-l21, v1n, aa[q]) * inv22 : 0.0;
+            const double v = r1 ? v1 : v2;                                // zero outside the two groups
+            if (j < 14) {
+                // the next pair's 2 x 2 block from registers, while the rank-2 update is in the matrix core
+                const int n0 = j + 2, n1 = j + 3;
+                const double x0 = readlane_f64(v, 16 * gj + n0), x1 = readlane_f64(v, 16 * gj + n1);                // L[n0][j], L[n1][j]
+                const double z0 = readlane_f64(v, 16 * (gj + 1) + n0), z1 = readlane_f64(v, 16 * (gj + 1) + n1);    // L[n0][j+1], L[n1][j+1]
+                const double t00 = readlane_f64(aa[n0 >> 2], 16 * (n0 & 3) + n0), t10 = readlane_f64(aa[n0 >> 2], 16 * (n0 & 3) + n1),
+                             t11 = readlane_f64(aa[n1 >> 2], 16 * (n1 & 3) + n1);
+                pa = __builtin_fma(-z0, z0, __builtin_fma(-x0, x0, t00));
+                pb = __builtin_fma(-z1, z0, __builtin_fma(-x1, x0, t10));
+                pc = __builtin_fma(-z1, z1, __builtin_fma(-x1, x1, t11));
+            }
+            aa = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, v, aa, 0, 0, 0);
+            if (!half) {
+                const double u1 = r1 ? a01[q] * rinv1 : 0.0;                                      // L[16 + c][j]
+                const double u1n = row_even_to_odd_f64(u1);
+                const double u2 = r2 ? __builtin_fma(-l21, u1n, a01[q]) * inv22 : 0.0;            // L[16 + c][j + 1]
+                const double u = r1 ? u1 : u2;
+                a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(-v, u, a01, 0, 0, 0);
+                lop[q] = (r1 || r2) ? u : lop[q];
+            }
+            // the inverse: row j scaled, row j + 1 = (row j + 1 - L21 row j) / L22, rows below minus their two multiples
+            const double y1 = r1 ? yy[q] * rinv1 : 0.0;
+            const double y1n = row_even_to_odd_f64(y1);
+            const double y2 = r2 ? __builtin_fma(-l21, y1n, yy[q]) * inv22 : 0.0;
+            yy[q] = r1 ? y1 : (r2 ? y2 : yy[q]);
+            const double vm = (c > j + 1) ? v : 0.0, yb = (r1 || r2) ? yy[q] : 0.0;
+            yy = __builtin_amdgcn_mfma_f64_16x16x4f64(-vm, yb, yy, 0, 0, 0);
+            if (!half && gj == 2) a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-lop[q], lop[q], a11, 0, 0, 0);
+        }
+    }
+    if (first_bad >= 0 && report && lane == 0 && info[0] == 0) info[0] = j0 + first_bad + 1;
+    d4 tt = {0., 0., 0., 0.};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[q], y00[q], tt, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Y[g + 4 * r][c] = y00[r]; Y[16 + g + 4 * r][16 + c] = y11[r]; Y[g + 4 * r][16 + c] = 0.; }
+    __builtin_amdgcn_wave_barrier();
+    d4 yl = {0., 0., 0., 0.};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yl = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[16 + c][16 + 4 * q + g], tt[q], yl, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y[16 + g + 4 * r][c] = -yl[r];
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------- fused Cholesky + solve, m <= 160: ONE launch
 // The per-panel launches above spend ~19 us per 32 columns, of which only a few us are the dependent pivot chain of the diagonal block;
 // the rest is launch latency, first-touch trips to the memory side and the left-looking re-read of S.  Here workgroup 0 keeps the whole
@@ -504,6 +613,7 @@ __device__ __forceinline__ void cf_deferred(cf_blk* Sb, cf_blk& Yp, int p, int n
 // passes the block of S to the RIGHT of the diagonal block being factored (rows 0..m-1, the columns of the rows still to come), so
 // that the launch also produces L21^T = L11^-1 A21^T for a matrix taller than 160 rows (launch_chol_solve).  row0 = the first row
 // of this diagonal block in the whole matrix (error reporting).
+template <int CHV>      // 1: one pivot per step (chol32_inv_mfma, the default), 2: two (chol32_inv_mfma2; LVK_CHOL_VARIANT=2)
 __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int lds_, int m, double* __restrict__ B, int ldb, int nbcols,
                                                    double* __restrict__ B2, int ldb2, int nbcols2, int row0,
                                                    double* __restrict__ Yg, int* __restrict__ flag, int base, int* __restrict__ info)
@@ -545,7 +655,11 @@ __global__ void __launch_bounds__(256) k_chol_fused(double* __restrict__ S, int 
         for (int p = 0; p < nblk; ++p) {
             cf_blk& Yi = Yb[p & 1];
             // ---- C1
-            if (wave == 0) { chol32_inv_mfma(Sb[cf_idx(p, p)], Yi, min(CP_NB, m - 32 * p), lane, info, row0 + 32 * p, true); BE_TICK(g_la_tick, true, 24 + 3 * p); }
+            if (wave == 0) {
+                if constexpr (CHV == 2) chol32_inv_mfma2(Sb[cf_idx(p, p)], Yi, min(CP_NB, m - 32 * p), lane, info, row0 + 32 * p, true);
+                else chol32_inv_mfma(Sb[cf_idx(p, p)], Yi, min(CP_NB, m - 32 * p), lane, info, row0 + 32 * p, true);
+                BE_TICK(g_la_tick, true, 24 + 3 * p);
+            }
             else if (p > 0) cf_deferred(Sb, Yb[(p - 1) & 1], p - 1, nblk, m, S, lds_, Yg, flag, base, wave, lane);
             __syncthreads();
             BE_TICK(g_la_tick, true, 25 + 3 * p);
@@ -674,14 +788,17 @@ static lvk_status launch_chol_solve(lvk_context* ctx, double* S, int lds_, int m
     // because of their LDS (144 KB of the CU's 160: the launch has one size, the larger of the two roles'); the factor workgroup
     // never waits for anybody, so solvers that were dispatched ahead of it only spin until it gets a CU - no ordering assumption
     // is needed for progress, only for speed.
-    LVK_LDS_OPTIN(ctx, 8, k_chol_fused, shm);
+    static const int chv = [] { const char* e = getenv("LVK_CHOL_VARIANT"); return (e && atoi(e) == 2) ? 2 : 1; }();
+    if (chv == 2) LVK_LDS_OPTIN(ctx, 8, k_chol_fused<2>, shm); else LVK_LDS_OPTIN(ctx, 13, k_chol_fused<1>, shm);
     for (int off = 0; off < m; off += MB) {
         const int mb = (m - off) < MB ? (m - off) : MB, rest = m - off - mb;
         double* S11 = S + (size_t)off * lds_ + off; double* B1 = B + (size_t)off * ldb;
         double* S12 = S11 + mb;                       // rows off..off+mb-1, columns off+mb..m-1: A21^T
         const int base = 8 * ctx->chol_epoch++;
-        hipLaunchKernelGGL(k_chol_fused, dim3(1 + (nbcols + 63) / 64 + (rest + 63) / 64), dim3(256), shm, s, S11, lds_, mb, B1, ldb, nbcols,
-                           S12, lds_, rest, off, (double*)ws, flag, base, info);
+        if (chv == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_fused<2>), dim3(1 + (nbcols + 63) / 64 + (rest + 63) / 64), dim3(256), shm, s, S11, lds_, mb, B1, ldb, nbcols,
+                                         S12, lds_, rest, off, (double*)ws, flag, base, info);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chol_fused<1>), dim3(1 + (nbcols + 63) / 64 + (rest + 63) / 64), dim3(256), shm, s, S11, lds_, mb, B1, ldb, nbcols,
+                                S12, lds_, rest, off, (double*)ws, flag, base, info);
         LVK_LAUNCH_CHECK(ctx);
         if (rest > 0) {
             double* S22 = S + (size_t)(off + mb) * lds_ + off + mb; double* B2 = B + (size_t)(off + mb) * ldb;
