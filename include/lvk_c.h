@@ -57,7 +57,8 @@ typedef struct {
  * streams share queues: -17 % frames/s), HIP_FORCE_DEV_KERNARG=1 (kernel arguments in device memory), and - opt-in - the calling
  * thread and every thread started after it bound to the physical cores of one L3 group of its socket (local_rank picks the group).
  * Variables already set by the user are respected.  Call it FIRST in main(), before any HIP call of the process; returns the flags
- * that took effect.  lvk_context_create applies LVK_RT_DEFAULT by itself (unless LVK_RUNTIME_ENV=0), which suffices when the library
+ * that took effect (a variable the user had set, or a call after this library has already initialised the runtime, reports nothing
+ * for that flag; the environment is process-wide state: call it before other threads exist).  lvk_context_create applies LVK_RT_DEFAULT by itself (unless LVK_RUNTIME_ENV=0), which suffices when the library
  * is what makes the process's first HIP call.  No reference counterpart: the reference has no device. */
 #define LVK_RT_HW_QUEUES   1u
 #define LVK_RT_DEV_KERNARG 2u
@@ -260,7 +261,10 @@ typedef struct {
 lvk_status lvk_ekf_create(lvk_context* ctx, const lvk_ekf_config* cfg, lvk_ekf** out);
 void       lvk_ekf_destroy(lvk_ekf* e);
 /* LarVio::processFeatures (larvio.cpp:363-461).  h_imu is the caller's buffer; *n_consumed = how many leading samples the
- * reference would erase from it (larvio.cpp:511-512, StaticInitializer.cpp:146-147); *updated = the bool it returns. */
+ * reference would erase from it (larvio.cpp:511-512, StaticInitializer.cpp:146-147); *updated = the bool it returns.
+ * The call returns when the HOST state (lvk_ekf_get_state, clones, features) is final; the covariance's last launches (the pruning's
+ * gather) may still be queued on the context's stream - every entry point that reads the covariance synchronises first, and a device
+ * fault in those tail launches is reported by the next call on the handle. */
 lvk_status lvk_ekf_process(lvk_ekf* e, double ts, const lvk_feature_obs* h_feats, int n_feats,
                            const lvk_imu* h_imu, int n_imu, int* n_consumed, int* updated);
 /* The same update, deferred: the call returns as soon as what the caller needs from processFeatures is known - *n_consumed (the

@@ -1359,8 +1359,9 @@ static inline void grid_add(lvk_ekf* e, int code, int cells)
 // kernel (FJ_TRI_PENDING: a failed triangulation = a rejected job = zero rows, which leave the update unchanged), every candidate
 // row has its slot, and triangulation results, gate results and dx come back in ONE sync.  Same decisions, same rows, same update
 // as the general path below (larvio.cpp:1897-2005): only the order in which the host learns them differs.
-static lvk_status remove_lost_fast(lvk_ekf* e, const std::vector<long long>& ekf_ids)
+static lvk_status remove_lost_fast(lvk_ekf* e, const std::vector<long long>& ekf_ids, bool* fall_back)
 {
+    *fall_back = false;
     const lvk_ekf_config& c = e->cfg;
     struct Pick { Feature* f; bool lost; int tri; };
     std::vector<Pick> picks; std::vector<long long> invalid; std::vector<TriReq> reqs;
@@ -1382,6 +1383,13 @@ static lvk_status remove_lost_fast(lvk_ekf* e, const std::vector<long long>& ekf
     }
     for (long long id : invalid) e->map.erase(id);
     if (picks.empty() && ekf_ids.empty()) return LVK_OK;
+    {   // Every candidate keeps its row slots here, also the ones whose (pending) triangulation will fail - the general path drops those
+        // before it stacks.  If the slots could exceed the stacked-row capacity while the rows that survive might still fit, take the
+        // general path (two waits) instead of failing the handle with LVK_ERR_CAPACITY.
+        long bound = 2L * n_ekf; bool pending = false;
+        for (const Pick& pk : picks) { bound += 2L * (long)pk.f->obs.size() - 3; pending |= pk.tri >= 0; }
+        if (bound > (long)e->hrows && pending) { *fall_back = true; return LVK_OK; }
+    }
     const int N = e->N;
     std::vector<RowJob> jobs; jobs.reserve(ekf_ids.size() + picks.size());
     for (long long id : ekf_ids) { Feature& f = e->map[id]; RowJob r; r.f = &f; r.type = JOB_EKF_TRACKED; r.sids = {e->imu_id}; r.want_gate = true; r.dof = 2; jobs.push_back(r); }
@@ -1483,7 +1491,7 @@ static lvk_status remove_lost_features(lvk_ekf* e)
                 const int gcount = grid_occupancy(e, code, cells);
                 if (gcount < c.max_features_in_one_grid) { admission = true; break; }
             }
-        if (!admission) return remove_lost_fast(e, ekf_ids);
+        if (!admission) { bool fall_back = false; const lvk_status fs = remove_lost_fast(e, ekf_ids, &fall_back); if (!fall_back) return fs; }
     }
     // ---- pass 1: every triangulation the triage may ask for, batched on the device, then replayed in map order.
     //      (a) lost, not initialised: initializePosition.  (b) tracked long, not in state: the EKF branch wants

@@ -151,11 +151,16 @@ static bool bind_l3_group(int local_rank)
 // =========================================================================== context
 extern "C" {
 
+static std::atomic<bool> g_hip_touched{false};          // this library has made a HIP call in this process: the runtime has read its environment
 unsigned lvk_runtime_env(unsigned flags, int local_rank)
 {
     unsigned done = 0;
-    if (flags & LVK_RT_HW_QUEUES) { if (setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0) done |= LVK_RT_HW_QUEUES; }
-    if (flags & LVK_RT_DEV_KERNARG) { if (setenv("HIP_FORCE_DEV_KERNARG", "1", 0) == 0) done |= LVK_RT_DEV_KERNARG; }
+    // a flag is reported only if it can still take effect: the variable was not set by the user and the runtime has not been
+    // initialised through this library (a host application that initialised HIP itself is beyond what can be seen from here:
+    // lvk_c.h says "call it first in main()")
+    const bool early = !g_hip_touched.load();
+    if ((flags & LVK_RT_HW_QUEUES) && early && !getenv("GPU_MAX_HW_QUEUES")) { if (setenv("GPU_MAX_HW_QUEUES", "8", 0) == 0) done |= LVK_RT_HW_QUEUES; }
+    if ((flags & LVK_RT_DEV_KERNARG) && early && !getenv("HIP_FORCE_DEV_KERNARG")) { if (setenv("HIP_FORCE_DEV_KERNARG", "1", 0) == 0) done |= LVK_RT_DEV_KERNARG; }
     if (flags & LVK_RT_BIND_L3) { if (bind_l3_group(local_rank)) done |= LVK_RT_BIND_L3; }
     return done;
 }
@@ -215,6 +220,7 @@ lvk_status lvk_context_create(int device, lvk_context** out)
         } }
     }
     int count = 0;
+    g_hip_touched.store(true);
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LVK_ERR_DEVICE;   // no CPU fallback
     if (hipSetDevice(device) != hipSuccess) return LVK_ERR_DEVICE;
     // LVK_WAIT_POLICY=spin: keep waiting host threads spinning on the completion signal (the runtime's default spins for 100 us,
@@ -245,7 +251,10 @@ void lvk_context_destroy(lvk_context* ctx)
 lvk_status lvk_context_set_stream(lvk_context* ctx, void* hip_stream)
 {
     if (!ctx) return LVK_ERR_ARG;
-    if (ctx->own_stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    // whatever the objects of this context still have queued on the OLD stream (lvk_ekf_process returns with its tail launches
+    // outstanding) must not race what the next call queues on the new one: drain it, also when the caller owns it
+    if (ctx->stream) LVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
     else { LVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
     return LVK_OK;
