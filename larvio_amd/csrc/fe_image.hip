@@ -196,8 +196,25 @@ __global__ void k_level0_pad_ext(const uint8_t* __restrict__ src, int w, int h, 
 // Scharr plane of level l and the (padded) image of level l+1 in ONE launch: both read only level l, and a launch on the
 // frame's dependent chain costs ~7 us (kernel + inter-kernel barrier) whatever it computes.  Rows [0, h) of the grid are Scharr
 // rows, rows [h, h + dh + 2 pad) are rows of the next level (none when dh == 0).
+// pyrDown of one pixel of the NEXT level straight from this level (the 5 x 5 binomial, (sum + 128) >> 8; the caller has reflected x, y)
+__device__ __forceinline__ int d_pyr_down_px(const uint8_t* __restrict__ s0, int sstride, int x, int y)
+{
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint8_t* r = s0 + (ptrdiff_t)(2 * y - 2 + j) * sstride + (2 * x - 2);
+        int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
+        const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+        acc += wj * row;
+    }
+    return (acc + 128) >> 8;
+}
+// Rows of workgroups: [0, h) the Scharr plane of this level; [h, h + dh + 2 pad) the next level's padded image; and - when d1 is given
+// (the next level is the LAST one: round 6, one launch less per frame) - [.., + dh) the NEXT level's Scharr plane too, each of its nine
+// taps recomputed from this level (the next level's own pixels are being written by other workgroups of this very launch; the value of
+// a tap, reflect-101 about the next level's frame included, is the same expression: the same bits).
 __global__ void k_scharr_and_down(const uint8_t* __restrict__ s0, int w, int h, int sstride, int16_t* __restrict__ d0, int dstride,
-                                  int dw, int dh, uint8_t* __restrict__ dst, int pad, int nstride)
+                                  int dw, int dh, uint8_t* __restrict__ dst, int pad, int nstride, int16_t* __restrict__ d1, int dstride1)
 {
     const int gx = blockIdx.x * blockDim.x + threadIdx.x;
     if ((int)blockIdx.y < h) {
@@ -212,19 +229,25 @@ __global__ void k_scharr_and_down(const uint8_t* __restrict__ s0, int w, int h, 
         o.x = (short)(a_p - a_m);
         o.y = (short)((b_p + b_m) * 3 + b_c * 10);
         *reinterpret_cast<short2*>(d0 + (size_t)y * dstride + 2 * x) = o;
-    } else {
+    } else if ((int)blockIdx.y < h + dh + 2 * pad) {
         const int ex = gx, ey = blockIdx.y - h;
         if (ex >= dw + 2 * pad) return;
         int x = d_reflect101(ex - pad, dw), y = d_reflect101(ey - pad, dh);
-        int acc = 0;
+        dst[(size_t)ey * nstride + ex] = (uint8_t)d_pyr_down_px(s0, sstride, x, y);
+    } else {
+        const int x = gx, y = blockIdx.y - (h + dh + 2 * pad);
+        if (x >= dw) return;
+        int v[3][3];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint8_t* r = s0 + (ptrdiff_t)(2 * y - 2 + j) * sstride + (2 * x - 2);
-            int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
-            const int wj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
-            acc += wj * row;
-        }
-        dst[(size_t)ey * nstride + ex] = (uint8_t)((acc + 128) >> 8);
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[j][i] = d_pyr_down_px(s0, sstride, d_reflect101(x - 1 + i, dw), d_reflect101(y - 1 + j, dh));
+        int a_m = (v[0][0] + v[2][0]) * 3 + v[1][0] * 10, a_p = (v[0][2] + v[2][2]) * 3 + v[1][2] * 10;
+        int b_m = v[2][0] - v[0][0], b_c = v[2][1] - v[0][1], b_p = v[2][2] - v[0][2];
+        short2 o;
+        o.x = (short)(a_p - a_m);
+        o.y = (short)((b_p + b_m) * 3 + b_c * 10);
+        *reinterpret_cast<short2*>(d1 + (size_t)y * dstride1 + 2 * x) = o;
     }
 }
 
@@ -894,10 +917,14 @@ static lvk_status build_levels(lvk_context* ctx, lvk_pyramid* p)
         const uint8_t* s0 = p->img[l] + (size_t)p->pad * p->istride[l] + p->pad;
         int16_t* d0 = p->der[l] + (size_t)p->pad * p->dstride[l] + 2 * p->pad;
         const bool next = l + 1 < p->n_levels;
+        const bool last2 = next && l + 2 == p->n_levels;     // the next level is the last: its Scharr plane rides in this launch
         const int dw = next ? p->w[l + 1] : 0, dh = next ? p->h[l + 1] : 0;
         const int gx = std::max((p->w[l] + 255) / 256, next ? (dw + 2 * p->pad + 255) / 256 : 0);
-        hipLaunchKernelGGL(k_scharr_and_down, dim3(gx, p->h[l] + (next ? dh + 2 * p->pad : 0)), dim3(256), 0, ctx->stream,
-                           s0, p->w[l], p->h[l], p->istride[l], d0, p->dstride[l], dw, dh, next ? p->img[l + 1] : nullptr, p->pad, next ? p->istride[l + 1] : 0);
+        int16_t* d1 = last2 ? p->der[l + 1] + (size_t)p->pad * p->dstride[l + 1] + 2 * p->pad : nullptr;
+        hipLaunchKernelGGL(k_scharr_and_down, dim3(gx, p->h[l] + (next ? dh + 2 * p->pad : 0) + (last2 ? dh : 0)), dim3(256), 0, ctx->stream,
+                           s0, p->w[l], p->h[l], p->istride[l], d0, p->dstride[l], dw, dh, next ? p->img[l + 1] : nullptr, p->pad, next ? p->istride[l + 1] : 0,
+                           d1, last2 ? p->dstride[l + 1] : 0);
+        if (last2) break;
     }
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;

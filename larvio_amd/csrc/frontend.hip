@@ -833,8 +833,10 @@ template <typename T> static bool dalloc(T** p, size_t n) { return hipMalloc((vo
 
 // host-side phase tracer of the calling thread (LVK_FE_TRACE=1; printed by lvk_frontend_destroy): where the caller's time per frame goes
 #include <chrono>
-enum { FT_SLOT_WAIT, FT_STAGE_COPY, FT_UPLOAD, FT_IMAGE_LAUNCH, FT_PREDICT, FT_TRACK_LAUNCH, FT_COMMIT_LAUNCH, FT_PUBLISH, FT_DETECT, FT_END, FT_N };
-static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: event queries + 6 launches", "frame checks + predict_homography",
+enum { FT_SLOT_WAIT, FT_STAGE_COPY, FT_UPLOAD, FT_IMAGE_LAUNCH, FT_OUTSIDE, FT_FRAME_WAITS, FT_PREDICT, FT_TRACK_LAUNCH, FT_COMMIT_LAUNCH, FT_PUBLISH, FT_DETECT, FT_END, FT_N };
+static const char* const FT_NAMES[FT_N] = {"staging slot free (end-of-frame event of f-2)", "image -> pinned staging slot (memcpy)", "H2D copy command", "image stage: event queries + 5 launches",
+    "OUTSIDE the front-end: between lvk_frontend_begin and lvk_frontend_process of the frame (the pipelined caller's own submit logic and its wait for the erase count)",
+    "frame start: query / wait for the pyramid event (ev_pyr or ev_orb) + the side stream's wait for the previous frame's end event", "frame checks + predict_homography (host math)",
     "track chains: 2 launches + events", "commits: 2 launches + events", "message: slot + launch + event", "detection: 4 launches", "end-of-frame events + rotation"};
 struct FeTrace {
     bool on = false; double acc[FT_N] = {0}; long n = 0; std::chrono::steady_clock::time_point last;
@@ -1280,6 +1282,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
     if (fe->image_done && fe->image_done_ts != ts)
         return lvk_set_error(ctx, LVK_ERR_ARG, "lvk_frontend_process(t = %.6f) after lvk_frontend_begin(t = %.6f): the queued image stage belongs to another frame", ts, fe->image_done_ts);
     if (!fe->image_done) st = fe_image_stage(fe, img, false);
+    else FT(FT_OUTSIDE);                                 // (the stage was queued by lvk_frontend_begin: what lies between is the caller's)
     fe->image_done = false;
     if (st != LVK_OK) return st;
     hipStream_t S1 = ctx->stream, S2 = fe->side[0]->stream;
@@ -1289,6 +1292,7 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
     }
     // the side stream reads (new points, their count) and overwrites (wn_*) what the previous frame's commits on the main stream used
     if (fe->n_img >= 2) fe_wait_unless_done(fe, S2, fe->ev_end[fe->n_img & 1]);
+    FT(FT_FRAME_WAITS);
     fe->prof_take = fe->prof_stride <= 1 || fe->n_img % fe->prof_stride == 0;
     fe->last_msg_slot = -1;
     fe->curr_img_time = ts;
