@@ -629,9 +629,14 @@ static void cal_phi_calib(const lvk_ekf* e, double* Phi, double dt, const double
 
 // Phi_tot <- Phi Phi_tot ; Q_tot <- Phi Q_tot Phi^T + Q for one IMU sample, with the legacy dimension as a compile-time constant
 // (22, or 46 when the IMU intrinsics are calibrated) so that the short fixed-length loops unroll and vectorise.
+#ifndef LVK_COMPOSE_TIMING
+#define CT_DECL do { } while (0)
+#define CT(k) do { } while (0)
+#endif
 template <int L, bool CALIB>
 static void compose_transition(lvk_ekf* e, const double* Phi, double dtime)
 {
+    CT_DECL;
     double C[9]; quat_to_rot(e->s_old.q, C);
     double G[15 * 12]; memset(G, 0, sizeof G);                      // rows 15.. of G are zero
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { G[i * 12 + j] = -C[i * 3 + j]; G[(3 + i) * 12 + 3 + j] = -C[i * 3 + j]; }
@@ -646,22 +651,46 @@ static void compose_transition(lvk_ekf* e, const double* Phi, double dtime)
     constexpr int nnz = NNZ;
     // Every sum below runs over its summation index in ascending order, one element at a time, exactly as the plain triple loops
     // would; the loops are only nested so that the innermost one walks independent output elements (it vectorises, the dependent
-    // scalar reductions it replaces did not).
+    // scalar reductions it replaced did not).  Round 6: terms whose factor is an EXACT zero are not formed at all - of the 9 x 15 block of
+    // Phi that differs from the identity only ~70 entries are non-zero (skew-symmetric blocks, dt I, the identity's own diagonal; without
+    // calibration the theta-row's accelerometer-bias block is zero as a whole), G has two 3 x 3 blocks and six ones, and the rows 9..14 of
+    // Phi G are unit rows.  A sum without its zero terms is the same double (x + 0 = x); tests/host/imu_compose_check.hip holds this
+    // function to the dense recurrences bit for bit.  The IMU batch is host work on the filter's critical path (the GPU idles through it
+    // between two messages): 16.6 -> ~9 us per message of 20 samples.
+    // ---- the non-zeros of Phi's rows 0..8 (ascending column order per row, as (column slot q, value)); column lists for the right product
+    int rz_q[A][NNZ]; int rz_n[A];
+    for (int i = 0; i < A; ++i) { int n = 0; for (int q = 0; q < nnz; ++q) if (Phi[i * L + nzc[q]] != 0.0) rz_q[i][n++] = q; rz_n[i] = n; }
+    CT(0);
     double PG[B * 12], PGT[12 * B], Q[B * B], PhiT[NNZ * 12];
+    for (int q = 0; q < nnz; ++q) { for (int j = 0; j < A; ++j) PhiT[q * 12 + j] = Phi[j * L + nzc[q]]; PhiT[q * 12 + 9] = PhiT[q * 12 + 10] = PhiT[q * 12 + 11] = 0.0; }
+    // PG = Phi G (rows 0..8; rows 9..14 of Phi are identity rows: PG = G there).  G: -C in (0..2, 0..2) and (3..5, 3..5), ones at (9+i, 6+i), (12+i, 9+i)
     for (int i = 0; i < A; ++i) {
         double* pg = PG + i * 12;
-        for (int j = 0; j < 12; ++j) pg[j] = 0;
-        for (int k = 0; k < B; ++k) { const double a = Phi[i * L + k]; const double* g = G + k * 12; for (int j = 0; j < 12; ++j) pg[j] += a * g[j]; }
+        for (int j = 0; j < 3; ++j) {
+            double s0 = 0, s1 = 0;
+            for (int k = 0; k < 3; ++k) { s0 += Phi[i * L + k] * G[k * 12 + j]; s1 += Phi[i * L + 3 + k] * G[(3 + k) * 12 + 3 + j]; }
+            pg[j] = s0; pg[3 + j] = s1;
+            pg[6 + j] = 0.0 + Phi[i * L + 9 + j] * 1.0; pg[9 + j] = 0.0 + Phi[i * L + 12 + j] * 1.0;
+        }
     }
     for (int i = A; i < B; ++i) for (int j = 0; j < 12; ++j) PG[i * 12 + j] = G[i * 12 + j];
     for (int i = 0; i < B; ++i) for (int k = 0; k < 12; ++k) PGT[k * B + i] = PG[i * 12 + k];
-    for (int i = 0; i < B; ++i) {
+    CT(1);
+    // Q = (PG diag(Qc) PG^T) dt: rows / columns 9..14 of PG are unit rows (a single 1 at column 6 + (r - 9))
+    for (int i = 0; i < A; ++i) {
         double* qr = Q + i * B;
-        for (int j = 0; j < B; ++j) qr[j] = 0;
-        for (int k = 0; k < 12; ++k) { const double a = PG[i * 12 + k] * e->Qc[k]; const double* g = PGT + k * B; for (int j = 0; j < B; ++j) qr[j] += a * g[j]; }
+        for (int j = 0; j < A; ++j) qr[j] = 0;
+        for (int k = 0; k < 12; ++k) { const double a = PG[i * 12 + k] * e->Qc[k]; const double* g = PGT + k * B; for (int j = 0; j < A; ++j) qr[j] += a * g[j]; }
+        for (int j = A; j < B; ++j) { const int kj = 6 + (j - A); qr[j] = 0.0 + (PG[i * 12 + kj] * e->Qc[kj]) * 1.0; }
         for (int j = 0; j < B; ++j) qr[j] *= dtime;
     }
-    for (int q = 0; q < nnz; ++q) for (int j = 0; j < A; ++j) PhiT[q * 12 + j] = Phi[j * L + nzc[q]];
+    for (int i = A; i < B; ++i) {
+        double* qr = Q + i * B; const int ki = 6 + (i - A);
+        for (int j = 0; j < A; ++j) qr[j] = 0.0 + (1.0 * e->Qc[ki]) * PG[j * 12 + ki];
+        for (int j = A; j < B; ++j) qr[j] = (j == i) ? 0.0 + (1.0 * e->Qc[ki]) * 1.0 : 0.0;
+        for (int j = 0; j < B; ++j) qr[j] *= dtime;
+    }
+    CT(2);
     if (!e->have_prop) {
         memcpy(e->Phi_tot, Phi, sizeof(double) * L * L);
         memset(e->Q_tot, 0, sizeof(double) * L * L);
@@ -669,28 +698,47 @@ static void compose_transition(lvk_ekf* e, const double* Phi, double dtime)
         e->have_prop = true;
     } else {
         double T[A * LEG_MAX];
-        // Phi_tot <- Phi Phi_tot : only rows 0..8 change
-        for (int i = 0; i < A; ++i) {
-            double* t = T + i * L;
-            for (int j = 0; j < L; ++j) t[j] = 0;
-            for (int q = 0; q < nnz; ++q) { const int k = nzc[q]; const double a = Phi[i * L + k]; const double* x = e->Phi_tot + k * L; for (int j = 0; j < L; ++j) t[j] += a * x[j]; }
+        // Phi_tot <- Phi Phi_tot : only rows 0..8 change.  Rows 9.. of Phi_tot ARE identity rows (they start as Phi's and never change), so
+        // a non-zero Phi[i][k] with k >= 9 contributes Phi[i][k] * 1 to column k alone - after the dense part k < 9, which is its place
+        // in the ascending sum
+        // (k outermost: the nine rows' accumulators are independent chains the core overlaps; each element still sums over k ascending)
+        for (int e_ = 0; e_ < A * L; ++e_) T[e_] = 0;
+        for (int k = 0; k < A; ++k) {
+            const double* x = e->Phi_tot + k * L;
+            for (int i = 0; i < A; ++i) {
+                const double a = Phi[i * L + k];
+                if (a == 0.0) continue;
+                double* t = T + i * L;
+                for (int j = 0; j < L; ++j) t[j] += a * x[j];
+            }
         }
+        for (int i = 0; i < A; ++i) { double* t = T + i * L; for (int z = 0; z < rz_n[i]; ++z) { const int k = nzc[rz_q[i][z]]; if (k >= A) t[k] += Phi[i * L + k] * 1.0; } }
         memcpy(e->Phi_tot, T, sizeof(double) * A * L);
-        // Q_tot <- Phi Q_tot Phi^T + Q : rows 0..8 of (Phi Q_tot), then columns 0..8 of (. Phi^T)
-        for (int i = 0; i < A; ++i) {
-            double* t = T + i * L;
-            for (int j = 0; j < L; ++j) t[j] = 0;
-            for (int q = 0; q < nnz; ++q) { const int k = nzc[q]; const double a = Phi[i * L + k]; const double* x = e->Q_tot + k * L; for (int j = 0; j < L; ++j) t[j] += a * x[j]; }
+        CT(3);
+        // Q_tot <- Phi Q_tot Phi^T + Q.  Q_tot is zero outside its leading 15 x 15 block (rows 9.. of Phi are identity rows and G is zero
+        // below row 14), so only k < 15 and the first 15 columns / rows take part: rows 0..8 of (Phi Q_tot), then columns 0..8 of (. Phi^T)
+        for (int e_ = 0; e_ < A * 16; ++e_) T[e_] = 0;
+        for (int k = 0; k < B; ++k) {
+            const double* x = e->Q_tot + k * L;
+            for (int i = 0; i < A; ++i) {
+                const double a = Phi[i * L + k];
+                if (a == 0.0) continue;
+                double* t = T + i * 16;
+                for (int j = 0; j < 16; ++j) t[j] += a * x[j];          // (column 15 of Q_tot is zero: a full fourth vector instead of a tail)
+            }
         }
-        memcpy(e->Q_tot, T, sizeof(double) * A * L);
-        for (int i = 0; i < L; ++i) {
-            double u[A];
+        for (int i = 0; i < A; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * L + j] = T[i * 16 + j];
+        CT(4);
+        for (int i = 0; i < B; ++i) {
+            double u[12];                                  // three full AVX2 vectors: the rows of PhiT are padded with zeros to 12 (lanes 9..11 are not stored)
             double* t = e->Q_tot + i * L;
-            for (int j = 0; j < A; ++j) u[j] = 0;
-            for (int q = 0; q < nnz; ++q) { const double a = t[nzc[q]]; const double* ph = PhiT + q * 12; for (int j = 0; j < A; ++j) u[j] += a * ph[j]; }
+            for (int j = 0; j < 12; ++j) u[j] = 0;
+            for (int q = 0; q < 15; ++q) { const double a = t[q]; const double* ph = PhiT + q * 12; for (int j = 0; j < 12; ++j) u[j] += a * ph[j]; }
             for (int j = 0; j < A; ++j) t[j] = u[j];
         }
+        CT(5);
         for (int i = 0; i < B; ++i) for (int j = 0; j < B; ++j) e->Q_tot[i * L + j] += Q[i * B + j];
+        CT(6);
     }
 }
 
