@@ -33,7 +33,7 @@ public:
   bool processImage(const ImageDataPtr& msg, const std::vector<ImuData>& imu_msg_buffer, MonoCameraMeasurementPtr features);
 
   // Get publish image (image_processor.h:63-65): the last published frame as RGB with the tracked features marked
-  cv::Mat getVisualImg() { if (vis_pending) publishVisual(); return visual_img; }
+  cv::Mat getVisualImg() { vis_wanted = true; if (vis_pending) publishVisual(); return visual_img; }
 
   typedef boost::shared_ptr<ImageProcessor> Ptr;
   typedef boost::shared_ptr<const ImageProcessor> ConstPtr;
@@ -46,7 +46,8 @@ private:
   lvk_frontend* fe;
   std::vector<lvk_feature_obs> out;
   cv::Mat visual_img;
-  cv::Mat vis_src;               // the last published frame's image (shared with the caller's cv::Mat, as a cv::Mat copy is)
+  cv::Mat vis_src;               // the last published frame's image: a snapshot (own pixels) once somebody has asked for pictures, the caller's own cv::Mat before
+  bool vis_wanted = false, vis_shared = false;   // getVisualImg has been called at least once; vis_src still shares the caller's pixels
   bool vis_pending = false;      // a frame was published since visual_img was built
   long frames_seen = 0, vis_frame = 0;
 };

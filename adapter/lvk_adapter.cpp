@@ -63,11 +63,16 @@ bool ImageProcessor::processImage(const ImageDataPtr& msg, const std::vector<Imu
     if (n) std::memcpy(static_cast<void*>(features->features.data()), out.data(), sizeof(lvk_feature_obs) * (size_t)n);
     // publish() (:1131-1175) draws the frame on every publish; here the picture is built when somebody asks for it (getVisualImg):
     // a whole-image colour conversion and a read-back of the track table do not belong on the path to the filter
-    // The pixels are SNAPSHOT now (one copy into a buffer that is reused): `im` may wrap memory the caller frees or overwrites before
-    // getVisualImg is called (cv_bridge's toCvShare, a camera ring buffer); the reference draws at publish time, from the live image.
-    if (vis_src.rows == im.rows && vis_src.cols == im.cols && vis_src.type() == im.type() && vis_src.data != im.data && !vis_src.empty()) {
-        for (int y = 0; y < im.rows; ++y) std::memcpy(vis_src.ptr(y), im.ptr(y), (size_t)im.cols);
-    } else vis_src = im.clone();
+    // Once a driver has asked for a picture (getVisualImg), the pixels are SNAPSHOT here (one copy into a buffer that is reused): `im` may
+    // wrap memory the caller frees or overwrites before getVisualImg is called (cv_bridge's toCvShare, a camera ring buffer); the reference
+    // draws at publish time, from the live image.  A driver that never asks never pays the copy; the very first request is served from the
+    // caller's own cv::Mat, and only if no later frame has been processed since (publishVisual).
+    if (vis_wanted) {
+        if (!vis_shared && vis_src.rows == im.rows && vis_src.cols == im.cols && vis_src.type() == im.type() && vis_src.data != im.data && !vis_src.empty()) {
+            for (int y = 0; y < im.rows; ++y) std::memcpy(vis_src.ptr(y), im.ptr(y), (size_t)im.cols);
+        } else vis_src = im.clone();
+        vis_shared = false;
+    } else { vis_src = im; vis_shared = true; }
     vis_frame = frames_seen; vis_pending = true;
     return true;
 }
@@ -77,6 +82,7 @@ bool ImageProcessor::processImage(const ImageDataPtr& msg, const std::vector<Imu
 void ImageProcessor::publishVisual()
 {
     vis_pending = false;
+    if (vis_shared && frames_seen != vis_frame) { vis_src = cv::Mat(); vis_shared = false; }     // the caller's pixels of an older frame: not ours to read any more
     const cv::Mat& gray = vis_src;
     if (gray.empty()) return;
     cv::Mat rgb(gray.rows, gray.cols, CV_8UC3);
