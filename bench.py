@@ -726,7 +726,9 @@ def main():
         # ---- roofline of the dominant kernel family (pyramidal LK): algorithmic bytes per SURVEY §8d
         lk_bytes = m["lk_pl"] * (win + 3) ** 2 + m["lk_it"] * (win + 1) ** 2
         lk_ms, lk_timed = m["lk_prof"]                   # event-bracketed launches: those of every LK_EVENT_STRIDE-th frame
-        lk_launches = 2 * K                              # two launches per frame (old tracks, new points: fixed-capacity launches with device-side counts)
+        lk_var_env = os.environ.get("LVK_LK_VARIANT")
+        lk_merged = win == 21 and os.environ.get("LVK_LK_MERGED") == "1" and (lk_var_env == "2" or (lk_var_env not in ("0", "1") and wl["max_features"] <= 600))
+        lk_launches = (1 if lk_merged else 2) * K        # k_fe_lk_pipe carries both track sets (old tracks, new points) in ONE launch per frame; k_fe_lk_both: two (frontend.hip: lk_merged_ok)
         achieved = (lk_bytes / max(lk_launches, 1)) / (lk_ms / max(lk_timed, 1) * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         # HBM traffic per launch: not measurable inside this process (PMC needs rocprofv3) - taken from the committed counter pass
         # of this same command (profiles/*_pmc_fetch_size.csv; FETCH_SIZE corrected as profiles/README.md's calibration states)

@@ -484,21 +484,36 @@ __global__ void __launch_bounds__(128) k_fe_lk_both(PyrView prev, PyrView next, 
 // only iterates; wavefronts 1-3 build the levels' templates of a pass at once (level w - 1, w + 2, ...) before it starts - forward: from
 // the point in the previous image, known at launch; reverse: from the forward result - and wavefront 4 is the descriptor / undistortion
 // wavefront of k_fe_lk_both.  Four block barriers, every wavefront passes each of them.
+// One track set of a launch: the old tracks (trackFeatures) or the new points (trackNewFeatures).  The kernel can carry BOTH in one launch
+// (blocks [0, grid0) the first set, the rest the second; LVK_LK_MERGED=1): the two chains are normally two launches on two streams joined
+// by an event between the commits - a barrier packet of ~7 us on every frame's dependent chain (profiles/r6_final_a_queue_gaps.txt:
+// k_fe_ransac_commit -> k_fe_ransac_commit 6.6-7.3 us).  Measured: the merged launch loses more than that packet costs (lk_merged_ok).
+struct LkSet {
+    const lvk_pt2f* src_pts; const int* n_ptr;
+    lvk_pt2f* w_curr; uint8_t* w_status;
+    const unsigned long long* stored_desc;   // old tracks: the first-seen descriptors the gate compares with
+    unsigned long long* w_desc;              // new points: the previous-image descriptor (out)
+    lvk_pt2f* w_und;
+    int is_new, pad_;
+};
 template <int WIN>
-__global__ void __launch_bounds__(320) k_fe_lk_pipe(PyrView prev, PyrView next, const lvk_pt2f* __restrict__ src_pts, const int* __restrict__ n_ptr,
-                                                   HMat H, int width, int height, int max_count, double epsilon,
-                                                   lvk_pt2f* __restrict__ w_curr, uint8_t* __restrict__ w_status, FeDev* __restrict__ dev,
+__global__ void __launch_bounds__(320) k_fe_lk_pipe(PyrView prev, PyrView next, LkSet set0, LkSet set1, int grid0,
+                                                   HMat H, int width, int height, int max_count, double epsilon, FeDev* __restrict__ dev,
                                                    const uint8_t* __restrict__ cur_ext, const uint8_t* __restrict__ cur_blur,
-                                                   const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur,
-                                                   const unsigned long long* __restrict__ stored_desc /*old*/, unsigned long long* __restrict__ w_desc /*new: out*/, int is_new,
-                                                   CamParams cam, lvk_pt2f* __restrict__ w_und)
+                                                   const uint8_t* __restrict__ prv_ext, const uint8_t* __restrict__ prv_blur, CamParams cam)
 {
     static_assert(WIN == 21, "row-segment layout");
     __shared__ lvk_pt2f s_np;
     __shared__ int s_st, s_dist;
     __shared__ __attribute__((aligned(16))) unsigned long long s_acc[4][4];
     __shared__ __attribute__((aligned(16))) LkTplLevel s_tpl[LK_PIPE_MAX_LEVELS];
-    const int p = blockIdx.x;
+    const bool second = (int)blockIdx.x >= grid0;
+    const LkSet& S = second ? set1 : set0;
+    const int p = (int)blockIdx.x - (second ? grid0 : 0);
+    const lvk_pt2f* __restrict__ src_pts = S.src_pts; const int* __restrict__ n_ptr = S.n_ptr;
+    lvk_pt2f* __restrict__ w_curr = S.w_curr; uint8_t* __restrict__ w_status = S.w_status;
+    const unsigned long long* __restrict__ stored_desc = S.stored_desc; unsigned long long* __restrict__ w_desc = S.w_desc;
+    lvk_pt2f* __restrict__ w_und = S.w_und; const int is_new = S.is_new;
 #ifdef LVK_LK_TIMING
     const unsigned long long lkt_c0 = clock64(), lkt_w0 = wall_clock64();
     unsigned long long lkt_c1 = 0, lkt_c2 = 0;
@@ -572,7 +587,7 @@ __global__ void __launch_bounds__(320) k_fe_lk_pipe(PyrView prev, PyrView next, 
         atomicAdd(&dev->lk_point_levels, (unsigned long long)(passes * n_levels));
         atomicAdd(&dev->lk_iterations, (unsigned long long)its);
 #ifdef LVK_LK_TIMING
-        if (p < 4096) { g_lk_span[p][0] = lkt_c1 - lkt_c0; g_lk_span[p][1] = lkt_c2 - lkt_c0; g_lk_span[p][2] = clock64() - lkt_c0; g_lk_span[p][3] = wall_clock64() - lkt_w0; }
+        if (!second && p < 4096) { g_lk_span[p][0] = lkt_c1 - lkt_c0; g_lk_span[p][1] = lkt_c2 - lkt_c0; g_lk_span[p][2] = clock64() - lkt_c0; g_lk_span[p][3] = wall_clock64() - lkt_w0; }
 #endif
     }
 }
@@ -868,9 +883,10 @@ static void launch_track_chain(lvk_frontend* fe, hipStream_t s, const PyrView& p
     if (var < 0) var = grid <= LVK_LK_PIPE_MAX_TRACKS ? 2 : 1;
     if constexpr (WIN == 21) {
         if (var == 2 && pv.n_levels <= LK_PIPE_MAX_LEVELS && cv.n_levels <= LK_PIPE_MAX_LEVELS) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_pipe<21>), dim3(grid), dim3(320), 0, s, pv, cv, src_pts, n_ptr, H, W, Hh, max_count, epsilon, w_curr, w_status, fe->dev,
-                               (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], stored_desc, w_desc, is_new,
-                               fe->cam, w_curr == fe->w_curr ? fe->w_und : fe->wn_und);
+            LkSet a; a.src_pts = src_pts; a.n_ptr = n_ptr; a.w_curr = w_curr; a.w_status = w_status; a.stored_desc = stored_desc; a.w_desc = w_desc;
+            a.w_und = w_curr == fe->w_curr ? fe->w_und : fe->wn_und; a.is_new = is_new; a.pad_ = 0;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_pipe<21>), dim3(grid), dim3(320), 0, s, pv, cv, a, a, grid, H, W, Hh, max_count, epsilon, fe->dev,
+                               (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], fe->cam);
             return;
         }
     }
@@ -891,6 +907,39 @@ static lvk_status track_chain(lvk_frontend* fe, hipStream_t stream, const lvk_pt
         case 15: launch_track_chain<15>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
         case 31: launch_track_chain<31>(fe, stream, pv, cv, src_pts, n_ptr, fe->cap, H, w_curr, w_status, stored_desc, w_desc, is_new, max_count, epsilon); break;
         default: return lvk_set_error(fe->ctx, LVK_ERR_UNSUPPORTED, "patch_size %d not instantiated (15, 21, 31)", fe->cfg.patch_size);
+    }
+    LVK_LAUNCH_CHECK(fe->ctx);
+    return LVK_OK;
+}
+
+// can the frame's two track chains ride in ONE launch?  (the five-wavefront kernel, patch 21, the library's own choice of variant or 2)
+static bool lk_merged_ok(const lvk_frontend* fe)
+{
+    const int var = lvk_lk_variant();
+    if (fe->cfg.patch_size != 21 || !(var == 2 || (var < 0 && fe->cap <= LVK_LK_PIPE_MAX_TRACKS))) return false;
+    // opt-in (LVK_LK_MERGED=1): built and measured in round 6 - bit-exact, and SLOWER in the pipelined driver (10,260 against 10,640 frames/s,
+    // LK launch 28.2 against 25.9 us: the launch then waits for the previous frame's detection on the side stream, and carries twice the
+    // blocks), +0.5 % through the adapter's schedule; profiles/r6_o_lk_merged_launch_ab.json
+    static const bool on = [] { const char* e = getenv("LVK_LK_MERGED"); return e && !strcmp(e, "1"); }();
+    return on && fe->pyr[0]->n_levels <= LK_PIPE_MAX_LEVELS && fe->pyr[1]->n_levels <= LK_PIPE_MAX_LEVELS;
+}
+// trackFeatures' and trackNewFeatures' LK + descriptor gate in one launch on `stream`: blocks [0, cap) the old tracks of set `src`, [cap, 2 cap) the new points
+static lvk_status track_chain_merged(lvk_frontend* fe, hipStream_t stream, int src, const HMat& H)
+{
+    int max_count = fe->cfg.max_iteration < 0 ? 0 : fe->cfg.max_iteration > 100 ? 100 : fe->cfg.max_iteration;
+    double epsilon = fe->cfg.track_precision < 0. ? 0. : fe->cfg.track_precision > 10. ? 10. : fe->cfg.track_precision;
+    epsilon *= epsilon;
+    PyrView pv = make_view(fe->pyr[0]), cv = make_view(fe->pyr[1]);
+    LkSet a, b;
+    a.src_pts = fe->set[src].pts; a.n_ptr = &fe->dev->n_tracks[src]; a.w_curr = fe->w_curr; a.w_status = fe->w_status; a.stored_desc = fe->set[src].desc; a.w_desc = nullptr;
+    a.w_und = fe->w_und; a.is_new = 0; a.pad_ = 0;
+    b.src_pts = fe->new_pts; b.n_ptr = &fe->dev->n_new; b.w_curr = fe->wn_curr; b.w_status = fe->wn_status; b.stored_desc = nullptr; b.w_desc = fe->wn_desc;
+    b.w_und = fe->wn_und; b.is_new = 1; b.pad_ = 0;
+    if (fe->pyr_event) hipStreamWaitEvent(stream, fe->ev_orb, 0);
+    {
+        ProfScope ps(fe, 2, stream);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fe_lk_pipe<21>), dim3(2 * fe->cap), dim3(320), 0, stream, pv, cv, a, b, fe->cap, H, fe->cfg.width, fe->cfg.height, max_count, epsilon, fe->dev,
+                           (const uint8_t*)fe->ext[1], (const uint8_t*)fe->blur[1], (const uint8_t*)fe->ext[0], (const uint8_t*)fe->blur[0], fe->cam);
     }
     LVK_LAUNCH_CHECK(fe->ctx);
     return LVK_OK;
@@ -1341,6 +1390,18 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             // behind the detection that produced the points; its RANSAC + append (:932-1001) joins the main stream.
             // (the side stream already waited for ev_pyr before the ORB planes: this frame's pyramid and everything the previous
             //  frame left on the main stream are done)
+            const TrackSet& so = fe->set[src];
+            if (lk_merged_ok(fe)) {
+                // ONE launch for both chains (LkSet), on the main stream.  The new points were written by the detection the previous publish
+                // frame queued on side[0]: its end-of-frame event (fired long ago unless the caller runs a frame ahead of the GPU)
+                if (fe->n_img >= 2) fe_wait_unless_done(fe, S1, fe->ev_side[(int)(fe->n_img & 1)]);
+                st = track_chain_merged(fe, S1, src, H);
+                if (st != LVK_OK) return st;
+                FT(FT_TRACK_LAUNCH);
+                st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst);
+                if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
+                if (st != LVK_OK) return st;
+            } else {
             st = track_chain(fe, S2, fe->new_pts, &fe->dev->n_new, H, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, 1);
             hipEventRecord(fe->ev_new, S2);
             if (st == LVK_OK) st = track_chain(fe, S1, fe->set[src].pts, &fe->dev->n_tracks[src], H, fe->w_curr, fe->w_status, fe->set[src].desc, nullptr, 0);
@@ -1349,11 +1410,11 @@ static lvk_status frontend_process(lvk_frontend* fe, const lvk_image* img, doubl
             // the old tracks' RANSAC + commit overlaps the wait for the new points' chain; their append and the message follow.
             // (Both commits - and all three stages - as ONE launch were measured in same-box A/B runs and were slower: the old tracks'
             //  commit then waits for the new points' chain; profiles/r3_jk_frontend_chain_ab.json)
-            const TrackSet& so = fe->set[src];
             st = commit(fe, 0, so.pts, &fe->dev->n_tracks[src], fe->w_curr, fe->w_status, &so, so.desc, dst);
             hipStreamWaitEvent(S1, fe->ev_new, 0);
             if (st == LVK_OK) st = commit(fe, 1, fe->new_pts, &fe->dev->n_new, fe->wn_curr, fe->wn_status, nullptr, fe->wn_desc, dst);
             if (st != LVK_OK) return st;
+            }
             curr_valid = true;
             if (!fe->ev_trim || (fe->frame_early && ts - fe->last_pub_time >= pub_gate)) hipEventRecord(fe->ev_commit, S1);          // only the detection of a publish frame waits for it - and in the blocking schedules for the message's event instead (fe_detect_new)
             FT(FT_COMMIT_LAUNCH);
