@@ -36,6 +36,17 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (datasheet; profi
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s achievable)
 
 
+def pmc_lk_traffic(path):
+    """average corrected FETCH_SIZE bytes per launch of the LK kernel family in a tools/pmc_summary.py table (kernel,launches,avg_kb,avg_bytes;
+    kernel names carry commas - k_fe_lk_both<21, 1> - so the rows are split from the right); None when the table has no LK row"""
+    with open(path) as f:
+        rows = [l.strip().rsplit(",", 3) for l in f.readlines()[1:] if l.strip()]
+    lk = [(int(r[1]), float(r[3])) for r in rows if len(r) == 4 and r[0].startswith("k_fe_lk_")]
+    if not lk:
+        return None
+    return round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1)
+
+
 def R2q(R):
     t = np.trace(R); s_ = np.sqrt(t + 1) * 2
     return np.array([(R[2, 1] - R[1, 2]) / s_, (R[0, 2] - R[2, 0]) / s_, (R[1, 0] - R[0, 1]) / s_, 0.25 * s_])
@@ -738,11 +749,9 @@ def main():
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_fetch_size.csv" % tag))) or \
              (sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_size.csv"))) if args.config == "A" else [])
         if pm:
-            with open(pm[-1]) as f:
-                rows = [l.strip().split(",") for l in f.readlines()[1:]]
-            lk = [(int(r[1]), float(r[3])) for r in rows if r[0].startswith("k_fe_lk_")]
-            if lk:
-                traffic = round(sum(n * b for n, b in lk) / sum(n for n, _ in lk), 1); traffic_src = os.path.basename(pm[-1])
+            traffic = pmc_lk_traffic(pm[-1])
+            if traffic is not None:
+                traffic_src = os.path.basename(pm[-1])
         lk_var = os.environ.get("LVK_LK_VARIANT")
         lk_pipe = win == 21 and (lk_var == "2" or (lk_var not in ("0", "1") and wl["max_features"] <= 600))     # frontend.hip: launch_track_chain, LVK_LK_PIPE_MAX_TRACKS
         lk_name = ("k_fe_lk_pipe<%d> (forward + reverse LK of every track, five wavefronts per track: one iterates, three build the levels' templates of a pass, "

@@ -58,3 +58,16 @@ def test_bench_source_reaches_the_stated_steady_state_before_timing():
     assert "sw_size - 2" in pre and 'c["msckf"] >= 2' in pre and "raise SystemExit" in pre and "no value printed" in pre
     assert "preroll(run, frames, None, n_pre_max, sw, 20, warmup=W, period=period)" in main
     assert "n_cpu = 0 if" in main and "else 300" in main                       # >= 200 steady-state CPU frames at the metric's configuration
+
+
+def test_every_committed_counter_table_parses():
+    """bench.py reads roofline.traffic from the newest profiles/r*_{a,c5}_pmc_fetch_size.csv; kernel names in those tables carry commas
+    (k_fe_lk_both<21, 1>): a naive split broke `--config 5` once (round 6)"""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.csv")))
+    assert files
+    got = {os.path.basename(f): bench.pmc_lk_traffic(f) for f in files}
+    assert got["r6_n_c5_pmc_fetch_size.csv"] > 4e7 and got["r6_i_a_pmc_fetch_size.csv"] > 4e6
