@@ -670,6 +670,22 @@ def main():
     shard = (rank, world, dist) if (args.sharded and world > 1) else None
 
     stream = torch.cuda.current_stream()
+    # Device spin-up (untimed, before anything of the estimator exists): ~1.5 s of plain GPU work, as any GPU benchmark warms its device
+    # (sclk idles at 104 MHz; the estimator's own pre-roll is ~15 ms of sparse work).  Measured on the driver's flags as the FIRST process
+    # of an idle box: filter 224 us per message without it (8,318 frames/s; 205 us / 9,011-9,075 for the second and third process),
+    # 196 us with it (8,558) - but the 20-frame window's run-to-run spread (8,420-9,070 on one box, the caller's thread 80-87 us per
+    # frame) is larger than that effect: it removes a known cold-start cost, it does not make the line repeatable (profiles/r6_s_*, r6_u_*).
+    # LVK_BENCH_SPINUP_S=0 turns it off.
+    spin_s = float(os.environ.get("LVK_BENCH_SPINUP_S", "1.5"))
+    if spin_s > 0:
+        a_ = torch.randn(2048, 2048, device="cuda", dtype=torch.float32)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < spin_s:
+            for _ in range(10):
+                a_ = (a_ @ a_).clamp_(-1.0, 1.0)
+            torch.cuda.synchronize()
+        del a_
+        torch.cuda.synchronize()
     # ---- pass 1 (headline): host images, H2D inside the timed region
     run = Run(wl, args, local_rank, imu_all, seq, ts, args.sequential, torch_stream=stream.cuda_stream, shard=shard)
     n_pre, hp = preroll(run, frames, None, n_pre_max, sw, 20, warmup=W, period=period)
