@@ -258,3 +258,22 @@ def test_fisheye_shape_through_the_references_main_against_the_references_whole_
               % (n, path, n_map, dp, dR))
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_calibrating_filter_through_the_references_main_against_the_references_whole_program():
+    """configs[2]'s options (larvio_amd.synthetic.workload("3"): online extrinsic + td + IMU-intrinsics calibration - the 46-dimensional
+    legacy block, larvio.cpp:158-161, 3475-3800 - at budget 170, sw_size 30), 15 s from rest, as above: the reference's main() on the
+    product against the reference's whole program, every pose within 1e-6 m.  By hand over 40 s (tools/gpu/long_whole_program.py 3 800):
+    390 poses, 16 m flown, 1.5e-9 m (profiles/r6_z_long_whole_program_config2.txt)."""
+    if not (os.path.exists(BIN) and os.path.exists(FULL)):
+        pytest.skip("oracle/_ref/larvio_ref_main / larvio_ref_full not built (need /root/reference: make -C oracle ref)")
+    d = tempfile.mkdtemp(prefix="lv", dir="/tmp")
+    try:
+        args, wl, _ = write_workload_sequence(d, "3", 300)
+        assert wl["bcfg"]["calib_imu_instrinsic"] == 1
+        n, dp, dR, n_map, path = _product_against_whole_program(args, d, 130, 1e-6)
+        print("configs[2] options (IMU-intrinsics calibration, sw_size 30), 300 frames, %d poses, %.2f m flown, %d stable map points: the reference's main() on the product against the reference's whole program: position %.2e m, rotation %.2e"
+              % (n, path, n_map, dp, dR))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
