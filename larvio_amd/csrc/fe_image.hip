@@ -750,7 +750,11 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
             // 16-32 comparisons each (two threads per key and 256 comparisons each were 13 of the kernel's 28 us)
             unsigned* rank = reinterpret_cast<unsigned*>(surv + 1024);
             unsigned long long* sorted = surv + 2048;
-            if (t < 512) rank[t] = 0u;
+            // sorted[] is cleared too: keys the grid test above set to 0 all get the SAME rank (the number of keys left), so the slots behind
+            // the first 0 are written by nobody - they held the previous bucket's keys (or whatever an earlier kernel left in LDS), and the
+            // greedy pass below took them for survivors: a corner of an earlier bucket accepted twice, or a "pixel index" that is no pixel
+            // (found by the whole-program fuzz, case 19: a new point at y = 1.9e6 and a memory fault in the LK kernel that read there)
+            if (t < 512) { rank[t] = 0u; sorted[t] = 0ull; }
             __syncthreads();
             int P = 64; while (P < ns) P <<= 1;
             const int parts = 1024 / P, e = t & (P - 1), part = t / P, span = (ns + parts - 1) / parts;

@@ -384,6 +384,23 @@ static __device__ unsigned long long g_lk_tick[4096][12];    // -DLVK_LK_TIMING=
 #define LKT_COUNT(k) do { } while (0)
 #define LKT_FLUSH(pass) do { } while (0)
 #endif
+// -DLVK_LK_BOUNDS (debug builds only): every window load of variants 1 / 2 is checked against the level's padded plane; the first
+// violation is recorded (frontend.hip prints it when the front-end is destroyed) and the load skipped
+#ifdef LVK_LK_BOUNDS
+static __device__ int g_lk_oob[16];
+__device__ __forceinline__ bool lk_in_bounds(const PyrView& V, int level, int row, int col, int tag, float fx, float fy)
+{
+    const bool ok = level >= 0 && level < V.n_levels && row >= -V.pad && row + 1 < V.h[level] + V.pad && col >= -V.pad && col + 8 <= V.w[level] + V.pad;
+    if (!ok && atomicAdd(&g_lk_oob[0], 1) == 0) {
+        g_lk_oob[1] = tag; g_lk_oob[2] = level; g_lk_oob[3] = row; g_lk_oob[4] = col; g_lk_oob[5] = V.w[level & 7]; g_lk_oob[6] = V.h[level & 7];
+        g_lk_oob[7] = __builtin_bit_cast(int, fx); g_lk_oob[8] = __builtin_bit_cast(int, fy); g_lk_oob[9] = blockIdx.x; g_lk_oob[10] = threadIdx.x; g_lk_oob[11] = V.n_levels;
+    }
+    return ok;
+}
+#define LK_INB(V, level, row, col, tag, fx, fy) lk_in_bounds(V, level, row, col, tag, fx, fy)
+#else
+#define LK_INB(V, level, row, col, tag, fx, fy) true
+#endif
 template <int LKT_PASS = 0>
 __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrView& next, int n_levels, lvk_pt2f prev_pt, lvk_pt2f& next_pt,
                                                  int& status, int max_count, double epsilon, int* __restrict__ iters_out, LkLdsAcc& acc)
@@ -407,7 +424,7 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
         r.ipx = d_cv_floor(prx); r.ipy = d_cv_floor(pry);
         const int cols = prev.w[level], rows = prev.h[level];
         r.ok = !(r.ipx < -WIN || r.ipx >= cols || r.ipy < -WIN || r.ipy >= rows);
-        if (r.ok && act) {
+        if (r.ok && act && LK_INB(prev, level, wrow + r.ipy, x0 + r.ipx, 1, prev_pt.x, prev_pt.y)) {
             const int stepI = prev.istride[level], dstep = prev.dstride[level];
             const uint8_t* src = prev.img[level] + (ptrdiff_t)(wrow + r.ipy) * stepI + (x0 + r.ipx);
             const int16_t* ds = prev.der[level] + (ptrdiff_t)(wrow + r.ipy) * dstep + 2 * (x0 + r.ipx);
@@ -495,7 +512,7 @@ __device__ __forceinline__ int lk_point_rs21_lds(const PyrView& prev, const PyrV
             ++n_it;
             if (inx != held_x || iny != held_y) {
                 held_x = inx; held_y = iny; LKT_COUNT(8);
-                if (act) {
+                if (act && LK_INB(next, level, wrow + iny, x0 + inx, 2, nx, ny)) {
                     const uint8_t* Jp = Jbase + (ptrdiff_t)(wrow + iny) * stepJ + (x0 + inx);
                     __builtin_memcpy(&j0, Jp, 8); __builtin_memcpy(&j1, Jp + stepJ, 8);
                 }
@@ -571,7 +588,7 @@ __device__ __forceinline__ void lk_tpl_build21(const PyrView& I, int level, lvk_
         return;
     }
     unsigned long long i0 = 0, i1 = 0; uint4 d00 = {0, 0, 0, 0}, d01 = d00, d10 = d00, d11 = d00;
-    if (act) {
+    if (act && LK_INB(I, level, wrow + ipy, x0 + ipx, 3, prev_pt.x, prev_pt.y)) {
         const int stepI = I.istride[level], dstep = I.dstride[level];
         const uint8_t* src = I.img[level] + (ptrdiff_t)(wrow + ipy) * stepI + (x0 + ipx);
         const int16_t* ds = I.der[level] + (ptrdiff_t)(wrow + ipy) * dstep + 2 * (x0 + ipx);
@@ -672,7 +689,7 @@ __device__ __forceinline__ int lk_pass_iterate21(const PyrView& next, int n_leve
             ++n_it;
             if (inx != held_x || iny != held_y) {
                 held_x = inx; held_y = iny;
-                if (act) {
+                if (act && LK_INB(next, level, wrow + iny, x0 + inx, 4, nx, ny)) {
                     const uint8_t* Jp = Jbase + (ptrdiff_t)(wrow + iny) * stepJ + (x0 + inx);
                     __builtin_memcpy(&j0, Jp, 8); __builtin_memcpy(&j1, Jp + stepJ, 8);
                 }

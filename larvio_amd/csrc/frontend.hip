@@ -528,6 +528,12 @@ __global__ void __launch_bounds__(320) k_fe_lk_pipe(PyrView prev, PyrView next, 
     unsigned long long dp[4] = {0, 0, 0, 0};
     LkLdsAcc acc; acc.off = 0; acc.prev[0] = acc.prev[1] = acc.prev[2] = 0;
     if (wave < 4) acc = lk_acc_init(s_acc[wave]);
+#ifdef LVK_LK_BOUNDS
+    if (!(pp.x >= 0 && pp.x <= width - 1 && pp.y >= 0 && pp.y <= height - 1)) {
+        if (threadIdx.x == 0 && atomicAdd(&g_lk_oob[0], 1) == 0) { g_lk_oob[1] = 5; g_lk_oob[2] = *n_ptr; g_lk_oob[3] = p; g_lk_oob[4] = is_new; g_lk_oob[7] = __builtin_bit_cast(int, pp.x); g_lk_oob[8] = __builtin_bit_cast(int, pp.y); g_lk_oob[9] = blockIdx.x; }
+        return;
+    }
+#endif
     // ---- before the forward pass: its templates, the gyro-predicted start, the previous-image descriptor of a new point
     if (wave == 0) np = apply_h(H, pp);
     else if (wave < 4) { for (int level = wave - 1; level < n_levels; level += 3) lk_tpl_build21(prev, level, pp, s_tpl[level], acc); }
@@ -576,6 +582,11 @@ __global__ void __launch_bounds__(320) k_fe_lk_pipe(PyrView prev, PyrView next, 
 #endif
     } else if (wave == 4 && fwd_ok) {
         unsigned long long dc[4];
+#ifdef LVK_LK_BOUNDS
+        if (!(fnp.x >= 0 && fnp.x <= width - 1 && fnp.y >= 0 && fnp.y <= height - 1)) {
+            if (lane == 0 && atomicAdd(&g_lk_oob[0], 1) == 0) { g_lk_oob[1] = 6; g_lk_oob[2] = *n_ptr; g_lk_oob[3] = p; g_lk_oob[4] = is_new; g_lk_oob[7] = __builtin_bit_cast(int, fnp.x); g_lk_oob[8] = __builtin_bit_cast(int, fnp.y); g_lk_oob[9] = blockIdx.x; }
+        } else
+#endif
         orb_point(cur_ext, cur_blur, step, fnp, dc);
         const int dist = is_new ? hamming256_u64(dc, dp) : hamming256_u64(dc, stored_desc + (size_t)p * 4);
         if (lane == 0) { s_dist = dist; w_und[2 * (size_t)p + 1] = undistort_point(fnp, cam, cam.intr); }
@@ -985,6 +996,14 @@ void lvk_frontend_destroy(lvk_frontend* fe)
     }
     prof_collect(fe);
     hipStreamSynchronize(fe->ctx->stream);
+#ifdef LVK_LK_BOUNDS
+    {
+        int o[16] = {0}; hipDeviceSynchronize(); hipMemcpyFromSymbol(o, HIP_SYMBOL(g_lk_oob), sizeof o);
+        float fx, fy; memcpy(&fx, &o[7], 4); memcpy(&fy, &o[8], 4);
+        fprintf(stderr, "[lvk LK bounds] %d window loads outside their plane; first: site %d level %d of %d, row %d col %d of %d x %d, position (%g, %g), block %d thread %d\n",
+                o[0], o[1], o[2], o[11], o[3], o[4], o[5], o[6], fx, fy, o[9], o[10]);
+    }
+#endif
     for (int i = 0; i < 2; ++i) if (fe->side[i]) { hipStreamSynchronize(fe->side[i]->stream); lvk_context_destroy(fe->side[i]); }
     hipEvent_t evs[] = {fe->ev_pyr, fe->ev_orb, fe->ev_new, fe->ev_commit, fe->ev_tail, fe->ev_main[0], fe->ev_main[1], fe->ev_side[0], fe->ev_side[1]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);

@@ -115,6 +115,29 @@ def test_good_features_identical(gpu_ctx, two_frames, masked):
         assert len(a) > 10
 
 
+@pytest.mark.parametrize("md", [10.0, 16.0, 25.0, 33.0])
+def test_good_features_second_bucket_with_ruled_out_candidates(gpu_ctx, two_frames, md):
+    """The selection kernel beyond its first strength bucket, where candidates an accepted corner already rules out are dropped before the
+    sort: with the tracked points masked out as the frame path masks them (discs of minDistance around the strongest corners) and more
+    corners asked for than the first bucket can give, the later buckets are short lists full of dropped keys (k_gftt_select's rank sort left
+    the slots behind the first dropped key unwritten: stale keys of the bucket before were taken for survivors - whole-program fuzz case
+    19).  Every budget against the oracle, and every corner inside the image."""
+    g, o = _pyr_pair(gpu_ctx, two_frames[0], clahe=True)
+    h, w = two_frames[0].shape
+    for n_tracked in (0, 60, 150):
+        mask = None
+        if n_tracked:
+            mask = np.full((h, w), 255, np.uint8)
+            yy, xx = np.mgrid[0:h, 0:w]
+            for x, y in o.good_features(n_tracked, 0.01, md):
+                mask[(xx - x) ** 2 + (yy - y) ** 2 <= md * md] = 0
+        for maxc in (20, 45, 90, 160, 300, 600):
+            a = g.good_features(maxc, 0.01, md, mask)
+            b = o.good_features(maxc, 0.01, md, mask)
+            assert a.shape == b.shape and np.array_equal(a, b), (md, n_tracked, maxc, len(a), len(b))
+            assert len(a) == 0 or (a[:, 0].min() >= 0 and a[:, 0].max() < w and a[:, 1].min() >= 0 and a[:, 1].max() < h)
+
+
 def test_good_features_with_an_unaligned_mask(gpu_ctx, two_frames):
     """A caller's device mask need not be word aligned (k_masked_max reads it as 32-bit words only when it is)."""
     import ctypes as C

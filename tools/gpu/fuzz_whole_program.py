@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Fuzz of the PRODUCT against the reference's whole program (not part of the suite): random configurations of camera model, window,
+augmentation grid, tracker budget, publish rate and the FEJ / td / extrinsics / ZUPT / IMU-intrinsics switches, each written as an ASL
+directory and run through the reference's main() twice - with the reference's own classes (oracle/_ref/larvio_ref_full, CPU) and on the
+product (oracle/_ref/larvio_ref_main over adapter/ + liblvk_hip.so, this GPU).  Per case: the number of poses, the largest position and
+rotation difference, the driver's count of stable map points on both sides, and which initialiser fired (the moving-start initialiser's
+minimisers are stand-ins on the reference side: 1e-3 m is what can be asked there, 1e-6 m after a static start).
+usage: tools/gpu/fuzz_whole_program.py <first seed> <count>"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
+
+
+def one(k):
+    from make_euroc_dir import write_euroc_dir
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    from tests import test_gpu_zzz_ref_main as T
+    rng = np.random.default_rng([k, 909])
+    fish = bool(rng.integers(0, 2))
+    cam = dict(S.CAM_TUMVI_LIKE if fish else S.EUROC)
+    n = int(rng.integers(220, 340))
+    budget = int(rng.integers(100, 300 if fish else 260))
+    fo = dict(max_features_num=budget, min_distance=int(rng.integers(10, 26)), pub_frequency=int(rng.choice([10, 10, 20])),
+              pyramid_levels=int(rng.choice([2, 2, 3])), max_iteration=int(rng.choice([30, 30, 10])))
+    bo = dict(sw_size=int(rng.integers(8, 31)), if_fej=int(rng.integers(0, 2)), estimate_td=int(rng.integers(0, 2)), estimate_extrin=int(rng.integers(0, 2)),
+              if_zupt_valid=int(rng.integers(0, 2)), calib_imu_instrinsic=int(rng.random() < 0.25),
+              aug_grid_rows=int(rng.integers(2, 7)), aug_grid_cols=int(rng.integers(2, 7)), max_features_in_one_grid=int(rng.integers(1, 4)),
+              max_track_len=int(rng.choice([6, 6, 8, 10])), pub_frequency=fo["pub_frequency"])
+    first = 70 if rng.random() < 0.2 else 0                  # one case in five starts in the moving part: the moving-start initialiser has to fire
+    fcfg = S.frontend_config(cam=cam, **fo); bcfg = S.backend_config(cam=cam, **bo)
+    frames = synth_frames(first, n, cam=cam)
+    seq = S.imu_only_sequence(cam=cam)
+    ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    keep = os.environ.get("LVK_FUZZ_KEEP")                     # a directory: write case k there and stop (for a rerun by hand)
+    d = keep if keep else tempfile.mkdtemp(prefix="lv", dir="/tmp")
+    try:
+        os.makedirs(os.path.join(d, "logs"))
+        write_euroc_dir(d, frames, imu_all, fcfg, bcfg, output_dir=os.path.join(d, "logs") + "/")
+        args = [d + "/mav0/imu0/data.csv", d + "/mav0/cam0/data.csv", d + "/mav0/cam0/data", d + "/config.yaml"]
+        if keep:
+            return "written: " + " ".join(args), 0.0
+        env = {kk: v for kk, v in os.environ.items() if kk != "LVK_GRID_REFERENCE"}
+        poses = os.path.join(d, "p.txt")
+        rf = subprocess.run([T.FULL] + args, capture_output=True, text=True, timeout=900, env=dict(env, LVREF_MAIN_POSES=poses + ".full"))
+        if os.environ.get("LVK_FUZZ_REF_ONLY"):
+            return "reference only: exit %d, %d poses | %s" % (rf.returncode, len(open(poses + ".full").readlines()) if os.path.exists(poses + ".full") else -1, rf.stdout[-300:].replace("\n", " ")), 0.0
+        rm = subprocess.run([T.BIN] + args, capture_output=True, text=True, timeout=600, env=dict(env, LVREF_MAIN_POSES=poses))
+        tag = "case %3d %s %3d frames budget %3d sw %2d grid %dx%dx%d pub %2d fej %d td %d ex %d zupt %d calib %d" % (
+            k, "fisheye" if fish else "radtan ", n, budget, bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
+            bo["if_fej"], bo["estimate_td"], bo["estimate_extrin"], bo["if_zupt_valid"], bo["calib_imu_instrinsic"])
+        if rf.returncode != 0 or rm.returncode != 0:
+            return tag + "  EXIT CODES reference %d product %d | %s" % (rf.returncode, rm.returncode, (rm.stdout + rm.stderr)[-200:].replace("\n", " ")), None
+        Mf = np.loadtxt(poses + ".full", ndmin=2) if os.path.exists(poses + ".full") and os.path.getsize(poses + ".full") else np.zeros((0, 16))
+        M = np.loadtxt(poses, ndmin=2) if os.path.exists(poses) and os.path.getsize(poses) else np.zeros((0, 16))
+        dyn = "Dynamic initialization success" in rf.stdout
+        nf = int(rf.stdout.split("Totally")[1].split()[0]) if "Totally" in rf.stdout else -1
+        nm = int(rm.stdout.split("Totally")[1].split()[0]) if "Totally" in rm.stdout else -1
+        if M.shape != Mf.shape:
+            return tag + "  POSE COUNTS reference %d product %d (%s start)" % (len(Mf), len(M), "moving" if dyn else "static"), None
+        if len(M) == 0:
+            return tag + "  no pose on either side (never initialised)", 0.0
+        dp = float(np.linalg.norm(M[:, 12:15] - Mf[:, 12:15], axis=1).max()); dR = float(np.abs(M[:, :12] - Mf[:, :12]).max())
+        ok = dp < (1e-3 if dyn else 1e-6) and nf == nm
+        return tag + "  %3d poses  position %.2e m  rotation %.2e  map points %d / %d  %s start%s" % (len(M), dp, dR, nf, nm, "moving" if dyn else "static", "" if ok else "  <-- DIFFERS"), (dp if ok else None)
+    finally:
+        if not keep:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def main():
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    bad = 0; worst_static = 0.0
+    for k in range(first, first + count):
+        line, dp = one(k)
+        print(line, flush=True)
+        if dp is None:
+            bad += 1
+        elif "static" in line:
+            worst_static = max(worst_static, dp)
+    print("%d cases, %d differ; worst position difference after a static start %.2e m" % (count, bad, worst_static))
+
+
+if __name__ == "__main__":
+    main()
