@@ -92,6 +92,7 @@ inline void Solve(const Solver::Options& opt, Problem* pb, Solver::Summary* sum)
     auto restore = [&](const std::vector<std::vector<double>>& saved) { for (size_t b = 0; b < pb->blocks.size(); ++b) for (int i = 0; i < pb->blocks[b].size; ++i) pb->blocks[b].p[i] = saved[b][(size_t)i]; };
     std::vector<double> r0, r1; double cost = cost_of(r0); sum->initial_cost = cost;
     double lambda = 1e-4; const double h = 1e-6;
+    bool ceres_stop = false;      // a successful step changed the cost by less than Ceres' default function_tolerance (1e-6) times the cost: where Ceres itself reports CONVERGENCE
     if (nt == 0 || nr == 0) { sum->final_cost = cost; sum->termination_type = CONVERGENCE; return; }
     for (int it = 0; it < opt.max_num_iterations; ++it) {
         // J^T J and J^T r, one residual block at a time (central differences in the tangent of each of its free parameter blocks)
@@ -145,13 +146,15 @@ inline void Solve(const Solver::Options& opt, Problem* pb, Solver::Summary* sum)
             std::vector<std::vector<double>> saved; apply(d, saved);
             const double c1 = cost_of(r1);
             double dn = 0; for (double v : d) dn = std::max(dn, std::fabs(v));
-            if (c1 <= cost) { const bool tiny = dn < 1e-13 || cost - c1 <= 1e-18 * std::max(cost, 1e-30); cost = c1; r0 = r1; lambda = std::max(lambda * 0.3, 1e-12); stepped = true; if (tiny) { it = opt.max_num_iterations; sum->termination_type = CONVERGENCE; } }
+            if (c1 <= cost) { const bool tiny = dn < 1e-13 || cost - c1 <= 1e-18 * std::max(cost, 1e-30); if (cost - c1 <= 1e-6 * cost) ceres_stop = true; cost = c1; r0 = r1; lambda = std::max(lambda * 0.3, 1e-12); stepped = true; if (tiny) { it = opt.max_num_iterations; sum->termination_type = CONVERGENCE; } }
             else { restore(saved); lambda *= 10; }
         }
         sum->iterations = it + 1;
         if (!stepped) { sum->termination_type = CONVERGENCE; break; }
     }
-    // (out of iterations on a cost that still falls: NO_CONVERGENCE stands, and the reference's second test - final_cost - decides)
+    // (out of iterations on a cost that still falls in its leading digits: NO_CONVERGENCE stands, and the reference's second test -
+    // final_cost - decides; falling only below Ceres' function tolerance: Ceres would have stopped there and said CONVERGENCE)
+    if (ceres_stop) sum->termination_type = CONVERGENCE;
     sum->final_cost = cost;
 }
 }  // namespace ceres
