@@ -594,7 +594,6 @@ __global__ void __launch_bounds__(256) k_gftt_candidates(const float* __restrict
 // conflicts live in the 3x3 cells around a candidate, <= 4 corners per cell), only the SURVIVORS are sorted (bitonic, LDS)
 // and wave 0 resolves them in order exactly like the sequential rule.  Rejections by the grid are final because the grid
 // only grows; buckets are visited in descending strength, survivors in descending (strength, index): identical result.
-#define GF_MAX_CELLS 8192
 #define GF_MAX_OUT 4096
 #define GF_SURV 8192
 __device__ __forceinline__ bool gf_grid_conflict(const unsigned short (*cells)[4], const short2* acc, int gw, int gh, int cell, float md2, int x, int y)
@@ -620,15 +619,15 @@ extern "C" void lvk_debug_gf_ticks(unsigned long long* out) { hipDeviceSynchroni
 #define GF_TICK(k) do { } while (0)
 #endif
 __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* __restrict__ cands, int cap, int w, int h,
-                                                     int max_corners, int cell, float md2,
+                                                     int max_corners, int cell, float md2, int surv_cap /* GF_SURV, or half of it when the grid is large */, int acc_cap,
                                                      unsigned* __restrict__ scratch /* read, then left zeroed for the next detection (no fill launch) */, lvk_pt2f* __restrict__ out, int out_cap,
                                                      int* __restrict__ n_out, const int* __restrict__ d_sub)
 {
-    extern __shared__ unsigned long long gf_sh[];           // surv [GF_SURV] u64 | cells [gw*gh][4] u16 | acc [GF_MAX_OUT] short2
+    extern __shared__ unsigned long long gf_sh[];           // surv [surv_cap] u64 | cells [gw*gh][4] u16 | acc [acc_cap] short2
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     unsigned long long* surv = gf_sh;
-    unsigned short (*cells)[4] = reinterpret_cast<unsigned short (*)[4]>(gf_sh + GF_SURV);
-    short2* acc = reinterpret_cast<short2*>(gf_sh + GF_SURV + gw * gh);
+    unsigned short (*cells)[4] = reinterpret_cast<unsigned short (*)[4]>(gf_sh + surv_cap);
+    short2* acc = reinterpret_cast<short2*>(gf_sh + surv_cap + gw * gh);
     __shared__ unsigned coarse[1024];                        // histogram folded to 1024 groups (8 bins each at 13 bits)
     __shared__ unsigned hist[1 << GF_HIST_BITS];
     __shared__ int sh_ns, sh_na, sh_done, sh_lo, sh_hi;
@@ -688,7 +687,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
             __syncthreads();
             if (t == 0 && sh_lo < 0) sh_lo = scan[0] > 0 ? 0 : sh_hi;                                     // fewer than target left: all of it
             __syncthreads();
-            serial_walk = sh_lo < sh_hi && scan[sh_lo / GROUP] > GF_SURV;
+            serial_walk = sh_lo < sh_hi && scan[sh_lo / GROUP] > (unsigned)surv_cap;
             __syncthreads();
         }
         if (serial_walk && t == 0) {
@@ -703,7 +702,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                 if (cnt >= (unsigned)target) break;
             }
             sh_lo = lo;
-            if (cnt > GF_SURV) sh_done = 2;                 // one histogram bin alone exceeds the survivor buffer
+            if (cnt > (unsigned)surv_cap) sh_done = 2;                 // one histogram bin alone exceeds the survivor buffer
         }
         __syncthreads();
         if (bucket == 0) GF_TICK(3);
@@ -726,13 +725,13 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&sh_ns, __popcll(mk));
                     base = __shfl(base, 0);
-                    if (keep) { const int slot = base + __popcll(mk & ((1ull << lane) - 1ull)); if (slot < GF_SURV) surv[slot] = k; }
+                    if (keep) { const int slot = base + __popcll(mk & ((1ull << lane) - 1ull)); if (slot < surv_cap) surv[slot] = k; }
                 }
             }
         }
         __syncthreads();
         if (bucket == 0) GF_TICK(4);
-        const int ns = min(sh_ns, GF_SURV);
+        const int ns = min(sh_ns, surv_cap);
         // candidates of this bucket that an already accepted corner rules out are dropped BEFORE the sort (key 0 sorts last and ends
         // the greedy pass); one candidate per thread, so the grid walk is paid once, not once per diverged lane group.  The grid
         // is empty in the first bucket.
@@ -812,7 +811,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                     const int xj = __builtin_amdgcn_readlane(sx, j), yj = __builtin_amdgcn_readlane(sy, j);
                     accm |= 1ull << j;
                     ++na;
-                    if ((max_corners > 0 && na == max_corners) || na >= GF_MAX_OUT) { done = true; break; }
+                    if ((max_corners > 0 && na == max_corners) || na >= acc_cap) { done = true; break; }
                     if (g && lane > j) {
                         const float dx = (float)sx - (float)xj, dy = (float)sy - (float)yj;
                         if (dx * dx + dy * dy < md2) g = false;
@@ -822,7 +821,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
                 if ((accm >> lane) & 1ull) {
                     const int r = na0 + __popcll(accm & ((1ull << lane) - 1ull));
                     if (r < out_cap) { out[r].x = (float)sx; out[r].y = (float)sy; }
-                    if (r < GF_MAX_OUT) {
+                    if (r < acc_cap) {
                         acc[r] = make_short2((short)sx, (short)sy);
                         // first free slot of the corner's cell (four 16-bit slots = one 64-bit word; slot order is irrelevant to the
                         // conflict test; a full cell drops the entry, as before)
@@ -846,7 +845,7 @@ __global__ void __launch_bounds__(1024) k_gftt_select(const unsigned long long* 
         __syncthreads();
         if (bucket == 0) GF_TICK(6);
         if (sh_done) break;
-        if (target < GF_SURV) target <<= 1;
+        if (target < surv_cap) target <<= 1;
     }
     GF_TICK(7);
     if (t == 0) { *n_out = sh_na < out_cap ? sh_na : out_cap; for (int q = 0; q < GF_SCRATCH_UINTS; ++q) scratch[q] = 0u; }   // every thread read scratch[1] many barriers ago
@@ -1057,17 +1056,26 @@ lvk_status lvk_gftt_run(lvk_context* ctx, const float* d_eig, const uint8_t* d_m
     if (min_distance < 1.0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "goodFeaturesToTrack with minDistance < 1 is not supported");
     const int cell = (int)rint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
-    if (gw * gh > GF_MAX_CELLS) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT grid %dx%d exceeds %d cells", gw, gh, GF_MAX_CELLS);
     if (max_corners > GF_MAX_OUT || max_corners <= 0) return lvk_set_error(ctx, LVK_ERR_UNSUPPORTED, "maxCorners must be in 1..%d", GF_MAX_OUT);
     if (!prepared) LVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, GF_SCRATCH_UINTS * sizeof(unsigned), ctx->stream));
     if (!max_done)
     { int mb = (w * h / 4 + 2047) / 2048; mb = mb < 128 ? 128 : mb > 1024 ? 1024 : mb;      // ~8 four-pixel loads per lane
       hipLaunchKernelGGL(k_masked_max, dim3(mb), dim3(256), 0, ctx->stream, d_eig, d_mask, w * h, d_scratch); }
     hipLaunchKernelGGL(k_gftt_candidates, dim3((w - 2 + 255) / 256, (h - 2 + GC_ROWS - 1) / GC_ROWS), dim3(256), 0, ctx->stream, d_eig, d_mask, w, h, (float)quality, d_scratch, d_cands, cand_cap);
-    const size_t shm = (size_t)GF_SURV * 8 + (size_t)gw * gh * 8 + (size_t)GF_MAX_OUT * 4;
+    // LDS of the selection kernel: survivors | one 8-byte cell per minDistance x minDistance square | the accepted corners (as many as can be
+    // asked for), next to its static 36 KB (histogram).  A fine grid (minDistance 6 on 752 x 480: 10,080 cells; found by the whole-program fuzz
+    // at 512 x 512 / 6, which asked for 177 KB and left the front-end in a failed state) takes the survivor buffer at half size - any
+    // bucket boundaries give the same corners, the buckets only get shorter.
+    static const size_t lds_static = [] { hipFuncAttributes fa; return hipFuncGetAttributes(&fa, (const void*)k_gftt_select) == hipSuccess ? (size_t)fa.sharedSizeBytes : (size_t)40 * 1024; }();
+    const size_t lds_avail = (size_t)160 * 1024 - lds_static;
+    const int acc_cap = max_corners;
+    int surv_cap = GF_SURV;
+    size_t shm = (size_t)surv_cap * 8 + (size_t)gw * gh * 8 + (size_t)acc_cap * 4;
+    if (shm > lds_avail) { surv_cap = GF_SURV / 2; shm = (size_t)surv_cap * 8 + (size_t)gw * gh * 8 + (size_t)acc_cap * 4; }
+    if (shm > lds_avail) return lvk_set_error(ctx, LVK_ERR_CAPACITY, "GFTT: a %dx%d grid of minDistance cells and %d corners need %zu bytes of LDS (%zu available)", gw, gh, max_corners, shm, lds_avail);
     LVK_LDS_OPTIN(ctx, 2, k_gftt_select, shm);   // the opt-in must leave room for the kernel's static LDS: ask for what is launched
     hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(1024), shm, ctx->stream, (const unsigned long long*)d_cands, cand_cap, w, h, max_corners, cell,
-                       (float)(min_distance * min_distance), d_scratch, d_out, cap, d_n_out, d_sub);
+                       (float)(min_distance * min_distance), surv_cap, acc_cap, d_scratch, d_out, cap, d_n_out, d_sub);
     LVK_LAUNCH_CHECK(ctx);
     return LVK_OK;
 }

@@ -115,13 +115,14 @@ def test_good_features_identical(gpu_ctx, two_frames, masked):
         assert len(a) > 10
 
 
-@pytest.mark.parametrize("md", [10.0, 16.0, 25.0, 33.0])
+@pytest.mark.parametrize("md", [6.0, 10.0, 16.0, 25.0, 33.0])
 def test_good_features_second_bucket_with_ruled_out_candidates(gpu_ctx, two_frames, md):
     """The selection kernel beyond its first strength bucket, where candidates an accepted corner already rules out are dropped before the
     sort: with the tracked points masked out as the frame path masks them (discs of minDistance around the strongest corners) and more
     corners asked for than the first bucket can give, the later buckets are short lists full of dropped keys (k_gftt_select's rank sort left
     the slots behind the first dropped key unwritten: stale keys of the bucket before were taken for survivors - whole-program fuzz case
-    19).  Every budget against the oracle, and every corner inside the image."""
+    19).  Every budget against the oracle, and every corner inside the image.  minDistance 6 is the fine grid (126 x 80 cells of 8 bytes): the
+    kernel then runs with its survivor buffer at half size (wide-profile fuzz case 8 asked for 177 KB of LDS and failed)."""
     g, o = _pyr_pair(gpu_ctx, two_frames[0], clahe=True)
     h, w = two_frames[0].shape
     for n_tracked in (0, 60, 150):

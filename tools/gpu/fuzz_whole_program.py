@@ -5,7 +5,7 @@ directory and run through the reference's main() twice - with the reference's ow
 product (oracle/_ref/larvio_ref_main over adapter/ + liblvk_hip.so, this GPU).  Per case: the number of poses, the largest position and
 rotation difference, the driver's count of stable map points on both sides, and which initialiser fired (the moving-start initialiser's
 minimisers are stand-ins on the reference side: 1e-3 m is what can be asked there, 1e-6 m after a static start).
-usage: tools/gpu/fuzz_whole_program.py <first seed> <count>"""
+usage: tools/gpu/fuzz_whole_program.py <first seed> <count> [wide]"""
 import os
 import shutil
 import subprocess
@@ -17,12 +17,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 
+WIDE = False
 
-def one(k):
-    from make_euroc_dir import write_euroc_dir
+
+def draw(k):
+    """the configuration of case k: camera, number of frames, front-end options, filter options, first frame (70 = a start in motion)"""
     from larvio_amd import synthetic as S
-    from tests.conftest import synth_frames
-    from tests import test_gpu_zzz_ref_main as T
     rng = np.random.default_rng([k, 909])
     fish = bool(rng.integers(0, 2))
     cam = dict(S.CAM_TUMVI_LIKE if fish else S.EUROC)
@@ -35,6 +35,21 @@ def one(k):
               aug_grid_rows=int(rng.integers(2, 7)), aug_grid_cols=int(rng.integers(2, 7)), max_features_in_one_grid=int(rng.integers(1, 4)),
               max_track_len=int(rng.choice([6, 6, 8, 10])), pub_frequency=fo["pub_frequency"])
     first = 70 if rng.random() < 0.2 else 0                  # one case in five starts in the moving part: the moving-start initialiser has to fire
+    if WIDE:                                                    # second profile: the code paths the first one never takes - LK windows 15 / 31 (the
+        fo["patch_size"] = int(rng.choice([15, 21, 31, 31]))    # generic kernel), budgets beyond 600 tracks (the two-wavefront LK kernel, the 1024-thread
+        fo["max_features_num"] = budget = int(rng.integers(100, 1000))   # commit), no CLAHE, a short descriptor gate; drawn AFTER the first profile's
+        fo["flag_equalize"] = int(rng.random() < 0.7)           # numbers, so a case number means the same sequence in both
+        fo["min_distance"] = int(rng.integers(6, 20))
+    return cam, n, fo, bo, first
+
+
+def one(k):
+    from make_euroc_dir import write_euroc_dir
+    from larvio_amd import synthetic as S
+    from tests.conftest import synth_frames
+    from tests import test_gpu_zzz_ref_main as T
+    cam, n, fo, bo, first = draw(k)
+    fish = cam["distortion_model"] == 1; budget = fo["max_features_num"]
     fcfg = S.frontend_config(cam=cam, **fo); bcfg = S.backend_config(cam=cam, **bo)
     frames = synth_frames(first, n, cam=cam)
     seq = S.imu_only_sequence(cam=cam)
@@ -54,8 +69,8 @@ def one(k):
         if os.environ.get("LVK_FUZZ_REF_ONLY"):
             return "reference only: exit %d, %d poses | %s" % (rf.returncode, len(open(poses + ".full").readlines()) if os.path.exists(poses + ".full") else -1, rf.stdout[-300:].replace("\n", " ")), 0.0
         rm = subprocess.run([T.BIN] + args, capture_output=True, text=True, timeout=600, env=dict(env, LVREF_MAIN_POSES=poses))
-        tag = "case %3d %s %3d frames budget %3d md %2d lv %d it %2d sw %2d grid %dx%dx%d pub %2d fej %d td %d ex %d zupt %d calib %d" % (
-            k, "fisheye" if fish else "radtan ", n, budget, fo["min_distance"], fo["pyramid_levels"], fo["max_iteration"], bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
+        tag = "case %3d%s %s %3d frames budget %3d md %2d lv %d it %2d sw %2d grid %dx%dx%d pub %2d fej %d td %d ex %d zupt %d calib %d" % (
+            k, (" wide patch %d clahe %d" % (fo["patch_size"], fo["flag_equalize"])) if WIDE else "", "fisheye" if fish else "radtan ", n, budget, fo["min_distance"], fo["pyramid_levels"], fo["max_iteration"], bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
             bo["if_fej"], bo["estimate_td"], bo["estimate_extrin"], bo["if_zupt_valid"], bo["calib_imu_instrinsic"])
         if rf.returncode != 0 or rm.returncode != 0:
             return tag + "  EXIT CODES reference %d product %d | %s" % (rf.returncode, rm.returncode, (rm.stdout + rm.stderr)[-200:].replace("\n", " ")), None
@@ -65,7 +80,13 @@ def one(k):
         nf = int(rf.stdout.split("Totally")[1].split()[0]) if "Totally" in rf.stdout else -1
         nm = int(rm.stdout.split("Totally")[1].split()[0]) if "Totally" in rm.stdout else -1
         if M.shape != Mf.shape:
-            return tag + "  POSE COUNTS reference %d product %d (%s start)" % (len(Mf), len(M), "moving" if dyn else "static"), None
+            # which end do they share?  (a product that stops early shares the FIRST poses, a different first message the LAST ones)
+            m = min(len(M), len(Mf)); head = tail = float("nan")
+            if m:
+                head = float(np.linalg.norm(M[:m, 12:15] - Mf[:m, 12:15], axis=1).max()); tail = float(np.linalg.norm(M[-m:, 12:15] - Mf[-m:, 12:15], axis=1).max())
+            err = [l for l in (rm.stdout + rm.stderr).splitlines() if "LarVio::" in l or "ImageProcessor::" in l]
+            return tag + "  POSE COUNTS reference %d product %d (%s start); aligned at the first pose %.1e m, at the last %.1e m%s" % (
+                len(Mf), len(M), "moving" if dyn else "static", head, tail, (" | product said: " + err[0][:160]) if err else ""), None
         if len(M) == 0:
             return tag + "  no pose on either side (never initialised)", 0.0
         dp = float(np.linalg.norm(M[:, 12:15] - Mf[:, 12:15], axis=1).max()); dR = float(np.abs(M[:, :12] - Mf[:, :12]).max())
@@ -84,7 +105,8 @@ def one(k):
 
 
 def main():
-    first, count = int(sys.argv[1]), int(sys.argv[2])
+    global WIDE
+    first, count = int(sys.argv[1]), int(sys.argv[2]); WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
     bad = 0; wild = 0; worst_static = 0.0
     for k in range(first, first + count):
         line, dp = one(k)
