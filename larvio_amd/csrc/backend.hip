@@ -1376,6 +1376,22 @@ static lvk_status dense_update(lvk_ekf* e, int m, std::vector<double>& dx, int e
         ws.ev_a = take(); ws.ev_b = take();
         e->prof_pending.push_back({ws.ev_a, ws.ev_b, 2.0 * m * (double)e->N * (double)e->N, 0, 0.0});
     }
+#ifdef LVK_NPD_DEBUG   // debug builds only: the stacked system of every small update, as the update kernels are about to read it
+    if (m > 0 && m <= 40) {
+        hipDeviceSynchronize();
+        std::vector<double> hH((size_t)m * e->ld), hr((size_t)m), hP((size_t)e->N * e->ld);
+        hipMemcpy(hH.data(), H, sizeof(double) * hH.size(), hipMemcpyDeviceToHost); hipMemcpy(hr.data(), r, sizeof(double) * m, hipMemcpyDeviceToHost);
+        hipMemcpy(hP.data(), e->dP[e->cur], sizeof(double) * hP.size(), hipMemcpyDeviceToHost);
+        double pmin = 1e300; bool pnan = false; for (int i = 0; i < e->N; ++i) { pmin = std::min(pmin, hP[(size_t)i * e->ld + i]); for (int j = 0; j < e->N; ++j) pnan = pnan || !std::isfinite(hP[(size_t)i * e->ld + j]); }
+        fprintf(stderr, "[npd] update t %.2f: %d rows, N %d, min diag P %.3e, P finite %d\n", e->s.t, m, e->N, pmin, (int)!pnan);
+        for (int i = 0; i < m; ++i) {
+            double n2 = 0, s00 = 0; bool bad = false; int nz = 0;
+            for (int j = 0; j < e->N; ++j) { const double v = hH[(size_t)i * e->ld + j]; bad = bad || !std::isfinite(v); n2 += v * v; nz += v != 0.; }
+            for (int j = 0; j < e->N; ++j) for (int k = 0; k < e->N; ++k) s00 += hH[(size_t)i * e->ld + j] * hP[(size_t)j * e->ld + k] * hH[(size_t)i * e->ld + k];
+            fprintf(stderr, "[npd]   row %2d: |h| %.3e nonzeros %d finite %d r %.3e  h P h' %.3e\n", i, sqrt(n2), nz, (int)!bad, hr[(size_t)i], s00);
+        }
+    }
+#endif
     st = lvk_update_core(e->ctx, e->dP[e->cur], e->ld, e->N, H, e->ld, m, r, e->sigma2, e->d_dx, ws);
     if (st != LVK_OK) return st;
     e->p00_valid = m > 0;

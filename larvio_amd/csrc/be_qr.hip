@@ -29,6 +29,12 @@ double lvk_chi2_005(int dof) { return (dof >= 1 && dof <= 99) ? k_chi2_005[dof] 
 // Blocks that would not shrink (rows <= columns, e.g. the two rows of each in-state feature with their scattered anchor columns)
 // are passed through by a copy.
 #define QS_THREADS 1024
+// A column whose sum of squares (at and below its diagonal) is at most this is left alone, like a zero column (beta = 0).  When the gate has
+// rejected all rows of a node but one or two, the matrix has rank 1 or 2: each further step works on the rounding residue of an exactly
+// cancelled column - 1e-17, 1e-34, ... of the entries - and around the 18th column the sum of squares is a denormal number, where 2 / |v|^2
+// overflows and the fast reciprocal square root below is not defined: NaN in every row handed to the update (found by the whole-program
+// fuzz: "pivot 0 of 19 rows" - 19 = the columns of a pruning node).  Entries below 1e-100 carry no information next to a pixel noise of 1e-2.
+#define QR_NEGLIGIBLE 1e-200
 #define QS_WAVES (QS_THREADS / 64)
 
 __device__ __forceinline__ void qs_prep_column(double* __restrict__ colk, int R, int k, int lane, double* __restrict__ diag, double* __restrict__ scal)
@@ -41,7 +47,7 @@ __device__ __forceinline__ void qs_prep_column(double* __restrict__ colk, int R,
         const double nrm = sqrt(s);
         const double alpha = akk >= 0. ? -nrm : nrm;
         const double vn2 = 2. * (s - alpha * akk);                 // |x - alpha e_k|^2
-        const double beta = (nrm == 0. || vn2 == 0.) ? 0. : 2. / vn2;
+        const double beta = (s <= QR_NEGLIGIBLE || vn2 == 0.) ? 0. : 2. / vn2;
         diag[k] = beta != 0. ? alpha : akk;
         if (beta != 0.) colk[k] = akk - alpha;
         scal[k & 1] = beta;
@@ -202,7 +208,7 @@ __global__ void __launch_bounds__(QS_THREADS) k_qr_sparse_reg(const double* __re
             const double s = row16_sum_f64((p[0] + p[1]) + (p[2] + p[3]));
             const double akk = readlane_dyn_f64(a[PC], 16 * (k & 3) + k15);
             // (1/sqrt and 1/x from FMA-refined hardware seeds: the IEEE sqrt and divide expand to ~80 instructions on this step's chain)
-            const double y = s > 0. ? rsqrt_goldschmidt(s) : 0.;
+            const double y = s > QR_NEGLIGIBLE ? rsqrt_goldschmidt(s) : 0.;       // (a negligible column is a zero column: see QR_NEGLIGIBLE)
             const double nrm = s * y;
             const double alpha = akk >= 0. ? -nrm : nrm;
             // beta = 2 / |x - alpha e_k|^2 = 2 / (2 (s - alpha a_kk)) = 1 / (|x| (|x| + |a_kk|))

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(CQ_FTHREADS) k_caqr_factor(double* __restrict_
         const double tail = s - akk * akk;            // nothing below the diagonal: leave the column alone (no sign flip of an existing R)
         const double alpha = akk >= 0. ? -nrm : nrm;
         const double vn2 = 2. * (s - alpha * akk);
-        const double bk = (nrm == 0. || vn2 == 0. || tail <= 0.) ? 0. : 2. / vn2;
+        const double bk = (s <= 1e-200 /* a negligible column is a zero column: QR_NEGLIGIBLE, be_qr.hip */ || vn2 == 0. || tail <= 0.) ? 0. : 2. / vn2;
         if (lane == lk && bk != 0.) {
 #pragma unroll
             for (int q = 0; q < RPL; ++q) if (q == qk) a[c][q] = akk - alpha;

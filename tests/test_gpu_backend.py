@@ -117,6 +117,29 @@ def test_structure_aware_qr_preserves_information(gpu_ctx, case):
     print(case, len(H), "->", len(Hc), "->", len(Hd), "rel", np.abs(G1 - G0).max() / np.abs(G0).max())
 
 
+@pytest.mark.parametrize("n_rows,n_live", [(190, 1), (400, 1), (190, 2), (64, 1), (700, 3)])
+def test_structure_aware_qr_when_the_gate_rejected_almost_every_row(gpu_ctx, n_rows, n_live):
+    """The pruning update of a filter that is rejecting nearly everything (a poor moving start: whole-program fuzz, second and third
+    profile, "pivot 0 of 19 rows"): hundreds of one-row blocks over the SAME 19 columns (extrinsics, td, the two clones that leave),
+    all zeroed by the gate but one or two.  The node's matrix then has rank 1 or 2; every further Householder step works on what the
+    step before left of an exactly cancelled column - 1e-17, 1e-34, ... of the entries - and by the 18th column the sum of squares is a
+    denormal number, where 2 / |v|^2 overflowed (and the fast reciprocal square root of the register kernel returned garbage): NaN
+    in all 19 rows handed to the update, reported as a non-positive pivot.  Asked: finite rows that carry the same information."""
+    from larvio_amd import larvio as lv
+    rng = np.random.default_rng(n_rows + n_live)
+    N = 94; cols = list(range(15, 22)) + list(range(22 + 6 * 3, 22 + 6 * 5))          # 7 + 12 = 19 columns
+    H = np.zeros((n_rows, N)); r = np.zeros(n_rows)
+    for i in rng.choice(n_rows, n_live, replace=False):
+        H[i, cols] = rng.normal(0, 15, len(cols)); r[i] = rng.normal(0, 0.01)
+    groups = [(1, cols)] * n_rows
+    G0, g0 = H.T @ H, H.T @ r
+    Hc, rc = lv.compress_qr_groups(gpu_ctx, H, r, groups)
+    assert np.isfinite(Hc).all() and np.isfinite(rc).all(), "NaN rows out of the compression"
+    assert len(Hc) < len(H) and np.abs(Hc.T @ Hc - G0).max() <= 1e-11 * np.abs(G0).max() and np.abs(Hc.T @ rc - g0).max() <= 1e-11 * np.abs(g0).max()
+    Hd, rd = lv.compress_qr(gpu_ctx, np.vstack([Hc, np.zeros((N, N))]), np.concatenate([rc, np.zeros(N)]))     # and the dense kernel on the same rank-1 system
+    assert np.isfinite(Hd).all() and np.abs(Hd.T @ Hd - G0).max() <= 1e-11 * np.abs(G0).max()
+
+
 def _R2q(R):
     t = np.trace(R); s = np.sqrt(t + 1) * 2
     return np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])

@@ -5,7 +5,7 @@ directory and run through the reference's main() twice - with the reference's ow
 product (oracle/_ref/larvio_ref_main over adapter/ + liblvk_hip.so, this GPU).  Per case: the number of poses, the largest position and
 rotation difference, the driver's count of stable map points on both sides, and which initialiser fired (the moving-start initialiser's
 minimisers are stand-ins on the reference side: 1e-3 m is what can be asked there, 1e-6 m after a static start).
-usage: tools/gpu/fuzz_whole_program.py <first seed> <count> [wide]"""
+usage: tools/gpu/fuzz_whole_program.py <first seed> <count> [wide] [sizes]"""
 import os
 import shutil
 import subprocess
@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 WIDE = False
+SIZES = False
 
 
 def draw(k):
@@ -40,6 +41,13 @@ def draw(k):
         fo["max_features_num"] = budget = int(rng.integers(100, 1000))   # commit), no CLAHE, a short descriptor gate; drawn AFTER the first profile's
         fo["flag_equalize"] = int(rng.random() < 0.7)           # numbers, so a case number means the same sequence in both
         fo["min_distance"] = int(rng.integers(6, 20))
+    if SIZES:                                                   # third profile: image sizes nobody chose - odd widths and heights (CLAHE tiles that do not
+        w = int(rng.integers(300, 1000)); h = int(rng.integers(220, 700))      # divide the image, byte paths of the image kernels, pyramid levels of odd size), the
+        sc = w / cam["width"]                                   # camera model scaled with the width, principal point off centre
+        fx, fy, cx, cy = cam["intrinsics"]
+        cam["width"] = w; cam["height"] = h
+        cam["intrinsics"] = (fx * sc, fy * sc, w * (0.5 + 0.04 * (rng.random() - 0.5)), h * (0.5 + 0.04 * (rng.random() - 0.5)))
+        n = min(n, 260)
     return cam, n, fo, bo, first
 
 
@@ -70,7 +78,7 @@ def one(k):
             return "reference only: exit %d, %d poses | %s" % (rf.returncode, len(open(poses + ".full").readlines()) if os.path.exists(poses + ".full") else -1, rf.stdout[-300:].replace("\n", " ")), 0.0
         rm = subprocess.run([T.BIN] + args, capture_output=True, text=True, timeout=600, env=dict(env, LVREF_MAIN_POSES=poses))
         tag = "case %3d%s %s %3d frames budget %3d md %2d lv %d it %2d sw %2d grid %dx%dx%d pub %2d fej %d td %d ex %d zupt %d calib %d" % (
-            k, (" wide patch %d clahe %d" % (fo["patch_size"], fo["flag_equalize"])) if WIDE else "", "fisheye" if fish else "radtan ", n, budget, fo["min_distance"], fo["pyramid_levels"], fo["max_iteration"], bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
+            k, ((" wide patch %d clahe %d" % (fo["patch_size"], fo["flag_equalize"])) if WIDE else "") + ((" %dx%d" % (cam["width"], cam["height"])) if SIZES else ""), "fisheye" if fish else "radtan ", n, budget, fo["min_distance"], fo["pyramid_levels"], fo["max_iteration"], bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
             bo["if_fej"], bo["estimate_td"], bo["estimate_extrin"], bo["if_zupt_valid"], bo["calib_imu_instrinsic"])
         if rf.returncode != 0 or rm.returncode != 0:
             return tag + "  EXIT CODES reference %d product %d | %s" % (rf.returncode, rm.returncode, (rm.stdout + rm.stderr)[-200:].replace("\n", " ")), None
@@ -105,8 +113,8 @@ def one(k):
 
 
 def main():
-    global WIDE
-    first, count = int(sys.argv[1]), int(sys.argv[2]); WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    global WIDE, SIZES
+    first, count = int(sys.argv[1]), int(sys.argv[2]); WIDE = "wide" in sys.argv[3:]; SIZES = "sizes" in sys.argv[3:]
     bad = 0; wild = 0; worst_static = 0.0
     for k in range(first, first + count):
         line, dp = one(k)
