@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples")); sy
 
 def main():
     import fuzz_whole_program as F
-    k = int(sys.argv[1]); F.WIDE = "wide" in sys.argv[2:]; F.SIZES = "sizes" in sys.argv[2:]
+    k = int(sys.argv[1]); F.WIDE = "wide" in sys.argv[2:]; F.SIZES = "sizes" in sys.argv[2:]; F.PARAMS = "params" in sys.argv[2:]
     nums = [int(a) for a in sys.argv[2:] if a.isdigit()]
     cam, n, fo, bo, first = F.draw(k)
     if nums:

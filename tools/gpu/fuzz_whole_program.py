@@ -5,7 +5,7 @@ directory and run through the reference's main() twice - with the reference's ow
 product (oracle/_ref/larvio_ref_main over adapter/ + liblvk_hip.so, this GPU).  Per case: the number of poses, the largest position and
 rotation difference, the driver's count of stable map points on both sides, and which initialiser fired (the moving-start initialiser's
 minimisers are stand-ins on the reference side: 1e-3 m is what can be asked there, 1e-6 m after a static start).
-usage: tools/gpu/fuzz_whole_program.py <first seed> <count> [wide] [sizes]"""
+usage: tools/gpu/fuzz_whole_program.py <first seed> <count> [wide] [sizes] [params]"""
 import os
 import shutil
 import subprocess
@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 
 WIDE = False
 SIZES = False
+PARAMS = False
 
 
 def draw(k):
@@ -48,6 +49,12 @@ def draw(k):
         cam["width"] = w; cam["height"] = h
         cam["intrinsics"] = (fx * sc, fy * sc, w * (0.5 + 0.04 * (rng.random() - 0.5)), h * (0.5 + 0.04 * (rng.random() - 0.5)))
         n = min(n, 260)
+    if PARAMS:                                                  # fourth profile: the filter's numbers - noises, the pruning and motion thresholds, track lengths, the
+        bo.update(noise_feature=float(rng.uniform(0.002, 0.03)), noise_gyro=0.004 * float(rng.uniform(0.3, 3)), noise_acc=0.08 * float(rng.uniform(0.3, 3)),   # window up to 45 clones
+                  rotation_threshold=float(rng.uniform(0.05, 0.5)), translation_threshold=float(rng.uniform(0.1, 1.0)), tracking_rate_threshold=float(rng.uniform(0.3, 0.8)),
+                  least_observation_number=int(rng.integers(2, 5)), max_track_len=int(rng.integers(4, 16)), sw_size=int(rng.integers(6, 46)),
+                  td=float(rng.uniform(-0.01, 0.01)) if bo["estimate_td"] else 0.0, static_duration=float(rng.choice([0.5, 1.0, 1.5])),
+                  feature_translation_threshold=float(rng.choice([-1.0, 0.05, 0.2])), zupt_max_feature_dis=float(rng.uniform(5e-4, 5e-3)))
     return cam, n, fo, bo, first
 
 
@@ -78,7 +85,7 @@ def one(k):
             return "reference only: exit %d, %d poses | %s" % (rf.returncode, len(open(poses + ".full").readlines()) if os.path.exists(poses + ".full") else -1, rf.stdout[-300:].replace("\n", " ")), 0.0
         rm = subprocess.run([T.BIN] + args, capture_output=True, text=True, timeout=600, env=dict(env, LVREF_MAIN_POSES=poses))
         tag = "case %3d%s %s %3d frames budget %3d md %2d lv %d it %2d sw %2d grid %dx%dx%d pub %2d fej %d td %d ex %d zupt %d calib %d" % (
-            k, ((" wide patch %d clahe %d" % (fo["patch_size"], fo["flag_equalize"])) if WIDE else "") + ((" %dx%d" % (cam["width"], cam["height"])) if SIZES else ""), "fisheye" if fish else "radtan ", n, budget, fo["min_distance"], fo["pyramid_levels"], fo["max_iteration"], bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
+            k, ((" wide patch %d clahe %d" % (fo["patch_size"], fo["flag_equalize"])) if WIDE else "") + ((" %dx%d" % (cam["width"], cam["height"])) if SIZES else "") + ((" params sigma %.3f len %d..%d thr %.2f/%.2f/%.2f" % (bo["noise_feature"], bo["least_observation_number"], bo["max_track_len"], bo["rotation_threshold"], bo["translation_threshold"], bo["tracking_rate_threshold"])) if PARAMS else ""), "fisheye" if fish else "radtan ", n, budget, fo["min_distance"], fo["pyramid_levels"], fo["max_iteration"], bo["sw_size"], bo["aug_grid_rows"], bo["aug_grid_cols"], bo["max_features_in_one_grid"], fo["pub_frequency"],
             bo["if_fej"], bo["estimate_td"], bo["estimate_extrin"], bo["if_zupt_valid"], bo["calib_imu_instrinsic"])
         if rf.returncode != 0 or rm.returncode != 0:
             return tag + "  EXIT CODES reference %d product %d | %s" % (rf.returncode, rm.returncode, (rm.stdout + rm.stderr)[-200:].replace("\n", " ")), None
@@ -113,8 +120,8 @@ def one(k):
 
 
 def main():
-    global WIDE, SIZES
-    first, count = int(sys.argv[1]), int(sys.argv[2]); WIDE = "wide" in sys.argv[3:]; SIZES = "sizes" in sys.argv[3:]
+    global WIDE, SIZES, PARAMS
+    first, count = int(sys.argv[1]), int(sys.argv[2]); WIDE = "wide" in sys.argv[3:]; SIZES = "sizes" in sys.argv[3:]; PARAMS = "params" in sys.argv[3:]
     bad = 0; wild = 0; worst_static = 0.0
     for k in range(first, first + count):
         line, dp = one(k)
