@@ -2724,7 +2724,8 @@ struct lvk_vio_pipe {
     // what submit() needs for an early count, all under mu: the filter is initialised, td after the last finished update, the state
     // time after the IMU batch of the last COUNTED job (the filter's own s.t belongs to its thread while a job runs)
     bool steady = false; double td_pub = 0, state_t = 0, td_margin = 5e-4;
-    double td_steps[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n_td = 0;       // |td change| of the last eight finished updates
+    static constexpr int TD_HIST = 32;
+    double td_steps[TD_HIST] = {}; long n_td = 0;                       // |td change| of the last TD_HIST finished updates
     int depth = 2;                                      // updates the caller may have in flight when a frame starts (LVK_PIPE_DEPTH; 1: never more than one update ahead - lower latency, the filter's thread waits for messages)
     long n_early = 0, n_early_wrong = 0;
     int in_flight = 0;                                  // queued + running
@@ -2739,9 +2740,14 @@ struct lvk_vio_pipe {
     void ev(int what) { if (logging) log.push_back({now_us_fwd(), what}); }   // LVK_EKF_TRACE: where the two threads spend their time (us)
     bool td_quiet() const
     {   // may submit() trust the published td for a count?  (depth + 1) updates can move td before the counted one starts
-        if (n_td < 3) return false;
-        double mx = 0; for (int i = 0; i < 8 && i < n_td; ++i) mx = std::max(mx, td_steps[i]);
-        return 2.0 * (depth + 1) * mx < td_margin;
+        // Eight quiet updates and a factor of two were not enough (pipeline fuzz, 2 of 280 configurations): a filter whose td is poorly
+        // observable (fisheye at 20 Hz publishing, td wandering by milliseconds) sits still for a few updates and then steps by 1 ms - two
+        // counts taken from the stale td were one sample off, and the frames in between integrated their gyro prediction over a window
+        // the sequential loop would not have given them.  A healthy filter moves td by microseconds per update: 32 updates and a factor of
+        // eight cost it nothing (bench.py's run takes as many counts early as before).
+        if (n_td < 8) return false;
+        double mx = 0; for (int i = 0; i < TD_HIST && i < n_td; ++i) mx = std::max(mx, td_steps[i]);
+        return 8.0 * (depth + 1) * mx < td_margin;
     }
 };
 static double now_us_fwd() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -2820,11 +2826,14 @@ static void pipe_worker(lvk_vio_pipe* p)
             double t_after = 0;
             const int n = batch_imu_count(p->ekf, job.ts + p->ekf->td, job.view.data(), (int)job.view.size(), &t_after);
             if (n != job.n_pre || p->ekf->s.t != job.t0_pre) {
+                static const bool verbose = getenv("LVK_VERBOSE") != nullptr;
+                if (verbose) fprintf(stderr, "[lvk pipe] early erase count not confirmed at t = %.4f: %d samples counted from td %.6f and state time %.4f, %d with td %.6f and state time %.4f (|td steps| of the last updates up to %.2e)\n",
+                                     job.ts, job.n_pre, p->td_pub, job.t0_pre, n, p->ekf->td, p->ekf->s.t, *std::max_element(p->td_steps, p->td_steps + lvk_vio_pipe::TD_HIST));
                 std::lock_guard<std::mutex> lk(p->mu);
                 const long nh = (long)p->head + (n - job.n_pre);
                 p->head = (size_t)std::max(nh, (long)(p->fhead - p->base)); p->head = std::min(p->head, p->imu.size()); p->n_early_wrong += 1;
                 if (p->q.empty()) p->state_t = t_after;                 // later jobs were counted from the wrong state time: they are checked in turn
-                for (int i = 0; i < 8; ++i) p->td_steps[i] = p->td_margin;   // and nobody guesses again until eight quiet updates have gone by
+                for (int i = 0; i < lvk_vio_pipe::TD_HIST; ++i) p->td_steps[i] = p->td_margin;   // and nobody guesses again until TD_HIST quiet updates have gone by
                 p->gen.fetch_add(1, std::memory_order_release);
             }
         }
@@ -2850,7 +2859,7 @@ static void pipe_worker(lvk_vio_pipe* p)
             p->n_updates += upd; p->in_flight -= 1;
             const bool was_steady = p->steady;
             p->steady = p->ekf->b_first_features && p->ekf->is_gravity_set;
-            if (was_steady && p->steady && upd) { p->td_steps[p->n_td % 8] = fabs(p->ekf->td - p->td_pub); p->n_td += 1; }
+            if (was_steady && p->steady && upd) { p->td_steps[p->n_td % lvk_vio_pipe::TD_HIST] = fabs(p->ekf->td - p->td_pub); p->n_td += 1; }
             p->td_pub = p->ekf->td;
             p->gen.fetch_add(1, std::memory_order_release);
         }

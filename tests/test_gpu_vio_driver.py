@@ -306,6 +306,46 @@ def _driver_pair(gpu_ctx, cam, first, count, fcfg_over, bcfg_over, init_from_gt,
     return n_upd, worst, co, len(to["ids"])
 
 
+def test_pipelined_driver_with_a_td_that_wanders_by_milliseconds(gpu_ctx):
+    """Pipeline fuzz case 124 (tools/gpu/fuzz_pipeline.py): a fisheye camera publishing at 20 Hz from rest, 9-clone window - the camera-IMU
+    time offset is poorly observable, sits still for a few updates and then steps by a millisecond.  Erase counts taken from the td
+    published eight updates earlier were one IMU sample off (twice), two front-end frames integrated their gyro prediction over another
+    window than the sequential loop's, and the runs parted.  The caller's thread now takes a count early only after 32 updates whose
+    largest td step, times eight, times the updates in flight, stays inside the margin.  Asked: no unconfirmed count, equal bits."""
+    import larvio_amd
+    from larvio_amd import synthetic as S
+    from larvio_amd.vio import VioDriver, VioPipeline
+    from tests.conftest import synth_frames
+    cam = dict(S.CAM_TUMVI_LIKE)
+    frames = synth_frames(0, 200, cam=cam)
+    seq = S.imu_only_sequence(cam=cam); ts = [f[0] for f in frames]
+    imu_all = seq.imu_array(max(int(ts[0] * 200) - 4, 0), int(ts[-1] * 200) + 40)
+    fcfg = S.frontend_config(cam=cam, max_features_num=189, min_distance=25, pub_frequency=20)
+    bcfg = S.backend_config(cam=cam, sw_size=9, if_fej=1, estimate_td=1, estimate_extrin=0, if_zupt_valid=0, aug_grid_rows=6, aug_grid_cols=6, max_features_in_one_grid=2,
+                            max_track_len=8, pub_frequency=20)
+    ctx2 = larvio_amd.Context(0); out = []
+    for mode in ("seq", "pipe"):
+        fe = larvio_amd.ImageProcessor(fcfg, gpu_ctx); assert fe.initialize()
+        be = larvio_amd.LarVio(bcfg, ctx2 if mode == "pipe" else gpu_ctx); assert be.initialize()
+        drv = (VioPipeline if mode == "pipe" else VioDriver)(fe, be, imu_all)
+        n_msg = 0
+        for t, img in frames:
+            r = drv.step(t, drv.visible_end(t), img=img); n_msg += int(r if mode == "pipe" else r[0])
+        if mode == "pipe":
+            drv.drain(); early, wrong = drv.early_counts()
+            print("wandering td: %d messages, %d erase counts taken early, %d not confirmed; td %.2e" % (n_msg, early, wrong, be.state()["td"]))
+            assert wrong == 0, (early, wrong)
+            drv.close()
+        out.append((n_msg, {k_: np.array(v, copy=True) for k_, v in be.state().items()}, be.cov(), be.counters(), fe.tracks()))
+        be.close(); fe.close()
+    ctx2.close()
+    a, b = out
+    assert a[0] == b[0] >= 150 and abs(a[1]["td"]) > 1e-3                      # the offset did wander (the true one is 0)
+    for k_ in a[1]:
+        assert np.array_equal(a[1][k_], b[1][k_]), k_
+    assert np.array_equal(a[2], b[2]) and a[3] == b[3] and np.array_equal(a[4]["pts"], b[4]["pts"])
+
+
 def test_driver_loop_config4_shape_equidistant_static_start_zupt(gpu_ctx):
     """512x512 equidistant camera, 300-feature budget, start at rest: static initialiser, ZUPT updates, then motion"""
     n_upd, worst, c, n_tracks = _driver_pair(gpu_ctx, TUMVI_LIKE, 0, 64, dict(max_features_num=300, min_distance=15),
