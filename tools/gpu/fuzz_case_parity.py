@@ -15,6 +15,7 @@ def main():
     k = int(sys.argv[1]); F.WIDE = "wide" in sys.argv[2:]; F.SIZES = "sizes" in sys.argv[2:]; F.PARAMS = "params" in sys.argv[2:]
     nums = [int(a) for a in sys.argv[2:] if a.isdigit()]
     cam, n, fo, bo, first = F.draw(k)
+    bo = dict(bo, max_features=fo["max_features_num"])       # the filter's capacity follows the tracker's budget (as the adapter sets it from the YAML file)
     if nums:
         n = nums[0]
     import larvio_amd

@@ -20,6 +20,7 @@ def one(k, ctx, ctx2):
     from larvio_amd.vio import VioDriver, VioPipeline
     from tests.conftest import synth_frames
     cam, n, fo, bo, first = F.draw(k)
+    bo = dict(bo, max_features=fo["max_features_num"])       # the filter's capacity follows the tracker's budget (as the adapter sets it from the YAML file)
     n = min(n, 200)
     frames = synth_frames(first, n, cam=cam)
     seq = S.imu_only_sequence(cam=cam); ts = [f[0] for f in frames]
