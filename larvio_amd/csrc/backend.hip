@@ -975,7 +975,8 @@ static lvk_status launch_triangulation(lvk_ekf* e, std::vector<TriReq>& reqs)
 {
     if (reqs.empty()) return LVK_OK;
     size_t tot = 0; for (auto& r : reqs) tot += (size_t)r.n;
-    if ((int)reqs.size() > e->feat_cap || (int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "triangulation batch exceeds capacity");
+    if ((int)reqs.size() > e->feat_cap || (int)tot > e->obs_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "triangulation batch of %d features / %zu observations exceeds capacity (%d / %d): lvk_ekf_config.max_features is %d - set it to the tracker's budget (max_features_num)",
+                                                                                            (int)reqs.size(), tot, e->feat_cap, e->obs_cap, e->cfg.max_features);
     for (auto& r : reqs) if (r.slot >= 2 * e->feat_cap) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "feature batch exceeds capacity");
     TriJob* hj = up_alloc<TriJob>(e, reqs.size()); int* hr = up_alloc<int>(e, tot); double* hz = up_alloc<double>(e, 2 * tot);
     if (!hj || !hr || !hz) return lvk_set_error(e->ctx, LVK_ERR_CAPACITY, "upload arena exhausted");
