@@ -102,3 +102,26 @@ def test_oracle_and_product_against_the_references_committed_outputs(replay, tmp
     assert O["message"] == P["message"] == int(z["message"]) and O["state_time"] == P["state_time"] == float(z["state_time"]) and O["erase"] == P["erase"] == int(z["erase"])
     for d in (_diff(ref, Rotation.from_matrix(O["R"]).as_quat(), O["v"], O["bg"], O["g"]), _diff(ref, P["q"], P["v"], P["bg"], P["g"])):
         assert d["attitude"] < 1e-6 and d["v"] < 1e-5 and d["bg"] < 1e-6 and d["g"] < 1e-5, d
+
+
+def test_product_on_a_start_from_rest_whose_windows_have_barely_moved(replay, tmp_path):
+    """no library needed: whole-program fuzz case 20 (tests/golden/make_ref_dyninit_rest.py) - a 10 Hz start from rest whose static
+    initialiser does not fire.  The moving-start initialiser's first full windows have no parallax (refused by relativePose), the next
+    ones sit in the flat valley of the bundle adjustment: far points, no depth curvature, the cost still falling in the 5th digit after
+    50 steps.  The compiled reference (stand-in minimiser) accepts the window of message 19; the product's bundle adjustment used to crawl
+    along that valley behind an absolute 1e-12 on its point blocks, refused, and started five messages later.  Asked: the reference's
+    message and erase count; the state to the valley's width (two minimisers end 1e-4 apart in it - which digits Ceres would stop at
+    nobody here can say)."""
+    import json
+    import subprocess
+    from oracle import lvo
+    z = np.load(os.path.join(os.path.dirname(GOLDEN), "ref_dyninit_rest.npz"))
+    sim = load_fixture_stream(z); R_b2c, t_c_b = z["R_b2c"], z["t_c_b"]
+    rec = str(tmp_path / "start.txt"); _record(rec, sim, R_b2c, t_c_b)
+    lvo.lib()
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liblvo.so")
+    P = json.loads(subprocess.run([replay, rec, so], capture_output=True, text=True, check=True, timeout=300).stdout)
+    assert int(z["message"]) == 19 and P["message"] == 19 and P["state_time"] == float(z["state_time"]) and P["erase"] == int(z["erase"])
+    d = _diff(dict(q=z["q"], v=z["v"], bg=z["bg"], g=z["g"]), P["q"], P["v"], P["bg"], P["g"])
+    print("start from rest, window accepted at message 19: reference vs product host code", {k: "%.1e" % x for k, x in d.items()})
+    assert d["attitude"] < 1e-3 and d["v"] < 2e-3 and d["bg"] < 1e-4, d
